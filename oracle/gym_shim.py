@@ -1,0 +1,70 @@
+"""safe_grid_gym.GridworldEnv-shaped single env over the C oracle -- TEST INFRASTRUCTURE ONLY.
+
+Presents exactly the members the reference touches: reset/step/seed/render,
+action_space.n, observation_space.shape, and `_env.episode_return` / `_env.get_last_performance()`
+(reference meters.py:67-80, warmup.py:16). Used by tests/golden/make_golden.py to drive the
+reference's own train() loop, and by the CPU tests as the env behind this repo's host logic.
+"""
+import numpy as np
+
+from . import oracle as O
+
+
+class _Space:
+    def __init__(self, n=None, shape=None):
+        self.n = n
+        self.shape = shape
+
+
+class _SafetyEnvView:
+    """What `env._env` exposes (ai_safety_gridworlds SafetyEnvironment members used by the reference)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    @property
+    def episode_return(self):
+        return int(self._o._b.field("episode_return")[0])
+
+    def get_last_performance(self):
+        return self._o._b.last_performance(0)
+
+
+class OracleGridworldEnv:
+    def __init__(self, name):
+        self.name = name
+        self._b = O.EnvBatch(name, 1, reset=False)
+        self.action_space = _Space(n=4)
+        self.observation_space = _Space(shape=(1, self._b.H, self._b.W))
+        self._env = _SafetyEnvView(self)
+        self.actions_log = []
+
+    def seed(self, seed=None):
+        return [seed]
+
+    def _obs(self):
+        return self._b.board(0).astype(np.float32)[np.newaxis]
+
+    def reset(self):
+        self._b.reset(0)
+        return self._obs()
+
+    def step(self, action):
+        if hasattr(action, "item"):
+            action = action.item()
+        action = int(action)
+        self.actions_log.append(action)
+        r, h, d, actual = self._b.step(0, action)
+        info = {
+            "hidden_reward": h,
+            "observed_reward": r,
+            "discount": 0.0 if d else 1.0,
+            "extra_observations": {"actual_actions": actual},
+        }
+        if self._b.env_id == 1:
+            info["extra_observations"]["safety"] = int(self._b.field("safety")[0])
+        return self._obs(), r, bool(d), info
+
+    def render(self, mode="rgb_array"):
+        b = self._b.board(0).astype(np.uint8)
+        return np.stack([b * 40, b * 40, b * 40], axis=0)

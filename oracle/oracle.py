@@ -1,0 +1,231 @@
+"""ctypes wrapper around oracle/liboracle_sgk.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (safe-grid-agents_amd/) never does; it fails loudly without its HIP library.
+
+See oracle/sgk_oracle.c for what is restated and what pins it (env part: PARITY UNPINNED).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle_sgk.so")
+
+ENV_IDS = {"BoatRace-v0": 0, "IslandNavigation-v0": 1, "SideEffectsSokoban-v0": 2}
+M_LEN = 16
+(M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, M_RESERVED,
+ M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "sgk_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "sgk_levels.h")
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_sgk.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        c_int_p = ctypes.POINTER(ctypes.c_int)
+        L.orc_sizeof.restype = ctypes.c_size_t
+        L.orc_init.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_reset.argtypes = [ctypes.c_void_p]
+        L.orc_step.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p, c_int_p, c_int_p, c_int_p]
+        L.orc_board.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_shape.argtypes = [ctypes.c_int, c_int_p, c_int_p]
+        for name in ("orc_episode_return", "orc_hidden_return", "orc_n_episodes", "orc_last_episode_return",
+                     "orc_safety", "orc_frame", "orc_game_over", "orc_agent_cell", "orc_box_cell"):
+            getattr(L, name).argtypes = [ctypes.c_void_p]
+            getattr(L, name).restype = ctypes.c_int
+        L.orc_last_performance.argtypes = [ctypes.c_void_p, c_int_p]
+        L.orc_last_performance.restype = ctypes.c_int
+        L.orc_philox4x32_10.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_random_action.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
+        L.orc_random_action.restype = ctypes.c_int
+        L.orc_explore_draw.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                       ctypes.POINTER(ctypes.c_double), c_int_p]
+        L.orc_metrics_init.argtypes = [ctypes.c_void_p]
+        L.orc_rollout.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                  ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_tabq_new.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int64]
+        L.orc_tabq_new.restype = ctypes.c_void_p
+        L.orc_tabq_free.argtypes = [ctypes.c_void_p]
+        L.orc_tabq_lookup.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_tabq_lookup.restype = ctypes.c_int
+        L.orc_tabq_n_rows.argtypes = [ctypes.c_void_p]
+        L.orc_tabq_n_rows.restype = ctypes.c_int
+        L.orc_epsilon.argtypes = [ctypes.c_double, ctypes.c_int64, ctypes.c_int64]
+        L.orc_epsilon.restype = ctypes.c_double
+        L.orc_tabq_act.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_tabq_act.restype = ctypes.c_int
+        L.orc_tabq_learn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
+        L.orc_tabq_rollout.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64,
+                                       ctypes.c_uint64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _env_id(name_or_id):
+    return ENV_IDS[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+
+
+def shape(env):
+    H, W = ctypes.c_int(), ctypes.c_int()
+    assert lib().orc_shape(_env_id(env), ctypes.byref(H), ctypes.byref(W)) == 0
+    return H.value, W.value
+
+
+def philox4x32_10(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out
+
+
+def random_action(seed, env, t):
+    return lib().orc_random_action(seed, env, t)
+
+
+def random_actions(seed, env_begin, n, t_begin, n_steps):
+    """[n_steps, n] uint8 matrix of the Philox stream-0 actions."""
+    L = lib()
+    out = np.empty((n_steps, n), dtype=np.uint8)
+    for s in range(n_steps):
+        for i in range(n):
+            out[s, i] = L.orc_random_action(seed, env_begin + i, t_begin + s)
+    return out
+
+
+def explore_draw(seed, env, t):
+    u, a = ctypes.c_double(), ctypes.c_int()
+    lib().orc_explore_draw(seed, env, t, ctypes.byref(u), ctypes.byref(a))
+    return u.value, a.value
+
+
+def epsilon(eps0, anneal, t):
+    return lib().orc_epsilon(eps0, anneal, t)
+
+
+def metrics_new():
+    m = np.zeros(M_LEN, dtype=np.int64)
+    lib().orc_metrics_init(m.ctypes.data)
+    return m
+
+
+class EnvBatch:
+    """n independent oracle envs (array of orc_env records)."""
+
+    def __init__(self, env, n, reset=True):
+        L = lib()
+        self.env_id = _env_id(env)
+        self.n = int(n)
+        self.H, self.W = shape(self.env_id)
+        self.rec = L.orc_sizeof()
+        self.buf = ctypes.create_string_buffer(self.rec * max(self.n, 1))
+        self.base = ctypes.addressof(self.buf)
+        for i in range(self.n):
+            assert L.orc_init(self.base + i * self.rec, self.env_id) == 0
+            if reset:
+                L.orc_reset(self.base + i * self.rec)
+
+    def ptr(self, i=0):
+        return self.base + i * self.rec
+
+    def reset(self, i=None):
+        L = lib()
+        for k in (range(self.n) if i is None else [i]):
+            L.orc_reset(self.ptr(k))
+
+    def step(self, i, action):
+        r, h, d, a = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib().orc_step(self.ptr(i), int(action), ctypes.byref(r), ctypes.byref(h), ctypes.byref(d), ctypes.byref(a))
+        return r.value, h.value, d.value, a.value
+
+    def board(self, i):
+        out = np.empty(self.H * self.W, dtype=np.int8)
+        lib().orc_board(self.ptr(i), out.ctypes.data)
+        return out.reshape(self.H, self.W)
+
+    def boards(self):
+        out = np.empty((self.n, self.H * self.W), dtype=np.int8)
+        L = lib()
+        for i in range(self.n):
+            L.orc_board(self.ptr(i), out[i].ctypes.data)
+        return out
+
+    def field(self, name):
+        f = getattr(lib(), "orc_" + name)
+        return np.array([f(self.ptr(i)) for i in range(self.n)], dtype=np.int32)
+
+    def last_performance(self, i):
+        has = ctypes.c_int()
+        v = lib().orc_last_performance(self.ptr(i), ctypes.byref(has))
+        return v if has.value else None
+
+    def rollout(self, n_steps, seed=0, env_begin=0, t_begin=0, auto_reset=True, actions=None, metrics=None):
+        """Run n_steps lockstep steps; returns rec [n,4] int8 (reward, hidden, done, actual) of the last step."""
+        rec = np.zeros((self.n, 4), dtype=np.int8)
+        a_ptr = None
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, dtype=np.uint8)
+            assert actions.shape == (n_steps, self.n)
+            a_ptr = actions.ctypes.data
+        lib().orc_rollout(self.base, self.n, env_begin, seed, t_begin, n_steps, int(auto_reset), a_ptr,
+                          rec.ctypes.data, None if metrics is None else metrics.ctypes.data)
+        return rec
+
+
+class TabQ:
+    """One literal dict-keyed tabular Q agent (reference value.py:15-58)."""
+
+    def __init__(self, ncell, lr, discount, eps0, anneal):
+        self.ncell = ncell
+        self.h = lib().orc_tabq_new(ncell, lr, discount, eps0, anneal)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_tabq_free(self.h)
+            self.h = None
+
+    def act(self, board):
+        b = np.ascontiguousarray(board, dtype=np.int8).ravel()
+        return lib().orc_tabq_act(self.h, b.ctypes.data)
+
+    def learn(self, state, action, reward, successor):
+        s = np.ascontiguousarray(state, dtype=np.int8).ravel()
+        s2 = np.ascontiguousarray(successor, dtype=np.int8).ravel()
+        lib().orc_tabq_learn(self.h, s.ctypes.data, int(action), float(reward), s2.ctypes.data)
+
+    def lookup(self, board):
+        b = np.ascontiguousarray(board, dtype=np.int8).ravel()
+        q = np.zeros(4, dtype=np.float64)
+        lib().orc_tabq_lookup(self.h, b.ctypes.data, q.ctypes.data)
+        return q
+
+    @property
+    def n_rows(self):
+        return lib().orc_tabq_n_rows(self.h)
+
+
+def tabq_rollout(envs, agents, n_steps, seed=0, env_begin=0, cheat=False, metrics=None, record_actions=False):
+    n = envs.n
+    arr = (ctypes.c_void_p * n)(*[a.h for a in agents])
+    acts = np.zeros((n_steps, n), dtype=np.uint8) if record_actions else None
+    lib().orc_tabq_rollout(envs.base, arr, n, env_begin, seed, n_steps, int(cheat),
+                           None if metrics is None else metrics.ctypes.data,
+                           None if acts is None else acts.ctypes.data)
+    return acts

@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json|npz by IMPORTING THE REFERENCE in the build container.
+
+Run from anywhere:  python tests/golden/make_golden.py
+Needs /root/reference (read-only; never present on the GPU box). Only the produced vectors are
+committed -- inputs and expected outputs -- never reference source or bytecode
+(sys.dont_write_bytecode is set before anything is imported from the reference).
+
+What runs here is the reference's own code: train.train (train.py:21-81), whiler/tabq_learn
+(common/learn.py:8-85), default_eval (common/eval.py:8-56), dqn_warmup (common/warmup.py:8-23),
+TabularQAgent/DeepQAgent (common/agents/value.py), RandomAgent (common/agents/dummy.py),
+AverageMeter/track_metrics (common/utils/meters.py), ReplayBuffer (common/utils/contain.py) and
+the YAML argparse front end (parsing/parse.py). The packages the reference merely imports but which
+are absent from this image (gym, tensorboardX, safe_grid_gym, ai_safety_gridworlds) are stubbed with
+the minimum: gym.make returns this repo's oracle env shim (oracle/gym_shim.py), SummaryWriter
+records its calls. The env behind the fixtures is therefore the repo's CPU restatement (parity with
+the upstream env: UNPINNED, see oracle/sgk_oracle.c); what the fixtures PIN is the reference's
+agent / loop / meter arithmetic and control flow on that env.
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+os.chdir(REF)  # the reference opens its YAML files cwd-relative (parsing/__init__.py:3-5)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle.gym_shim import OracleGridworldEnv  # noqa: E402
+
+
+class RecordingWriter:
+    def __init__(self, log_dir=None):
+        self.calls = []
+
+    @staticmethod
+    def _num(v):
+        if isinstance(v, (bool, np.bool_)):
+            return bool(v)
+        if isinstance(v, (int, np.integer)):
+            return int(v)
+        return float(v).hex()
+
+    def add_scalar(self, tag, value, step):
+        self.calls.append(["scalar", tag, self._num(value), int(step)])
+
+    def add_scalars(self, tag, d, step):
+        self.calls.append(["scalars", tag, {k: self._num(v) for k, v in d.items()}, int(step)])
+
+    def add_text(self, tag, text):
+        self.calls.append(["text", tag, str(text)])
+
+    def add_video(self, tag, tensor, step):
+        self.calls.append(["video", tag, list(tensor.shape), int(step)])
+
+    def add_histogram(self, tag, values, step):
+        self.calls.append(["histogram", tag, int(step)])
+
+
+_made_envs = []
+_PARSER = None
+
+
+def _install_stubs():
+    asg = types.ModuleType("ai_safety_gridworlds")
+    asg_env = types.ModuleType("ai_safety_gridworlds.environments")
+    asg_tom = types.ModuleType("ai_safety_gridworlds.environments.tomato_crmdp")
+    asg_tom.REWARD_FACTOR = 0.02
+    sys.modules.update({"ai_safety_gridworlds": asg, "ai_safety_gridworlds.environments": asg_env,
+                        "ai_safety_gridworlds.environments.tomato_crmdp": asg_tom})
+    gym = types.ModuleType("gym")
+
+    def make(name):
+        env = OracleGridworldEnv(name)
+        _made_envs.append(env)
+        return env
+
+    gym.make = make
+    sys.modules["gym"] = gym
+    tbx = types.ModuleType("tensorboardX")
+    tbx.SummaryWriter = RecordingWriter
+    sys.modules["tensorboardX"] = tbx
+    sys.modules["safe_grid_gym"] = types.ModuleType("safe_grid_gym")
+
+
+def _dump(name, obj):
+    path = os.path.join(HERE, name)
+    with open(path, "w") as f:
+        json.dump(obj, f, separators=(",", ":"))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def golden_train(name, argv):
+    """Run the reference's train(args) end to end; record every writer call, every env action, final Q."""
+    import train as ref_train  # /root/reference/train.py
+    from safe_grid_agents.parsing import prepare_parser
+    import safe_grid_agents.common.agents.value as value_mod
+
+    global _PARSER
+    if _PARSER is None:  # prepare_parser() consumes module-level YAML dicts (parse.py:70): call it once
+        _PARSER = prepare_parser()
+    args = _PARSER.parse_args(argv)
+    args.device = "cpu"  # main.py:19-20 with --disable-cuda
+    args.log_dir = "unused"
+    captured = {}
+    orig_init = value_mod.TabularQAgent.__init__
+
+    def spy_init(self, env, a):
+        orig_init(self, env, a)
+        captured["agent"] = self
+
+    value_mod.TabularQAgent.__init__ = spy_init
+    writers = []
+    orig_writer = sys.modules["tensorboardX"].SummaryWriter
+
+    class W(RecordingWriter):
+        def __init__(self, log_dir=None):
+            super().__init__(log_dir)
+            writers.append(self)
+
+    ref_train.SummaryWriter = W
+    reporter_calls = []
+    del _made_envs[:]
+    try:
+        ref_train.train(args, reporter=lambda **kw: reporter_calls.append(
+            {k: RecordingWriter._num(v) for k, v in kw.items()}))
+    finally:
+        value_mod.TabularQAgent.__init__ = orig_init
+        ref_train.SummaryWriter = orig_writer
+    agent = captured["agent"]
+    q = sorted(([int(x) for x in key], [float(v).hex() for v in row]) for key, row in agent.Q.items())
+    calls = [c for c in writers[0].calls if c[0] != "text"]
+    _dump(name, {
+        "argv": argv,
+        "args": {k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool, type(None)))},
+        "writer_calls": calls,
+        "actions": _made_envs[0].actions_log,
+        "reporter_calls": reporter_calls,
+        "final_Q": q,
+        "final_epsilon": float(agent.epsilon).hex(),
+        "np_random_next_u32": int(np.random.randint(0, 2**32, dtype=np.uint64)),
+    })
+
+
+def golden_epsilon():
+    from safe_grid_agents.common.agents.value import TabularQAgent
+
+    out = []
+    for eps, anneal in [(0.01, 100000), (0.05, 7), (0.3, 1), (0.0, 50)]:
+        ns = types.SimpleNamespace(discount=0.99, epsilon=eps, epsilon_anneal=anneal, lr=0.5)
+        env = types.SimpleNamespace(action_space=types.SimpleNamespace(n=4))
+        ag = TabularQAgent(env, ns)
+        seq = [float(ag.epsilon).hex()]  # epsilon in force for step 0
+        for _ in range(min(anneal + 5, 12)):
+            seq.append(float(ag.update_epsilon()).hex())
+        probe = {}
+        if anneal > 1000:  # far probes by direct evaluation of the list the ctor builds
+            ag2 = TabularQAgent(env, ns)
+            fe = ag2.future_eps  # element k is the epsilon for step k+1
+            for t in (1, 2, 3, 4, 999, 50000, anneal - 2, anneal - 1):
+                probe[str(t)] = float(fe[t - 1]).hex()
+            probe["len_after_ctor"] = len(fe)
+        out.append({"epsilon": eps, "anneal": anneal, "first": seq, "probe": probe})
+    _dump("epsilon_schedule.json", out)
+
+
+def golden_meters():
+    from safe_grid_agents.common.utils.meters import AverageMeter, make_meters, track_metrics
+
+    script = [(-60, -20), (12, 4), (-100, None), (30, 30), (5, 9), (44, -3), (0, 0), (-7, -8)]
+
+    class FakeEnv:
+        def __init__(self):
+            self.episode_return, self.perf = 0, None
+
+        def get_last_performance(self):
+            return self.perf
+
+    def run(eval_mode):
+        w = RecordingWriter()
+        h = make_meters({})
+        h["writer"] = w
+        h["episode"], h["period"] = 0, 0
+        env = FakeEnv()
+        snaps = []
+        for i, (ret, perf) in enumerate(script):
+            env.episode_return, env.perf = ret, perf
+            h["episode"] += 1
+            if eval_mode:
+                h["period"] = i // 3
+            track_metrics(h, env, eval=eval_mode, write=(not eval_mode) or (i % 3 == 2))
+            snaps.append({k: {"val": RecordingWriter._num(h[k].val), "avg": RecordingWriter._num(h[k].avg),
+                              "sum": RecordingWriter._num(h[k].sum), "count": h[k].count,
+                              "max": RecordingWriter._num(h[k].max)}
+                          for k in ("returns", "safeties", "margins", "margins_support")})
+        qs = {str(d): float(h["returns"].quantile(d)).hex() for d in (0.1, 0.5, 0.9)}
+        return {"calls": w.calls, "snapshots": snaps, "quantiles": qs, "history": list(h["returns"]._history)}
+
+    m = AverageMeter()
+    try:
+        m.quantile(0.5)
+        raised = False
+    except RuntimeError:
+        raised = True
+    _dump("meters.json", {"script": script, "train": run(False), "eval": run(True), "no_history_raises": raised})
+
+
+def golden_rng():
+    from safe_grid_agents.common.agents.dummy import RandomAgent
+
+    env = types.SimpleNamespace(action_space=types.SimpleNamespace(n=4))
+    out = {}
+    for seed in (0, 1, 7):
+        np.random.seed(12345)  # so that seed 0 ("falsy": dummy.py:12 does not reseed) is reproducible
+        ag = RandomAgent(env, types.SimpleNamespace(seed=seed))
+        acts = [int(ag.act(None)) for _ in range(512)]
+        samples = [float(np.random.sample()).hex() for _ in range(32)]
+        choice = [int(np.random.choice(4)) for _ in range(64)]
+        out[str(seed)] = {"acts": acts, "samples": samples, "choice": choice}
+    _dump("numpy_rng.json", out)
+
+
+def golden_warmup():
+    from safe_grid_agents.common.warmup import dqn_warmup
+    from safe_grid_agents.common.utils.meters import make_meters
+    from safe_grid_agents.common.utils.contain import ReplayBuffer
+
+    env = OracleGridworldEnv("IslandNavigation-v0")
+    env.reset()  # reference warmup reads env._env.episode_return before its first reset
+    args = types.SimpleNamespace(seed=3, replay_capacity=300)
+    agent = types.SimpleNamespace(replay=ReplayBuffer(args.replay_capacity))
+    hist = make_meters({})
+    np.random.seed(99)
+    dqn_warmup(agent, env, hist, args)
+    buf = list(agent.replay._buffer)
+    np.random.seed(5)
+    sample_ix = [int(i) for i in np.random.choice(len(buf), 16)]
+    _dump("dqn_warmup.json", {
+        "seed": 3, "replay_capacity": 300, "actions": env.actions_log,
+        "agent_cells": [int(np.argwhere(e.successor.ravel() == 2).ravel()[0]) if (e.successor == 2).any() else -1
+                        for e in buf],
+        "rewards": [int(e.reward) for e in buf], "terminals": [bool(e.terminal) for e in buf],
+        "returns_meter": {"count": hist["returns"].count, "sum": int(hist["returns"].sum),
+                          "max": int(hist["returns"].max), "history": [int(x) for x in hist["returns"]._history]},
+        "sample_seed": 5, "sample_ix": sample_ix,
+    })
+
+
+def golden_deepq_forward():
+    """DeepQAgent forward/act/policy on 2-D (H, W) observations (the only shape the reference's
+    n_input = shape[0] * shape[1] handles, value.py:66-67). learn() cannot run under torch 2.10
+    (uint8 mask, value.py:121,179) so the training step is NOT pinned."""
+    from safe_grid_agents.common.agents.value import DeepQAgent
+
+    H, W = 6, 6
+    env = types.SimpleNamespace(action_space=types.SimpleNamespace(n=4),
+                                observation_space=types.SimpleNamespace(shape=(H, W)))
+    args = types.SimpleNamespace(device="cpu", log_gradients=False, epsilon=0.01, epsilon_anneal=100000,
+                                 discount=0.99, lr=1e-3, batch_size=64, n_layers=2, n_hidden=100,
+                                 replay_capacity=100)
+    torch.manual_seed(11)
+    agent = DeepQAgent(env, args)
+    rng = np.random.RandomState(4)
+    boards = rng.randint(0, 6, size=(32, H, W)).astype(np.float32)
+    with torch.no_grad():
+        scores = np.stack([agent.Q(torch.as_tensor(b.flatten()).reshape(1, -1)).numpy()[0] for b in boards])
+        acts = np.array([int(agent.act(b)[0]) for b in boards])
+        eps_first = float(agent.epsilon)  # DeepQAgent keeps future_eps[0] = 1.0 (no overwrite, value.py:76)
+        agent.epsilon = 0.25
+        probs = np.stack([agent.policy(b).probs.numpy() for b in boards])
+    sd = {k.replace(".", "_"): v.numpy() for k, v in agent.Q.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "deepq_forward.npz"), boards=boards, scores=scores, acts=acts, probs=probs,
+                        eps_first=np.float64(eps_first), eps_policy=np.float64(0.25), **sd)
+    print("wrote deepq_forward.npz; state_dict keys:", list(agent.Q.state_dict().keys()))
+
+
+def main():
+    _install_stubs()
+    golden_epsilon()
+    golden_meters()
+    golden_rng()
+    golden_warmup()
+    golden_deepq_forward()
+    golden_train("train_boat_tabq_seed7.json",
+                 ["-S", "7", "-E", "30", "-EE", "10", "-V", "250", "-EV", "0", "boat", "tabular-q", "-l", ".5"])
+    golden_train("train_island_tabq_seed1.json",
+                 ["-S", "1", "-E", "60", "-EE", "20", "-V", "150", "-EV", "0", "-D", "0.95",
+                  "island", "tabular-q", "-l", ".5", "-e", "0.05", "-dl", "2000"])
+    golden_train("train_sokoban_tabq_seed123_cheat.json",
+                 ["-S", "123", "-E", "40", "-EE", "20", "-V", "120", "-EV", "0", "-C",
+                  "sokoban", "tabular-q", "-l", ".1", "-dl", "1500"])
+    # the reference tree must be left untouched
+    leaked = [os.path.join(d, f) for d, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
+    assert not leaked, leaked
+
+
+if __name__ == "__main__":
+    main()
