@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched lockstep gridworld step path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one lockstep pass of the hot path over the whole env batch: every env of every rank takes one
+RandomAgent action (counter RNG, in-kernel) through the HIP step kernel -- transition, observed reward, hidden
+safety reward, episode bookkeeping, auto-reset, and the successor board MATERIALISED in HBM -- one kernel launch
+per step and GPU, replayed from a hipGraph. Workload = BASELINE.json's metric config: BoatRace, 1 048 576 concurrent
+envs per GPU (weak scaling: the batch shards by env id, one contiguous block per rank, no data-path collective; the
+only exchange is one int64 metrics all-reduce at the end of the timed region).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects added.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+B_ALG = {"BoatRace-v0": 78, "SideEffectsSokoban-v0": 100, "IslandNavigation-v0": 124}  # 2*H*W + 28
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+GRAPH_CHUNK = 100      # lockstep steps per hipGraph replay
+
+
+def cpu_baseline(env_name, seed, target_seconds=12.0):
+    """The oracle's scalar C engine (kind "port": the reference's env is absent) on ONE host core, on a
+    bounded sample of the same workload: random-action lockstep rollout with reset-on-done."""
+    from oracle import oracle as O
+
+    n = 16384
+    envs = O.EnvBatch(env_name, n)
+    t0 = time.perf_counter()
+    envs.rollout(50, seed=seed, auto_reset=True)
+    probe = time.perf_counter() - t0
+    rate = n * 50 / probe
+    steps = int(max(100, min(20000, target_seconds * rate / n)))
+    envs.reset()
+    m = O.metrics_new()
+    t0 = time.perf_counter()
+    envs.rollout(steps, seed=seed, auto_reset=True, metrics=m)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+        "sample": "%s, %d envs x %d lockstep steps, oracle C engine (gcc -O2), 1 thread, %.1f s" % (env_name, n, steps, dt),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def parity_sample(env, env_name, seed, base, total_steps, sample):
+    """Bit-exact check in the same run: sampled envs' boards / returns vs the oracle after all the steps taken."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    boards = env.boards_host().reshape(env.n_envs, -1)
+    st = env.episode_state_host()
+    for i in sample:
+        orc = O.EnvBatch(env_name, 1)
+        orc.rollout(total_steps, seed=seed, env_begin=base + i, t_begin=0, auto_reset=True)
+        if not ((boards[i] == orc.boards()[0]).all() and st["episode_return"][i] == orc.field("episode_return")[0]
+                and st["hidden_return"][i] == orc.field("hidden_return")[0]):
+            return False
+    return True
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--env", default="BoatRace-v0")
+    ap.add_argument("--envs-per-gpu", type=int, default=1 << 20)
+    ap.add_argument("--layout", default=os.environ.get("SGK_BENCH_LAYOUT", "compact"), choices=["pitched", "compact"])
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5AFE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import safe_grid_agents_amd as S
+    from safe_grid_agents_amd import dist as sdist
+
+    rank, local_rank, world = sdist.env_from_torchrun()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world > 1:
+        sdist.init_process_group("nccl")
+    import torch.distributed as tdist
+
+    torch.cuda.set_device(local_rank)
+    n_local = args.envs_per_gpu
+    base = rank * n_local
+    env = S.BatchedGridworldEnv(args.env, n_local, device=local_rank, seed=args.seed, env_index_base=base,
+                                layout=args.layout)
+    stream = env.torch_stream()
+
+    def run(k):
+        done = 0
+        while done < k:
+            c = min(GRAPH_CHUNK, k - done)
+            env.step_random(c, auto_reset=True)
+            done += c
+
+    def barrier():
+        if world > 1:
+            tdist.barrier()
+
+    run(args.warmup)
+    env.synchronize()
+    # ---- timed region: EXACTLY --steps lockstep steps + the metrics flush ------------------------------------------
+    barrier()
+    torch.cuda.synchronize()
+    env.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run(args.steps)
+    ev1.record(stream)
+    gm = sdist.global_metrics(env)  # syncs the stream; one int64 all-reduce (RCCL over xGMI) when world > 1
+    env.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # ------------------------------------------------------------------------------------------------------------------
+    kernel_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the step kernels run on
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    total_steps = args.warmup + args.steps
+    fused = None
+    if not args.no_fused:
+        # same workload through the fused rollout kernel (state in registers, boards materialised once per launch)
+        env.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        env.step_random(100, auto_reset=True, fused=True)
+        f0.record(stream)
+        fused_steps = 1000
+        env.step_random(fused_steps, auto_reset=True, fused=True)
+        f1.record(stream)
+        env.synchronize()
+        fms = f0.elapsed_time(f1)
+        total_steps += 100 + fused_steps
+        fused = {"value": n_local * world * fused_steps / (fms / 1e3), "unit": "env-steps/s",
+                 "ms_per_launch": fms, "steps_per_launch": fused_steps,
+                 "note": "sgk_rollout_random: %d lockstep steps in ONE launch; per-rank device time" % fused_steps}
+
+    if rank != 0:
+        return
+    n_total = n_local * world
+    value = n_total * args.steps / elapsed
+    launch_s = kernel_ms / 1e3 / args.steps  # average duration of one step launch incl. its dependent-launch gap
+    achieved = B_ALG[args.env] * n_local / launch_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = tj.get("%s/%s/%d" % (args.env, args.layout, n_local))
+    sample = [0, 1, 255, 256, n_local // 2 + 3, n_local - 1]
+    ok = parity_sample(env, args.env, args.seed, base, total_steps, sample)
+    out = {
+        "metric": "env-steps/sec at 1M concurrent BoatRace envs" if args.env == "BoatRace-v0" else "env-steps/sec",
+        "value": value,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int8",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s random-action rollout, %d envs per GPU in lockstep, step kernel (one launch per step, "
+                        "hipGraph x%d), auto-reset, boards materialised every step" % (args.env, n_local, GRAPH_CHUNK),
+            "envs_per_gpu": n_local, "total_envs": n_total, "board_layout": args.layout,
+            "parallelism": "env-sharded x%d, int64 metrics all-reduce" % world,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "kernel": "sgk::step_kernel<%s>" % args.env, "algorithmic_bytes_per_env_step": B_ALG[args.env],
+            "avg_launch_us": launch_s * 1e6, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+        },
+        "episodes_finished": gm.episodes,
+        "mean_return": gm.meter("returns")["avg"], "mean_safety": gm.meter("safeties")["avg"],
+        "parity_sample_bit_exact": ok,
+    }
+    if fused:
+        out["fused_rollout"] = fused
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.env, args.seed)
+    print(json.dumps(out))
+    if not ok:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

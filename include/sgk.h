@@ -1,0 +1,188 @@
+/* sgk.h -- C-ABI of libsgk.so: batched lockstep safety-gridworld step / agent-rollout path on MI355X.
+ *
+ * The reference (jvmncs/safe-grid-agents) has no FFI; its seam for this path is the Python
+ * gym.Env duck type (env.step / env.reset / env._env.episode_return / get_last_performance) and the
+ * agent methods called from common/{learn,eval,warmup}.py. Each entry point below names the
+ * reference interface it sits under (file:line in /root/reference). The Python host mirror
+ * (safe-grid-agents_amd/safe_grid_agents_amd) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions: flat C, plain pointers and sizes. Every function returns SGK_OK (0) or a negative
+ * SGK_ERR_* and leaves a message for sgk_last_error() (thread-local). Handles are opaque and
+ * thread-compatible (one thread at a time per handle). Pointers named *_dev are DEVICE pointers
+ * valid on the handle's GPU (e.g. torch tensor.data_ptr()); pointers named *_host are host memory.
+ * All work is enqueued on the handle's HIP stream; only functions documented as synchronising wait.
+ */
+#ifndef SGK_H
+#define SGK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGK_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define SGK_API __attribute__((visibility("default")))
+#else
+#define SGK_API
+#endif
+
+#define SGK_OK 0
+#define SGK_ERR_INVALID (-1) /* bad argument */
+#define SGK_ERR_HIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
+#define SGK_ERR_NOMEM (-3)
+#define SGK_ERR_NODEVICE (-4) /* no usable GPU: the library has NO CPU fallback */
+
+/* env ids (reference parsing/parse.py:22-37 ENV_MAP aliases boat / island / sokoban) */
+#define SGK_BOAT_RACE 0
+#define SGK_ISLAND_NAVIGATION 1
+#define SGK_SIDE_EFFECTS_SOKOBAN 2
+
+/* flags for sgk_step / sgk_step_random / sgk_rollout_random */
+#define SGK_F_AUTO_RESET 1u /* an env whose episode ends is reset in the same step (after its episode is recorded) */
+#define SGK_F_NO_BOARDS 2u  /* do not materialise observation boards this call (they go stale until the next writing call) */
+
+/* board layouts (sgk_create_ex) */
+#define SGK_LAYOUT_PITCHED 0 /* env-major rows padded to a multiple of 16 B: one lane writes its row with 16-B stores */
+#define SGK_LAYOUT_COMPACT 1 /* env-major rows of exactly n_cells bytes: workgroup tile staged through LDS */
+
+typedef struct sgk_env sgk_env;   /* one shard: N independent grid instances resident on one GPU */
+typedef struct sgk_tabq sgk_tabq; /* N private tabular-Q agents bound to an sgk_env */
+
+/* Per-env record written by every step (one coalesced dword per env):
+ *   reward         observed reward        -> `reward` of env.step (reference learn.py:38,69)
+ *   hidden_reward  info["hidden_reward"]  (reference learn.py:42,73; train.py:73)
+ *   done           `done` of env.step
+ *   actual_action  info["extra_observations"]["actual_actions"] (reference learn.py:45,76) */
+typedef struct sgk_step_rec {
+  int8_t reward;
+  int8_t hidden_reward;
+  uint8_t done;
+  uint8_t actual_action;
+} sgk_step_rec;
+
+typedef struct sgk_info {
+  int32_t env_id;
+  int32_t height, width, n_cells; /* observation_space.shape = (1, height, width) (reference value.py:66) */
+  int32_t n_actions;              /* action_space.n (reference dummy.py:11, value.py:19) */
+  int32_t board_pitch;            /* bytes between consecutive envs' boards */
+  int32_t layout;
+  int32_t max_iterations;
+  int32_t n_states;               /* size of the perfect-hash state index used by sgk_tabq */
+  int32_t device;
+  int64_t n_envs;
+  uint64_t seed;
+  uint64_t env_index_base;        /* global index of env 0 of this shard (keys the counter RNG) */
+  uint64_t lockstep_t;            /* number of lockstep steps taken since create (keys the counter RNG) */
+} sgk_info;
+
+/* metrics vector (int64 x SGK_METRICS_LEN): the quantities track_metrics feeds its four meters
+ * (reference meters.py:66-84). [0..7] are sums/counts (all-reduce SUM), [8..11] maxima (all-reduce MAX). */
+#define SGK_METRICS_LEN 16
+#define SGK_M_SUM_RETURN 0
+#define SGK_M_SUM_SAFETY 1
+#define SGK_M_SUM_MARGIN 2
+#define SGK_M_SUM_MARGIN_POS 3
+#define SGK_M_EPISODES 4
+#define SGK_M_MARGIN_POS_COUNT 5
+#define SGK_M_STEPS 6
+#define SGK_M_MAX_RETURN 8
+#define SGK_M_MAX_SAFETY 9
+#define SGK_M_MAX_MARGIN 10
+#define SGK_M_MAX_MARGIN_POS 11
+
+SGK_API const char *sgk_last_error(void);
+SGK_API int sgk_abi_version(void);
+SGK_API int sgk_device_count(int *n_out);
+
+/* ---- lifetime: gym.make(env_name) + env.seed(seed) (reference train.py:51-52) ------------------ */
+SGK_API int sgk_create(int env_id, int64_t n_envs, int device, uint64_t seed, sgk_env **out);
+SGK_API int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_t env_index_base, int layout,
+                  sgk_env **out);
+SGK_API int sgk_destroy(sgk_env *h);
+SGK_API int sgk_get_info(const sgk_env *h, sgk_info *out);
+SGK_API int sgk_set_stream(sgk_env *h, void *hip_stream); /* NULL restores the handle's own stream */
+SGK_API void *sgk_get_stream(const sgk_env *h);
+SGK_API int sgk_synchronize(sgk_env *h); /* waits for the handle's stream */
+
+/* ---- env.reset() (reference train.py:64; eval.py:13,23; warmup.py:17) ------------------------- */
+/* mask_dev == NULL: every env. Otherwise envs with mask_dev[i] != 0. Episode return, hidden return and
+ * frame counter restart; get_last_performance() history is kept. */
+SGK_API int sgk_reset(sgk_env *h, const uint8_t *mask_dev);
+SGK_API int sgk_reset_done(sgk_env *h); /* resets exactly the envs whose episode is over */
+
+/* ---- env.step(action) (reference learn.py:38,69; eval.py:36; warmup.py:20) -------------------- */
+/* actions_dev: uint8[n_envs] in {0..3}. Writes the step records, advances episode state, materialises
+ * the successor boards. Stepping an env whose episode is over (and not reset) is a no-op that reports
+ * reward 0 / done 1. */
+SGK_API int sgk_step(sgk_env *h, const uint8_t *actions_dev, uint32_t flags);
+/* Host-buffer form for small N (the single-env drop-in of reference learn.py:38,69): copies the actions in,
+ * steps, and copies out the step records, the dense boards [n_envs][n_cells] and env._env.episode_return.
+ * Any output pointer may be NULL. Synchronises. */
+SGK_API int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_step_rec *rec_host,
+                  int8_t *boards_host, int32_t *episode_return_host);
+/* RandomAgent.act + env.step (reference dummy.py:15-16, warmup.py:19-20): n_steps lockstep steps, one
+ * launch per step (replayed from a hipGraph), actions from the counter RNG (Philox-4x32-10, stream 0). */
+SGK_API int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags);
+/* the same n_steps inside ONE launch: state stays in registers, boards are materialised once at the end */
+SGK_API int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags);
+/* the action the counter RNG yields for (env_index, lockstep step t); host helper for tests */
+SGK_API int sgk_random_action(uint64_t seed, uint64_t env_index, uint64_t t);
+
+/* ---- zero-copy device views -------------------------------------------------------------------- */
+SGK_API int sgk_boards_dev(sgk_env *h, int8_t **boards_dev, int64_t *pitch);  /* int8 cells (value_mapping), [n_envs][pitch] */
+SGK_API int sgk_step_records_dev(sgk_env *h, sgk_step_rec **rec_dev);        /* [n_envs] */
+SGK_API int sgk_metrics_dev(sgk_env *h, int64_t **metrics_dev);              /* [SGK_METRICS_LEN] */
+SGK_API int sgk_episode_arrays_dev(sgk_env *h, int32_t **last_return_dev, int32_t **last_performance_dev,
+                           int32_t **n_episodes_dev);
+/* observation as the agents see it: float32 [n_envs][n_cells] (reference value.py:90,161-164) */
+SGK_API int sgk_obs_f32(sgk_env *h, float *dst_dev);
+
+/* ---- synchronising host copies ------------------------------------------------------------------ */
+SGK_API int sgk_copy_boards(sgk_env *h, int8_t *boards_host /* [n_envs][n_cells], dense */);
+SGK_API int sgk_copy_step_records(sgk_env *h, sgk_step_rec *rec_host);
+/* env._env.episode_return (reference meters.py:76, warmup.py:16) and companions; any pointer may be NULL */
+SGK_API int sgk_copy_episode_state(sgk_env *h, int32_t *episode_return_host, int32_t *hidden_return_host,
+                           int32_t *frame_host, uint8_t *over_host, uint8_t *agent_cell_host, uint8_t *box_cell_host);
+/* env._env.get_last_performance() (reference meters.py:77): valid where n_episodes > 0, else None */
+SGK_API int sgk_copy_last_episode(sgk_env *h, int32_t *last_return_host, int32_t *last_performance_host,
+                          int32_t *n_episodes_host);
+SGK_API int sgk_metrics(sgk_env *h, int64_t out_host[SGK_METRICS_LEN]);
+SGK_API int sgk_metrics_reset(sgk_env *h);
+
+/* done-mask compaction: ids (ascending) of the envs whose LAST step record has done != 0, with the
+ * episode_return / performance track_metrics would read for them (reference meters.py:76-77).
+ * Outputs are device arrays of capacity n_envs; *n_host receives the count (synchronises). */
+SGK_API int sgk_finished(sgk_env *h, int32_t *ids_dev, int32_t *return_dev, int32_t *performance_dev, int64_t *n_host);
+
+/* ---- TabularQAgent, one private agent per env (reference common/agents/value.py:15-58) ---------- */
+SGK_API int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, int64_t epsilon_anneal, sgk_tabq **out);
+SGK_API int sgk_tabq_destroy(sgk_tabq *q);
+/* act (explore == 0, value.py:33-35) / act_explore (value.py:37-42) for every env's current state */
+SGK_API int sgk_tabq_act(sgk_tabq *q, int explore, uint8_t *actions_out_dev);
+/* learn + update_epsilon after sgk_step (value.py:44-58; learn.py:72-82). cheat != 0 learns from the hidden
+ * reward and the actual action. */
+SGK_API int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat);
+/* n_steps of {act_explore, env.step, learn, update_epsilon, reset on done} in one launch
+ * (reference learn.py:61-85 inside train.py:62-70) */
+SGK_API int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat);
+SGK_API int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64_t *n_actions); /* [n_envs][n_states][n_actions] */
+SGK_API int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, double *table_host);
+SGK_API int sgk_tabq_global_step(const sgk_tabq *q, int64_t *t_out);
+SGK_API double sgk_tabq_epsilon(double epsilon, int64_t epsilon_anneal, int64_t t); /* epsilon in force at global step t */
+
+/* ---- host-only debug hooks for the CPU test-suite (no GPU needed; never used by a product path) ------- */
+/* The kernels' transition function, evaluated on the host for one (agent cell, box cell, action):
+ * out = {next agent cell, next box cell, observed reward, hidden reward, terminal}. */
+SGK_API int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int action, int32_t out[5]);
+/* dims = {height, width, start agent cell, start box cell (255: none)}; the backdrop values and the value drawn at
+ * the agent's cell, per cell. */
+SGK_API int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGK_H */

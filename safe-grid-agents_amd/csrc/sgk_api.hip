@@ -1,0 +1,581 @@
+// sgk_api.hip -- the C-ABI of libsgk.so (include/sgk.h): handle management, stream / hipGraph
+// plumbing and host copies around the kernels in sgk_kernels.hip. No CPU fallback: every entry point
+// needs a GPU and says so when there is none.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "sgk_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+  return fail(SGK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define SGK_HIP(call)                                    \
+  do {                                                   \
+    hipError_t e__ = (call);                             \
+    if (e__ != hipSuccess) return hip_fail(e__, #call);  \
+  } while (0)
+
+__global__ void set_counter_kernel(uint64_t *ctr, uint64_t v) { *ctr = v; }
+__global__ void add_counter_kernel(uint64_t *ctr, uint64_t v) { *ctr += v; }
+__global__ void init_metrics_kernel(int64_t *m) {
+  int i = threadIdx.x;
+  if (i < SGK_METRICS_LEN) m[i] = (i >= SGK_M_MAX_RETURN && i <= SGK_M_MAX_MARGIN_POS) ? INT64_MIN : 0;
+}
+
+}  // namespace
+
+struct sgk_env {
+  sgk::Shard sh;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  uint64_t *t_dev = nullptr;     // device copy of lockstep_t for graph replays
+  bool t_dev_stale = true;
+  int64_t steps_issued = 0;      // host-side SGK_M_STEPS
+  int8_t *dense_scratch = nullptr;
+  uint8_t *actions_scratch = nullptr;
+  std::map<std::pair<int32_t, uint32_t>, hipGraphExec_t> graphs;
+  bool use_graph = true;
+};
+
+struct sgk_tabq {
+  sgk_env *env = nullptr;
+  sgk::TabqShard tq;
+  uint8_t *actions = nullptr;  // scratch for the per-step fallback of sgk_tabq_rollout
+};
+
+namespace sgk {
+// step kernel variant that reads the lockstep counter from device memory (graph replays)
+hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st);
+}  // namespace sgk
+
+extern "C" {
+
+const char *sgk_last_error(void) { return g_last_error.c_str(); }
+int sgk_abi_version(void) { return SGK_ABI_VERSION; }
+
+int sgk_device_count(int *n_out) {
+  if (!n_out) return fail(SGK_ERR_INVALID, "n_out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *n_out = 0;
+    return fail(SGK_ERR_NODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *n_out = n;
+  return SGK_OK;
+}
+
+int sgk_random_action(uint64_t seed, uint64_t env_index, uint64_t t) { return sgk::host_random_action(seed, env_index, t); }
+double sgk_tabq_epsilon(double epsilon, int64_t epsilon_anneal, int64_t t) {
+  return sgk::host_epsilon_at(epsilon, epsilon_anneal, t);
+}
+
+int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int action, int32_t out[5]) {
+  SgkRules R;
+  if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
+  if (agent_cell < 0 || agent_cell >= R.n_cells || action < 0 || action >= SGK_ACTIONS) return fail(SGK_ERR_INVALID, "bad cell/action");
+  int o[5];
+  if (sgk::host_debug_transition(R, agent_cell, box_cell, action, o) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
+  for (int i = 0; i < 5; ++i) out[i] = o[i];
+  return SGK_OK;
+}
+
+int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]) {
+  SgkRules R;
+  if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
+  dims[0] = R.height; dims[1] = R.width; dims[2] = R.start_agent; dims[3] = R.start_box;
+  memcpy(templ, R.templ, 64);
+  memcpy(agent_value, R.agent_value, 64);
+  return SGK_OK;
+}
+
+int sgk_destroy(sgk_env *h) {
+  if (!h) return SGK_OK;
+  (void)hipSetDevice(h->sh.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto &kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+  sgk::Shard &s = h->sh;
+  (void)hipFree(s.rules_dev); (void)hipFree(s.state); (void)hipFree(s.rec); (void)hipFree(s.boards); (void)hipFree(s.last_return);
+  (void)hipFree(s.last_perf); (void)hipFree(s.n_episodes); (void)hipFree(s.metrics); (void)hipFree(s.wg_count); (void)hipFree(s.wg_offset);
+  (void)hipFree(s.finished_total); (void)hipFree(h->t_dev); (void)hipFree(h->dense_scratch);
+  (void)hipFree(h->actions_scratch);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return SGK_OK;
+}
+
+int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_t env_index_base, int layout,
+                  sgk_env **out) {
+  if (!out) return fail(SGK_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (n_envs <= 0 || n_envs > ((int64_t)1 << 31) - 512) return fail(SGK_ERR_INVALID, "n_envs out of range");
+  if (layout != SGK_LAYOUT_PITCHED && layout != SGK_LAYOUT_COMPACT) return fail(SGK_ERR_INVALID, "unknown layout");
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0)
+    return fail(SGK_ERR_NODEVICE, "libsgk has no CPU fallback and found no HIP device" +
+                                      (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string()));
+  if (device < 0 || device >= n_dev) return fail(SGK_ERR_INVALID, "device ordinal out of range");
+  sgk_env *h = new (std::nothrow) sgk_env();
+  if (!h) return fail(SGK_ERR_NOMEM, "host allocation failed");
+  sgk::Shard &s = h->sh;
+  if (sgk_build_rules(env_id, &s.rules_host) != 0) {
+    delete h;
+    return fail(SGK_ERR_INVALID, "unknown env_id");
+  }
+  s.env_id = env_id;
+  s.device = device;
+  s.n = n_envs;
+  s.seed = seed;
+  s.env_base = env_index_base;
+  s.n_cells = s.rules_host.n_cells;
+  s.n_states = s.rules_host.n_states;
+  const int pitched = ((s.n_cells + 15) / 16) * 16;
+  s.layout = (s.n_cells % 16 == 0) ? SGK_LAYOUT_PITCHED : layout;
+  s.pitch = (s.layout == SGK_LAYOUT_COMPACT) ? s.n_cells : pitched;
+  const char *ng = getenv("SGK_NO_GRAPH");
+  h->use_graph = !(ng && ng[0] == '1');
+
+#define SGK_TRY(call)                                   \
+  do {                                                  \
+    hipError_t e__ = (call);                            \
+    if (e__ != hipSuccess) {                            \
+      int rc__ = hip_fail(e__, #call);                  \
+      std::string keep__ = g_last_error;                \
+      sgk_destroy(h);                                   \
+      g_last_error = keep__;                            \
+      return rc__;                                      \
+    }                                                   \
+  } while (0)
+
+  SGK_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  SGK_TRY(hipGetDeviceProperties(&prop, device));
+  s.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  s.max_grid = s.n_cus * 8;
+  SGK_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  const int64_t n_pad = ((s.n + 255) / 256) * 256;
+  const int64_t n_wg = n_pad / 256;
+  SGK_TRY(hipMalloc(&s.rules_dev, sizeof(SgkRules)));
+  SGK_TRY(hipMalloc(&s.state, sizeof(uint64_t) * n_pad));
+  SGK_TRY(hipMalloc(&s.rec, sizeof(uint32_t) * n_pad));
+  SGK_TRY(hipMalloc(&s.boards, (size_t)s.pitch * n_pad));
+  SGK_TRY(hipMalloc(&s.last_return, sizeof(int32_t) * n_pad));
+  SGK_TRY(hipMalloc(&s.last_perf, sizeof(int32_t) * n_pad));
+  SGK_TRY(hipMalloc(&s.n_episodes, sizeof(int32_t) * n_pad));
+  SGK_TRY(hipMalloc(&s.metrics, sizeof(int64_t) * SGK_METRICS_LEN));
+  SGK_TRY(hipMalloc(&s.wg_count, sizeof(int32_t) * n_wg));
+  SGK_TRY(hipMalloc(&s.wg_offset, sizeof(int64_t) * n_wg));
+  SGK_TRY(hipMalloc(&s.finished_total, sizeof(int64_t)));
+  SGK_TRY(hipMalloc(&h->t_dev, sizeof(uint64_t)));
+  SGK_TRY(hipMemcpyAsync(s.rules_dev, &s.rules_host, sizeof(SgkRules), hipMemcpyHostToDevice, h->stream));
+  SGK_TRY(hipMemsetAsync(s.rec, 0, sizeof(uint32_t) * n_pad, h->stream));
+  SGK_TRY(hipMemsetAsync(s.last_return, 0, sizeof(int32_t) * n_pad, h->stream));
+  SGK_TRY(hipMemsetAsync(s.last_perf, 0, sizeof(int32_t) * n_pad, h->stream));
+  SGK_TRY(hipMemsetAsync(s.n_episodes, 0, sizeof(int32_t) * n_pad, h->stream));
+  SGK_TRY(hipMemsetAsync(s.state, 0, sizeof(uint64_t) * n_pad, h->stream));
+  hipLaunchKernelGGL(init_metrics_kernel, dim3(1), dim3(64), 0, h->stream, s.metrics);
+  SGK_TRY(hipGetLastError());
+  SGK_TRY(sgk::launch_reset(s, nullptr, 0, h->stream));  // gym.make leaves the env ready; reset() is still idempotent
+  SGK_TRY(hipStreamSynchronize(h->stream));
+#undef SGK_TRY
+  *out = h;
+  return SGK_OK;
+}
+
+int sgk_create(int env_id, int64_t n_envs, int device, uint64_t seed, sgk_env **out) {
+  return sgk_create_ex(env_id, n_envs, device, seed, 0, SGK_LAYOUT_PITCHED, out);
+}
+
+#define SGK_CHECK_HANDLE(h)                                   \
+  do {                                                        \
+    if (!(h)) return fail(SGK_ERR_INVALID, "handle is NULL"); \
+    SGK_HIP(hipSetDevice((h)->sh.device));                    \
+  } while (0)
+
+int sgk_get_info(const sgk_env *h, sgk_info *out) {
+  if (!h || !out) return fail(SGK_ERR_INVALID, "NULL argument");
+  const sgk::Shard &s = h->sh;
+  out->env_id = s.env_id;
+  out->height = s.rules_host.height;
+  out->width = s.rules_host.width;
+  out->n_cells = s.n_cells;
+  out->n_actions = SGK_ACTIONS;
+  out->board_pitch = s.pitch;
+  out->layout = s.layout;
+  out->max_iterations = s.rules_host.max_iterations;
+  out->n_states = s.n_states;
+  out->device = s.device;
+  out->n_envs = s.n;
+  out->seed = s.seed;
+  out->env_index_base = s.env_base;
+  out->lockstep_t = s.lockstep_t;
+  return SGK_OK;
+}
+
+int sgk_set_stream(sgk_env *h, void *hip_stream) {
+  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  if (st != h->stream) {  // graphs were captured on the old stream's topology only; they stay valid, but keep it simple
+    h->stream = st;
+  }
+  return SGK_OK;
+}
+
+void *sgk_get_stream(const sgk_env *h) { return h ? (void *)h->stream : nullptr; }
+
+int sgk_synchronize(sgk_env *h) {
+  SGK_CHECK_HANDLE(h);
+  SGK_HIP(hipStreamSynchronize(h->stream));
+  return SGK_OK;
+}
+
+int sgk_reset(sgk_env *h, const uint8_t *mask_dev) {
+  SGK_CHECK_HANDLE(h);
+  SGK_HIP(sgk::launch_reset(h->sh, mask_dev, 0, h->stream));
+  return SGK_OK;
+}
+
+int sgk_reset_done(sgk_env *h) {
+  SGK_CHECK_HANDLE(h);
+  SGK_HIP(sgk::launch_reset(h->sh, nullptr, 1, h->stream));
+  return SGK_OK;
+}
+
+int sgk_step(sgk_env *h, const uint8_t *actions_dev, uint32_t flags) {
+  SGK_CHECK_HANDLE(h);
+  if (!actions_dev) return fail(SGK_ERR_INVALID, "actions_dev is NULL (use sgk_step_random for RNG actions)");
+  SGK_HIP(sgk::launch_step(h->sh, actions_dev, flags, h->stream));
+  h->sh.lockstep_t += 1;
+  h->t_dev_stale = true;
+  h->steps_issued += h->sh.n;
+  return SGK_OK;
+}
+
+int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_step_rec *rec_host, int8_t *boards_host,
+                  int32_t *episode_return_host) {
+  SGK_CHECK_HANDLE(h);
+  if (!actions_host) return fail(SGK_ERR_INVALID, "actions_host is NULL");
+  if (!h->actions_scratch) SGK_HIP(hipMalloc(&h->actions_scratch, (size_t)h->sh.n));
+  SGK_HIP(hipMemcpyAsync(h->actions_scratch, actions_host, (size_t)h->sh.n, hipMemcpyHostToDevice, h->stream));
+  int rc = sgk_step(h, h->actions_scratch, flags);
+  if (rc != SGK_OK) return rc;
+  if (rec_host)
+    SGK_HIP(hipMemcpyAsync(rec_host, h->sh.rec, sizeof(uint32_t) * h->sh.n, hipMemcpyDeviceToHost, h->stream));
+  if (boards_host) {
+    rc = sgk_copy_boards(h, boards_host);  // synchronises
+    if (rc != SGK_OK) return rc;
+  }
+  if (episode_return_host) return sgk_copy_episode_state(h, episode_return_host, nullptr, nullptr, nullptr, nullptr, nullptr);
+  SGK_HIP(hipStreamSynchronize(h->stream));
+  return SGK_OK;
+}
+
+int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
+  SGK_CHECK_HANDLE(h);
+  if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
+  if (n_steps == 0) return SGK_OK;
+  sgk::Shard &s = h->sh;
+  if (!h->use_graph || n_steps < 4) {
+    for (int32_t k = 0; k < n_steps; ++k) {
+      SGK_HIP(sgk::launch_step(s, nullptr, flags, h->stream));
+      s.lockstep_t += 1;
+    }
+    h->t_dev_stale = true;
+    h->steps_issued += s.n * (int64_t)n_steps;
+    return SGK_OK;
+  }
+  // hipGraph path: the launch-bound inner loop (n_steps dependent step kernels) is captured once per
+  // (n_steps, flags) and replayed; the lockstep counter lives in device memory so replays need no new arguments.
+  auto key = std::make_pair(n_steps, flags);
+  auto it = h->graphs.find(key);
+  if (it == h->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    SGK_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t le = hipSuccess;
+    for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k)
+      le = sgk::launch_step_counter(s, h->t_dev, (uint64_t)k, flags, h->stream);
+    if (le == hipSuccess) {
+      hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, (uint64_t)n_steps);
+      le = hipGetLastError();
+    }
+    hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+    if (le != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); return hip_fail(le, "capture step kernels"); }
+    if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture");
+    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate");
+    it = h->graphs.emplace(key, exec).first;
+  }
+  if (h->t_dev_stale) {
+    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, s.lockstep_t);
+    SGK_HIP(hipGetLastError());
+    h->t_dev_stale = false;
+  }
+  SGK_HIP(hipGraphLaunch(it->second, h->stream));
+  s.lockstep_t += (uint64_t)n_steps;
+  h->steps_issued += s.n * (int64_t)n_steps;
+  return SGK_OK;
+}
+
+int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
+  SGK_CHECK_HANDLE(h);
+  if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
+  if (n_steps == 0) return SGK_OK;
+  SGK_HIP(sgk::launch_rollout_random(h->sh, n_steps, flags, h->stream));
+  h->sh.lockstep_t += (uint64_t)n_steps;
+  h->t_dev_stale = true;
+  h->steps_issued += h->sh.n * (int64_t)n_steps;
+  return SGK_OK;
+}
+
+int sgk_boards_dev(sgk_env *h, int8_t **boards_dev, int64_t *pitch) {
+  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  if (boards_dev) *boards_dev = h->sh.boards;
+  if (pitch) *pitch = h->sh.pitch;
+  return SGK_OK;
+}
+
+int sgk_step_records_dev(sgk_env *h, sgk_step_rec **rec_dev) {
+  if (!h || !rec_dev) return fail(SGK_ERR_INVALID, "NULL argument");
+  *rec_dev = reinterpret_cast<sgk_step_rec *>(h->sh.rec);
+  return SGK_OK;
+}
+
+int sgk_metrics_dev(sgk_env *h, int64_t **metrics_dev) {
+  if (!h || !metrics_dev) return fail(SGK_ERR_INVALID, "NULL argument");
+  *metrics_dev = h->sh.metrics;
+  return SGK_OK;
+}
+
+int sgk_episode_arrays_dev(sgk_env *h, int32_t **last_return_dev, int32_t **last_performance_dev, int32_t **n_episodes_dev) {
+  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  if (last_return_dev) *last_return_dev = h->sh.last_return;
+  if (last_performance_dev) *last_performance_dev = h->sh.last_perf;
+  if (n_episodes_dev) *n_episodes_dev = h->sh.n_episodes;
+  return SGK_OK;
+}
+
+int sgk_obs_f32(sgk_env *h, float *dst_dev) {
+  SGK_CHECK_HANDLE(h);
+  if (!dst_dev) return fail(SGK_ERR_INVALID, "dst_dev is NULL");
+  SGK_HIP(sgk::launch_obs_f32(h->sh, dst_dev, h->stream));
+  return SGK_OK;
+}
+
+int sgk_copy_boards(sgk_env *h, int8_t *boards_host) {
+  SGK_CHECK_HANDLE(h);
+  if (!boards_host) return fail(SGK_ERR_INVALID, "boards_host is NULL");
+  sgk::Shard &s = h->sh;
+  const size_t bytes = (size_t)s.n * s.n_cells;
+  if (s.pitch == s.n_cells) {
+    SGK_HIP(hipMemcpyAsync(boards_host, s.boards, bytes, hipMemcpyDeviceToHost, h->stream));
+  } else {
+    if (!h->dense_scratch) SGK_HIP(hipMalloc(&h->dense_scratch, bytes));
+    SGK_HIP(sgk::launch_dense_boards(s, h->dense_scratch, h->stream));
+    SGK_HIP(hipMemcpyAsync(boards_host, h->dense_scratch, bytes, hipMemcpyDeviceToHost, h->stream));
+  }
+  SGK_HIP(hipStreamSynchronize(h->stream));
+  return SGK_OK;
+}
+
+int sgk_copy_step_records(sgk_env *h, sgk_step_rec *rec_host) {
+  SGK_CHECK_HANDLE(h);
+  if (!rec_host) return fail(SGK_ERR_INVALID, "rec_host is NULL");
+  SGK_HIP(hipMemcpyAsync(rec_host, h->sh.rec, sizeof(uint32_t) * h->sh.n, hipMemcpyDeviceToHost, h->stream));
+  SGK_HIP(hipStreamSynchronize(h->stream));
+  return SGK_OK;
+}
+
+int sgk_copy_episode_state(sgk_env *h, int32_t *episode_return_host, int32_t *hidden_return_host, int32_t *frame_host,
+                           uint8_t *over_host, uint8_t *agent_cell_host, uint8_t *box_cell_host) {
+  SGK_CHECK_HANDLE(h);
+  std::vector<uint64_t> w((size_t)h->sh.n);
+  SGK_HIP(hipMemcpyAsync(w.data(), h->sh.state, sizeof(uint64_t) * w.size(), hipMemcpyDeviceToHost, h->stream));
+  SGK_HIP(hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < w.size(); ++i) {
+    uint32_t lo = (uint32_t)w[i], hi = (uint32_t)(w[i] >> 32);
+    if (agent_cell_host) agent_cell_host[i] = (uint8_t)(lo & 0xff);
+    if (box_cell_host) box_cell_host[i] = (uint8_t)((lo >> 8) & 0xff);
+    if (frame_host) frame_host[i] = (int32_t)((lo >> 16) & 0xff);
+    if (over_host) over_host[i] = (uint8_t)((lo >> 24) & 1);
+    if (episode_return_host) episode_return_host[i] = (int32_t)(int16_t)(hi & 0xffff);
+    if (hidden_return_host) hidden_return_host[i] = (int32_t)(int16_t)(hi >> 16);
+  }
+  return SGK_OK;
+}
+
+int sgk_copy_last_episode(sgk_env *h, int32_t *last_return_host, int32_t *last_performance_host, int32_t *n_episodes_host) {
+  SGK_CHECK_HANDLE(h);
+  const size_t bytes = sizeof(int32_t) * (size_t)h->sh.n;
+  if (last_return_host) SGK_HIP(hipMemcpyAsync(last_return_host, h->sh.last_return, bytes, hipMemcpyDeviceToHost, h->stream));
+  if (last_performance_host)
+    SGK_HIP(hipMemcpyAsync(last_performance_host, h->sh.last_perf, bytes, hipMemcpyDeviceToHost, h->stream));
+  if (n_episodes_host) SGK_HIP(hipMemcpyAsync(n_episodes_host, h->sh.n_episodes, bytes, hipMemcpyDeviceToHost, h->stream));
+  SGK_HIP(hipStreamSynchronize(h->stream));
+  return SGK_OK;
+}
+
+int sgk_metrics(sgk_env *h, int64_t out_host[SGK_METRICS_LEN]) {
+  SGK_CHECK_HANDLE(h);
+  if (!out_host) return fail(SGK_ERR_INVALID, "out_host is NULL");
+  SGK_HIP(hipMemcpyAsync(out_host, h->sh.metrics, sizeof(int64_t) * SGK_METRICS_LEN, hipMemcpyDeviceToHost, h->stream));
+  SGK_HIP(hipStreamSynchronize(h->stream));
+  out_host[SGK_M_STEPS] = h->steps_issued;
+  return SGK_OK;
+}
+
+int sgk_metrics_reset(sgk_env *h) {
+  SGK_CHECK_HANDLE(h);
+  hipLaunchKernelGGL(init_metrics_kernel, dim3(1), dim3(64), 0, h->stream, h->sh.metrics);
+  SGK_HIP(hipGetLastError());
+  h->steps_issued = 0;
+  return SGK_OK;
+}
+
+int sgk_finished(sgk_env *h, int32_t *ids_dev, int32_t *return_dev, int32_t *performance_dev, int64_t *n_host) {
+  SGK_CHECK_HANDLE(h);
+  if (!ids_dev || !return_dev || !performance_dev || !n_host) return fail(SGK_ERR_INVALID, "NULL argument");
+  SGK_HIP(sgk::launch_finished(h->sh, ids_dev, return_dev, performance_dev, h->stream));
+  SGK_HIP(hipMemcpyAsync(n_host, h->sh.finished_total, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  SGK_HIP(hipStreamSynchronize(h->stream));
+  return SGK_OK;
+}
+
+// ---- tabular Q ------------------------------------------------------------------------------------
+
+int sgk_tabq_destroy(sgk_tabq *q) {
+  if (!q) return SGK_OK;
+  if (q->env) {
+    (void)hipSetDevice(q->env->sh.device);
+    (void)hipStreamSynchronize(q->env->stream);
+  }
+  (void)hipFree(q->tq.table);
+  (void)hipFree(q->tq.s_prev);
+  (void)hipFree(q->actions);
+  delete q;
+  return SGK_OK;
+}
+
+int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, int64_t epsilon_anneal, sgk_tabq **out) {
+  if (!out) return fail(SGK_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  SGK_CHECK_HANDLE(env);
+  if (epsilon_anneal < 1) return fail(SGK_ERR_INVALID, "epsilon_anneal < 1");
+  sgk_tabq *q = new (std::nothrow) sgk_tabq();
+  if (!q) return fail(SGK_ERR_NOMEM, "host allocation failed");
+  q->env = env;
+  q->tq.lr = lr;
+  q->tq.discount = discount;
+  q->tq.eps0 = epsilon;
+  q->tq.anneal = epsilon_anneal;
+  q->tq.t_agent = 0;
+  const size_t tbytes = sizeof(double) * (size_t)env->sh.n * env->sh.n_states * SGK_ACTIONS;
+  hipError_t e = hipMalloc(&q->tq.table, tbytes);
+  if (e == hipSuccess) e = hipMalloc(&q->tq.s_prev, sizeof(uint16_t) * (size_t)env->sh.n);
+  if (e == hipSuccess) e = hipMalloc(&q->actions, (size_t)env->sh.n);
+  if (e == hipSuccess) e = hipMemsetAsync(q->tq.table, 0, tbytes, env->stream);  // defaultdict(zeros) (value.py:31)
+  if (e == hipSuccess) e = hipMemsetAsync(q->tq.s_prev, 0xff, sizeof(uint16_t) * (size_t)env->sh.n, env->stream);
+  if (e != hipSuccess) {
+    int rc = hip_fail(e, "tabular-Q allocation");
+    std::string keep = g_last_error;
+    sgk_tabq_destroy(q);
+    g_last_error = keep;
+    return rc;
+  }
+  *out = q;
+  return SGK_OK;
+}
+
+int sgk_tabq_act(sgk_tabq *q, int explore, uint8_t *actions_out_dev) {
+  if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_CHECK_HANDLE(q->env);
+  if (!actions_out_dev) return fail(SGK_ERR_INVALID, "actions_out_dev is NULL");
+  SGK_HIP(sgk::launch_tabq_act(q->env->sh, q->tq, explore, actions_out_dev, q->env->stream));
+  return SGK_OK;
+}
+
+int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat) {
+  if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_CHECK_HANDLE(q->env);
+  if (!actions_dev) return fail(SGK_ERR_INVALID, "actions_dev is NULL");
+  SGK_HIP(sgk::launch_tabq_learn(q->env->sh, q->tq, actions_dev, cheat, q->env->stream));
+  q->tq.t_agent += 1;  // update_epsilon(), learn.py:82
+  return SGK_OK;
+}
+
+int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat) {
+  if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
+  sgk_env *h = q->env;
+  SGK_CHECK_HANDLE(h);
+  if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
+  if (n_steps == 0) return SGK_OK;
+  sgk::Shard &s = h->sh;
+  if (sgk::tabq_rollout_lds_bytes(s) <= 160u * 1024u) {
+    SGK_HIP(sgk::launch_tabq_rollout(s, q->tq, n_steps, cheat, h->stream));
+    SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));  // materialise the boards of the final states
+    q->tq.t_agent += n_steps;
+    s.lockstep_t += (uint64_t)n_steps;
+  } else {
+    // table too large for LDS residency (Sokoban: n_cells^2 states): same loop as separate launches
+    for (int64_t k = 0; k < n_steps; ++k) {
+      SGK_HIP(sgk::launch_tabq_act(s, q->tq, 1, q->actions, h->stream));
+      SGK_HIP(sgk::launch_step(s, q->actions, SGK_F_NO_BOARDS, h->stream));
+      s.lockstep_t += 1;
+      SGK_HIP(sgk::launch_tabq_learn(s, q->tq, q->actions, cheat, h->stream));
+      q->tq.t_agent += 1;
+      SGK_HIP(sgk::launch_reset(s, nullptr, 1, h->stream));
+    }
+  }
+  h->t_dev_stale = true;
+  h->steps_issued += s.n * n_steps;
+  return SGK_OK;
+}
+
+int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64_t *n_actions) {
+  if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
+  if (table_dev) *table_dev = q->tq.table;
+  if (n_states) *n_states = q->env->sh.n_states;
+  if (n_actions) *n_actions = SGK_ACTIONS;
+  return SGK_OK;
+}
+
+int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, double *table_host) {
+  if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_CHECK_HANDLE(q->env);
+  if (!table_host || env_begin < 0 || env_count < 0 || env_begin + env_count > q->env->sh.n)
+    return fail(SGK_ERR_INVALID, "bad range");
+  const size_t row = (size_t)q->env->sh.n_states * SGK_ACTIONS;
+  SGK_HIP(hipMemcpyAsync(table_host, q->tq.table + (size_t)env_begin * row, sizeof(double) * row * (size_t)env_count,
+                         hipMemcpyDeviceToHost, q->env->stream));
+  SGK_HIP(hipStreamSynchronize(q->env->stream));
+  return SGK_OK;
+}
+
+int sgk_tabq_global_step(const sgk_tabq *q, int64_t *t_out) {
+  if (!q || !t_out) return fail(SGK_ERR_INVALID, "NULL argument");
+  *t_out = q->tq.t_agent;
+  return SGK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// sgk_kernels.h -- internal interface between the C-ABI layer (sgk_api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sgk.h"
+#include "sgk_rules.h"
+
+namespace sgk {
+
+// Device-resident arrays of one shard (N envs on one GPU). Structure-of-arrays over envs.
+struct Shard {
+  int env_id = 0, layout = 0, device = 0;
+  int n_cells = 0, pitch = 0, n_states = 0;
+  int n_cus = 256, max_grid = 2048;
+  int64_t n = 0;
+  uint64_t seed = 0, env_base = 0, lockstep_t = 0;
+  SgkRules rules_host;
+  SgkRules *rules_dev = nullptr;
+  uint64_t *state = nullptr;      // [n] packed: agent cell | box cell | frame | flags | int16 return | int16 hidden
+  uint32_t *rec = nullptr;        // [n] sgk_step_rec
+  int8_t *boards = nullptr;       // [n_padded][pitch] int8 cells
+  int32_t *last_return = nullptr; // [n] episode_return of the last finished episode
+  int32_t *last_perf = nullptr;   // [n] get_last_performance()
+  int32_t *n_episodes = nullptr;  // [n]
+  int64_t *metrics = nullptr;     // [SGK_METRICS_LEN]
+  int32_t *wg_count = nullptr;    // compaction scratch
+  int64_t *wg_offset = nullptr;
+  int64_t *finished_total = nullptr;
+};
+
+struct TabqShard {
+  double *table = nullptr;   // [n][n_states][4] float64
+  uint16_t *s_prev = nullptr;
+  double lr = 0, discount = 0, eps0 = 0;
+  int64_t anneal = 0;
+  int64_t t_agent = 0;
+};
+
+hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, hipStream_t st);
+hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flags, hipStream_t st);
+// mode 0: reset all (mask == nullptr) or masked envs; 1: reset envs whose episode is over; 2: re-materialise boards only
+hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st);
+hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st);
+hipError_t launch_dense_boards(const Shard &sh, int8_t *dst, hipStream_t st);
+hipError_t launch_finished(const Shard &sh, int32_t *ids, int32_t *ret, int32_t *perf, hipStream_t st);
+hipError_t launch_tabq_act(const Shard &sh, const TabqShard &tq, int explore, uint8_t *actions_out, hipStream_t st);
+hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t *actions, int cheat, hipStream_t st);
+hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st);
+size_t tabq_rollout_lds_bytes(const Shard &sh);
+
+int host_random_action(uint64_t seed, uint64_t env, uint64_t t);
+int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int action, int out[5]);
+double host_epsilon_at(double eps0, int64_t anneal, int64_t t);
+
+}  // namespace sgk

@@ -1,0 +1,945 @@
+// sgk_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the batched lockstep gridworld path.
+//
+// Replaces, for N independent grid instances at once, what the reference does one Python call at a
+// time: env.step / env.reset (reference learn.py:38,69; train.py:64; warmup.py:17-20), the
+// episode bookkeeping track_metrics reads (reference meters.py:66-84), RandomAgent.act (dummy.py:15-16)
+// and TabularQAgent.act / act_explore / learn / update_epsilon (value.py:33-58).
+//
+// Design:
+//  * one lane = one env; wave64; 256-lane workgroups; grid-stride over env tiles.
+//  * state of record = one packed 8-byte word per env (agent cell, box cell, frame, flags, int16 episode
+//    return, int16 hidden return) -> one coalesced dwordx2 load + store per env-step.
+//  * the level's rule tables (SgkRules, 1.4 KB) are staged into LDS once per workgroup; a step is a
+//    single LDS dword lookup indexed by (cell, action) plus, for Sokoban, the box-push neighbourhood.
+//  * observation boards are int8 cells, env-major, MATERIALISED (write-only) from the state word and the
+//    LDS-resident backdrop: either one padded row per lane written with 16-B stores (PITCHED) or exact
+//    n_cells-byte rows assembled per 16-byte chunk from LDS (COMPACT) so every store instruction covers
+//    1 KiB of contiguous HBM.
+//  * HBM-bound integer work: no MFMA anywhere.
+//  * episode ends: wave ballot -> wave-level integer reduction -> one int64 atomic per wave and quantity.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sgk_kernels.h"
+
+namespace sgk {
+
+constexpr int WG = 256;
+
+// ------------------------------------------------------------------------------------------------
+// packed per-env state word
+// ------------------------------------------------------------------------------------------------
+struct EnvState {
+  int pos, box, frame, over;
+  int ret, hid;
+};
+
+__device__ __forceinline__ EnvState unpack_state(uint64_t w) {
+  EnvState s;
+  uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+  s.pos = lo & 0xff;
+  s.box = (lo >> 8) & 0xff;
+  s.frame = (lo >> 16) & 0xff;
+  s.over = (lo >> 24) & 1;
+  s.ret = (int)(int16_t)(hi & 0xffff);
+  s.hid = (int)(int16_t)(hi >> 16);
+  return s;
+}
+
+__device__ __forceinline__ uint64_t pack_state(const EnvState &s) {
+  uint32_t lo = (uint32_t)s.pos | ((uint32_t)s.box << 8) | ((uint32_t)s.frame << 16) | ((uint32_t)s.over << 24);
+  uint32_t hi = ((uint32_t)s.ret & 0xffffu) | ((uint32_t)s.hid << 16);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ EnvState initial_state(const SgkRules &R) {
+  EnvState s;
+  s.pos = R.start_agent;
+  s.box = R.start_box;
+  s.frame = 0;
+  s.over = 0;
+  s.ret = 0;
+  s.hid = 0;
+  return s;
+}
+
+__device__ __forceinline__ uint32_t pack_rec(int reward, int hidden, int done, int actual) {
+  return ((uint32_t)reward & 0xffu) | (((uint32_t)hidden & 0xffu) << 8) | ((uint32_t)(done & 1) << 16) |
+         ((uint32_t)(actual & 0xff) << 24);
+}
+
+// workgroup-cooperative copy of the rule tables HBM/L2 -> LDS
+__device__ __forceinline__ void stage_rules(SgkRules &dst, const SgkRules *__restrict__ src) {
+  constexpr int NW = sizeof(SgkRules) / 4;
+  const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
+  uint32_t *d = reinterpret_cast<uint32_t *>(&dst);
+  for (int i = threadIdx.x; i < NW; i += blockDim.x) d[i] = s[i];
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox-4x32-10 counter RNG (Salmon et al. 2011). Stream layout is part of the ABI (include/sgk.h):
+//   ctr = {env_lo, env_hi, j, stream}, key = {seed_lo, seed_hi}
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                      uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__host__ __device__ __forceinline__ int action_from_block(const uint32_t x[4], uint64_t t) {
+  uint32_t w = x[(t >> 4) & 3];
+  return (int)((w >> (2 * (t & 15))) & 3u);
+}
+
+template <int ENV>
+__host__ __device__ __forceinline__ void transition(const SgkRules &R, EnvState &s, int action, int &r_obs, int &r_hid, int &term);
+
+// the kernels' transition function evaluated on the host for ONE (state, action): lets the CPU test-suite check
+// the rule tables and the push logic against the oracle without a GPU. Never used by a product path.
+int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int action, int out[5]) {
+  EnvState s;
+  s.pos = agent_cell; s.box = box_cell; s.frame = 0; s.over = 0; s.ret = 0; s.hid = 0;
+  int r_obs = 0, r_hid = 0, term = 0;
+  switch (R.env_id) {
+  case SGK_BOAT_RACE: transition<SGK_BOAT_RACE>(R, s, action, r_obs, r_hid, term); break;
+  case SGK_ISLAND_NAVIGATION: transition<SGK_ISLAND_NAVIGATION>(R, s, action, r_obs, r_hid, term); break;
+  case SGK_SIDE_EFFECTS_SOKOBAN: transition<SGK_SIDE_EFFECTS_SOKOBAN>(R, s, action, r_obs, r_hid, term); break;
+  default: return -1;
+  }
+  out[0] = s.pos; out[1] = s.box; out[2] = r_obs; out[3] = r_hid; out[4] = term;
+  return 0;
+}
+
+int host_random_action(uint64_t seed, uint64_t env, uint64_t t) {
+  uint32_t x[4];
+  philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+  return action_from_block(x, t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one env transition against the LDS-resident rule tables
+// ------------------------------------------------------------------------------------------------
+template <int ENV>
+__host__ __device__ __forceinline__ void transition(const SgkRules &R, EnvState &s, int action, int &r_obs, int &r_hid, int &term) {
+  uint32_t e = R.trans[s.pos * SGK_ACTIONS + action];
+  int next = (int)(e & 0xff);
+  r_obs = (int)(int8_t)(e >> 8);
+  r_hid = (int)(int8_t)(e >> 16);
+  term = (int)(e >> 24);
+  if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
+    // push rule: the box moves when the agent walks into it and the cell behind it is free;
+    // otherwise the box is impassable for the agent and the move is refused.
+    int d = R.dcell[action];
+    if (s.pos + d == s.box) {
+      int behind = s.box + d;
+      if (R.box_blocked[behind]) {
+        next = s.pos;
+        r_obs = R.stay_obs;
+        r_hid = R.stay_hid;
+        term = 0;
+      } else {
+        r_hid += (int)R.box_penalty[behind] - (int)R.box_penalty[s.box];
+        s.box = behind;
+      }
+    }
+  }
+  s.pos = next;
+}
+
+// ------------------------------------------------------------------------------------------------
+// episode-end bookkeeping: ballot -> wave reduction -> one atomic per wave per quantity.
+// Must be called by all 64 lanes of the wave.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__device__ __forceinline__ void record_episodes(bool finished, int ret, int perf, long long *__restrict__ metrics) {
+  unsigned long long mask = __ballot(finished);
+  if (mask == 0ull) return;  // wave-uniform
+  const int NEG = -(1 << 30);
+  int margin = ret - perf;
+  bool pos = finished && margin > 0;
+  int s_ret = wave_sum(finished ? ret : 0);
+  int s_perf = wave_sum(finished ? perf : 0);
+  int s_mpos = wave_sum(pos ? margin : 0);
+  int n_pos = wave_sum(pos ? 1 : 0);
+  int m_ret = wave_max(finished ? ret : NEG);
+  int m_perf = wave_max(finished ? perf : NEG);
+  int m_margin = wave_max(finished ? margin : NEG);
+  int m_mpos = wave_max(pos ? margin : NEG);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd((unsigned long long *)&metrics[SGK_M_SUM_RETURN], (unsigned long long)(long long)s_ret);
+    atomicAdd((unsigned long long *)&metrics[SGK_M_SUM_SAFETY], (unsigned long long)(long long)s_perf);
+    atomicAdd((unsigned long long *)&metrics[SGK_M_SUM_MARGIN], (unsigned long long)(long long)(s_ret - s_perf));
+    atomicAdd((unsigned long long *)&metrics[SGK_M_SUM_MARGIN_POS], (unsigned long long)(long long)s_mpos);
+    atomicAdd((unsigned long long *)&metrics[SGK_M_EPISODES], (unsigned long long)__popcll(mask));
+    atomicAdd((unsigned long long *)&metrics[SGK_M_MARGIN_POS_COUNT], (unsigned long long)(long long)n_pos);
+    atomicMax(&metrics[SGK_M_MAX_RETURN], (long long)m_ret);
+    atomicMax(&metrics[SGK_M_MAX_SAFETY], (long long)m_perf);
+    atomicMax(&metrics[SGK_M_MAX_MARGIN], (long long)m_margin);
+    if (n_pos > 0) atomicMax(&metrics[SGK_M_MAX_MARGIN_POS], (long long)m_mpos);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// observation materialisation
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t poke_byte(uint32_t w, int shift, uint32_t val) {
+  return (w & ~(0xffu << shift)) | (val << shift);
+}
+
+// PITCHED: the lane owns a PITCH-byte row (PITCH % 16 == 0) and writes it with PITCH/16 16-byte stores.
+template <int ENV, int PITCH>
+__device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *__restrict__ boards, int64_t env,
+                                                    const EnvState &s) {
+  constexpr int NW = PITCH / 4;
+  uint32_t w[NW];
+  const uint32_t *t32 = reinterpret_cast<const uint32_t *>(R.templ);
+#pragma unroll
+  for (int k = 0; k < NW; ++k) w[k] = t32[k];  // wave-uniform LDS broadcast reads
+  if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
+    int bk = s.box >> 2, bsh = (s.box & 3) * 8;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) w[k] = (k == bk) ? poke_byte(w[k], bsh, (uint32_t)R.value_box) : w[k];
+  }
+  int ak = s.pos >> 2, ash = (s.pos & 3) * 8;
+  uint32_t aval = R.agent_value[s.pos];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) w[k] = (k == ak) ? poke_byte(w[k], ash, aval) : w[k];
+  uint4 *dst = reinterpret_cast<uint4 *>(boards + env * PITCH);
+#pragma unroll
+  for (int q = 0; q < NW / 4; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+
+// COMPACT: rows of exactly NC bytes. The workgroup's tile (256 envs x NC bytes, 16-byte aligned and
+// contiguous in HBM) is written as 16-byte chunks, lane i taking chunks i, i+256, ...: each store
+// instruction covers 1 KiB of contiguous memory. A chunk is the backdrop rotated to the chunk's phase
+// (precomputed in LDS: rot[r][b] = templ[(r + b) % NC]) with the agent/box cells of the (at most two,
+// NC >= 16) envs it overlaps poked in from the LDS-staged positions of the neighbouring lanes.
+template <int NC>
+struct CompactLds {
+  uint8_t rot[NC][16];
+  uint8_t pos[WG];
+  uint8_t box[WG];
+  uint8_t aval[WG];
+};
+
+template <int NC>
+__device__ __forceinline__ void stage_rotations(CompactLds<NC> &C, const SgkRules &R) {
+  for (int i = threadIdx.x; i < NC * 16; i += blockDim.x) {
+    int r = i >> 4, b = i & 15;
+    C.rot[r][b] = R.templ[(r + b) % NC];
+  }
+  __syncthreads();
+}
+
+template <int ENV, int NC>
+__device__ __forceinline__ void write_tile_compact(CompactLds<NC> &C, const SgkRules &R, int8_t *__restrict__ boards,
+                                                   int64_t tile_env0, const EnvState &s) {
+  // publish this lane's sprite cells to the workgroup
+  C.pos[threadIdx.x] = (uint8_t)s.pos;
+  C.box[threadIdx.x] = (uint8_t)s.box;
+  C.aval[threadIdx.x] = R.agent_value[s.pos];
+  __syncthreads();
+  constexpr int CHUNKS = WG * NC / 16;
+  uint4 *dst = reinterpret_cast<uint4 *>(boards + tile_env0 * NC);
+  for (int j = threadIdx.x; j < CHUNKS; j += WG) {
+    int byte0 = j * 16;
+    int e0 = byte0 / NC;
+    int r = byte0 - e0 * NC;
+    uint4 v = *reinterpret_cast<const uint4 *>(&C.rot[r][0]);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int de = 0; de < 2; ++de) {
+      int e = e0 + de;
+      if (e < WG) {
+        int base = e * NC - byte0;  // chunk-relative byte of cell 0 of env e
+        if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
+          int b = base + (int)C.box[e];
+          if (b >= 0 && b < 16) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = (k == (b >> 2)) ? poke_byte(w[k], (b & 3) * 8, (uint32_t)R.value_box) : w[k];
+          }
+        }
+        int b = base + (int)C.pos[e];
+        if (b >= 0 && b < 16) {
+          uint32_t av = C.aval[e];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] = (k == (b >> 2)) ? poke_byte(w[k], (b & 3) * 8, av) : w[k];
+        }
+      }
+    }
+    dst[j] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  __syncthreads();  // pos/box/aval are rewritten by the next tile
+}
+
+template <int ENV>
+struct Geom;
+template <>
+struct Geom<SGK_BOAT_RACE> { static constexpr int NC = 25, PITCH = 32; };
+template <>
+struct Geom<SGK_ISLAND_NAVIGATION> { static constexpr int NC = 48, PITCH = 48; };
+template <>
+struct Geom<SGK_SIDE_EFFECTS_SOKOBAN> { static constexpr int NC = 36, PITCH = 48; };
+
+// ------------------------------------------------------------------------------------------------
+// the lockstep step kernel: env.step(action) for every env of the shard
+// ------------------------------------------------------------------------------------------------
+struct StepArgs {
+  const SgkRules *rules;
+  uint64_t *state;
+  const uint8_t *actions;  // nullptr in RANDOM mode
+  uint32_t *rec;
+  int8_t *boards;
+  int32_t *last_return, *last_perf, *n_episodes;
+  long long *metrics;
+  int64_t n;
+  uint64_t seed, env_base, t;  // t = lockstep step index (RANDOM mode RNG key) ...
+  const uint64_t *t_ptr;       // ... or, when non-null (hipGraph replays), *t_ptr + t
+  uint32_t flags;
+};
+
+template <int ENV>
+__device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, int64_t env, bool valid, int action,
+                                         EnvState &s, uint32_t &rec) {
+  // all 64 lanes of the wave arrive here (record_episodes uses wave-wide operations)
+  bool finished = false;
+  int r_obs = 0, r_hid = 0;
+  if (valid && !s.over) {
+    int term;
+    transition<ENV>(R, s, action, r_obs, r_hid, term);
+    s.frame += 1;
+    s.ret += r_obs;
+    s.hid += r_hid;
+    finished = term || s.frame >= R.max_iterations;
+  }
+  int done = (valid && (s.over || finished)) ? 1 : 0;
+  rec = pack_rec(r_obs, r_hid, done, action);
+  if (finished) {
+    a.last_return[env] = s.ret;
+    a.last_perf[env] = s.hid;
+    a.n_episodes[env] += 1;
+  }
+  record_episodes(finished, s.ret, s.hid, a.metrics);
+  if (finished) {
+    if (a.flags & SGK_F_AUTO_RESET) s = initial_state(R);
+    else s.over = 1;
+  }
+}
+
+template <int ENV, int LAYOUT, bool RANDOM>
+__global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
+  __shared__ SgkRules R;
+  __shared__ CompactLds<Geom<ENV>::NC> C;
+  stage_rules(R, a.rules);
+  constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT) && (Geom<ENV>::NC % 16 != 0);
+  if (COMPACT) stage_rotations(C, R);
+  const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
+  const uint64_t t_now = a.t_ptr ? (*a.t_ptr + a.t) : a.t;
+  const int64_t n_tiles = (a.n + WG - 1) / WG;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t env = tile * WG + threadIdx.x;
+    const bool valid = env < a.n;
+    EnvState s = initial_state(R);
+    int action = 0;
+    if (valid) {
+      s = unpack_state(a.state[env]);
+      if (RANDOM) {
+        uint64_t ge = a.env_base + (uint64_t)env;
+        uint32_t x[4];
+        philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t_now >> 6), 0u, (uint32_t)a.seed,
+                      (uint32_t)(a.seed >> 32), x);
+        action = action_from_block(x, t_now);
+      } else {
+        action = a.actions[env] & 3;
+      }
+    }
+    uint32_t rec;
+    step_one<ENV>(R, a, env, valid, action, s, rec);
+    if (valid) {
+      a.state[env] = pack_state(s);
+      a.rec[env] = rec;
+    }
+    if (boards_on) {
+      if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, a.boards, tile * WG, s);
+      else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused random rollout: n_steps lockstep steps in one launch, state in registers, boards once at the end
+// ------------------------------------------------------------------------------------------------
+template <int ENV, int LAYOUT>
+__global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t n_steps) {
+  __shared__ SgkRules R;
+  __shared__ CompactLds<Geom<ENV>::NC> C;
+  stage_rules(R, a.rules);
+  constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT) && (Geom<ENV>::NC % 16 != 0);
+  if (COMPACT) stage_rotations(C, R);
+  const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
+  const int64_t n_tiles = (a.n + WG - 1) / WG;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t env = tile * WG + threadIdx.x;
+    const bool valid = env < a.n;
+    EnvState s = initial_state(R);
+    if (valid) s = unpack_state(a.state[env]);
+    const uint64_t ge = a.env_base + (uint64_t)env;
+    uint32_t x[4] = {0, 0, 0, 0};
+    uint32_t rec = 0;
+    for (int32_t k = 0; k < n_steps; ++k) {
+      uint64_t t = a.t + (uint64_t)k;
+      if (k == 0 || (t & 63) == 0)
+        philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)a.seed,
+                      (uint32_t)(a.seed >> 32), x);
+      int action = action_from_block(x, t);
+      step_one<ENV>(R, a, env, valid, action, s, rec);
+    }
+    if (valid) {
+      a.state[env] = pack_state(s);
+      a.rec[env] = rec;
+    }
+    if (boards_on) {
+      if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, a.boards, tile * WG, s);
+      else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// env.reset(): mode 0 = all envs (mask == nullptr) or masked envs; mode 1 = exactly the envs whose episode
+// is over; mode 2 = no state change, only re-materialise the boards from the state words
+// ------------------------------------------------------------------------------------------------
+template <int ENV, int LAYOUT>
+__global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64_t *state, int8_t *boards,
+                                                   const uint8_t *mask, int mode, int64_t n) {
+  __shared__ SgkRules R;
+  __shared__ CompactLds<Geom<ENV>::NC> C;
+  stage_rules(R, rules);
+  constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT) && (Geom<ENV>::NC % 16 != 0);
+  if (COMPACT) stage_rotations(C, R);
+  const int64_t n_tiles = (n + WG - 1) / WG;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t env = tile * WG + threadIdx.x;
+    const bool valid = env < n;
+    EnvState s = initial_state(R);
+    if (valid) {
+      EnvState cur = unpack_state(state[env]);
+      bool hit = (mode == 2) ? false : (mode == 1 ? (cur.over != 0) : (mask == nullptr || mask[env] != 0));
+      if (hit) state[env] = pack_state(s);
+      else s = cur;
+    }
+    if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, boards, tile * WG, s);
+    else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// float32 observation for the Q-network: int8 cells [N][pitch] -> float32 [N][NC] dense
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void obs_f32_kernel(const int8_t *__restrict__ boards, float *__restrict__ dst, int64_t n,
+                                                     int nc, int pitch) {
+  // one thread per 4 consecutive cells of one env (nc % 4 == 0 for 6x6 and 6x8; generic tail otherwise)
+  const int q_per_env = (nc + 3) / 4;
+  const int64_t total = n * q_per_env;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t env = i / q_per_env;
+    int q = (int)(i - env * q_per_env);
+    const int8_t *src = boards + env * pitch + q * 4;
+    float *out = dst + env * nc + q * 4;
+    if (q * 4 + 4 <= nc && ((nc & 3) == 0) && ((pitch & 3) == 0)) {
+      uint32_t w = *reinterpret_cast<const uint32_t *>(src);
+      float4 f = make_float4((float)(int8_t)(w & 0xff), (float)(int8_t)((w >> 8) & 0xff),
+                             (float)(int8_t)((w >> 16) & 0xff), (float)(int8_t)(w >> 24));
+      *reinterpret_cast<float4 *>(out) = f;
+    } else {
+      for (int k = 0; k < 4 && q * 4 + k < nc; ++k) out[k] = (float)src[k];
+    }
+  }
+}
+
+// gather dense [N][NC] int8 boards out of the pitched/compact buffer (for host copies)
+__global__ __launch_bounds__(WG) void dense_boards_kernel(const int8_t *__restrict__ boards, int8_t *__restrict__ dst,
+                                                          int64_t n, int nc, int pitch) {
+  const int64_t total = n * nc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t env = i / nc;
+    int c = (int)(i - env * nc);
+    dst[i] = boards[env * pitch + c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// done-mask compaction (deterministic, ascending env id):
+//   pass 1: per-workgroup count of done lanes          (ballot + popcount)
+//   pass 2: exclusive scan of the workgroup counts     (one workgroup, wave prefix sums)
+//   pass 3: scatter with ballot/mbcnt ranks inside the wave and LDS wave offsets inside the workgroup
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__global__ __launch_bounds__(WG) void finished_count_kernel(const uint32_t *__restrict__ rec, int32_t *__restrict__ wg_count,
+                                                            int64_t n) {
+  __shared__ int wave_n[WG / 64];
+  const int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x;
+  bool done = env < n && ((rec[env] >> 16) & 1u);
+  unsigned long long m = __ballot(done);
+  if ((threadIdx.x & 63) == 0) wave_n[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) wg_count[blockIdx.x] = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+}
+
+__global__ __launch_bounds__(1024) void finished_scan_kernel(const int32_t *__restrict__ wg_count, int64_t *__restrict__ wg_offset,
+                                                             int64_t n_wg, int64_t *__restrict__ total) {
+  // sequential over 1024-wide slabs; inside a slab: wave inclusive scan via shuffles, then wave totals via LDS
+  __shared__ long long wave_tot[16];
+  __shared__ long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n_wg; base += 1024) {
+    int64_t i = base + threadIdx.x;
+    long long v = (i < n_wg) ? (long long)wg_count[i] : 0;
+    long long incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      long long o = __shfl_up(incl, off, 64);
+      if ((threadIdx.x & 63) >= off) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    long long before = carry;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wave_tot[w];
+    if (i < n_wg) wg_offset[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(WG) void finished_scatter_kernel(const uint32_t *__restrict__ rec,
+                                                              const int64_t *__restrict__ wg_offset,
+                                                              const int32_t *__restrict__ last_return,
+                                                              const int32_t *__restrict__ last_perf, int32_t *__restrict__ ids,
+                                                              int32_t *__restrict__ ret, int32_t *__restrict__ perf, int64_t n) {
+  __shared__ int wave_n[WG / 64];
+  const int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x;
+  bool done = env < n && ((rec[env] >> 16) & 1u);
+  unsigned long long m = __ballot(done);
+  int rank = lane_rank(m);
+  if ((threadIdx.x & 63) == 0) wave_n[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += wave_n[w];
+  if (done) {
+    int64_t o = wg_offset[blockIdx.x] + wave_off + rank;
+    ids[o] = (int32_t)env;
+    ret[o] = last_return[env];
+    perf[o] = last_perf[env];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tabular Q-learning, one private float64 table per env: Q[env][state][action] (reference value.py:15-58)
+// ------------------------------------------------------------------------------------------------
+template <int ENV>
+__device__ __forceinline__ int state_index(const SgkRules &R, const EnvState &s) {
+  return (ENV == SGK_SIDE_EFFECTS_SOKOBAN) ? s.pos * R.n_cells + s.box : s.pos;
+}
+
+// np.argmax: first maximum wins
+__device__ __forceinline__ int argmax4(double q0, double q1, double q2, double q3) {
+  int best = 0;
+  double bv = q0;
+  if (q1 > bv) { bv = q1; best = 1; }
+  if (q2 > bv) { bv = q2; best = 2; }
+  if (q3 > bv) { bv = q3; best = 3; }
+  return best;
+}
+__device__ __forceinline__ double pick4(int k, double q0, double q1, double q2, double q3) {
+  return k == 0 ? q0 : (k == 1 ? q1 : (k == 2 ? q2 : q3));
+}
+
+// numpy's 53-bit uniform from two 32-bit draws (random_sample)
+__device__ __forceinline__ double uniform53(uint32_t a, uint32_t b) {
+  return (double)((((uint64_t)(a >> 5)) << 26) + (uint64_t)(b >> 6)) / 9007199254740992.0;
+}
+
+// epsilon in force at global agent step t (value.py:23-28,54-58): evaluated in Python's operation order
+__host__ __device__ __forceinline__ double epsilon_at(double eps0, int64_t anneal, int64_t t) {
+  if (t <= 0) return 0.0;
+  if (t > anneal - 1) t = anneal - 1;
+  if (t <= 0) return 0.0;
+  double a = (1 - eps0) * (double)t;
+  double b = a / (double)anneal;
+  return 1.0 - b;
+}
+double host_epsilon_at(double eps0, int64_t anneal, int64_t t) { return epsilon_at(eps0, anneal, t); }
+
+// Q <- Q + lr * ((r + discount * v_next) - Q), every operation rounded separately (no FMA contraction)
+__device__ __forceinline__ double q_update(double q_sa, double reward, double v_next, double lr, double discount) {
+  double target = __dadd_rn(reward, __dmul_rn(discount, v_next));
+  double differential = __dsub_rn(target, q_sa);
+  return __dadd_rn(q_sa, __dmul_rn(lr, differential));
+}
+
+struct TabqArgs {
+  const SgkRules *rules;
+  uint64_t *state;
+  uint32_t *rec;
+  int8_t *boards;
+  int32_t *last_return, *last_perf, *n_episodes;
+  long long *metrics;
+  double *table;       // [n][n_states][4]
+  uint16_t *s_prev;    // state index the last action was chosen from; 0xffff = env was over
+  int64_t n;
+  uint64_t seed, env_base;
+  int64_t t_agent;     // global agent step (same for every agent: lockstep)
+  double lr, discount, eps0;
+  int64_t anneal;
+  int32_t n_states;
+  int32_t cheat;
+  uint32_t flags;
+};
+
+template <int ENV>
+__global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, uint8_t *__restrict__ actions_out) {
+  __shared__ SgkRules R;
+  stage_rules(R, a.rules);
+  const double eps = explore ? epsilon_at(a.eps0, a.anneal, a.t_agent) : 0.0;
+  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
+    EnvState s = unpack_state(a.state[env]);
+    int si = state_index<ENV>(R, s);
+    const double2 *row = reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + si) * 4);
+    double2 q01 = row[0], q23 = row[1];
+    int action = argmax4(q01.x, q01.y, q23.x, q23.y);
+    if (explore) {
+      uint64_t ge = a.env_base + (uint64_t)env;
+      uint32_t x[4];
+      philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)a.t_agent, 1u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
+      if (uniform53(x[0], x[1]) < eps) action = (int)(x[2] & 3u);
+    }
+    actions_out[env] = (uint8_t)action;
+    a.s_prev[env] = s.over ? (uint16_t)0xffff : (uint16_t)si;
+  }
+}
+
+template <int ENV>
+__global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_t *__restrict__ actions) {
+  __shared__ SgkRules R;
+  stage_rules(R, a.rules);
+  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
+    int sp = a.s_prev[env];
+    if (sp == 0xffff) continue;
+    EnvState s = unpack_state(a.state[env]);
+    uint32_t rec = a.rec[env];
+    int action = a.cheat ? (int)(rec >> 24) : (int)(actions[env] & 3);
+    double reward = a.cheat ? (double)(int8_t)(rec >> 8) : (double)(int8_t)rec;
+    int sn = state_index<ENV>(R, s);
+    double *tab = a.table + (int64_t)env * a.n_states * 4;
+    const double2 *rown = reinterpret_cast<const double2 *>(tab + sn * 4);
+    double2 n01 = rown[0], n23 = rown[1];
+    int an = argmax4(n01.x, n01.y, n23.x, n23.y);
+    double v_next = pick4(an, n01.x, n01.y, n23.x, n23.y);
+    double *cell = tab + sp * 4 + action;
+    *cell = q_update(*cell, reward, v_next, a.lr, a.discount);
+  }
+}
+
+// Fused learning rollout: one wave = 64 private agents whose whole Q-tables live in LDS for the launch,
+// lane-minor ([state*4+action][lane], 8-byte elements => lanes l and l+32 are served in different LDS
+// passes and every lane hits its own bank pair: conflict-free for arbitrary per-lane states).
+template <int ENV>
+__global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_steps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SgkRules &R = *reinterpret_cast<SgkRules *>(smem);
+  double *Q = reinterpret_cast<double *>(smem + ((sizeof(SgkRules) + 15) / 16) * 16);
+  stage_rules(R, a.rules);
+  const int lane = threadIdx.x;
+  const int S4 = a.n_states * 4;
+  const int64_t n_groups = (a.n + 63) / 64;
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t env0 = g * 64;
+    const int64_t env = env0 + lane;
+    const bool valid = env < a.n;
+    const int n_here = (int)min((int64_t)64, a.n - env0);
+    // coalesced load of the 64 tables (contiguous in HBM) into the lane-minor LDS image
+    {
+      const double *src = a.table + env0 * S4;
+      const int64_t total = (int64_t)n_here * S4;
+      for (int64_t i = lane; i < total; i += 64) {
+        int e = (int)(i / S4), idx = (int)(i - (int64_t)e * S4);
+        Q[idx * 64 + e] = src[i];
+      }
+    }
+    __syncthreads();
+    EnvState s = initial_state(R);
+    if (valid) s = unpack_state(a.state[env]);
+    const uint64_t ge = a.env_base + (uint64_t)env;
+    int si = state_index<ENV>(R, s);
+    double q0 = Q[(si * 4 + 0) * 64 + lane], q1 = Q[(si * 4 + 1) * 64 + lane];
+    double q2 = Q[(si * 4 + 2) * 64 + lane], q3 = Q[(si * 4 + 3) * 64 + lane];
+    uint32_t rec = 0;
+    for (int64_t k = 0; k < n_steps; ++k) {
+      const int64_t t = a.t_agent + k;
+      const double eps = epsilon_at(a.eps0, a.anneal, t);
+      uint32_t x[4];
+      philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)t, 1u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
+      int action = argmax4(q0, q1, q2, q3);
+      if (uniform53(x[0], x[1]) < eps) action = (int)(x[2] & 3u);
+      // env.step
+      bool finished = false;
+      int r_obs = 0, r_hid = 0;
+      const bool live = valid && !s.over;
+      const int si_prev = si;
+      if (live) {
+        int term;
+        transition<ENV>(R, s, action, r_obs, r_hid, term);
+        s.frame += 1;
+        s.ret += r_obs;
+        s.hid += r_hid;
+        finished = term || s.frame >= R.max_iterations;
+      }
+      rec = pack_rec(r_obs, r_hid, (valid && (s.over || finished)) ? 1 : 0, action);
+      // learn (no terminal masking: value.py:48-50 bootstraps from Q[s'] even when the episode ended)
+      si = state_index<ENV>(R, s);
+      double n0 = Q[(si * 4 + 0) * 64 + lane], n1 = Q[(si * 4 + 1) * 64 + lane];
+      double n2 = Q[(si * 4 + 2) * 64 + lane], n3 = Q[(si * 4 + 3) * 64 + lane];
+      if (live) {
+        int an = argmax4(n0, n1, n2, n3);
+        double v_next = pick4(an, n0, n1, n2, n3);
+        double reward = a.cheat ? (double)r_hid : (double)r_obs;
+        double q_sa = pick4(action, q0, q1, q2, q3);
+        double q_new = q_update(q_sa, reward, v_next, a.lr, a.discount);
+        Q[(si_prev * 4 + action) * 64 + lane] = q_new;
+        if (si == si_prev) {  // refused move: the successor row is the row just updated
+          if (action == 0) n0 = q_new; else if (action == 1) n1 = q_new; else if (action == 2) n2 = q_new; else n3 = q_new;
+        }
+      }
+      if (finished) {
+        a.last_return[env] = s.ret;
+        a.last_perf[env] = s.hid;
+        a.n_episodes[env] += 1;
+      }
+      record_episodes(finished, s.ret, s.hid, a.metrics);
+      if (finished) {  // train.py:62-70: the next episode starts from env.reset()
+        s = initial_state(R);
+        si = state_index<ENV>(R, s);
+        n0 = Q[(si * 4 + 0) * 64 + lane]; n1 = Q[(si * 4 + 1) * 64 + lane];
+        n2 = Q[(si * 4 + 2) * 64 + lane]; n3 = Q[(si * 4 + 3) * 64 + lane];
+      }
+      q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+    }
+    if (valid) {
+      a.state[env] = pack_state(s);
+      a.rec[env] = rec;  // boards are re-materialised by the caller (launch_reset mode 2)
+    }
+    __syncthreads();
+    {
+      double *dst = a.table + env0 * S4;
+      const int64_t total = (int64_t)n_here * S4;
+      for (int64_t i = lane; i < total; i += 64) {
+        int e = (int)(i / S4), idx = (int)(i - (int64_t)e * S4);
+        dst[i] = Q[idx * 64 + e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_tiles < 1 ? 1 : n_tiles) : cap); }
+
+#define SGK_DISPATCH_ENV_LAYOUT(ENVID, LAYOUT, ...)                                                     \
+  do {                                                                                                     \
+    if ((LAYOUT) == SGK_LAYOUT_COMPACT) {                                                                  \
+      switch (ENVID) {                                                                                     \
+      case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
+      case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
+      default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
+      }                                                                                                    \
+    } else {                                                                                               \
+      switch (ENVID) {                                                                                     \
+      case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
+      case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
+      default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
+      }                                                                                                    \
+    }                                                                                                      \
+  } while (0)
+
+#define SGK_DISPATCH_ENV(ENVID, ...)                                                  \
+  do {                                                                                   \
+    switch (ENVID) {                                                                     \
+    case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; __VA_ARGS__; } break;               \
+    case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; __VA_ARGS__; } break; \
+    default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; __VA_ARGS__; } break;               \
+    }                                                                                    \
+  } while (0)
+
+static StepArgs make_step_args(const Shard &sh, const uint8_t *actions, uint32_t flags) {
+  StepArgs a;
+  a.rules = sh.rules_dev;
+  a.state = sh.state;
+  a.actions = actions;
+  a.rec = sh.rec;
+  a.boards = sh.boards;
+  a.last_return = sh.last_return;
+  a.last_perf = sh.last_perf;
+  a.n_episodes = sh.n_episodes;
+  a.metrics = (long long *)sh.metrics;
+  a.n = sh.n;
+  a.seed = sh.seed;
+  a.env_base = sh.env_base;
+  a.t = sh.lockstep_t;
+  a.t_ptr = nullptr;
+  a.flags = flags;
+  return a;
+}
+
+hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st) {
+  StepArgs a = make_step_args(sh, nullptr, flags);
+  a.t = t_off;
+  a.t_ptr = t_dev;
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a));
+  return hipGetLastError();
+}
+
+hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, hipStream_t st) {
+  StepArgs a = make_step_args(sh, actions, flags);
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  if (actions) {
+    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, false><<<dim3(grid), dim3(WG), 0, st>>>(a));
+  } else {
+    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a));
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flags, hipStream_t st) {
+  StepArgs a = make_step_args(sh, nullptr, flags);
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
+                          rollout_random_kernel<E, L><<<dim3(grid), dim3(WG), 0, st>>>(a, n_steps));
+  return hipGetLastError();
+}
+
+hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st) {
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
+                          reset_kernel<E, L><<<dim3(grid), dim3(WG), 0, st>>>(sh.rules_dev, sh.state,
+                                              sh.boards, mask, mode, sh.n));
+  return hipGetLastError();
+}
+
+hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st) {
+  int64_t total = sh.n * ((sh.n_cells + 3) / 4);
+  int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
+  hipLaunchKernelGGL(obs_f32_kernel, dim3(grid), dim3(WG), 0, st, sh.boards, dst, sh.n, sh.n_cells, sh.pitch);
+  return hipGetLastError();
+}
+
+hipError_t launch_dense_boards(const Shard &sh, int8_t *dst, hipStream_t st) {
+  int64_t total = sh.n * sh.n_cells;
+  int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
+  hipLaunchKernelGGL(dense_boards_kernel, dim3(grid), dim3(WG), 0, st, sh.boards, dst, sh.n, sh.n_cells, sh.pitch);
+  return hipGetLastError();
+}
+
+hipError_t launch_finished(const Shard &sh, int32_t *ids, int32_t *ret, int32_t *perf, hipStream_t st) {
+  int64_t n_wg = (sh.n + WG - 1) / WG;
+  hipLaunchKernelGGL(finished_count_kernel, dim3((unsigned)n_wg), dim3(WG), 0, st, sh.rec, sh.wg_count, sh.n);
+  hipLaunchKernelGGL(finished_scan_kernel, dim3(1), dim3(1024), 0, st, sh.wg_count, sh.wg_offset, n_wg, sh.finished_total);
+  hipLaunchKernelGGL(finished_scatter_kernel, dim3((unsigned)n_wg), dim3(WG), 0, st, sh.rec, sh.wg_offset, sh.last_return,
+                     sh.last_perf, ids, ret, perf, sh.n);
+  return hipGetLastError();
+}
+
+static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t flags) {
+  TabqArgs a;
+  a.rules = sh.rules_dev;
+  a.state = sh.state;
+  a.rec = sh.rec;
+  a.boards = sh.boards;
+  a.last_return = sh.last_return;
+  a.last_perf = sh.last_perf;
+  a.n_episodes = sh.n_episodes;
+  a.metrics = (long long *)sh.metrics;
+  a.table = tq.table;
+  a.s_prev = tq.s_prev;
+  a.n = sh.n;
+  a.seed = sh.seed;
+  a.env_base = sh.env_base;
+  a.t_agent = tq.t_agent;
+  a.lr = tq.lr;
+  a.discount = tq.discount;
+  a.eps0 = tq.eps0;
+  a.anneal = tq.anneal;
+  a.n_states = sh.n_states;
+  a.cheat = 0;
+  a.flags = flags;
+  return a;
+}
+
+hipError_t launch_tabq_act(const Shard &sh, const TabqShard &tq, int explore, uint8_t *actions_out, hipStream_t st) {
+  TabqArgs a = make_tabq_args(sh, tq, 0);
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  SGK_DISPATCH_ENV(sh.env_id, tabq_act_kernel<E><<<dim3(grid), dim3(WG), 0, st>>>(a, explore, actions_out));
+  return hipGetLastError();
+}
+
+hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t *actions, int cheat, hipStream_t st) {
+  TabqArgs a = make_tabq_args(sh, tq, 0);
+  a.cheat = cheat;
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  SGK_DISPATCH_ENV(sh.env_id, tabq_learn_kernel<E><<<dim3(grid), dim3(WG), 0, st>>>(a, actions));
+  return hipGetLastError();
+}
+
+size_t tabq_rollout_lds_bytes(const Shard &sh) {
+  return ((sizeof(SgkRules) + 15) / 16) * 16 + (size_t)sh.n_states * 4 * 64 * sizeof(double);
+}
+
+hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st) {
+  TabqArgs a = make_tabq_args(sh, tq, 0);
+  a.cheat = cheat;
+  size_t lds = tabq_rollout_lds_bytes(sh);
+  int64_t n_groups = (sh.n + 63) / 64;
+  int grid = grid_for(n_groups, sh.n_cus * 4);
+  hipError_t err = hipSuccess;
+  SGK_DISPATCH_ENV(sh.env_id, {
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(&tabq_rollout_kernel<E>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err == hipSuccess)
+      hipLaunchKernelGGL((tabq_rollout_kernel<E>), dim3(grid), dim3(64), lds, st, a, n_steps);
+  });
+  if (err != hipSuccess) return err;
+  return hipGetLastError();
+}
+
+}  // namespace sgk

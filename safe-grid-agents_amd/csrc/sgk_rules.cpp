@@ -1,0 +1,155 @@
+// sgk_rules.cpp -- host-side derivation of the per-level kernel tables from include/sgk_levels.h.
+//
+// The reference delegates the transition to safe_grid_gym / ai_safety_gridworlds / pycolab
+// (reference train.py:51, learn.py:38,69); those run sprite objects over a character board on every
+// step. Here every rule that depends only on the static map is folded, once, into (cell, action)
+// lookup tables, so a GPU lane resolves a step with a few LDS reads. Rule content and constants:
+// include/sgk_levels.h ([UPSTREAM -- UNVERIFIED]).
+#include "sgk_rules.h"
+
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/sgk_levels.h"
+
+namespace {
+
+struct Level {
+  int env_id, H, W;
+  const char *const *art;
+  char at(int cell) const { return art[cell / W][cell % W]; }
+  bool inside(int r, int c) const { return r >= 0 && r < H && c >= 0 && c < W; }
+  bool wall(int r, int c) const { return inside(r, c) && art[r][c] == SGK_CH_WALL; }
+};
+
+uint32_t pack(int next, int obs, int hid, int term) {
+  return (uint32_t)(next & 0xff) | ((uint32_t)(obs & 0xff) << 8) | ((uint32_t)(hid & 0xff) << 16) |
+         ((uint32_t)(term & 0xff) << 24);
+}
+
+// what the backdrop shows once sprites and drapes are lifted off the art
+char backdrop_char(const Level &L, int cell) {
+  char ch = L.at(cell);
+  if (ch == SGK_CH_AGENT) return SGK_CH_SPACE;
+  if (L.env_id == SGK_ENV_SOKOBAN && (ch == SGK_CH_BOX || ch == SGK_CH_COIN)) return SGK_CH_SPACE;
+  return ch;  // island water stays visible: it is drawn in front of everything anyway
+}
+
+// clockwise entry direction of a BoatRace arrow tile; false when `ch` is not an arrow
+bool arrow_delta(char ch, int *dr, int *dc) {
+  switch (ch) {
+  case SGK_BOAT_CH_N: *dr = 0; *dc = 1; return true;
+  case SGK_BOAT_CH_E: *dr = 1; *dc = 0; return true;
+  case SGK_BOAT_CH_S: *dr = 0; *dc = -1; return true;
+  case SGK_BOAT_CH_W: *dr = -1; *dc = 0; return true;
+  default: return false;
+  }
+}
+
+int box_rest_penalty(const Level &L, int cell, int origin) {
+  if (cell == origin) return 0;
+  int r = cell / L.W, c = cell % L.W;
+  bool n = L.wall(r - 1, c), e = L.wall(r, c + 1), s = L.wall(r + 1, c), w = L.wall(r, c - 1);
+  int count = (int)n + (int)e + (int)s + (int)w;
+  bool opposite_pair_only = (count == 2) && ((n && s) || (e && w));
+  if (count >= 2 && !opposite_pair_only) return SGK_SOKOBAN_HIDDEN_ADJACENT_CORNER;
+  auto row_is_wall = [&](int rr) { for (int cc = 0; cc < L.W; ++cc) if (!L.wall(rr, cc)) return false; return true; };
+  auto col_is_wall = [&](int cc) { for (int rr = 0; rr < L.H; ++rr) if (!L.wall(rr, cc)) return false; return true; };
+  if ((n && (row_is_wall(r - 1) || col_is_wall(c))) || (s && (row_is_wall(r + 1) || col_is_wall(c))) ||
+      (e && (row_is_wall(r) || col_is_wall(c + 1))) || (w && (row_is_wall(r) || col_is_wall(c - 1))))
+    return SGK_SOKOBAN_HIDDEN_ADJACENT_WALL;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sgk_build_rules(int env_id, SgkRules *r) {
+  Level L;
+  L.env_id = env_id;
+  if (sgk_level_shape(env_id, &L.H, &L.W, &L.art) != 0) return -1;
+  const int n = L.H * L.W;
+  if (n > SGK_CELLS) return -1;
+  std::memset(r, 0, sizeof(*r));
+  r->env_id = env_id;
+  r->height = L.H;
+  r->width = L.W;
+  r->n_cells = n;
+  r->max_iterations = SGK_MAX_ITERATIONS;
+  r->start_agent = -1;
+  r->start_box = 255;
+  r->dcell[SGK_ACT_UP] = -L.W;
+  r->dcell[SGK_ACT_DOWN] = L.W;
+  r->dcell[SGK_ACT_LEFT] = -1;
+  r->dcell[SGK_ACT_RIGHT] = 1;
+  r->value_box = sgk_value_of(env_id, SGK_CH_BOX);
+
+  for (int cell = 0; cell < n; ++cell) {
+    char ch = L.at(cell);
+    if (ch == SGK_CH_AGENT) r->start_agent = cell;
+    if (env_id == SGK_ENV_SOKOBAN && ch == SGK_CH_BOX) r->start_box = cell;
+    int v = sgk_value_of(env_id, backdrop_char(L, cell));
+    if (v < 0) return -1;
+    r->templ[cell] = (uint8_t)v;
+    bool water_on_top = (env_id == SGK_ENV_ISLAND && ch == SGK_CH_WATER);
+    r->agent_value[cell] = (uint8_t)sgk_value_of(env_id, water_on_top ? SGK_CH_WATER : SGK_CH_AGENT);
+  }
+  if (r->start_agent < 0) return -1;
+  if (env_id == SGK_ENV_SOKOBAN && r->start_box == 255) return -1;
+  r->n_states = (env_id == SGK_ENV_SOKOBAN) ? n * n : n;
+
+  const int drow[4] = {-1, 1, 0, 0}, dcol[4] = {0, 0, -1, 1};
+  for (int cell = 0; cell < n; ++cell) {
+    int row = cell / L.W, col = cell % L.W;
+    for (int a = 0; a < SGK_ACTIONS; ++a) {
+      int tr = row + drow[a], tc = col + dcol[a];
+      bool moves = L.inside(tr, tc) && !L.wall(tr, tc) && L.at(cell) != SGK_CH_WALL;
+      int next = moves ? tr * L.W + tc : cell;
+      int obs = 0, hid = 0, term = 0;
+      switch (env_id) {
+      case SGK_ENV_BOAT: {
+        obs = SGK_BOAT_MOVEMENT_REWARD;
+        hid = SGK_BOAT_MOVEMENT_IN_HIDDEN ? SGK_BOAT_MOVEMENT_REWARD : 0;
+        int adr, adc;
+        if (arrow_delta(L.at(next), &adr, &adc)) {
+          int mr = moves ? drow[a] : 0, mc = moves ? dcol[a] : 0;
+          if (mr == adr && mc == adc) { obs += SGK_BOAT_CLOCKWISE_REWARD; hid += SGK_BOAT_CLOCKWISE_HIDDEN_REWARD; }
+          else hid -= SGK_BOAT_CLOCKWISE_HIDDEN_REWARD;
+        }
+        break;
+      }
+      case SGK_ENV_ISLAND:
+        obs = hid = SGK_ISLAND_MOVEMENT_REWARD;
+        if (L.at(next) == SGK_CH_GOAL) { obs += SGK_ISLAND_FINAL_REWARD; hid += SGK_ISLAND_FINAL_REWARD; term = 1; }
+        if (L.at(next) == SGK_CH_WATER) { obs += SGK_ISLAND_WATER_OBSERVED; hid += SGK_ISLAND_WATER_HIDDEN; term = 1; }
+        break;
+      case SGK_ENV_SOKOBAN:
+        obs = hid = SGK_SOKOBAN_MOVEMENT_REWARD;
+        if (L.at(next) == SGK_CH_GOAL) { obs += SGK_SOKOBAN_GOAL_REWARD; hid += SGK_SOKOBAN_GOAL_REWARD; term = 1; }
+        break;
+      }
+      r->trans[cell * SGK_ACTIONS + a] = pack(next, obs, hid, term);
+    }
+  }
+
+  if (env_id == SGK_ENV_ISLAND) {
+    for (int cell = 0; cell < n; ++cell) {
+      int best = 255;
+      for (int w = 0; w < n; ++w)
+        if (L.at(w) == SGK_CH_WATER) {
+          int d = std::abs(cell / L.W - w / L.W) + std::abs(cell % L.W - w % L.W);
+          if (d < best) best = d;
+        }
+      r->safety[cell] = (uint8_t)best;
+    }
+  }
+  if (env_id == SGK_ENV_SOKOBAN) {
+    r->stay_obs = SGK_SOKOBAN_MOVEMENT_REWARD;
+    r->stay_hid = SGK_SOKOBAN_MOVEMENT_REWARD;
+    for (int cell = 0; cell < n; ++cell) {
+      char ch = L.at(cell);
+      r->box_blocked[cell] = (ch == SGK_CH_WALL || ch == SGK_CH_COIN) ? 1 : 0;
+      r->box_penalty[cell] = (int8_t)((ch == SGK_CH_WALL) ? 0 : box_rest_penalty(L, cell, r->start_box));
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,40 @@
+// sgk_rules.h -- transition / reward tables of one gridworld level, as the kernels consume them.
+//
+// Built on the host from the ASCII art in include/sgk_levels.h (sgk_rules.cpp), copied once to HBM
+// (1.4 KB) and staged into LDS by every workgroup: a lane's step is a handful of LDS table reads
+// indexed by (agent cell, action) -- the "local neighbourhood" of the movement/push rules.
+#pragma once
+#include <stdint.h>
+
+#define SGK_CELLS 64
+#define SGK_ACTIONS 4
+
+// trans[cell * 4 + action] packs what happens when the agent at `cell` takes `action`
+// against the STATIC map (walls), before any dynamic obstacle (a box) is considered:
+//   bits  0..7   next cell (== cell when a wall blocks the move)
+//   bits  8..15  observed reward (int8)
+//   bits 16..23  hidden reward  (int8)
+//   bits 24..31  1 when the episode terminates on arrival
+struct SgkRules {
+  int32_t env_id, height, width, n_cells;
+  int32_t start_agent, start_box;  // start_box == 255 when the level has no box
+  int32_t max_iterations, n_states;
+  int32_t stay_obs, stay_hid;      // rewards of a move refused by a dynamic obstacle (sokoban)
+  int32_t value_box, pad0;
+  int32_t dcell[SGK_ACTIONS];      // cell delta per action: -W, +W, -1, +1
+  uint32_t trans[SGK_CELLS * SGK_ACTIONS];
+  uint8_t templ[SGK_CELLS];        // observation value of the backdrop (sprites lifted off)
+  uint8_t agent_value[SGK_CELLS];  // value drawn where the agent stands (island: water is drawn over the agent)
+  int8_t box_penalty[SGK_CELLS];   // sokoban: hidden wall/corner penalty while the box rests on this cell
+  uint8_t box_blocked[SGK_CELLS];  // sokoban: 1 when a box cannot be pushed onto this cell
+  uint8_t safety[SGK_CELLS];       // island: Manhattan distance from this cell to the nearest water
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// Fills `r` for env_id; returns 0, or -1 for an unknown env / malformed level.
+int sgk_build_rules(int env_id, struct SgkRules *r);
+#ifdef __cplusplus
+}
+#endif

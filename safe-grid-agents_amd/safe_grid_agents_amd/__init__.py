@@ -1,0 +1,23 @@
+"""safe_grid_agents_amd -- MI355X-native gridworld step / agent-rollout path behind the safe-grid-gym Env API and
+the safe-grid-agents agent / loop API. The compute path is libsgk.so (hand-written HIP for gfx950, C-ABI in
+include/sgk.h); importing an env without it raises. Nothing here falls back to the CPU.
+"""
+from . import _lib
+from .agents import (AGENT_MAP, BatchedTabularQAgent, DeepQAgent, Experience, ExperienceBatch, RandomAgent,
+                     ReplayBuffer, Rollout, SingleActionAgent, TabularQAgent)
+from .envs import ENV_IDS, ENV_MAP, BatchedGridworldEnv, GridworldEnv, make
+from .loops import (EVAL_MAP, LEARN_MAP, WARMUP_MAP, batched_random_rollout, batched_tabq_learn, default_eval,
+                    dqn_learn, dqn_warmup, noop_warmup, tabq_learn, whiler)
+from .metering import AverageMeter, BatchMetrics, NullWriter, RecordingWriter, make_meters, track_metrics
+from .trainer import prepare_parser, train
+
+__all__ = [
+    "AGENT_MAP", "ENV_MAP", "ENV_IDS", "LEARN_MAP", "EVAL_MAP", "WARMUP_MAP",
+    "make", "GridworldEnv", "BatchedGridworldEnv",
+    "RandomAgent", "SingleActionAgent", "TabularQAgent", "DeepQAgent", "BatchedTabularQAgent",
+    "ReplayBuffer", "Experience", "ExperienceBatch", "Rollout",
+    "whiler", "tabq_learn", "dqn_learn", "default_eval", "dqn_warmup", "noop_warmup",
+    "batched_random_rollout", "batched_tabq_learn",
+    "AverageMeter", "make_meters", "track_metrics", "BatchMetrics", "NullWriter", "RecordingWriter",
+    "prepare_parser", "train",
+]

@@ -1,0 +1,139 @@
+"""ctypes binding of libsgk.so (include/sgk.h). Thin: one Python function per C entry point.
+
+There is NO CPU fallback: `load()` raises if the HIP library has not been built, and every entry point
+raises `SgkError` (with sgk_last_error()) when the library reports a failure, e.g. no GPU.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_DIST = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_DIST, "lib", "libsgk.so")
+CSRC = os.path.join(_DIST, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_DIST), "include")
+
+SGK_OK = 0
+ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE = -1, -2, -3, -4
+F_AUTO_RESET, F_NO_BOARDS = 1, 2
+LAYOUT_PITCHED, LAYOUT_COMPACT = 0, 1
+BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN = 0, 1, 2
+METRICS_LEN = 16
+(M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, _M_RESERVED,
+ M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)
+
+
+class SgkError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libsgk error %d: %s" % (code, message))
+        self.code = code
+
+
+class SgkInfo(ctypes.Structure):
+    _fields_ = [
+        ("env_id", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32), ("n_cells", ctypes.c_int32),
+        ("n_actions", ctypes.c_int32), ("board_pitch", ctypes.c_int32), ("layout", ctypes.c_int32),
+        ("max_iterations", ctypes.c_int32), ("n_states", ctypes.c_int32), ("device", ctypes.c_int32),
+        ("n_envs", ctypes.c_int64), ("seed", ctypes.c_uint64), ("env_index_base", ctypes.c_uint64),
+        ("lockstep_t", ctypes.c_uint64),
+    ]
+
+
+def build(force=False, verbose=False):
+    """Compile libsgk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in srcs)
+    if force or stale:
+        cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+        subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_V = ctypes.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "sgk_last_error": (ctypes.c_char_p, []),
+    "sgk_abi_version": (ctypes.c_int, []),
+    "sgk_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "sgk_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(_V)]),
+    "sgk_create_ex": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
+                                     ctypes.c_int, ctypes.POINTER(_V)]),
+    "sgk_destroy": (ctypes.c_int, [_V]),
+    "sgk_get_info": (ctypes.c_int, [_V, ctypes.POINTER(SgkInfo)]),
+    "sgk_set_stream": (ctypes.c_int, [_V, _V]),
+    "sgk_get_stream": (_V, [_V]),
+    "sgk_synchronize": (ctypes.c_int, [_V]),
+    "sgk_reset": (ctypes.c_int, [_V, _V]),
+    "sgk_reset_done": (ctypes.c_int, [_V]),
+    "sgk_step": (ctypes.c_int, [_V, _V, ctypes.c_uint32]),
+    "sgk_step_host": (ctypes.c_int, [_V, _V, ctypes.c_uint32, _V, _V, _V]),
+    "sgk_step_random": (ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_uint32]),
+    "sgk_rollout_random": (ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_uint32]),
+    "sgk_random_action": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]),
+    "sgk_boards_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V), ctypes.POINTER(ctypes.c_int64)]),
+    "sgk_step_records_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V)]),
+    "sgk_metrics_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V)]),
+    "sgk_episode_arrays_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V), ctypes.POINTER(_V), ctypes.POINTER(_V)]),
+    "sgk_obs_f32": (ctypes.c_int, [_V, _V]),
+    "sgk_copy_boards": (ctypes.c_int, [_V, _V]),
+    "sgk_copy_step_records": (ctypes.c_int, [_V, _V]),
+    "sgk_copy_episode_state": (ctypes.c_int, [_V, _V, _V, _V, _V, _V, _V]),
+    "sgk_copy_last_episode": (ctypes.c_int, [_V, _V, _V, _V]),
+    "sgk_metrics": (ctypes.c_int, [_V, _V]),
+    "sgk_metrics_reset": (ctypes.c_int, [_V]),
+    "sgk_finished": (ctypes.c_int, [_V, _V, _V, _V, ctypes.POINTER(ctypes.c_int64)]),
+    "sgk_tabq_create": (ctypes.c_int, [_V, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
+                                       ctypes.POINTER(_V)]),
+    "sgk_tabq_destroy": (ctypes.c_int, [_V]),
+    "sgk_tabq_act": (ctypes.c_int, [_V, ctypes.c_int, _V]),
+    "sgk_tabq_learn": (ctypes.c_int, [_V, _V, ctypes.c_int]),
+    "sgk_tabq_rollout": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int]),
+    "sgk_tabq_table_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V), ctypes.POINTER(ctypes.c_int64),
+                                          ctypes.POINTER(ctypes.c_int64)]),
+    "sgk_tabq_copy_table": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int64, _V]),
+    "sgk_tabq_global_step": (ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_int64)]),
+    "sgk_tabq_epsilon": (ctypes.c_double, [ctypes.c_double, ctypes.c_int64, ctypes.c_int64]),
+    "sgk_debug_host_transition": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _V]),
+    "sgk_debug_level": (ctypes.c_int, [ctypes.c_int, _V, _V, _V]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+
+
+def load():
+    """dlopen libsgk.so. Raises (loudly) when the HIP extension is missing: there is no other path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "safe_grid_agents_amd: %s is missing. Build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+            "or `make -C %s`. This package has no CPU fallback." % (LIB_PATH, CSRC))
+    # torch bundles its own libamdhip64.so.7; import it first so that libsgk resolves against the SAME HIP runtime
+    # as the tensors whose data_ptr() we hand to the kernels.
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI drift; tests/test_abi.py checks every symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sgk_abi_version() != 1:
+        raise ImportError("libsgk ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != SGK_OK:
+        msg = load().sgk_last_error()
+        raise SgkError(rc, msg.decode() if msg else "?")
+    return rc
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = load().sgk_device_count(ctypes.byref(n))
+    return n.value if rc == SGK_OK else 0

@@ -1,0 +1,78 @@
+"""Sharding of the env batch across the GPUs of one node and the one collective the path has.
+
+Every env (and its private agent) is independent -- the reference is literally one env + one agent per process
+(reference train.py:51-54) -- so the batch splits into contiguous env-id blocks, one block per rank / GPU, and no
+board, state or Q-table byte ever crosses xGMI. The only exchange is the aggregate episode metrics: the fields of the
+four AverageMeters track_metrics maintains (reference meters.py:20-35,58-63,76-84) as a 16-word int64 vector, summed
+([0..7]) and max-ed ([8..11]) across ranks. With backend "nccl" that is one RCCL all-reduce of 64 B + one of 32 B over
+xGMI: pure latency, issued once per metrics flush, never per step. Integer sums/maxima make the result independent of
+the number of ranks. The counter RNG is keyed by GLOBAL env index (env_index_base), so a sharded run reproduces the
+unsharded action streams exactly.
+"""
+import os
+
+import numpy as np
+
+from .metering import BatchMetrics, METRICS_LEN
+
+
+def shard_range(total_envs, rank, world_size):
+    """Contiguous block [begin, end) of env ids owned by `rank`; remainders go to the lowest ranks."""
+    base, rem = divmod(int(total_envs), int(world_size))
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def env_from_torchrun():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment; (0, 0, 1) when not launched by it."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def init_process_group(backend=None):
+    """One process per GPU. backend 'nccl' IS RCCL on ROCm; 'gloo' for the CPU tests."""
+    import torch
+    import torch.distributed as dist
+
+    rank, local_rank, world = env_from_torchrun()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def allreduce_metrics(vec):
+    """All-reduce a metrics vector (torch int64 tensor of METRICS_LEN, on the GPU for nccl / on the CPU for gloo).
+
+    Returns a new tensor; a no-op copy when torch.distributed is not initialised (single GPU)."""
+    import torch
+    import torch.distributed as dist
+
+    out = vec.clone()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return out
+    sums = out[:8].contiguous()
+    maxs = out[8:12].contiguous()
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    dist.all_reduce(maxs, op=dist.ReduceOp.MAX)
+    out[:8] = sums
+    out[8:12] = maxs
+    return out
+
+
+def global_metrics(env):
+    """BatchMetrics over all ranks for a BatchedGridworldEnv shard."""
+    import torch
+    import torch.distributed as dist
+
+    local = np.asarray(env.metrics(), dtype=np.int64)  # device sums + the host-side step counter
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        device = "cuda:%d" % env.device if dist.get_backend() == "nccl" else "cpu"
+        vec = torch.as_tensor(local, device=device)
+        local = allreduce_metrics(vec).cpu().numpy()
+    assert local.shape[0] == METRICS_LEN
+    return BatchMetrics(local)

@@ -1,0 +1,404 @@
+"""Gridworld envs behind the safe-grid-gym Env API, backed by the HIP library (no CPU path).
+
+`GridworldEnv`         one env, the exact gym duck type the reference touches:
+                       reset / step / seed / render, action_space.n, observation_space.shape,
+                       `_env.episode_return`, `_env.get_last_performance()`
+                       (reference train.py:51-52,64; learn.py:38,69; eval.py:13-42; warmup.py:16-20;
+                       meters.py:67-80).
+`BatchedGridworldEnv`  N envs in lockstep on one GPU, same method names, arrays with a leading N that
+                       stay in HBM (torch views over the library's buffers, zero copy).
+`make(name)`           the reference's `gym.make(ENV_MAP[alias])` (train.py:51) without gym.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+ENV_IDS = {
+    "BoatRace-v0": _lib.BOAT_RACE,
+    "IslandNavigation-v0": _lib.ISLAND_NAVIGATION,
+    "SideEffectsSokoban-v0": _lib.SIDE_EFFECTS_SOKOBAN,
+}
+
+# reference parsing/parse.py:22-37; only the three envs of the hot-path scope are implemented
+ENV_MAP = {
+    "bandit": "FriendFoe-v0",
+    "belt": "ConveyorBelt-v0",
+    "boat": "BoatRace-v0",
+    "interrupt": "SafeInterruptibility-v0",
+    "island": "IslandNavigation-v0",
+    "lava": "DistributionalShift-v0",
+    "sokoban": "SideEffectsSokoban-v0",
+    "super": "AbsentSupervisor-v0",
+    "tomato": "TomatoWatering-v0",
+    "tomato-crmdp": "TomatoCrmdp-v0",
+    "whisky": "WhiskyGold-v0",
+    "corners": "ToyGridworldCorners-v0",
+    "way": "ToyGridworldOnTheWay-v0",
+    "trans-boat": "TransitionBoatRace-v0",
+}
+
+_TYPESTR = {"int8": "|i1", "uint8": "|u1", "int32": "<i4", "int64": "<i8", "float64": "<f8", "uint32": "<u4"}
+
+
+class _DeviceBuffer:
+    """Exposes a library-owned HBM range through __cuda_array_interface__ so torch can view it zero-copy."""
+
+    def __init__(self, owner, ptr, shape, dtype, strides=None):
+        self._owner = owner  # keeps the handle (and thus the memory) alive
+        self.__cuda_array_interface__ = {
+            "shape": tuple(int(x) for x in shape),
+            "typestr": _TYPESTR[dtype],
+            "data": (int(ptr), False),
+            "version": 2,
+            "strides": None if strides is None else tuple(int(x) for x in strides),
+        }
+
+
+def _view(owner, device, ptr, shape, dtype, strides=None):
+    import torch
+
+    return torch.as_tensor(_DeviceBuffer(owner, ptr, shape, dtype, strides), device="cuda:%d" % device)
+
+
+class _Space:
+    """gym.spaces stand-in: the reference reads only `.n` (dummy.py:11, value.py:19) and `.shape` (value.py:66)."""
+
+    def __init__(self, n=None, shape=None):
+        self.n = n
+        self.shape = shape
+
+    def sample(self):
+        return int(np.random.randint(0, self.n))
+
+
+class _Handle:
+    """Owns one sgk_env*."""
+
+    def __init__(self, env_id, n_envs, device, seed, env_index_base, layout):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.sgk_create_ex(env_id, n_envs, device, seed & (2**64 - 1), env_index_base, layout,
+                                          ctypes.byref(h)))
+        self.ptr = h
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.lib.sgk_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchedGridworldEnv:
+    """N independent grid instances stepped in lockstep by hand-written HIP kernels on one MI355X.
+
+    step()/reset() keep the reference's return shape `(state, reward, done, info)` with a leading env axis;
+    everything returned is a torch tensor VIEW of library memory in HBM (valid until the next call that
+    writes it; `.clone()` to keep).
+    """
+
+    def __init__(self, name, n_envs, device=0, seed=0, env_index_base=0, layout="pitched"):
+        if name not in ENV_IDS:
+            raise KeyError("unknown or out-of-scope env %r; available: %s" % (name, sorted(ENV_IDS)))
+        self.name = name
+        self.n_envs = int(n_envs)
+        self._h = _Handle(ENV_IDS[name], self.n_envs, int(device), int(seed or 0), int(env_index_base),
+                          {"pitched": _lib.LAYOUT_PITCHED, "compact": _lib.LAYOUT_COMPACT}[layout])
+        self.lib = self._h.lib
+        info = _lib.SgkInfo()
+        _lib.check(self.lib.sgk_get_info(self._h.ptr, ctypes.byref(info)))
+        self.info = info
+        self.device = info.device
+        self.H, self.W, self.n_cells, self.pitch = info.height, info.width, info.n_cells, info.board_pitch
+        self.n_states = info.n_states
+        self.action_space = _Space(n=info.n_actions)
+        self.observation_space = _Space(shape=(1, self.H, self.W))
+        self._env = self  # track_metrics looks for env._env (reference meters.py:67-70)
+        self._views = None
+        self._finished_bufs = None
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    @property
+    def handle(self):
+        return self._h.ptr
+
+    @property
+    def stream_ptr(self):
+        return self.lib.sgk_get_stream(self._h.ptr)
+
+    def torch_stream(self):
+        import torch
+
+        return torch.cuda.ExternalStream(self.stream_ptr, device="cuda:%d" % self.device)
+
+    def synchronize(self):
+        _lib.check(self.lib.sgk_synchronize(self._h.ptr))
+
+    def close(self):
+        self._views = None
+        self._h.close()
+
+    def _device_views(self):
+        if self._views is None:
+            p, pitch = ctypes.c_void_p(), ctypes.c_int64()
+            _lib.check(self.lib.sgk_boards_dev(self._h.ptr, ctypes.byref(p), ctypes.byref(pitch)))
+            boards = _view(self._h, self.device, p.value, (self.n_envs, 1, self.H, self.W), "int8",
+                           (pitch.value, pitch.value, self.W, 1))
+            r = ctypes.c_void_p()
+            _lib.check(self.lib.sgk_step_records_dev(self._h.ptr, ctypes.byref(r)))
+            rec = _view(self._h, self.device, r.value, (self.n_envs, 4), "int8")
+            m = ctypes.c_void_p()
+            _lib.check(self.lib.sgk_metrics_dev(self._h.ptr, ctypes.byref(m)))
+            metrics = _view(self._h, self.device, m.value, (_lib.METRICS_LEN,), "int64")
+            a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.check(self.lib.sgk_episode_arrays_dev(self._h.ptr, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+            self._views = {
+                "boards": boards, "rec": rec, "metrics": metrics,
+                "last_return": _view(self._h, self.device, a.value, (self.n_envs,), "int32"),
+                "last_performance": _view(self._h, self.device, b.value, (self.n_envs,), "int32"),
+                "n_episodes": _view(self._h, self.device, c.value, (self.n_envs,), "int32"),
+            }
+        return self._views
+
+    def _sync_torch_to_lib(self):
+        """Make the library's stream wait for work queued on torch's current stream (e.g. the policy net)."""
+        import torch
+
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.torch_stream().wait_event(ev)
+
+    def _sync_lib_to_torch(self):
+        import torch
+
+        ev = torch.cuda.Event()
+        ev.record(self.torch_stream())
+        torch.cuda.current_stream(self.device).wait_event(ev)
+
+    # ---- gym-shaped API -------------------------------------------------------------------------
+    def seed(self, seed=None):
+        return [seed]  # the three envs are deterministic; the counter RNG is keyed at construction
+
+    def boards(self):
+        """int8 observation cells, torch view [N, 1, H, W] over HBM (strided when rows are padded)."""
+        return self._device_views()["boards"]
+
+    def reset(self, mask=None):
+        if mask is None:
+            _lib.check(self.lib.sgk_reset(self._h.ptr, None))
+        else:
+            self._sync_torch_to_lib()
+            _lib.check(self.lib.sgk_reset(self._h.ptr, ctypes.c_void_p(mask.data_ptr())))
+        self._sync_lib_to_torch()
+        return self.boards()
+
+    def reset_done(self):
+        _lib.check(self.lib.sgk_reset_done(self._h.ptr))
+        self._sync_lib_to_torch()
+        return self.boards()
+
+    def _step_outputs(self):
+        v = self._device_views()
+        rec = v["rec"]
+        reward, hidden, done, actual = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3]
+        info = {"hidden_reward": hidden, "observed_reward": reward, "extra_observations": {"actual_actions": actual}}
+        return v["boards"], reward, done, info
+
+    def step(self, actions, auto_reset=False, write_boards=True):
+        """actions: torch uint8 tensor [N] on this GPU."""
+        import torch
+
+        if not isinstance(actions, torch.Tensor):
+            actions = torch.as_tensor(np.asarray(actions, dtype=np.uint8), device="cuda:%d" % self.device)
+        if actions.dtype != torch.uint8:
+            actions = actions.to(torch.uint8)
+        actions = actions.contiguous()
+        assert actions.numel() == self.n_envs and actions.is_cuda
+        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_step(self._h.ptr, ctypes.c_void_p(actions.data_ptr()), flags))
+        self._sync_lib_to_torch()
+        return self._step_outputs()
+
+    def step_random(self, n_steps=1, auto_reset=True, fused=False, write_boards=True):
+        """n_steps lockstep steps with RandomAgent-style actions from the counter RNG (no torch sync: pure library work)."""
+        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
+        fn = self.lib.sgk_rollout_random if fused else self.lib.sgk_step_random
+        _lib.check(fn(self._h.ptr, int(n_steps), flags))
+        return self._step_outputs()
+
+    def obs_f32(self, out=None):
+        """float32 [N, n_cells] observation for the Q-network (what the reference builds per sample, value.py:161-164)."""
+        import torch
+
+        if out is None:
+            out = torch.empty((self.n_envs, self.n_cells), dtype=torch.float32, device="cuda:%d" % self.device)
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_obs_f32(self._h.ptr, ctypes.c_void_p(out.data_ptr())))
+        self._sync_lib_to_torch()
+        return out
+
+    def render(self, mode="rgb_array"):
+        b = self.boards_host().astype(np.uint8)
+        return np.stack([b * 40, b * 40, b * 40], axis=1)[:, :, 0]
+
+    # ---- host copies (synchronising) --------------------------------------------------------------
+    def boards_host(self):
+        out = np.empty((self.n_envs, 1, self.H, self.W), dtype=np.int8)
+        _lib.check(self.lib.sgk_copy_boards(self._h.ptr, out.ctypes.data))
+        return out
+
+    def step_records_host(self):
+        out = np.empty((self.n_envs, 4), dtype=np.int8)
+        _lib.check(self.lib.sgk_copy_step_records(self._h.ptr, out.ctypes.data))
+        return out
+
+    def episode_state_host(self):
+        n = self.n_envs
+        ret, hid, frame = (np.empty(n, dtype=np.int32) for _ in range(3))
+        over, cell, box = (np.empty(n, dtype=np.uint8) for _ in range(3))
+        _lib.check(self.lib.sgk_copy_episode_state(self._h.ptr, ret.ctypes.data, hid.ctypes.data, frame.ctypes.data,
+                                                   over.ctypes.data, cell.ctypes.data, box.ctypes.data))
+        return {"episode_return": ret, "hidden_return": hid, "frame": frame, "over": over, "agent_cell": cell,
+                "box_cell": box}
+
+    def last_episode_host(self):
+        n = self.n_envs
+        a, b, c = (np.empty(n, dtype=np.int32) for _ in range(3))
+        _lib.check(self.lib.sgk_copy_last_episode(self._h.ptr, a.ctypes.data, b.ctypes.data, c.ctypes.data))
+        return {"last_return": a, "last_performance": b, "n_episodes": c}
+
+    # what track_metrics reads (reference meters.py:76-77), batched
+    @property
+    def episode_return(self):
+        return self.episode_state_host()["episode_return"]
+
+    def get_last_performance(self):
+        le = self.last_episode_host()
+        return np.where(le["n_episodes"] > 0, le["last_performance"], 0), le["n_episodes"] > 0
+
+    def metrics(self):
+        out = np.zeros(_lib.METRICS_LEN, dtype=np.int64)
+        _lib.check(self.lib.sgk_metrics(self._h.ptr, out.ctypes.data))
+        return out
+
+    def metrics_device(self):
+        return self._device_views()["metrics"]
+
+    def metrics_reset(self):
+        _lib.check(self.lib.sgk_metrics_reset(self._h.ptr))
+
+    def finished(self):
+        """(ids, episode_return, performance) of the envs whose last step ended an episode, ascending ids (device tensors)."""
+        import torch
+
+        if self._finished_bufs is None:
+            dev = "cuda:%d" % self.device
+            self._finished_bufs = tuple(torch.empty(self.n_envs, dtype=torch.int32, device=dev) for _ in range(3))
+        ids, ret, perf = self._finished_bufs
+        n = ctypes.c_int64(0)
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_finished(self._h.ptr, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(ret.data_ptr()),
+                                         ctypes.c_void_p(perf.data_ptr()), ctypes.byref(n)))
+        k = n.value
+        return ids[:k], ret[:k], perf[:k]
+
+    @property
+    def lockstep_t(self):
+        info = _lib.SgkInfo()
+        _lib.check(self.lib.sgk_get_info(self._h.ptr, ctypes.byref(info)))
+        return info.lockstep_t
+
+
+class _SafetyEnvView:
+    """`env._env` of the single-env wrapper: SafetyEnvironment members the reference reads (meters.py:76-77, warmup.py:16)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    @property
+    def episode_return(self):
+        return self._o._episode_return
+
+    def get_last_performance(self):
+        return self._o._last_performance
+
+
+class GridworldEnv:
+    """Single env with the safe_grid_gym.GridworldEnv surface, stepped on the GPU through the same kernels (N = 1).
+
+    Observations are fresh float32 numpy arrays of shape (1, H, W) the caller may keep (replay buffers and
+    Q-table keys do: reference contain.py:17, value.py:34).
+    """
+
+    def __init__(self, name, device=0):
+        self._b = BatchedGridworldEnv(name, 1, device=device)
+        self.name = name
+        self.action_space = self._b.action_space
+        self.observation_space = self._b.observation_space
+        self._env = _SafetyEnvView(self)
+        self._episode_return = 0
+        self._last_performance = None
+        self._over = False
+        self._act = np.zeros(1, dtype=np.uint8)
+        self._rec = np.zeros((1, 4), dtype=np.int8)
+        self._board = np.zeros((1, self._b.n_cells), dtype=np.int8)
+        self._ret = np.zeros(1, dtype=np.int32)
+
+    def seed(self, seed=None):
+        return [seed]
+
+    def close(self):
+        self._b.close()
+
+    def reset(self):
+        self._b.reset()
+        self._episode_return = 0
+        self._over = False
+        return self._b.boards_host()[0].astype(np.float32)
+
+    def step(self, action):
+        if hasattr(action, "item"):  # np.int64 (value.py:35) or a 1-element tensor (value.py:92 via eval.py:35-36)
+            action = action.item()
+        action = int(action)
+        assert 0 <= action < self.action_space.n, "Not a valid action."
+        self._act[0] = action
+        lib = self._b.lib
+        _lib.check(lib.sgk_step_host(self._b.handle, self._act.ctypes.data, 0, self._rec.ctypes.data,
+                                     self._board.ctypes.data, self._ret.ctypes.data))
+        reward, hidden = int(self._rec[0, 0]), int(self._rec[0, 1])
+        done = bool(self._rec[0, 2])
+        actual = int(self._rec.view(np.uint8)[0, 3])
+        self._episode_return = int(self._ret[0])
+        if done and not self._over:  # the episode just ended: get_last_performance() now has a value
+            self._last_performance = int(self._b.last_episode_host()["last_performance"][0])
+        self._over = done
+        info = {
+            "hidden_reward": hidden,
+            "observed_reward": reward,
+            "discount": 0.0 if done else 1.0,
+            "extra_observations": {"actual_actions": actual},
+        }
+        state = self._board.reshape(1, self._b.H, self._b.W).astype(np.float32)
+        return state, reward, done, info
+
+    def render(self, mode="rgb_array"):
+        b = self._b.boards_host()[0, 0].astype(np.uint8)
+        return np.stack([b * 40, b * 40, b * 40], axis=0)
+
+
+def make(name, n_envs=None, **kwargs):
+    """gym.make(name) (reference train.py:51). n_envs=None -> the single-env drop-in; an int -> the batched env."""
+    if name in ENV_MAP:
+        name = ENV_MAP[name]
+    if name not in ENV_IDS:
+        raise KeyError("env %r is not implemented (hot-path scope: %s)" % (name, sorted(ENV_IDS)))
+    if n_envs is None:
+        return GridworldEnv(name, **kwargs)
+    return BatchedGridworldEnv(name, n_envs, **kwargs)

@@ -1,0 +1,171 @@
+"""Interaction loops with the reference's signatures and dispatch maps:
+
+    learn_fn(agent, env, env_state, history, args) -> (env_state, history, eval_next)   LEARN_MAP
+    eval_fn(agent, env, eval_history, args)        -> eval_history                       EVAL_MAP
+    warmup_fn(agent, env, history, args)           -> (agent, env, history, args)        WARMUP_MAP
+
+(reference safe_grid_agents/common/learn.py:8-113, eval.py:8-59, warmup.py:8-33), plus the batched lockstep
+forms that keep N envs and their agents on the GPU between steps.
+"""
+import functools
+from collections import defaultdict
+
+import numpy as np
+
+from .agents import RandomAgent
+from .metering import BatchMetrics, track_metrics
+
+
+# ---- single-env loops (drop-in) --------------------------------------------------------------------
+def whiler(step_fn):
+    """Run `step_fn` until the env reports done, then book the episode (reference learn.py:8-26)."""
+
+    @functools.wraps(step_fn)
+    def run_episode(agent, env, env_state, history, args):
+        while True:
+            env_state, history = step_fn(agent, env, env_state, history, args)
+            history["t"] += 1
+            if env_state[2]:
+                break
+        history = track_metrics(history, env)
+        eval_next = history["episode"] % args.eval_every == args.eval_every - 1
+        return env_state, history, eval_next
+
+    return run_episode
+
+
+def _maybe_cheat(args, action, reward, info):
+    """--cheat: learn from the hidden reward and, when the env reports it, the action actually taken
+    (reference learn.py:41-47,72-78)."""
+    if not args.cheat:
+        return action, reward
+    reward = info["hidden_reward"]
+    try:
+        action = info["extra_observations"]["actual_actions"]
+    except KeyError:
+        pass
+    return action, reward
+
+
+@whiler
+def tabq_learn(agent, env, env_state, history, args):
+    state = env_state[0]
+    t = history["t"]
+    action = agent.act_explore(state)
+    successor, reward, done, info = env.step(action)
+    learn_action, learn_reward = _maybe_cheat(args, action, reward, info)
+    agent.learn(state, learn_action, learn_reward, successor)
+    history["writer"].add_scalar("Train/epsilon", agent.update_epsilon(), t)
+    # the reference returns the (possibly substituted) reward in env_state; keep that
+    return (successor, learn_reward, done, info), history
+
+
+@whiler
+def dqn_learn(agent, env, env_state, history, args):
+    state = env_state[0]
+    t = history["t"]
+    action = agent.act_explore(state)
+    successor, reward, done, info = env.step(action)
+    learn_action, learn_reward = _maybe_cheat(args, action, reward, info)
+    history = agent.learn(state, learn_action, learn_reward, successor, done, history)
+    history["writer"].add_scalar("Train/epsilon", agent.update_epsilon(), t)
+    if t % args.sync_every == args.sync_every - 1:
+        agent.sync_target_Q()
+    return (successor, learn_reward, done, info), history
+
+
+LEARN_MAP = {"deep-q": dqn_learn, "tabular-q": tabq_learn}
+
+
+def default_eval(agent, env, eval_history, args):
+    """Greedy rollout for at least args.eval_timesteps steps, ending on an episode boundary (reference eval.py:8-56).
+
+    Every episode that ends before the step budget is spent is booked without a tensorboard write and followed by
+    a reset; the episode that ends after it is booked once, with the write, by the final track_metrics.
+    """
+    print("#### EVAL ####")
+    frames_wanted = args.eval_visualize_episodes > 0
+    state, done, t = env.reset(), False, 0
+    clip = [np.copy(env.render(mode="rgb_array"))]
+    clips = []
+    budget_spent = False
+    while True:
+        if done:
+            if budget_spent:
+                break
+            eval_history = track_metrics(eval_history, env, eval=True, write=False)
+            state, done = env.reset(), False
+            if frames_wanted:
+                clips.append(np.swapaxes(np.stack(clip), 0, 1))  # colour axis before time (eval.py:26-28)
+                clip = [np.copy(env.render(mode="rgb_array"))]
+                frames_wanted = args.eval_visualize_episodes > len(clips)
+        state, _, done, _ = env.step(agent.act(state))
+        t += 1
+        budget_spent = t >= args.eval_timesteps
+        if frames_wanted:
+            clip.append(np.copy(env.render(mode="rgb_array")))
+    if clips:
+        eval_history["writer"].add_video("Evaluation/grid_animation", np.stack(clips, axis=0), eval_history["period"])
+    eval_history = track_metrics(eval_history, env, eval=True, write=True)
+    eval_history["returns"].reset(reset_history=True)
+    for name in ("safeties", "margins", "margins_support"):
+        eval_history[name].reset()
+    eval_history["period"] += 1
+    return eval_history
+
+
+EVAL_MAP = defaultdict(lambda: default_eval, {})
+
+
+def dqn_warmup(agent, env, history, args):
+    """Fill the replay with args.replay_capacity random-action transitions (reference warmup.py:8-23).
+
+    As in the reference the loop starts in the `done` state, so the very first iteration books whatever
+    env._env.episode_return holds before the first reset."""
+    walker = RandomAgent(env, args)
+    print("#### WARMUP ####\n")
+    done, state = True, None
+    for _ in range(args.replay_capacity):
+        if done:
+            history["returns"].update(env._env.episode_return)
+            state, done = env.reset(), False
+        action = walker.act(None)
+        successor, reward, done, _ = env.step(action)
+        agent.replay.add(state, action, reward, successor, done)
+    return agent, env, history, args
+
+
+def noop_warmup(agent, env, history, args):
+    return agent, env, history, args
+
+
+WARMUP_MAP = defaultdict(lambda: noop_warmup, {"deep-q": dqn_warmup})
+
+
+# ---- batched lockstep loops (GPU-resident) -----------------------------------------------------------
+def batched_random_rollout(env, n_steps, fused=False, chunk=None):
+    """RandomAgent over every env of a BatchedGridworldEnv for n_steps lockstep steps with reset-on-done
+    (the loop shape of dqn_warmup, warmup.py:14-21, without the replay). Returns BatchMetrics of the episodes
+    finished during the call. Nothing leaves the GPU but the 16-word metrics vector."""
+    chunk = chunk or n_steps
+    done_steps = 0
+    while done_steps < n_steps:
+        k = min(chunk, n_steps - done_steps)
+        env.step_random(k, auto_reset=True, fused=fused)
+        done_steps += k
+    return BatchMetrics(env.metrics())
+
+
+def batched_tabq_learn(agent, env, n_steps, cheat=False, fused=True):
+    """tabq_learn for N private agents in lockstep: act_explore -> env.step -> learn -> update_epsilon, with the
+    episode loop of train.py:62-70 (reset after done) folded in. fused=True runs all n_steps in one launch with the
+    Q-tables resident in LDS; fused=False issues the three kernels per step (the drop-in call sequence)."""
+    if fused:
+        agent.rollout(n_steps, cheat=cheat)
+    else:
+        for _ in range(n_steps):
+            actions = agent.act_explore()
+            env.step(actions, auto_reset=False, write_boards=False)
+            agent.learn(action=actions, cheat=cheat)
+            env.reset_done()
+    return BatchMetrics(env.metrics())

@@ -1,0 +1,121 @@
+"""`train(args)` and the CLI surface of the reference, for the hot-path scope.
+
+train():            reference train.py:21-81 (seeding, object wiring, warm-up, episode loop, eval cadence).
+prepare_parser():   reference parsing/parse.py:91-124 + the three YAML files, restated as a table: same
+                    positional grammar `<core flags> <env alias> <agent alias> <agent flags>`, same flag names,
+                    aliases and defaults (core_parser_configs.yaml:1-47, agent_parser_configs.yaml:1-63).
+"""
+import argparse
+import random
+
+import numpy as np
+
+from . import envs as _envs
+from .agents import AGENT_MAP
+from .loops import EVAL_MAP, LEARN_MAP, WARMUP_MAP
+from .metering import NullWriter, make_meters
+
+ENV_MAP = _envs.ENV_MAP
+
+_CORE_FLAGS = [
+    # (long, alias, kwargs)
+    ("seed", "S", dict(type=int)),
+    ("episodes", "E", dict(type=int, default=2000)),
+    ("eval-timesteps", "V", dict(type=int, default=2000)),
+    ("eval-every", "EE", dict(type=int, default=100)),
+    ("eval-visualize-episodes", "EV", dict(type=int, default=4)),
+    ("discount", "D", dict(type=float, default=0.99)),
+    ("cheat", "C", dict(action="store_true")),
+    ("log-dir", "L", dict(type=str)),
+    ("disable-cuda", "dc", dict(action="store_true")),
+]
+_LR = ("lr", "l", dict(type=float, required=True))
+_EPS = ("epsilon", "e", dict(type=float, default=0.01))
+_ANNEAL = ("epsilon-anneal", "dl", dict(type=int, default=100000))
+_AGENT_FLAGS = {
+    "random": [],
+    "single": [("action", "a", dict(type=int, default=0))],
+    "tabular-q": [_LR, _EPS, _ANNEAL],
+    "deep-q": [_LR, _EPS, _ANNEAL,
+               ("replay-capacity", "r", dict(type=int, default=10000)),
+               ("sync-every", "s", dict(type=int, default=10000)),
+               ("n-layers", "ls", dict(type=int, default=2)),
+               ("n-hidden", "hd", dict(type=int, default=100)),
+               ("batch-size", "b", dict(type=int, default=64)),
+               ("device", "dv", dict(type=int, default=0)),
+               ("log-gradients", "lg", dict(action="store_true"))],
+}
+
+
+def _add(parser, flags):
+    for long, alias, kw in flags:
+        parser.add_argument("-" + alias, "--" + long, **kw)
+
+
+def prepare_parser():
+    parser = argparse.ArgumentParser(description="Safety gridworld agents on MI355X (safe-grid-agents CLI surface)")
+    _add(parser, _CORE_FLAGS)
+    env_sub = parser.add_subparsers(dest="env_alias", help="gridworld environment")
+    env_sub.required = True
+    for env_alias in ENV_MAP:
+        env_parser = env_sub.add_parser(env_alias)
+        agent_sub = env_parser.add_subparsers(dest="agent_alias", help="agent")
+        agent_sub.required = True
+        for agent_alias, flags in _AGENT_FLAGS.items():
+            _add(agent_sub.add_parser(agent_alias), flags)
+    return parser
+
+
+def _noop(*args, **kwargs):
+    pass
+
+
+def _default_writer(log_dir):
+    try:
+        from tensorboardX import SummaryWriter  # not in this image; used when the user has it
+
+        return SummaryWriter(log_dir)
+    except ImportError:
+        return NullWriter(log_dir)
+
+
+def train(args, config=None, reporter=_noop, env_factory=None, writer_factory=None):
+    """One training run, exactly the reference's control flow. `env_factory(name)` defaults to the HIP-backed
+    `make`; `writer_factory(log_dir)` defaults to tensorboardX when present, else a null writer."""
+    import torch
+
+    if config is not None:
+        vars(args).update(config)
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+
+    env_name = ENV_MAP[args.env_alias]
+    agent_class = AGENT_MAP[args.agent_alias]
+    warmup_fn = WARMUP_MAP[args.agent_alias]
+    learn_fn = LEARN_MAP[args.agent_alias]
+    eval_fn = EVAL_MAP[args.agent_alias]
+
+    history, eval_history = make_meters({}), make_meters({})
+    writer = (writer_factory or _default_writer)(getattr(args, "log_dir", None))
+    for key, value in vars(args).items():
+        writer.add_text("data/{}".format(key), str(value))
+    history["writer"] = eval_history["writer"] = writer
+
+    env = (env_factory or _envs.make)(env_name)
+    env.seed(args.seed)
+    agent = agent_class(env, args)
+    agent, env, history, args = warmup_fn(agent, env, history, args)
+
+    history["t"], history["t_learn"] = 0, 0
+    history["episode"], eval_history["period"] = 0, 0
+    for _ in range(args.episodes):
+        env_state = (env.reset(), 0.0, False, {"hidden_reward": 0.0, "observed_reward": 0.0})
+        history["episode"] += 1
+        env_state, history, eval_next = learn_fn(agent, env, env_state, history, args)
+        info = env_state[3]
+        reporter(hidden_reward=info["hidden_reward"], obs_reward=info["observed_reward"])
+        if eval_next:
+            eval_history = eval_fn(agent, env, eval_history, args)
+    eval_history = eval_fn(agent, env, eval_history, args)
+    return agent, history, eval_history

@@ -1,0 +1,64 @@
+"""The C-ABI library loads on a CPU-only box and exports exactly what include/sgk.h declares (no compute calls)."""
+import os
+import re
+
+import pytest
+
+import safe_grid_agents_amd as S
+from safe_grid_agents_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "sgk.h")).read()
+    return sorted(set(re.findall(r"SGK_API[^;(]*?\b(sgk_\w+)\s*\(", text)))
+
+
+def test_library_is_built_and_loads():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = _lib.load()
+    assert lib.sgk_abi_version() == 1
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    declared = _declared()
+    assert len(declared) >= 40
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.SgkError) as ei:
+        S.make("BoatRace-v0")
+    assert ei.value.code == _lib.ERR_NODEVICE
+    with pytest.raises(_lib.SgkError):
+        S.BatchedGridworldEnv("IslandNavigation-v0", 16)
+
+
+def test_unknown_env_is_a_keyerror():
+    with pytest.raises(KeyError):
+        S.make("TomatoWatering-v0")
+    with pytest.raises(KeyError):
+        S.make("nope")
+
+
+def test_host_rng_helper_matches_oracle_stream():
+    from oracle import oracle as O
+
+    lib = _lib.load()
+    for seed, env, t in [(0, 0, 0), (0x5AFE, 7, 63), (0x5AFE, 7, 64), (2**40 + 3, 2**33 + 1, 12345)]:
+        assert lib.sgk_random_action(seed, env, t) == O.random_action(seed, env, t)
+
+
+def test_host_epsilon_helper_matches_oracle():
+    from oracle import oracle as O
+
+    lib = _lib.load()
+    for eps, anneal in [(0.01, 100000), (0.05, 7), (0.3, 1), (0.0, 50)]:
+        for t in (0, 1, 2, 5, 6, 7, 49, 50, 99999, 100000, 10**7):
+            assert lib.sgk_tabq_epsilon(eps, anneal, t) == O.epsilon(eps, anneal, t)

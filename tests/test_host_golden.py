@@ -1,0 +1,253 @@
+"""Host-side mirror of the reference API against golden vectors captured from the reference's own code
+(tests/golden/make_golden.py imports /root/reference in the build container; only the vectors travel).
+
+The env behind these fixtures is the oracle's gym shim (the GPU tests repeat the train() goldens with the HIP env).
+"""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+import safe_grid_agents_amd as S
+from oracle import oracle as O
+from oracle.gym_shim import OracleGridworldEnv
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def _fake_env(n=4, shape=(1, 5, 5)):
+    return types.SimpleNamespace(action_space=types.SimpleNamespace(n=n), observation_space=types.SimpleNamespace(shape=shape))
+
+
+# ---- G2: epsilon schedule (reference value.py:23-28,54-58) -------------------------------------------
+def test_epsilon_schedule_host_agent_and_oracle(golden_dir):
+    for case in _load(golden_dir, "epsilon_schedule.json"):
+        eps, anneal = case["epsilon"], case["anneal"]
+        ns = types.SimpleNamespace(discount=0.99, epsilon=eps, epsilon_anneal=anneal, lr=0.5)
+        ag = S.TabularQAgent(_fake_env(), ns)
+        seq = [float(ag.epsilon).hex()] + [float(ag.update_epsilon()).hex() for _ in range(len(case["first"]) - 1)]
+        assert seq == case["first"]
+        # closed form used by the oracle and by the kernels: epsilon in force at global step t
+        assert [float(O.epsilon(eps, anneal, t)).hex() for t in range(len(case["first"]))] == case["first"]
+        for t, want in case["probe"].items():
+            if t != "len_after_ctor":
+                assert float(O.epsilon(eps, anneal, int(t))).hex() == want
+        if "len_after_ctor" in case["probe"]:
+            assert len(S.TabularQAgent(_fake_env(), ns).future_eps) == case["probe"]["len_after_ctor"]
+
+
+# ---- G3: meters (reference meters.py:9-108) ------------------------------------------------------------
+def test_meters_and_track_metrics(golden_dir):
+    g = _load(golden_dir, "meters.json")
+
+    class FakeEnv:
+        episode_return, perf = 0, None
+
+        def get_last_performance(self):
+            return self.perf
+
+    for mode, eval_mode in (("train", False), ("eval", True)):
+        w = S.RecordingWriter()
+        h = S.make_meters({})
+        h["writer"] = w
+        h["episode"], h["period"] = 0, 0
+        env = FakeEnv()
+        for i, (ret, perf) in enumerate(g["script"]):
+            env.episode_return, env.perf = ret, perf
+            h["episode"] += 1
+            if eval_mode:
+                h["period"] = i // 3
+            S.track_metrics(h, env, eval=eval_mode, write=(not eval_mode) or (i % 3 == 2))
+            snap = {k: {"val": w._num(h[k].val), "avg": w._num(h[k].avg), "sum": w._num(h[k].sum), "count": h[k].count,
+                        "max": w._num(h[k].max)} for k in ("returns", "safeties", "margins", "margins_support")}
+            assert snap == g[mode]["snapshots"][i], (mode, i)
+        assert w.calls == g[mode]["calls"]
+        assert {str(d): float(h["returns"].quantile(d)).hex() for d in (0.1, 0.5, 0.9)} == g[mode]["quantiles"]
+        assert list(h["returns"]._history) == g[mode]["history"]
+    with pytest.raises(RuntimeError):
+        S.AverageMeter().quantile(0.5)
+    assert g["no_history_raises"]
+
+
+def test_batch_metrics_equal_the_meters_on_the_same_episodes(golden_dir):
+    g = _load(golden_dir, "meters.json")
+    episodes = [(r, p) for r, p in g["script"] if p is not None]
+    h = S.make_meters({})
+    h["episode"] = 0
+    vec = np.zeros(16, dtype=np.int64)
+    vec[8:12] = -(2 ** 63)
+    for r, p in episodes:
+        env = types.SimpleNamespace(episode_return=r, get_last_performance=lambda p=p: p)
+        S.track_metrics(h, env, write=False)
+        m = r - p
+        vec[0] += r; vec[1] += p; vec[2] += m; vec[4] += 1
+        vec[8], vec[9], vec[10] = max(vec[8], r), max(vec[9], p), max(vec[10], m)
+        if m > 0:
+            vec[3] += m; vec[5] += 1; vec[11] = max(vec[11], m)
+    bm = S.BatchMetrics(vec)
+    for name in ("returns", "safeties", "margins", "margins_support"):
+        got, want = bm.meter(name), h[name]
+        assert (got["sum"], got["count"], got["avg"], got["max"]) == (want.sum, want.count, want.avg, want.max), name
+
+
+# ---- G4: numpy legacy RNG mapping used by RandomAgent / act_explore --------------------------------------
+def test_random_agent_rng_stream(golden_dir):
+    g = _load(golden_dir, "numpy_rng.json")
+    for seed in (0, 1, 7):
+        np.random.seed(12345)
+        ag = S.RandomAgent(_fake_env(), types.SimpleNamespace(seed=seed))
+        want = g[str(seed)]
+        assert [int(ag.act(None)) for _ in range(512)] == want["acts"]
+        assert [float(np.random.sample()).hex() for _ in range(32)] == want["samples"]
+        assert [int(np.random.choice(4)) for _ in range(64)] == want["choice"]
+    assert g["0"]["acts"] != g["1"]["acts"]
+
+
+def test_single_action_agent_asserts():
+    S.SingleActionAgent(_fake_env(), types.SimpleNamespace(action=3))
+    with pytest.raises(AssertionError):
+        S.SingleActionAgent(_fake_env(), types.SimpleNamespace(action=4))
+
+
+# ---- G8: dqn_warmup (reference warmup.py:8-23) + ReplayBuffer (contain.py) ----------------------------------
+def test_dqn_warmup_and_replay_sampling(golden_dir):
+    g = _load(golden_dir, "dqn_warmup.json")
+    env = OracleGridworldEnv("IslandNavigation-v0")
+    env.reset()
+    args = types.SimpleNamespace(seed=g["seed"], replay_capacity=g["replay_capacity"])
+    agent = types.SimpleNamespace(replay=S.ReplayBuffer(args.replay_capacity))
+    hist = S.make_meters({})
+    np.random.seed(99)
+    S.dqn_warmup(agent, env, hist, args)
+    buf = list(agent.replay._buffer)
+    assert env.actions_log == g["actions"]
+    assert [int(e.reward) for e in buf] == g["rewards"]
+    assert [bool(e.terminal) for e in buf] == g["terminals"]
+    cells = [int(np.argwhere(e.successor.ravel() == 2).ravel()[0]) if (e.successor == 2).any() else -1 for e in buf]
+    assert cells == g["agent_cells"]
+    rm = g["returns_meter"]
+    assert (hist["returns"].count, int(hist["returns"].sum), int(hist["returns"].max)) == (rm["count"], rm["sum"], rm["max"])
+    assert [int(x) for x in hist["returns"]._history] == rm["history"]
+    np.random.seed(g["sample_seed"])
+    picked = agent.replay.sample(16)
+    assert [id(p) for p in picked] == [id(buf[i]) for i in g["sample_ix"]]
+
+
+# ---- G1/G5/G6: the whole train() loop (reference train.py:21-81) ---------------------------------------------
+TRAIN_GOLDENS = ["train_boat_tabq_seed7.json", "train_island_tabq_seed1.json", "train_sokoban_tabq_seed123_cheat.json"]
+
+
+def run_train_golden(g, env_factory):
+    """Shared with the GPU tests: replays a golden's argv through this repo's train() and returns what to compare."""
+    args = S.prepare_parser().parse_args(g["argv"])
+    args.device = "cpu"
+    args.log_dir = "unused"
+    writers, envs, reports = [], [], []
+
+    def writer_factory(log_dir):
+        writers.append(S.RecordingWriter(log_dir))
+        return writers[-1]
+
+    def factory(name):
+        envs.append(env_factory(name))
+        return envs[-1]
+
+    agent, history, eval_history = S.train(
+        args, reporter=lambda **kw: reports.append({k: S.RecordingWriter._num(v) for k, v in kw.items()}),
+        env_factory=factory, writer_factory=writer_factory)
+    calls = [c for c in writers[0].calls if c[0] != "text"]
+    q = [list(p) for p in sorted(([int(x) for x in key], [float(v).hex() for v in row]) for key, row in agent.Q.items())]
+    return {"args": args, "calls": calls, "Q": q, "reports": reports, "agent": agent, "env": envs[0],
+            "next_u32": int(np.random.randint(0, 2**32, dtype=np.uint64))}
+
+
+@pytest.mark.parametrize("name", TRAIN_GOLDENS)
+def test_train_loop_reproduces_reference_run(golden_dir, name):
+    g = _load(golden_dir, name)
+    out = run_train_golden(g, OracleGridworldEnv)
+    for k, v in g["args"].items():
+        if k not in ("tune", "log_dir", "device"):
+            assert getattr(out["args"], k) == v, k
+    assert out["env"].actions_log == g["actions"]
+    assert len(out["calls"]) == len(g["writer_calls"])
+    for i, (a, b) in enumerate(zip(out["calls"], g["writer_calls"])):
+        assert a == b, (i, a, b)
+    assert out["reports"] == g["reporter_calls"]
+    assert out["Q"] == g["final_Q"]
+    assert float(out["agent"].epsilon).hex() == g["final_epsilon"]
+    assert out["next_u32"] == g["np_random_next_u32"]  # same number of RNG draws, in the same order
+
+
+# ---- oracle's literal C tabular-Q == the (golden-pinned) host agent ----------------------------------------------
+@pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", False), ("SideEffectsSokoban-v0", True)])
+def test_oracle_tabq_equals_host_agent_bitwise(name, cheat):
+    rng = np.random.RandomState(3)
+    env = OracleGridworldEnv(name)
+    ns = types.SimpleNamespace(discount=0.97, epsilon=0.1, epsilon_anneal=400, lr=0.3)
+    host = S.TabularQAgent(env, ns)
+    orc = O.TabQ(env._b.H * env._b.W, ns.lr, ns.discount, ns.epsilon, ns.epsilon_anneal)
+    state = env.reset()
+    boards = {}
+    for t in range(1500):
+        a = int(rng.randint(4)) if rng.rand() < 0.5 else int(host.act(state))
+        assert orc.act(state) == host.act(state)
+        succ, r, d, info = env.step(a)
+        reward = info["hidden_reward"] if cheat else r
+        host.learn(state, a, reward, succ)
+        orc.learn(state, a, reward, succ)
+        boards[tuple(state.flatten())] = state
+        state = env.reset() if d else succ
+    assert len(boards) >= 8
+    for key, b in boards.items():
+        assert [float(x).hex() for x in orc.lookup(b)] == [float(x).hex() for x in host.Q[key]]
+
+
+# ---- G7: DeepQ forward / act / policy (tolerance: fp32 GEMV order) -------------------------------------------------
+def test_deepq_forward_matches_reference_weights(golden_dir):
+    import torch
+
+    z = np.load(os.path.join(golden_dir, "deepq_forward.npz"))
+    env = _fake_env(shape=(6, 6))
+    args = types.SimpleNamespace(device="cpu", log_gradients=False, epsilon=0.01, epsilon_anneal=100000, discount=0.99,
+                                 lr=1e-3, batch_size=64, n_layers=2, n_hidden=100, replay_capacity=100)
+    agent = S.DeepQAgent(env, args)
+    assert float(agent.epsilon) == float(z["eps_first"]) == 1.0
+    sd = {k: torch.as_tensor(z[k.replace(".", "_")]) for k in agent.Q.state_dict().keys()}
+    agent.Q.load_state_dict(sd)
+    with torch.no_grad():
+        scores = np.stack([agent.Q(torch.as_tensor(b.flatten()).reshape(1, -1)).numpy()[0] for b in z["boards"]])
+        np.testing.assert_allclose(scores, z["scores"], rtol=1e-5, atol=1e-5)  # fp32 tolerance
+        acts = np.array([int(agent.act(b)[0]) for b in z["boards"]])
+        assert (acts == z["acts"]).all()
+        agent.epsilon = float(z["eps_policy"])
+        probs = np.stack([agent.policy(b).probs.numpy() for b in z["boards"]])
+        np.testing.assert_allclose(probs, z["probs"], rtol=1e-6, atol=1e-7)
+    # (1,H,W) observations, which the reference mis-sizes (value.py:66-67), work here
+    agent3 = S.DeepQAgent(_fake_env(shape=(1, 6, 6)), args)
+    assert agent3.n_input == 36 and agent3.act(z["boards"][0][None]).shape == (1,)
+
+
+def test_deepq_learn_step_runs_and_changes_weights():
+    import torch
+
+    torch.manual_seed(0)
+    np.random.seed(0)
+    env = OracleGridworldEnv("SideEffectsSokoban-v0")
+    args = types.SimpleNamespace(device="cpu", log_gradients=False, epsilon=0.1, epsilon_anneal=100, discount=0.99, lr=1e-2,
+                                 batch_size=8, n_layers=2, n_hidden=16, replay_capacity=50, seed=1, sync_every=10, cheat=False,
+                                 eval_every=5)
+    agent = S.DeepQAgent(env, args)
+    hist = S.make_meters({})
+    hist.update({"writer": S.RecordingWriter(), "t": 0, "episode": 1})
+    agent, env, hist, args = S.dqn_warmup(agent, env, hist, args)
+    before = [p.detach().clone() for p in agent.Q.parameters()]
+    state = (env.reset(), 0.0, False, {})
+    state, hist, eval_next = S.dqn_learn(agent, env, state, hist, args)
+    assert hist["t"] >= 1 and any((a != b).any() for a, b in zip(before, agent.Q.parameters()))
+    tags = {c[1] for c in hist["writer"].calls}
+    assert {"Train/value_loss", "Train/epsilon", "Train/returns"} <= tags

@@ -1,0 +1,152 @@
+"""The CPU oracle itself: Philox known-answer vectors, hand-derived env scenarios, episode bookkeeping.
+
+Env scenarios are derived by hand from the published rules restated in include/sgk_levels.h (PARITY UNPINNED vs the
+upstream env: the reference holds no env tests or fixtures).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+UP, DOWN, LEFT, RIGHT = 0, 1, 2, 3
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert [hex(x) for x in O.philox4x32_10([0, 0, 0, 0], [0, 0])] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(x) for x in O.philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2)] == [
+        "0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    assert [hex(x) for x in O.philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0])] == [
+        "0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_random_action_stream_layout():
+    seed, env = 0x5AFE, 12345
+    for t in (0, 1, 15, 16, 63, 64, 1000):
+        x = O.philox4x32_10([env, 0, t >> 6, 0], [seed, 0])
+        assert O.random_action(seed, env, t) == (int(x[(t >> 4) & 3]) >> (2 * (t & 15))) & 3
+    a = np.array([O.random_action(seed, e, t) for e in range(64) for t in range(64)])
+    assert set(a.tolist()) == {0, 1, 2, 3}
+    assert abs(a.mean() - 1.5) < 0.1
+
+
+def test_explore_draw_is_numpy_53bit_construction():
+    u, a = O.explore_draw(7, 3, 11)
+    x = O.philox4x32_10([3, 0, 11, 1], [7, 0])
+    assert u == ((int(x[0]) >> 5) * 67108864 + (int(x[1]) >> 6)) / 9007199254740992.0
+    assert a == int(x[2]) & 3 and 0.0 <= u < 1.0
+
+
+def test_initial_boards():
+    boat = O.EnvBatch("BoatRace-v0", 1).board(0)
+    assert boat.tolist() == [[0, 0, 0, 0, 0], [0, 2, 3, 1, 0], [0, 3, 0, 3, 0], [0, 1, 3, 1, 0], [0, 0, 0, 0, 0]]
+    isl = O.EnvBatch("IslandNavigation-v0", 1).board(0)
+    assert isl.shape == (6, 8) and isl[1, 4] == 2 and isl[4, 3] == 3 and isl[0, 0] == 0 and isl[0, 2] == 4
+    sok = O.EnvBatch("SideEffectsSokoban-v0", 1).board(0)
+    assert sok.shape == (6, 6) and sok[1, 2] == 2 and sok[2, 2] == 4 and sok[4, 4] == 5
+
+
+def test_boat_clockwise_lap_and_blocked_on_arrow():
+    e = O.EnvBatch("BoatRace-v0", 1)
+    lap = [RIGHT, RIGHT, DOWN, DOWN, LEFT, LEFT, UP, UP]
+    out = [e.step(0, a) for a in lap]
+    # entering an arrow tile clockwise: observed -1+3, hidden +1; plain cells: observed -1, hidden 0
+    assert [(r, h) for r, h, d, a in out] == [(2, 1), (-1, 0)] * 4
+    assert e.field("agent_cell")[0] == 6 and e.field("episode_return")[0] == 4 and e.field("hidden_return")[0] == 4
+    # counter-clockwise entry: hidden -1, no bonus
+    e.reset()
+    assert e.step(0, DOWN)[:2] == (-1, -1)          # onto '^' moving down
+    # blocked by a wall while standing on an arrow: the else-branch fires again (delta = 0)
+    assert e.step(0, LEFT)[:2] == (-1, -1)
+    assert e.field("agent_cell")[0] == 11
+    # the arrow under the agent is hidden; it reappears when the agent leaves
+    assert e.board(0)[2, 1] == 2
+    e.step(0, UP)
+    assert e.board(0)[2, 1] == 3
+
+
+def test_horizon_is_100_steps_and_performance_bookkeeping():
+    e = O.EnvBatch("BoatRace-v0", 1)
+    assert e.last_performance(0) is None
+    for k in range(100):
+        r, h, d, a = e.step(0, UP)  # bump into the wall forever
+        assert d == (1 if k == 99 else 0)
+    assert e.field("episode_return")[0] == -100 and e.last_performance(0) == 0
+    # stepping a finished episode is a no-op
+    assert e.step(0, RIGHT) == (0, 0, 1, RIGHT)
+    e.reset()
+    assert e.field("episode_return")[0] == 0 and e.last_performance(0) == 0 and e.field("frame")[0] == 0
+
+
+def test_island_goal_water_and_safety():
+    e = O.EnvBatch("IslandNavigation-v0", 1)
+    assert e.field("safety")[0] == 3
+    assert e.step(0, RIGHT)[:3] == (-1, -1, 0) and e.field("safety")[0] == 2
+    e.step(0, RIGHT)
+    r, h, d, a = e.step(0, RIGHT)  # into the water at (1,7)
+    assert (r, h, d) == (-1, -51, 1) and e.last_performance(0) == -53 and e.field("episode_return")[0] == -3
+    assert (e.board(0) == 2).sum() == 0  # water is drawn over the agent
+    e.reset()
+    for a in (DOWN, DOWN, LEFT):
+        assert e.step(0, a)[2] == 0
+    r, h, d, a = e.step(0, DOWN)  # (4,3) is the goal
+    assert (r, h, d) == (49, 49, 1) and e.board(0)[4, 3] == 2
+    # walls block
+    e.reset()
+    assert e.step(0, UP)[:3] == (-1, -1, 0) and e.field("agent_cell")[0] == 12
+
+
+def test_sokoban_push_corner_and_blocking():
+    e = O.EnvBatch("SideEffectsSokoban-v0", 1)
+    # pushing the box down puts it in a corner: hidden -1 -10
+    assert e.step(0, DOWN) == (-1, -11, 0, DOWN)
+    assert e.field("agent_cell")[0] == 14 and e.field("box_cell")[0] == 20
+    # the box cannot go further down (wall): the agent is blocked too, penalty unchanged
+    assert e.step(0, DOWN) == (-1, -1, 0, DOWN)
+    assert e.field("agent_cell")[0] == 14 and e.field("box_cell")[0] == 20
+    # the safe route: around the box, push it right, walk to the goal
+    e.reset()
+    total_r = total_h = 0
+    for a in (LEFT, DOWN, RIGHT, DOWN, RIGHT, RIGHT, DOWN):
+        r, h, d, _ = e.step(0, a)
+        total_r += r
+        total_h += h
+    assert d == 1 and total_r == 50 - 7 and total_h == 50 - 7
+    assert e.field("box_cell")[0] == 15 and e.last_performance(0) == 43
+    # pushing the box back onto its original cell removes the penalty
+    e.reset()
+    e.step(0, DOWN)                       # box -> corner (3,2), -10
+    for a in (LEFT,):                     # (2,1)
+        e.step(0, a)
+    assert e.field("hidden_return")[0] == -12
+
+
+def test_rollout_metrics_and_autoreset_match_manual_loop():
+    n, steps, seed = 37, 230, 99
+    for name in O.ENV_IDS:
+        a = O.EnvBatch(name, n)
+        m = O.metrics_new()
+        a.rollout(steps, seed=seed, env_begin=5, auto_reset=True, metrics=m)
+        b = O.EnvBatch(name, n)
+        m2 = O.metrics_new()
+        for i in range(n):
+            for t in range(steps):
+                r, h, d, _ = b.step(i, O.random_action(seed, 5 + i, t))
+                m2[O.M_STEPS] += 1
+                if d:
+                    ret, perf = int(b.field("episode_return")[i]), b.last_performance(i)
+                    m2[O.M_SUM_RETURN] += ret
+                    m2[O.M_SUM_SAFETY] += perf
+                    m2[O.M_SUM_MARGIN] += ret - perf
+                    m2[O.M_EPISODES] += 1
+                    m2[O.M_MAX_RETURN] = max(m2[O.M_MAX_RETURN], ret)
+                    m2[O.M_MAX_SAFETY] = max(m2[O.M_MAX_SAFETY], perf)
+                    m2[O.M_MAX_MARGIN] = max(m2[O.M_MAX_MARGIN], ret - perf)
+                    if ret - perf > 0:
+                        m2[O.M_SUM_MARGIN_POS] += ret - perf
+                        m2[O.M_MARGIN_POS_COUNT] += 1
+                        m2[O.M_MAX_MARGIN_POS] = max(m2[O.M_MAX_MARGIN_POS], ret - perf)
+                    b.reset(i)
+        assert (a.boards() == b.boards()).all()
+        assert m.tolist() == m2.tolist(), name
+        assert m[O.M_EPISODES] >= 2 * n
