@@ -35,10 +35,6 @@ int hip_fail(hipError_t e, const char *what) {
 
 __global__ void set_counter_kernel(uint64_t *ctr, uint64_t v) { *ctr = v; }
 __global__ void add_counter_kernel(uint64_t *ctr, uint64_t v) { *ctr += v; }
-__global__ void init_metrics_kernel(int64_t *m) {
-  int i = threadIdx.x;
-  if (i < SGK_METRICS_LEN) m[i] = (i >= SGK_M_MAX_RETURN && i <= SGK_M_MAX_MARGIN_POS) ? INT64_MIN : 0;
-}
 
 }  // namespace
 
@@ -114,7 +110,7 @@ int sgk_destroy(sgk_env *h) {
   for (auto &kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   sgk::Shard &s = h->sh;
   (void)hipFree(s.rules_dev); (void)hipFree(s.state); (void)hipFree(s.rec); (void)hipFree(s.boards); (void)hipFree(s.last_return);
-  (void)hipFree(s.last_perf); (void)hipFree(s.n_episodes); (void)hipFree(s.metrics); (void)hipFree(s.wg_count); (void)hipFree(s.wg_offset);
+  (void)hipFree(s.last_perf); (void)hipFree(s.n_episodes); (void)hipFree(s.metrics); (void)hipFree(s.metric_slab); (void)hipFree(s.wg_count); (void)hipFree(s.wg_offset);
   (void)hipFree(s.finished_total); (void)hipFree(h->t_dev); (void)hipFree(h->dense_scratch);
   (void)hipFree(h->actions_scratch);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -183,6 +179,8 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(hipMalloc(&s.last_perf, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.n_episodes, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.metrics, sizeof(int64_t) * SGK_METRICS_LEN));
+  SGK_TRY(hipMalloc(&s.metric_slab, sizeof(int64_t) * SGK_METRICS_LEN * SGK_METRIC_SLOTS));
+  if (s.max_grid > SGK_METRIC_SLOTS) s.max_grid = SGK_METRIC_SLOTS;
   SGK_TRY(hipMalloc(&s.wg_count, sizeof(int32_t) * n_wg));
   SGK_TRY(hipMalloc(&s.wg_offset, sizeof(int64_t) * n_wg));
   SGK_TRY(hipMalloc(&s.finished_total, sizeof(int64_t)));
@@ -193,8 +191,8 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(hipMemsetAsync(s.last_perf, 0, sizeof(int32_t) * n_pad, h->stream));
   SGK_TRY(hipMemsetAsync(s.n_episodes, 0, sizeof(int32_t) * n_pad, h->stream));
   SGK_TRY(hipMemsetAsync(s.state, 0, sizeof(uint64_t) * n_pad, h->stream));
-  hipLaunchKernelGGL(init_metrics_kernel, dim3(1), dim3(64), 0, h->stream, s.metrics);
-  SGK_TRY(hipGetLastError());
+  SGK_TRY(sgk::launch_metrics_init(s, h->stream));
+  SGK_TRY(sgk::launch_metrics_reduce(s, h->stream));
   SGK_TRY(sgk::launch_reset(s, nullptr, 0, h->stream));  // gym.make leaves the env ready; reset() is still idempotent
   SGK_TRY(hipStreamSynchronize(h->stream));
 #undef SGK_TRY
@@ -364,6 +362,8 @@ int sgk_step_records_dev(sgk_env *h, sgk_step_rec **rec_dev) {
 
 int sgk_metrics_dev(sgk_env *h, int64_t **metrics_dev) {
   if (!h || !metrics_dev) return fail(SGK_ERR_INVALID, "NULL argument");
+  SGK_HIP(hipSetDevice(h->sh.device));
+  SGK_HIP(sgk::launch_metrics_reduce(h->sh, h->stream));  // folds the per-workgroup partials; stream-ordered
   *metrics_dev = h->sh.metrics;
   return SGK_OK;
 }
@@ -439,6 +439,7 @@ int sgk_copy_last_episode(sgk_env *h, int32_t *last_return_host, int32_t *last_p
 int sgk_metrics(sgk_env *h, int64_t out_host[SGK_METRICS_LEN]) {
   SGK_CHECK_HANDLE(h);
   if (!out_host) return fail(SGK_ERR_INVALID, "out_host is NULL");
+  SGK_HIP(sgk::launch_metrics_reduce(h->sh, h->stream));
   SGK_HIP(hipMemcpyAsync(out_host, h->sh.metrics, sizeof(int64_t) * SGK_METRICS_LEN, hipMemcpyDeviceToHost, h->stream));
   SGK_HIP(hipStreamSynchronize(h->stream));
   out_host[SGK_M_STEPS] = h->steps_issued;
@@ -447,8 +448,7 @@ int sgk_metrics(sgk_env *h, int64_t out_host[SGK_METRICS_LEN]) {
 
 int sgk_metrics_reset(sgk_env *h) {
   SGK_CHECK_HANDLE(h);
-  hipLaunchKernelGGL(init_metrics_kernel, dim3(1), dim3(64), 0, h->stream, h->sh.metrics);
-  SGK_HIP(hipGetLastError());
+  SGK_HIP(sgk::launch_metrics_init(h->sh, h->stream));
   h->steps_issued = 0;
   return SGK_OK;
 }

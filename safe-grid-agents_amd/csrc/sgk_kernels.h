@@ -6,6 +6,8 @@
 #include "../../include/sgk.h"
 #include "sgk_rules.h"
 
+#define SGK_METRIC_SLOTS 2048
+
 namespace sgk {
 
 // Device-resident arrays of one shard (N envs on one GPU). Structure-of-arrays over envs.
@@ -23,7 +25,8 @@ struct Shard {
   int32_t *last_return = nullptr; // [n] episode_return of the last finished episode
   int32_t *last_perf = nullptr;   // [n] get_last_performance()
   int32_t *n_episodes = nullptr;  // [n]
-  int64_t *metrics = nullptr;     // [SGK_METRICS_LEN]
+  int64_t *metrics = nullptr;     // [SGK_METRICS_LEN] reduced vector (valid after launch_metrics_reduce)
+  int64_t *metric_slab = nullptr; // [SGK_METRIC_SLOTS][SGK_METRICS_LEN] per-workgroup partials
   int32_t *wg_count = nullptr;    // compaction scratch
   int64_t *wg_offset = nullptr;
   int64_t *finished_total = nullptr;
@@ -41,6 +44,8 @@ hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, 
 hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flags, hipStream_t st);
 // mode 0: reset all (mask == nullptr) or masked envs; 1: reset envs whose episode is over; 2: re-materialise boards only
 hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st);
+hipError_t launch_metrics_init(const Shard &sh, hipStream_t st);
+hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st);
 hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st);
 hipError_t launch_dense_boards(const Shard &sh, int8_t *dst, hipStream_t st);
 hipError_t launch_finished(const Shard &sh, int32_t *ids, int32_t *ret, int32_t *perf, hipStream_t st);

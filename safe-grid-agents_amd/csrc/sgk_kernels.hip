@@ -18,6 +18,7 @@
 //  * HBM-bound integer work: no MFMA anywhere.
 //  * episode ends: wave ballot -> wave-level integer reduction -> one int64 atomic per wave and quantity.
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 
 #include "sgk_kernels.h"
@@ -174,31 +175,92 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
-__device__ __forceinline__ void record_episodes(bool finished, int ret, int perf, long long *__restrict__ metrics) {
-  unsigned long long mask = __ballot(finished);
-  if (mask == 0ull) return;  // wave-uniform
-  const int NEG = -(1 << 30);
-  int margin = ret - perf;
-  bool pos = finished && margin > 0;
-  int s_ret = wave_sum(finished ? ret : 0);
-  int s_perf = wave_sum(finished ? perf : 0);
-  int s_mpos = wave_sum(pos ? margin : 0);
-  int n_pos = wave_sum(pos ? 1 : 0);
-  int m_ret = wave_max(finished ? ret : NEG);
-  int m_perf = wave_max(finished ? perf : NEG);
-  int m_margin = wave_max(finished ? margin : NEG);
-  int m_mpos = wave_max(pos ? margin : NEG);
+__device__ __forceinline__ long long wave_sum64(long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Per-lane accumulators of the episodes a lane finished during one launch. Nothing is exchanged while stepping;
+// flush() runs once per launch: wave reduction (skipped by waves that finished nothing), then one add per quantity
+// into the WORKGROUP'S OWN slot of the metrics slab (SGK_METRIC_SLOTS x 16 int64). Slots are summed / max-ed when
+// the host reads the metrics. One address per workgroup instead of one address for the whole chip: same-address
+// atomics from 16 K waves cost ~1.2 ms per step on MI355X (profiles/r01_*), this costs nothing measurable.
+struct EpisodeAcc {
+  int s_ret, s_perf, s_mpos, n_eps, n_pos;
+  int m_ret, m_perf, m_margin, m_mpos;
+};
+constexpr int ACC_NEG = -(1 << 30);
+
+__device__ __forceinline__ void acc_init(EpisodeAcc &a) {
+  a.s_ret = a.s_perf = a.s_mpos = a.n_eps = a.n_pos = 0;
+  a.m_ret = a.m_perf = a.m_margin = a.m_mpos = ACC_NEG;
+}
+
+__device__ __forceinline__ void acc_add(EpisodeAcc &a, bool finished, int ret, int perf) {
+  if (finished) {
+    int margin = ret - perf;
+    a.s_ret += ret;
+    a.s_perf += perf;
+    a.n_eps += 1;
+    a.m_ret = max(a.m_ret, ret);
+    a.m_perf = max(a.m_perf, perf);
+    a.m_margin = max(a.m_margin, margin);
+    if (margin > 0) {
+      a.s_mpos += margin;
+      a.n_pos += 1;
+      a.m_mpos = max(a.m_mpos, margin);
+    }
+  }
+}
+
+// must be reached by all 64 lanes of the wave
+__device__ __forceinline__ void acc_flush(const EpisodeAcc &a, long long *__restrict__ slab) {
+  if (__ballot(a.n_eps > 0) == 0ull) return;  // wave-uniform
+  long long s_ret = wave_sum64(a.s_ret), s_perf = wave_sum64(a.s_perf), s_mpos = wave_sum64(a.s_mpos);
+  long long n_eps = wave_sum64(a.n_eps), n_pos = wave_sum64(a.n_pos);
+  int m_ret = wave_max(a.m_ret), m_perf = wave_max(a.m_perf), m_margin = wave_max(a.m_margin), m_mpos = wave_max(a.m_mpos);
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd((unsigned long long *)&metrics[SGK_M_SUM_RETURN], (unsigned long long)(long long)s_ret);
-    atomicAdd((unsigned long long *)&metrics[SGK_M_SUM_SAFETY], (unsigned long long)(long long)s_perf);
-    atomicAdd((unsigned long long *)&metrics[SGK_M_SUM_MARGIN], (unsigned long long)(long long)(s_ret - s_perf));
-    atomicAdd((unsigned long long *)&metrics[SGK_M_SUM_MARGIN_POS], (unsigned long long)(long long)s_mpos);
-    atomicAdd((unsigned long long *)&metrics[SGK_M_EPISODES], (unsigned long long)__popcll(mask));
-    atomicAdd((unsigned long long *)&metrics[SGK_M_MARGIN_POS_COUNT], (unsigned long long)(long long)n_pos);
-    atomicMax(&metrics[SGK_M_MAX_RETURN], (long long)m_ret);
-    atomicMax(&metrics[SGK_M_MAX_SAFETY], (long long)m_perf);
-    atomicMax(&metrics[SGK_M_MAX_MARGIN], (long long)m_margin);
-    if (n_pos > 0) atomicMax(&metrics[SGK_M_MAX_MARGIN_POS], (long long)m_mpos);
+    long long *slot = slab + (size_t)(blockIdx.x % SGK_METRIC_SLOTS) * SGK_METRICS_LEN;
+    atomicAdd((unsigned long long *)&slot[SGK_M_SUM_RETURN], (unsigned long long)s_ret);
+    atomicAdd((unsigned long long *)&slot[SGK_M_SUM_SAFETY], (unsigned long long)s_perf);
+    atomicAdd((unsigned long long *)&slot[SGK_M_SUM_MARGIN], (unsigned long long)(s_ret - s_perf));
+    atomicAdd((unsigned long long *)&slot[SGK_M_SUM_MARGIN_POS], (unsigned long long)s_mpos);
+    atomicAdd((unsigned long long *)&slot[SGK_M_EPISODES], (unsigned long long)n_eps);
+    atomicAdd((unsigned long long *)&slot[SGK_M_MARGIN_POS_COUNT], (unsigned long long)n_pos);
+    atomicMax(&slot[SGK_M_MAX_RETURN], (long long)m_ret);
+    atomicMax(&slot[SGK_M_MAX_SAFETY], (long long)m_perf);
+    atomicMax(&slot[SGK_M_MAX_MARGIN], (long long)m_margin);
+    if (n_pos > 0) atomicMax(&slot[SGK_M_MAX_MARGIN_POS], (long long)m_mpos);
+  }
+}
+
+// slab -> one metrics vector (sums over slots for [0..7], maxima for [8..11]); one workgroup
+__global__ __launch_bounds__(WG) void metrics_reduce_kernel(const long long *__restrict__ slab, long long *__restrict__ out) {
+  __shared__ long long part[WG];
+  const int col = threadIdx.x & 15, lane_slot = threadIdx.x >> 4;  // 16 columns x 16 slot-lanes
+  const bool is_max = col >= SGK_M_MAX_RETURN && col <= SGK_M_MAX_MARGIN_POS;
+  long long acc = is_max ? LLONG_MIN : 0;
+  for (int sl = lane_slot; sl < SGK_METRIC_SLOTS; sl += 16) {
+    long long v = slab[(size_t)sl * SGK_METRICS_LEN + col];
+    acc = is_max ? max(acc, v) : acc + v;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    long long r = part[threadIdx.x];
+    for (int k = 1; k < 16; ++k) {
+      long long v = part[k * 16 + threadIdx.x];
+      r = is_max ? max(r, v) : r + v;
+    }
+    out[threadIdx.x] = r;
+  }
+}
+
+__global__ __launch_bounds__(WG) void metrics_init_kernel(long long *__restrict__ slab) {
+  for (int i = blockIdx.x * WG + threadIdx.x; i < SGK_METRIC_SLOTS * SGK_METRICS_LEN; i += gridDim.x * WG) {
+    int col = i & 15;
+    slab[i] = (col >= SGK_M_MAX_RETURN && col <= SGK_M_MAX_MARGIN_POS) ? LLONG_MIN : 0;
   }
 }
 
@@ -323,8 +385,7 @@ struct StepArgs {
 
 template <int ENV>
 __device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, int64_t env, bool valid, int action,
-                                         EnvState &s, uint32_t &rec) {
-  // all 64 lanes of the wave arrive here (record_episodes uses wave-wide operations)
+                                         EnvState &s, uint32_t &rec, EpisodeAcc &acc) {
   bool finished = false;
   int r_obs = 0, r_hid = 0;
   if (valid && !s.over) {
@@ -337,13 +398,11 @@ __device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, i
   }
   int done = (valid && (s.over || finished)) ? 1 : 0;
   rec = pack_rec(r_obs, r_hid, done, action);
+  acc_add(acc, finished, s.ret, s.hid);
   if (finished) {
     a.last_return[env] = s.ret;
     a.last_perf[env] = s.hid;
     a.n_episodes[env] += 1;
-  }
-  record_episodes(finished, s.ret, s.hid, a.metrics);
-  if (finished) {
     if (a.flags & SGK_F_AUTO_RESET) s = initial_state(R);
     else s.over = 1;
   }
@@ -359,6 +418,8 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
   const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
   const uint64_t t_now = a.t_ptr ? (*a.t_ptr + a.t) : a.t;
   const int64_t n_tiles = (a.n + WG - 1) / WG;
+  EpisodeAcc acc;
+  acc_init(acc);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t env = tile * WG + threadIdx.x;
     const bool valid = env < a.n;
@@ -377,7 +438,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
       }
     }
     uint32_t rec;
-    step_one<ENV>(R, a, env, valid, action, s, rec);
+    step_one<ENV>(R, a, env, valid, action, s, rec, acc);
     if (valid) {
       a.state[env] = pack_state(s);
       a.rec[env] = rec;
@@ -387,6 +448,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
       else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
     }
   }
+  acc_flush(acc, a.metrics);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -401,6 +463,8 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
   if (COMPACT) stage_rotations(C, R);
   const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
   const int64_t n_tiles = (a.n + WG - 1) / WG;
+  EpisodeAcc acc;
+  acc_init(acc);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t env = tile * WG + threadIdx.x;
     const bool valid = env < a.n;
@@ -415,7 +479,7 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
         philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)a.seed,
                       (uint32_t)(a.seed >> 32), x);
       int action = action_from_block(x, t);
-      step_one<ENV>(R, a, env, valid, action, s, rec);
+      step_one<ENV>(R, a, env, valid, action, s, rec, acc);
     }
     if (valid) {
       a.state[env] = pack_state(s);
@@ -426,6 +490,7 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
       else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
     }
   }
+  acc_flush(acc, a.metrics);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -681,6 +746,8 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
   const int lane = threadIdx.x;
   const int S4 = a.n_states * 4;
   const int64_t n_groups = (a.n + 63) / 64;
+  EpisodeAcc acc;
+  acc_init(acc);
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     const int64_t env0 = g * 64;
     const int64_t env = env0 + lane;
@@ -739,13 +806,11 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
           if (action == 0) n0 = q_new; else if (action == 1) n1 = q_new; else if (action == 2) n2 = q_new; else n3 = q_new;
         }
       }
-      if (finished) {
+      acc_add(acc, finished, s.ret, s.hid);
+      if (finished) {  // train.py:62-70: the next episode starts from env.reset()
         a.last_return[env] = s.ret;
         a.last_perf[env] = s.hid;
         a.n_episodes[env] += 1;
-      }
-      record_episodes(finished, s.ret, s.hid, a.metrics);
-      if (finished) {  // train.py:62-70: the next episode starts from env.reset()
         s = initial_state(R);
         si = state_index<ENV>(R, s);
         n0 = Q[(si * 4 + 0) * 64 + lane]; n1 = Q[(si * 4 + 1) * 64 + lane];
@@ -768,6 +833,7 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
     }
     __syncthreads();
   }
+  acc_flush(acc, a.metrics);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -811,7 +877,7 @@ static StepArgs make_step_args(const Shard &sh, const uint8_t *actions, uint32_t
   a.last_return = sh.last_return;
   a.last_perf = sh.last_perf;
   a.n_episodes = sh.n_episodes;
-  a.metrics = (long long *)sh.metrics;
+  a.metrics = (long long *)sh.metric_slab;
   a.n = sh.n;
   a.seed = sh.seed;
   a.env_base = sh.env_base;
@@ -857,6 +923,16 @@ hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStrea
   return hipGetLastError();
 }
 
+hipError_t launch_metrics_init(const Shard &sh, hipStream_t st) {
+  metrics_init_kernel<<<dim3(32), dim3(WG), 0, st>>>((long long *)sh.metric_slab);
+  return hipGetLastError();
+}
+
+hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st) {
+  metrics_reduce_kernel<<<dim3(1), dim3(WG), 0, st>>>((const long long *)sh.metric_slab, (long long *)sh.metrics);
+  return hipGetLastError();
+}
+
 hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st) {
   int64_t total = sh.n * ((sh.n_cells + 3) / 4);
   int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
@@ -889,7 +965,7 @@ static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t fl
   a.last_return = sh.last_return;
   a.last_perf = sh.last_perf;
   a.n_episodes = sh.n_episodes;
-  a.metrics = (long long *)sh.metrics;
+  a.metrics = (long long *)sh.metric_slab;
   a.table = tq.table;
   a.s_prev = tq.s_prev;
   a.n = sh.n;

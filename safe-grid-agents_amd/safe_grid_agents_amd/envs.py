@@ -122,6 +122,9 @@ class BatchedGridworldEnv:
         self._env = self  # track_metrics looks for env._env (reference meters.py:67-70)
         self._views = None
         self._finished_bufs = None
+        self._tstream = None
+        self._bound = False
+        self._events = None
 
     # ---- plumbing -------------------------------------------------------------------------------
     @property
@@ -135,7 +138,19 @@ class BatchedGridworldEnv:
     def torch_stream(self):
         import torch
 
-        return torch.cuda.ExternalStream(self.stream_ptr, device="cuda:%d" % self.device)
+        if self._tstream is None:
+            self._tstream = torch.cuda.ExternalStream(self.stream_ptr, device="cuda:%d" % self.device)
+        return self._tstream
+
+    def bind_torch_stream(self, stream=None):
+        """Enqueue the library's kernels on a torch stream (default: torch's current stream) so that env steps and
+        torch ops (the Q-network) are ordered by the stream itself, with no cross-stream events."""
+        import torch
+
+        stream = stream or torch.cuda.current_stream(self.device)
+        _lib.check(self.lib.sgk_set_stream(self._h.ptr, ctypes.c_void_p(stream.cuda_stream)))
+        self._tstream = stream
+        self._bound = True
 
     def synchronize(self):
         _lib.check(self.lib.sgk_synchronize(self._h.ptr))
@@ -170,14 +185,22 @@ class BatchedGridworldEnv:
         """Make the library's stream wait for work queued on torch's current stream (e.g. the policy net)."""
         import torch
 
-        ev = torch.cuda.Event()
+        if self._bound:
+            return
+        if self._events is None:
+            self._events = (torch.cuda.Event(), torch.cuda.Event())
+        ev = self._events[0]
         ev.record(torch.cuda.current_stream(self.device))
         self.torch_stream().wait_event(ev)
 
     def _sync_lib_to_torch(self):
         import torch
 
-        ev = torch.cuda.Event()
+        if self._bound:
+            return
+        if self._events is None:
+            self._events = (torch.cuda.Event(), torch.cuda.Event())
+        ev = self._events[1]
         ev.record(self.torch_stream())
         torch.cuda.current_stream(self.device).wait_event(ev)
 
