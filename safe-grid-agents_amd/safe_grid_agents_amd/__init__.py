@@ -5,6 +5,7 @@ include/sgk.h); importing an env without it raises. Nothing here falls back to t
 from . import _lib
 from .agents import (AGENT_MAP, BatchedTabularQAgent, DeepQAgent, Experience, ExperienceBatch, RandomAgent,
                      ReplayBuffer, Rollout, SingleActionAgent, TabularQAgent)
+from .deepq_batched import BatchedDeepQAgent, DeviceReplay
 from .envs import ENV_IDS, ENV_MAP, BatchedGridworldEnv, GridworldEnv, make
 from .loops import (EVAL_MAP, LEARN_MAP, WARMUP_MAP, batched_random_rollout, batched_tabq_learn, default_eval,
                     dqn_learn, dqn_warmup, noop_warmup, tabq_learn, whiler)
@@ -14,7 +15,7 @@ from .trainer import prepare_parser, train
 __all__ = [
     "AGENT_MAP", "ENV_MAP", "ENV_IDS", "LEARN_MAP", "EVAL_MAP", "WARMUP_MAP",
     "make", "GridworldEnv", "BatchedGridworldEnv",
-    "RandomAgent", "SingleActionAgent", "TabularQAgent", "DeepQAgent", "BatchedTabularQAgent",
+    "RandomAgent", "SingleActionAgent", "TabularQAgent", "DeepQAgent", "BatchedTabularQAgent", "BatchedDeepQAgent", "DeviceReplay",
     "ReplayBuffer", "Experience", "ExperienceBatch", "Rollout",
     "whiler", "tabq_learn", "dqn_learn", "default_eval", "dqn_warmup", "noop_warmup",
     "batched_random_rollout", "batched_tabq_learn",

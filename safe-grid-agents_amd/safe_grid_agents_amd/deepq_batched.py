@@ -1,0 +1,167 @@
+"""DeepQAgent over a BatchedGridworldEnv: one shared Q-network (PyTorch-ROCm MLP, the reference's architecture and
+defaults: value.py:148-158, agent_parser_configs.yaml:40-54) acting for N envs per lockstep step, everything resident in
+HBM. BASELINE.json config 4 (SideEffectsSokoban + deep-q, 32 768 envs).
+
+What is kept from the reference (value.py:61-187, learn.py:29-58, warmup.py:8-23): network, target network and
+`sync_every`, Adam(amsgrad), MSE on `discount * max target_Q(s') * (1 - terminal) + r`, grad-clip 10, the epsilon
+schedule, epsilon-greedy = Categorical(eps/n + (1 - eps) on the argmax), uniform replay sampling with replacement.
+
+What necessarily differs, and is stated next to any number: the reference does ONE SGD step on 64
+samples per SINGLE env-step of its single env; with N envs in lockstep one call produces N transitions, so the ratio is
+a parameter here: `sgd_steps` SGD steps of `batch_size` samples per LOCKSTEP step, replay of `replay_slices` x N
+transitions (a ring of whole lockstep slices). The [B,1]-vs-[B] mse_loss broadcast of value.py:119-123 is NOT kept here
+(shapes are squeezed): this is a different training schedule anyway, parity is claimed only for forward / argmax / policy.
+"""
+import numpy as np
+
+
+class DeviceReplay:
+    """Ring of lockstep slices in HBM: int8 boards (state, successor), uint8 action, int8 reward, bool terminal."""
+
+    def __init__(self, n_envs, n_cells, slices, device):
+        import torch
+
+        self.n, self.slices, self.device = n_envs, slices, device
+        self.states = torch.empty((slices, n_envs, n_cells), dtype=torch.int8, device=device)
+        self.successors = torch.empty_like(self.states)
+        self.actions = torch.empty((slices, n_envs), dtype=torch.uint8, device=device)
+        self.rewards = torch.empty((slices, n_envs), dtype=torch.int8, device=device)
+        self.terminals = torch.empty((slices, n_envs), dtype=torch.bool, device=device)
+        self.head = 0      # next slice to write
+        self.filled = 0    # slices holding data
+
+    def __len__(self):
+        return self.filled * self.n
+
+    def add_slice(self, states, actions, rewards, successors, terminals):
+        k = self.head
+        self.states[k].copy_(states)
+        self.actions[k].copy_(actions)
+        self.rewards[k].copy_(rewards)
+        self.successors[k].copy_(successors)
+        self.terminals[k].copy_(terminals)
+        self.head = (k + 1) % self.slices
+        self.filled = min(self.filled + 1, self.slices)
+
+    def sample(self, batch):
+        """Uniform with replacement over everything stored (contain.py:19-22), indices drawn on the device."""
+        import torch
+
+        total = self.filled * self.n
+        ix = torch.randint(0, total, (batch,), device=self.device)
+        flat = lambda t: t.reshape(self.slices * self.n, *t.shape[2:])  # noqa: E731
+        return (flat(self.states)[ix], flat(self.actions)[ix], flat(self.rewards)[ix], flat(self.successors)[ix],
+                flat(self.terminals)[ix])
+
+
+class BatchedDeepQAgent:
+    def __init__(self, env, args, sgd_steps=1, replay_slices=8):
+        import torch
+
+        self.torch = torch
+        self.env = env
+        self.device = "cuda:%d" % env.device
+        self.action_n = env.action_space.n
+        self.n_input = env.n_cells
+        self.discount, self.lr = float(args.discount), float(args.lr)
+        self.batch_size, self.sync_every = int(args.batch_size), int(args.sync_every)
+        self.sgd_steps = int(sgd_steps)
+        self.eps0, self.anneal = float(args.epsilon), int(args.epsilon_anneal)
+        self.t = 0  # lockstep steps taken == update_epsilon() calls
+        n_layers, n_hidden = int(args.n_layers), int(args.n_hidden)
+        self.Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
+        self.target_Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
+        self.sync_target_Q()
+        self.optim = torch.optim.Adam(self.Q.parameters(), lr=self.lr, amsgrad=True)
+        self.replay = DeviceReplay(env.n_envs, env.n_cells, replay_slices, self.device)
+        self._obs = torch.empty((env.n_envs, env.n_cells), dtype=torch.float32, device=self.device)
+        self._prev_boards = torch.empty((env.n_envs, env.n_cells), dtype=torch.int8, device=self.device)
+        self.last_loss = None
+
+    def build_Q(self, n_input, n_layers, n_hidden):
+        nn = self.torch.nn
+        first = nn.Sequential(nn.Linear(n_input, n_hidden), nn.ReLU())
+        hidden = nn.Sequential(*[nn.Sequential(nn.Linear(n_hidden, n_hidden), nn.ReLU()) for _ in range(n_layers - 1)])
+        return nn.Sequential(first, hidden, nn.Linear(n_hidden, int(self.action_n)))
+
+    # epsilon schedule of DeepQAgent (value.py:70-76,142-146): NO overwrite to 0.0, so step 0 acts with 1.0
+    @property
+    def epsilon(self):
+        t = min(self.t, self.anneal - 1)
+        return 1.0 - (1 - self.eps0) * t / self.anneal
+
+    def update_epsilon(self):
+        self.t += 1
+        return self.epsilon
+
+    def sync_target_Q(self):
+        self.target_Q.load_state_dict(self.Q.state_dict())
+
+    def scores(self, obs=None):
+        obs = self.env.obs_f32(self._obs) if obs is None else obs
+        with self.torch.no_grad():
+            return self.Q(obs)
+
+    def act(self, obs=None):
+        return self.scores(obs).argmax(1).to(self.torch.uint8)
+
+    def act_explore(self, obs=None):
+        """Categorical(eps/n everywhere + (1 - eps) on the argmax), sampled for every env (value.py:94-111)."""
+        torch = self.torch
+        greedy = self.scores(obs).argmax(1)
+        eps = self.epsilon
+        n = greedy.shape[0]
+        explore = torch.rand(n, device=self.device) < eps
+        rand_a = torch.randint(0, self.action_n, (n,), device=self.device)
+        return torch.where(explore, rand_a, greedy).to(torch.uint8)
+
+    def learn_batch(self):
+        torch = self.torch
+        states, actions, rewards, successors, terminals = self.replay.sample(self.batch_size)
+        self.Q.train()
+        q_sa = self.Q(states.float()).gather(1, actions.long().unsqueeze(1)).squeeze(1)
+        with torch.no_grad():
+            next_q = self.target_Q(successors.float()).max(1)[0]
+            next_q = torch.where(terminals, torch.zeros_like(next_q), next_q)
+            expected = self.discount * next_q + rewards.float()
+        loss = torch.nn.functional.mse_loss(q_sa, expected)
+        self.optim.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.Q.parameters(), 10.0)
+        self.optim.step()
+        self.Q.eval()
+        self.last_loss = loss.detach()
+        return self.last_loss
+
+    def step(self, learn=True, cheat=False, explore=True):
+        """One lockstep iteration of dqn_learn for every env: act_explore -> env.step -> replay.add -> learn ->
+        update_epsilon -> (sync target) -> reset finished envs (the episode loop of train.py:62-70)."""
+        env = self.env
+        boards = env.boards().reshape(env.n_envs, -1)
+        self._prev_boards.copy_(boards)
+        env.obs_f32(self._obs)
+        actions = self.act_explore(self._obs) if explore else self.act(self._obs)
+        succ, reward, done, info = env.step(actions, auto_reset=False)
+        if learn:
+            r = info["hidden_reward"] if cheat else reward
+            a = info["extra_observations"]["actual_actions"].to(self.torch.uint8) if cheat else actions
+            self.replay.add_slice(self._prev_boards, a, r, succ.reshape(env.n_envs, -1), done.bool())
+            for _ in range(self.sgd_steps):
+                self.learn_batch()
+        t = self.t
+        self.update_epsilon()
+        if learn and t % self.sync_every == self.sync_every - 1:
+            self.sync_target_Q()
+        env.reset_done()
+        return actions
+
+    def warmup(self, n_steps):
+        """dqn_warmup (warmup.py:8-23): fill the replay with random-action slices."""
+        torch = self.torch
+        env = self.env
+        for _ in range(n_steps):
+            self._prev_boards.copy_(env.boards().reshape(env.n_envs, -1))
+            actions = torch.randint(0, self.action_n, (env.n_envs,), device=self.device).to(torch.uint8)
+            succ, reward, done, info = env.step(actions, auto_reset=False)
+            self.replay.add_slice(self._prev_boards, actions, reward, succ.reshape(env.n_envs, -1), done.bool())
+            env.reset_done()
