@@ -49,6 +49,10 @@ struct sgk_env {
   uint8_t *actions_scratch = nullptr;
   std::map<std::pair<int32_t, uint32_t>, hipGraphExec_t> graphs;
   bool use_graph = true;
+  int partitions = 1;                 // independent env partitions stepped on concurrent graph branches
+  hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork_event = nullptr;
+  hipEvent_t join_events[3] = {nullptr, nullptr, nullptr};
 };
 
 struct sgk_tabq {
@@ -59,7 +63,8 @@ struct sgk_tabq {
 
 namespace sgk {
 // step kernel variant that reads the lockstep counter from device memory (graph replays)
-hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st);
+hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st,
+                               int64_t env_off, int64_t count);
 }  // namespace sgk
 
 extern "C" {
@@ -113,6 +118,11 @@ int sgk_destroy(sgk_env *h) {
   (void)hipFree(s.last_perf); (void)hipFree(s.n_episodes); (void)hipFree(s.metrics); (void)hipFree(s.metric_slab); (void)hipFree(s.wg_count); (void)hipFree(s.wg_offset);
   (void)hipFree(s.finished_total); (void)hipFree(h->t_dev); (void)hipFree(h->dense_scratch);
   (void)hipFree(h->actions_scratch);
+  for (int i = 0; i < 3; ++i) {
+    if (h->side_streams[i]) (void)hipStreamDestroy(h->side_streams[i]);
+    if (h->join_events[i]) (void)hipEventDestroy(h->join_events[i]);
+  }
+  if (h->fork_event) (void)hipEventDestroy(h->fork_event);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return SGK_OK;
@@ -149,6 +159,10 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   s.pitch = (s.layout == SGK_LAYOUT_COMPACT) ? s.n_cells : pitched;
   const char *ng = getenv("SGK_NO_GRAPH");
   h->use_graph = !(ng && ng[0] == '1');
+  const char *np = getenv("SGK_PARTITIONS");
+  h->partitions = np ? atoi(np) : 1;
+  if (h->partitions < 1) h->partitions = 1;
+  if (h->partitions > 4) h->partitions = 4;
 
 #define SGK_TRY(call)                                   \
   do {                                                  \
@@ -309,10 +323,34 @@ int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // partitions: the env batch is cut into P independent ranges (multiples of 256 envs); each range's chain of
+    // n_steps dependent launches is a separate branch of the graph, so one range's launch/ramp/drain latency
+    // overlaps another range's bandwidth phase (the envs are independent: reference train.py:51-54).
+    int P = h->partitions;
+    const int64_t n_tiles = (s.n + 255) / 256;
+    if (n_tiles < 4 * P) P = 1;
+    if (P > 1) {
+      if (!h->fork_event) SGK_HIP(hipEventCreateWithFlags(&h->fork_event, hipEventDisableTiming));
+      for (int i = 0; i < P - 1; ++i) {
+        if (!h->side_streams[i]) SGK_HIP(hipStreamCreateWithFlags(&h->side_streams[i], hipStreamNonBlocking));
+        if (!h->join_events[i]) SGK_HIP(hipEventCreateWithFlags(&h->join_events[i], hipEventDisableTiming));
+      }
+    }
     SGK_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     hipError_t le = hipSuccess;
-    for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k)
-      le = sgk::launch_step_counter(s, h->t_dev, (uint64_t)k, flags, h->stream);
+    if (P > 1) {
+      le = hipEventRecord(h->fork_event, h->stream);
+      for (int i = 0; i < P - 1 && le == hipSuccess; ++i) le = hipStreamWaitEvent(h->side_streams[i], h->fork_event, 0);
+    }
+    for (int p = 0; p < P && le == hipSuccess; ++p) {
+      const int64_t t0 = n_tiles * p / P, t1 = n_tiles * (p + 1) / P;
+      const int64_t off = t0 * 256, cnt = (p == P - 1 ? s.n : t1 * 256) - off;
+      hipStream_t st = (p == 0) ? h->stream : h->side_streams[p - 1];
+      for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k)
+        le = sgk::launch_step_counter(s, h->t_dev, (uint64_t)k, flags, st, off, cnt);
+      if (p > 0 && le == hipSuccess) le = hipEventRecord(h->join_events[p - 1], st);
+    }
+    for (int i = 0; i < P - 1 && le == hipSuccess; ++i) le = hipStreamWaitEvent(h->stream, h->join_events[i], 0);
     if (le == hipSuccess) {
       hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, (uint64_t)n_steps);
       le = hipGetLastError();

@@ -412,6 +412,16 @@ template <int ENV, int LAYOUT, bool RANDOM>
 __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
   __shared__ SgkRules R;
   __shared__ CompactLds<Geom<ENV>::NC> C;
+  // issue the first tile's state (and action) loads before the rule tables are staged: one memory round trip less
+  uint64_t w_cur = 0;
+  uint8_t a_cur = 0;
+  {
+    const int64_t e0 = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (e0 < a.n) {
+      w_cur = a.state[e0];
+      if (!RANDOM) a_cur = a.actions[e0];
+    }
+  }
   stage_rules(R, a.rules);
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT) && (Geom<ENV>::NC % 16 != 0);
   if (COMPACT) stage_rotations(C, R);
@@ -423,19 +433,26 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t env = tile * WG + threadIdx.x;
     const bool valid = env < a.n;
-    EnvState s = initial_state(R);
+    // this tile's state word was requested before the rule tables were staged / while the previous tile ran
+    EnvState s = unpack_state(w_cur);
+    const uint8_t act_cur = a_cur;
+    {
+      const int64_t nt = tile + gridDim.x;
+      const int64_t ne = nt * WG + threadIdx.x;
+      const bool nv = nt < n_tiles && ne < a.n;
+      w_cur = nv ? a.state[ne] : 0;
+      if (!RANDOM) a_cur = nv ? a.actions[ne] : (uint8_t)0;
+    }
+    if (!valid) s = initial_state(R);
     int action = 0;
-    if (valid) {
-      s = unpack_state(a.state[env]);
-      if (RANDOM) {
-        uint64_t ge = a.env_base + (uint64_t)env;
-        uint32_t x[4];
-        philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t_now >> 6), 0u, (uint32_t)a.seed,
-                      (uint32_t)(a.seed >> 32), x);
-        action = action_from_block(x, t_now);
-      } else {
-        action = a.actions[env] & 3;
-      }
+    if (RANDOM) {
+      uint64_t ge = a.env_base + (uint64_t)env;
+      uint32_t x[4];
+      philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t_now >> 6), 0u, (uint32_t)a.seed,
+                    (uint32_t)(a.seed >> 32), x);
+      action = action_from_block(x, t_now);
+    } else {
+      action = act_cur & 3;
     }
     uint32_t rec;
     step_one<ENV>(R, a, env, valid, action, s, rec, acc);
@@ -887,12 +904,29 @@ static StepArgs make_step_args(const Shard &sh, const uint8_t *actions, uint32_t
   return a;
 }
 
-hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st) {
-  StepArgs a = make_step_args(sh, nullptr, flags);
+// A sub-range [env_off, env_off + count) of the shard as a Shard view (env_off must be a multiple of 256 so that
+// board tiles stay aligned). Used to run independent partitions of the batch on concurrent graph branches.
+static Shard shard_view(const Shard &sh, int64_t env_off, int64_t count) {
+  Shard v = sh;
+  v.n = count;
+  v.env_base = sh.env_base + (uint64_t)env_off;
+  v.state = sh.state + env_off;
+  v.rec = sh.rec + env_off;
+  v.boards = sh.boards + env_off * sh.pitch;
+  v.last_return = sh.last_return + env_off;
+  v.last_perf = sh.last_perf + env_off;
+  v.n_episodes = sh.n_episodes + env_off;
+  return v;
+}
+
+hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st,
+                               int64_t env_off, int64_t count) {
+  Shard v = shard_view(sh, env_off, count);
+  StepArgs a = make_step_args(v, nullptr, flags);
   a.t = t_off;
   a.t_ptr = t_dev;
-  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
-  SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a));
+  int grid = grid_for((v.n + WG - 1) / WG, v.max_grid);
+  SGK_DISPATCH_ENV_LAYOUT(v.env_id, v.layout, step_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a));
   return hipGetLastError();
 }
 

@@ -125,6 +125,7 @@ class BatchedGridworldEnv:
         self._tstream = None
         self._bound = False
         self._events = None
+        self._outputs = None
 
     # ---- plumbing -------------------------------------------------------------------------------
     @property
@@ -157,6 +158,7 @@ class BatchedGridworldEnv:
 
     def close(self):
         self._views = None
+        self._outputs = None
         self._h.close()
 
     def _device_views(self):
@@ -227,11 +229,14 @@ class BatchedGridworldEnv:
         return self.boards()
 
     def _step_outputs(self):
-        v = self._device_views()
-        rec = v["rec"]
-        reward, hidden, done, actual = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3]
-        info = {"hidden_reward": hidden, "observed_reward": reward, "extra_observations": {"actual_actions": actual}}
-        return v["boards"], reward, done, info
+        if self._outputs is None:  # the views alias fixed library buffers: build them once
+            v = self._device_views()
+            rec = v["rec"]
+            reward, hidden, done, actual = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3]
+            info = {"hidden_reward": hidden, "observed_reward": reward,
+                    "extra_observations": {"actual_actions": actual}}
+            self._outputs = (v["boards"], reward, done, info)
+        return self._outputs
 
     def step(self, actions, auto_reset=False, write_boards=True):
         """actions: torch uint8 tensor [N] on this GPU."""

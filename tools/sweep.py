@@ -26,11 +26,13 @@ def timed(env, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-for name in ("BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0"):
+NAMES = [a for a in sys.argv[1:] if a.endswith("-v0")] or ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0"]
+SIZES = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1 << 10, 1 << 16, 1 << 18, 1 << 20, 1 << 22]
+for name in NAMES:
     for layout in ("compact", "pitched"):
         if name == "IslandNavigation-v0" and layout == "compact":
             continue
-        for n in (1 << 10, 1 << 16, 1 << 18, 1 << 20, 1 << 22):
+        for n in SIZES:
             env = S.BatchedGridworldEnv(name, n, seed=1, layout=layout)
             acts = torch.randint(0, 4, (n,), dtype=torch.uint8, device="cuda")
             ms_graph = timed(env, lambda: env.step_random(100, auto_reset=True), 5) / 100
