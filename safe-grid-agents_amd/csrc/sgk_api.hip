@@ -534,6 +534,14 @@ int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, in
   if (e == hipSuccess) e = hipMalloc(&q->actions, (size_t)env->sh.n);
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.table, 0, tbytes, env->stream);  // defaultdict(zeros) (value.py:31)
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.s_prev, 0xff, sizeof(uint16_t) * (size_t)env->sh.n, env->stream);
+  if (e == hipSuccess && epsilon_anneal <= (int64_t)(4 << 20)) {
+    // the schedule the reference keeps as a Python list (value.py:23-26), tabulated once: the fused kernel reads
+    // eps(t) with one scalar load instead of a float64 divide per step
+    std::vector<double> tab((size_t)epsilon_anneal);
+    for (int64_t t = 0; t < epsilon_anneal; ++t) tab[(size_t)t] = sgk::host_epsilon_at(epsilon, epsilon_anneal, t);
+    e = hipMalloc(&q->tq.eps_table, sizeof(double) * tab.size());
+    if (e == hipSuccess) e = hipMemcpy(q->tq.eps_table, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     int rc = hip_fail(e, "tabular-Q allocation");
     std::string keep = g_last_error;
@@ -569,7 +577,8 @@ int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat) {
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
   if (n_steps == 0) return SGK_OK;
   sgk::Shard &s = h->sh;
-  if (sgk::tabq_rollout_lds_bytes(s) <= 160u * 1024u) {
+  const size_t lds_need = sgk::tabq_rollout_lds_bytes(s);
+  if (lds_need != 0 && lds_need <= 160u * 1024u) {
     SGK_HIP(sgk::launch_tabq_rollout(s, q->tq, n_steps, cheat, h->stream));
     SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));  // materialise the boards of the final states
     q->tq.t_agent += n_steps;

@@ -35,6 +35,7 @@ struct Shard {
 struct TabqShard {
   double *table = nullptr;   // [n][n_states][4] float64
   uint16_t *s_prev = nullptr;
+  double *eps_table = nullptr;  // [anneal] epsilon schedule (null when anneal is too long to tabulate)
   double lr = 0, discount = 0, eps0 = 0;
   int64_t anneal = 0;
   int64_t t_agent = 0;

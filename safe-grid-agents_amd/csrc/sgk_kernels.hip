@@ -670,6 +670,19 @@ __device__ __forceinline__ double uniform53(uint32_t a, uint32_t b) {
   return (double)((((uint64_t)(a >> 5)) << 26) + (uint64_t)(b >> 6)) / 9007199254740992.0;
 }
 
+// Stream 1 (epsilon-greedy draws): one block serves TWO consecutive agent steps of one env:
+//   x = philox4x32_10(ctr = {env_lo, env_hi, (t >> 1)_lo, 1}, key); h = t & 1
+//   u(t) = uniform53(x[2h], x[2h+1]),  explore action(t) = x[2h] & 3   (bits the 53-bit construction discards)
+__device__ __forceinline__ void explore_block(uint64_t seed, uint64_t ge, int64_t t, uint32_t x[4]) {
+  philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)((uint64_t)t >> 1), 1u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+}
+__device__ __forceinline__ void explore_draw(const uint32_t x[4], int64_t t, double &u, int &action) {
+  const bool h = (t & 1) != 0;
+  const uint32_t a = h ? x[2] : x[0], b = h ? x[3] : x[1];
+  u = uniform53(a, b);
+  action = (int)(a & 3u);
+}
+
 // epsilon in force at global agent step t (value.py:23-28,54-58): evaluated in Python's operation order
 __host__ __device__ __forceinline__ double epsilon_at(double eps0, int64_t anneal, int64_t t) {
   if (t <= 0) return 0.0;
@@ -702,6 +715,7 @@ struct TabqArgs {
   int64_t t_agent;     // global agent step (same for every agent: lockstep)
   double lr, discount, eps0;
   int64_t anneal;
+  const double *eps_table;  // eps_table[t] for t < anneal (host-computed, bit-identical to the formula); may be null
   int32_t n_states;
   int32_t cheat;
   uint32_t flags;
@@ -721,8 +735,11 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
     if (explore) {
       uint64_t ge = a.env_base + (uint64_t)env;
       uint32_t x[4];
-      philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)a.t_agent, 1u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
-      if (uniform53(x[0], x[1]) < eps) action = (int)(x[2] & 3u);
+      explore_block(a.seed, ge, a.t_agent, x);
+      double u;
+      int ea;
+      explore_draw(x, a.t_agent, u, ea);
+      if (u < eps) action = ea;
     }
     actions_out[env] = (uint8_t)action;
     a.s_prev[env] = s.over ? (uint16_t)0xffff : (uint16_t)si;
@@ -761,7 +778,8 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
   double *Q = reinterpret_cast<double *>(smem + ((sizeof(SgkRules) + 15) / 16) * 16);
   stage_rules(R, a.rules);
   const int lane = threadIdx.x;
-  const int S4 = a.n_states * 4;
+  const int S4 = a.n_states * 4;  // HBM row stride: tables are indexed by cell there
+  const int L4 = R.n_slots * 4;   // LDS image: only the cells the agent can stand on
   const int64_t n_groups = (a.n + 63) / 64;
   EpisodeAcc acc;
   acc_init(acc);
@@ -770,30 +788,39 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
     const int64_t env = env0 + lane;
     const bool valid = env < a.n;
     const int n_here = (int)min((int64_t)64, a.n - env0);
-    // coalesced load of the 64 tables (contiguous in HBM) into the lane-minor LDS image
+    // load the 64 tables' reachable rows into the lane-minor LDS image
     {
       const double *src = a.table + env0 * S4;
-      const int64_t total = (int64_t)n_here * S4;
-      for (int64_t i = lane; i < total; i += 64) {
-        int e = (int)(i / S4), idx = (int)(i - (int64_t)e * S4);
-        Q[idx * 64 + e] = src[i];
+      const int total = n_here * L4;
+      for (int i = lane; i < total; i += 64) {
+        int e = i / L4, idx = i - e * L4;
+        Q[idx * 64 + e] = src[(int64_t)e * S4 + (int)R.slot_cell[idx >> 2] * 4 + (idx & 3)];
       }
     }
     __syncthreads();
     EnvState s = initial_state(R);
     if (valid) s = unpack_state(a.state[env]);
     const uint64_t ge = a.env_base + (uint64_t)env;
-    int si = state_index<ENV>(R, s);
+    int si = R.state_slot[s.pos];
     double q0 = Q[(si * 4 + 0) * 64 + lane], q1 = Q[(si * 4 + 1) * 64 + lane];
     double q2 = Q[(si * 4 + 2) * 64 + lane], q3 = Q[(si * 4 + 3) * 64 + lane];
     uint32_t rec = 0;
+    uint32_t x[4] = {0, 0, 0, 0};
     for (int64_t k = 0; k < n_steps; ++k) {
       const int64_t t = a.t_agent + k;
-      const double eps = epsilon_at(a.eps0, a.anneal, t);
-      uint32_t x[4];
-      philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)t, 1u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
+      double eps;
+      if (a.eps_table) {
+        const int64_t tc = t < a.anneal ? t : a.anneal - 1;
+        eps = a.eps_table[tc];  // wave-uniform address: one scalar load
+      } else {
+        eps = epsilon_at(a.eps0, a.anneal, t);
+      }
+      if (k == 0 || (t & 1) == 0) explore_block(a.seed, ge, t, x);
+      double u;
+      int ea;
+      explore_draw(x, t, u, ea);
       int action = argmax4(q0, q1, q2, q3);
-      if (uniform53(x[0], x[1]) < eps) action = (int)(x[2] & 3u);
+      if (u < eps) action = ea;
       // env.step
       bool finished = false;
       int r_obs = 0, r_hid = 0;
@@ -809,7 +836,7 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
       }
       rec = pack_rec(r_obs, r_hid, (valid && (s.over || finished)) ? 1 : 0, action);
       // learn (no terminal masking: value.py:48-50 bootstraps from Q[s'] even when the episode ended)
-      si = state_index<ENV>(R, s);
+      si = R.state_slot[s.pos];
       double n0 = Q[(si * 4 + 0) * 64 + lane], n1 = Q[(si * 4 + 1) * 64 + lane];
       double n2 = Q[(si * 4 + 2) * 64 + lane], n3 = Q[(si * 4 + 3) * 64 + lane];
       if (live) {
@@ -829,7 +856,7 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
         a.last_perf[env] = s.hid;
         a.n_episodes[env] += 1;
         s = initial_state(R);
-        si = state_index<ENV>(R, s);
+        si = R.state_slot[s.pos];
         n0 = Q[(si * 4 + 0) * 64 + lane]; n1 = Q[(si * 4 + 1) * 64 + lane];
         n2 = Q[(si * 4 + 2) * 64 + lane]; n3 = Q[(si * 4 + 3) * 64 + lane];
       }
@@ -842,10 +869,10 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
     __syncthreads();
     {
       double *dst = a.table + env0 * S4;
-      const int64_t total = (int64_t)n_here * S4;
-      for (int64_t i = lane; i < total; i += 64) {
-        int e = (int)(i / S4), idx = (int)(i - (int64_t)e * S4);
-        dst[i] = Q[idx * 64 + e];
+      const int total = n_here * L4;
+      for (int i = lane; i < total; i += 64) {
+        int e = i / L4, idx = i - e * L4;
+        dst[(int64_t)e * S4 + (int)R.slot_cell[idx >> 2] * 4 + (idx & 3)] = Q[idx * 64 + e];
       }
     }
     __syncthreads();
@@ -1010,6 +1037,7 @@ static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t fl
   a.discount = tq.discount;
   a.eps0 = tq.eps0;
   a.anneal = tq.anneal;
+  a.eps_table = tq.eps_table;
   a.n_states = sh.n_states;
   a.cheat = 0;
   a.flags = flags;
@@ -1031,8 +1059,10 @@ hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t
   return hipGetLastError();
 }
 
+// Sokoban's state is (agent cell, box cell): n_cells^2 rows do not fit LDS -> 0 = "use the per-step kernels"
 size_t tabq_rollout_lds_bytes(const Shard &sh) {
-  return ((sizeof(SgkRules) + 15) / 16) * 16 + (size_t)sh.n_states * 4 * 64 * sizeof(double);
+  if (sh.n_states != sh.n_cells) return 0;
+  return ((sizeof(SgkRules) + 15) / 16) * 16 + (size_t)sh.rules_host.n_slots * 4 * 64 * sizeof(double);
 }
 
 hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st) {
@@ -1040,7 +1070,10 @@ hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_s
   a.cheat = cheat;
   size_t lds = tabq_rollout_lds_bytes(sh);
   int64_t n_groups = (sh.n + 63) / 64;
-  int grid = grid_for(n_groups, sh.n_cus * 4);
+  int per_cu = (int)((160u * 1024u) / lds);  // workgroups (= waves) the LDS lets a CU hold
+  if (per_cu > 16) per_cu = 16;
+  if (per_cu < 1) per_cu = 1;
+  int grid = grid_for(n_groups, sh.n_cus * per_cu);
   hipError_t err = hipSuccess;
   SGK_DISPATCH_ENV(sh.env_id, {
     err = hipFuncSetAttribute(reinterpret_cast<const void *>(&tabq_rollout_kernel<E>),

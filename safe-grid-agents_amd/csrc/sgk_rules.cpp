@@ -131,6 +131,31 @@ extern "C" int sgk_build_rules(int env_id, SgkRules *r) {
     }
   }
 
+  // cells the agent can ever occupy: closure of the start cell under the static move table (terminal cells
+  // included: their all-zero Q rows are still read by the bootstrap, reference value.py:48-50)
+  {
+    std::memset(r->state_slot, 255, sizeof(r->state_slot));
+    std::memset(r->slot_cell, 255, sizeof(r->slot_cell));
+    bool seen[SGK_CELLS] = {false}, absorbing[SGK_CELLS] = {false};
+    int queue[SGK_CELLS], head = 0, tail = 0;
+    queue[tail++] = r->start_agent;
+    seen[r->start_agent] = true;
+    while (head < tail) {
+      int c = queue[head++];
+      if (absorbing[c]) continue;  // the episode ended on arrival: the agent never moves on from here
+      for (int a = 0; a < SGK_ACTIONS; ++a) {
+        uint32_t e = r->trans[c * SGK_ACTIONS + a];
+        int nxt = (int)(e & 0xff);
+        if (e >> 24) absorbing[nxt] = true;  // termination depends on the destination cell only
+        if (!seen[nxt]) { seen[nxt] = true; queue[tail++] = nxt; }
+      }
+    }
+    int k = 0;
+    for (int c = 0; c < n; ++c)
+      if (seen[c]) { r->state_slot[c] = (uint8_t)k; r->slot_cell[k] = (uint8_t)c; ++k; }
+    r->n_slots = k;
+  }
+
   if (env_id == SGK_ENV_ISLAND) {
     for (int cell = 0; cell < n; ++cell) {
       int best = 255;

@@ -28,6 +28,9 @@ struct SgkRules {
   int8_t box_penalty[SGK_CELLS];   // sokoban: hidden wall/corner penalty while the box rests on this cell
   uint8_t box_blocked[SGK_CELLS];  // sokoban: 1 when a box cannot be pushed onto this cell
   uint8_t safety[SGK_CELLS];       // island: Manhattan distance from this cell to the nearest water
+  uint8_t state_slot[SGK_CELLS];   // agent cell -> dense index among the cells the agent can ever stand on (255: never)
+  uint8_t slot_cell[SGK_CELLS];    // inverse of state_slot
+  int32_t n_slots, pad1[3];        // number of reachable agent cells (LDS-resident tabular-Q uses n_slots rows)
 };
 
 #ifdef __cplusplus

@@ -31,10 +31,12 @@ def test_random_action_stream_layout():
 
 
 def test_explore_draw_is_numpy_53bit_construction():
-    u, a = O.explore_draw(7, 3, 11)
-    x = O.philox4x32_10([3, 0, 11, 1], [7, 0])
-    assert u == ((int(x[0]) >> 5) * 67108864 + (int(x[1]) >> 6)) / 9007199254740992.0
-    assert a == int(x[2]) & 3 and 0.0 <= u < 1.0
+    for t in (10, 11):
+        u, a = O.explore_draw(7, 3, t)
+        x = O.philox4x32_10([3, 0, t >> 1, 1], [7, 0])
+        h = 2 * (t & 1)
+        assert u == ((int(x[h]) >> 5) * 67108864 + (int(x[h + 1]) >> 6)) / 9007199254740992.0
+        assert a == int(x[h]) & 3 and 0.0 <= u < 1.0
 
 
 def test_initial_boards():
