@@ -30,27 +30,34 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (
 GRAPH_CHUNK = 100      # lockstep steps per hipGraph replay
 
 
-def cpu_baseline(env_name, seed, target_seconds=12.0):
-    """The oracle's scalar C engine (kind "port": the reference's env is absent) on ONE host core, on a
-    bounded sample of the same workload: random-action lockstep rollout with reset-on-done."""
+def cpu_baseline(env_name, seed, target_seconds=10.0):
+    """The oracle's scalar C engine (kind "port": the reference's env is absent) on the host cores, on a
+    bounded sample of the same workload (random-action lockstep rollout with reset-on-done): first ONE thread, then one
+    thread per host core (contiguous env ranges, no sharing). `value`/`cores` report the all-core run."""
     from oracle import oracle as O
 
-    n = 16384
-    envs = O.EnvBatch(env_name, n)
-    t0 = time.perf_counter()
-    envs.rollout(50, seed=seed, auto_reset=True)
-    probe = time.perf_counter() - t0
-    rate = n * 50 / probe
-    steps = int(max(100, min(20000, target_seconds * rate / n)))
-    envs.reset()
-    m = O.metrics_new()
-    t0 = time.perf_counter()
-    envs.rollout(steps, seed=seed, auto_reset=True, metrics=m)
-    dt = time.perf_counter() - t0
+    def timed(n, steps, threads):
+        envs = O.EnvBatch(env_name, n)
+        t0 = time.perf_counter()
+        if threads == 1:
+            envs.rollout(steps, seed=seed, auto_reset=True)
+        else:
+            threads = O.rollout_mt(envs, steps, threads, seed=seed, auto_reset=True)
+        return n * steps / (time.perf_counter() - t0), threads
+
+    n1 = 16384
+    probe, _ = timed(n1, 50, 1)
+    steps1 = int(max(100, min(20000, target_seconds * probe / n1)))
+    one, _ = timed(n1, steps1, 1)
+    cores = os.cpu_count() or 1
+    n_all = max(n1, 256 * cores)
+    steps_all = int(max(100, min(20000, target_seconds * one * cores * 0.5 / n_all)))
+    allc, used = timed(n_all, steps_all, cores)
     return {
-        "value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-        "sample": "%s, %d envs x %d lockstep steps, oracle C engine (gcc -O2), 1 thread, %.1f s" % (env_name, n, steps, dt),
-        "host_cpus": os.cpu_count(),
+        "value": allc, "unit": "env-steps/s", "cores": used, "kind": "port",
+        "sample": "%s random rollout, oracle C engine (gcc -O2): %d envs x %d steps on %d threads; 1 thread: %d envs x %d "
+                  "steps" % (env_name, n_all, steps_all, used, n1, steps1),
+        "one_core_value": one, "host_cpus": cores,
     }
 
 
@@ -154,6 +161,9 @@ def main():
                  "ms_per_launch": fms, "steps_per_launch": fused_steps,
                  "note": "sgk_rollout_random: %d lockstep steps in ONE launch; per-rank device time" % fused_steps}
 
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
     if rank != 0:
         return
     n_total = n_local * world

@@ -60,6 +60,9 @@ def lib():
         L.orc_metrics_init.argtypes = [ctypes.c_void_p]
         L.orc_rollout.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                   ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_rollout_mt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                     ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.orc_rollout_mt.restype = ctypes.c_int
         L.orc_tabq_new.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int64]
         L.orc_tabq_new.restype = ctypes.c_void_p
         L.orc_tabq_free.argtypes = [ctypes.c_void_p]
@@ -187,6 +190,14 @@ class EnvBatch:
         lib().orc_rollout(self.base, self.n, env_begin, seed, t_begin, n_steps, int(auto_reset), a_ptr,
                           rec.ctypes.data, None if metrics is None else metrics.ctypes.data)
         return rec
+
+
+def rollout_mt(envs, n_steps, n_threads, seed=0, env_begin=0, t_begin=0, auto_reset=True, metrics=None):
+    """EnvBatch.rollout with the env range split over n_threads POSIX threads; returns the thread count used."""
+    used = lib().orc_rollout_mt(envs.base, envs.n, env_begin, seed, t_begin, n_steps, int(auto_reset),
+                                None if metrics is None else metrics.ctypes.data, int(n_threads))
+    assert used > 0, "thread creation failed"
+    return used
 
 
 class TabQ:

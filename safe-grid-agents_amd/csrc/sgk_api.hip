@@ -47,6 +47,7 @@ struct sgk_env {
   int64_t steps_issued = 0;      // host-side SGK_M_STEPS
   int8_t *dense_scratch = nullptr;
   uint8_t *actions_scratch = nullptr;
+  uint8_t *pinned = nullptr;         // host staging for sgk_step_host: [actions n][rec 4n][state 8n][boards n*n_cells]
   std::map<std::pair<int32_t, uint32_t>, hipGraphExec_t> graphs;
   bool use_graph = true;
   int partitions = 1;                 // independent env partitions stepped on concurrent graph branches
@@ -118,6 +119,7 @@ int sgk_destroy(sgk_env *h) {
   (void)hipFree(s.last_perf); (void)hipFree(s.n_episodes); (void)hipFree(s.metrics); (void)hipFree(s.metric_slab); (void)hipFree(s.wg_count); (void)hipFree(s.wg_offset);
   (void)hipFree(s.finished_total); (void)hipFree(h->t_dev); (void)hipFree(h->dense_scratch);
   (void)hipFree(h->actions_scratch);
+  if (h->pinned) (void)hipHostFree(h->pinned);
   for (int i = 0; i < 3; ++i) {
     if (h->side_streams[i]) (void)hipStreamDestroy(h->side_streams[i]);
     if (h->join_events[i]) (void)hipEventDestroy(h->join_events[i]);
@@ -287,18 +289,34 @@ int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_s
                   int32_t *episode_return_host) {
   SGK_CHECK_HANDLE(h);
   if (!actions_host) return fail(SGK_ERR_INVALID, "actions_host is NULL");
-  if (!h->actions_scratch) SGK_HIP(hipMalloc(&h->actions_scratch, (size_t)h->sh.n));
-  SGK_HIP(hipMemcpyAsync(h->actions_scratch, actions_host, (size_t)h->sh.n, hipMemcpyHostToDevice, h->stream));
+  sgk::Shard &s = h->sh;
+  const size_t n = (size_t)s.n, bbytes = n * (size_t)s.n_cells;
+  // one pinned staging block, every transfer asynchronous on the handle's stream, ONE synchronisation per call
+  const size_t off_rec = (n + 15) / 16 * 16, off_state = off_rec + 4 * n, off_boards = off_state + 8 * n;
+  if (!h->pinned) SGK_HIP(hipHostMalloc((void **)&h->pinned, off_boards + bbytes + 16, hipHostMallocDefault));
+  if (!h->actions_scratch) SGK_HIP(hipMalloc(&h->actions_scratch, n));
+  memcpy(h->pinned, actions_host, n);
+  SGK_HIP(hipMemcpyAsync(h->actions_scratch, h->pinned, n, hipMemcpyHostToDevice, h->stream));
   int rc = sgk_step(h, h->actions_scratch, flags);
   if (rc != SGK_OK) return rc;
-  if (rec_host)
-    SGK_HIP(hipMemcpyAsync(rec_host, h->sh.rec, sizeof(uint32_t) * h->sh.n, hipMemcpyDeviceToHost, h->stream));
+  if (rec_host) SGK_HIP(hipMemcpyAsync(h->pinned + off_rec, s.rec, 4 * n, hipMemcpyDeviceToHost, h->stream));
+  if (episode_return_host) SGK_HIP(hipMemcpyAsync(h->pinned + off_state, s.state, 8 * n, hipMemcpyDeviceToHost, h->stream));
   if (boards_host) {
-    rc = sgk_copy_boards(h, boards_host);  // synchronises
-    if (rc != SGK_OK) return rc;
+    const int8_t *src = s.boards;
+    if (s.pitch != s.n_cells) {
+      if (!h->dense_scratch) SGK_HIP(hipMalloc(&h->dense_scratch, bbytes));
+      SGK_HIP(sgk::launch_dense_boards(s, h->dense_scratch, h->stream));
+      src = h->dense_scratch;
+    }
+    SGK_HIP(hipMemcpyAsync(h->pinned + off_boards, src, bbytes, hipMemcpyDeviceToHost, h->stream));
   }
-  if (episode_return_host) return sgk_copy_episode_state(h, episode_return_host, nullptr, nullptr, nullptr, nullptr, nullptr);
   SGK_HIP(hipStreamSynchronize(h->stream));
+  if (rec_host) memcpy(rec_host, h->pinned + off_rec, 4 * n);
+  if (boards_host) memcpy(boards_host, h->pinned + off_boards, bbytes);
+  if (episode_return_host) {
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(h->pinned + off_state);
+    for (size_t i = 0; i < n; ++i) episode_return_host[i] = (int32_t)(int16_t)((uint32_t)(w[i] >> 32) & 0xffff);
+  }
   return SGK_OK;
 }
 

@@ -156,6 +156,24 @@ def batched_random_rollout(env, n_steps, fused=False, chunk=None):
     return BatchMetrics(env.metrics())
 
 
+def batched_default_eval(agent, env, eval_timesteps):
+    """default_eval (reference eval.py:8-56) for N envs in lockstep, greedy `agent.act`.
+
+    Per env the reference plays episodes back to back, resetting after every `done` that arrives before step
+    `eval_timesteps`, and leaves its loop at the first `done` at or after it (eval.py:19-39): whole episodes only.
+    Lockstep form: `eval_timesteps - 1` iterations of {step, reset finished envs}, then steps WITHOUT reset until every
+    env's current episode has ended (at most `max_iterations` more; finished envs idle, their steps are no-ops).
+    No host synchronisation inside the loop. Returns BatchMetrics of the evaluation (metrics are reset first)."""
+    env.metrics_reset()
+    env.reset()
+    for _ in range(max(int(eval_timesteps) - 1, 0)):
+        env.step(agent.act(), auto_reset=False, write_boards=False)
+        env.reset_done()
+    for _ in range(int(env.info.max_iterations)):
+        env.step(agent.act(), auto_reset=False, write_boards=False)
+    return BatchMetrics(env.metrics())
+
+
 def batched_tabq_learn(agent, env, n_steps, cheat=False, fused=True):
     """tabq_learn for N private agents in lockstep: act_explore -> env.step -> learn -> update_epsilon, with the
     episode loop of train.py:62-70 (reset after done) folded in. fused=True runs all n_steps in one launch with the

@@ -376,3 +376,66 @@ def test_million_env_properties():
             orc.rollout(57, seed=0x5AFE, env_begin=i, t_begin=100, auto_reset=True)
             assert (got[i] == orc.boards()[0]).all(), i
         env.close()
+
+
+# ---- batched greedy evaluation (default_eval in lockstep) -----------------------------------------------------------
+@pytest.mark.parametrize("name,T", [("IslandNavigation-v0", 37), ("BoatRace-v0", 130), ("IslandNavigation-v0", 1)])
+def test_batched_default_eval_counts_whole_episodes_like_the_reference(name, T):
+    _torch()
+    n, train_steps, seed = 96, 400, 13
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    agent = S.BatchedTabularQAgent(env, _tabq_args())
+    agent.rollout(train_steps)
+    orc, agents, _, _ = _oracle_tabq(name, n, train_steps, seed, False)
+    bm = S.batched_default_eval(agent, env, T)
+    # the reference's loop (eval.py:8-56), one env at a time, on the oracle env with the oracle's greedy agent
+    want = O.metrics_new()
+    single = O.EnvBatch(name, 1)
+    for i in range(n):
+        single.reset(0)
+        t = 0
+        while True:
+            r, h, d, _ = single.step(0, agents[i].act(single.board(0)))
+            t += 1
+            if d:
+                ret, perf = int(single.field("episode_return")[0]), single.last_performance(0)
+                want[O.M_SUM_RETURN] += ret; want[O.M_SUM_SAFETY] += perf; want[O.M_SUM_MARGIN] += ret - perf
+                want[O.M_EPISODES] += 1
+                want[O.M_MAX_RETURN] = max(want[O.M_MAX_RETURN], ret); want[O.M_MAX_SAFETY] = max(want[O.M_MAX_SAFETY], perf)
+                want[O.M_MAX_MARGIN] = max(want[O.M_MAX_MARGIN], ret - perf)
+                if ret - perf > 0:
+                    want[O.M_SUM_MARGIN_POS] += ret - perf; want[O.M_MARGIN_POS_COUNT] += 1
+                    want[O.M_MAX_MARGIN_POS] = max(want[O.M_MAX_MARGIN_POS], ret - perf)
+                if t >= T:
+                    break
+                single.reset(0)
+    got = bm.vec
+    assert got[:6] == want[:6].tolist() and got[8:12] == want[8:12].tolist()
+    assert bm.episodes >= n
+    agent.close(); env.close()
+
+
+def test_error_paths_on_gpu():
+    import ctypes
+
+    _torch()
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.sgk_create(0, 0, 0, 0, ctypes.byref(h)) == _lib.ERR_INVALID
+    assert lib.sgk_create(0, 16, 99, 0, ctypes.byref(h)) == _lib.ERR_INVALID and b"device" in lib.sgk_last_error()
+    assert lib.sgk_create(7, 16, 0, 0, ctypes.byref(h)) == _lib.ERR_INVALID
+    assert lib.sgk_create_ex(0, 16, 0, 0, 0, 5, ctypes.byref(h)) == _lib.ERR_INVALID
+    assert lib.sgk_step(None, None, 0) == _lib.ERR_INVALID
+    env = S.BatchedGridworldEnv("BoatRace-v0", 16)
+    assert lib.sgk_step(env.handle, None, 0) == _lib.ERR_INVALID
+    assert lib.sgk_step_random(env.handle, -1, 0) == _lib.ERR_INVALID
+    assert lib.sgk_copy_boards(env.handle, None) == _lib.ERR_INVALID
+    q = ctypes.c_void_p()
+    assert lib.sgk_tabq_create(env.handle, 0.5, 0.99, 0.01, 0, ctypes.byref(q)) == _lib.ERR_INVALID
+    env.close()
+    # ragged / tiny sizes work
+    for n in (1, 2, 63, 64, 65, 255, 256, 257):
+        e = S.BatchedGridworldEnv("SideEffectsSokoban-v0", n, layout="compact")
+        e.step_random(101, auto_reset=True)
+        assert e.metrics()[_lib.M_STEPS] == 101 * n
+        e.close()

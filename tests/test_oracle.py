@@ -152,3 +152,12 @@ def test_rollout_metrics_and_autoreset_match_manual_loop():
         assert (a.boards() == b.boards()).all()
         assert m.tolist() == m2.tolist(), name
         assert m[O.M_EPISODES] >= 2 * n
+
+
+def test_multithreaded_rollout_equals_single_thread():
+    n, steps = 501, 140
+    a, b = O.EnvBatch("IslandNavigation-v0", n), O.EnvBatch("IslandNavigation-v0", n)
+    ma, mb = O.metrics_new(), O.metrics_new()
+    a.rollout(steps, seed=3, env_begin=17, auto_reset=True, metrics=ma)
+    assert O.rollout_mt(b, steps, 5, seed=3, env_begin=17, auto_reset=True, metrics=mb) == 5
+    assert (a.boards() == b.boards()).all() and ma.tolist() == mb.tolist()
