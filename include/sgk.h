@@ -129,6 +129,11 @@ SGK_API int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flag
 SGK_API int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags);
 /* the same n_steps inside ONE launch: state stays in registers, boards are materialised once at the end */
 SGK_API int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags);
+/* Book n_steps lockstep steps that were issued OUTSIDE the library's sight: a caller that captured sgk_step() into its
+ * own hipGraph (e.g. torch.cuda.CUDAGraph around policy + env.step) replays it without re-entering sgk_step, so the
+ * host-side lockstep counter and SGK_M_STEPS must be advanced by hand after each replay (n_steps < 0 un-counts the
+ * launch that was only recorded during capture). */
+SGK_API int sgk_account_steps(sgk_env *h, int64_t n_steps);
 /* the action the counter RNG yields for (env_index, lockstep step t); host helper for tests */
 SGK_API int sgk_random_action(uint64_t seed, uint64_t env_index, uint64_t t);
 

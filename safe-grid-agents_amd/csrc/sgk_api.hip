@@ -285,6 +285,15 @@ int sgk_step(sgk_env *h, const uint8_t *actions_dev, uint32_t flags) {
   return SGK_OK;
 }
 
+int sgk_account_steps(sgk_env *h, int64_t n_steps) {
+  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  if (n_steps < 0 && (uint64_t)(-n_steps) > h->sh.lockstep_t) return fail(SGK_ERR_INVALID, "would make the step counter negative");
+  h->sh.lockstep_t += (uint64_t)n_steps;  // two's complement: also un-counts a launch that was only recorded
+  h->t_dev_stale = true;
+  h->steps_issued += h->sh.n * n_steps;
+  return SGK_OK;
+}
+
 int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_step_rec *rec_host, int8_t *boards_host,
                   int32_t *episode_return_host) {
   SGK_CHECK_HANDLE(h);

@@ -29,6 +29,7 @@ class DeviceReplay:
         self.terminals = torch.empty((slices, n_envs), dtype=torch.bool, device=device)
         self.head = 0      # next slice to write
         self.filled = 0    # slices holding data
+        self.head_dev = torch.zeros(1, dtype=torch.long, device=device)  # the same head, for graph-captured adds
 
     def __len__(self):
         return self.filled * self.n
@@ -40,8 +41,26 @@ class DeviceReplay:
         self.rewards[k].copy_(rewards)
         self.successors[k].copy_(successors)
         self.terminals[k].copy_(terminals)
-        self.head = (k + 1) % self.slices
+        self._advance()
+        self.head_dev.fill_(self.head)
+
+    def _advance(self):
+        self.head = (self.head + 1) % self.slices
         self.filled = min(self.filled + 1, self.slices)
+
+    def add_slice_captured(self, states, actions, rewards, successors, terminals):
+        """The same write with the slice index read from device memory: safe to record in a CUDA/HIP graph (a Python
+        int would be frozen into the graph). The caller advances the host-side head with note_replayed_add()."""
+        k = self.head_dev
+        self.states.index_copy_(0, k, states.unsqueeze(0))
+        self.actions.index_copy_(0, k, actions.unsqueeze(0))
+        self.rewards.index_copy_(0, k, rewards.unsqueeze(0))
+        self.successors.index_copy_(0, k, successors.unsqueeze(0))
+        self.terminals.index_copy_(0, k, terminals.unsqueeze(0))
+        self.head_dev.add_(1).remainder_(self.slices)
+
+    def note_replayed_add(self):
+        self._advance()
 
     def sample(self, batch):
         """Uniform with replacement over everything stored (contain.py:19-22), indices drawn on the device."""
@@ -72,11 +91,14 @@ class BatchedDeepQAgent:
         self.Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
         self.target_Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
         self.sync_target_Q()
-        self.optim = torch.optim.Adam(self.Q.parameters(), lr=self.lr, amsgrad=True)
+        # capturable: Adam's step counters live on the device, so optim.step() can be recorded in a hipGraph
+        self.optim = torch.optim.Adam(self.Q.parameters(), lr=self.lr, amsgrad=True, capturable=True)
         self.replay = DeviceReplay(env.n_envs, env.n_cells, replay_slices, self.device)
         self._obs = torch.empty((env.n_envs, env.n_cells), dtype=torch.float32, device=self.device)
         self._prev_boards = torch.empty((env.n_envs, env.n_cells), dtype=torch.int8, device=self.device)
         self.last_loss = None
+        self._eps_dev = torch.ones(1, dtype=torch.float32, device=self.device)
+        self._graphs = {}
 
     def build_Q(self, n_input, n_layers, n_hidden):
         nn = self.torch.nn
@@ -154,6 +176,68 @@ class BatchedDeepQAgent:
             self.sync_target_Q()
         env.reset_done()
         return actions
+
+    # ---- the same lockstep iteration replayed from ONE hipGraph (torch.cuda.CUDAGraph) -------------------------------
+    # Eager PyTorch costs ~10 us of host time per op; one iteration is ~15 ops without learning and ~100 with, so at
+    # 32 768 envs the GPU idles most of the time. Capturing the iteration (the library's obs / step / reset kernels are
+    # plain launches on the capture stream) removes that: everything that varies between replays lives in device memory
+    # (epsilon scalar, replay ring head, Adam's capturable step counter).
+    def _captured_iteration(self, learn):
+        torch = self.torch
+        env = self.env
+        self._prev_boards.copy_(env.boards().reshape(env.n_envs, -1))
+        env.obs_f32(self._obs)
+        with torch.no_grad():
+            greedy = self.Q(self._obs).argmax(1)
+        n = greedy.shape[0]
+        explore = torch.rand(n, device=self.device) < self._eps_dev
+        rand_a = torch.randint(0, self.action_n, (n,), device=self.device)
+        actions = torch.where(explore, rand_a, greedy).to(torch.uint8)
+        succ, reward, done, info = env.step(actions, auto_reset=False)
+        if learn:
+            self.replay.add_slice_captured(self._prev_boards, actions, reward, succ.reshape(env.n_envs, -1), done.bool())
+            for _ in range(self.sgd_steps):
+                self.learn_batch()
+        env.reset_done()
+
+    def enable_graphs(self, learn=True):
+        """Capture one lockstep iteration. Needs a full replay ring (run warmup(replay_slices) first) so that the sampling
+        range is a constant, and Adam(capturable=True)."""
+        torch = self.torch
+        if learn in self._graphs:
+            return
+        if learn:
+            assert self.replay.filled == self.replay.slices, "fill the replay ring (warmup) before capturing the learn graph"
+        env = self.env
+        with torch.no_grad() if not learn else torch.enable_grad():
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                env.bind_torch_stream(side)
+                for _ in range(3):  # warm-up on the side stream (allocator, lazy init), as the capture recipe requires
+                    self._captured_iteration(learn)
+                    if learn:
+                        self.replay.note_replayed_add()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                env.bind_torch_stream(torch.cuda.current_stream(self.device))  # the capture stream
+                self._captured_iteration(learn)
+            env.bind_torch_stream(torch.cuda.current_stream(self.device))
+        env.account_steps(-1)  # the recorded (not executed) sgk_step bumped the host-side counters once
+        self._graphs[learn] = graph
+
+    def step_graphed(self, learn=True):
+        """One lockstep iteration = one graph replay (+ two scalar updates)."""
+        self._eps_dev.fill_(self.epsilon)
+        self._graphs[learn].replay()
+        self.env.account_steps(1)
+        if learn:
+            self.replay.note_replayed_add()
+        t = self.t
+        self.update_epsilon()
+        if learn and t % self.sync_every == self.sync_every - 1:
+            self.sync_target_Q()
 
     def warmup(self, n_steps):
         """dqn_warmup (warmup.py:8-23): fill the replay with random-action slices."""

@@ -261,6 +261,10 @@ class BatchedGridworldEnv:
         _lib.check(fn(self._h.ptr, int(n_steps), flags))
         return self._step_outputs()
 
+    def account_steps(self, n_steps):
+        """After replaying an external graph that contains step() launches: advance the host-side counters."""
+        _lib.check(self.lib.sgk_account_steps(self._h.ptr, int(n_steps)))
+
     def obs_f32(self, out=None):
         """float32 [N, n_cells] observation for the Q-network (what the reference builds per sample, value.py:161-164)."""
         import torch

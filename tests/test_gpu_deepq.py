@@ -103,3 +103,57 @@ def test_pipeline_steps_learns_and_env_stays_bit_exact_vs_oracle():
     m = env.metrics()
     assert m[:6].tolist() == orc_m[:6].tolist() and m[8:12].tolist() == orc_m[8:12].tolist()
     env.close()
+
+
+def test_graph_captured_iteration_matches_oracle_env_and_learns():
+    import torch
+
+    torch.manual_seed(7)
+    n = 4096
+    env = S.BatchedGridworldEnv("SideEffectsSokoban-v0", n, seed=2, layout="compact")
+    env.bind_torch_stream()
+    orc = O.EnvBatch("SideEffectsSokoban-v0", n)
+    orc_m = O.metrics_new()
+    agent = S.BatchedDeepQAgent(env, _args(sync_every=7), sgd_steps=1, replay_slices=3)
+
+    def mirror(slice_k):
+        acts = agent.replay.actions[slice_k].cpu().numpy()
+        rec = orc.rollout(1, actions=acts[None], auto_reset=False, metrics=orc_m)
+        assert (agent.replay.rewards[slice_k].cpu().numpy() == rec[:, 0]).all()
+        assert (agent.replay.successors[slice_k].cpu().numpy() == orc.boards()).all()
+        for i in np.nonzero(orc.field("game_over"))[0]:
+            orc.reset(int(i))
+
+    agent.warmup(3)
+    for k in range(3):
+        mirror(k)
+    t_before = env.lockstep_t
+    agent.enable_graphs(learn=True)   # 3 eager warm-up iterations on a side stream + capture
+    assert env.lockstep_t == t_before + 3
+    for k in range(3):                # the warm-up iterations wrote slices 0, 1, 2 again
+        mirror(k)
+    before = [p.detach().clone() for p in agent.Q.parameters()]
+    for it in range(25):
+        k = agent.replay.head
+        agent.step_graphed(learn=True)
+        torch.cuda.synchronize()
+        mirror(k)
+        assert (env.boards_host().reshape(n, -1) == orc.boards()).all(), it
+    assert env.lockstep_t == t_before + 3 + 25 and agent.t == 25
+    assert torch.isfinite(agent.last_loss).item()
+    assert any((a != b).any().item() for a, b in zip(before, agent.Q.parameters()))
+    m = env.metrics()
+    assert m[:6].tolist() == orc_m[:6].tolist() and m[_lib_M_STEPS()] == (3 + 3 + 25) * n
+    # the no-learning graph
+    agent.enable_graphs(learn=False)
+    for _ in range(5):
+        agent.step_graphed(learn=False)
+    torch.cuda.synchronize()
+    assert env.lockstep_t == t_before + 3 + 25 + 3 + 5
+    env.close()
+
+
+def _lib_M_STEPS():
+    from safe_grid_agents_amd import _lib
+
+    return _lib.M_STEPS

@@ -439,3 +439,22 @@ def test_error_paths_on_gpu():
         e.step_random(101, auto_reset=True)
         assert e.metrics()[_lib.M_STEPS] == 101 * n
         e.close()
+
+
+def test_env_traces_on_gpu_single_env(golden_dir):
+    """The HIP single env replays the committed env traces step for step."""
+    _torch()
+    with open(os.path.join(golden_dir, "env_traces.json")) as f:
+        traces = json.load(f)
+    for name, tr in traces.items():
+        env = S.make(name)
+        s = env.reset()
+        assert s.ravel().astype(int).tolist() == tr["initial_board"]
+        for t, (a, want) in enumerate(zip(tr["actions"], tr["steps"])):
+            s, r, d, info = env.step(a)
+            assert [r, info["hidden_reward"], int(d)] == want[:3], (name, t)
+            if str(t) in tr["boards"]:
+                assert s.ravel().astype(int).tolist() == tr["boards"][str(t)]
+            if d:
+                env.reset()
+        env.close()

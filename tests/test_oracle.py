@@ -161,3 +161,22 @@ def test_multithreaded_rollout_equals_single_thread():
     a.rollout(steps, seed=3, env_begin=17, auto_reset=True, metrics=ma)
     assert O.rollout_mt(b, steps, 5, seed=3, env_begin=17, auto_reset=True, metrics=mb) == 5
     assert (a.boards() == b.boards()).all() and ma.tolist() == mb.tolist()
+
+
+def test_env_traces_are_frozen(golden_dir):
+    """The oracle reproduces the committed traces (tests/golden/make_env_traces.py): semantics cannot drift silently."""
+    import json
+    import os
+
+    with open(os.path.join(golden_dir, "env_traces.json")) as f:
+        traces = json.load(f)
+    for name, tr in traces.items():
+        e = O.EnvBatch(name, 1)
+        assert e.board(0).ravel().tolist() == tr["initial_board"]
+        for t, (a, want) in enumerate(zip(tr["actions"], tr["steps"])):
+            r, h, d, _ = e.step(0, a)
+            assert [r, h, d, int(e.field("agent_cell")[0]), int(e.field("box_cell")[0])] == want, (name, t)
+            if str(t) in tr["boards"]:
+                assert e.board(0).ravel().tolist() == tr["boards"][str(t)]
+            if d:
+                e.reset(0)

@@ -121,6 +121,18 @@ for _ in range(20):
 dt = wall_time(lambda: dq.step(learn=True), 300)
 out.append({"config": 4, "what": "same with learning: 1 SGD step (batch 64, Adam amsgrad) per lockstep step, replay 8 x 32768 transitions",
             "us_per_step": dt * 1e6, "env_steps_per_s": n / dt})
+dq.enable_graphs(learn=False)
+dq.enable_graphs(learn=True)
+for _ in range(20):
+    dq.step_graphed(learn=False)
+dt = wall_time(lambda: dq.step_graphed(learn=False), 500)
+out.append({"config": 4, "what": "no learning, the whole lockstep iteration replayed from one hipGraph (torch.cuda.CUDAGraph incl. the library's kernels)",
+            "us_per_step": dt * 1e6, "env_steps_per_s": n / dt})
+for _ in range(20):
+    dq.step_graphed(learn=True)
+dt = wall_time(lambda: dq.step_graphed(learn=True), 500)
+out.append({"config": 4, "what": "with learning (1 SGD step, batch 64, Adam amsgrad capturable), one hipGraph per lockstep iteration",
+            "us_per_step": dt * 1e6, "env_steps_per_s": n / dt})
 env.close()
 
 for o in out:
