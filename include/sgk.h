@@ -49,6 +49,11 @@ extern "C" {
 #define SGK_LAYOUT_PITCHED 0 /* env-major rows padded to a multiple of 16 B: one lane writes its row with 16-B stores */
 #define SGK_LAYOUT_COMPACT 1 /* env-major rows of exactly n_cells bytes: workgroup tile staged through LDS */
 
+/* memory placement, OR-ed into the `layout` argument of sgk_create_ex */
+#define SGK_MEM_HOST_VISIBLE 0x100 /* state words, step records, boards in pinned device-mapped HOST memory: for the
+                                      single-env / small-batch case with a host-side agent in the loop (sgk_step_host then
+                                      needs no staging copies: one launch + one synchronisation). n_envs <= 65536. */
+
 typedef struct sgk_env sgk_env;   /* one shard: N independent grid instances resident on one GPU */
 typedef struct sgk_tabq sgk_tabq; /* N private tabular-Q agents bound to an sgk_env */
 

@@ -48,6 +48,8 @@ struct sgk_env {
   int8_t *dense_scratch = nullptr;
   uint8_t *actions_scratch = nullptr;
   uint8_t *pinned = nullptr;         // host staging for sgk_step_host: [actions n][rec 4n][state 8n][boards n*n_cells]
+  bool host_visible = false;         // SGK_MEM_HOST_VISIBLE: state/rec/boards/actions live in pinned device-mapped host memory
+  uint8_t *hv_actions = nullptr;     // host-visible action buffer (host_visible mode)
   std::map<std::pair<int32_t, uint32_t>, hipGraphExec_t> graphs;
   bool use_graph = true;
   int partitions = 1;                 // independent env partitions stepped on concurrent graph branches
@@ -115,6 +117,13 @@ int sgk_destroy(sgk_env *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto &kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   sgk::Shard &s = h->sh;
+  if (h->host_visible) {
+    if (s.state) (void)hipHostFree(s.state);
+    if (s.rec) (void)hipHostFree(s.rec);
+    if (s.boards) (void)hipHostFree(s.boards);
+    if (h->hv_actions) (void)hipHostFree(h->hv_actions);
+    s.state = nullptr; s.rec = nullptr; s.boards = nullptr;
+  }
   (void)hipFree(s.rules_dev); (void)hipFree(s.state); (void)hipFree(s.rec); (void)hipFree(s.boards); (void)hipFree(s.last_return);
   (void)hipFree(s.last_perf); (void)hipFree(s.n_episodes); (void)hipFree(s.metrics); (void)hipFree(s.metric_slab); (void)hipFree(s.wg_count); (void)hipFree(s.wg_offset);
   (void)hipFree(s.finished_total); (void)hipFree(h->t_dev); (void)hipFree(h->dense_scratch);
@@ -135,7 +144,10 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   if (!out) return fail(SGK_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (n_envs <= 0 || n_envs > ((int64_t)1 << 31) - 512) return fail(SGK_ERR_INVALID, "n_envs out of range");
+  const bool host_visible = (layout & SGK_MEM_HOST_VISIBLE) != 0;
+  layout &= ~SGK_MEM_HOST_VISIBLE;
   if (layout != SGK_LAYOUT_PITCHED && layout != SGK_LAYOUT_COMPACT) return fail(SGK_ERR_INVALID, "unknown layout");
+  if (host_visible && n_envs > 65536) return fail(SGK_ERR_INVALID, "SGK_MEM_HOST_VISIBLE is for small batches (<= 65536 envs)");
   int n_dev = 0;
   hipError_t e = hipGetDeviceCount(&n_dev);
   if (e != hipSuccess || n_dev <= 0)
@@ -188,9 +200,19 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   const int64_t n_pad = ((s.n + 255) / 256) * 256;
   const int64_t n_wg = n_pad / 256;
   SGK_TRY(hipMalloc(&s.rules_dev, sizeof(SgkRules)));
-  SGK_TRY(hipMalloc(&s.state, sizeof(uint64_t) * n_pad));
-  SGK_TRY(hipMalloc(&s.rec, sizeof(uint32_t) * n_pad));
-  SGK_TRY(hipMalloc(&s.boards, (size_t)s.pitch * n_pad));
+  h->host_visible = host_visible;
+  if (host_visible) {
+    // pinned, fine-grained, device-mapped host memory: the kernels read/write it over PCIe, the host reads it after one
+    // stream synchronisation -- no staging copies for the single-env / small-batch host-in-the-loop case
+    SGK_TRY(hipHostMalloc((void **)&s.state, sizeof(uint64_t) * n_pad, hipHostMallocMapped));
+    SGK_TRY(hipHostMalloc((void **)&s.rec, sizeof(uint32_t) * n_pad, hipHostMallocMapped));
+    SGK_TRY(hipHostMalloc((void **)&s.boards, (size_t)s.pitch * n_pad, hipHostMallocMapped));
+    SGK_TRY(hipHostMalloc((void **)&h->hv_actions, (size_t)n_pad, hipHostMallocMapped));
+  } else {
+    SGK_TRY(hipMalloc(&s.state, sizeof(uint64_t) * n_pad));
+    SGK_TRY(hipMalloc(&s.rec, sizeof(uint32_t) * n_pad));
+    SGK_TRY(hipMalloc(&s.boards, (size_t)s.pitch * n_pad));
+  }
   SGK_TRY(hipMalloc(&s.last_return, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.last_perf, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.n_episodes, sizeof(int32_t) * n_pad));
@@ -300,6 +322,25 @@ int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_s
   if (!actions_host) return fail(SGK_ERR_INVALID, "actions_host is NULL");
   sgk::Shard &s = h->sh;
   const size_t n = (size_t)s.n, bbytes = n * (size_t)s.n_cells;
+  if (h->host_visible) {
+    // zero-copy: the action vector, the state words, the records and the boards are host-visible; one launch, one sync
+    memcpy(h->hv_actions, actions_host, n);
+    int rc0 = sgk_step(h, h->hv_actions, flags);
+    if (rc0 != SGK_OK) return rc0;
+    // latency matters here, not CPU time: poll instead of a blocking wait (bounded, then fall back to the blocking form)
+    {
+      hipError_t q = hipErrorNotReady;
+      for (int spin = 0; spin < 2000000 && q == hipErrorNotReady; ++spin) q = hipStreamQuery(h->stream);
+      if (q == hipErrorNotReady) q = hipStreamSynchronize(h->stream);
+      if (q != hipSuccess) return hip_fail(q, "sgk_step_host wait");
+    }
+    if (rec_host) memcpy(rec_host, s.rec, 4 * n);
+    if (boards_host)
+      for (size_t i = 0; i < n; ++i) memcpy(boards_host + i * s.n_cells, s.boards + i * s.pitch, (size_t)s.n_cells);
+    if (episode_return_host)
+      for (size_t i = 0; i < n; ++i) episode_return_host[i] = (int32_t)(int16_t)((uint32_t)(s.state[i] >> 32) & 0xffff);
+    return SGK_OK;
+  }
   // one pinned staging block, every transfer asynchronous on the handle's stream, ONE synchronisation per call
   const size_t off_rec = (n + 15) / 16 * 16, off_state = off_rec + 4 * n, off_boards = off_state + 8 * n;
   if (!h->pinned) SGK_HIP(hipHostMalloc((void **)&h->pinned, off_boards + bbytes + 16, hipHostMallocDefault));

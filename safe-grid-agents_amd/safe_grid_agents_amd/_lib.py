@@ -17,6 +17,7 @@ SGK_OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE = -1, -2, -3, -4
 F_AUTO_RESET, F_NO_BOARDS = 1, 2
 LAYOUT_PITCHED, LAYOUT_COMPACT = 0, 1
+MEM_HOST_VISIBLE = 0x100
 BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN = 0, 1, 2
 METRICS_LEN = 16
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, _M_RESERVED,
@@ -108,6 +109,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH):
+        try:  # a build step, not a fallback: compile the HIP library in-tree when hipcc is at hand
+            build()
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "safe_grid_agents_amd: %s is missing. Build it with `python -c \"import __graft_entry__ as g; g.build()\"` "

@@ -103,13 +103,14 @@ class BatchedGridworldEnv:
     writes it; `.clone()` to keep).
     """
 
-    def __init__(self, name, n_envs, device=0, seed=0, env_index_base=0, layout="pitched"):
+    def __init__(self, name, n_envs, device=0, seed=0, env_index_base=0, layout="pitched", host_visible=False):
         if name not in ENV_IDS:
             raise KeyError("unknown or out-of-scope env %r; available: %s" % (name, sorted(ENV_IDS)))
         self.name = name
         self.n_envs = int(n_envs)
         self._h = _Handle(ENV_IDS[name], self.n_envs, int(device), int(seed or 0), int(env_index_base),
-                          {"pitched": _lib.LAYOUT_PITCHED, "compact": _lib.LAYOUT_COMPACT}[layout])
+                          {"pitched": _lib.LAYOUT_PITCHED, "compact": _lib.LAYOUT_COMPACT}[layout]
+                          | (_lib.MEM_HOST_VISIBLE if host_visible else 0))
         self.lib = self._h.lib
         info = _lib.SgkInfo()
         _lib.check(self.lib.sgk_get_info(self._h.ptr, ctypes.byref(info)))
@@ -370,7 +371,7 @@ class GridworldEnv:
     """
 
     def __init__(self, name, device=0):
-        self._b = BatchedGridworldEnv(name, 1, device=device)
+        self._b = BatchedGridworldEnv(name, 1, device=device, host_visible=True)
         self.name = name
         self.action_space = self._b.action_space
         self.observation_space = self._b.observation_space
@@ -390,7 +391,7 @@ class GridworldEnv:
         self._b.close()
 
     def reset(self):
-        self._b.reset()
+        _lib.check(self._b.lib.sgk_reset(self._b.handle, None))  # host-visible memory: no torch views involved
         self._episode_return = 0
         self._over = False
         return self._b.boards_host()[0].astype(np.float32)

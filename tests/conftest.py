@@ -11,6 +11,19 @@ for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # (re)build the native pieces when sources are newer than the in-tree .so files (hipcc cross-compiles on CPU boxes)
+    try:
+        from safe_grid_agents_amd import _lib
+
+        _lib.build()
+    except Exception as exc:  # the tests that need the library will fail loudly on load
+        print("conftest: libsgk build skipped/failed: %r" % (exc,))
+    try:
+        from oracle import oracle as O
+
+        O.build()
+    except Exception as exc:
+        print("conftest: oracle build skipped/failed: %r" % (exc,))
 
 
 @pytest.fixture(scope="session")
