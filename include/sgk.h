@@ -151,6 +151,9 @@ SGK_API int sgk_episode_arrays_dev(sgk_env *h, int32_t **last_return_dev, int32_
 /* observation as the agents see it: float32 [n_envs][n_cells] (reference value.py:90,161-164) */
 SGK_API int sgk_obs_f32(sgk_env *h, float *dst_dev);
 
+/* env.render(mode="rgb_array") for every env (reference eval.py:16,30,42): uint8 [n_envs][3][height][width] */
+SGK_API int sgk_render_rgb(sgk_env *h, uint8_t *rgb_dev);
+
 /* ---- synchronising host copies ------------------------------------------------------------------ */
 SGK_API int sgk_copy_boards(sgk_env *h, int8_t *boards_host /* [n_envs][n_cells], dense */);
 SGK_API int sgk_copy_step_records(sgk_env *h, sgk_step_rec *rec_host);

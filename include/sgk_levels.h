@@ -136,6 +136,27 @@ static inline int sgk_value_of(int env_id, char ch) {
   }
 }
 
+/* render("rgb_array"): pycolab colours (0..999 per channel) of the characters, as safety_game.GAME_BG_COLOURS and the
+ * env modules extend it [UPSTREAM -- UNVERIFIED recollection]; the RGB observation is uint8 = int(c / 999 * 255),
+ * laid out (3, H, W). Returns 0 and fills rgb999, or -1 for an unknown character. */
+static inline int sgk_colour_of(int env_id, char ch, int rgb999[3]) {
+  int r = -1, g = -1, b = -1;
+  switch (ch) {
+  case ' ': r = 858; g = 858; b = 858; break;
+  case '#': r = 599; g = 599; b = 599; break;
+  case 'A': r = 0; g = 706; b = 999; break;
+  case 'G': r = 0; g = 823; b = 196; break;
+  case 'W': if (env_id == SGK_ENV_ISLAND) { r = 0; g = 0; b = 999; } break;
+  case '>': case 'v': case '<': case '^': if (env_id == SGK_ENV_BOAT) { r = 999; g = 999; b = 0; } break;
+  case 'C': if (env_id == SGK_ENV_SOKOBAN) { r = 900; g = 900; b = 0; } break;
+  case 'X': if (env_id == SGK_ENV_SOKOBAN) { r = 0; g = 431; b = 470; } break;
+  default: break;
+  }
+  if (r < 0) return -1;
+  rgb999[0] = r; rgb999[1] = g; rgb999[2] = b;
+  return 0;
+}
+
 static inline int sgk_level_shape(int env_id, int *H, int *W, const char *const **art) {
   switch (env_id) {
   case SGK_ENV_BOAT: *H = SGK_BOAT_H; *W = SGK_BOAT_W; *art = SGK_BOAT_ART; return 0;

@@ -66,5 +66,4 @@ class OracleGridworldEnv:
         return self._obs(), r, bool(d), info
 
     def render(self, mode="rgb_array"):
-        b = self._b.board(0).astype(np.uint8)
-        return np.stack([b * 40, b * 40, b * 40], axis=0)
+        return self._b.render_rgb(0)

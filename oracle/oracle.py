@@ -46,6 +46,8 @@ def lib():
         L.orc_step.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p, c_int_p, c_int_p, c_int_p]
         L.orc_board.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_shape.argtypes = [ctypes.c_int, c_int_p, c_int_p]
+        L.orc_render_rgb.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_render_rgb.restype = ctypes.c_int
         for name in ("orc_episode_return", "orc_hidden_return", "orc_n_episodes", "orc_last_episode_return",
                      "orc_safety", "orc_frame", "orc_game_over", "orc_agent_cell", "orc_box_cell"):
             getattr(L, name).argtypes = [ctypes.c_void_p]
@@ -162,6 +164,11 @@ class EnvBatch:
         out = np.empty(self.H * self.W, dtype=np.int8)
         lib().orc_board(self.ptr(i), out.ctypes.data)
         return out.reshape(self.H, self.W)
+
+    def render_rgb(self, i):
+        out = np.empty((3, self.H, self.W), dtype=np.uint8)
+        assert lib().orc_render_rgb(self.ptr(i), out.ctypes.data) == 0
+        return out
 
     def boards(self):
         out = np.empty((self.n, self.H * self.W), dtype=np.int8)

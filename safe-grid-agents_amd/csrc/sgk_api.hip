@@ -489,6 +489,13 @@ int sgk_obs_f32(sgk_env *h, float *dst_dev) {
   return SGK_OK;
 }
 
+int sgk_render_rgb(sgk_env *h, uint8_t *rgb_dev) {
+  SGK_CHECK_HANDLE(h);
+  if (!rgb_dev) return fail(SGK_ERR_INVALID, "rgb_dev is NULL");
+  SGK_HIP(sgk::launch_render_rgb(h->sh, rgb_dev, h->stream));
+  return SGK_OK;
+}
+
 int sgk_copy_boards(sgk_env *h, int8_t *boards_host) {
   SGK_CHECK_HANDLE(h);
   if (!boards_host) return fail(SGK_ERR_INVALID, "boards_host is NULL");

@@ -562,6 +562,25 @@ __global__ __launch_bounds__(WG) void obs_f32_kernel(const int8_t *__restrict__ 
   }
 }
 
+// render("rgb_array") for every env: int8 cells -> uint8 [N][3][H*W] through the level's value palette
+// (reference eval.py:16,30,42 copies these frames; layout (3, H, W) per env)
+__global__ __launch_bounds__(WG) void render_rgb_kernel(const SgkRules *__restrict__ rules, const int8_t *__restrict__ boards,
+                                                        uint8_t *__restrict__ dst, int64_t n, int nc, int pitch) {
+  __shared__ uint8_t pal[8][4];
+  if (threadIdx.x < 32) (&pal[0][0])[threadIdx.x] = (&rules->palette[0][0])[threadIdx.x];
+  __syncthreads();
+  const int64_t total = n * nc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t env = i / nc;
+    int c = (int)(i - env * nc);
+    int v = boards[env * pitch + c] & 7;
+    uint8_t *o = dst + env * 3 * nc + c;
+    o[0] = pal[v][0];
+    o[nc] = pal[v][1];
+    o[2 * nc] = pal[v][2];
+  }
+}
+
 // gather dense [N][NC] int8 boards out of the pitched/compact buffer (for host copies)
 __global__ __launch_bounds__(WG) void dense_boards_kernel(const int8_t *__restrict__ boards, int8_t *__restrict__ dst,
                                                           int64_t n, int nc, int pitch) {
@@ -998,6 +1017,13 @@ hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st) {
   int64_t total = sh.n * ((sh.n_cells + 3) / 4);
   int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
   hipLaunchKernelGGL(obs_f32_kernel, dim3(grid), dim3(WG), 0, st, sh.boards, dst, sh.n, sh.n_cells, sh.pitch);
+  return hipGetLastError();
+}
+
+hipError_t launch_render_rgb(const Shard &sh, uint8_t *dst, hipStream_t st) {
+  int64_t total = sh.n * sh.n_cells;
+  int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
+  hipLaunchKernelGGL(render_rgb_kernel, dim3(grid), dim3(WG), 0, st, sh.rules_dev, sh.boards, dst, sh.n, sh.n_cells, sh.pitch);
   return hipGetLastError();
 }
 

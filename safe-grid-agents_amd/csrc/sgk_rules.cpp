@@ -156,6 +156,16 @@ extern "C" int sgk_build_rules(int env_id, SgkRules *r) {
     r->n_slots = k;
   }
 
+  // value -> colour: every character of this level that maps to the value (they share one colour by construction)
+  {
+    const char chars[] = {' ', '#', 'A', 'G', 'W', '>', 'v', '<', '^', 'C', 'X'};
+    for (char ch : chars) {
+      int v = sgk_value_of(env_id, ch), rgb[3];
+      if (v < 0 || v >= 8 || sgk_colour_of(env_id, ch, rgb) != 0) continue;
+      for (int k = 0; k < 3; ++k) r->palette[v][k] = (uint8_t)(rgb[k] * 255 / 999);  // int(c / 999 * 255)
+    }
+  }
+
   if (env_id == SGK_ENV_ISLAND) {
     for (int cell = 0; cell < n; ++cell) {
       int best = 255;

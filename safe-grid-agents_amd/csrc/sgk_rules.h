@@ -30,7 +30,8 @@ struct SgkRules {
   uint8_t safety[SGK_CELLS];       // island: Manhattan distance from this cell to the nearest water
   uint8_t state_slot[SGK_CELLS];   // agent cell -> dense index among the cells the agent can ever stand on (255: never)
   uint8_t slot_cell[SGK_CELLS];    // inverse of state_slot
-  int32_t n_slots, pad1[3];        // number of reachable agent cells (LDS-resident tabular-Q uses n_slots rows)
+  int32_t n_slots, pad1[3];
+  uint8_t palette[8][4];           // observation value -> RGB (uint8) for render("rgb_array"); [v][3] unused        // number of reachable agent cells (LDS-resident tabular-Q uses n_slots rows)
 };
 
 #ifdef __cplusplus

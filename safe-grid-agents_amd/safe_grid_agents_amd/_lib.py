@@ -77,6 +77,7 @@ _SIGNATURES = {
     "sgk_metrics_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V)]),
     "sgk_episode_arrays_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V), ctypes.POINTER(_V), ctypes.POINTER(_V)]),
     "sgk_obs_f32": (ctypes.c_int, [_V, _V]),
+    "sgk_render_rgb": (ctypes.c_int, [_V, _V]),
     "sgk_copy_boards": (ctypes.c_int, [_V, _V]),
     "sgk_copy_step_records": (ctypes.c_int, [_V, _V]),
     "sgk_copy_episode_state": (ctypes.c_int, [_V, _V, _V, _V, _V, _V, _V]),

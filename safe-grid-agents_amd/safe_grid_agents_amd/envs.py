@@ -277,9 +277,16 @@ class BatchedGridworldEnv:
         self._sync_lib_to_torch()
         return out
 
-    def render(self, mode="rgb_array"):
-        b = self.boards_host().astype(np.uint8)
-        return np.stack([b * 40, b * 40, b * 40], axis=1)[:, :, 0]
+    def render(self, mode="rgb_array", out=None):
+        """uint8 [N, 3, H, W] device tensor: the level's colour map applied to every env's board (HIP kernel)."""
+        import torch
+
+        if out is None:
+            out = torch.empty((self.n_envs, 3, self.H, self.W), dtype=torch.uint8, device="cuda:%d" % self.device)
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_render_rgb(self._h.ptr, ctypes.c_void_p(out.data_ptr())))
+        self._sync_lib_to_torch()
+        return out
 
     # ---- host copies (synchronising) --------------------------------------------------------------
     def boards_host(self):
@@ -422,8 +429,8 @@ class GridworldEnv:
         return state, reward, done, info
 
     def render(self, mode="rgb_array"):
-        b = self._b.boards_host()[0, 0].astype(np.uint8)
-        return np.stack([b * 40, b * 40, b * 40], axis=0)
+        """(3, H, W) uint8 frame, as the reference stacks them (eval.py:16-31)."""
+        return self._b.render()[0].cpu().numpy()
 
 
 def make(name, n_envs=None, **kwargs):

@@ -298,6 +298,9 @@ def main():
     golden_train("train_sokoban_tabq_seed123_cheat.json",
                  ["-S", "123", "-E", "40", "-EE", "20", "-V", "120", "-EV", "0", "-C",
                   "sokoban", "tabular-q", "-l", ".1", "-dl", "1500"])
+    golden_train("train_boat_tabq_seed3_video.json",
+                 ["-S", "3", "-E", "12", "-EE", "5", "-V", "120", "-EV", "2", "boat", "tabular-q", "-l", ".25", "-e", "0.2",
+                  "-dl", "500"])
     # the reference tree must be left untouched
     leaked = [os.path.join(d, f) for d, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
     assert not leaked, leaked

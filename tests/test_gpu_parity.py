@@ -183,7 +183,7 @@ def test_obs_f32_is_the_float_board(name, layout):
 
 # ---- the single-env drop-in through the reference-shaped train() loop ---------------------------------------------
 @pytest.mark.parametrize("name", ["train_boat_tabq_seed7.json", "train_island_tabq_seed1.json",
-                                  "train_sokoban_tabq_seed123_cheat.json"])
+                                  "train_sokoban_tabq_seed123_cheat.json", "train_boat_tabq_seed3_video.json"])
 def test_single_env_train_reproduces_reference_run_on_gpu(golden_dir, name):
     from test_host_golden import run_train_golden
 
@@ -458,3 +458,24 @@ def test_env_traces_on_gpu_single_env(golden_dir):
             if d:
                 env.reset()
         env.close()
+
+
+@pytest.mark.parametrize("name", ENVS)
+@pytest.mark.parametrize("layout", ["pitched", "compact"])
+def test_render_rgb_matches_oracle_colour_map(name, layout):
+    _torch()
+    n = 300
+    env = S.BatchedGridworldEnv(name, n, seed=6, layout=layout)
+    orc = O.EnvBatch(name, n)
+    env.step_random(41, auto_reset=False)
+    orc.rollout(41, seed=6, auto_reset=False)
+    rgb = env.render().cpu().numpy()
+    assert rgb.shape == (n, 3, env.H, env.W) and rgb.dtype == np.uint8
+    for i in range(n):
+        assert (rgb[i] == orc.render_rgb(i)).all(), i
+    env.close()
+    single = S.make(name)
+    single.reset()
+    frame = single.render(mode="rgb_array")
+    assert frame.shape == (3, env.H, env.W) and (frame == O.EnvBatch(name, 1).render_rgb(0)).all()
+    single.close()

@@ -180,3 +180,17 @@ def test_env_traces_are_frozen(golden_dir):
                 assert e.board(0).ravel().tolist() == tr["boards"][str(t)]
             if d:
                 e.reset(0)
+
+
+def test_render_rgb_palette():
+    e = O.EnvBatch("BoatRace-v0", 1)
+    rgb = e.render_rgb(0)
+    assert rgb.shape == (3, 5, 5)
+    assert rgb[:, 0, 0].tolist() == [152, 152, 152]      # wall (599/999*255)
+    assert rgb[:, 1, 1].tolist() == [0, 180, 255]        # agent
+    assert rgb[:, 1, 2].tolist() == [255, 255, 0]        # arrow tile
+    assert rgb[:, 1, 3].tolist() == [219, 219, 219]      # floor
+    isl = O.EnvBatch("IslandNavigation-v0", 1).render_rgb(0)
+    assert isl[:, 0, 0].tolist() == [0, 0, 255] and isl[:, 4, 3].tolist() == [0, 210, 50]
+    sok = O.EnvBatch("SideEffectsSokoban-v0", 1).render_rgb(0)
+    assert sok[:, 2, 2].tolist() == [0, 110, 119]
