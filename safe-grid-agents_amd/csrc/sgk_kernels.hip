@@ -106,7 +106,7 @@ __host__ __device__ __forceinline__ int action_from_block(const uint32_t x[4], u
 }
 
 template <int ENV>
-__host__ __device__ __forceinline__ void transition(const SgkRules &R, EnvState &s, int action, int &r_obs, int &r_hid, int &term);
+__host__ __device__ __forceinline__ uint32_t transition(const SgkRules &R, EnvState &s, int action, int &r_obs, int &r_hid, int &term);
 
 // the kernels' transition function evaluated on the host for ONE (state, action): lets the CPU test-suite check
 // the rule tables and the push logic against the oracle without a GPU. Never used by a product path.
@@ -134,12 +134,12 @@ int host_random_action(uint64_t seed, uint64_t env, uint64_t t) {
 // one env transition against the LDS-resident rule tables
 // ------------------------------------------------------------------------------------------------
 template <int ENV>
-__host__ __device__ __forceinline__ void transition(const SgkRules &R, EnvState &s, int action, int &r_obs, int &r_hid, int &term) {
+__host__ __device__ __forceinline__ uint32_t transition(const SgkRules &R, EnvState &s, int action, int &r_obs, int &r_hid, int &term) {
   uint32_t e = R.trans[s.pos * SGK_ACTIONS + action];
   int next = (int)(e & 0xff);
   r_obs = (int)(int8_t)(e >> 8);
   r_hid = (int)(int8_t)(e >> 16);
-  term = (int)(e >> 24);
+  term = (int)((e >> 24) & 1u);
   if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
     // push rule: the box moves when the agent walks into it and the cell behind it is free;
     // otherwise the box is impassable for the agent and the move is refused.
@@ -158,6 +158,7 @@ __host__ __device__ __forceinline__ void transition(const SgkRules &R, EnvState 
     }
   }
   s.pos = next;
+  return e;  // bits 25..31: slot of the static next cell (valid when no dynamic obstacle refused the move)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -847,7 +848,8 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
       const int si_prev = si;
       if (live) {
         int term;
-        transition<ENV>(R, s, action, r_obs, r_hid, term);
+        uint32_t e = transition<ENV>(R, s, action, r_obs, r_hid, term);
+        si = (int)(e >> 25);  // successor's slot straight from the transition word (no box in these levels)
         s.frame += 1;
         s.ret += r_obs;
         s.hid += r_hid;
@@ -855,7 +857,6 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
       }
       rec = pack_rec(r_obs, r_hid, (valid && (s.over || finished)) ? 1 : 0, action);
       // learn (no terminal masking: value.py:48-50 bootstraps from Q[s'] even when the episode ended)
-      si = R.state_slot[s.pos];
       double n0 = Q[(si * 4 + 0) * 64 + lane], n1 = Q[(si * 4 + 1) * 64 + lane];
       double n2 = Q[(si * 4 + 2) * 64 + lane], n3 = Q[(si * 4 + 3) * 64 + lane];
       if (live) {

@@ -14,7 +14,8 @@
 //   bits  0..7   next cell (== cell when a wall blocks the move)
 //   bits  8..15  observed reward (int8)
 //   bits 16..23  hidden reward  (int8)
-//   bits 24..31  1 when the episode terminates on arrival
+//   bit  24      1 when the episode terminates on arrival
+//   bits 25..31  dense slot of the next cell (state_slot[next]; 0x7f when the cell is unreachable)
 struct SgkRules {
   int32_t env_id, height, width, n_cells;
   int32_t start_agent, start_box;  // start_box == 255 when the level has no box
