@@ -11,7 +11,7 @@ from .loops import (EVAL_MAP, LEARN_MAP, WARMUP_MAP, batched_default_eval, batch
                     default_eval,
                     dqn_learn, dqn_warmup, noop_warmup, tabq_learn, whiler)
 from .metering import AverageMeter, BatchMetrics, NullWriter, RecordingWriter, make_meters, track_metrics
-from .trainer import prepare_parser, train
+from .trainer import prepare_parser, train, train_batched
 
 __all__ = [
     "AGENT_MAP", "ENV_MAP", "ENV_IDS", "LEARN_MAP", "EVAL_MAP", "WARMUP_MAP",
@@ -21,5 +21,5 @@ __all__ = [
     "whiler", "tabq_learn", "dqn_learn", "default_eval", "dqn_warmup", "noop_warmup",
     "batched_random_rollout", "batched_tabq_learn", "batched_default_eval",
     "AverageMeter", "make_meters", "track_metrics", "BatchMetrics", "NullWriter", "RecordingWriter",
-    "prepare_parser", "train",
+    "prepare_parser", "train", "train_batched",
 ]

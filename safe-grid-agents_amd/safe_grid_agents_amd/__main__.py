@@ -4,7 +4,7 @@ default log dir runs/<env>/<agent>/<baseline|corrupt>/<seed>."""
 import os
 import random
 
-from .trainer import prepare_parser, train
+from .trainer import prepare_parser, train, train_batched
 
 
 def main(argv=None):
@@ -17,6 +17,8 @@ def main(argv=None):
         cheating = "baseline" if args.cheat else "corrupt"
         args.log_dir = os.path.join("runs", args.env_alias, args.agent_alias, cheating, str(args.seed))
     os.makedirs(args.log_dir, exist_ok=True)
+    if getattr(args, "n_envs", 0) > 0:
+        return train_batched(args)
     return train(args)
 
 

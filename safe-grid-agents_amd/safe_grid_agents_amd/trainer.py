@@ -28,6 +28,8 @@ _CORE_FLAGS = [
     ("cheat", "C", dict(action="store_true")),
     ("log-dir", "L", dict(type=str)),
     ("disable-cuda", "dc", dict(action="store_true")),
+    # extension: N > 0 runs N envs with N private agents in lockstep on the GPU (train_batched)
+    ("n-envs", "N", dict(type=int, default=0)),
 ]
 _LR = ("lr", "l", dict(type=float, required=True))
 _EPS = ("epsilon", "e", dict(type=float, default=0.01))
@@ -119,3 +121,46 @@ def train(args, config=None, reporter=_noop, env_factory=None, writer_factory=No
             eval_history = eval_fn(agent, env, eval_history, args)
     eval_history = eval_fn(agent, env, eval_history, args)
     return agent, history, eval_history
+
+
+def train_batched(args, writer_factory=None, reporter=_noop):
+    """The same experiment for `args.n_envs` independent (env, agent) pairs in lockstep on one GPU.
+
+    Keeps train()'s cadence in units of lockstep steps: one "episode" = `max_iterations` steps (every env finishes at least
+    one episode in that span), an evaluation (greedy, batched_default_eval) after every `eval_every` of them and once at
+    the end; metrics are the aggregate meters (BatchMetrics) written under the reference's tensorboard tags. Supports the
+    agents whose learning runs on the device: tabular-q and random."""
+    from .agents import BatchedTabularQAgent
+    from .loops import batched_default_eval
+    from .metering import BatchMetrics
+
+    env_name = ENV_MAP[args.env_alias]
+    writer = (writer_factory or _default_writer)(getattr(args, "log_dir", None))
+    for key, value in vars(args).items():
+        writer.add_text("data/{}".format(key), str(value))
+    env = _envs.make(env_name, n_envs=args.n_envs, seed=args.seed or 0)
+    horizon = int(env.info.max_iterations)
+    if args.agent_alias == "tabular-q":
+        agent = BatchedTabularQAgent(env, args)
+    elif args.agent_alias == "random":
+        agent = None
+    else:
+        raise KeyError("train_batched supports tabular-q and random, not %r" % (args.agent_alias,))
+    period = 0
+    for episode in range(1, args.episodes + 1):
+        env.metrics_reset()
+        if agent is None:
+            env.step_random(horizon, auto_reset=True)
+        else:
+            agent.rollout(horizon, cheat=args.cheat)
+        bm = BatchMetrics(env.metrics())
+        bm.write(writer, episode, prefix="Train/")
+        if agent is not None:
+            writer.add_scalar("Train/epsilon", agent.epsilon, agent.t)
+        reporter(hidden_reward=bm.meter("safeties")["avg"], obs_reward=bm.meter("returns")["avg"])
+        if agent is not None and (episode % args.eval_every == args.eval_every - 1 or episode == args.episodes):
+            print("#### EVAL ####")
+            batched_default_eval(agent, env, args.eval_timesteps).write(writer, period, prefix="Evaluation/")
+            period += 1
+            env.reset()
+    return agent, env

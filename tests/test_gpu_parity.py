@@ -479,3 +479,28 @@ def test_render_rgb_matches_oracle_colour_map(name, layout):
     frame = single.render(mode="rgb_array")
     assert frame.shape == (3, env.H, env.W) and (frame == O.EnvBatch(name, 1).render_rgb(0)).all()
     single.close()
+
+
+def test_cli_batched_training_runs_and_improves_returns(tmp_path):
+    """`python -m safe_grid_agents_amd -N 4096 island tabular-q ...`: the batched trainer end to end."""
+    _torch()
+    from safe_grid_agents_amd.__main__ import main
+
+    writers = []
+    import safe_grid_agents_amd.trainer as T
+
+    orig = T._default_writer
+    T._default_writer = lambda d: writers.append(S.RecordingWriter(d)) or writers[-1]
+    try:
+        agent, env = main(["-S", "3", "-E", "12", "-EE", "6", "-V", "60", "-N", "4096", "-L", str(tmp_path),
+                           "island", "tabular-q", "-l", ".5", "-e", "0.05", "-dl", "600"])
+    finally:
+        T._default_writer = orig
+    calls = writers[0].calls
+    train_returns = [c[2]["avg"] for c in calls if c[0] == "scalars" and c[1] == "Train/returns"]
+    evals = [c for c in calls if c[0] == "scalars" and c[1] == "Evaluation/returns"]
+    assert len(train_returns) == 12 and len(evals) == 3  # episodes 5 and 11 (cadence) + the final one, as train.py:70-81
+    first, last = float.fromhex(train_returns[0]), float.fromhex(train_returns[-1])
+    assert last > first  # learning: mean episode return improves from the random-walk start
+    assert agent.t == 12 * 100
+    env.close()
