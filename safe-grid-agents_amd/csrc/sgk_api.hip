@@ -195,6 +195,10 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(hipGetDeviceProperties(&prop, device));
   s.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   s.max_grid = s.n_cus * 8;
+  if (const char *mg = getenv("SGK_MAX_GRID")) {  // tuning knob: workgroups per launch (grid-stride over env tiles)
+    int v = atoi(mg);
+    if (v >= 64) s.max_grid = v;
+  }
   SGK_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   const int64_t n_pad = ((s.n + 255) / 256) * 256;
@@ -218,7 +222,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(hipMalloc(&s.n_episodes, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.metrics, sizeof(int64_t) * SGK_METRICS_LEN));
   SGK_TRY(hipMalloc(&s.metric_slab, sizeof(int64_t) * SGK_METRICS_LEN * SGK_METRIC_SLOTS));
-  if (s.max_grid > SGK_METRIC_SLOTS) s.max_grid = SGK_METRIC_SLOTS;
+  // (grids larger than SGK_METRIC_SLOTS are fine: slots are indexed modulo and updated atomically)
   SGK_TRY(hipMalloc(&s.wg_count, sizeof(int32_t) * n_wg));
   SGK_TRY(hipMalloc(&s.wg_offset, sizeof(int64_t) * n_wg));
   SGK_TRY(hipMalloc(&s.finished_total, sizeof(int64_t)));
