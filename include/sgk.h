@@ -187,6 +187,14 @@ SGK_API int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_coun
 SGK_API int sgk_tabq_global_step(const sgk_tabq *q, int64_t *t_out);
 SGK_API double sgk_tabq_epsilon(double epsilon, int64_t epsilon_anneal, int64_t t); /* epsilon in force at global step t */
 
+/* ---- PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186), batched ------------------------------ */
+/* rewards_dev / returns_dev: float32 [n_trajectories][t_max] row-major; lengths_dev: int32 [n_trajectories] or NULL
+ * (every trajectory t_max long). returns[i][t] = sum_{k >= t} float32(discount ** k) * rewards[i][k], accumulated left
+ * to right in float32 exactly as the reference's Python sum() does (bit-exact, tests/golden/discounted_returns.json).
+ * t_max <= 1024. Runs on the handle's stream. */
+SGK_API int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const int32_t *lengths_dev, float *returns_dev,
+                                   int64_t n_trajectories, int32_t t_max, double discount);
+
 /* ---- host-only debug hooks for the CPU test-suite (no GPU needed; never used by a product path) ------- */
 /* The kernels' transition function, evaluated on the host for one (agent cell, box cell, action):
  * out = {next agent cell, next box cell, observed reward, hidden reward, terminal}. */

@@ -65,6 +65,7 @@ def lib():
         L.orc_rollout_mt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                      ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.orc_rollout_mt.restype = ctypes.c_int
+        L.orc_discounted_returns.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
         L.orc_tabq_new.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int64]
         L.orc_tabq_new.restype = ctypes.c_void_p
         L.orc_tabq_free.argtypes = [ctypes.c_void_p]
@@ -205,6 +206,13 @@ def rollout_mt(envs, n_steps, n_threads, seed=0, env_begin=0, t_begin=0, auto_re
                                 None if metrics is None else metrics.ctypes.data, int(n_threads))
     assert used > 0, "thread creation failed"
     return used
+
+
+def discounted_returns(rewards, discount):
+    r = np.ascontiguousarray(rewards, dtype=np.float32)
+    out = np.empty_like(r)
+    lib().orc_discounted_returns(r.ctypes.data, r.shape[0], float(discount), out.ctypes.data)
+    return out
 
 
 class TabQ:

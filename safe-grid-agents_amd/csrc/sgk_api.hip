@@ -3,6 +3,7 @@
 // needs a GPU and says so when there is none.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -48,6 +49,8 @@ struct sgk_env {
   int8_t *dense_scratch = nullptr;
   uint8_t *actions_scratch = nullptr;
   uint8_t *pinned = nullptr;         // host staging for sgk_step_host: [actions n][rec 4n][state 8n][boards n*n_cells]
+  float *gamma_dev = nullptr;        // [1024] float32(discount ** t) for sgk_discounted_returns
+  double gamma_discount = -1.0;
   bool host_visible = false;         // SGK_MEM_HOST_VISIBLE: state/rec/boards/actions live in pinned device-mapped host memory
   uint8_t *hv_actions = nullptr;     // host-visible action buffer (host_visible mode)
   std::map<std::pair<int32_t, uint32_t>, hipGraphExec_t> graphs;
@@ -128,6 +131,7 @@ int sgk_destroy(sgk_env *h) {
   (void)hipFree(s.last_perf); (void)hipFree(s.n_episodes); (void)hipFree(s.metrics); (void)hipFree(s.metric_slab); (void)hipFree(s.wg_count); (void)hipFree(s.wg_offset);
   (void)hipFree(s.finished_total); (void)hipFree(h->t_dev); (void)hipFree(h->dense_scratch);
   (void)hipFree(h->actions_scratch);
+  (void)hipFree(h->gamma_dev);
   if (h->pinned) (void)hipHostFree(h->pinned);
   for (int i = 0; i < 3; ++i) {
     if (h->side_streams[i]) (void)hipStreamDestroy(h->side_streams[i]);
@@ -424,6 +428,7 @@ int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
     }
     for (int i = 0; i < P - 1 && le == hipSuccess; ++i) le = hipStreamWaitEvent(h->stream, h->join_events[i], 0);
     if (le == hipSuccess) {
+      (void)hipGetLastError();
       hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, (uint64_t)n_steps);
       le = hipGetLastError();
     }
@@ -436,6 +441,7 @@ int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
     it = h->graphs.emplace(key, exec).first;
   }
   if (h->t_dev_stale) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, s.lockstep_t);
     SGK_HIP(hipGetLastError());
     h->t_dev_stale = false;
@@ -490,6 +496,25 @@ int sgk_obs_f32(sgk_env *h, float *dst_dev) {
   SGK_CHECK_HANDLE(h);
   if (!dst_dev) return fail(SGK_ERR_INVALID, "dst_dev is NULL");
   SGK_HIP(sgk::launch_obs_f32(h->sh, dst_dev, h->stream));
+  return SGK_OK;
+}
+
+int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const int32_t *lengths_dev, float *returns_dev,
+                           int64_t n_trajectories, int32_t t_max, double discount) {
+  SGK_CHECK_HANDLE(h);
+  if (!rewards_dev || !returns_dev) return fail(SGK_ERR_INVALID, "NULL argument");
+  if (n_trajectories < 0 || t_max < 1 || t_max > 1024) return fail(SGK_ERR_INVALID, "t_max must be in 1..1024");
+  if (n_trajectories == 0) return SGK_OK;
+  if (!h->gamma_dev) SGK_HIP(hipMalloc(&h->gamma_dev, sizeof(float) * 1024));
+  if (h->gamma_discount != discount) {
+    float tab[1024];
+    for (int t = 0; t < 1024; ++t) tab[t] = (float)std::pow(discount, (double)t);  // Python: float ** int, then float32
+    SGK_HIP(hipStreamSynchronize(h->stream));  // a previous launch may still read the old table
+    SGK_HIP(hipMemcpy(h->gamma_dev, tab, sizeof(tab), hipMemcpyHostToDevice));
+    h->gamma_discount = discount;
+  }
+  SGK_HIP(sgk::launch_discounted_returns(h->sh, rewards_dev, lengths_dev, h->gamma_dev, returns_dev, n_trajectories, t_max,
+                                         h->stream));
   return SGK_OK;
 }
 

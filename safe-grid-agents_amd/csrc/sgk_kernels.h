@@ -48,6 +48,8 @@ hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStrea
 hipError_t launch_metrics_init(const Shard &sh, hipStream_t st);
 hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st);
 hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st);
+hipError_t launch_discounted_returns(const Shard &sh, const float *rewards, const int32_t *lengths, const float *gamma_pow,
+                                     float *returns, int64_t n, int t_max, hipStream_t st);
 hipError_t launch_render_rgb(const Shard &sh, uint8_t *dst, hipStream_t st);
 hipError_t launch_dense_boards(const Shard &sh, int8_t *dst, hipStream_t st);
 hipError_t launch_finished(const Shard &sh, int32_t *ids, int32_t *ret, int32_t *perf, hipStream_t st);

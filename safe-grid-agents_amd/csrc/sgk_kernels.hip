@@ -582,6 +582,37 @@ __global__ __launch_bounds__(WG) void render_rgb_kernel(const SgkRules *__restri
   }
 }
 
+// PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186) for a batch of trajectories.
+// The reference is an O(T^2) Python double loop per trajectory; its float32 rounding order is kept exactly:
+//   d[t] = float32(discount ** t) * r[t];   returns[t] = ((d[t] + d[t+1]) + d[t+2]) + ...   (Python sum(): left to right)
+// One wave per trajectory: the wave stages d[] in LDS, then lane t accumulates its own suffix serially -- consecutive
+// lanes read consecutive LDS words at every iteration (conflict-free). gamma_pow[t] is computed on the host in double.
+constexpr int RET_TMAX = 1024;
+__global__ __launch_bounds__(WG) void discounted_returns_kernel(const float *__restrict__ rewards,
+                                                                const int32_t *__restrict__ lengths,
+                                                                const float *__restrict__ gamma_pow,
+                                                                float *__restrict__ returns, int64_t n, int t_max) {
+  __shared__ float d[WG / 64][RET_TMAX];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t traj = (int64_t)blockIdx.x * (WG / 64) + wave; traj < n; traj += (int64_t)gridDim.x * (WG / 64)) {
+    const int len = lengths ? min(lengths[traj], t_max) : t_max;
+    const float *r = rewards + traj * t_max;
+    for (int t = lane; t < len; t += 64) d[wave][t] = __fmul_rn(gamma_pow[t], r[t]);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
+    for (int t0 = 0; t0 < len; t0 += 64) {
+      const int t = t0 + lane;
+      float acc = 0.0f;
+      if (t < len) {
+        acc = d[wave][t];
+        for (int k = t + 1; k < len; ++k) acc = __fadd_rn(acc, d[wave][k]);
+        returns[traj * t_max + t] = acc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // gather dense [N][NC] int8 boards out of the pitched/compact buffer (for host copies)
 __global__ __launch_bounds__(WG) void dense_boards_kernel(const int8_t *__restrict__ boards, int8_t *__restrict__ dst,
                                                           int64_t n, int nc, int pitch) {
@@ -968,6 +999,7 @@ static Shard shard_view(const Shard &sh, int64_t env_off, int64_t count) {
 
 hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st,
                                int64_t env_off, int64_t count) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   Shard v = shard_view(sh, env_off, count);
   StepArgs a = make_step_args(v, nullptr, flags);
   a.t = t_off;
@@ -978,6 +1010,7 @@ hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t 
 }
 
 hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   StepArgs a = make_step_args(sh, actions, flags);
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
   if (actions) {
@@ -989,6 +1022,7 @@ hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, 
 }
 
 hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flags, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   StepArgs a = make_step_args(sh, nullptr, flags);
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
@@ -997,6 +1031,7 @@ hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flag
 }
 
 hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
                           reset_kernel<E, L><<<dim3(grid), dim3(WG), 0, st>>>(sh.rules_dev, sh.state,
@@ -1005,23 +1040,35 @@ hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStrea
 }
 
 hipError_t launch_metrics_init(const Shard &sh, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   metrics_init_kernel<<<dim3(32), dim3(WG), 0, st>>>((long long *)sh.metric_slab);
   return hipGetLastError();
 }
 
 hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   metrics_reduce_kernel<<<dim3(1), dim3(WG), 0, st>>>((const long long *)sh.metric_slab, (long long *)sh.metrics);
   return hipGetLastError();
 }
 
 hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   int64_t total = sh.n * ((sh.n_cells + 3) / 4);
   int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
   hipLaunchKernelGGL(obs_f32_kernel, dim3(grid), dim3(WG), 0, st, sh.boards, dst, sh.n, sh.n_cells, sh.pitch);
   return hipGetLastError();
 }
 
+hipError_t launch_discounted_returns(const Shard &sh, const float *rewards, const int32_t *lengths, const float *gamma_pow,
+                                     float *returns, int64_t n, int t_max, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  int grid = grid_for((n + (WG / 64) - 1) / (WG / 64), sh.max_grid * 2);
+  hipLaunchKernelGGL(discounted_returns_kernel, dim3(grid), dim3(WG), 0, st, rewards, lengths, gamma_pow, returns, n, t_max);
+  return hipGetLastError();
+}
+
 hipError_t launch_render_rgb(const Shard &sh, uint8_t *dst, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   int64_t total = sh.n * sh.n_cells;
   int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
   hipLaunchKernelGGL(render_rgb_kernel, dim3(grid), dim3(WG), 0, st, sh.rules_dev, sh.boards, dst, sh.n, sh.n_cells, sh.pitch);
@@ -1029,6 +1076,7 @@ hipError_t launch_render_rgb(const Shard &sh, uint8_t *dst, hipStream_t st) {
 }
 
 hipError_t launch_dense_boards(const Shard &sh, int8_t *dst, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   int64_t total = sh.n * sh.n_cells;
   int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
   hipLaunchKernelGGL(dense_boards_kernel, dim3(grid), dim3(WG), 0, st, sh.boards, dst, sh.n, sh.n_cells, sh.pitch);
@@ -1036,6 +1084,7 @@ hipError_t launch_dense_boards(const Shard &sh, int8_t *dst, hipStream_t st) {
 }
 
 hipError_t launch_finished(const Shard &sh, int32_t *ids, int32_t *ret, int32_t *perf, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   int64_t n_wg = (sh.n + WG - 1) / WG;
   hipLaunchKernelGGL(finished_count_kernel, dim3((unsigned)n_wg), dim3(WG), 0, st, sh.rec, sh.wg_count, sh.n);
   hipLaunchKernelGGL(finished_scan_kernel, dim3(1), dim3(1024), 0, st, sh.wg_count, sh.wg_offset, n_wg, sh.finished_total);
@@ -1072,6 +1121,7 @@ static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t fl
 }
 
 hipError_t launch_tabq_act(const Shard &sh, const TabqShard &tq, int explore, uint8_t *actions_out, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   TabqArgs a = make_tabq_args(sh, tq, 0);
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
   SGK_DISPATCH_ENV(sh.env_id, tabq_act_kernel<E><<<dim3(grid), dim3(WG), 0, st>>>(a, explore, actions_out));
@@ -1079,6 +1129,7 @@ hipError_t launch_tabq_act(const Shard &sh, const TabqShard &tq, int explore, ui
 }
 
 hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t *actions, int cheat, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   TabqArgs a = make_tabq_args(sh, tq, 0);
   a.cheat = cheat;
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
@@ -1093,6 +1144,7 @@ size_t tabq_rollout_lds_bytes(const Shard &sh) {
 }
 
 hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   TabqArgs a = make_tabq_args(sh, tq, 0);
   a.cheat = cheat;
   size_t lds = tabq_rollout_lds_bytes(sh);

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "sgk_episode_arrays_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V), ctypes.POINTER(_V), ctypes.POINTER(_V)]),
     "sgk_obs_f32": (ctypes.c_int, [_V, _V]),
     "sgk_render_rgb": (ctypes.c_int, [_V, _V]),
+    "sgk_discounted_returns": (ctypes.c_int, [_V, _V, _V, _V, ctypes.c_int64, ctypes.c_int32, ctypes.c_double]),
     "sgk_copy_boards": (ctypes.c_int, [_V, _V]),
     "sgk_copy_step_records": (ctypes.c_int, [_V, _V]),
     "sgk_copy_episode_state": (ctypes.c_int, [_V, _V, _V, _V, _V, _V, _V]),

@@ -262,6 +262,27 @@ class BatchedGridworldEnv:
         _lib.check(fn(self._h.ptr, int(n_steps), flags))
         return self._step_outputs()
 
+    def discounted_returns(self, rewards, discount, lengths=None, out=None):
+        """PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186) for a batch: rewards float32
+        [n_trajectories, T] on this GPU (lengths int32 [n_trajectories] optional) -> returns of the same shape, with the
+        reference's float32 rounding order (bit-exact)."""
+        import torch
+
+        rewards = rewards.contiguous()
+        assert rewards.dtype == torch.float32 and rewards.dim() == 2 and rewards.is_cuda
+        if out is None:
+            out = torch.zeros_like(rewards)
+        lp = None
+        if lengths is not None:
+            lengths = lengths.to(torch.int32).contiguous()
+            lp = ctypes.c_void_p(lengths.data_ptr())
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_discounted_returns(self._h.ptr, ctypes.c_void_p(rewards.data_ptr()), lp,
+                                                   ctypes.c_void_p(out.data_ptr()), rewards.shape[0], rewards.shape[1],
+                                                   float(discount)))
+        self._sync_lib_to_torch()
+        return out
+
     def account_steps(self, n_steps):
         """After replaying an external graph that contains step() launches: advance the host-side counters."""
         _lib.check(self.lib.sgk_account_steps(self._h.ptr, int(n_steps)))

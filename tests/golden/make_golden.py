@@ -283,8 +283,27 @@ def golden_deepq_forward():
     print("wrote deepq_forward.npz; state_dict keys:", list(agent.Q.state_dict().keys()))
 
 
+def golden_discounted_returns():
+    """PPOBaseAgent.get_discounted_returns (policy_base.py:179-186): float32, gamma**t in Python floats, suffix sums
+    accumulated left to right by Python's sum()."""
+    from safe_grid_agents.common.agents.policy_base import PPOBaseAgent
+
+    rng = np.random.RandomState(8)
+    cases = []
+    for discount in (0.99, 0.95, 1.0, 0.5):
+        for rewards in ([-1.0], [-1.0, 2.0], [-1.0, 2.0, -1.0, 49.0], [float(x) for x in rng.choice([-1, 2, -51, 49], size=100)],
+                        [float(np.float32(x)) for x in rng.randn(37)], [-1.0] * 100):
+            fake = types.SimpleNamespace(device="cpu", discount=discount)
+            out = PPOBaseAgent.get_discounted_returns(fake, rewards)
+            assert all(o.dtype == torch.float32 for o in out)
+            cases.append({"discount": discount, "rewards": [float(np.float32(r)).hex() for r in rewards],
+                          "returns": [float(o).hex() for o in out]})
+    _dump("discounted_returns.json", cases)
+
+
 def main():
     _install_stubs()
+    golden_discounted_returns()
     golden_epsilon()
     golden_meters()
     golden_rng()

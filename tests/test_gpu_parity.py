@@ -504,3 +504,29 @@ def test_cli_batched_training_runs_and_improves_returns(tmp_path):
     assert last > first  # learning: mean episode return improves from the random-walk start
     assert agent.t == 12 * 100
     env.close()
+
+
+def test_discounted_returns_kernel_bit_exact_vs_reference_golden_and_oracle(golden_dir):
+    torch = _torch()
+    with open(os.path.join(golden_dir, "discounted_returns.json")) as f:
+        cases = json.load(f)
+    env = S.BatchedGridworldEnv("BoatRace-v0", 8)
+    for c in cases:  # the reference's own outputs
+        r = np.array([float.fromhex(x) for x in c["rewards"]], dtype=np.float32)
+        out = env.discounted_returns(torch.as_tensor(r[None], device="cuda"), c["discount"]).cpu().numpy()[0]
+        assert [float(x).hex() for x in out] == c["returns"], (c["discount"], len(r))
+    # ragged batch against the oracle restatement
+    rng = np.random.RandomState(1)
+    n, T = 3000, 100
+    rewards = rng.choice([-1.0, 2.0, 49.0, -51.0, 0.5], size=(n, T)).astype(np.float32)
+    lengths = rng.randint(1, T + 1, size=n).astype(np.int32)
+    out = env.discounted_returns(torch.as_tensor(rewards, device="cuda"), 0.97,
+                                 lengths=torch.as_tensor(lengths, device="cuda")).cpu().numpy()
+    for i in range(0, n, 37):
+        want = O.discounted_returns(rewards[i, : lengths[i]], 0.97)
+        assert (out[i, : lengths[i]].view(np.uint32) == want.view(np.uint32)).all(), i
+        assert (out[i, lengths[i]:] == 0).all()
+    import ctypes
+
+    assert env.lib.sgk_discounted_returns(env.handle, None, None, None, 1, 10, 0.9) == _lib.ERR_INVALID
+    env.close()

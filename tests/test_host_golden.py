@@ -252,3 +252,13 @@ def test_deepq_learn_step_runs_and_changes_weights():
     assert hist["t"] >= 1 and any((a != b).any() for a, b in zip(before, agent.Q.parameters()))
     tags = {c[1] for c in hist["writer"].calls}
     assert {"Train/value_loss", "Train/epsilon", "Train/returns"} <= tags
+
+
+# ---- PPO discounted returns (reference policy_base.py:179-186): oracle restatement vs the reference's outputs ---------
+def test_discounted_returns_oracle_matches_reference(golden_dir):
+    cases = _load(golden_dir, "discounted_returns.json")
+    assert len(cases) == 24
+    for c in cases:
+        r = np.array([float.fromhex(x) for x in c["rewards"]], dtype=np.float32)
+        got = O.discounted_returns(r, c["discount"])
+        assert [float(x).hex() for x in got] == c["returns"], (c["discount"], len(r))
