@@ -7,7 +7,7 @@ from .agents import (AGENT_MAP, BatchedTabularQAgent, DeepQAgent, Experience, Ex
                      ReplayBuffer, Rollout, SingleActionAgent, TabularQAgent)
 from .deepq_batched import BatchedDeepQAgent, DeviceReplay
 from .envs import ENV_IDS, ENV_MAP, BatchedGridworldEnv, GridworldEnv, make
-from .loops import (EVAL_MAP, LEARN_MAP, WARMUP_MAP, batched_default_eval, batched_random_rollout, batched_tabq_learn,
+from .loops import (EVAL_MAP, LEARN_MAP, WARMUP_MAP, BatchedRollout, batched_default_eval, batched_gather_rollout, batched_random_rollout, batched_tabq_learn,
                     default_eval,
                     dqn_learn, dqn_warmup, noop_warmup, tabq_learn, whiler)
 from .metering import AverageMeter, BatchMetrics, NullWriter, RecordingWriter, make_meters, track_metrics
@@ -19,7 +19,7 @@ __all__ = [
     "RandomAgent", "SingleActionAgent", "TabularQAgent", "DeepQAgent", "BatchedTabularQAgent", "BatchedDeepQAgent", "DeviceReplay",
     "ReplayBuffer", "Experience", "ExperienceBatch", "Rollout",
     "whiler", "tabq_learn", "dqn_learn", "default_eval", "dqn_warmup", "noop_warmup",
-    "batched_random_rollout", "batched_tabq_learn", "batched_default_eval",
+    "batched_random_rollout", "batched_tabq_learn", "batched_default_eval", "batched_gather_rollout", "BatchedRollout",
     "AverageMeter", "make_meters", "track_metrics", "BatchMetrics", "NullWriter", "RecordingWriter",
     "prepare_parser", "train", "train_batched",
 ]

@@ -7,6 +7,7 @@
 (reference safe_grid_agents/common/learn.py:8-113, eval.py:8-59, warmup.py:8-33), plus the batched lockstep
 forms that keep N envs and their agents on the GPU between steps.
 """
+import collections
 import functools
 from collections import defaultdict
 
@@ -172,6 +173,44 @@ def batched_default_eval(agent, env, eval_timesteps):
     for _ in range(int(env.info.max_iterations)):
         env.step(agent.act(), auto_reset=False, write_boards=False)
     return BatchMetrics(env.metrics())
+
+
+BatchedRollout = collections.namedtuple("BatchedRollout", ["states", "actions", "rewards", "returns", "lengths"])
+
+
+def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None):
+    """PPOBaseAgent.gather_rollout (reference policy_base.py:133-177) with one rollout = one episode PER ENV, all envs in
+    lockstep: `policy(boards) -> uint8 actions [N]` acts on the int8 board view, finished envs idle until the horizon, and
+    the discounted returns come from the bit-exact batched kernel (policy_base.py:179-186). Everything stays in HBM.
+
+    Returns BatchedRollout(states int8 [T, N, cells], actions uint8 [T, N], rewards float32 [N, T], returns float32 [N, T],
+    lengths int32 [N]); entries past an env's length are zero. The episodes are booked in the env's metrics vector
+    (track_metrics, policy_base.py:168) and every env is reset afterwards (policy_base.py:174)."""
+    import torch
+
+    T = int(horizon or env.info.max_iterations)
+    n, dev = env.n_envs, "cuda:%d" % env.device
+    states = torch.zeros((T, n, env.n_cells), dtype=torch.int8, device=dev)
+    actions = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+    rewards = torch.zeros((n, T), dtype=torch.float32, device=dev)
+    lengths = torch.zeros(n, dtype=torch.int32, device=dev)
+    env.reset()
+    live = torch.ones(n, dtype=torch.bool, device=dev)
+    for t in range(T):
+        boards = env.boards().reshape(n, -1)
+        a = policy(boards).to(torch.uint8)
+        states[t].copy_(boards)
+        succ, reward, done, info = env.step(a, auto_reset=False)
+        r = info["hidden_reward"] if cheat else reward
+        act = info["extra_observations"]["actual_actions"].to(torch.uint8) if cheat else a
+        actions[t].copy_(torch.where(live, act, torch.zeros_like(act)))
+        rewards[:, t].copy_(torch.where(live, r.float(), torch.zeros(n, device=dev)))
+        states[t].mul_(live.to(torch.int8).unsqueeze(1))
+        lengths.add_(live.to(torch.int32))
+        live = live & (done == 0)
+    returns = env.discounted_returns(rewards, discount, lengths=lengths)
+    env.reset()
+    return BatchedRollout(states, actions, rewards, returns, lengths)
 
 
 def batched_tabq_learn(agent, env, n_steps, cheat=False, fused=True):

@@ -530,3 +530,44 @@ def test_discounted_returns_kernel_bit_exact_vs_reference_golden_and_oracle(gold
 
     assert env.lib.sgk_discounted_returns(env.handle, None, None, None, 1, 10, 0.9) == _lib.ERR_INVALID
     env.close()
+
+
+def test_batched_gather_rollout_matches_per_env_reference_shape():
+    """One episode per env under a fixed random policy; per env the recorded trajectory and its discounted returns equal
+    what the oracle env + the reference-pinned returns restatement give."""
+    torch = _torch()
+    name, n, seed = "IslandNavigation-v0", 512, 5
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    T = 100
+    script = torch.randint(0, 4, (T, n), generator=gen, device="cuda", dtype=torch.uint8)
+    step = {"t": 0}
+
+    def policy(boards):
+        a = script[step["t"]]
+        step["t"] += 1
+        return a
+
+    ro = S.batched_gather_rollout(policy, env, discount=0.95)
+    acts = script.cpu().numpy()
+    lengths = ro.lengths.cpu().numpy()
+    rewards, returns = ro.rewards.cpu().numpy(), ro.returns.cpu().numpy()
+    states = ro.states.cpu().numpy()
+    orc = O.EnvBatch(name, 1)
+    for i in range(0, n, 7):
+        orc.reset(0)
+        rs, t = [], 0
+        while True:
+            assert (states[t, i] == orc.board(0).ravel()).all(), (i, t)
+            r, h, d, _ = orc.step(0, int(acts[t, i]))
+            rs.append(r)
+            t += 1
+            if d:
+                break
+        assert lengths[i] == t
+        assert rewards[i, :t].tolist() == [float(x) for x in rs] and (rewards[i, t:] == 0).all()
+        want = O.discounted_returns(np.array(rs, dtype=np.float32), 0.95)
+        assert (returns[i, :t].view(np.uint32) == want.view(np.uint32)).all()
+    m = env.metrics()
+    assert m[_lib.M_EPISODES] == n
+    env.close()
