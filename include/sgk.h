@@ -112,6 +112,12 @@ SGK_API int sgk_get_info(const sgk_env *h, sgk_info *out);
 SGK_API int sgk_set_stream(sgk_env *h, void *hip_stream); /* NULL restores the handle's own stream */
 SGK_API void *sgk_get_stream(const sgk_env *h);
 SGK_API int sgk_synchronize(sgk_env *h); /* waits for the handle's stream */
+/* Stream ordering against another HIP stream of the same device (e.g. torch's current stream, where the policy network
+ * runs) without a host wait: sgk_stream_wait makes the handle's stream wait for everything queued on other_stream so far
+ * (call before handing it actions produced there); sgk_stream_signal makes other_stream wait for the handle's stream
+ * (call before the consumer reads boards / records there). */
+SGK_API int sgk_stream_wait(sgk_env *h, void *other_stream);
+SGK_API int sgk_stream_signal(sgk_env *h, void *other_stream);
 
 /* ---- env.reset() (reference train.py:64; eval.py:13,23; warmup.py:17) ------------------------- */
 /* mask_dev == NULL: every env. Otherwise envs with mask_dev[i] != 0. Episode return, hidden return and

@@ -49,6 +49,7 @@ struct sgk_env {
   int8_t *dense_scratch = nullptr;
   uint8_t *actions_scratch = nullptr;
   uint8_t *pinned = nullptr;         // host staging for sgk_step_host: [actions n][rec 4n][state 8n][boards n*n_cells]
+  hipEvent_t order_events[2] = {nullptr, nullptr};  // sgk_stream_wait / sgk_stream_signal
   float *gamma_dev = nullptr;        // [1024] float32(discount ** t) for sgk_discounted_returns
   double gamma_discount = -1.0;
   bool host_visible = false;         // SGK_MEM_HOST_VISIBLE: state/rec/boards/actions live in pinned device-mapped host memory
@@ -138,6 +139,8 @@ int sgk_destroy(sgk_env *h) {
     if (h->join_events[i]) (void)hipEventDestroy(h->join_events[i]);
   }
   if (h->fork_event) (void)hipEventDestroy(h->fork_event);
+  for (int i = 0; i < 2; ++i)
+    if (h->order_events[i]) (void)hipEventDestroy(h->order_events[i]);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return SGK_OK;
@@ -286,6 +289,24 @@ int sgk_set_stream(sgk_env *h, void *hip_stream) {
 }
 
 void *sgk_get_stream(const sgk_env *h) { return h ? (void *)h->stream : nullptr; }
+
+int sgk_stream_wait(sgk_env *h, void *other_stream) {
+  SGK_CHECK_HANDLE(h);
+  if ((hipStream_t)other_stream == h->stream) return SGK_OK;
+  if (!h->order_events[0]) SGK_HIP(hipEventCreateWithFlags(&h->order_events[0], hipEventDisableTiming));
+  SGK_HIP(hipEventRecord(h->order_events[0], (hipStream_t)other_stream));
+  SGK_HIP(hipStreamWaitEvent(h->stream, h->order_events[0], 0));
+  return SGK_OK;
+}
+
+int sgk_stream_signal(sgk_env *h, void *other_stream) {
+  SGK_CHECK_HANDLE(h);
+  if ((hipStream_t)other_stream == h->stream) return SGK_OK;
+  if (!h->order_events[1]) SGK_HIP(hipEventCreateWithFlags(&h->order_events[1], hipEventDisableTiming));
+  SGK_HIP(hipEventRecord(h->order_events[1], h->stream));
+  SGK_HIP(hipStreamWaitEvent((hipStream_t)other_stream, h->order_events[1], 0));
+  return SGK_OK;
+}
 
 int sgk_synchronize(sgk_env *h) {
   SGK_CHECK_HANDLE(h);

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "sgk_set_stream": (ctypes.c_int, [_V, _V]),
     "sgk_get_stream": (_V, [_V]),
     "sgk_synchronize": (ctypes.c_int, [_V]),
+    "sgk_stream_wait": (ctypes.c_int, [_V, _V]),
+    "sgk_stream_signal": (ctypes.c_int, [_V, _V]),
     "sgk_reset": (ctypes.c_int, [_V, _V]),
     "sgk_reset_done": (ctypes.c_int, [_V]),
     "sgk_step": (ctypes.c_int, [_V, _V, ctypes.c_uint32]),

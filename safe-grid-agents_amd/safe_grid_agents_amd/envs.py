@@ -186,26 +186,18 @@ class BatchedGridworldEnv:
 
     def _sync_torch_to_lib(self):
         """Make the library's stream wait for work queued on torch's current stream (e.g. the policy net)."""
-        import torch
-
         if self._bound:
             return
-        if self._events is None:
-            self._events = (torch.cuda.Event(), torch.cuda.Event())
-        ev = self._events[0]
-        ev.record(torch.cuda.current_stream(self.device))
-        self.torch_stream().wait_event(ev)
+        import torch
+
+        _lib.check(self.lib.sgk_stream_wait(self._h.ptr, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     def _sync_lib_to_torch(self):
-        import torch
-
         if self._bound:
             return
-        if self._events is None:
-            self._events = (torch.cuda.Event(), torch.cuda.Event())
-        ev = self._events[1]
-        ev.record(self.torch_stream())
-        torch.cuda.current_stream(self.device).wait_event(ev)
+        import torch
+
+        _lib.check(self.lib.sgk_stream_signal(self._h.ptr, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     # ---- gym-shaped API -------------------------------------------------------------------------
     def seed(self, seed=None):
