@@ -53,8 +53,25 @@ def cpu_baseline(env_name, seed, target_seconds=10.0):
     n_all = max(n1, 256 * cores)
     steps_all = int(max(100, min(20000, target_seconds * one * cores * 0.5 / n_all)))
     allc, used = timed(n_all, steps_all, cores)
+    # the reference-shaped single-process Python loop (train(): TabularQAgent + env.step per step)
+    # on the oracle env -- what `python main.py boat tabular-q --lr .5` does, minus the upstream env's own cost
+    import safe_grid_agents_amd as S
+    from oracle.gym_shim import OracleGridworldEnv
+
+    a = S.prepare_parser().parse_args(["-S", "7", "-E", "40", "-EE", "1000", "-V", "100", "-EV", "0", "boat", "tabular-q",
+                                       "-l", ".5"])
+    import contextlib
+    import io
+
+    import torch  # noqa: F401  (keep its import time out of the measurement)
+
+    with contextlib.redirect_stdout(io.StringIO()):  # default_eval prints a banner; bench.py owns stdout (ONE JSON line)
+        t0 = time.perf_counter()
+        _, hist, _ = S.train(a, env_factory=OracleGridworldEnv, writer_factory=lambda d: S.NullWriter(d))
+        py_loop = (hist["t"] + 100) / (time.perf_counter() - t0)
     return {
         "value": allc, "unit": "env-steps/s", "cores": used, "kind": "port",
+        "reference_shaped_python_loop_1core": py_loop,
         "sample": "%s random rollout, oracle C engine (gcc -O2): %d envs x %d steps on %d threads; 1 thread: %d envs x %d "
                   "steps" % (env_name, n_all, steps_all, used, n1, steps1),
         "one_core_value": one, "host_cpus": cores,

@@ -138,6 +138,9 @@ SGK_API int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flag
 /* RandomAgent.act + env.step (reference dummy.py:15-16, warmup.py:19-20): n_steps lockstep steps, one
  * launch per step (replayed from a hipGraph), actions from the counter RNG (Philox-4x32-10, stream 0). */
 SGK_API int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags);
+/* SingleActionAgent.act + env.step (reference dummy.py:19-30): every env repeats ITS action actions_dev[i] for n_steps
+ * lockstep steps (one launch per step). */
+SGK_API int sgk_step_repeat(sgk_env *h, const uint8_t *actions_dev, int32_t n_steps, uint32_t flags);
 /* the same n_steps inside ONE launch: state stays in registers, boards are materialised once at the end */
 SGK_API int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags);
 /* Book n_steps lockstep steps that were issued OUTSIDE the library's sight: a caller that captured sgk_step() into its

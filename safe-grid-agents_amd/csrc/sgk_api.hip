@@ -473,6 +473,19 @@ int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
   return SGK_OK;
 }
 
+int sgk_step_repeat(sgk_env *h, const uint8_t *actions_dev, int32_t n_steps, uint32_t flags) {
+  SGK_CHECK_HANDLE(h);
+  if (!actions_dev) return fail(SGK_ERR_INVALID, "actions_dev is NULL");
+  if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
+  for (int32_t k = 0; k < n_steps; ++k) {
+    SGK_HIP(sgk::launch_step(h->sh, actions_dev, flags, h->stream));
+    h->sh.lockstep_t += 1;
+  }
+  h->t_dev_stale = true;
+  h->steps_issued += h->sh.n * (int64_t)n_steps;
+  return SGK_OK;
+}
+
 int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
   SGK_CHECK_HANDLE(h);
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");

@@ -236,26 +236,30 @@ __device__ __forceinline__ void acc_flush(const EpisodeAcc &a, long long *__rest
   }
 }
 
-// slab -> one metrics vector (sums over slots for [0..7], maxima for [8..11]); one workgroup
-__global__ __launch_bounds__(WG) void metrics_reduce_kernel(const long long *__restrict__ slab, long long *__restrict__ out) {
-  __shared__ long long part[WG];
-  const int col = threadIdx.x & 15, lane_slot = threadIdx.x >> 4;  // 16 columns x 16 slot-lanes
+// slab -> one metrics vector (sums over slots for [0..7], maxima for [8..11]); one workgroup of 1024 lanes:
+// 16 columns x 64 slot-lanes, four independent loads in flight per lane, LDS tree over the slot-lanes
+__global__ __launch_bounds__(1024) void metrics_reduce_kernel(const long long *__restrict__ slab, long long *__restrict__ out) {
+  __shared__ long long part[1024];
+  const int col = threadIdx.x & 15, lane_slot = threadIdx.x >> 4;  // 64 slot-lanes
   const bool is_max = col >= SGK_M_MAX_RETURN && col <= SGK_M_MAX_MARGIN_POS;
   long long acc = is_max ? LLONG_MIN : 0;
-  for (int sl = lane_slot; sl < SGK_METRIC_SLOTS; sl += 16) {
-    long long v = slab[(size_t)sl * SGK_METRICS_LEN + col];
-    acc = is_max ? max(acc, v) : acc + v;
+  for (int sl = lane_slot; sl < SGK_METRIC_SLOTS; sl += 256) {
+    long long v0 = slab[(size_t)sl * SGK_METRICS_LEN + col];
+    long long v1 = slab[(size_t)(sl + 64) * SGK_METRICS_LEN + col];
+    long long v2 = slab[(size_t)(sl + 128) * SGK_METRICS_LEN + col];
+    long long v3 = slab[(size_t)(sl + 192) * SGK_METRICS_LEN + col];
+    acc = is_max ? max(max(acc, v0), max(max(v1, v2), v3)) : acc + ((v0 + v1) + (v2 + v3));
   }
   part[threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.x < 16) {
-    long long r = part[threadIdx.x];
-    for (int k = 1; k < 16; ++k) {
-      long long v = part[k * 16 + threadIdx.x];
-      r = is_max ? max(r, v) : r + v;
+  for (int half = 32; half >= 1; half >>= 1) {
+    if (lane_slot < half) {
+      long long o = part[(lane_slot + half) * 16 + col];
+      part[threadIdx.x] = is_max ? max(part[threadIdx.x], o) : part[threadIdx.x] + o;
     }
-    out[threadIdx.x] = r;
+    __syncthreads();
   }
+  if (threadIdx.x < 16) out[threadIdx.x] = part[threadIdx.x];
 }
 
 __global__ __launch_bounds__(WG) void metrics_init_kernel(long long *__restrict__ slab) {
@@ -1047,7 +1051,7 @@ hipError_t launch_metrics_init(const Shard &sh, hipStream_t st) {
 
 hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st) {
   (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
-  metrics_reduce_kernel<<<dim3(1), dim3(WG), 0, st>>>((const long long *)sh.metric_slab, (long long *)sh.metrics);
+  metrics_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>((const long long *)sh.metric_slab, (long long *)sh.metrics);
   return hipGetLastError();
 }
 

@@ -247,6 +247,14 @@ class BatchedGridworldEnv:
         self._sync_lib_to_torch()
         return self._step_outputs()
 
+    def step_repeat(self, actions, n_steps, auto_reset=True, write_boards=True):
+        """SingleActionAgent over the batch (reference dummy.py:19-30): env i repeats actions[i] for n_steps steps."""
+        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_step_repeat(self._h.ptr, ctypes.c_void_p(actions.data_ptr()), int(n_steps), flags))
+        self._sync_lib_to_torch()
+        return self._step_outputs()
+
     def step_random(self, n_steps=1, auto_reset=True, fused=False, write_boards=True):
         """n_steps lockstep steps with RandomAgent-style actions from the counter RNG (no torch sync: pure library work)."""
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)

@@ -571,3 +571,18 @@ def test_batched_gather_rollout_matches_per_env_reference_shape():
     m = env.metrics()
     assert m[_lib.M_EPISODES] == n
     env.close()
+
+
+def test_step_repeat_is_a_batched_single_action_agent():
+    torch = _torch()
+    n, k = 700, 130
+    for name in ENVS:
+        env = S.BatchedGridworldEnv(name, n, layout="compact")
+        orc = O.EnvBatch(name, n)
+        acts = np.random.RandomState(3).randint(0, 4, size=n).astype(np.uint8)
+        env.step_repeat(torch.as_tensor(acts, device="cuda"), k, auto_reset=True)
+        m = O.metrics_new()
+        orc.rollout(k, actions=np.repeat(acts[None], k, axis=0), auto_reset=True, metrics=m)
+        assert_same_state(env, orc, name)
+        assert env.metrics()[:6].tolist() == m[:6].tolist()
+        env.close()

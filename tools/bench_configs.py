@@ -38,8 +38,7 @@ def wall_time(fn, reps=1):
 out = []
 
 # config 1: BoatRace + tabular-q, single env, the reference-shaped Python loop (`main.py boat tabular-q --lr .5`)
-from oracle.gym_shim import OracleGridworldEnv  # noqa: E402  (CPU baseline leg only)
-
+# (the CPU leg of this config lives in bench.py's cpu_baseline: only tests/, smoke() and that leg may touch oracle/)
 
 def single_env_rate(env_factory, episodes=30):
     args = S.prepare_parser().parse_args(["-S", "7", "-E", str(episodes), "-EE", "1000", "-V", "100", "-EV", "0",
@@ -51,10 +50,7 @@ def single_env_rate(env_factory, episodes=30):
     return (hist["t"] + 100) / dt  # + the final eval's 100 steps
 
 
-r_cpu = single_env_rate(OracleGridworldEnv)
 r_gpu = single_env_rate(lambda name: S.make(name))
-out.append({"config": 1, "what": "single env BoatRace + TabularQAgent through train(): Python loop on the oracle env (CPU, 1 core)",
-            "env_steps_per_s": r_cpu})
 out.append({"config": 1, "what": "same loop on the HIP single env (sgk_step_host: H2D action + launch + D2H record/board per step; PCIe-inclusive)",
             "env_steps_per_s": r_gpu})
 

@@ -38,10 +38,11 @@ for name in NAMES:
             ms_graph = timed(env, lambda: env.step_random(100, auto_reset=True), 5) / 100
             ms_nob = timed(env, lambda: env.step_random(100, auto_reset=True, write_boards=False), 5) / 100
             ms_given = timed(env, lambda: env.step(acts, auto_reset=True), 200)
+            ms_rep = timed(env, lambda: env.step_repeat(acts, 100, auto_reset=True), 5) / 100
             ms_fused = timed(env, lambda: env.step_random(200, auto_reset=True, fused=True), 3) / 200
             gbs = B_ALG[name] * n / (ms_graph / 1e3) / 1e9
             print("%-22s %-8s n=%8d  step(graph) %8.2f us  %7.2e steps/s  %6.0f GB/s-alg | no-boards %8.2f us | "
-                  "given-actions(eager,torch) %8.2f us | fused %8.3f us/step %7.2e steps/s"
-                  % (name, layout, n, ms_graph * 1e3, n / (ms_graph / 1e3), gbs, ms_nob * 1e3, ms_given * 1e3,
+                  "given-actions(eager,torch) %8.2f us | repeat(eager C loop, no RNG) %8.2f us | fused %8.3f us/step %7.2e steps/s"
+                  % (name, layout, n, ms_graph * 1e3, n / (ms_graph / 1e3), gbs, ms_nob * 1e3, ms_given * 1e3, ms_rep * 1e3,
                      ms_fused * 1e3, n / (ms_fused / 1e3)), flush=True)
             env.close()
