@@ -47,7 +47,8 @@ extern "C" {
 
 /* board layouts (sgk_create_ex) */
 #define SGK_LAYOUT_PITCHED 0 /* env-major rows padded to a multiple of 16 B: one lane writes its row with 16-B stores */
-#define SGK_LAYOUT_COMPACT 1 /* env-major rows of exactly n_cells bytes: workgroup tile staged through LDS */
+#define SGK_LAYOUT_COMPACT 1 /* env-major rows of exactly n_cells bytes; a workgroup assembles its 256-env tile from LDS and
+                                writes it as 1-KiB-per-wave streaming stores. Default of sgk_create (faster from ~128 K envs). */
 
 /* memory placement, OR-ed into the `layout` argument of sgk_create_ex */
 #define SGK_MEM_HOST_VISIBLE 0x100 /* state words, step records, boards in pinned device-mapped HOST memory: for the

@@ -176,7 +176,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   s.n_cells = s.rules_host.n_cells;
   s.n_states = s.rules_host.n_states;
   const int pitched = ((s.n_cells + 15) / 16) * 16;
-  s.layout = (s.n_cells % 16 == 0) ? SGK_LAYOUT_PITCHED : layout;
+  s.layout = layout;  // for 16-byte-multiple rows (IslandNavigation) both layouts have pitch == n_cells; they differ in who writes which bytes
   s.pitch = (s.layout == SGK_LAYOUT_COMPACT) ? s.n_cells : pitched;
   const char *ng = getenv("SGK_NO_GRAPH");
   h->use_graph = !(ng && ng[0] == '1');
@@ -250,7 +250,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
 }
 
 int sgk_create(int env_id, int64_t n_envs, int device, uint64_t seed, sgk_env **out) {
-  return sgk_create_ex(env_id, n_envs, device, seed, 0, SGK_LAYOUT_PITCHED, out);
+  return sgk_create_ex(env_id, n_envs, device, seed, 0, SGK_LAYOUT_COMPACT, out);
 }
 
 #define SGK_CHECK_HANDLE(h)                                   \

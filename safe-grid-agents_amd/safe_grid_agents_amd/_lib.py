@@ -9,7 +9,7 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _DIST = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_DIST, "lib", "libsgk.so")
+LIB_PATH = os.environ.get("SGK_LIB_PATH") or os.path.join(_DIST, "lib", "libsgk.so")  # override: A/B builds of the kernels
 CSRC = os.path.join(_DIST, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_DIST), "include")
 

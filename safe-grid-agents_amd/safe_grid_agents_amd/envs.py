@@ -103,7 +103,7 @@ class BatchedGridworldEnv:
     writes it; `.clone()` to keep).
     """
 
-    def __init__(self, name, n_envs, device=0, seed=0, env_index_base=0, layout="pitched", host_visible=False):
+    def __init__(self, name, n_envs, device=0, seed=0, env_index_base=0, layout="compact", host_visible=False):
         if name not in ENV_IDS:
             raise KeyError("unknown or out-of-scope env %r; available: %s" % (name, sorted(ENV_IDS)))
         self.name = name

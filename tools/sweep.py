@@ -30,8 +30,6 @@ NAMES = [a for a in sys.argv[1:] if a.endswith("-v0")] or ["BoatRace-v0", "Islan
 SIZES = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1 << 10, 1 << 16, 1 << 18, 1 << 20, 1 << 22]
 for name in NAMES:
     for layout in ("compact", "pitched"):
-        if name == "IslandNavigation-v0" and layout == "compact":
-            continue
         for n in SIZES:
             env = S.BatchedGridworldEnv(name, n, seed=1, layout=layout)
             acts = torch.randint(0, 4, (n,), dtype=torch.uint8, device="cuda")
