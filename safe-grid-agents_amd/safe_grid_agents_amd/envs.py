@@ -399,7 +399,7 @@ class GridworldEnv:
     """
 
     def __init__(self, name, device=0):
-        self._b = BatchedGridworldEnv(name, 1, device=device, host_visible=True)
+        self._b = BatchedGridworldEnv(name, 1, device=device, host_visible=True, layout="pitched")
         self.name = name
         self.action_space = self._b.action_space
         self.observation_space = self._b.observation_space
