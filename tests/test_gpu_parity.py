@@ -586,3 +586,34 @@ def test_step_repeat_is_a_batched_single_action_agent():
         assert_same_state(env, orc, name)
         assert env.metrics()[:6].tolist() == m[:6].tolist()
         env.close()
+
+
+def test_maximum_sizes_and_64bit_env_ids():
+    """16.7M envs on one GPU (int32 id space of sgk_finished is the documented limit: < 2^31) and global env ids beyond
+    2^32 (the counter RNG is keyed by a 64-bit env index)."""
+    torch = _torch()
+    n = 1 << 24
+    env = S.BatchedGridworldEnv("BoatRace-v0", n, seed=9)
+    env.step_random(100, auto_reset=True)
+    m = env.metrics()
+    assert m[_lib.M_EPISODES] == n and m[_lib.M_STEPS] == 100 * n
+    le = env.last_episode_host()
+    assert (le["n_episodes"] == 1).all()
+    assert int(le["last_return"].astype(np.int64).sum()) == m[_lib.M_SUM_RETURN]
+    assert int(le["last_performance"].astype(np.int64).sum()) == m[_lib.M_SUM_SAFETY]
+    ids, ret, perf = env.finished()
+    assert ids.numel() == n and int(ids[-1]) == n - 1 and bool((ids[1:] > ids[:-1]).all())
+    # spot samples at the far end against the oracle
+    rec = env.step_records_host()
+    for i in (0, n // 3, n - 2, n - 1):
+        orc = O.EnvBatch("BoatRace-v0", 1)
+        r = orc.rollout(100, seed=9, env_begin=i, auto_reset=True)
+        assert (rec[i] == r[0]).all() and le["last_return"][i] == orc.field("last_episode_return")[0]
+    env.close()
+    base = (1 << 40) + 12345
+    env = S.BatchedGridworldEnv("SideEffectsSokoban-v0", 1000, seed=3, env_index_base=base)
+    orc = O.EnvBatch("SideEffectsSokoban-v0", 1000)
+    env.step_random(150, auto_reset=True, fused=True)
+    orc.rollout(150, seed=3, env_begin=base, auto_reset=True)
+    assert_same_state(env, orc, "64-bit env ids")
+    env.close()
