@@ -111,6 +111,7 @@ SGK_API int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed,
 SGK_API int sgk_destroy(sgk_env *h);
 SGK_API int sgk_get_info(const sgk_env *h, sgk_info *out);
 SGK_API int sgk_set_stream(sgk_env *h, void *hip_stream); /* NULL restores the handle's own stream */
+SGK_API int sgk_use_default_stream(sgk_env *h);           /* enqueue on the device's NULL (legacy default) stream */
 SGK_API void *sgk_get_stream(const sgk_env *h);
 SGK_API int sgk_synchronize(sgk_env *h); /* waits for the handle's stream */
 /* Stream ordering against another HIP stream of the same device (e.g. torch's current stream, where the policy network
@@ -196,6 +197,32 @@ SGK_API int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_state
 SGK_API int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, double *table_host);
 SGK_API int sgk_tabq_global_step(const sgk_tabq *q, int64_t *t_out);
 SGK_API double sgk_tabq_epsilon(double epsilon, int64_t epsilon_anneal, int64_t t); /* epsilon in force at global step t */
+
+/* ---- DeepQAgent.act_explore, batched (reference value.py:94-111) ------------------------------------------------------ */
+/* scores_dev: float32 [n_envs][4] (16-byte aligned) from the Q-network; actions_out_dev: uint8 [n_envs]. Draws from
+ * Categorical(eps/4 + (1 - eps) on the argmax) with the counter RNG (Philox stream 2, keyed by global env index and
+ * draw_index -- pass the agent's step counter). epsilon = 0 is DeepQAgent.act (value.py:89-92). */
+SGK_API int sgk_epsilon_greedy(sgk_env *h, const float *scores_dev, double epsilon, uint64_t draw_index,
+                               uint8_t *actions_out_dev);
+/* same, with epsilon and/or the draw index read from device memory when the pointers are non-NULL (so that the launch can be
+ * recorded once in a caller's hipGraph and replayed while the schedule advances) */
+SGK_API int sgk_epsilon_greedy_ex(sgk_env *h, const float *scores_dev, double epsilon, uint64_t draw_index,
+                                  const double *epsilon_dev, const uint64_t *draw_index_dev, uint8_t *actions_out_dev);
+
+/* ---- DeepQAgent: Q-network forward + act_explore in one launch (reference value.py:89-111,148-158) ------------------- */
+/* The reference's default topology (n_layers = 2): Linear(n_cells, H) + ReLU, Linear(H, H) + ReLU, Linear(H, 4); H = 100.
+ * Device pointers into the (PyTorch) parameters, float32: w1t = W1 transposed [n_cells][H]; b1 [H]; w2 = W2 [H][H] as torch
+ * stores it ([out][in]); b2 [H]; w3t = W3 transposed [H][4]; b3 [4]. Reads the env's int8 boards directly. */
+typedef struct sgk_mlp_weights {
+  const float *w1t, *b1, *w2, *b2, *w3t, *b3;
+  int32_t n_hidden;
+} sgk_mlp_weights;
+/* actions_out_dev: uint8 [n_envs]; scores_out_dev: float32 [n_envs][4] or NULL. epsilon / draw_index as in
+ * sgk_epsilon_greedy_ex (device pointers override the scalars when non-NULL). fp32 accumulation order differs from a BLAS
+ * GEMM: scores agree with the torch forward to fp32 tolerance, not bit for bit. */
+SGK_API int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon, uint64_t draw_index,
+                           const double *epsilon_dev, const uint64_t *draw_index_dev, uint8_t *actions_out_dev,
+                           float *scores_out_dev);
 
 /* ---- PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186), batched ------------------------------ */
 /* rewards_dev / returns_dev: float32 [n_trajectories][t_max] row-major; lengths_dev: int32 [n_trajectories] or NULL

@@ -65,6 +65,8 @@ def lib():
         L.orc_rollout_mt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                      ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.orc_rollout_mt.restype = ctypes.c_int
+        L.orc_eps_greedy.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
+        L.orc_eps_greedy.restype = ctypes.c_int
         L.orc_discounted_returns.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
         L.orc_tabq_new.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int64]
         L.orc_tabq_new.restype = ctypes.c_void_p
@@ -206,6 +208,13 @@ def rollout_mt(envs, n_steps, n_threads, seed=0, env_begin=0, t_begin=0, auto_re
                                 None if metrics is None else metrics.ctypes.data, int(n_threads))
     assert used > 0, "thread creation failed"
     return used
+
+
+def eps_greedy(scores, eps, seed, env_begin, draw):
+    sc = np.ascontiguousarray(scores, dtype=np.float32)
+    L = lib()
+    return np.array([L.orc_eps_greedy(sc[i].ctypes.data, float(eps), seed, env_begin + i, draw) for i in range(sc.shape[0])],
+                    dtype=np.uint8)
 
 
 def discounted_returns(rewards, discount):

@@ -118,7 +118,8 @@ int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agen
 int sgk_destroy(sgk_env *h) {
   if (!h) return SGK_OK;
   (void)hipSetDevice(h->sh.device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamSynchronize(h->stream);  // nullptr = the NULL stream
+  if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   for (auto &kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   sgk::Shard &s = h->sh;
   if (h->host_visible) {
@@ -281,10 +282,13 @@ int sgk_get_info(const sgk_env *h, sgk_info *out) {
 
 int sgk_set_stream(sgk_env *h, void *hip_stream) {
   if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
-  if (st != h->stream) {  // graphs were captured on the old stream's topology only; they stay valid, but keep it simple
-    h->stream = st;
-  }
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;  // graphs are captured on own_stream and stay valid
+  return SGK_OK;
+}
+
+int sgk_use_default_stream(sgk_env *h) {
+  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  h->stream = nullptr;  // the device's NULL (legacy default) stream: where PyTorch queues work unless told otherwise
   return SGK_OK;
 }
 
@@ -433,27 +437,28 @@ int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
         if (!h->join_events[i]) SGK_HIP(hipEventCreateWithFlags(&h->join_events[i], hipEventDisableTiming));
       }
     }
-    SGK_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    hipStream_t cap = h->own_stream;  // never the caller's stream: it may be the NULL stream, which cannot be captured
+    SGK_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
     hipError_t le = hipSuccess;
     if (P > 1) {
-      le = hipEventRecord(h->fork_event, h->stream);
+      le = hipEventRecord(h->fork_event, cap);
       for (int i = 0; i < P - 1 && le == hipSuccess; ++i) le = hipStreamWaitEvent(h->side_streams[i], h->fork_event, 0);
     }
     for (int p = 0; p < P && le == hipSuccess; ++p) {
       const int64_t t0 = n_tiles * p / P, t1 = n_tiles * (p + 1) / P;
       const int64_t off = t0 * 256, cnt = (p == P - 1 ? s.n : t1 * 256) - off;
-      hipStream_t st = (p == 0) ? h->stream : h->side_streams[p - 1];
+      hipStream_t st = (p == 0) ? cap : h->side_streams[p - 1];
       for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k)
         le = sgk::launch_step_counter(s, h->t_dev, (uint64_t)k, flags, st, off, cnt);
       if (p > 0 && le == hipSuccess) le = hipEventRecord(h->join_events[p - 1], st);
     }
-    for (int i = 0; i < P - 1 && le == hipSuccess; ++i) le = hipStreamWaitEvent(h->stream, h->join_events[i], 0);
+    for (int i = 0; i < P - 1 && le == hipSuccess; ++i) le = hipStreamWaitEvent(cap, h->join_events[i], 0);
     if (le == hipSuccess) {
       (void)hipGetLastError();
-      hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, (uint64_t)n_steps);
+      hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, cap, h->t_dev, (uint64_t)n_steps);
       le = hipGetLastError();
     }
-    hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+    hipError_t ce = hipStreamEndCapture(cap, &graph);
     if (le != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); return hip_fail(le, "capture step kernels"); }
     if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture");
     hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -530,6 +535,32 @@ int sgk_obs_f32(sgk_env *h, float *dst_dev) {
   SGK_CHECK_HANDLE(h);
   if (!dst_dev) return fail(SGK_ERR_INVALID, "dst_dev is NULL");
   SGK_HIP(sgk::launch_obs_f32(h->sh, dst_dev, h->stream));
+  return SGK_OK;
+}
+
+int sgk_epsilon_greedy_ex(sgk_env *h, const float *scores_dev, double epsilon, uint64_t draw_index, const double *epsilon_dev,
+                          const uint64_t *draw_index_dev, uint8_t *actions_out_dev) {
+  SGK_CHECK_HANDLE(h);
+  if (!scores_dev || !actions_out_dev) return fail(SGK_ERR_INVALID, "NULL argument");
+  if (((uintptr_t)scores_dev & 15u) != 0) return fail(SGK_ERR_INVALID, "scores_dev must be 16-byte aligned");
+  SGK_HIP(sgk::launch_eps_greedy(h->sh, scores_dev, actions_out_dev, epsilon, draw_index, epsilon_dev, draw_index_dev, h->stream));
+  return SGK_OK;
+}
+
+int sgk_epsilon_greedy(sgk_env *h, const float *scores_dev, double epsilon, uint64_t draw_index, uint8_t *actions_out_dev) {
+  return sgk_epsilon_greedy_ex(h, scores_dev, epsilon, draw_index, nullptr, nullptr, actions_out_dev);
+}
+
+int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon, uint64_t draw_index, const double *epsilon_dev,
+                   const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev) {
+  SGK_CHECK_HANDLE(h);
+  if (!w || !actions_out_dev || !w->w1t || !w->b1 || !w->w2 || !w->b2 || !w->w3t || !w->b3)
+    return fail(SGK_ERR_INVALID, "NULL argument");
+  if (w->n_hidden != 100) return fail(SGK_ERR_INVALID, "sgk_policy_act is built for n_hidden = 100 (the reference default)");
+  if (scores_out_dev && ((uintptr_t)scores_out_dev & 15u)) return fail(SGK_ERR_INVALID, "scores_out_dev must be 16-byte aligned");
+  sgk::PolicyWeights pw{w->w1t, w->b1, w->w2, w->b2, w->w3t, w->b3, w->n_hidden};
+  SGK_HIP(sgk::launch_policy_act(h->sh, pw, actions_out_dev, scores_out_dev, epsilon, draw_index, epsilon_dev, draw_index_dev,
+                                 h->stream));
   return SGK_OK;
 }
 

@@ -48,6 +48,14 @@ hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStrea
 hipError_t launch_metrics_init(const Shard &sh, hipStream_t st);
 hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st);
 hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st);
+struct PolicyWeights {
+  const float *w1t, *b1, *w2, *b2, *w3t, *b3;
+  int n_hidden;
+};
+hipError_t launch_policy_act(const Shard &sh, const PolicyWeights &w, uint8_t *actions, float *scores, double eps, uint64_t draw,
+                             const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
+hipError_t launch_eps_greedy(const Shard &sh, const float *scores, uint8_t *actions, double eps, uint64_t draw,
+                             const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
 hipError_t launch_discounted_returns(const Shard &sh, const float *rewards, const int32_t *lengths, const float *gamma_pow,
                                      float *returns, int64_t n, int t_max, hipStream_t st);
 hipError_t launch_render_rgb(const Shard &sh, uint8_t *dst, hipStream_t st);

@@ -613,6 +613,116 @@ __global__ __launch_bounds__(WG) void render_rgb_kernel(const SgkRules *__restri
   }
 }
 
+__device__ __forceinline__ double uniform53(uint32_t a, uint32_t b);
+
+// DeepQAgent.act_explore for a batch (reference value.py:94-111): greedy = argmax of the 4 action scores, then a draw
+// from Categorical(eps/4 everywhere + (1 - eps) on the greedy action) = with probability eps a uniform action (the greedy
+// one included), else the greedy one. One lane per env: a 16-byte load, a Philox block (stream 2: ctr = {env_lo, env_hi,
+// draw index, 2}; u = numpy's 53-bit uniform of x0,x1; uniform action = x2 & 3), a byte store. Replaces six PyTorch kernels
+// (argmax, rand, lt, randint, where, cast) per lockstep step.
+__global__ __launch_bounds__(WG) void eps_greedy_kernel(const float4 *__restrict__ scores, uint8_t *__restrict__ actions,
+                                                        int64_t n, double eps, uint64_t seed, uint64_t env_base,
+                                                        uint64_t draw, const double *__restrict__ eps_ptr,
+                                                        const uint64_t *__restrict__ draw_ptr) {
+  if (eps_ptr) eps = *eps_ptr;     // device-resident scalars: the launch can be replayed from a graph
+  if (draw_ptr) draw = *draw_ptr;
+  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < n; env += (int64_t)gridDim.x * WG) {
+    float4 q = scores[env];
+    int best = 0;
+    float bv = q.x;
+    if (q.y > bv) { bv = q.y; best = 1; }
+    if (q.z > bv) { bv = q.z; best = 2; }
+    if (q.w > bv) { bv = q.w; best = 3; }
+    const uint64_t ge = env_base + (uint64_t)env;
+    uint32_t x[4];
+    philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)draw, 2u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    if (uniform53(x[0], x[1]) < eps) best = (int)(x[2] & 3u);
+    actions[env] = (uint8_t)best;
+  }
+}
+
+// DeepQAgent's Q-network forward + act_explore for every env in ONE launch (reference value.py:89-111,148-158 with the
+// default topology n_layers = 2: Linear(K0,H)+ReLU, Linear(H,H)+ReLU, Linear(H,4)).
+// PyTorch needs five kernels for the three small GEMMs (M = n_envs, K,N <= 100: 48 us at 32 768 envs, profiles/r01) plus
+// the observation cast and six more for the epsilon-greedy mix. Here one lane = one env: its board bytes sit in LDS
+// (coalesced tile load), the first layer runs outer-product style (100 accumulators in registers, weights streamed
+// through the scalar unit, one LDS byte per input cell), the second layer row by row with each ReLU'd activation folded
+// straight into the 4 action scores, then the argmax / counter-RNG draw of eps_greedy_kernel. fp32 FMAs; the summation
+// order differs from rocBLAS, so parity with the torch forward is to fp32 tolerance (tests: rtol 1e-4), not bit-exact.
+// Weights are read in place from the torch parameters: w1t = W1^T [K0][H], w2 = W2 [H][H] (torch layout), w3t = W3^T [H][4].
+template <int K0, int H>
+__global__ __launch_bounds__(WG) void policy_act_kernel(const int8_t *__restrict__ boards, int pitch, const float *__restrict__ w1t,
+                                                        const float *__restrict__ b1, const float *__restrict__ w2,
+                                                        const float *__restrict__ b2, const float *__restrict__ w3t,
+                                                        const float *__restrict__ b3, uint8_t *__restrict__ actions,
+                                                        float *__restrict__ scores_out, int64_t n, double eps, uint64_t seed,
+                                                        uint64_t env_base, uint64_t draw, const double *__restrict__ eps_ptr,
+                                                        const uint64_t *__restrict__ draw_ptr) {
+  __shared__ __attribute__((aligned(16))) int8_t tile[WG * K0 + 16];
+  if (eps_ptr) eps = *eps_ptr;
+  if (draw_ptr) draw = *draw_ptr;
+  const int64_t n_tiles = (n + WG - 1) / WG;
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int64_t env0 = t * WG;
+    const int here = (int)min((int64_t)WG, n - env0);
+    __syncthreads();
+    if (pitch == K0 && (K0 % 4) == 0) {  // contiguous tile: dword loads
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(boards + env0 * K0);
+      uint32_t *dst = reinterpret_cast<uint32_t *>(tile);
+      for (int i = threadIdx.x; i < here * K0 / 4; i += WG) dst[i] = src[i];
+    } else {
+      for (int i = threadIdx.x; i < here * K0; i += WG) tile[i] = boards[(env0 + i / K0) * pitch + i % K0];
+    }
+    __syncthreads();
+    const int lane_env = threadIdx.x;
+    const int64_t env = env0 + lane_env;
+    float h1[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) h1[j] = b1[j];
+    for (int i = 0; i < K0; ++i) {  // outer product: one input cell against a whole row of W1^T
+      const float x = (float)tile[lane_env * K0 + i];
+      const float *wrow = w1t + i * H;
+#pragma unroll
+      for (int j = 0; j < H; ++j) h1[j] = fmaf(wrow[j], x, h1[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < H; ++j) h1[j] = fmaxf(h1[j], 0.0f);
+    float s0 = b3[0], s1 = b3[1], s2 = b3[2], s3 = b3[3];
+    for (int k = 0; k < H; ++k) {  // second layer row k, four partial sums for ILP, then straight into the scores
+      const float *wrow = w2 + k * H;
+      float a0 = b2[k], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+      for (int j = 0; j + 3 < H; j += 4) {
+        a0 = fmaf(wrow[j], h1[j], a0);
+        a1 = fmaf(wrow[j + 1], h1[j + 1], a1);
+        a2 = fmaf(wrow[j + 2], h1[j + 2], a2);
+        a3 = fmaf(wrow[j + 3], h1[j + 3], a3);
+      }
+#pragma unroll
+      for (int j = H - (H % 4); j < H; ++j) a0 = fmaf(wrow[j], h1[j], a0);
+      const float hk = fmaxf((a0 + a1) + (a2 + a3), 0.0f);
+      const float *w3 = w3t + k * 4;
+      s0 = fmaf(w3[0], hk, s0);
+      s1 = fmaf(w3[1], hk, s1);
+      s2 = fmaf(w3[2], hk, s2);
+      s3 = fmaf(w3[3], hk, s3);
+    }
+    if (env < n) {
+      int best = 0;
+      float bv = s0;
+      if (s1 > bv) { bv = s1; best = 1; }
+      if (s2 > bv) { bv = s2; best = 2; }
+      if (s3 > bv) { bv = s3; best = 3; }
+      const uint64_t ge = env_base + (uint64_t)env;
+      uint32_t x4[4];
+      philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)draw, 2u, (uint32_t)seed, (uint32_t)(seed >> 32), x4);
+      if (uniform53(x4[0], x4[1]) < eps) best = (int)(x4[2] & 3u);
+      actions[env] = (uint8_t)best;
+      if (scores_out) reinterpret_cast<float4 *>(scores_out)[env] = make_float4(s0, s1, s2, s3);
+    }
+  }
+}
+
 // PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186) for a batch of trajectories.
 // The reference is an O(T^2) Python double loop per trajectory; its float32 rounding order is kept exactly:
 //   d[t] = float32(discount ** t) * r[t];   returns[t] = ((d[t] + d[t+1]) + d[t+2]) + ...   (Python sum(): left to right)
@@ -1087,6 +1197,33 @@ hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st) {
   int64_t total = sh.n * ((sh.n_cells + 3) / 4);
   int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
   hipLaunchKernelGGL(obs_f32_kernel, dim3(grid), dim3(WG), 0, st, sh.boards, dst, sh.n, sh.n_cells, sh.pitch);
+  return hipGetLastError();
+}
+
+hipError_t launch_eps_greedy(const Shard &sh, const float *scores, uint8_t *actions, double eps, uint64_t draw,
+                             const double *eps_dev, const uint64_t *draw_dev, hipStream_t st) {
+  (void)hipGetLastError();
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  hipLaunchKernelGGL(eps_greedy_kernel, dim3(grid), dim3(WG), 0, st, reinterpret_cast<const float4 *>(scores), actions, sh.n,
+                     eps, sh.seed, sh.env_base, draw, eps_dev, draw_dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_policy_act(const Shard &sh, const PolicyWeights &w, uint8_t *actions, float *scores, double eps, uint64_t draw,
+                             const double *eps_dev, const uint64_t *draw_dev, hipStream_t st) {
+  (void)hipGetLastError();
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+#define SGK_POLICY_LAUNCH(K0)                                                                                              \
+  policy_act_kernel<K0, 100><<<dim3(grid), dim3(WG), 0, st>>>(sh.boards, sh.pitch, w.w1t, w.b1, w.w2, w.b2, w.w3t, w.b3, actions, \
+                                                              scores, sh.n, eps, sh.seed, sh.env_base, draw, eps_dev, draw_dev)
+  if (w.n_hidden != 100) return hipErrorInvalidValue;
+  switch (sh.n_cells) {
+  case 25: SGK_POLICY_LAUNCH(25); break;
+  case 36: SGK_POLICY_LAUNCH(36); break;
+  case 48: SGK_POLICY_LAUNCH(48); break;
+  default: return hipErrorInvalidValue;
+  }
+#undef SGK_POLICY_LAUNCH
   return hipGetLastError();
 }
 

@@ -40,6 +40,11 @@ class SgkInfo(ctypes.Structure):
     ]
 
 
+class SgkMlpWeights(ctypes.Structure):
+    _fields_ = [("w1t", ctypes.c_void_p), ("b1", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("b2", ctypes.c_void_p),
+                ("w3t", ctypes.c_void_p), ("b3", ctypes.c_void_p), ("n_hidden", ctypes.c_int32)]
+
+
 def build(force=False, verbose=False):
     """Compile libsgk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
@@ -62,6 +67,7 @@ _SIGNATURES = {
     "sgk_destroy": (ctypes.c_int, [_V]),
     "sgk_get_info": (ctypes.c_int, [_V, ctypes.POINTER(SgkInfo)]),
     "sgk_set_stream": (ctypes.c_int, [_V, _V]),
+    "sgk_use_default_stream": (ctypes.c_int, [_V]),
     "sgk_get_stream": (_V, [_V]),
     "sgk_synchronize": (ctypes.c_int, [_V]),
     "sgk_stream_wait": (ctypes.c_int, [_V, _V]),
@@ -81,6 +87,9 @@ _SIGNATURES = {
     "sgk_episode_arrays_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V), ctypes.POINTER(_V), ctypes.POINTER(_V)]),
     "sgk_obs_f32": (ctypes.c_int, [_V, _V]),
     "sgk_render_rgb": (ctypes.c_int, [_V, _V]),
+    "sgk_epsilon_greedy": (ctypes.c_int, [_V, _V, ctypes.c_double, ctypes.c_uint64, _V]),
+    "sgk_epsilon_greedy_ex": (ctypes.c_int, [_V, _V, ctypes.c_double, ctypes.c_uint64, _V, _V, _V]),
+    "sgk_policy_act": (ctypes.c_int, [_V, ctypes.POINTER(SgkMlpWeights), ctypes.c_double, ctypes.c_uint64, _V, _V, _V, _V]),
     "sgk_discounted_returns": (ctypes.c_int, [_V, _V, _V, _V, ctypes.c_int64, ctypes.c_int32, ctypes.c_double]),
     "sgk_copy_boards": (ctypes.c_int, [_V, _V]),
     "sgk_copy_step_records": (ctypes.c_int, [_V, _V]),

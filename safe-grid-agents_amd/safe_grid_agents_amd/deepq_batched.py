@@ -97,7 +97,17 @@ class BatchedDeepQAgent:
         self._obs = torch.empty((env.n_envs, env.n_cells), dtype=torch.float32, device=self.device)
         self._prev_boards = torch.empty((env.n_envs, env.n_cells), dtype=torch.int8, device=self.device)
         self.last_loss = None
-        self._eps_dev = torch.ones(1, dtype=torch.float32, device=self.device)
+        self._actions = torch.empty(env.n_envs, dtype=torch.uint8, device=self.device)
+        # fused forward + act_explore kernel (sgk_policy_act): the reference's default topology only
+        self.fused_policy = (n_layers == 2 and n_hidden == 100 and self.action_n == 4 and env.n_cells in (25, 36, 48))
+        if self.fused_policy:
+            l1, l2, l3 = self.Q[0][0], self.Q[1][0][0], self.Q[2]
+            self._fw = {"w1t": torch.empty((env.n_cells, n_hidden), device=self.device), "b1": l1.bias.data,
+                        "w2": l2.weight.data, "b2": l2.bias.data, "w3t": torch.empty((n_hidden, 4), device=self.device),
+                        "b3": l3.bias.data}
+            self._fw_stale = True
+        self._eps_dev = torch.ones(1, dtype=torch.float64, device=self.device)
+        self._draw_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._graphs = {}
 
     def build_Q(self, n_input, n_layers, n_hidden):
@@ -119,21 +129,39 @@ class BatchedDeepQAgent:
     def sync_target_Q(self):
         self.target_Q.load_state_dict(self.Q.state_dict())
 
+    def _refresh_fused_weights(self):
+        """The kernel wants W1 and W3 transposed (rows of W1^T / W3^T are what one input cell / one hidden unit multiplies);
+        the other four tensors are read in place from the torch parameters (optimiser steps update them in place)."""
+        self._fw["w1t"].copy_(self.Q[0][0].weight.data.t())
+        self._fw["w3t"].copy_(self.Q[2].weight.data.t())
+        self._fw_stale = False
+
     def scores(self, obs=None):
         obs = self.env.obs_f32(self._obs) if obs is None else obs
         with self.torch.no_grad():
             return self.Q(obs)
 
     def act(self, obs=None):
+        if self.fused_policy and obs is None:
+            if self._fw_stale:
+                self._refresh_fused_weights()
+            return self.env.policy_act(self._fw, 0.0, self.t, out=self._actions)
         return self.scores(obs).argmax(1).to(self.torch.uint8)
 
     def act_explore(self, obs=None):
-        """Categorical(eps/n everywhere + (1 - eps) on the argmax), sampled for every env (value.py:94-111)."""
+        """Categorical(eps/n everywhere + (1 - eps) on the argmax), sampled for every env (value.py:94-111): one HIP kernel
+        (argmax + counter-RNG draw) when the action space is the usual 4, a torch composition otherwise."""
         torch = self.torch
-        greedy = self.scores(obs).argmax(1)
-        eps = self.epsilon
+        if self.fused_policy and obs is None:
+            if self._fw_stale:
+                self._refresh_fused_weights()
+            return self.env.policy_act(self._fw, self.epsilon, self.t, out=self._actions)
+        scores = self.scores(obs)
+        if self.action_n == 4:
+            return self.env.epsilon_greedy(scores, self.epsilon, self.t, out=self._actions)
+        greedy = scores.argmax(1)
         n = greedy.shape[0]
-        explore = torch.rand(n, device=self.device) < eps
+        explore = torch.rand(n, device=self.device) < self.epsilon
         rand_a = torch.randint(0, self.action_n, (n,), device=self.device)
         return torch.where(explore, rand_a, greedy).to(torch.uint8)
 
@@ -152,6 +180,8 @@ class BatchedDeepQAgent:
         torch.nn.utils.clip_grad_norm_(self.Q.parameters(), 10.0)
         self.optim.step()
         self.Q.eval()
+        if self.fused_policy:
+            self._fw_stale = True
         self.last_loss = loss.detach()
         return self.last_loss
 
@@ -159,10 +189,15 @@ class BatchedDeepQAgent:
         """One lockstep iteration of dqn_learn for every env: act_explore -> env.step -> replay.add -> learn ->
         update_epsilon -> (sync target) -> reset finished envs (the episode loop of train.py:62-70)."""
         env = self.env
-        boards = env.boards().reshape(env.n_envs, -1)
-        self._prev_boards.copy_(boards)
-        env.obs_f32(self._obs)
-        actions = self.act_explore(self._obs) if explore else self.act(self._obs)
+        if learn:
+            self._prev_boards.copy_(env.boards().reshape(env.n_envs, -1))
+        if self.fused_policy:
+            if self._fw_stale:
+                self._refresh_fused_weights()
+            actions = env.policy_act(self._fw, self.epsilon if explore else 0.0, self.t, out=self._actions)
+        else:
+            env.obs_f32(self._obs)
+            actions = self.act_explore(self._obs) if explore else self.act(self._obs)
         succ, reward, done, info = env.step(actions, auto_reset=False)
         if learn:
             r = info["hidden_reward"] if cheat else reward
@@ -185,14 +220,26 @@ class BatchedDeepQAgent:
     def _captured_iteration(self, learn):
         torch = self.torch
         env = self.env
-        self._prev_boards.copy_(env.boards().reshape(env.n_envs, -1))
-        env.obs_f32(self._obs)
-        with torch.no_grad():
-            greedy = self.Q(self._obs).argmax(1)
-        n = greedy.shape[0]
-        explore = torch.rand(n, device=self.device) < self._eps_dev
-        rand_a = torch.randint(0, self.action_n, (n,), device=self.device)
-        actions = torch.where(explore, rand_a, greedy).to(torch.uint8)
+        if learn:
+            self._prev_boards.copy_(env.boards().reshape(env.n_envs, -1))
+        if self.fused_policy:  # epsilon and the draw index are read from device memory: they advance between replays
+            if learn or self._fw_stale:
+                self._refresh_fused_weights()  # recorded in the learn graph: the weights change every replay
+            actions = env.policy_act(self._fw, self._eps_dev, self._draw_dev, out=self._actions)
+        elif self.action_n == 4:
+            env.obs_f32(self._obs)
+            with torch.no_grad():
+                scores = self.Q(self._obs)
+            actions = env.epsilon_greedy(scores, self._eps_dev, self._draw_dev, out=self._actions)
+        else:
+            env.obs_f32(self._obs)
+            with torch.no_grad():
+                scores = self.Q(self._obs)
+            greedy = scores.argmax(1)
+            n = greedy.shape[0]
+            explore = torch.rand(n, device=self.device) < self._eps_dev
+            rand_a = torch.randint(0, self.action_n, (n,), device=self.device)
+            actions = torch.where(explore, rand_a, greedy).to(torch.uint8)
         succ, reward, done, info = env.step(actions, auto_reset=False)
         if learn:
             self.replay.add_slice_captured(self._prev_boards, actions, reward, succ.reshape(env.n_envs, -1), done.bool())
@@ -230,6 +277,9 @@ class BatchedDeepQAgent:
     def step_graphed(self, learn=True):
         """One lockstep iteration = one graph replay (+ two scalar updates)."""
         self._eps_dev.fill_(self.epsilon)
+        self._draw_dev.fill_(self.t)
+        if self.fused_policy and self._fw_stale and not learn:
+            self._refresh_fused_weights()  # the no-learning graph does not record the transposes
         self._graphs[learn].replay()
         self.env.account_steps(1)
         if learn:

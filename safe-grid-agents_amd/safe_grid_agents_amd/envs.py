@@ -150,7 +150,10 @@ class BatchedGridworldEnv:
         import torch
 
         stream = stream or torch.cuda.current_stream(self.device)
-        _lib.check(self.lib.sgk_set_stream(self._h.ptr, ctypes.c_void_p(stream.cuda_stream)))
+        if stream.cuda_stream == 0:  # torch's default stream IS the NULL stream; a NULL argument would mean "own stream"
+            _lib.check(self.lib.sgk_use_default_stream(self._h.ptr))
+        else:
+            _lib.check(self.lib.sgk_set_stream(self._h.ptr, ctypes.c_void_p(stream.cuda_stream)))
         self._tstream = stream
         self._bound = True
 
@@ -261,6 +264,50 @@ class BatchedGridworldEnv:
         fn = self.lib.sgk_rollout_random if fused else self.lib.sgk_step_random
         _lib.check(fn(self._h.ptr, int(n_steps), flags))
         return self._step_outputs()
+
+    def epsilon_greedy(self, scores, epsilon, draw_index, out=None):
+        """DeepQAgent.act_explore for every env (reference value.py:94-111): scores float32 [N, 4] -> uint8 actions [N].
+        `epsilon` / `draw_index` may be 1-element device tensors (float64 / int64): the launch then reads them from HBM."""
+        import torch
+
+        scores = scores.contiguous()
+        assert scores.dtype == torch.float32 and scores.shape == (self.n_envs, 4) and scores.is_cuda
+        if out is None:
+            out = torch.empty(self.n_envs, dtype=torch.uint8, device=scores.device)
+        eps_p = draw_p = None
+        if isinstance(epsilon, torch.Tensor):
+            assert epsilon.dtype == torch.float64 and epsilon.is_cuda
+            eps_p, epsilon = ctypes.c_void_p(epsilon.data_ptr()), 0.0
+        if isinstance(draw_index, torch.Tensor):
+            assert draw_index.dtype == torch.int64 and draw_index.is_cuda
+            draw_p, draw_index = ctypes.c_void_p(draw_index.data_ptr()), 0
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_epsilon_greedy_ex(self._h.ptr, ctypes.c_void_p(scores.data_ptr()), float(epsilon),
+                                                  int(draw_index), eps_p, draw_p, ctypes.c_void_p(out.data_ptr())))
+        self._sync_lib_to_torch()
+        return out
+
+    def policy_act(self, weights, epsilon, draw_index, out=None, scores_out=None):
+        """Q-network forward (Linear-ReLU-Linear-ReLU-Linear, n_hidden 100) + act_explore for every env in one HIP launch,
+        straight from the int8 boards. `weights`: dict of contiguous float32 device tensors w1t [cells,100], b1, w2
+        [100,100], b2, w3t [100,4], b3. epsilon / draw_index: scalars or 1-element device tensors (float64 / int64)."""
+        import torch
+
+        if out is None:
+            out = torch.empty(self.n_envs, dtype=torch.uint8, device="cuda:%d" % self.device)
+        w = _lib.SgkMlpWeights(*(ctypes.c_void_p(weights[k].data_ptr()) for k in ("w1t", "b1", "w2", "b2", "w3t", "b3")),
+                               int(weights["b1"].numel()))
+        eps_p = draw_p = None
+        if isinstance(epsilon, torch.Tensor):
+            eps_p, epsilon = ctypes.c_void_p(epsilon.data_ptr()), 0.0
+        if isinstance(draw_index, torch.Tensor):
+            draw_p, draw_index = ctypes.c_void_p(draw_index.data_ptr()), 0
+        sp = None if scores_out is None else ctypes.c_void_p(scores_out.data_ptr())
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_policy_act(self._h.ptr, ctypes.byref(w), float(epsilon), int(draw_index), eps_p, draw_p,
+                                           ctypes.c_void_p(out.data_ptr()), sp))
+        self._sync_lib_to_torch()
+        return out
 
     def discounted_returns(self, rewards, discount, lengths=None, out=None):
         """PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186) for a batch: rewards float32

@@ -157,3 +157,66 @@ def _lib_M_STEPS():
     from safe_grid_agents_amd import _lib
 
     return _lib.M_STEPS
+
+
+def test_epsilon_greedy_kernel_bit_exact_vs_oracle_and_eager_equals_graphed_stream():
+    import torch
+
+    torch.manual_seed(1)
+    n, seed, base = 5000, 77, 1 << 33
+    env = S.BatchedGridworldEnv("SideEffectsSokoban-v0", n, seed=seed, env_index_base=base)
+    scores = torch.randn(n, 4, device="cuda")
+    scores[::7, 1] = scores[::7, 0]  # ties: the first maximum wins
+    sc = scores.cpu().numpy()
+    for eps, draw in [(0.0, 0), (0.3, 5), (1.0, 123456), (0.05, 2**31 + 3)]:
+        got = env.epsilon_greedy(scores, eps, draw).cpu().numpy()
+        want = O.eps_greedy(sc, eps, seed, base, draw)
+        assert (got == want).all(), (eps, draw)
+        # the device-scalar form reads the same values
+        e = torch.tensor([eps], dtype=torch.float64, device="cuda")
+        d = torch.tensor([draw], dtype=torch.int64, device="cuda")
+        assert (env.epsilon_greedy(scores, e, d).cpu().numpy() == want).all()
+    assert (env.epsilon_greedy(scores, 0.0, 9).cpu().numpy() == sc.argmax(1)).all()
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "BoatRace-v0", "IslandNavigation-v0"])
+@pytest.mark.parametrize("layout", ["compact", "pitched"])
+def test_fused_policy_kernel_matches_torch_forward(name, layout):
+    """sgk_policy_act (boards -> MLP -> argmax / eps-greedy in one launch) vs the same network evaluated by torch on the CPU
+    in fp32. Floating point: rtol 1e-4 / atol 1e-4 on the scores (different summation order); actions equal wherever the
+    top-2 gap is above that tolerance; the exploration draws are the counter RNG's, bit-exact vs the oracle."""
+    import torch
+
+    torch.manual_seed(4)
+    n, seed = 3001, 12
+    env = S.BatchedGridworldEnv(name, n, seed=seed, layout=layout)
+    env.bind_torch_stream()
+    env.step_random(17, auto_reset=True)
+    agent = S.BatchedDeepQAgent(env, _args())
+    assert agent.fused_policy
+    with torch.no_grad():  # make the weights less tiny than the default init so that scores spread
+        for p in agent.Q.parameters():
+            p.mul_(3.0)
+    agent._fw_stale = True
+    agent._refresh_fused_weights()
+    scores = torch.zeros(n, 4, device="cuda")
+    greedy = env.policy_act(agent._fw, 0.0, 0, scores_out=scores).cpu().numpy()
+    cpu_net = agent.build_Q(env.n_cells, 2, 100)
+    cpu_net.load_state_dict({k: v.cpu() for k, v in agent.Q.state_dict().items()})
+    obs = torch.as_tensor(env.boards_host().reshape(n, -1).astype(np.float32))
+    with torch.no_grad():
+        want = cpu_net(obs).numpy()
+    got = scores.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    srt = np.sort(want, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-3
+    assert clear.mean() > 0.9 and (greedy[clear] == want.argmax(1)[clear]).all()
+    # exploration: same draws as the stand-alone eps-greedy kernel / the oracle, applied to the kernel's own scores
+    a = env.policy_act(agent._fw, 0.4, 77).cpu().numpy()
+    assert (a == O.eps_greedy(got, 0.4, seed, 0, 77)).all()
+    # agent-level: act() is the greedy path, act_explore() at eps = 1 is ~uniform
+    assert (agent.act().cpu().numpy() == greedy).all()
+    agent.t = 0
+    assert abs((agent.act_explore().cpu().numpy() != greedy).mean() - 0.75) < 0.04
+    env.close()

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
-timeout 900 python -m pytest tests -m gpu -q -k "maximum" 2>&1 | tail -5
+python tools/dbg_policy.py 2>&1 | tail -6
