@@ -650,63 +650,94 @@ __global__ __launch_bounds__(WG) void eps_greedy_kernel(const float4 *__restrict
 // straight into the 4 action scores, then the argmax / counter-RNG draw of eps_greedy_kernel. fp32 FMAs; the summation
 // order differs from rocBLAS, so parity with the torch forward is to fp32 tolerance (tests: rtol 1e-4), not bit-exact.
 // Weights are read in place from the torch parameters: w1t = W1^T [K0][H], w2 = W2 [H][H] (torch layout), w3t = W3^T [H][4].
+// workgroup of the policy kernel: 128 lanes = 2 waves, so that 32 768 envs already occupy all 256 CUs (two lone waves
+// per CU share the LDS broadcast bandwidth instead of four)
+constexpr int PWG = 128;
+
 template <int K0, int H>
-__global__ __launch_bounds__(WG) void policy_act_kernel(const int8_t *__restrict__ boards, int pitch, const float *__restrict__ w1t,
+__global__ __launch_bounds__(PWG) __attribute__((amdgpu_waves_per_eu(1, 1))) void policy_act_kernel(const int8_t *__restrict__ boards, int pitch, const float *__restrict__ w1t,
                                                         const float *__restrict__ b1, const float *__restrict__ w2,
                                                         const float *__restrict__ b2, const float *__restrict__ w3t,
                                                         const float *__restrict__ b3, uint8_t *__restrict__ actions,
                                                         float *__restrict__ scores_out, int64_t n, double eps, uint64_t seed,
                                                         uint64_t env_base, uint64_t draw, const double *__restrict__ eps_ptr,
                                                         const uint64_t *__restrict__ draw_ptr) {
-  __shared__ __attribute__((aligned(16))) int8_t tile[WG * K0 + 16];
+  static_assert(H % 4 == 0, "rows are read as float4");
+  // All weights of the network (56 KB for 36-100-100-4) live in LDS for the launch: every lane of every wave multiplies by
+  // the same weight at the same time, so each ds_read_b128 is a conflict-free broadcast of four weights.
+  // Measured at 32 768 envs (profiles/r01): 39 us, against 59 us with the weights streamed through the scalar unit and
+  // ~65 us for the PyTorch kernels it replaces (three GEMMs 48 us + two ReLUs 11 us + cast + epsilon-greedy mix).
+  // The bound is instruction issue, not FLOPs: 32 768 envs are only 512 waves for 1 024 SIMDs, a lone wave issues a
+  // v_pk_fma_f32 every ~8 cycles (100 rows x 52 of them ~ 24 us) and stalls on the LDS latency at the head of every row.
+  // What mattered: pair-typed accumulators (no shuffle moves) and amdgpu_waves_per_eu(1,1) so that the compiler issues
+  // a row's 25 broadcast reads up front (with the default register budget it waited after every read: 93 us).
+  // Next step if this ever matters: split one env over several lanes to get two waves per SIMD.
+  extern __shared__ __attribute__((aligned(16))) unsigned char policy_smem[];
+  float *lw1 = reinterpret_cast<float *>(policy_smem);  // [K0][H]
+  float *lw2 = lw1 + K0 * H;                            // [H][H]
+  float *lw3 = lw2 + H * H;                             // [H][4]
+  float *lb1 = lw3 + H * 4;                             // [H]
+  float *lb2 = lb1 + H;                                 // [H]
+  float *lb3 = lb2 + H;                                 // [4]
+  int8_t *tile = reinterpret_cast<int8_t *>(lb3 + 4);   // [PWG][K0] boards of the current tile
+  for (int i = threadIdx.x; i < K0 * H; i += PWG) lw1[i] = w1t[i];
+  for (int i = threadIdx.x; i < H * H; i += PWG) lw2[i] = w2[i];
+  for (int i = threadIdx.x; i < H * 4; i += PWG) lw3[i] = w3t[i];
+  for (int i = threadIdx.x; i < H; i += PWG) { lb1[i] = b1[i]; lb2[i] = b2[i]; }
+  if (threadIdx.x < 4) lb3[threadIdx.x] = b3[threadIdx.x];
   if (eps_ptr) eps = *eps_ptr;
   if (draw_ptr) draw = *draw_ptr;
-  const int64_t n_tiles = (n + WG - 1) / WG;
+  const int64_t n_tiles = (n + PWG - 1) / PWG;
   for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const int64_t env0 = t * WG;
-    const int here = (int)min((int64_t)WG, n - env0);
+    const int64_t env0 = t * PWG;
+    const int here = (int)min((int64_t)PWG, n - env0);
     __syncthreads();
     if (pitch == K0 && (K0 % 4) == 0) {  // contiguous tile: dword loads
       const uint32_t *src = reinterpret_cast<const uint32_t *>(boards + env0 * K0);
       uint32_t *dst = reinterpret_cast<uint32_t *>(tile);
-      for (int i = threadIdx.x; i < here * K0 / 4; i += WG) dst[i] = src[i];
+      for (int i = threadIdx.x; i < here * K0 / 4; i += PWG) dst[i] = src[i];
     } else {
-      for (int i = threadIdx.x; i < here * K0; i += WG) tile[i] = boards[(env0 + i / K0) * pitch + i % K0];
+      for (int i = threadIdx.x; i < here * K0; i += PWG) tile[i] = boards[(env0 + i / K0) * pitch + i % K0];
     }
     __syncthreads();
     const int lane_env = threadIdx.x;
     const int64_t env = env0 + lane_env;
-    float h1[H];
+    // activations and weights are handled as aligned float pairs so that every multiply-add is one v_pk_fma_f32 on
+    // register pairs as they come out of the ds_read_b128 (no shuffling moves)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f2 h1[H / 2];
 #pragma unroll
-    for (int j = 0; j < H; ++j) h1[j] = b1[j];
+    for (int j = 0; j < H / 2; ++j) h1[j] = reinterpret_cast<const f2 *>(lb1)[j];
     for (int i = 0; i < K0; ++i) {  // outer product: one input cell against a whole row of W1^T
-      const float x = (float)tile[lane_env * K0 + i];
-      const float *wrow = w1t + i * H;
+      const float xs = (float)tile[lane_env * K0 + i];
+      const f2 x = {xs, xs};
+      const f4 *wrow = reinterpret_cast<const f4 *>(lw1 + i * H);
 #pragma unroll
-      for (int j = 0; j < H; ++j) h1[j] = fmaf(wrow[j], x, h1[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < H; ++j) h1[j] = fmaxf(h1[j], 0.0f);
-    float s0 = b3[0], s1 = b3[1], s2 = b3[2], s3 = b3[3];
-    for (int k = 0; k < H; ++k) {  // second layer row k, four partial sums for ILP, then straight into the scores
-      const float *wrow = w2 + k * H;
-      float a0 = b2[k], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-#pragma unroll
-      for (int j = 0; j + 3 < H; j += 4) {
-        a0 = fmaf(wrow[j], h1[j], a0);
-        a1 = fmaf(wrow[j + 1], h1[j + 1], a1);
-        a2 = fmaf(wrow[j + 2], h1[j + 2], a2);
-        a3 = fmaf(wrow[j + 3], h1[j + 3], a3);
+      for (int j = 0; j < H / 4; ++j) {
+        const f4 w = wrow[j];
+        h1[2 * j + 0] = __builtin_elementwise_fma(w.xy, x, h1[2 * j + 0]);
+        h1[2 * j + 1] = __builtin_elementwise_fma(w.zw, x, h1[2 * j + 1]);
       }
-#pragma unroll
-      for (int j = H - (H % 4); j < H; ++j) a0 = fmaf(wrow[j], h1[j], a0);
-      const float hk = fmaxf((a0 + a1) + (a2 + a3), 0.0f);
-      const float *w3 = w3t + k * 4;
-      s0 = fmaf(w3[0], hk, s0);
-      s1 = fmaf(w3[1], hk, s1);
-      s2 = fmaf(w3[2], hk, s2);
-      s3 = fmaf(w3[3], hk, s3);
     }
+#pragma unroll
+    for (int j = 0; j < H / 2; ++j) h1[j] = __builtin_elementwise_max(h1[j], (f2){0.0f, 0.0f});
+    f4 sc = *reinterpret_cast<const f4 *>(lb3);
+    for (int k = 0; k < H; ++k) {  // second layer row k: two pair-accumulators, then straight into the four scores
+      const f4 *wrow = reinterpret_cast<const f4 *>(lw2 + k * H);
+      f2 a01 = {lb2[k], 0.0f}, a23 = {0.0f, 0.0f};
+#pragma unroll
+      for (int j = 0; j < H / 4; ++j) {
+        const f4 w = wrow[j];
+        a01 = __builtin_elementwise_fma(w.xy, h1[2 * j + 0], a01);
+        a23 = __builtin_elementwise_fma(w.zw, h1[2 * j + 1], a23);
+      }
+      const f2 a = a01 + a23;
+      const float hk = fmaxf(a.x + a.y, 0.0f);
+      const f4 w3 = reinterpret_cast<const f4 *>(lw3)[k];
+      sc = __builtin_elementwise_fma(w3, (f4){hk, hk, hk, hk}, sc);
+    }
+    const float s0 = sc.x, s1 = sc.y, s2 = sc.z, s3 = sc.w;
     if (env < n) {
       int best = 0;
       float bv = s0;
@@ -721,6 +752,11 @@ __global__ __launch_bounds__(WG) void policy_act_kernel(const int8_t *__restrict
       if (scores_out) reinterpret_cast<float4 *>(scores_out)[env] = make_float4(s0, s1, s2, s3);
     }
   }
+}
+
+template <int K0, int H>
+constexpr size_t policy_lds_bytes() {
+  return sizeof(float) * (K0 * H + H * H + H * 4 + H + H + 4) + (size_t)PWG * K0 + 16;
 }
 
 // PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186) for a batch of trajectories.
@@ -1212,10 +1248,17 @@ hipError_t launch_eps_greedy(const Shard &sh, const float *scores, uint8_t *acti
 hipError_t launch_policy_act(const Shard &sh, const PolicyWeights &w, uint8_t *actions, float *scores, double eps, uint64_t draw,
                              const double *eps_dev, const uint64_t *draw_dev, hipStream_t st) {
   (void)hipGetLastError();
-  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  int grid = grid_for((sh.n + PWG - 1) / PWG, sh.n_cus * 2);
 #define SGK_POLICY_LAUNCH(K0)                                                                                              \
-  policy_act_kernel<K0, 100><<<dim3(grid), dim3(WG), 0, st>>>(sh.boards, sh.pitch, w.w1t, w.b1, w.w2, w.b2, w.w3t, w.b3, actions, \
-                                                              scores, sh.n, eps, sh.seed, sh.env_base, draw, eps_dev, draw_dev)
+  do {                                                                                                                     \
+    constexpr size_t lds = policy_lds_bytes<K0, 100>();                                                                    \
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&policy_act_kernel<K0, 100>),                       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+    if (ae != hipSuccess) return ae;                                                                                       \
+    policy_act_kernel<K0, 100><<<dim3(grid), dim3(PWG), lds, st>>>(sh.boards, sh.pitch, w.w1t, w.b1, w.w2, w.b2, w.w3t, w.b3, \
+                                                                  actions, scores, sh.n, eps, sh.seed, sh.env_base, draw,  \
+                                                                  eps_dev, draw_dev);                                      \
+  } while (0)
   if (w.n_hidden != 100) return hipErrorInvalidValue;
   switch (sh.n_cells) {
   case 25: SGK_POLICY_LAUNCH(25); break;
