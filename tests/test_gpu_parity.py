@@ -617,3 +617,60 @@ def test_maximum_sizes_and_64bit_env_ids():
     orc.rollout(150, seed=3, env_begin=base, auto_reset=True)
     assert_same_state(env, orc, "64-bit env ids")
     env.close()
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_interleaving_every_kind_of_step_keeps_the_random_stream_exact(name):
+    """The RandomAgent action byte cached in the state words must never go stale: mix graph / eager random steps (at every
+    phase of the 4-step block), given-action steps, SingleActionAgent steps, fused rollouts, reset_done and masked resets
+    on ONE env batch and compare with the oracle driven by the same schedule."""
+    torch = _torch()
+    n, seed = 600, 31
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    orc = O.EnvBatch(name, n)
+    rng = np.random.RandomState(2)
+    t = 0
+
+    def rnd(k, auto_reset=True, fused=False):
+        nonlocal t
+        env.step_random(k, auto_reset=auto_reset, fused=fused)
+        orc.rollout(k, seed=seed, t_begin=t, auto_reset=auto_reset)
+        t += k
+
+    def given(auto_reset):
+        nonlocal t
+        acts = rng.randint(0, 4, size=n).astype(np.uint8)
+        env.step(torch.as_tensor(acts, device="cuda"), auto_reset=auto_reset)
+        orc.rollout(1, actions=acts[None], auto_reset=auto_reset)
+        t += 1
+
+    schedule = [("rnd", 1), ("rnd", 1), ("given", True), ("rnd", 2), ("rnd", 5), ("given", False), ("rnd", 1), ("reset_done",),
+                ("rnd", 3), ("rnd", 64), ("rnd", 1), ("repeat", 3), ("rnd", 2), ("fused", 7), ("rnd", 1), ("rnd", 6),
+                ("mask",), ("rnd", 9), ("noreset", 30), ("reset_done",), ("rnd", 2), ("rnd", 70), ("given", True), ("rnd", 4)]
+    for step in schedule:
+        if step[0] == "rnd":
+            rnd(step[1])
+        elif step[0] == "fused":
+            rnd(step[1], fused=True)
+        elif step[0] == "noreset":
+            rnd(step[1], auto_reset=False)
+        elif step[0] == "given":
+            given(step[1])
+        elif step[0] == "repeat":
+            acts = rng.randint(0, 4, size=n).astype(np.uint8)
+            env.step_repeat(torch.as_tensor(acts, device="cuda"), step[1], auto_reset=True)
+            orc.rollout(step[1], actions=np.repeat(acts[None], step[1], axis=0), auto_reset=True)
+            t += step[1]
+        elif step[0] == "reset_done":
+            env.reset_done()
+            for i in np.nonzero(orc.field("game_over"))[0]:
+                orc.reset(int(i))
+        elif step[0] == "mask":
+            mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            mask[::5] = 1
+            env.reset(mask)
+            for i in range(0, n, 5):
+                orc.reset(i)
+        assert_same_state(env, orc, str(step))
+    assert env.lockstep_t == t
+    env.close()
