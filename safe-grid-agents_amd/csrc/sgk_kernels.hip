@@ -186,7 +186,7 @@ __device__ __forceinline__ long long wave_sum64(long long v) {
 // flush() runs once per launch: wave reduction (skipped by waves that finished nothing), then one add per quantity
 // into the WORKGROUP'S OWN slot of the metrics slab (SGK_METRIC_SLOTS x 16 int64). Slots are summed / max-ed when
 // the host reads the metrics. One address per workgroup instead of one address for the whole chip: same-address
-// atomics from 16 K waves cost ~1.2 ms per step on MI355X (profiles/r01_*), this costs nothing measurable.
+// atomics from 16 K waves cost ~1.2 ms per step on MI355X (profiles/r01/00_before_slot_metrics), this costs nothing measurable.
 struct EpisodeAcc {
   int s_ret, s_perf, s_mpos, n_eps, n_pos;
   int m_ret, m_perf, m_margin, m_mpos;
