@@ -109,6 +109,9 @@ SGK_API int sgk_create(int env_id, int64_t n_envs, int device, uint64_t seed, sg
 SGK_API int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_t env_index_base, int layout,
                   sgk_env **out);
 SGK_API int sgk_destroy(sgk_env *h);
+/* env.seed(seed) (reference train.py:52): re-keys the counter RNG of later random-action / exploration draws. The three
+ * envs themselves are deterministic. */
+SGK_API int sgk_set_seed(sgk_env *h, uint64_t seed);
 SGK_API int sgk_get_info(const sgk_env *h, sgk_info *out);
 SGK_API int sgk_set_stream(sgk_env *h, void *hip_stream); /* NULL restores the handle's own stream */
 SGK_API int sgk_use_default_stream(sgk_env *h);           /* enqueue on the device's NULL (legacy default) stream */

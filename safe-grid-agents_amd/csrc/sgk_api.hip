@@ -286,6 +286,14 @@ int sgk_set_stream(sgk_env *h, void *hip_stream) {
   return SGK_OK;
 }
 
+int sgk_set_seed(sgk_env *h, uint64_t seed) {
+  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  h->sh.seed = seed;  // kernel argument of every later launch; captured step graphs carry the old seed and are dropped
+  for (auto &kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+  h->graphs.clear();
+  return SGK_OK;
+}
+
 int sgk_use_default_stream(sgk_env *h) {
   if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
   h->stream = nullptr;  // the device's NULL (legacy default) stream: where PyTorch queues work unless told otherwise

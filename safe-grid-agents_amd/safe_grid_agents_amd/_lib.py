@@ -65,6 +65,7 @@ _SIGNATURES = {
     "sgk_create_ex": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
                                      ctypes.c_int, ctypes.POINTER(_V)]),
     "sgk_destroy": (ctypes.c_int, [_V]),
+    "sgk_set_seed": (ctypes.c_int, [_V, ctypes.c_uint64]),
     "sgk_get_info": (ctypes.c_int, [_V, ctypes.POINTER(SgkInfo)]),
     "sgk_set_stream": (ctypes.c_int, [_V, _V]),
     "sgk_use_default_stream": (ctypes.c_int, [_V]),

@@ -204,7 +204,11 @@ class BatchedGridworldEnv:
 
     # ---- gym-shaped API -------------------------------------------------------------------------
     def seed(self, seed=None):
-        return [seed]  # the three envs are deterministic; the counter RNG is keyed at construction
+        """env.seed(seed) (reference train.py:52): the envs are deterministic; this re-keys the counter RNG that drives
+        step_random / exploration draws from now on."""
+        if seed is not None:
+            _lib.check(self.lib.sgk_set_seed(self._h.ptr, int(seed) & (2**64 - 1)))
+        return [seed]
 
     def boards(self):
         """int8 observation cells, torch view [N, 1, H, W] over HBM (strided when rows are padded)."""
@@ -458,6 +462,10 @@ class GridworldEnv:
         self._rec = np.zeros((1, 4), dtype=np.int8)
         self._board = np.zeros((1, self._b.n_cells), dtype=np.int8)
         self._ret = np.zeros(1, dtype=np.int32)
+        self._water = None
+        if name == "IslandNavigation-v0":
+            first = self._b.boards_host()[0, 0]
+            self._water = np.argwhere(first == 0)  # value_mapping: water = 0
 
     def seed(self, seed=None):
         return [seed]
@@ -494,6 +502,10 @@ class GridworldEnv:
             "extra_observations": {"actual_actions": actual},
         }
         state = self._board.reshape(1, self._b.H, self._b.W).astype(np.float32)
+        if self._water is not None:  # IslandNavigation's side information: Manhattan distance to the nearest water cell
+            at = np.argwhere(state[0] == 2)
+            info["extra_observations"]["safety"] = (
+                0 if at.size == 0 else int(np.abs(self._water - at[0]).sum(axis=1).min()))
         return state, reward, done, info
 
     def render(self, mode="rgb_array"):

@@ -674,3 +674,30 @@ def test_interleaving_every_kind_of_step_keeps_the_random_stream_exact(name):
         assert_same_state(env, orc, str(step))
     assert env.lockstep_t == t
     env.close()
+
+
+def test_island_safety_side_information_and_reseeding():
+    _torch()
+    env = S.make("island")
+    shim_rng = np.random.RandomState(0)
+    from oracle.gym_shim import OracleGridworldEnv
+
+    ref = OracleGridworldEnv("IslandNavigation-v0")
+    env.reset(); ref.reset()
+    for _ in range(300):
+        a = int(shim_rng.randint(4))
+        s, r, d, info = env.step(a)
+        s2, r2, d2, info2 = ref.step(a)
+        assert info["extra_observations"]["safety"] == info2["extra_observations"]["safety"]
+        assert (r, d, info["hidden_reward"]) == (r2, d2, info2["hidden_reward"]) and (s == s2).all()
+        if d:
+            env.reset(); ref.reset()
+    env.close()
+    # env.seed() re-keys the counter RNG of the batched env
+    b = S.BatchedGridworldEnv("BoatRace-v0", 512, seed=1)
+    b.seed(99)
+    b.step_random(70, auto_reset=True)   # 70 >= 4: goes through a freshly captured graph
+    orc = O.EnvBatch("BoatRace-v0", 512)
+    orc.rollout(70, seed=99, auto_reset=True)
+    assert_same_state(b, orc, "after seed()")
+    b.close()

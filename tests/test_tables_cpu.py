@@ -76,3 +76,36 @@ def test_bad_arguments_are_rejected():
     assert lib.sgk_debug_host_transition(0, 99, 0, 0, out) == _lib.ERR_INVALID
     assert lib.sgk_debug_host_transition(0, 6, 255, 4, out) == _lib.ERR_INVALID
     assert b"bad" in lib.sgk_last_error()
+
+
+def test_random_walks_through_the_host_transition_match_the_oracle():
+    """Property test (hypothesis): any action sequence, stepped through the kernels' transition function on the host
+    (state carried in Python), gives the oracle's rewards, terminations and positions."""
+    from hypothesis import given, settings, strategies as st
+
+    lib = _lib.load()
+
+    @settings(max_examples=150, deadline=None)
+    @given(env_name=st.sampled_from(sorted(O.ENV_IDS)), actions=st.lists(st.integers(0, 3), min_size=1, max_size=120))
+    def run(env_name, actions):
+        env_id = O.ENV_IDS[env_name]
+        e = O.EnvBatch(env_name, 1)
+        dims = (ctypes.c_int32 * 4)()
+        templ = (ctypes.c_uint8 * 64)()
+        aval = (ctypes.c_uint8 * 64)()
+        _lib.check(lib.sgk_debug_level(env_id, dims, templ, aval))
+        cell, box, frame = dims[2], dims[3], 0
+        out = (ctypes.c_int32 * 5)()
+        for a in actions:
+            r, h, d, _ = e.step(0, a)
+            _lib.check(lib.sgk_debug_host_transition(env_id, cell, box, a, out))
+            cell, box = out[0], out[1]
+            frame += 1
+            done = bool(out[4]) or frame >= 100
+            assert (out[2], out[3], int(done)) == (r, h, d)
+            assert cell == e.field("agent_cell")[0] and box == e.field("box_cell")[0]
+            if d:
+                e.reset(0)
+                cell, box, frame = dims[2], dims[3], 0
+
+    run()
