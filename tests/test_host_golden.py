@@ -262,3 +262,25 @@ def test_discounted_returns_oracle_matches_reference(golden_dir):
         r = np.array([float.fromhex(x) for x in c["rewards"]], dtype=np.float32)
         got = O.discounted_returns(r, c["discount"])
         assert [float(x).hex() for x in got] == c["returns"], (c["discount"], len(r))
+
+
+def test_deepq_train_loop_end_to_end_on_cpu():
+    """`python main.py sokoban deep-q ...` shape: warm-up fills the replay, dqn_learn steps, target syncs, evals run."""
+    args = S.prepare_parser().parse_args(["-S", "5", "-E", "4", "-EE", "2", "-V", "250", "-EV", "1", "-dc", "sokoban", "deep-q",
+                                          "-l", "0.001", "-r", "150", "-s", "30", "-b", "16", "-hd", "32", "-dl", "200"])
+    args.device = "cpu"  # main.py:19-20
+    args.log_dir = None
+    writers = []
+
+    def wf(d):
+        writers.append(S.RecordingWriter(d))
+        return writers[-1]
+
+    agent, hist, ev = S.train(args, env_factory=OracleGridworldEnv, writer_factory=wf)
+    assert isinstance(agent, S.DeepQAgent) and len(agent.replay) == 150
+    tags = [c[1] for c in writers[0].calls]
+    assert tags.count("Train/returns") == 4 and "Train/value_loss" in tags and "Evaluation/returns" in tags
+    assert any(c[0] == "video" for c in writers[0].calls)  # -EV 1: the eval animation (frames from env.render)
+    assert hist["t"] >= 4 and ev["period"] == 2  # eval after episode 1 (1 % 2 == 1) and the final one
+    # the DeepQ schedule starts at 1.0 (no overwrite to 0.0, unlike TabularQAgent) and anneals per step
+    assert agent.epsilon < 1.0
