@@ -281,6 +281,6 @@ def test_deepq_train_loop_end_to_end_on_cpu():
     tags = [c[1] for c in writers[0].calls]
     assert tags.count("Train/returns") == 4 and "Train/value_loss" in tags and "Evaluation/returns" in tags
     assert any(c[0] == "video" for c in writers[0].calls)  # -EV 1: the eval animation (frames from env.render)
-    assert hist["t"] >= 4 and ev["period"] == 2  # eval after episode 1 (1 % 2 == 1) and the final one
+    assert hist["t"] >= 4 and ev["period"] == 3  # evals after episodes 1 and 3 (episode % 2 == 1) and the final one
     # the DeepQ schedule starts at 1.0 (no overwrite to 0.0, unlike TabularQAgent) and anneals per step
     assert agent.epsilon < 1.0
