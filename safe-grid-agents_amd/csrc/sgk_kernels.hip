@@ -522,14 +522,50 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
     const uint64_t ge = a.env_base + (uint64_t)env;
     uint32_t x[4] = {0, 0, 0, 0};
     uint32_t rec = 0;
+    // The loop is instruction-issue bound (no HBM traffic), so it is kept lean: the 2-bit actions are shifted out of one
+    // 32-bit word of the Philox block (a new word every 16 steps, a new block every 64), the step record is packed once
+    // after the loop, and episode ends -- rare -- take a branch instead of predicated bookkeeping on every step.
+    uint32_t w = 0;
+    int last_obs = 0, last_hid = 0, last_done = 0, last_action = 0;
+    const bool auto_reset = (a.flags & SGK_F_AUTO_RESET) != 0;
     for (int32_t k = 0; k < n_steps; ++k) {
-      uint64_t t = a.t + (uint64_t)k;
-      if (k == 0 || (t & 63) == 0)
-        philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)a.seed,
-                      (uint32_t)(a.seed >> 32), x);
-      int action = action_from_block(x, t);
-      step_one<ENV>(R, a, env, valid, action, s, rec, acc);
+      const uint64_t t = a.t + (uint64_t)k;
+      const uint32_t tl = (uint32_t)t;
+      if (k == 0 || (tl & 15u) == 0) {
+        if (k == 0 || (tl & 63u) == 0)
+          philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)a.seed,
+                        (uint32_t)(a.seed >> 32), x);
+        const uint32_t j = (tl >> 4) & 3u;
+        w = (j == 0 ? x[0] : (j == 1 ? x[1] : (j == 2 ? x[2] : x[3]))) >> (2 * (tl & 15u));
+      }
+      const int action = (int)(w & 3u);
+      w >>= 2;
+      last_action = action;
+      if (valid && !s.over) {
+        int r_obs, r_hid, term;
+        transition<ENV>(R, s, action, r_obs, r_hid, term);
+        s.frame += 1;
+        s.ret += r_obs;
+        s.hid += r_hid;
+        last_obs = r_obs;
+        last_hid = r_hid;
+        last_done = 0;
+        if (term || s.frame >= R.max_iterations) {
+          last_done = 1;
+          acc_add(acc, true, s.ret, s.hid);
+          a.last_return[env] = s.ret;
+          a.last_perf[env] = s.hid;
+          a.n_episodes[env] += 1;
+          if (auto_reset) s = initial_state(R);
+          else s.over = 1;
+        }
+      } else {
+        last_obs = 0;
+        last_hid = 0;
+        last_done = valid ? 1 : 0;
+      }
     }
+    rec = pack_rec(last_obs, last_hid, last_done, last_action);
     if (valid) {
       a.state[env] = pack_state(s);
       a.rec[env] = rec;
