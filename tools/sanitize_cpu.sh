@@ -1,0 +1,54 @@
+#!/bin/bash
+# AddressSanitizer + UBSan over the CPU-side C/C++ (the oracle and the product's host-side rule builder). GPU ASan is not
+# available on this pool; the kernels are covered by the bit-exact parity tests instead.
+set -e
+cd "$(dirname "$0")/.."
+T=$(mktemp -d)
+gcc -O1 -g -std=gnu11 -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -shared -fPIC -o $T/liboracle_asan.so oracle/sgk_oracle.c -lpthread -lm
+cat > $T/drv.c <<'C'
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+size_t orc_sizeof(void); int orc_init(void*, int); void orc_reset(void*);
+void orc_rollout(void*, int64_t, uint64_t, uint64_t, uint64_t, int64_t, int, const uint8_t*, int8_t*, int64_t*);
+int orc_rollout_mt(void*, int64_t, uint64_t, uint64_t, uint64_t, int64_t, int, int64_t*, int);
+void orc_metrics_init(int64_t*);
+void* orc_tabq_new(int, double, double, double, int64_t); void orc_tabq_free(void*);
+void orc_tabq_rollout(void*, void**, int64_t, uint64_t, uint64_t, int64_t, int, int64_t*, uint8_t*);
+void orc_discounted_returns(const float*, int, double, float*);
+int orc_render_rgb(const void*, uint8_t*);
+int main(void) {
+  for (int env = 0; env < 3; ++env) {
+    int64_t n = 97; size_t sz = orc_sizeof();
+    char* envs = malloc(sz * n);
+    for (int i = 0; i < n; ++i) { orc_init(envs + i * sz, env); orc_reset(envs + i * sz); }
+    int64_t m[16]; orc_metrics_init(m);
+    int8_t* rec = malloc(4 * n);
+    orc_rollout(envs, n, 5, 77, 0, 333, 1, NULL, rec, m);
+    orc_rollout_mt(envs, n, 5, 77, 333, 200, 1, m, 7);
+    void** ag = malloc(sizeof(void*) * n);
+    for (int i = 0; i < n; ++i) ag[i] = orc_tabq_new(env == 0 ? 25 : env == 1 ? 48 : 36, 0.5, 0.99, 0.05, 300);
+    uint8_t* acts = malloc(400 * n);
+    orc_tabq_rollout(envs, ag, n, 0, 3, 400, env == 2, m, acts);
+    uint8_t rgb[3 * 64]; orc_render_rgb(envs, rgb);
+    for (int i = 0; i < n; ++i) orc_tabq_free(ag[i]);
+    free(ag); free(acts); free(rec); free(envs);
+    printf("oracle env %d: %lld episodes, clean\n", env, (long long)m[4]);
+  }
+  float r[100], out[100]; for (int i = 0; i < 100; ++i) r[i] = (float)(i % 7) - 3; orc_discounted_returns(r, 100, 0.97, out);
+  return 0;
+}
+C
+gcc -O1 -g -fsanitize=address,undefined $T/drv.c -o $T/drv $T/liboracle_asan.so -Wl,-rpath,$T
+ASAN_OPTIONS=detect_leaks=1 $T/drv
+cat > $T/rules.cpp <<'C'
+#include <cstdio>
+#include "sgk_rules.h"
+int main() {
+  for (int env = 0; env < 4; ++env) { SgkRules r; int rc = sgk_build_rules(env, &r); std::printf("rules env %d rc %d, clean\n", env, rc); }
+  return 0;
+}
+C
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -Isafe-grid-agents_amd/csrc $T/rules.cpp safe-grid-agents_amd/csrc/sgk_rules.cpp -o $T/rules
+$T/rules
+rm -rf $T
