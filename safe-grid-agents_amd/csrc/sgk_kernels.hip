@@ -319,7 +319,7 @@ __device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *_
 // (precomputed in LDS: rot[r][b] = templ[(r + b) % NC]) with the agent/box cells of the (at most two,
 // NC >= 16) envs it overlaps poked in from the LDS-staged positions of the neighbouring lanes.
 template <int NC>
-struct CompactLds {
+struct alignas(16) CompactLds {  // rot rows are read with ds_read_b128
   uint8_t rot[NC][16];
   uint8_t pos[WG];
   uint8_t box[WG];
