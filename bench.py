@@ -126,8 +126,12 @@ def main():
 
     rank, local_rank, world = sdist.env_from_torchrun()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    # test-only knobs for exercising the multi-rank control flow on a 1-GPU box: every rank on GPU 0, gloo collectives
+    backend = os.environ.get("SGK_BENCH_BACKEND", "nccl")
+    if os.environ.get("SGK_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
-        sdist.init_process_group("nccl")
+        sdist.init_process_group(backend)
     import torch.distributed as tdist
 
     torch.cuda.set_device(local_rank)
@@ -167,7 +171,7 @@ def main():
     # ------------------------------------------------------------------------------------------------------------------
     kernel_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the step kernels run on
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 

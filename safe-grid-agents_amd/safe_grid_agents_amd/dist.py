@@ -39,7 +39,7 @@ def init_process_group(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
+        if backend == "nccl" and os.environ.get("SGK_BENCH_ONE_DEVICE") != "1":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
