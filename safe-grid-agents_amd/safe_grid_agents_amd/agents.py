@@ -302,9 +302,13 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         return out
 
 
-AGENT_MAP = {  # reference parsing/parse.py:39-48, restricted to the hot-path scope
+from .ppo import PPOCNNAgent, PPOMLPAgent  # noqa: E402  (ppo.py needs the mixins defined above)
+
+AGENT_MAP = {  # reference parsing/parse.py:39-48, restricted to the hot-path scope and its "next" rows
     "random": RandomAgent,
     "single": SingleActionAgent,
     "tabular-q": TabularQAgent,
     "deep-q": DeepQAgent,
+    "ppo-mlp": PPOMLPAgent,
+    "ppo-cnn": PPOCNNAgent,
 }

@@ -75,7 +75,18 @@ def dqn_learn(agent, env, env_state, history, args):
     return (successor, learn_reward, done, info), history
 
 
-LEARN_MAP = {"deep-q": dqn_learn, "tabular-q": tabq_learn}
+def ppo_learn(agent, env, env_state, history, args):
+    """One PPO iteration: gather `rollouts` episodes under the old policy, `epochs` minibatch updates, then make the
+    updated policy the old one (reference learn.py:88-104). Evaluation follows every iteration whose episode counter
+    is a multiple of eval_every; the env_state handed in is returned untouched, as in the reference."""
+    rollout = agent.gather_rollout(env, env_state, history, args)
+    history = agent.learn(*rollout, history, args)
+    agent.sync()
+    eval_next = history["episode"] > 0 and history["episode"] % args.eval_every == 0
+    return env_state, history, eval_next
+
+
+LEARN_MAP = {"deep-q": dqn_learn, "tabular-q": tabq_learn, "ppo-mlp": ppo_learn, "ppo-cnn": ppo_learn}
 
 
 def default_eval(agent, env, eval_history, args):

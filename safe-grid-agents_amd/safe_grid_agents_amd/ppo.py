@@ -1,0 +1,228 @@
+"""PPO agents of the reference: the clipped-surrogate actor-critic with an MLP or a CNN body.
+
+  PPOBaseAgent / PPOMLPAgent / PPOCNNAgent   single-env drop-ins for reference common/agents/policy_base.py:14-203,
+                                             policy_mlp.py:9-43, policy_cnn.py:9-81: same constructor arguments,
+                                             layer creation order (so torch.manual_seed reproduces the reference's
+                                             initial weights), RNG draw order (Categorical.sample per step,
+                                             torch.randint per epoch) and loss arithmetic; a seeded CPU run reproduces
+                                             the reference's own run (tests/golden/train_boat_ppo_*.json).
+  BatchedPPOAgent                            the same algorithm with ONE policy acting in N lockstep envs on the GPU:
+                                             rollouts are gathered by loops.batched_gather_rollout (boards, actions,
+                                             rewards and the discounted-return scan kernel all stay in HBM) and the
+                                             epochs sample minibatches from that device-resident rollout.
+
+The networks are PyTorch-ROCm modules (SURVEY.md 8(f).2 keeps the bodies in torch); the env step, the observation cast
+and get_discounted_returns run in libsgk.so.
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.distributions import Categorical
+
+from .agents import BaseActor, BaseExplorer, BaseLearner, Rollout
+from .metering import track_metrics
+
+def discounted_returns_f32(rewards, discount):
+    """get_discounted_returns (reference policy_base.py:179-186) in the reference's float32 arithmetic: each reward is
+    scaled by float32(discount ** t) and every suffix is summed left to right (Python's sum over float32 scalars).
+    Bit-exact with the reference (tests/golden/discounted_returns.json)."""
+    r = np.asarray(rewards, dtype=np.float32)
+    scale = np.array([discount ** t for t in range(r.shape[0])], dtype=np.float64).astype(np.float32)
+    d = scale * r
+    out = np.empty_like(d)
+    for t in range(d.shape[0]):
+        out[t] = np.cumsum(d[t:], dtype=np.float32)[-1]  # sequential float32 accumulation from d[t]
+    return out
+
+
+class PPOBaseAgent(nn.Module, BaseActor, BaseLearner, BaseExplorer):
+    """Actor-critic PPO with a frozen copy of itself as the behaviour ("old") policy."""
+
+    def __init__(self, env, args):
+        super().__init__()
+        self.action_n = env.action_space.n
+        self.discount = args.discount
+        self.board_shape = tuple(env.observation_space.shape)
+        self.n_input = int(np.prod(self.board_shape))
+        self.device = "cuda:%d" % args.device if isinstance(args.device, int) else args.device
+        self.log_gradients = getattr(args, "log_gradients", False)
+        self.lr = args.lr
+        self.batch_size = args.batch_size
+        self.rollouts = args.rollouts
+        self.epochs = args.epochs
+        self.clipping = args.clipping
+        self.entropy_bonus = args.entropy_bonus
+        self.critic_coeff = args.critic_coeff
+        self.build_ac()
+        self.to(self.device)
+        self.optim = torch.optim.Adam(self.parameters(), self.lr)  # before old_policy exists: current weights only
+        self.old_policy = copy.deepcopy(self)
+        self.sync()
+        self.old_policy.eval()
+
+    # -- acting ------------------------------------------------------------------------------------
+    def _lift(self, state):
+        return torch.as_tensor(np.asarray(state) if not torch.is_tensor(state) else state,
+                               dtype=torch.float32, device=self.device)
+
+    def act(self, state):
+        logits, _ = self(self._lift(state))
+        return logits.argmax(-1).item()
+
+    def policy(self, state):
+        logits, _ = self(state)
+        return Categorical(logits=logits)
+
+    def act_explore(self, state):
+        return self.policy(self._lift(state)).sample().item()
+
+    # -- learning ----------------------------------------------------------------------------------
+    def surrogate_loss(self, s, a, r):
+        """Clipped surrogate + critic MSE - entropy bonus for one minibatch (reference policy_base.py:82-106);
+        returns (loss, policy_loss, value_loss, entropy)."""
+        logits, values = self(s)
+        values = values.reshape(-1)
+        current = Categorical(logits=logits)
+        advantage = r - values
+        advantage = (advantage - advantage.mean()) / advantage.std()
+        with torch.no_grad():
+            old_logits, _ = self.old_policy(s)
+            old_log_prob = Categorical(logits=old_logits).log_prob(a)
+        ratio = torch.exp(current.log_prob(a) - old_log_prob)
+        entropy = current.entropy().mean()
+        value_loss = nn.functional.mse_loss(values, r)
+        clipped = ratio.clamp(1 - self.clipping, 1 + self.clipping)
+        policy_loss = -torch.min(advantage * ratio, advantage * clipped).mean()
+        loss = policy_loss + self.critic_coeff * value_loss - self.entropy_bonus * entropy
+        return loss, policy_loss, value_loss, entropy
+
+    def _epoch(self, s, a, r, history):
+        loss, policy_loss, value_loss, entropy = self.surrogate_loss(s, a, r)
+        writer, t_learn = history["writer"], history["t_learn"]
+        writer.add_scalar("Train/policy_loss", policy_loss.item(), t_learn)
+        writer.add_scalar("Train/value_loss", value_loss.item(), t_learn)
+        writer.add_scalar("Train/policy_entropy", entropy, t_learn)
+        self.optim.zero_grad()
+        loss.backward()
+        if self.log_gradients:
+            for name, param in self.named_parameters():
+                if param.grad is not None:
+                    writer.add_histogram(name, param.grad.clone().cpu().data.numpy(), history["t"])
+        self.optim.step()
+        history["t_learn"] += 1
+
+    def learn(self, states, actions, rewards, returns, history, args):
+        """`epochs` minibatch steps on the gathered rollouts; minibatch rows are drawn with replacement by
+        torch.randint on the CPU generator (reference policy_base.py:64-131). Rollouts of different lengths are
+        concatenated (the reference can only stack equal-length ones)."""
+        flat_states = np.concatenate([np.asarray(ep, dtype=np.float32).reshape((len(ep),) + self.board_shape)
+                                      for ep in states])
+        s_all = torch.as_tensor(flat_states, device=self.device)
+        a_all = torch.as_tensor(np.concatenate([np.asarray(ep, dtype=np.int64) for ep in actions]), device=self.device)
+        r_all = torch.as_tensor(np.concatenate([np.asarray(ep, dtype=np.float32) for ep in returns]), device=self.device)
+        n_rows = s_all.shape[0]
+        for _ in range(self.epochs):
+            rows = torch.randint(n_rows, size=(self.batch_size,), dtype=torch.long)
+            rows = rows.to(s_all.device)
+            self._epoch(s_all[rows], a_all[rows], r_all[rows], history)
+        return history
+
+    def gather_rollout(self, env, env_state, history, args):
+        """`rollouts` whole episodes under the old policy (reference policy_base.py:133-177)."""
+        state = env_state[0]
+        rollout = Rollout(states=[], actions=[], rewards=[], returns=[])
+        for index in range(self.rollouts):
+            states, actions, rewards = [], [], []
+            done = False
+            while not done:
+                with torch.no_grad():
+                    action = self.old_policy.act_explore(state)
+                successor, reward, done, info = env.step(action)
+                if args.cheat:
+                    reward = info["hidden_reward"]
+                    try:
+                        action = info["extra_observations"]["actual_actions"]
+                    except KeyError:
+                        pass
+                states.append(state)
+                actions.append(action)
+                rewards.append(float(reward))
+                state = successor
+                history["t"] += 1
+            if index:
+                history["episode"] += 1  # train() already counted the first one
+            history = track_metrics(history, env)
+            rollout.states.append(states)
+            rollout.actions.append(actions)
+            rollout.rewards.append(rewards)
+            rollout.returns.append(self.get_discounted_returns(rewards))
+            state = env.reset()
+        return rollout
+
+    def get_discounted_returns(self, rewards):
+        return discounted_returns_f32(rewards, self.discount)
+
+    def sync(self):
+        """Copy the current weights into the old policy."""
+        own = {k: v for k, v in self.state_dict().items() if not k.startswith("old_")}
+        self.old_policy.load_state_dict(own)
+
+    def build_ac(self):
+        raise NotImplementedError
+
+class PPOMLPAgent(PPOBaseAgent):
+    """MLP trunk of n_layers x n_hidden ReLU units, linear actor and critic heads (reference policy_mlp.py)."""
+
+    def __init__(self, env, args):
+        self.n_layers = args.n_layers
+        self.n_hidden = args.n_hidden
+        super().__init__(env, args)
+
+    def build_ac(self):
+        def block(n_in):
+            return nn.Sequential(nn.Linear(n_in, self.n_hidden), nn.ReLU())
+
+        first = block(self.n_input)
+        hidden = nn.Sequential(*[block(self.n_hidden) for _ in range(self.n_layers - 1)])
+        self.network = nn.Sequential(first, hidden)
+        self.actor = nn.Linear(self.n_hidden, int(self.action_n))
+        self.critic = nn.Linear(self.n_hidden, 1)
+
+    def forward(self, x):
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.device)
+        x = x.reshape(1, -1) if x.dim() <= 2 else x.reshape(x.shape[0], -1)
+        trunk = self.network(x)
+        return self.actor(trunk), self.critic(trunk)
+
+class PPOCNNAgent(PPOBaseAgent):
+    """3x3 conv trunk with a 1x1 residual bottleneck, conv + linear actor and critic heads (reference policy_cnn.py)."""
+
+    def __init__(self, env, args):
+        self.n_channels = args.n_channels
+        self.n_layers = args.n_layers
+        super().__init__(env, args)
+
+    def build_ac(self):
+        ch, (in_ch, height, width) = self.n_channels, self.board_shape
+
+        def conv3(n_in):
+            return nn.Sequential(nn.Conv2d(n_in, ch, kernel_size=3, stride=1, padding=1), nn.ReLU())
+
+        first = conv3(in_ch)
+        hidden = nn.Sequential(*[conv3(ch) for _ in range(self.n_layers - 1)])
+        self.network = nn.Sequential(first, hidden)
+        self.bottleneck = nn.Conv2d(in_ch, ch, kernel_size=1, stride=1)
+        self.actor_cnn = conv3(ch)
+        self.actor_linear = nn.Linear(ch * height * width, int(self.action_n))
+        self.critic_cnn = conv3(ch)
+        self.critic_linear = nn.Linear(ch * height * width, 1)
+
+    def forward(self, x):
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        trunk = self.network(x) + self.bottleneck(x)
+        actor = self.actor_linear(self.actor_cnn(trunk).flatten(1))
+        critic = self.critic_linear(self.critic_cnn(trunk).flatten(1))
+        return actor, critic

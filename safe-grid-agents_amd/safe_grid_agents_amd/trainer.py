@@ -34,6 +34,18 @@ _CORE_FLAGS = [
 _LR = ("lr", "l", dict(type=float, required=True))
 _EPS = ("epsilon", "e", dict(type=float, default=0.01))
 _ANNEAL = ("epsilon-anneal", "dl", dict(type=int, default=100000))
+_BATCH = ("batch-size", "b", dict(type=int, default=64))
+_LAYERS = ("n-layers", "ls", dict(type=int, default=2))
+_DEVICE = ("device", "dv", dict(type=int, default=0))
+_GRADLOG = ("log-gradients", "lg", dict(action="store_true"))
+_PPO_FLAGS = [_LR,
+              ("rollouts", "r", dict(type=int, required=True)),
+              ("epochs", "e", dict(type=int, required=True)),
+              _BATCH,
+              ("clipping", "c", dict(type=float, default=0.2)),
+              ("critic-coeff", "cc", dict(type=float, default=1.0)),
+              ("entropy-bonus", "eb", dict(type=float, default=0.01)),
+              _LAYERS]
 _AGENT_FLAGS = {
     "random": [],
     "single": [("action", "a", dict(type=int, default=0))],
@@ -46,6 +58,8 @@ _AGENT_FLAGS = {
                ("batch-size", "b", dict(type=int, default=64)),
                ("device", "dv", dict(type=int, default=0)),
                ("log-gradients", "lg", dict(action="store_true"))],
+    "ppo-mlp": _PPO_FLAGS + [("n-hidden", "hd", dict(type=int, default=100)), _DEVICE, _GRADLOG],
+    "ppo-cnn": [("n-channels", "ch", dict(type=int, default=5))] + _PPO_FLAGS + [_DEVICE, _GRADLOG],
 }
 
 

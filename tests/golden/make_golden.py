@@ -151,6 +151,64 @@ def golden_train(name, argv):
     })
 
 
+def golden_train_ppo(name, argv):
+    """The reference's train(args) with a PPO agent (policy_base.py / policy_mlp.py / policy_cnn.py, learn.py:88-104)
+    on the CPU: every writer call (losses as hex floats), every env action, and the final weights."""
+    import warnings
+
+    import train as ref_train
+    from safe_grid_agents.parsing import prepare_parser
+    import safe_grid_agents.common.agents.policy_base as pb
+
+    global _PARSER
+    if _PARSER is None:
+        _PARSER = prepare_parser()
+    args = _PARSER.parse_args(argv)
+    args.device = "cpu"
+    args.log_dir = "unused"
+    captured = {}
+    orig_init = pb.PPOBaseAgent.__init__
+
+    def spy_init(self, env, a):
+        orig_init(self, env, a)
+        captured.setdefault("agent", self)
+
+    pb.PPOBaseAgent.__init__ = spy_init
+    writers = []
+    orig_writer = sys.modules["tensorboardX"].SummaryWriter
+
+    class W(RecordingWriter):
+        def __init__(self, log_dir=None):
+            super().__init__(log_dir)
+            writers.append(self)
+
+    ref_train.SummaryWriter = W
+    del _made_envs[:]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)  # multi-threaded conv backward reduces in a thread-count-dependent order
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # torch.tensor(tensor) copy-construct warnings (policy_mlp.py:32)
+            ref_train.train(args)
+    finally:
+        torch.set_num_threads(threads)
+        pb.PPOBaseAgent.__init__ = orig_init
+        ref_train.SummaryWriter = orig_writer
+    agent = captured["agent"]
+    weights = {k: [float(x).hex() for x in v.detach().double().flatten()[:8].tolist()] + [float(v.detach().double().sum()).hex()]
+               for k, v in agent.state_dict().items() if not k.startswith("old_")}
+    calls = [c for c in writers[0].calls if c[0] != "text"]
+    _dump(name, {
+        "argv": argv,
+        "args": {k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool, type(None)))},
+        "writer_calls": calls,
+        "actions": [int(a) for a in _made_envs[0].actions_log],
+        "final_weights_head8_and_sum": weights,
+        "torch_next_randint": int(torch.randint(1 << 30, (1,)).item()),
+        "torch_version": torch.__version__,
+    })
+
+
 def golden_epsilon():
     from safe_grid_agents.common.agents.value import TabularQAgent
 
@@ -320,6 +378,12 @@ def main():
     golden_train("train_boat_tabq_seed3_video.json",
                  ["-S", "3", "-E", "12", "-EE", "5", "-V", "120", "-EV", "2", "boat", "tabular-q", "-l", ".25", "-e", "0.2",
                   "-dl", "500"])
+    golden_train_ppo("train_boat_ppo_mlp_seed5.json",
+                     ["-S", "5", "-E", "4", "-EE", "3", "-V", "120", "-EV", "0", "boat", "ppo-mlp", "-l", "0.001", "-r", "2",
+                      "-e", "5", "-b", "32", "-hd", "24"])
+    golden_train_ppo("train_boat_ppo_cnn_seed9_cheat.json",
+                     ["-S", "9", "-E", "3", "-EE", "2", "-V", "110", "-EV", "0", "-C", "-D", "0.9", "boat", "ppo-cnn", "-l", "0.002",
+                      "-r", "3", "-e", "4", "-b", "16", "-ch", "3", "-c", "0.1", "-eb", "0.02", "-cc", "0.5"])
     # the reference tree must be left untouched
     leaked = [os.path.join(d, f) for d, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
     assert not leaked, leaked

@@ -284,3 +284,98 @@ def test_deepq_train_loop_end_to_end_on_cpu():
     assert hist["t"] >= 4 and ev["period"] == 3  # evals after episodes 1 and 3 (episode % 2 == 1) and the final one
     # the DeepQ schedule starts at 1.0 (no overwrite to 0.0, unlike TabularQAgent) and anneals per step
     assert agent.epsilon < 1.0
+
+
+# ---- PPO: reference policy_base.py / policy_mlp.py / policy_cnn.py / learn.py:88-104 ---------------
+def test_discounted_returns_host_matches_reference(golden_dir):
+    for c in _load(golden_dir, "discounted_returns.json"):
+        r = np.array([float.fromhex(x) for x in c["rewards"]], dtype=np.float32)
+        got = S.discounted_returns_f32(r, c["discount"])
+        assert got.dtype == np.float32 and [float(x).hex() for x in got] == c["returns"], (c["discount"], len(r))
+
+
+def _same(a, b, rel=2e-5, tol=1e-6):
+    """Equality of recorded values: everything exact (bit-for-bit on the machine that generated the fixtures), except
+    that hex-encoded floats may differ by float32 rounding (rel 2e-5) where another CPU's BLAS/conv kernels round
+    differently -- the tolerance for the floating-point (fp32) part of the path."""
+    if a == b:
+        return True
+    if isinstance(a, str) and isinstance(b, str):
+        try:
+            x, y = float.fromhex(a), float.fromhex(b)
+        except ValueError:
+            return False
+        return abs(x - y) <= tol + rel * max(abs(x), abs(y))
+    if isinstance(a, (list, tuple)) and isinstance(b, (list, tuple)):
+        return len(a) == len(b) and all(_same(p, q, rel, tol) for p, q in zip(a, b))
+    if isinstance(a, dict) and isinstance(b, dict):
+        return a.keys() == b.keys() and all(_same(a[k], b[k], rel, tol) for k in a)
+    return False
+
+
+def run_ppo_golden(g, env_factory):
+    import torch
+
+    args = S.prepare_parser().parse_args(g["argv"])
+    args.device = "cpu"
+    args.log_dir = "unused"
+    writers, envs = [], []
+
+    def writer_factory(log_dir):
+        writers.append(S.RecordingWriter(log_dir))
+        return writers[-1]
+
+    def factory(name):
+        envs.append(env_factory(name))
+        return envs[-1]
+
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)  # as when the fixture was generated: conv backward's reduction order depends on it
+    try:
+        agent, history, eval_history = S.train(args, env_factory=factory, writer_factory=writer_factory)
+    finally:
+        torch.set_num_threads(threads)
+    weights = {k: [float(x).hex() for x in v.detach().double().flatten()[:8].tolist()] + [float(v.detach().double().sum()).hex()]
+               for k, v in agent.state_dict().items() if not k.startswith("old_")}
+    return {"args": args, "calls": [c for c in writers[0].calls if c[0] != "text"], "weights": weights, "agent": agent,
+            "env": envs[0], "next_randint": int(torch.randint(1 << 30, (1,)).item()), "history": history}
+
+
+@pytest.mark.parametrize("name", ["train_boat_ppo_mlp_seed5.json", "train_boat_ppo_cnn_seed9_cheat.json"])
+def test_ppo_train_reproduces_reference_run(golden_dir, name):
+    """Seeded CPU run of train() with the PPO agents == the reference's own run: same actions (torch Categorical draws),
+    same losses/entropies written per epoch, same final weights, same number of torch RNG draws."""
+    import torch
+
+    g = _load(golden_dir, name)
+    if g["torch_version"] != torch.__version__:
+        pytest.skip("fixture was generated with torch %s" % g["torch_version"])
+    out = run_ppo_golden(g, OracleGridworldEnv)
+    for k, v in g["args"].items():
+        if k not in ("tune", "log_dir", "device"):
+            assert getattr(out["args"], k) == v, k
+    assert out["env"].actions_log == g["actions"]
+    assert len(out["calls"]) == len(g["writer_calls"])
+    for i, (a, b) in enumerate(zip(out["calls"], g["writer_calls"])):
+        assert _same(a, b), (i, a, b)
+    assert _same(out["weights"], g["final_weights_head8_and_sum"])
+    assert out["next_randint"] == g["torch_next_randint"]
+
+
+def test_ppo_handles_ragged_rollouts_and_state_dict_names():
+    """IslandNavigation episodes differ in length (the reference's learn() cannot stack those); the parameter names are
+    the reference's (network.0.0.weight, actor.weight, ... and the old_policy.* copies)."""
+    args = S.prepare_parser().parse_args(["-S", "2", "-E", "2", "-EE", "5", "-V", "60", "-EV", "0", "island", "ppo-mlp", "-l", "0.01",
+                                          "-r", "3", "-e", "2", "-b", "8", "-hd", "16"])
+    args.device = "cpu"
+    agent, hist, ev = S.train(args, env_factory=OracleGridworldEnv, writer_factory=S.RecordingWriter)
+    names = list(agent.state_dict().keys())
+    assert names[:8] == ["network.0.0.weight", "network.0.0.bias", "network.1.0.0.weight", "network.1.0.0.bias",
+                         "actor.weight", "actor.bias", "critic.weight", "critic.bias"]
+    assert all(n.startswith("old_policy.") for n in names[8:]) and len(names) == 16
+    assert hist["episode"] == 2 + 2 * 2 and hist["t_learn"] == 4  # r-1 extra episodes per iteration, e epochs each
+    cnn = S.PPOCNNAgent(_fake_env(shape=(1, 6, 8)), args.__class__(**{**vars(args), "n_channels": 4}))
+    assert [n for n in cnn.state_dict() if not n.startswith("old_")] == [
+        "network.0.0.weight", "network.0.0.bias", "network.1.0.0.weight", "network.1.0.0.bias", "bottleneck.weight",
+        "bottleneck.bias", "actor_cnn.0.weight", "actor_cnn.0.bias", "actor_linear.weight", "actor_linear.bias",
+        "critic_cnn.0.weight", "critic_cnn.0.bias", "critic_linear.weight", "critic_linear.bias"]
