@@ -227,6 +227,20 @@ SGK_API int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon,
                            const double *epsilon_dev, const uint64_t *draw_index_dev, uint8_t *actions_out_dev,
                            float *scores_out_dev);
 
+/* ---- PPOBaseAgent.act_explore for every env (reference policy_base.py:54-64: Categorical(logits).sample()) ------------- */
+/* logits_dev: float32 [n_envs][4], 16-byte aligned (the actor head of any network: PPOMLPAgent policy_mlp.py:29-43,
+ * PPOCNNAgent policy_cnn.py:66-81). Inverse-CDF draw with the counter RNG (Philox stream 3, keyed by global env index and
+ * draw_index; *draw_index_dev overrides the scalar when non-NULL): weights e_i = expf(l_i - max l) in float32, action = the
+ * first i with u * sum(e) < e_0 + .. + e_i. Greedy PPOBaseAgent.act (policy_base.py:47-52) is sgk_epsilon_greedy with
+ * epsilon = 0. */
+SGK_API int sgk_categorical_sample(sgk_env *h, const float *logits_dev, uint64_t draw_index, const uint64_t *draw_index_dev,
+                                   uint8_t *actions_out_dev);
+/* PPOMLPAgent with the default topology (n_layers = 2, n_hidden = 100): trunk + actor head forward + the draw above in one
+ * launch, straight from the int8 boards. w: w1t/b1 = network[0][0], w2/b2 = network[1][0][0], w3t/b3 = actor (layouts as
+ * for sgk_policy_act). logits_out_dev: float32 [n_envs][4] or NULL. */
+SGK_API int sgk_policy_sample(sgk_env *h, const sgk_mlp_weights *w, uint64_t draw_index, const uint64_t *draw_index_dev,
+                              uint8_t *actions_out_dev, float *logits_out_dev);
+
 /* ---- PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186), batched ------------------------------ */
 /* rewards_dev / returns_dev: float32 [n_trajectories][t_max] row-major; lengths_dev: int32 [n_trajectories] or NULL
  * (every trajectory t_max long). returns[i][t] = sum_{k >= t} float32(discount ** k) * rewards[i][k], accumulated left

@@ -67,6 +67,8 @@ def lib():
         L.orc_rollout_mt.restype = ctypes.c_int
         L.orc_eps_greedy.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
         L.orc_eps_greedy.restype = ctypes.c_int
+        L.orc_categorical_sample.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        L.orc_categorical_sample.restype = ctypes.c_int
         L.orc_discounted_returns.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
         L.orc_tabq_new.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int64]
         L.orc_tabq_new.restype = ctypes.c_void_p
@@ -215,6 +217,19 @@ def eps_greedy(scores, eps, seed, env_begin, draw):
     L = lib()
     return np.array([L.orc_eps_greedy(sc[i].ctypes.data, float(eps), seed, env_begin + i, draw) for i in range(sc.shape[0])],
                     dtype=np.uint8)
+
+
+def categorical_sample(logits, seed, env_begin, draw):
+    """(actions uint8 [n], margins float64 [n]) of orc_categorical_sample for envs env_begin .. env_begin + n - 1."""
+    lg = np.ascontiguousarray(logits, dtype=np.float32)
+    L = lib()
+    margin = ctypes.c_double()
+    acts = np.empty(lg.shape[0], dtype=np.uint8)
+    margins = np.empty(lg.shape[0], dtype=np.float64)
+    for i in range(lg.shape[0]):
+        acts[i] = L.orc_categorical_sample(lg[i].ctypes.data, seed, env_begin + i, draw, ctypes.byref(margin))
+        margins[i] = margin.value
+    return acts, margins
 
 
 def discounted_returns(rewards, discount):

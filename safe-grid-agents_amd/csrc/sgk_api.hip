@@ -551,7 +551,16 @@ int sgk_epsilon_greedy_ex(sgk_env *h, const float *scores_dev, double epsilon, u
   SGK_CHECK_HANDLE(h);
   if (!scores_dev || !actions_out_dev) return fail(SGK_ERR_INVALID, "NULL argument");
   if (((uintptr_t)scores_dev & 15u) != 0) return fail(SGK_ERR_INVALID, "scores_dev must be 16-byte aligned");
-  SGK_HIP(sgk::launch_eps_greedy(h->sh, scores_dev, actions_out_dev, epsilon, draw_index, epsilon_dev, draw_index_dev, h->stream));
+  SGK_HIP(sgk::launch_eps_greedy(h->sh, 0, scores_dev, actions_out_dev, epsilon, draw_index, epsilon_dev, draw_index_dev, h->stream));
+  return SGK_OK;
+}
+
+int sgk_categorical_sample(sgk_env *h, const float *logits_dev, uint64_t draw_index, const uint64_t *draw_index_dev,
+                           uint8_t *actions_out_dev) {
+  SGK_CHECK_HANDLE(h);
+  if (!logits_dev || !actions_out_dev) return fail(SGK_ERR_INVALID, "NULL argument");
+  if (((uintptr_t)logits_dev & 15u) != 0) return fail(SGK_ERR_INVALID, "logits_dev must be 16-byte aligned");
+  SGK_HIP(sgk::launch_eps_greedy(h->sh, 1, logits_dev, actions_out_dev, 0.0, draw_index, nullptr, draw_index_dev, h->stream));
   return SGK_OK;
 }
 
@@ -567,7 +576,20 @@ int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon, uint64_
   if (w->n_hidden != 100) return fail(SGK_ERR_INVALID, "sgk_policy_act is built for n_hidden = 100 (the reference default)");
   if (scores_out_dev && ((uintptr_t)scores_out_dev & 15u)) return fail(SGK_ERR_INVALID, "scores_out_dev must be 16-byte aligned");
   sgk::PolicyWeights pw{w->w1t, w->b1, w->w2, w->b2, w->w3t, w->b3, w->n_hidden};
-  SGK_HIP(sgk::launch_policy_act(h->sh, pw, actions_out_dev, scores_out_dev, epsilon, draw_index, epsilon_dev, draw_index_dev,
+  SGK_HIP(sgk::launch_policy_act(h->sh, 0, pw, actions_out_dev, scores_out_dev, epsilon, draw_index, epsilon_dev, draw_index_dev,
+                                 h->stream));
+  return SGK_OK;
+}
+
+int sgk_policy_sample(sgk_env *h, const sgk_mlp_weights *w, uint64_t draw_index, const uint64_t *draw_index_dev,
+                      uint8_t *actions_out_dev, float *logits_out_dev) {
+  SGK_CHECK_HANDLE(h);
+  if (!w || !actions_out_dev || !w->w1t || !w->b1 || !w->w2 || !w->b2 || !w->w3t || !w->b3)
+    return fail(SGK_ERR_INVALID, "NULL argument");
+  if (w->n_hidden != 100) return fail(SGK_ERR_INVALID, "sgk_policy_sample is built for n_hidden = 100 (the reference default)");
+  if (logits_out_dev && ((uintptr_t)logits_out_dev & 15u)) return fail(SGK_ERR_INVALID, "logits_out_dev must be 16-byte aligned");
+  sgk::PolicyWeights pw{w->w1t, w->b1, w->w2, w->b2, w->w3t, w->b3, w->n_hidden};
+  SGK_HIP(sgk::launch_policy_act(h->sh, 1, pw, actions_out_dev, logits_out_dev, 0.0, draw_index, nullptr, draw_index_dev,
                                  h->stream));
   return SGK_OK;
 }

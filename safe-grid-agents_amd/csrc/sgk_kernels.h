@@ -52,9 +52,10 @@ struct PolicyWeights {
   const float *w1t, *b1, *w2, *b2, *w3t, *b3;
   int n_hidden;
 };
-hipError_t launch_policy_act(const Shard &sh, const PolicyWeights &w, uint8_t *actions, float *scores, double eps, uint64_t draw,
-                             const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
-hipError_t launch_eps_greedy(const Shard &sh, const float *scores, uint8_t *actions, double eps, uint64_t draw,
+// mode 0: epsilon-greedy over the scores (DeepQAgent.act_explore); mode 1: Categorical(logits = scores).sample() (PPO)
+hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, uint8_t *actions, float *scores, double eps,
+                             uint64_t draw, const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
+hipError_t launch_eps_greedy(const Shard &sh, int mode, const float *scores, uint8_t *actions, double eps, uint64_t draw,
                              const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
 hipError_t launch_discounted_returns(const Shard &sh, const float *rewards, const int32_t *lengths, const float *gamma_pow,
                                      float *returns, int64_t n, int t_max, hipStream_t st);

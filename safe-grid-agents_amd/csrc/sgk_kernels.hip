@@ -651,11 +651,40 @@ __global__ __launch_bounds__(WG) void render_rgb_kernel(const SgkRules *__restri
 
 __device__ __forceinline__ double uniform53(uint32_t a, uint32_t b);
 
-// DeepQAgent.act_explore for a batch (reference value.py:94-111): greedy = argmax of the 4 action scores, then a draw
-// from Categorical(eps/4 everywhere + (1 - eps) on the greedy action) = with probability eps a uniform action (the greedy
-// one included), else the greedy one. One lane per env: a 16-byte load, a Philox block (stream 2: ctr = {env_lo, env_hi,
-// draw index, 2}; u = numpy's 53-bit uniform of x0,x1; uniform action = x2 & 3), a byte store. Replaces six PyTorch kernels
-// (argmax, rand, lt, randint, where, cast) per lockstep step.
+// The action of one env from its four scores, with the counter RNG keyed by the global env index `ge` and a draw index.
+// MODE 0 -- DeepQAgent.act_explore (reference value.py:94-111): greedy = argmax of the 4 action scores, then a draw from
+//   Categorical(eps/4 everywhere + (1 - eps) on the greedy action) = with probability eps a uniform action (the greedy one
+//   included), else the greedy one. Philox stream 2: ctr = {env_lo, env_hi, draw, 2}; u = numpy's 53-bit uniform of x0,x1;
+//   uniform action = x2 & 3.
+// MODE 1 -- PPOBaseAgent.act_explore (reference policy_base.py:54-64): Categorical(logits = scores).sample(), by inverse
+//   CDF on the unnormalised float32 weights e_i = expf(s_i - max s): action = first i with u * (e_0+..+e_3) < e_0+..+e_i
+//   (partial sums in float32 left to right, the comparison in double). Philox stream 3, u from x0,x1 as above.
+template <int MODE>
+__device__ __forceinline__ int pick_action(float s0, float s1, float s2, float s3, uint64_t ge, uint64_t draw, uint64_t seed,
+                                           double eps) {
+  uint32_t x[4];
+  philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)draw, MODE == 0 ? 2u : 3u, (uint32_t)seed,
+                (uint32_t)(seed >> 32), x);
+  const double u = uniform53(x[0], x[1]);
+  if (MODE == 0) {
+    int best = 0;
+    float bv = s0;
+    if (s1 > bv) { bv = s1; best = 1; }
+    if (s2 > bv) { bv = s2; best = 2; }
+    if (s3 > bv) { bv = s3; best = 3; }
+    if (u < eps) best = (int)(x[2] & 3u);
+    return best;
+  }
+  const float m = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+  const float e0 = expf(__fsub_rn(s0, m)), e1 = expf(__fsub_rn(s1, m)), e2 = expf(__fsub_rn(s2, m)), e3 = expf(__fsub_rn(s3, m));
+  const float c1 = __fadd_rn(e0, e1), c2 = __fadd_rn(c1, e2), c3 = __fadd_rn(c2, e3);
+  const double target = __dmul_rn(u, (double)c3);
+  return target < (double)e0 ? 0 : (target < (double)c1 ? 1 : (target < (double)c2 ? 2 : 3));
+}
+
+// One lane per env: a 16-byte load of the scores, a Philox block, a byte store. Replaces six PyTorch kernels (argmax,
+// rand, lt, randint, where, cast -- or softmax, multinomial, cast) per lockstep step.
+template <int MODE>
 __global__ __launch_bounds__(WG) void eps_greedy_kernel(const float4 *__restrict__ scores, uint8_t *__restrict__ actions,
                                                         int64_t n, double eps, uint64_t seed, uint64_t env_base,
                                                         uint64_t draw, const double *__restrict__ eps_ptr,
@@ -663,17 +692,8 @@ __global__ __launch_bounds__(WG) void eps_greedy_kernel(const float4 *__restrict
   if (eps_ptr) eps = *eps_ptr;     // device-resident scalars: the launch can be replayed from a graph
   if (draw_ptr) draw = *draw_ptr;
   for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < n; env += (int64_t)gridDim.x * WG) {
-    float4 q = scores[env];
-    int best = 0;
-    float bv = q.x;
-    if (q.y > bv) { bv = q.y; best = 1; }
-    if (q.z > bv) { bv = q.z; best = 2; }
-    if (q.w > bv) { bv = q.w; best = 3; }
-    const uint64_t ge = env_base + (uint64_t)env;
-    uint32_t x[4];
-    philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)draw, 2u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-    if (uniform53(x[0], x[1]) < eps) best = (int)(x[2] & 3u);
-    actions[env] = (uint8_t)best;
+    const float4 q = scores[env];
+    actions[env] = (uint8_t)pick_action<MODE>(q.x, q.y, q.z, q.w, env_base + (uint64_t)env, draw, seed, eps);
   }
 }
 
@@ -690,7 +710,7 @@ __global__ __launch_bounds__(WG) void eps_greedy_kernel(const float4 *__restrict
 // per CU share the LDS broadcast bandwidth instead of four)
 constexpr int PWG = 128;
 
-template <int K0, int H>
+template <int K0, int H, int MODE>
 __global__ __launch_bounds__(PWG) __attribute__((amdgpu_waves_per_eu(1, 1))) void policy_act_kernel(const int8_t *__restrict__ boards, int pitch, const float *__restrict__ w1t,
                                                         const float *__restrict__ b1, const float *__restrict__ w2,
                                                         const float *__restrict__ b2, const float *__restrict__ w3t,
@@ -775,16 +795,7 @@ __global__ __launch_bounds__(PWG) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     const float s0 = sc.x, s1 = sc.y, s2 = sc.z, s3 = sc.w;
     if (env < n) {
-      int best = 0;
-      float bv = s0;
-      if (s1 > bv) { bv = s1; best = 1; }
-      if (s2 > bv) { bv = s2; best = 2; }
-      if (s3 > bv) { bv = s3; best = 3; }
-      const uint64_t ge = env_base + (uint64_t)env;
-      uint32_t x4[4];
-      philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)draw, 2u, (uint32_t)seed, (uint32_t)(seed >> 32), x4);
-      if (uniform53(x4[0], x4[1]) < eps) best = (int)(x4[2] & 3u);
-      actions[env] = (uint8_t)best;
+      actions[env] = (uint8_t)pick_action<MODE>(s0, s1, s2, s3, env_base + (uint64_t)env, draw, seed, eps);
       if (scores_out) reinterpret_cast<float4 *>(scores_out)[env] = make_float4(s0, s1, s2, s3);
     }
   }
@@ -1272,28 +1283,36 @@ hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_eps_greedy(const Shard &sh, const float *scores, uint8_t *actions, double eps, uint64_t draw,
+hipError_t launch_eps_greedy(const Shard &sh, int mode, const float *scores, uint8_t *actions, double eps, uint64_t draw,
                              const double *eps_dev, const uint64_t *draw_dev, hipStream_t st) {
   (void)hipGetLastError();
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
-  hipLaunchKernelGGL(eps_greedy_kernel, dim3(grid), dim3(WG), 0, st, reinterpret_cast<const float4 *>(scores), actions, sh.n,
-                     eps, sh.seed, sh.env_base, draw, eps_dev, draw_dev);
+  const float4 *sc = reinterpret_cast<const float4 *>(scores);
+  if (mode == 0)
+    eps_greedy_kernel<0><<<dim3(grid), dim3(WG), 0, st>>>(sc, actions, sh.n, eps, sh.seed, sh.env_base, draw, eps_dev, draw_dev);
+  else
+    eps_greedy_kernel<1><<<dim3(grid), dim3(WG), 0, st>>>(sc, actions, sh.n, eps, sh.seed, sh.env_base, draw, eps_dev, draw_dev);
   return hipGetLastError();
 }
 
-hipError_t launch_policy_act(const Shard &sh, const PolicyWeights &w, uint8_t *actions, float *scores, double eps, uint64_t draw,
-                             const double *eps_dev, const uint64_t *draw_dev, hipStream_t st) {
+hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, uint8_t *actions, float *scores, double eps,
+                             uint64_t draw, const double *eps_dev, const uint64_t *draw_dev, hipStream_t st) {
   (void)hipGetLastError();
   int grid = grid_for((sh.n + PWG - 1) / PWG, sh.n_cus * 2);
-#define SGK_POLICY_LAUNCH(K0)                                                                                              \
+#define SGK_POLICY_LAUNCH_M(K0, MODE)                                                                                      \
   do {                                                                                                                     \
     constexpr size_t lds = policy_lds_bytes<K0, 100>();                                                                    \
-    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&policy_act_kernel<K0, 100>),                       \
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&policy_act_kernel<K0, 100, MODE>),                 \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
     if (ae != hipSuccess) return ae;                                                                                       \
-    policy_act_kernel<K0, 100><<<dim3(grid), dim3(PWG), lds, st>>>(sh.boards, sh.pitch, w.w1t, w.b1, w.w2, w.b2, w.w3t, w.b3, \
-                                                                  actions, scores, sh.n, eps, sh.seed, sh.env_base, draw,  \
-                                                                  eps_dev, draw_dev);                                      \
+    policy_act_kernel<K0, 100, MODE><<<dim3(grid), dim3(PWG), lds, st>>>(sh.boards, sh.pitch, w.w1t, w.b1, w.w2, w.b2, w.w3t, \
+                                                                        w.b3, actions, scores, sh.n, eps, sh.seed,         \
+                                                                        sh.env_base, draw, eps_dev, draw_dev);             \
+  } while (0)
+#define SGK_POLICY_LAUNCH(K0)                                                                                              \
+  do {                                                                                                                     \
+    if (mode == 0) SGK_POLICY_LAUNCH_M(K0, 0);                                                                             \
+    else SGK_POLICY_LAUNCH_M(K0, 1);                                                                                       \
   } while (0)
   if (w.n_hidden != 100) return hipErrorInvalidValue;
   switch (sh.n_cells) {
@@ -1303,6 +1322,7 @@ hipError_t launch_policy_act(const Shard &sh, const PolicyWeights &w, uint8_t *a
   default: return hipErrorInvalidValue;
   }
 #undef SGK_POLICY_LAUNCH
+#undef SGK_POLICY_LAUNCH_M
   return hipGetLastError();
 }
 

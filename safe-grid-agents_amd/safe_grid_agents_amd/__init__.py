@@ -5,10 +5,10 @@ include/sgk.h); importing an env without it raises. Nothing here falls back to t
 from . import _lib
 from .agents import (AGENT_MAP, BatchedTabularQAgent, DeepQAgent, Experience, ExperienceBatch, RandomAgent,
                      ReplayBuffer, Rollout, SingleActionAgent, TabularQAgent)
-from .ppo import PPOBaseAgent, PPOCNNAgent, PPOMLPAgent, discounted_returns_f32
+from .ppo import BatchedPPOAgent, PPOBaseAgent, PPOCNNAgent, PPOMLPAgent, discounted_returns_f32
 from .deepq_batched import BatchedDeepQAgent, DeviceReplay
 from .envs import ENV_IDS, ENV_MAP, BatchedGridworldEnv, GridworldEnv, make
-from .loops import (EVAL_MAP, LEARN_MAP, WARMUP_MAP, BatchedRollout, batched_default_eval, batched_gather_rollout, batched_random_rollout, batched_tabq_learn,
+from .loops import (EVAL_MAP, LEARN_MAP, WARMUP_MAP, BatchedRollout, batched_default_eval, batched_gather_rollout, batched_ppo_learn, batched_random_rollout, batched_tabq_learn,
                     default_eval,
                     dqn_learn, dqn_warmup, noop_warmup, ppo_learn, tabq_learn, whiler)
 from .metering import AverageMeter, BatchMetrics, NullWriter, RecordingWriter, make_meters, track_metrics
@@ -19,7 +19,7 @@ __all__ = [
     "make", "GridworldEnv", "BatchedGridworldEnv",
     "RandomAgent", "SingleActionAgent", "TabularQAgent", "DeepQAgent", "BatchedTabularQAgent", "BatchedDeepQAgent", "DeviceReplay",
     "ReplayBuffer", "Experience", "ExperienceBatch", "Rollout",
-    "PPOBaseAgent", "PPOMLPAgent", "PPOCNNAgent", "discounted_returns_f32",
+    "BatchedPPOAgent", "batched_ppo_learn", "PPOBaseAgent", "PPOMLPAgent", "PPOCNNAgent", "discounted_returns_f32",
     "whiler", "tabq_learn", "dqn_learn", "ppo_learn", "default_eval", "dqn_warmup", "noop_warmup",
     "batched_random_rollout", "batched_tabq_learn", "batched_default_eval", "batched_gather_rollout", "BatchedRollout",
     "AverageMeter", "make_meters", "track_metrics", "BatchMetrics", "NullWriter", "RecordingWriter",

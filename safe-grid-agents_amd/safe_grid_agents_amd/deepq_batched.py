@@ -74,6 +74,8 @@ class DeviceReplay:
 
 
 class BatchedDeepQAgent:
+    reads_boards = True  # acts on the materialised cells (batched_default_eval must keep writing them)
+
     def __init__(self, env, args, sgd_steps=1, replay_slices=8):
         import torch
 

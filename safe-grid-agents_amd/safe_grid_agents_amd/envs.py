@@ -313,6 +313,44 @@ class BatchedGridworldEnv:
         self._sync_lib_to_torch()
         return out
 
+    def categorical_sample(self, logits, draw_index, out=None):
+        """PPOBaseAgent.act_explore for every env (reference policy_base.py:54-64): logits float32 [N, 4] -> uint8 actions
+        [N] drawn from Categorical(logits) with the counter RNG. `draw_index`: int or a 1-element int64 device tensor."""
+        import torch
+
+        logits = logits.contiguous()
+        assert logits.dtype == torch.float32 and logits.shape == (self.n_envs, 4) and logits.is_cuda
+        if out is None:
+            out = torch.empty(self.n_envs, dtype=torch.uint8, device=logits.device)
+        draw_p = None
+        if isinstance(draw_index, torch.Tensor):
+            assert draw_index.dtype == torch.int64 and draw_index.is_cuda
+            draw_p, draw_index = ctypes.c_void_p(draw_index.data_ptr()), 0
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_categorical_sample(self._h.ptr, ctypes.c_void_p(logits.data_ptr()), int(draw_index), draw_p,
+                                                   ctypes.c_void_p(out.data_ptr())))
+        self._sync_lib_to_torch()
+        return out
+
+    def policy_sample(self, weights, draw_index, out=None, logits_out=None):
+        """PPOMLPAgent (default topology) trunk + actor forward and the Categorical draw for every env in one HIP launch,
+        straight from the int8 boards. `weights` as for policy_act (w3t / b3 = the actor head)."""
+        import torch
+
+        if out is None:
+            out = torch.empty(self.n_envs, dtype=torch.uint8, device="cuda:%d" % self.device)
+        w = _lib.SgkMlpWeights(*(ctypes.c_void_p(weights[k].data_ptr()) for k in ("w1t", "b1", "w2", "b2", "w3t", "b3")),
+                               int(weights["b1"].numel()))
+        draw_p = None
+        if isinstance(draw_index, torch.Tensor):
+            draw_p, draw_index = ctypes.c_void_p(draw_index.data_ptr()), 0
+        lp = None if logits_out is None else ctypes.c_void_p(logits_out.data_ptr())
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_policy_sample(self._h.ptr, ctypes.byref(w), int(draw_index), draw_p,
+                                              ctypes.c_void_p(out.data_ptr()), lp))
+        self._sync_lib_to_torch()
+        return out
+
     def discounted_returns(self, rewards, discount, lengths=None, out=None):
         """PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186) for a batch: rewards float32
         [n_trajectories, T] on this GPU (lengths int32 [n_trajectories] optional) -> returns of the same shape, with the

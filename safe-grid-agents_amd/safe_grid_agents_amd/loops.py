@@ -176,13 +176,14 @@ def batched_default_eval(agent, env, eval_timesteps):
     Lockstep form: `eval_timesteps - 1` iterations of {step, reset finished envs}, then steps WITHOUT reset until every
     env's current episode has ended (at most `max_iterations` more; finished envs idle, their steps are no-ops).
     No host synchronisation inside the loop. Returns BatchMetrics of the evaluation (metrics are reset first)."""
+    boards = bool(getattr(agent, "reads_boards", False))  # table agents act on the state word; networks need the cells
     env.metrics_reset()
     env.reset()
     for _ in range(max(int(eval_timesteps) - 1, 0)):
-        env.step(agent.act(), auto_reset=False, write_boards=False)
+        env.step(agent.act(), auto_reset=False, write_boards=boards)
         env.reset_done()
     for _ in range(int(env.info.max_iterations)):
-        env.step(agent.act(), auto_reset=False, write_boards=False)
+        env.step(agent.act(), auto_reset=False, write_boards=boards)
     return BatchMetrics(env.metrics())
 
 
@@ -222,6 +223,17 @@ def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None):
     returns = env.discounted_returns(rewards, discount, lengths=lengths)
     env.reset()
     return BatchedRollout(states, actions, rewards, returns, lengths)
+
+
+def batched_ppo_learn(agent, env, history=None, cheat=False):
+    """ppo_learn (reference learn.py:88-104) for a BatchedPPOAgent: one rollout of N episodes (one per env) under the old
+    policy, the epochs, then the sync. Returns the BatchMetrics of the gathered episodes."""
+    env.metrics_reset()
+    rollout = agent.gather_rollout(cheat=cheat)
+    bm = BatchMetrics(env.metrics())
+    agent.learn(rollout, history)
+    agent.sync()
+    return bm
 
 
 def batched_tabq_learn(agent, env, n_steps, cheat=False, fused=True):

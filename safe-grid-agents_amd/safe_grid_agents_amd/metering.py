@@ -121,6 +121,8 @@ class RecordingWriter(NullWriter):
             return bool(v)
         if isinstance(v, (int, np.integer)):
             return int(v)
+        if hasattr(v, "detach"):  # a 0-d torch tensor (PPO logs its entropy as one, policy_base.py:117-119)
+            v = v.detach()
         return float(v).hex()
 
     def add_scalar(self, tag, value, step):

@@ -226,3 +226,107 @@ class PPOCNNAgent(PPOBaseAgent):
         actor = self.actor_linear(self.actor_cnn(trunk).flatten(1))
         critic = self.critic_linear(self.critic_cnn(trunk).flatten(1))
         return actor, critic
+
+
+class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
+    """The same PPO with ONE policy acting in all N envs of a BatchedGridworldEnv: a rollout is one whole episode per env
+    (N episodes gathered in lockstep, loops.batched_gather_rollout), the epochs draw minibatches from that rollout where
+    it lies in HBM, and acting under the old policy is one HIP launch per lockstep step:
+
+      * ppo-mlp with the default topology (n_layers 2, n_hidden 100): sgk_policy_sample -- trunk + actor forward from the
+        int8 boards and the Categorical draw fused (no observation tensor, no softmax/multinomial kernels);
+      * any other body (ppo-cnn, other widths): the torch forward on the float32 observation (sgk_obs_f32) followed by
+        sgk_categorical_sample on the logits.
+
+    The action stream comes from the counter RNG (keyed by global env index and the agent's draw counter), so it does not
+    depend on how the envs are sharded over GPUs. `net` is a PPOMLPAgent / PPOCNNAgent on the env's device: its
+    surrogate_loss / sync / old_policy are used as they are."""
+
+    reads_boards = True  # acts on the materialised cells (batched_default_eval must keep writing them)
+
+    def __init__(self, env, args, body="mlp"):
+        import types
+
+        cfg = types.SimpleNamespace(**vars(args))
+        cfg.device = "cuda:%d" % env.device
+        self.env = env
+        self.device = cfg.device
+        self.body = body
+        self.net = (PPOMLPAgent if body == "mlp" else PPOCNNAgent)(env, cfg)
+        self.discount = float(args.discount)
+        self.epochs, self.batch_size = int(args.epochs), int(args.batch_size)
+        self.action_n = env.action_space.n
+        self.draws = 0  # lockstep act_explore calls so far == the RNG draw index
+        self._actions = torch.empty(env.n_envs, dtype=torch.uint8, device=self.device)
+        self._obs = torch.empty((env.n_envs, env.n_cells), dtype=torch.float32, device=self.device)
+        self.fused_policy = (body == "mlp" and int(args.n_layers) == 2 and int(args.n_hidden) == 100 and self.action_n == 4
+                             and env.n_cells in (25, 36, 48))
+        if self.fused_policy:
+            old = self.net.old_policy
+            l1, l2, head = old.network[0][0], old.network[1][0][0], old.actor
+            self._fw = {"w1t": torch.empty((env.n_cells, 100), device=self.device), "b1": l1.bias.data,
+                        "w2": l2.weight.data, "b2": l2.bias.data, "w3t": torch.empty((100, 4), device=self.device),
+                        "b3": head.bias.data}
+            self._refresh_fused_weights()
+
+    def _refresh_fused_weights(self):
+        old = self.net.old_policy  # load_state_dict copies in place: the untransposed tensors stay aliased
+        self._fw["w1t"].copy_(old.network[0][0].weight.data.t())
+        self._fw["w3t"].copy_(old.actor.weight.data.t())
+
+    def _observe(self):
+        shape = (self.env.n_envs,) + tuple(self.env.observation_space.shape)
+        return self.env.obs_f32(out=self._obs).reshape(shape)
+
+    def logits(self, old=False):
+        """Actor logits [N, 4] of the current (or the old) policy for the env's current boards, by the torch forward."""
+        with torch.no_grad():
+            out, _ = (self.net.old_policy if old else self.net)(self._observe())
+        return out
+
+    def act(self, boards=None):
+        """PPOBaseAgent.act for every env: argmax of the current policy's logits (reference policy_base.py:47-52)."""
+        return self.logits().argmax(-1).to(torch.uint8)
+
+    def act_explore(self, boards=None):
+        """PPOBaseAgent.act_explore under the OLD policy, as gather_rollout uses it (reference policy_base.py:145)."""
+        if self.fused_policy:
+            out = self.env.policy_sample(self._fw, self.draws, out=self._actions)
+        else:
+            out = self.env.categorical_sample(self.logits(old=True), self.draws, out=self._actions)
+        self.draws += 1
+        return out
+
+    def gather_rollout(self, cheat=False, horizon=None):
+        from .loops import batched_gather_rollout
+
+        return batched_gather_rollout(self.act_explore, self.env, self.discount, cheat=cheat, horizon=horizon)
+
+    def learn(self, rollout, history=None, rows=None):
+        """`epochs` minibatch updates (reference policy_base.py:64-131) on a BatchedRollout. Rows are drawn with replacement
+        among the (t, env) pairs that belong to an episode (t < length of that env's episode), in (t, env) order; `rows`
+        (one index tensor per epoch) replaces the torch.randint draws, for reproducing an update elsewhere."""
+        steps, n = rollout.actions.shape
+        valid = torch.arange(steps, device=self.device).unsqueeze(1) < rollout.lengths.unsqueeze(0)  # [T, N]
+        t_ix, n_ix = valid.nonzero(as_tuple=True)
+        shape = tuple(self.env.observation_space.shape)
+        for epoch in range(self.epochs):
+            pick = (torch.randint(t_ix.numel(), (self.batch_size,), device=self.device) if rows is None
+                    else torch.as_tensor(rows[epoch], device=self.device))
+            t_sel, n_sel = t_ix[pick], n_ix[pick]
+            s = rollout.states[t_sel, n_sel].to(torch.float32).reshape((-1,) + shape)
+            a = rollout.actions[t_sel, n_sel].to(torch.long)
+            r = rollout.returns[n_sel, t_sel]
+            if history is not None:
+                self.net._epoch(s, a, r, history)
+            else:
+                loss = self.net.surrogate_loss(s, a, r)[0]
+                self.net.optim.zero_grad()
+                loss.backward()
+                self.net.optim.step()
+        return history
+
+    def sync(self):
+        self.net.sync()
+        if self.fused_policy:
+            self._refresh_fused_weights()

@@ -143,10 +143,12 @@ def train_batched(args, writer_factory=None, reporter=_noop):
     Keeps train()'s cadence in units of lockstep steps: one "episode" = `max_iterations` steps (every env finishes at least
     one episode in that span), an evaluation (greedy, batched_default_eval) after every `eval_every` of them and once at
     the end; metrics are the aggregate meters (BatchMetrics) written under the reference's tensorboard tags. Supports the
-    agents whose learning runs on the device: tabular-q and random."""
+    agents whose learning runs on the device: tabular-q (private tables), ppo-mlp / ppo-cnn (one shared policy; an
+    "episode" is one PPO iteration = one episode per env + the epochs) and random."""
     from .agents import BatchedTabularQAgent
-    from .loops import batched_default_eval
+    from .loops import batched_default_eval, batched_ppo_learn
     from .metering import BatchMetrics
+    from .ppo import BatchedPPOAgent
 
     env_name = ENV_MAP[args.env_alias]
     writer = (writer_factory or _default_writer)(getattr(args, "log_dir", None))
@@ -156,20 +158,31 @@ def train_batched(args, writer_factory=None, reporter=_noop):
     horizon = int(env.info.max_iterations)
     if args.agent_alias == "tabular-q":
         agent = BatchedTabularQAgent(env, args)
+    elif args.agent_alias in ("ppo-mlp", "ppo-cnn"):
+        import torch
+
+        torch.manual_seed(args.seed or 0)
+        agent = BatchedPPOAgent(env, args, body=args.agent_alias[4:])
     elif args.agent_alias == "random":
         agent = None
     else:
-        raise KeyError("train_batched supports tabular-q and random, not %r" % (args.agent_alias,))
+        raise KeyError("train_batched supports tabular-q, ppo-mlp, ppo-cnn and random, not %r" % (args.agent_alias,))
+    ppo = isinstance(agent, BatchedPPOAgent)
+    history = {"writer": writer, "t": 0, "t_learn": 0}
     period = 0
     for episode in range(1, args.episodes + 1):
-        env.metrics_reset()
-        if agent is None:
-            env.step_random(horizon, auto_reset=True)
+        if ppo:
+            bm = batched_ppo_learn(agent, env, history, cheat=args.cheat)
+            history["t"] += horizon
         else:
-            agent.rollout(horizon, cheat=args.cheat)
-        bm = BatchMetrics(env.metrics())
+            env.metrics_reset()
+            if agent is None:
+                env.step_random(horizon, auto_reset=True)
+            else:
+                agent.rollout(horizon, cheat=args.cheat)
+            bm = BatchMetrics(env.metrics())
         bm.write(writer, episode, prefix="Train/")
-        if agent is not None:
+        if agent is not None and not ppo:
             writer.add_scalar("Train/epsilon", agent.epsilon, agent.t)
         reporter(hidden_reward=bm.meter("safeties")["avg"], obs_reward=bm.meter("returns")["avg"])
         if agent is not None and (episode % args.eval_every == args.eval_every - 1 or episode == args.episodes):

@@ -210,6 +210,39 @@ def test_single_env_train_reproduces_reference_run_on_gpu(golden_dir, name):
     assert out["Q"] == g["final_Q"]
 
 
+@pytest.mark.parametrize("name", ["train_boat_ppo_mlp_seed5.json", "train_boat_ppo_cnn_seed9_cheat.json"])
+def test_single_env_ppo_train_reproduces_reference_run_on_gpu(golden_dir, name):
+    """The reference's PPO run (CPU torch networks, as in the fixture) with the HIP-backed env in place of the oracle's."""
+    from test_host_golden import _same, run_ppo_golden
+
+    torch = _torch()
+    with open(os.path.join(golden_dir, name)) as f:
+        g = json.load(f)
+    if g["torch_version"] != torch.__version__:
+        pytest.skip("fixture was generated with torch %s" % g["torch_version"])
+    actions = []
+
+    def factory(env_name):
+        env = S.make(env_name)
+        inner = env.step
+
+        def logged(a):
+            actions.append(int(a.item() if hasattr(a, "item") else a))
+            return inner(a)
+
+        env.step = logged
+        return env
+
+    out = run_ppo_golden(g, factory)
+    assert actions == g["actions"]
+    assert len(out["calls"]) == len(g["writer_calls"])
+    for i, (a, b) in enumerate(zip(out["calls"], g["writer_calls"])):
+        assert _same(a, b), (i, a, b)
+    assert _same(out["weights"], g["final_weights_head8_and_sum"])
+    assert out["next_randint"] == g["torch_next_randint"]
+
+
+
 def test_single_env_api_surface():
     _torch()
     env = S.make("boat")
