@@ -192,7 +192,8 @@ BatchedRollout = collections.namedtuple("BatchedRollout", ["states", "actions", 
 
 def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None):
     """PPOBaseAgent.gather_rollout (reference policy_base.py:133-177) with one rollout = one episode PER ENV, all envs in
-    lockstep: `policy(boards) -> uint8 actions [N]` acts on the int8 board view, finished envs idle until the horizon, and
+    lockstep: `policy(boards) -> uint8 actions [N]` acts on the int8 board view (a policy with the attribute
+    `writes_out = True` is called as policy(boards, out=row) instead), finished envs idle until the horizon, and
     the discounted returns come from the bit-exact batched kernel (policy_base.py:179-186). Everything stays in HBM.
 
     Returns BatchedRollout(states int8 [T, N, cells], actions uint8 [T, N], rewards float32 [N, T], returns float32 [N, T],
@@ -202,24 +203,30 @@ def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None):
 
     T = int(horizon or env.info.max_iterations)
     n, dev = env.n_envs, "cuda:%d" % env.device
-    states = torch.zeros((T, n, env.n_cells), dtype=torch.int8, device=dev)
-    actions = torch.zeros((T, n), dtype=torch.uint8, device=dev)
-    rewards = torch.zeros((n, T), dtype=torch.float32, device=dev)
-    lengths = torch.zeros(n, dtype=torch.int32, device=dev)
+    states = torch.empty((T, n, env.n_cells), dtype=torch.int8, device=dev)
+    actions = torch.empty((T, n), dtype=torch.uint8, device=dev)
+    recs = torch.empty((T, n, 4), dtype=torch.int8, device=dev)  # step records: reward, hidden reward, done, actual action
     env.reset()
-    live = torch.ones(n, dtype=torch.bool, device=dev)
-    for t in range(T):
+    record = env._device_views()["rec"]
+    direct = bool(getattr(policy, "writes_out", False))  # policy(boards, out=row) stores its actions itself
+    for t in range(T):  # four launches per lockstep step: policy, board copy, env step, record copy
         boards = env.boards().reshape(n, -1)
-        a = policy(boards).to(torch.uint8)
+        if direct:
+            policy(boards, out=actions[t])
+        else:
+            actions[t].copy_(policy(boards))
         states[t].copy_(boards)
-        succ, reward, done, info = env.step(a, auto_reset=False)
-        r = info["hidden_reward"] if cheat else reward
-        act = info["extra_observations"]["actual_actions"].to(torch.uint8) if cheat else a
-        actions[t].copy_(torch.where(live, act, torch.zeros_like(act)))
-        rewards[:, t].copy_(torch.where(live, r.float(), torch.zeros(n, device=dev)))
-        states[t].mul_(live.to(torch.int8).unsqueeze(1))
-        lengths.add_(live.to(torch.int32))
-        live = live & (done == 0)
+        env.step(actions[t], auto_reset=False)
+        recs[t].copy_(record)
+    # a finished env idles: its later records read (0, 0, done, .), so everything per-episode follows from the done flags
+    finished_steps = (recs[:, :, 2] != 0).sum(0, dtype=torch.int32)  # done stays set from the last step of the episode on
+    lengths = torch.clamp(T - finished_steps + 1, max=T)
+    live = torch.arange(T, device=dev).unsqueeze(1) < lengths.unsqueeze(0)  # [T, N]
+    rewards = recs[:, :, 1 if cheat else 0].to(torch.float32).t().contiguous()
+    if cheat:
+        actions = recs[:, :, 3].view(torch.uint8).contiguous()
+    actions.mul_(live)
+    states.mul_(live.unsqueeze(2))
     returns = env.discounted_returns(rewards, discount, lengths=lengths)
     env.reset()
     return BatchedRollout(states, actions, rewards, returns, lengths)

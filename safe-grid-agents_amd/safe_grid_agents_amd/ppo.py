@@ -288,19 +288,24 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         """PPOBaseAgent.act for every env: argmax of the current policy's logits (reference policy_base.py:47-52)."""
         return self.logits().argmax(-1).to(torch.uint8)
 
-    def act_explore(self, boards=None):
+    def act_explore(self, boards=None, out=None):
         """PPOBaseAgent.act_explore under the OLD policy, as gather_rollout uses it (reference policy_base.py:145)."""
+        out = self._actions if out is None else out
         if self.fused_policy:
-            out = self.env.policy_sample(self._fw, self.draws, out=self._actions)
+            self.env.policy_sample(self._fw, self.draws, out=out)
         else:
-            out = self.env.categorical_sample(self.logits(old=True), self.draws, out=self._actions)
+            self.env.categorical_sample(self.logits(old=True), self.draws, out=out)
         self.draws += 1
         return out
 
     def gather_rollout(self, cheat=False, horizon=None):
         from .loops import batched_gather_rollout
 
-        return batched_gather_rollout(self.act_explore, self.env, self.discount, cheat=cheat, horizon=horizon)
+        def policy(boards, out=None):
+            return self.act_explore(out=out)
+
+        policy.writes_out = True  # the draw kernel stores straight into the rollout's action row
+        return batched_gather_rollout(policy, self.env, self.discount, cheat=cheat, horizon=horizon)
 
     def learn(self, rollout, history=None, rows=None):
         """`epochs` minibatch updates (reference policy_base.py:64-131) on a BatchedRollout. Rows are drawn with replacement

@@ -1,0 +1,31 @@
+"""Batched PPO timing on one GPU: rollout gather (env-steps/s, us per lockstep step) and the epochs, per env / body.
+Run on the GPU box: python tools/bench_ppo.py (log kept under profiles/rNN/bench_ppo.log)."""
+import sys, os, types, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "safe-grid-agents_amd"))
+import torch
+import safe_grid_agents_amd as S
+
+def run(name, n, body, hidden=100):
+    torch.manual_seed(0)
+    env = S.BatchedGridworldEnv(name, n, seed=5)
+    env.bind_torch_stream()
+    a = types.SimpleNamespace(discount=0.99, lr=1e-3, batch_size=4096, rollouts=1, epochs=16, clipping=0.2, entropy_bonus=0.0,
+                              critic_coeff=1e-4, n_layers=2, n_hidden=hidden, n_channels=5, device=0, log_gradients=False, cheat=False)
+    agent = S.BatchedPPOAgent(env, a, body=body)
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ro = agent.gather_rollout()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        agent.learn(ro); agent.sync()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+    steps = int(ro.lengths.sum().item())
+    print(f"{name} n={n} body={body} fused={agent.fused_policy}: gather {1e3*(t1-t0):.1f} ms ({steps/(t1-t0):.3e} env-steps/s, "
+          f"{1e6*(t1-t0)/ro.actions.shape[0]:.1f} us/lockstep), learn {1e3*(t2-t1):.1f} ms", flush=True)
+    env.close()
+
+for n in (4096, 32768, 262144):
+    run("BoatRace-v0", n, "mlp")
+run("BoatRace-v0", 32768, "mlp", hidden=64)
+run("BoatRace-v0", 32768, "cnn")
+run("SideEffectsSokoban-v0", 32768, "mlp")
+run("IslandNavigation-v0", 32768, "mlp")
