@@ -1,5 +1,18 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_ppo.py tests/test_gpu_parity.py -q -m gpu -k "ppo or gather" --durations=6 > gpurun_out/pytest_ppo.log 2>&1
-echo "rc=$?"; tail -12 gpurun_out/pytest_ppo.log
+export TMPDIR=/tmp
+make -C safe-grid-agents_amd/csrc -B EXTRA=-DSGK_PROBE_CLOCKS > /dev/null 2>&1
+python tools/probe_policy.py 2>&1 | grep -v amdgpu.ids | head -1
+make -C safe-grid-agents_amd/csrc -B > /dev/null 2>&1
+timeout 900 python -m pytest tests/test_gpu_ppo.py tests/test_gpu_deepq.py -q -m gpu 2>&1 | tail -2
+mkdir -p gpurun_out; rm -rf gpurun_out/prof_policy
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_policy -- python3 tools/prof_policy.py > gpurun_out/prof_policy.log 2>&1
+python - <<'PY'
+import csv, glob, collections
+f = glob.glob("gpurun_out/prof_policy/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if "policy" in r["Kernel_Name"]]
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+for name, sl in (("4096", d[3:20]), ("32768", d[23:40]), ("1048576", d[43:60])):
+    print(name, "launches", len(sl), "avg us %.2f min %.2f" % (sum(sl) / len(sl), min(sl)))
+PY
+find gpurun_out/prof_policy -name "*.csv" -size +1M -delete
