@@ -190,7 +190,21 @@ def batched_default_eval(agent, env, eval_timesteps):
 BatchedRollout = collections.namedtuple("BatchedRollout", ["states", "actions", "rewards", "returns", "lengths"])
 
 
-def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None):
+def rollout_buffers(env, horizon=None):
+    """Device tensors one batched rollout needs (reusable across rollouts: a captured learner reads fixed addresses)."""
+    import torch
+
+    T = int(horizon or env.info.max_iterations)
+    n, dev = env.n_envs, "cuda:%d" % env.device
+    return {"states": torch.empty((T, n, env.n_cells), dtype=torch.int8, device=dev),
+            "actions": torch.empty((T, n), dtype=torch.uint8, device=dev),
+            "recs": torch.empty((T, n, 4), dtype=torch.int8, device=dev),  # reward, hidden reward, done, actual action
+            "rewards": torch.empty((n, T), dtype=torch.float32, device=dev),
+            "returns": torch.empty((n, T), dtype=torch.float32, device=dev),
+            "lengths": torch.empty(n, dtype=torch.int32, device=dev)}
+
+
+def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None, buffers=None):
     """PPOBaseAgent.gather_rollout (reference policy_base.py:133-177) with one rollout = one episode PER ENV, all envs in
     lockstep: `policy(boards) -> uint8 actions [N]` acts on the int8 board view (a policy with the attribute
     `writes_out = True` is called as policy(boards, out=row) instead), finished envs idle until the horizon, and
@@ -198,14 +212,15 @@ def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None):
 
     Returns BatchedRollout(states int8 [T, N, cells], actions uint8 [T, N], rewards float32 [N, T], returns float32 [N, T],
     lengths int32 [N]); entries past an env's length are zero. The episodes are booked in the env's metrics vector
-    (track_metrics, policy_base.py:168) and every env is reset afterwards (policy_base.py:174)."""
+    (track_metrics, policy_base.py:168) and every env is reset afterwards (policy_base.py:174). `buffers`
+    (rollout_buffers) are overwritten and returned when given."""
     import torch
 
-    T = int(horizon or env.info.max_iterations)
-    n, dev = env.n_envs, "cuda:%d" % env.device
-    states = torch.empty((T, n, env.n_cells), dtype=torch.int8, device=dev)
-    actions = torch.empty((T, n), dtype=torch.uint8, device=dev)
-    recs = torch.empty((T, n, 4), dtype=torch.int8, device=dev)  # step records: reward, hidden reward, done, actual action
+    buf = buffers or rollout_buffers(env, horizon)
+    states, actions, recs = buf["states"], buf["actions"], buf["recs"]
+    rewards, returns, lengths = buf["rewards"], buf["returns"], buf["lengths"]
+    T, n = actions.shape
+    dev = actions.device
     env.reset()
     record = env._device_views()["rec"]
     direct = bool(getattr(policy, "writes_out", False))  # policy(boards, out=row) stores its actions itself
@@ -220,14 +235,15 @@ def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None):
         recs[t].copy_(record)
     # a finished env idles: its later records read (0, 0, done, .), so everything per-episode follows from the done flags
     finished_steps = (recs[:, :, 2] != 0).sum(0, dtype=torch.int32)  # done stays set from the last step of the episode on
-    lengths = torch.clamp(T - finished_steps + 1, max=T)
+    lengths.copy_(torch.clamp(T - finished_steps + 1, max=T))
     live = torch.arange(T, device=dev).unsqueeze(1) < lengths.unsqueeze(0)  # [T, N]
-    rewards = recs[:, :, 1 if cheat else 0].to(torch.float32).t().contiguous()
+    rewards.copy_(recs[:, :, 1 if cheat else 0].t())
     if cheat:
-        actions = recs[:, :, 3].view(torch.uint8).contiguous()
+        actions.copy_(recs[:, :, 3].view(torch.uint8))
     actions.mul_(live)
     states.mul_(live.unsqueeze(2))
-    returns = env.discounted_returns(rewards, discount, lengths=lengths)
+    returns.zero_()
+    env.discounted_returns(rewards, discount, lengths=lengths, out=returns)
     env.reset()
     return BatchedRollout(states, actions, rewards, returns, lengths)
 

@@ -84,12 +84,13 @@ class PPOBaseAgent(nn.Module, BaseActor, BaseLearner, BaseExplorer):
         returns (loss, policy_loss, value_loss, entropy)."""
         logits, values = self(s)
         values = values.reshape(-1)
-        current = Categorical(logits=logits)
+        # validate_args only adds host-synchronising checks (forbidden while a hipGraph is being captured); no numeric effect
+        current = Categorical(logits=logits, validate_args=False)
         advantage = r - values
         advantage = (advantage - advantage.mean()) / advantage.std()
         with torch.no_grad():
             old_logits, _ = self.old_policy(s)
-            old_log_prob = Categorical(logits=old_logits).log_prob(a)
+            old_log_prob = Categorical(logits=old_logits, validate_args=False).log_prob(a)
         ratio = torch.exp(current.log_prob(a) - old_log_prob)
         entropy = current.entropy().mean()
         value_loss = nn.functional.mse_loss(values, r)
@@ -244,7 +245,7 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
 
     reads_boards = True  # acts on the materialised cells (batched_default_eval must keep writing them)
 
-    def __init__(self, env, args, body="mlp"):
+    def __init__(self, env, args, body="mlp", graph_epochs=True):
         import types
 
         cfg = types.SimpleNamespace(**vars(args))
@@ -257,6 +258,13 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         self.epochs, self.batch_size = int(args.epochs), int(args.batch_size)
         self.action_n = env.action_space.n
         self.draws = 0  # lockstep act_explore calls so far == the RNG draw index
+        # Adam with its step counter on the device, so that the epochs can be recorded in a hipGraph (same arithmetic)
+        own = [p for name, p in self.net.named_parameters() if not name.startswith("old_policy.")]
+        self.net.optim = torch.optim.Adam(own, self.net.lr, capturable=True)
+        self.graph_epochs = bool(graph_epochs)
+        self._buffers = None   # rollout tensors, allocated once: the captured epochs read fixed addresses
+        self._graph = None
+        self._stats = torch.zeros((self.epochs, 3), dtype=torch.float32, device=self.device)  # policy loss, value loss, entropy
         self._actions = torch.empty(env.n_envs, dtype=torch.uint8, device=self.device)
         self._obs = torch.empty((env.n_envs, env.n_cells), dtype=torch.float32, device=self.device)
         self.fused_policy = (body == "mlp" and int(args.n_layers) == 2 and int(args.n_hidden) == 100 and self.action_n == 4
@@ -299,36 +307,86 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         return out
 
     def gather_rollout(self, cheat=False, horizon=None):
-        from .loops import batched_gather_rollout
+        from .loops import batched_gather_rollout, rollout_buffers
 
         def policy(boards, out=None):
             return self.act_explore(out=out)
 
         policy.writes_out = True  # the draw kernel stores straight into the rollout's action row
-        return batched_gather_rollout(policy, self.env, self.discount, cheat=cheat, horizon=horizon)
+        if self._buffers is None or (horizon is not None and int(horizon) != self._buffers["actions"].shape[0]):
+            self._buffers, self._graph = rollout_buffers(self.env, horizon), None
+        return batched_gather_rollout(policy, self.env, self.discount, cheat=cheat, horizon=horizon, buffers=self._buffers)
+
+    def _minibatch(self, rollout, pick=None):
+        """One minibatch of (state, action, return) rows. Without `pick`: batch_size rows drawn with replacement, uniformly
+        over the (t, env) pairs that belong to an episode -- an env in proportion to its episode length, then a step of that
+        episode -- with static shapes and no host synchronisation. With `pick`: those indices into the valid pairs in
+        (t, env) order."""
+        if pick is None:
+            n_sel = torch.multinomial(rollout.lengths.to(torch.float32), self.batch_size, replacement=True)
+            span = rollout.lengths[n_sel]
+            t_sel = torch.minimum((torch.rand(self.batch_size, device=self.device) * span).to(torch.int64), span.to(torch.int64) - 1)
+        else:
+            steps = rollout.actions.shape[0]
+            valid = torch.arange(steps, device=self.device).unsqueeze(1) < rollout.lengths.unsqueeze(0)  # [T, N]
+            t_ix, n_ix = valid.nonzero(as_tuple=True)
+            pick = torch.as_tensor(pick, device=self.device)
+            t_sel, n_sel = t_ix[pick], n_ix[pick]
+        shape = tuple(self.env.observation_space.shape)
+        s = rollout.states[t_sel, n_sel].to(torch.float32).reshape((-1,) + shape)
+        return s, rollout.actions[t_sel, n_sel].to(torch.long), rollout.returns[n_sel, t_sel]
+
+    def _epochs_on_device(self, rollout):
+        """All epochs back to back; the three logged scalars of each land in self._stats (no host synchronisation)."""
+        net = self.net
+        for epoch in range(self.epochs):
+            s, a, r = self._minibatch(rollout)
+            loss, policy_loss, value_loss, entropy = net.surrogate_loss(s, a, r)
+            self._stats[epoch].copy_(torch.stack((policy_loss.detach(), value_loss.detach(), entropy.detach())))
+            net.optim.zero_grad(set_to_none=True)
+            loss.backward()
+            net.optim.step()
+
+    def _capture(self, rollout):
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):  # warm-up on a side stream (allocator, lazy init), as the capture recipe requires
+            self._epochs_on_device(rollout)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._epochs_on_device(rollout)
+        return graph
 
     def learn(self, rollout, history=None, rows=None):
-        """`epochs` minibatch updates (reference policy_base.py:64-131) on a BatchedRollout. Rows are drawn with replacement
-        among the (t, env) pairs that belong to an episode (t < length of that env's episode), in (t, env) order; `rows`
-        (one index tensor per epoch) replaces the torch.randint draws, for reproducing an update elsewhere."""
-        steps, n = rollout.actions.shape
-        valid = torch.arange(steps, device=self.device).unsqueeze(1) < rollout.lengths.unsqueeze(0)  # [T, N]
-        t_ix, n_ix = valid.nonzero(as_tuple=True)
-        shape = tuple(self.env.observation_space.shape)
-        for epoch in range(self.epochs):
-            pick = (torch.randint(t_ix.numel(), (self.batch_size,), device=self.device) if rows is None
-                    else torch.as_tensor(rows[epoch], device=self.device))
-            t_sel, n_sel = t_ix[pick], n_ix[pick]
-            s = rollout.states[t_sel, n_sel].to(torch.float32).reshape((-1,) + shape)
-            a = rollout.actions[t_sel, n_sel].to(torch.long)
-            r = rollout.returns[n_sel, t_sel]
-            if history is not None:
-                self.net._epoch(s, a, r, history)
-            else:
-                loss = self.net.surrogate_loss(s, a, r)[0]
-                self.net.optim.zero_grad()
-                loss.backward()
-                self.net.optim.step()
+        """`epochs` minibatch updates (reference policy_base.py:64-131) on a BatchedRollout; `rows` (one index tensor per
+        epoch) replaces the random draws, for reproducing an update elsewhere. With graph_epochs (default) and the agent's
+        own rollout buffers, the whole call is ONE hipGraph replay -- sampling, gathers, forward, backward and Adam of every
+        epoch (~100 launches each) -- plus one read-back of the logged scalars when a history is given."""
+        own = self._buffers is not None and rollout.states is self._buffers["states"]
+        if rows is not None or not (self.graph_epochs and own):
+            for epoch in range(self.epochs):
+                s, a, r = self._minibatch(rollout, None if rows is None else rows[epoch])
+                if history is not None:
+                    self.net._epoch(s, a, r, history)
+                else:
+                    loss = self.net.surrogate_loss(s, a, r)[0]
+                    self.net.optim.zero_grad()
+                    loss.backward()
+                    self.net.optim.step()
+            return history
+        if self._graph is None:
+            self._graph = self._capture(rollout)  # the warm-up pass inside performs this call's update
+        else:
+            self._graph.replay()
+        if history is not None:
+            stats = self._stats.cpu().numpy()
+            writer = history["writer"]
+            for epoch in range(self.epochs):  # the reference's three scalars per epoch (policy_base.py:108-119)
+                writer.add_scalar("Train/policy_loss", float(stats[epoch, 0]), history["t_learn"])
+                writer.add_scalar("Train/value_loss", float(stats[epoch, 1]), history["t_learn"])
+                writer.add_scalar("Train/policy_entropy", float(stats[epoch, 2]), history["t_learn"])
+                history["t_learn"] += 1
         return history
 
     def sync(self):

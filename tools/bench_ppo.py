@@ -12,15 +12,20 @@ def run(name, n, body, hidden=100):
     a = types.SimpleNamespace(discount=0.99, lr=1e-3, batch_size=4096, rollouts=1, epochs=16, clipping=0.2, entropy_bonus=0.0,
                               critic_coeff=1e-4, n_layers=2, n_hidden=hidden, n_channels=5, device=0, log_gradients=False, cheat=False)
     agent = S.BatchedPPOAgent(env, a, body=body)
-    for it in range(3):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        ro = agent.gather_rollout()
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        agent.learn(ro); agent.sync()
-        torch.cuda.synchronize(); t2 = time.perf_counter()
+    learn_ms = {}
+    for graphed in (False, True):
+        agent.graph_epochs = graphed
+        for it in range(4):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ro = agent.gather_rollout()
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            agent.learn(ro); agent.sync()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+        learn_ms[graphed] = 1e3 * (t2 - t1)
     steps = int(ro.lengths.sum().item())
     print(f"{name} n={n} body={body} fused={agent.fused_policy}: gather {1e3*(t1-t0):.1f} ms ({steps/(t1-t0):.3e} env-steps/s, "
-          f"{1e6*(t1-t0)/ro.actions.shape[0]:.1f} us/lockstep), learn {1e3*(t2-t1):.1f} ms", flush=True)
+          f"{1e6*(t1-t0)/ro.actions.shape[0]:.1f} us/lockstep), learn (16 epochs x 4096 rows) eager {learn_ms[False]:.1f} ms, "
+          f"one hipGraph {learn_ms[True]:.2f} ms", flush=True)
     env.close()
 
 for n in (4096, 32768, 262144):
