@@ -40,6 +40,7 @@ extern "C" {
 #define SGK_BOAT_RACE 0
 #define SGK_ISLAND_NAVIGATION 1
 #define SGK_SIDE_EFFECTS_SOKOBAN 2
+#define SGK_DISTRIBUTIONAL_SHIFT 3 /* "lava" -> "DistributionalShift-v0", training level */
 
 /* flags for sgk_step / sgk_step_random / sgk_rollout_random */
 #define SGK_F_AUTO_RESET 1u /* an env whose episode ends is reset in the same step (after its episode is recorded) */

@@ -63,6 +63,8 @@ class OracleGridworldEnv:
         }
         if self._b.env_id == 1:
             info["extra_observations"]["safety"] = int(self._b.field("safety")[0])
+        if not O.has_hidden_reward(self._b.env_id):
+            info["hidden_reward"] = None  # safe_grid_gym reports None for envs that define no hidden reward
         return self._obs(), r, bool(d), info
 
     def render(self, mode="rgb_array"):

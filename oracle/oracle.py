@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle_sgk.so")
 
-ENV_IDS = {"BoatRace-v0": 0, "IslandNavigation-v0": 1, "SideEffectsSokoban-v0": 2}
+ENV_IDS = {"BoatRace-v0": 0, "IslandNavigation-v0": 1, "SideEffectsSokoban-v0": 2, "DistributionalShift-v0": 3}
 M_LEN = 16
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, M_RESERVED,
  M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)
@@ -230,6 +230,11 @@ def categorical_sample(logits, seed, env_begin, draw):
         acts[i] = L.orc_categorical_sample(lg[i].ctypes.data, seed, env_begin + i, draw, ctypes.byref(margin))
         margins[i] = margin.value
     return acts, margins
+
+
+def has_hidden_reward(env):
+    """False for envs that define no hidden reward (their step record mirrors the observed reward; performance = return)."""
+    return bool(lib().orc_has_hidden_reward(_env_id(env)))
 
 
 def discounted_returns(rewards, discount):

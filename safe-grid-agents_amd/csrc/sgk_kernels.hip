@@ -118,6 +118,7 @@ int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int a
   case SGK_BOAT_RACE: transition<SGK_BOAT_RACE>(R, s, action, r_obs, r_hid, term); break;
   case SGK_ISLAND_NAVIGATION: transition<SGK_ISLAND_NAVIGATION>(R, s, action, r_obs, r_hid, term); break;
   case SGK_SIDE_EFFECTS_SOKOBAN: transition<SGK_SIDE_EFFECTS_SOKOBAN>(R, s, action, r_obs, r_hid, term); break;
+  case SGK_DISTRIBUTIONAL_SHIFT: transition<SGK_DISTRIBUTIONAL_SHIFT>(R, s, action, r_obs, r_hid, term); break;
   default: return -1;
   }
   out[0] = s.pos; out[1] = s.box; out[2] = r_obs; out[3] = r_hid; out[4] = term;
@@ -165,22 +166,16 @@ __host__ __device__ __forceinline__ uint32_t transition(const SgkRules &R, EnvSt
 // episode-end bookkeeping: ballot -> wave reduction -> one atomic per wave per quantity.
 // Must be called by all 64 lanes of the wave.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-  return v;
-}
-
-__device__ __forceinline__ long long wave_sum64(long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// The device library's wavefront reductions (DPP row shifts / broadcasts on the VALU, ~6 dependent ops per value); a
+// __shfl_xor butterfly goes through ds_bpermute (the LDS crossbar) six times per value: with ten values per flush that was
+// 84 dependent LDS round trips at the end of every launch that finished an episode -- 2.3 us of IslandNavigation's 6.1 us
+// launch at 1 K envs and 4.4 of its 19.7 us at 1 M (measured by disabling the flush).
+extern "C" __device__ int __ockl_wfred_add_i32(int);
+extern "C" __device__ int __ockl_wfred_max_i32(int);
+extern "C" __device__ long __ockl_wfred_add_i64(long);
+__device__ __forceinline__ int wave_sum(int v) { return __ockl_wfred_add_i32(v); }
+__device__ __forceinline__ int wave_max(int v) { return __ockl_wfred_max_i32(v); }
+__device__ __forceinline__ long long wave_sum64(long long v) { return (long long)__ockl_wfred_add_i64((long)v); }
 
 // Per-lane accumulators of the episodes a lane finished during one launch. Nothing is exchanged while stepping;
 // flush() runs once per launch: wave reduction (skipped by waves that finished nothing), then one add per quantity
@@ -215,24 +210,29 @@ __device__ __forceinline__ void acc_add(EpisodeAcc &a, bool finished, int ret, i
   }
 }
 
+// n_episodes[env] += 1 as a fire-and-forget atomic: a plain read-modify-write makes the finishing wave wait out a memory round
+// trip in the middle of its step (each env is owned by exactly one lane, so this is not about races)
+__device__ __forceinline__ void bump_episode_count(int32_t *__restrict__ n_episodes, int64_t env) {
+  (void)__hip_atomic_fetch_add(&n_episodes[env], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // must be reached by all 64 lanes of the wave
 __device__ __forceinline__ void acc_flush(const EpisodeAcc &a, long long *__restrict__ slab) {
   if (__ballot(a.n_eps > 0) == 0ull) return;  // wave-uniform
   long long s_ret = wave_sum64(a.s_ret), s_perf = wave_sum64(a.s_perf), s_mpos = wave_sum64(a.s_mpos);
   long long n_eps = wave_sum64(a.n_eps), n_pos = wave_sum64(a.n_pos);
   int m_ret = wave_max(a.m_ret), m_perf = wave_max(a.m_perf), m_margin = wave_max(a.m_margin), m_mpos = wave_max(a.m_mpos);
-  if ((threadIdx.x & 63) == 0) {
-    long long *slot = slab + (size_t)(blockIdx.x % SGK_METRIC_SLOTS) * SGK_METRICS_LEN;
-    atomicAdd((unsigned long long *)&slot[SGK_M_SUM_RETURN], (unsigned long long)s_ret);
-    atomicAdd((unsigned long long *)&slot[SGK_M_SUM_SAFETY], (unsigned long long)s_perf);
-    atomicAdd((unsigned long long *)&slot[SGK_M_SUM_MARGIN], (unsigned long long)(s_ret - s_perf));
-    atomicAdd((unsigned long long *)&slot[SGK_M_SUM_MARGIN_POS], (unsigned long long)s_mpos);
-    atomicAdd((unsigned long long *)&slot[SGK_M_EPISODES], (unsigned long long)n_eps);
-    atomicAdd((unsigned long long *)&slot[SGK_M_MARGIN_POS_COUNT], (unsigned long long)n_pos);
-    atomicMax(&slot[SGK_M_MAX_RETURN], (long long)m_ret);
-    atomicMax(&slot[SGK_M_MAX_SAFETY], (long long)m_perf);
-    atomicMax(&slot[SGK_M_MAX_MARGIN], (long long)m_margin);
-    if (n_pos > 0) atomicMax(&slot[SGK_M_MAX_MARGIN_POS], (long long)m_mpos);
+  // every lane holds the wave totals; lane c forwards column c of the slot: one atomic instruction for the six sums and one
+  // for the four maxima (instead of ten single-lane atomics in a row on the same 128-byte line)
+  const int c = threadIdx.x & 63;
+  long long *slot = slab + (size_t)(blockIdx.x % SGK_METRIC_SLOTS) * SGK_METRICS_LEN;
+  if (c < 6) {
+    const long long v = c == SGK_M_SUM_RETURN ? s_ret : c == SGK_M_SUM_SAFETY ? s_perf : c == SGK_M_SUM_MARGIN ? s_ret - s_perf
+                      : c == SGK_M_SUM_MARGIN_POS ? s_mpos : c == SGK_M_EPISODES ? n_eps : n_pos;
+    atomicAdd((unsigned long long *)&slot[c], (unsigned long long)v);
+  } else if (c >= SGK_M_MAX_RETURN && c <= SGK_M_MAX_MARGIN_POS) {
+    const int m = c == SGK_M_MAX_RETURN ? m_ret : c == SGK_M_MAX_SAFETY ? m_perf : c == SGK_M_MAX_MARGIN ? m_margin : m_mpos;
+    if (c != SGK_M_MAX_MARGIN_POS || n_pos > 0) atomicMax(&slot[c], (long long)m);
   }
 }
 
@@ -393,6 +393,8 @@ template <>
 struct Geom<SGK_ISLAND_NAVIGATION> { static constexpr int NC = 48, PITCH = 48; };
 template <>
 struct Geom<SGK_SIDE_EFFECTS_SOKOBAN> { static constexpr int NC = 36, PITCH = 48; };
+template <>
+struct Geom<SGK_DISTRIBUTIONAL_SHIFT> { static constexpr int NC = 63, PITCH = 64; };
 
 // ------------------------------------------------------------------------------------------------
 // the lockstep step kernel: env.step(action) for every env of the shard
@@ -430,7 +432,7 @@ __device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, i
   if (finished) {
     a.last_return[env] = s.ret;
     a.last_perf[env] = s.hid;
-    a.n_episodes[env] += 1;
+    bump_episode_count(a.n_episodes, env);
     if (a.flags & SGK_F_AUTO_RESET) s = initial_state(R);
     else s.over = 1;
   }
@@ -483,8 +485,8 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
       action = act_cur & 3;
     }
     uint32_t rec;
-    step_one<ENV>(R, a, env, valid, action, s, rec, acc);
-    if (valid) {
+      step_one<ENV>(R, a, env, valid, action, s, rec, acc);
+      if (valid) {
       a.state[env] = pack_state(s);
 #if SGK_STREAM_STORES
       __hip_atomic_store(&a.rec[env], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
       if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, a.boards, tile * WG, s);
       else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
     }
-  }
+    }
   acc_flush(acc, a.metrics);
 }
 
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
           acc_add(acc, true, s.ret, s.hid);
           a.last_return[env] = s.ret;
           a.last_perf[env] = s.hid;
-          a.n_episodes[env] += 1;
+          bump_episode_count(a.n_episodes, env);
           if (auto_reset) s = initial_state(R);
           else s.over = 1;
         }
@@ -1286,7 +1288,7 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
       if (finished) {  // train.py:62-70: the next episode starts from env.reset()
         a.last_return[env] = s.ret;
         a.last_perf[env] = s.hid;
-        a.n_episodes[env] += 1;
+        bump_episode_count(a.n_episodes, env);
         s = initial_state(R);
         si = R.state_slot[s.pos];
         n0 = Q[(si * 4 + 0) * 64 + lane]; n1 = Q[(si * 4 + 1) * 64 + lane];
@@ -1323,12 +1325,14 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       switch (ENVID) {                                                                                     \
       case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
       case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
+      case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
       }                                                                                                    \
     } else {                                                                                               \
       switch (ENVID) {                                                                                     \
       case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
       case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
+      case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
       }                                                                                                    \
     }                                                                                                      \
@@ -1339,6 +1343,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
     switch (ENVID) {                                                                     \
     case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; __VA_ARGS__; } break;               \
     case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; __VA_ARGS__; } break; \
+    case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; __VA_ARGS__; } break; \
     default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; __VA_ARGS__; } break;               \
     }                                                                                    \
   } while (0)
@@ -1481,6 +1486,7 @@ hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, 
   case 25: SGK_POLICY_LAUNCH(25); break;
   case 36: SGK_POLICY_LAUNCH(36); break;
   case 48: SGK_POLICY_LAUNCH(48); break;
+  case 63: SGK_POLICY_LAUNCH(63); break;
   default: return hipErrorInvalidValue;
   }
 #undef SGK_POLICY_LAUNCH

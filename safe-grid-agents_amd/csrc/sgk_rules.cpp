@@ -126,6 +126,12 @@ extern "C" int sgk_build_rules(int env_id, SgkRules *r) {
         obs = hid = SGK_SOKOBAN_MOVEMENT_REWARD;
         if (L.at(next) == SGK_CH_GOAL) { obs += SGK_SOKOBAN_GOAL_REWARD; hid += SGK_SOKOBAN_GOAL_REWARD; term = 1; }
         break;
+      case SGK_ENV_LAVA:  // no hidden reward upstream: the record's hidden channel mirrors the observed one (sgk_levels.h)
+        obs = SGK_LAVA_MOVEMENT_REWARD;
+        if (L.at(next) == SGK_CH_GOAL) { obs += SGK_LAVA_GOAL_REWARD; term = 1; }
+        else if (L.at(next) == SGK_CH_LAVA) { obs += SGK_LAVA_LAVA_REWARD; term = 1; }
+        hid = obs;
+        break;
       }
       r->trans[cell * SGK_ACTIONS + a] = pack(next, obs, hid, term);
     }
@@ -165,7 +171,7 @@ extern "C" int sgk_build_rules(int env_id, SgkRules *r) {
 
   // value -> colour: every character of this level that maps to the value (they share one colour by construction)
   {
-    const char chars[] = {' ', '#', 'A', 'G', 'W', '>', 'v', '<', '^', 'C', 'X'};
+    const char chars[] = {' ', '#', 'A', 'G', 'W', '>', 'v', '<', '^', 'C', 'X', 'L'};
     for (char ch : chars) {
       int v = sgk_value_of(env_id, ch), rgb[3];
       if (v < 0 || v >= 8 || sgk_colour_of(env_id, ch, rgb) != 0) continue;

@@ -19,9 +19,13 @@ ENV_IDS = {
     "BoatRace-v0": _lib.BOAT_RACE,
     "IslandNavigation-v0": _lib.ISLAND_NAVIGATION,
     "SideEffectsSokoban-v0": _lib.SIDE_EFFECTS_SOKOBAN,
+    "DistributionalShift-v0": _lib.DISTRIBUTIONAL_SHIFT,
 }
+# envs that define no hidden reward upstream: performance = episode return, info["hidden_reward"] is None in the
+# single-env wrapper (the batched integer record mirrors the observed reward instead, include/sgk_levels.h)
+NO_HIDDEN_REWARD = frozenset({"DistributionalShift-v0"})
 
-# reference parsing/parse.py:22-37; only the three envs of the hot-path scope are implemented
+# reference parsing/parse.py:22-37; the three envs of the hot-path scope plus DistributionalShift
 ENV_MAP = {
     "bandit": "FriendFoe-v0",
     "belt": "ConveyorBelt-v0",
@@ -540,6 +544,8 @@ class GridworldEnv:
             "extra_observations": {"actual_actions": actual},
         }
         state = self._board.reshape(1, self._b.H, self._b.W).astype(np.float32)
+        if self.name in NO_HIDDEN_REWARD:
+            info["hidden_reward"] = None  # as safe_grid_gym reports it for an env without a hidden reward
         if self._water is not None:  # IslandNavigation's side information: Manhattan distance to the nearest water cell
             at = np.argwhere(state[0] == 2)
             info["extra_observations"]["safety"] = (

@@ -117,6 +117,8 @@ class RecordingWriter(NullWriter):
 
     @staticmethod
     def _num(v):
+        if v is None:
+            return None
         if isinstance(v, (bool, np.bool_)):
             return bool(v)
         if isinstance(v, (int, np.integer)):

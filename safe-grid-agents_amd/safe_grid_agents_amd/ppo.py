@@ -268,7 +268,7 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         self._actions = torch.empty(env.n_envs, dtype=torch.uint8, device=self.device)
         self._obs = torch.empty((env.n_envs, env.n_cells), dtype=torch.float32, device=self.device)
         self.fused_policy = (body == "mlp" and int(args.n_layers) == 2 and int(args.n_hidden) == 100 and self.action_n == 4
-                             and env.n_cells in (25, 36, 48))
+                             and env.n_cells in (25, 36, 48, 63))
         if self.fused_policy:
             old = self.net.old_policy
             l1, l2, head = old.network[0][0], old.network[1][0][0], old.actor

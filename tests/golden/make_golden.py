@@ -44,6 +44,8 @@ class RecordingWriter:
 
     @staticmethod
     def _num(v):
+        if v is None:
+            return None
         if isinstance(v, (bool, np.bool_)):
             return bool(v)
         if isinstance(v, (int, np.integer)):
@@ -378,6 +380,9 @@ def main():
     golden_train("train_boat_tabq_seed3_video.json",
                  ["-S", "3", "-E", "12", "-EE", "5", "-V", "120", "-EV", "2", "boat", "tabular-q", "-l", ".25", "-e", "0.2",
                   "-dl", "500"])
+    golden_train("train_lava_tabq_seed11.json",
+                 ["-S", "11", "-E", "50", "-EE", "25", "-V", "130", "-EV", "1", "-D", "0.9",
+                  "lava", "tabular-q", "-l", ".3", "-e", "0.1", "-dl", "800"])
     golden_train_ppo("train_boat_ppo_mlp_seed5.json",
                      ["-S", "5", "-E", "4", "-EE", "3", "-V", "120", "-EV", "0", "boat", "ppo-mlp", "-l", "0.001", "-r", "2",
                       "-e", "5", "-b", "32", "-hd", "24"])

@@ -180,7 +180,7 @@ def test_epsilon_greedy_kernel_bit_exact_vs_oracle_and_eager_equals_graphed_stre
     env.close()
 
 
-@pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "BoatRace-v0", "IslandNavigation-v0"])
+@pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "BoatRace-v0", "IslandNavigation-v0", "DistributionalShift-v0"])
 @pytest.mark.parametrize("layout", ["compact", "pitched"])
 def test_fused_policy_kernel_matches_torch_forward(name, layout):
     """sgk_policy_act (boards -> MLP -> argmax / eps-greedy in one launch) vs the same network evaluated by torch on the CPU

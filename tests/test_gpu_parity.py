@@ -16,7 +16,7 @@ from safe_grid_agents_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
-ENVS = ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0"]
+ENVS = ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0", "DistributionalShift-v0"]
 
 
 def _torch():
@@ -183,7 +183,8 @@ def test_obs_f32_is_the_float_board(name, layout):
 
 # ---- the single-env drop-in through the reference-shaped train() loop ---------------------------------------------
 @pytest.mark.parametrize("name", ["train_boat_tabq_seed7.json", "train_island_tabq_seed1.json",
-                                  "train_sokoban_tabq_seed123_cheat.json", "train_boat_tabq_seed3_video.json"])
+                                  "train_sokoban_tabq_seed123_cheat.json", "train_boat_tabq_seed3_video.json",
+                                  "train_lava_tabq_seed11.json"])
 def test_single_env_train_reproduces_reference_run_on_gpu(golden_dir, name):
     from test_host_golden import run_train_golden
 

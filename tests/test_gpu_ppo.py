@@ -56,7 +56,7 @@ def test_categorical_sample_kernel_vs_oracle_and_law():
     env.close()
 
 
-@pytest.mark.parametrize("name", ["BoatRace-v0", "SideEffectsSokoban-v0", "IslandNavigation-v0"])
+@pytest.mark.parametrize("name", ["BoatRace-v0", "SideEffectsSokoban-v0", "IslandNavigation-v0", "DistributionalShift-v0"])
 def test_fused_policy_sample_matches_torch_forward_and_oracle_draw(name):
     import torch
 
