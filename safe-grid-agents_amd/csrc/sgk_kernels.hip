@@ -485,8 +485,8 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
       action = act_cur & 3;
     }
     uint32_t rec;
-      step_one<ENV>(R, a, env, valid, action, s, rec, acc);
-      if (valid) {
+    step_one<ENV>(R, a, env, valid, action, s, rec, acc);
+    if (valid) {
       a.state[env] = pack_state(s);
 #if SGK_STREAM_STORES
       __hip_atomic_store(&a.rec[env], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
       if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, a.boards, tile * WG, s);
       else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
     }
-    }
+  }
   acc_flush(acc, a.metrics);
 }
 

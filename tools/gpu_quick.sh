@@ -1,5 +1,8 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
-mkdir -p gpurun_out
-timeout 900 python tools/sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/sweep.log; wc -l gpurun_out/sweep.log
-timeout 900 python tools/bench_configs.py > gpurun_out/configs.log 2>&1; tail -10 gpurun_out/configs.log | cut -c1-260
+for rep in 1 2; do
+for v in old new; do
+  echo "variant $v"
+  SGK_LIB_PATH=$PWD/safe-grid-agents_amd/lib/libsgk_$v.so timeout 600 python tools/sweep.py BoatRace-v0 IslandNavigation-v0 1024 65536 1048576 2>&1 | grep compact | cut -c1-130
+done
+done
