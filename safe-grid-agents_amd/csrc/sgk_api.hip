@@ -202,7 +202,10 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   hipDeviceProp_t prop;
   SGK_TRY(hipGetDeviceProperties(&prop, device));
   s.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  s.max_grid = s.n_cus * 8;
+  // workgroups per launch of the grid-stride kernels: 6 per CU. Measured at 1 M envs (profiles/r01/sweep_all_envs.log,
+  // SGK_MAX_GRID sweep): 4 per CU 11.7 us, 6 per CU 10.4, 8 per CU 10.7-10.9, 16 per CU 11.6 -- a launch lasts the dispatch
+  // ramp of its waves plus one workgroup's lifetime, and the two trade off around here.
+  s.max_grid = s.n_cus * 6;
   if (const char *mg = getenv("SGK_MAX_GRID")) {  // tuning knob: workgroups per launch (grid-stride over env tiles)
     int v = atoi(mg);
     if (v >= 64) s.max_grid = v;
