@@ -1,5 +1,5 @@
 // sgk_api.hip -- the C-ABI of libsgk.so (include/sgk.h): handle management, stream / hipGraph
-// plumbing and host copies around the kernels in sgk_kernels.hip. No CPU fallback: every entry point
+// plumbing and host copies around the kernels in sgk_step.hip, sgk_tabq.hip and sgk_policy.hip. No CPU fallback: every entry point
 // needs a GPU and says so when there is none.
 #include <hip/hip_runtime.h>
 

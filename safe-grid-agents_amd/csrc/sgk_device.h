@@ -1,0 +1,377 @@
+// sgk_device.h -- device-side building blocks shared by the kernel files (sgk_step.hip, sgk_policy.hip, sgk_tabq.hip):
+// the packed env state word, the counter RNG, the table-driven transition, the episode-metrics accumulators and the two
+// board writers. Everything here is a template or __forceinline__; the file is included, never compiled on its own.
+//
+// Design:
+//  * one lane = one env; wave64; 256-lane workgroups; grid-stride over env tiles.
+//  * state of record = one packed 8-byte word per env (agent cell, box cell, frame, flags, int16 episode
+//    return, int16 hidden return) -> one coalesced dwordx2 load + store per env-step.
+//  * the level's rule tables (SgkRules, 1.4 KB) are staged into LDS once per workgroup; a step is a
+//    single LDS dword lookup indexed by (cell, action) plus, for Sokoban, the box-push neighbourhood.
+//  * observation boards are int8 cells, env-major, MATERIALISED (write-only) from the state word and the
+//    LDS-resident backdrop: either one padded row per lane written with 16-B stores (PITCHED) or exact
+//    n_cells-byte rows assembled per 16-byte chunk from LDS (COMPACT) so every store instruction covers
+//    1 KiB of contiguous HBM.
+//  * episode ends: per-lane accumulators -> wave reduction -> one vector atomic per wave on the workgroup's slab slot.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "sgk_kernels.h"
+
+
+namespace sgk {
+
+constexpr int WG = 256;
+
+// ------------------------------------------------------------------------------------------------
+// packed per-env state word
+// ------------------------------------------------------------------------------------------------
+struct EnvState {
+  int pos, box, frame, over;
+  int ret, hid;
+};
+
+__device__ __forceinline__ EnvState unpack_state(uint64_t w) {
+  EnvState s;
+  uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+  s.pos = lo & 0xff;
+  s.box = (lo >> 8) & 0xff;
+  s.frame = (lo >> 16) & 0xff;
+  s.over = (lo >> 24) & 1;
+  s.ret = (int)(int16_t)(hi & 0xffff);
+  s.hid = (int)(int16_t)(hi >> 16);
+  return s;
+}
+
+__device__ __forceinline__ uint64_t pack_state(const EnvState &s) {
+  uint32_t lo = (uint32_t)s.pos | ((uint32_t)s.box << 8) | ((uint32_t)s.frame << 16) | ((uint32_t)s.over << 24);
+  uint32_t hi = ((uint32_t)s.ret & 0xffffu) | ((uint32_t)s.hid << 16);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ EnvState initial_state(const SgkRules &R) {
+  EnvState s;
+  s.pos = R.start_agent;
+  s.box = R.start_box;
+  s.frame = 0;
+  s.over = 0;
+  s.ret = 0;
+  s.hid = 0;
+  return s;
+}
+
+__device__ __forceinline__ uint32_t pack_rec(int reward, int hidden, int done, int actual) {
+  return ((uint32_t)reward & 0xffu) | (((uint32_t)hidden & 0xffu) << 8) | ((uint32_t)(done & 1) << 16) |
+         ((uint32_t)(actual & 0xff) << 24);
+}
+
+// workgroup-cooperative copy of the rule tables HBM/L2 -> LDS
+__device__ __forceinline__ void stage_rules(SgkRules &dst, const SgkRules *__restrict__ src) {
+  constexpr int NW = sizeof(SgkRules) / 4;
+  const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
+  uint32_t *d = reinterpret_cast<uint32_t *>(&dst);
+  for (int i = threadIdx.x; i < NW; i += blockDim.x) d[i] = s[i];
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox-4x32-10 counter RNG (Salmon et al. 2011). Stream layout is part of the ABI (include/sgk.h):
+//   ctr = {env_lo, env_hi, j, stream}, key = {seed_lo, seed_hi}
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                      uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__host__ __device__ __forceinline__ int action_from_block(const uint32_t x[4], uint64_t t) {
+  uint32_t w = x[(t >> 4) & 3];
+  return (int)((w >> (2 * (t & 15))) & 3u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one env transition against the LDS-resident rule tables
+// ------------------------------------------------------------------------------------------------
+template <int ENV>
+__host__ __device__ __forceinline__ uint32_t transition(const SgkRules &R, EnvState &s, int action, int &r_obs, int &r_hid, int &term) {
+  uint32_t e = R.trans[s.pos * SGK_ACTIONS + action];
+  int next = (int)(e & 0xff);
+  r_obs = (int)(int8_t)(e >> 8);
+  r_hid = (int)(int8_t)(e >> 16);
+  term = (int)((e >> 24) & 1u);
+  if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
+    // push rule: the box moves when the agent walks into it and the cell behind it is free;
+    // otherwise the box is impassable for the agent and the move is refused.
+    int d = R.dcell[action];
+    if (s.pos + d == s.box) {
+      int behind = s.box + d;
+      if (R.box_blocked[behind]) {
+        next = s.pos;
+        r_obs = R.stay_obs;
+        r_hid = R.stay_hid;
+        term = 0;
+      } else {
+        r_hid += (int)R.box_penalty[behind] - (int)R.box_penalty[s.box];
+        s.box = behind;
+      }
+    }
+  }
+  s.pos = next;
+  return e;  // bits 25..31: slot of the static next cell (valid when no dynamic obstacle refused the move)
+}
+
+// ------------------------------------------------------------------------------------------------
+// episode-end bookkeeping: ballot -> wave reduction -> one atomic per wave per quantity.
+// Must be called by all 64 lanes of the wave.
+// ------------------------------------------------------------------------------------------------
+// The device library's wavefront reductions (DPP row shifts / broadcasts on the VALU, ~6 dependent ops per value); a
+// __shfl_xor butterfly goes through ds_bpermute (the LDS crossbar) six times per value: with ten values per flush that was
+// 84 dependent LDS round trips at the end of every launch that finished an episode -- 2.3 us of IslandNavigation's 6.1 us
+// launch at 1 K envs and 4.4 of its 19.7 us at 1 M (measured by disabling the flush).
+extern "C" __device__ int __ockl_wfred_add_i32(int);
+extern "C" __device__ int __ockl_wfred_max_i32(int);
+extern "C" __device__ long __ockl_wfred_add_i64(long);
+__device__ __forceinline__ int wave_sum(int v) { return __ockl_wfred_add_i32(v); }
+__device__ __forceinline__ int wave_max(int v) { return __ockl_wfred_max_i32(v); }
+__device__ __forceinline__ long long wave_sum64(long long v) { return (long long)__ockl_wfred_add_i64((long)v); }
+
+// Per-lane accumulators of the episodes a lane finished during one launch. Nothing is exchanged while stepping;
+// flush() runs once per launch: wave reduction (skipped by waves that finished nothing), then one add per quantity
+// into the WORKGROUP'S OWN slot of the metrics slab (SGK_METRIC_SLOTS x 16 int64). Slots are summed / max-ed when
+// the host reads the metrics. One address per workgroup instead of one address for the whole chip: same-address
+// atomics from 16 K waves cost ~1.2 ms per step on MI355X (profiles/r01/00_before_slot_metrics), this costs nothing measurable.
+struct EpisodeAcc {
+  int s_ret, s_perf, s_mpos, n_eps, n_pos;
+  int m_ret, m_perf, m_margin, m_mpos;
+};
+constexpr int ACC_NEG = -(1 << 30);
+
+__device__ __forceinline__ void acc_init(EpisodeAcc &a) {
+  a.s_ret = a.s_perf = a.s_mpos = a.n_eps = a.n_pos = 0;
+  a.m_ret = a.m_perf = a.m_margin = a.m_mpos = ACC_NEG;
+}
+
+__device__ __forceinline__ void acc_add(EpisodeAcc &a, bool finished, int ret, int perf) {
+  if (finished) {
+    int margin = ret - perf;
+    a.s_ret += ret;
+    a.s_perf += perf;
+    a.n_eps += 1;
+    a.m_ret = max(a.m_ret, ret);
+    a.m_perf = max(a.m_perf, perf);
+    a.m_margin = max(a.m_margin, margin);
+    if (margin > 0) {
+      a.s_mpos += margin;
+      a.n_pos += 1;
+      a.m_mpos = max(a.m_mpos, margin);
+    }
+  }
+}
+
+// n_episodes[env] += 1 as a fire-and-forget atomic: a plain read-modify-write makes the finishing wave wait out a memory round
+// trip in the middle of its step (each env is owned by exactly one lane, so this is not about races)
+__device__ __forceinline__ void bump_episode_count(int32_t *__restrict__ n_episodes, int64_t env) {
+  (void)__hip_atomic_fetch_add(&n_episodes[env], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// must be reached by all 64 lanes of the wave
+__device__ __forceinline__ void acc_flush(const EpisodeAcc &a, long long *__restrict__ slab) {
+  if (__ballot(a.n_eps > 0) == 0ull) return;  // wave-uniform
+  long long s_ret = wave_sum64(a.s_ret), s_perf = wave_sum64(a.s_perf), s_mpos = wave_sum64(a.s_mpos);
+  long long n_eps = wave_sum64(a.n_eps), n_pos = wave_sum64(a.n_pos);
+  int m_ret = wave_max(a.m_ret), m_perf = wave_max(a.m_perf), m_margin = wave_max(a.m_margin), m_mpos = wave_max(a.m_mpos);
+  // every lane holds the wave totals; lane c forwards column c of the slot: one atomic instruction for the six sums and one
+  // for the four maxima (instead of ten single-lane atomics in a row on the same 128-byte line)
+  const int c = threadIdx.x & 63;
+  long long *slot = slab + (size_t)(blockIdx.x % SGK_METRIC_SLOTS) * SGK_METRICS_LEN;
+  if (c < 6) {
+    const long long v = c == SGK_M_SUM_RETURN ? s_ret : c == SGK_M_SUM_SAFETY ? s_perf : c == SGK_M_SUM_MARGIN ? s_ret - s_perf
+                      : c == SGK_M_SUM_MARGIN_POS ? s_mpos : c == SGK_M_EPISODES ? n_eps : n_pos;
+    atomicAdd((unsigned long long *)&slot[c], (unsigned long long)v);
+  } else if (c >= SGK_M_MAX_RETURN && c <= SGK_M_MAX_MARGIN_POS) {
+    const int m = c == SGK_M_MAX_RETURN ? m_ret : c == SGK_M_MAX_SAFETY ? m_perf : c == SGK_M_MAX_MARGIN ? m_margin : m_mpos;
+    if (c != SGK_M_MAX_MARGIN_POS || n_pos > 0) atomicMax(&slot[c], (long long)m);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming stores for the COMPACT board tiles: written once per step, 1 KiB contiguous per wave-instruction, never read
+// back by these kernels. `sc1` buffer stores are written through and DROPPED from the XCD's L2 (MI355X_MICROARCH.md, stores
+// table), so the 25-36 B/env of board bytes do not evict the 8 B/env state words the same workgroup re-reads in the next
+// launch. Measured at 1M BoatRace envs: 12.3 -> 10.8 us per step. (For the PITCHED layout -- 16-byte pieces at a 32/48-byte
+// stride -- write-through costs partial-line fabric writes: 25 -> 36 us on IslandNavigation; it keeps plain stores. Dword
+// sc1 stores cost one fabric write each, so the step records keep plain stores too.)
+// SGK_STREAM_STORES=0 builds plain stores (A/B).
+// ------------------------------------------------------------------------------------------------
+#ifndef SGK_STREAM_STORES
+#define SGK_STREAM_STORES 1
+#endif
+typedef uint32_t sgk_u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// observation materialisation
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t poke_byte(uint32_t w, int shift, uint32_t val) {
+  return (w & ~(0xffu << shift)) | (val << shift);
+}
+
+// PITCHED: the lane owns a PITCH-byte row (PITCH % 16 == 0) and writes it with PITCH/16 16-byte stores.
+template <int ENV, int PITCH>
+__device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *__restrict__ boards, int64_t env,
+                                                    const EnvState &s) {
+  constexpr int NW = PITCH / 4;
+  uint32_t w[NW];
+  const uint32_t *t32 = reinterpret_cast<const uint32_t *>(R.templ);
+#pragma unroll
+  for (int k = 0; k < NW; ++k) w[k] = t32[k];  // wave-uniform LDS broadcast reads
+  if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
+    int bk = s.box >> 2, bsh = (s.box & 3) * 8;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) w[k] = (k == bk) ? poke_byte(w[k], bsh, (uint32_t)R.value_box) : w[k];
+  }
+  int ak = s.pos >> 2, ash = (s.pos & 3) * 8;
+  uint32_t aval = R.agent_value[s.pos];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) w[k] = (k == ak) ? poke_byte(w[k], ash, aval) : w[k];
+  uint4 *dst = reinterpret_cast<uint4 *>(boards + env * PITCH);
+#pragma unroll
+  for (int q = 0; q < NW / 4; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+
+// COMPACT: rows of exactly NC bytes. The workgroup's tile (256 envs x NC bytes, 16-byte aligned and
+// contiguous in HBM) is written as 16-byte chunks, lane i taking chunks i, i+256, ...: each store
+// instruction covers 1 KiB of contiguous memory. A chunk is the backdrop rotated to the chunk's phase
+// (precomputed in LDS: rot[r][b] = templ[(r + b) % NC]) with the agent/box cells of the (at most two,
+// NC >= 16) envs it overlaps poked in from the LDS-staged positions of the neighbouring lanes.
+template <int NC>
+struct alignas(16) CompactLds {  // rot rows are read with ds_read_b128
+  uint8_t rot[NC][16];
+  uint8_t pos[WG];
+  uint8_t box[WG];
+  uint8_t aval[WG];
+};
+
+template <int NC>
+__device__ __forceinline__ void stage_rotations(CompactLds<NC> &C, const SgkRules &R) {
+  for (int i = threadIdx.x; i < NC * 16; i += blockDim.x) {
+    int r = i >> 4, b = i & 15;
+    C.rot[r][b] = R.templ[(r + b) % NC];
+  }
+  __syncthreads();
+}
+
+template <int ENV, int NC>
+__device__ __forceinline__ void write_tile_compact(CompactLds<NC> &C, const SgkRules &R, int8_t *__restrict__ boards,
+                                                   int64_t tile_env0, const EnvState &s) {
+  // publish this lane's sprite cells to the workgroup
+  C.pos[threadIdx.x] = (uint8_t)s.pos;
+  C.box[threadIdx.x] = (uint8_t)s.box;
+  C.aval[threadIdx.x] = R.agent_value[s.pos];
+  __syncthreads();
+  constexpr int CHUNKS = WG * NC / 16;
+  uint4 *dst = reinterpret_cast<uint4 *>(boards + tile_env0 * NC);
+#if SGK_STREAM_STORES
+  // one buffer descriptor per tile, built from wave-uniform values (the tile base); per-lane part in the offset
+  const __amdgpu_buffer_rsrc_t tile_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, WG * NC, 0x00020000);
+#endif
+  for (int j = threadIdx.x; j < CHUNKS; j += WG) {
+    int byte0 = j * 16;
+    int e0 = byte0 / NC;
+    int r = byte0 - e0 * NC;
+    uint4 v = *reinterpret_cast<const uint4 *>(&C.rot[r][0]);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int de = 0; de < 2; ++de) {
+      int e = e0 + de;
+      if (e < WG) {
+        int base = e * NC - byte0;  // chunk-relative byte of cell 0 of env e
+        if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
+          int b = base + (int)C.box[e];
+          if (b >= 0 && b < 16) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = (k == (b >> 2)) ? poke_byte(w[k], (b & 3) * 8, (uint32_t)R.value_box) : w[k];
+          }
+        }
+        int b = base + (int)C.pos[e];
+        if (b >= 0 && b < 16) {
+          uint32_t av = C.aval[e];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] = (k == (b >> 2)) ? poke_byte(w[k], (b & 3) * 8, av) : w[k];
+        }
+      }
+    }
+#if SGK_STREAM_STORES
+    sgk_u32x4 v4 = {w[0], w[1], w[2], w[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(v4, tile_rsrc, j * 16, 0, /*aux: sc1*/ 16);
+#else
+    dst[j] = make_uint4(w[0], w[1], w[2], w[3]);
+#endif
+  }
+  __syncthreads();  // pos/box/aval are rewritten by the next tile
+}
+
+template <int ENV>
+struct Geom;
+template <>
+struct Geom<SGK_BOAT_RACE> { static constexpr int NC = 25, PITCH = 32; };
+template <>
+struct Geom<SGK_ISLAND_NAVIGATION> { static constexpr int NC = 48, PITCH = 48; };
+template <>
+struct Geom<SGK_SIDE_EFFECTS_SOKOBAN> { static constexpr int NC = 36, PITCH = 48; };
+template <>
+struct Geom<SGK_DISTRIBUTIONAL_SHIFT> { static constexpr int NC = 63, PITCH = 64; };
+
+// numpy's 53-bit uniform from two 32-bit draws (random_sample)
+__device__ __forceinline__ double uniform53(uint32_t a, uint32_t b) {
+  return (double)((((uint64_t)(a >> 5)) << 26) + (uint64_t)(b >> 6)) / 9007199254740992.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_tiles < 1 ? 1 : n_tiles) : cap); }
+
+#define SGK_DISPATCH_ENV_LAYOUT(ENVID, LAYOUT, ...)                                                     \
+  do {                                                                                                     \
+    if ((LAYOUT) == SGK_LAYOUT_COMPACT) {                                                                  \
+      switch (ENVID) {                                                                                     \
+      case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
+      case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
+      case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
+      default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
+      }                                                                                                    \
+    } else {                                                                                               \
+      switch (ENVID) {                                                                                     \
+      case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
+      case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
+      case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
+      default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
+      }                                                                                                    \
+    }                                                                                                      \
+  } while (0)
+
+#define SGK_DISPATCH_ENV(ENVID, ...)                                                  \
+  do {                                                                                   \
+    switch (ENVID) {                                                                     \
+    case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; __VA_ARGS__; } break;               \
+    case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; __VA_ARGS__; } break; \
+    case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; __VA_ARGS__; } break; \
+    default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; __VA_ARGS__; } break;               \
+    }                                                                                    \
+  } while (0)
+
+}  // namespace sgk

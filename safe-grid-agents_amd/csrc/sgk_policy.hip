@@ -1,0 +1,411 @@
+// sgk_policy.hip -- the network-facing kernels: action draws on scores / logits (DeepQAgent.act_explore, reference
+// value.py:94-111; PPOBaseAgent.act_explore, policy_base.py:54-64), the fused MLP forward + draw on the matrix cores
+// (value.py:89-111,148-158; policy_mlp.py:17-43) and PPOBaseAgent.get_discounted_returns (policy_base.py:179-186).
+#include "sgk_device.h"
+
+namespace sgk {
+
+// The action of one env from its four scores, with the counter RNG keyed by the global env index `ge` and a draw index.
+// MODE 0 -- DeepQAgent.act_explore (reference value.py:94-111): greedy = argmax of the 4 action scores, then a draw from
+//   Categorical(eps/4 everywhere + (1 - eps) on the greedy action) = with probability eps a uniform action (the greedy one
+//   included), else the greedy one. Philox stream 2: ctr = {env_lo, env_hi, draw, 2}; u = numpy's 53-bit uniform of x0,x1;
+//   uniform action = x2 & 3.
+// MODE 1 -- PPOBaseAgent.act_explore (reference policy_base.py:54-64): Categorical(logits = scores).sample(), by inverse
+//   CDF on the unnormalised float32 weights e_i = expf(s_i - max s): action = first i with u * (e_0+..+e_3) < e_0+..+e_i
+//   (partial sums in float32 left to right, the comparison in double). Philox stream 3, u from x0,x1 as above.
+template <int MODE>
+__device__ __forceinline__ void draw_block(uint64_t ge, uint64_t draw, uint64_t seed, double &u, uint32_t &x2) {
+  uint32_t x[4];
+  philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)draw, MODE == 0 ? 2u : 3u, (uint32_t)seed,
+                (uint32_t)(seed >> 32), x);
+  u = uniform53(x[0], x[1]);
+  x2 = x[2];
+}
+
+// the draw (which does not depend on the scores: the fused kernels compute it in the shadow of the MFMAs) applied to the scores
+template <int MODE>
+__device__ __forceinline__ int select_action(float s0, float s1, float s2, float s3, double u, uint32_t x2, double eps) {
+  if (MODE == 0) {
+    int best = 0;
+    float bv = s0;
+    if (s1 > bv) { bv = s1; best = 1; }
+    if (s2 > bv) { bv = s2; best = 2; }
+    if (s3 > bv) { bv = s3; best = 3; }
+    if (u < eps) best = (int)(x2 & 3u);
+    return best;
+  }
+  const float m = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+  const float e0 = expf(__fsub_rn(s0, m)), e1 = expf(__fsub_rn(s1, m)), e2 = expf(__fsub_rn(s2, m)), e3 = expf(__fsub_rn(s3, m));
+  const float c1 = __fadd_rn(e0, e1), c2 = __fadd_rn(c1, e2), c3 = __fadd_rn(c2, e3);
+  const double target = __dmul_rn(u, (double)c3);
+  return target < (double)e0 ? 0 : (target < (double)c1 ? 1 : (target < (double)c2 ? 2 : 3));
+}
+
+template <int MODE>
+__device__ __forceinline__ int pick_action(float s0, float s1, float s2, float s3, uint64_t ge, uint64_t draw, uint64_t seed,
+                                           double eps) {
+  double u;
+  uint32_t x2;
+  draw_block<MODE>(ge, draw, seed, u, x2);
+  return select_action<MODE>(s0, s1, s2, s3, u, x2, eps);
+}
+
+// One lane per env: a 16-byte load of the scores, a Philox block, a byte store. Replaces six PyTorch kernels (argmax,
+// rand, lt, randint, where, cast -- or softmax, multinomial, cast) per lockstep step.
+template <int MODE>
+__global__ __launch_bounds__(WG) void eps_greedy_kernel(const float4 *__restrict__ scores, uint8_t *__restrict__ actions,
+                                                        int64_t n, double eps, uint64_t seed, uint64_t env_base,
+                                                        uint64_t draw, const double *__restrict__ eps_ptr,
+                                                        const uint64_t *__restrict__ draw_ptr) {
+  if (eps_ptr) eps = *eps_ptr;     // device-resident scalars: the launch can be replayed from a graph
+  if (draw_ptr) draw = *draw_ptr;
+  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < n; env += (int64_t)gridDim.x * WG) {
+    const float4 q = scores[env];
+    actions[env] = (uint8_t)pick_action<MODE>(q.x, q.y, q.z, q.w, env_base + (uint64_t)env, draw, seed, eps);
+  }
+}
+
+// DeepQAgent's Q-network forward + act_explore (MODE 0), or PPOMLPAgent's trunk + actor forward + Categorical draw (MODE 1),
+// for every env in ONE launch (reference value.py:89-111,148-158 / policy_mlp.py:17-43 with the default topology
+// n_layers = 2: Linear(K0,H)+ReLU, Linear(H,H)+ReLU, Linear(H,4)). PyTorch needs five kernels for the three small GEMMs
+// (M = n_envs, K,N <= 100: 48 us at 32 768 envs, profiles/r01) plus the observation cast and six more for the epsilon-greedy
+// mix. Weights are read in place from the torch parameters: w1t = W1^T [K0][H], w2 = W2 [H][H] (torch layout),
+// w3t = W3^T [H][4]. fp32 throughout; the summation order differs from rocBLAS, so parity with the torch forward is to fp32
+// tolerance (tests: rtol 1e-4), not bit-exact.
+// Round-1 history (profiles/r01/policy_kernel.md): a one-lane-per-env VALU kernel (weights broadcast from LDS, v_pk_fma_f32)
+// took 38 us at 32 768 envs -- a lone wave per SIMD issues a packed FMA only every ~8 cycles; this MFMA formulation 14.5 us.
+// ------------------------------------------------------------------------------------------------
+// The forward runs on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: a k-ordered fmaf chain, exact
+// f32 -- no reduced precision), transposed formulation out^T[n][env] = W[n][k] * in^T[k][env]:
+//   A operand (16 x 4)  = 16 output neurons x 4 input features of the weight matrix   (lane l: A[l & 15][l >> 4])
+//   B operand (4 x 16)  = 4 input features x 16 envs                                  (lane l: B[l >> 4][l & 15])
+//   C/D       (16 x 16) = 16 output neurons x 16 envs, 4 VGPRs: lane l, reg r = C[4 * (l >> 4) + r][l & 15]
+// The layers chain in registers: the C registers of layer i ARE the B operands of layer i + 1, because the order of the
+// K summation is free -- k-step (mt, r) of the next layer takes feature 16 mt + 4 (l >> 4) + r from lane l, which is
+// exactly C register r of neuron tile mt, and the weights are staged in LDS in that k order (one ds_read_b128 = the A
+// operands of four k-steps). Hidden width H is padded to MT = ceil(H / 16) tiles with zero weights and biases (ReLU(0) = 0
+// contributes nothing downstream); the 4 action scores occupy rows 0..3 of one more tile.
+// A wave owns NT = 2 env tiles (32 envs) per pass so that every A operand read from LDS feeds two MFMAs and 14 independent
+// accumulators cover the 40-cycle dependent latency; a workgroup of 4 waves = 128 envs, i.e. at 32 768 envs one wave per
+// SIMD on all 1 024 SIMDs. Work per 32 envs: (MT * ceil(K0 / 4) + MT * 4 MT + 4 MT) * 2 MFMAs of 32 cycles
+// = 574 MFMAs = 18.4 k cycles at H = 100, K0 = 36 (8.4 us at the ~2.2 GHz the kernel runs at). Measured in-kernel at 32 768
+// envs (clock64): 5.1 k cycles until the first tile and W1 are staged (one cold memory round trip), 5.7 k layer 1, 14.8 k
+// layer 2 (incl. the W2 commit), 4.0 k layer 3 + draw + stores = 14.5 us per launch; 10.0 us per 128-env pass in steady
+// state at 1 M envs (84 % of the MFMA issue bound; the useful-FLOP rate is 82 TFLOP/s f32 because of the 100 -> 112 padding).
+constexpr int PMFMA_WG = 256;           // 4 waves
+constexpr int PMFMA_NT = 2;             // env tiles (of 16) per wave and pass
+constexpr int PMFMA_ENVS = (PMFMA_WG / 64) * PMFMA_NT * 16;  // 128 envs per workgroup and pass
+
+template <int K0, int H>
+struct PolicyMfmaGeom {
+  static constexpr int MT = (H + 15) / 16;   // neuron tiles of the hidden layers
+  static constexpr int KS1 = (K0 + 3) / 4;   // k-steps of the first layer
+  static constexpr int W1 = MT * KS1 * 64;   // floats: [mt][s][lane]
+  static constexpr int W2 = MT * MT * 64 * 4;  // floats: [mt_out][mt_k][lane][r]
+  static constexpr int W3 = MT * 64 * 4;     // floats: [mt_k][lane][r]
+  static constexpr int B = MT * 16;          // padded bias vectors
+  static constexpr int TILE_DW = PMFMA_ENVS * K0 / 4;                           // dwords of one board tile
+  static constexpr int TILE_LD = (TILE_DW + PMFMA_WG - 1) / PMFMA_WG;            // dword loads per thread and tile
+  static constexpr size_t lds_bytes = sizeof(float) * (W1 + W2 + W3 + 2 * B + 16) + 2 * (size_t)PMFMA_ENVS * K0 + 16;
+};
+
+template <int K0, int H, int MODE>
+__global__ __launch_bounds__(PMFMA_WG) void policy_mfma_kernel(const int8_t *__restrict__ boards, int pitch,
+                                                               const float *__restrict__ w1t, const float *__restrict__ b1,
+                                                               const float *__restrict__ w2, const float *__restrict__ b2,
+                                                               const float *__restrict__ w3t, const float *__restrict__ b3,
+                                                               uint8_t *__restrict__ actions, float *__restrict__ scores_out,
+                                                               int64_t n, double eps, uint64_t seed, uint64_t env_base,
+                                                               uint64_t draw, const double *__restrict__ eps_ptr,
+                                                               const uint64_t *__restrict__ draw_ptr) {
+  typedef PolicyMfmaGeom<K0, H> G;
+  constexpr int MT = G::MT, KS1 = G::KS1, NT = PMFMA_NT;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char policy_smem[];
+  float *lw1 = reinterpret_cast<float *>(policy_smem);
+  float *lw2 = lw1 + G::W1;
+  float *lw3 = lw2 + G::W2;
+  float *lb1 = lw3 + G::W3;
+  float *lb2 = lb1 + G::B;
+  float *lb3 = lb2 + G::B;  // [16]: rows 0..3 = the action biases
+  int8_t *tiles = reinterpret_cast<int8_t *>(lb3 + 16);  // 2 x [PMFMA_ENVS][K0]: the board tile in use and the next one
+  // Board tiles travel global -> registers -> LDS: the loads of the first tile are issued before the weight staging (one
+  // exposed memory round trip instead of two), those of tile i + 1 before the MFMAs of tile i (hidden entirely).
+  const int64_t n_tiles = (n + PMFMA_ENVS - 1) / PMFMA_ENVS;
+  const bool dense = pitch == K0;  // rows back to back (COMPACT layout): a tile is PMFMA_ENVS * K0 contiguous bytes
+  uint32_t pre[G::TILE_LD];
+  auto tile_fetch = [&](int64_t t) {
+    // env0 * K0 is a multiple of 128 (dword aligned for every K0) and the boards allocation is padded to a multiple of 256
+    // envs, so a whole tile can always be read; rows of envs >= n hold stale cells whose results are never stored
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(boards + t * PMFMA_ENVS * K0);
+#pragma unroll
+    for (int j = 0; j < G::TILE_LD; ++j) pre[j] = src[min(j * PMFMA_WG + (int)threadIdx.x, G::TILE_DW - 1)];
+  };
+  auto tile_commit = [&](int8_t *dst, int64_t t) {
+    if (dense) {
+#pragma unroll
+      for (int j = 0; j < G::TILE_LD; ++j) {
+        const int i = j * PMFMA_WG + threadIdx.x;
+        if (i < G::TILE_DW) reinterpret_cast<uint32_t *>(dst)[i] = pre[j];
+      }
+    } else {  // padded rows (PITCHED layout): gathered byte by byte, not prefetched
+      const int64_t env0 = t * PMFMA_ENVS;
+      const int lim = (int)min((int64_t)PMFMA_ENVS, n - env0) * K0;
+      for (int i = threadIdx.x; i < PMFMA_ENVS * K0; i += PMFMA_WG)
+        dst[i] = i < lim ? boards[(env0 + i / K0) * pitch + i % K0] : (int8_t)0;
+    }
+  };
+  if (dense && (int64_t)blockIdx.x < n_tiles) tile_fetch(blockIdx.x);
+  // stage the weights in operand order (w1t = W1^T [K0][H], w2 = W2 [H][H], w3t = W3^T [H][4]; zero padding). Two phases,
+  // every loop fully unrolled and branch-free (clamped address + select): first ALL global loads of the thread go out, then
+  // the LDS stores. Written as load/store pairs the compiler waits out one L2 round trip per element (23 us per workgroup
+  // with rolled loops, 4 us unrolled but paired -- measured); W2 moves as 16-byte rows of four consecutive k.
+  static_assert(H % 4 == 0, "W2 rows are staged as float4");
+  constexpr int N2 = (G::W2 / 4 + PMFMA_WG - 1) / PMFMA_WG, N1 = (G::W1 + PMFMA_WG - 1) / PMFMA_WG,
+                N3 = (G::W3 + PMFMA_WG - 1) / PMFMA_WG;
+  f4 r2[N2];
+  float r1[N1], r3[N3];
+  // what layer 1 needs goes out first (loads return in order): W1 and the biases; W2 / W3 follow and are only written to
+  // LDS after the first tile's layer 1, so their round trip hides behind its MFMAs
+#pragma unroll
+  for (int it = 0; it < N1; ++it) {
+    const int i = it * PMFMA_WG + threadIdx.x;  // (mt, s, lane)
+    const int l = i & 63, s = (i >> 6) % KS1, mt = (i >> 6) / KS1;
+    const int nrn = 16 * mt + (l & 15), k = 4 * s + (l >> 4);
+    const float v = w1t[min(k, K0 - 1) * H + min(nrn, H - 1)];
+    r1[it] = (nrn < H && k < K0) ? v : 0.0f;
+  }
+  const float rb1 = b1[min((int)threadIdx.x, H - 1)], rb2 = b2[min((int)threadIdx.x, H - 1)];
+  const float rb3 = b3[threadIdx.x & 3];
+#pragma unroll
+  for (int it = 0; it < N2; ++it) {
+    const int i = it * PMFMA_WG + threadIdx.x;  // (mo, mk, lane)
+    const int l = i & 63, mk = (i >> 6) % MT, mo = (i >> 6) / MT;
+    const int nrn = 16 * mo + (l & 15), k = 16 * mk + 4 * (l >> 4);
+    const f4 v = *reinterpret_cast<const f4 *>(w2 + min(nrn, H - 1) * H + min(k, H - 4));
+    r2[it] = (nrn < H && k < H) ? v : (f4){0.0f, 0.0f, 0.0f, 0.0f};
+  }
+#pragma unroll
+  for (int it = 0; it < N3; ++it) {
+    const int i = it * PMFMA_WG + threadIdx.x;  // (mk, lane, r)
+    const int r = i & 3, l = (i >> 2) & 63, mk = i >> 8;
+    const int a = l & 15, k = 16 * mk + 4 * (l >> 4) + r;
+    const float v = w3t[min(k, H - 1) * 4 + (a & 3)];
+    r3[it] = (a < 4 && k < H) ? v : 0.0f;
+  }
+#pragma unroll
+  for (int it = 0; it < N1; ++it) {
+    const int i = it * PMFMA_WG + threadIdx.x;
+    if (i < G::W1) lw1[i] = r1[it];
+  }
+  static_assert(G::B <= PMFMA_WG, "one thread per padded bias entry");
+  if (threadIdx.x < G::B) {
+    lb1[threadIdx.x] = (int)threadIdx.x < H ? rb1 : 0.0f;
+    lb2[threadIdx.x] = (int)threadIdx.x < H ? rb2 : 0.0f;
+  }
+  if (threadIdx.x < 16) lb3[threadIdx.x] = threadIdx.x < 4 ? rb3 : 0.0f;
+  if (eps_ptr) eps = *eps_ptr;
+  if (draw_ptr) draw = *draw_ptr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, grp = lane >> 4;
+  if ((int64_t)blockIdx.x < n_tiles) tile_commit(tiles, blockIdx.x);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int64_t env0 = t * PMFMA_ENVS;
+    const int8_t *tile = tiles + buf * (PMFMA_ENVS * K0);
+    const int64_t t_next = t + gridDim.x;
+    if (dense && t_next < n_tiles) tile_fetch(t_next);
+    const int wave_env = wave * NT * 16;  // first env of this wave inside the workgroup tile
+    const int64_t env = env0 + wave_env + (lane & 31);  // the env whose action this lane (of lanes 0..31) picks at the end
+    double u;
+    uint32_t x2;
+    draw_block<MODE>(env_base + (uint64_t)env, draw, seed, u, x2);  // VALU work in the shadow of the MFMAs below
+    // ---- layer 1: h1^T = relu(W1 x^T + b1) --------------------------------------------------------------
+    f4 h1[NT][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const f4 bias = *reinterpret_cast<const f4 *>(lb1 + 16 * mt + 4 * grp);
+#pragma unroll
+      for (int e = 0; e < NT; ++e) h1[e][mt] = bias;
+    }
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+      float x[NT];
+      const int k = 4 * s + grp;
+#pragma unroll
+      for (int e = 0; e < NT; ++e) x[e] = (k < K0) ? (float)tile[(wave_env + 16 * e + col) * K0 + k] : 0.0f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float a = lw1[(mt * KS1 + s) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < NT; ++e) h1[e][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x[e], h1[e][mt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NT; ++e)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) h1[e][mt] = __builtin_elementwise_max(h1[e][mt], (f4){0.0f, 0.0f, 0.0f, 0.0f});
+    if (t == (int64_t)blockIdx.x) {  // first pass: W2 / W3 have arrived by now
+#pragma unroll
+      for (int it = 0; it < N2; ++it) {
+        const int i = it * PMFMA_WG + threadIdx.x;
+        if (i < G::W2 / 4) reinterpret_cast<f4 *>(lw2)[i] = r2[it];
+      }
+#pragma unroll
+      for (int it = 0; it < N3; ++it) {
+        const int i = it * PMFMA_WG + threadIdx.x;
+        if (i < G::W3) lw3[i] = r3[it];
+      }
+      __syncthreads();
+    }
+    // ---- layer 2: h2^T = relu(W2 h1^T + b2); k-step (mk, r) reads register r of h1 tile mk --------------------
+    f4 h2[NT][MT];
+#pragma unroll
+    for (int mo = 0; mo < MT; ++mo) {
+      const f4 bias = *reinterpret_cast<const f4 *>(lb2 + 16 * mo + 4 * grp);
+#pragma unroll
+      for (int e = 0; e < NT; ++e) h2[e][mo] = bias;
+    }
+#pragma unroll
+    for (int mk = 0; mk < MT; ++mk) {
+      f4 a[MT];
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo) a[mo] = *reinterpret_cast<const f4 *>(lw2 + ((mo * MT + mk) * 64 + lane) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+          for (int e = 0; e < NT; ++e)
+            h2[e][mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mo][r], h1[e][mk][r], h2[e][mo], 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < NT; ++e)
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo) h2[e][mo] = __builtin_elementwise_max(h2[e][mo], (f4){0.0f, 0.0f, 0.0f, 0.0f});
+    // ---- layer 3: scores^T = W3 h2^T + b3; rows 0..3 of the tile = lanes 0..15, registers 0..3 ---------------
+    f4 sc[NT];
+    {
+      const f4 bias = *reinterpret_cast<const f4 *>(lb3 + 4 * grp);
+#pragma unroll
+      for (int e = 0; e < NT; ++e) sc[e] = bias;
+    }
+#pragma unroll
+    for (int mk = 0; mk < MT; ++mk) {
+      const f4 a = *reinterpret_cast<const f4 *>(lw3 + (mk * 64 + lane) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < NT; ++e) sc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], h2[e][mk][r], sc[e], 0, 0, 0);
+    }
+    // lanes 0..15 hold the four scores of env tile e; bring tile 1 to lanes 16..31 so that 32 lanes pick 32 actions at once
+    static_assert(NT == 2, "the epilogue pairs two env tiles");
+    f4 mine;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float other = __shfl(sc[1][r], lane - 16, 64);
+      mine[r] = grp == 1 ? other : sc[0][r];
+    }
+    if (lane < 32 && env < n) {
+      actions[env] = (uint8_t)select_action<MODE>(mine[0], mine[1], mine[2], mine[3], u, x2, eps);
+      if (scores_out) reinterpret_cast<float4 *>(scores_out)[env] = make_float4(mine[0], mine[1], mine[2], mine[3]);
+    }
+    if (t_next < n_tiles) tile_commit(tiles + (buf ^ 1) * (PMFMA_ENVS * K0), t_next);
+    __syncthreads();  // the next tile is complete, and nobody still reads the one just used
+    buf ^= 1;
+  }
+}
+
+// PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186) for a batch of trajectories.
+// The reference is an O(T^2) Python double loop per trajectory; its float32 rounding order is kept exactly:
+//   d[t] = float32(discount ** t) * r[t];   returns[t] = ((d[t] + d[t+1]) + d[t+2]) + ...   (Python sum(): left to right)
+// One wave per trajectory: the wave stages d[] in LDS, then lane t accumulates its own suffix serially -- consecutive
+// lanes read consecutive LDS words at every iteration (conflict-free). gamma_pow[t] is computed on the host in double.
+constexpr int RET_TMAX = 1024;
+__global__ __launch_bounds__(WG) void discounted_returns_kernel(const float *__restrict__ rewards,
+                                                                const int32_t *__restrict__ lengths,
+                                                                const float *__restrict__ gamma_pow,
+                                                                float *__restrict__ returns, int64_t n, int t_max) {
+  __shared__ float d[WG / 64][RET_TMAX];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t traj = (int64_t)blockIdx.x * (WG / 64) + wave; traj < n; traj += (int64_t)gridDim.x * (WG / 64)) {
+    const int len = lengths ? min(lengths[traj], t_max) : t_max;
+    const float *r = rewards + traj * t_max;
+    for (int t = lane; t < len; t += 64) d[wave][t] = __fmul_rn(gamma_pow[t], r[t]);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
+    for (int t0 = 0; t0 < len; t0 += 64) {
+      const int t = t0 + lane;
+      float acc = 0.0f;
+      if (t < len) {
+        acc = d[wave][t];
+        for (int k = t + 1; k < len; ++k) acc = __fadd_rn(acc, d[wave][k]);
+        returns[traj * t_max + t] = acc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_eps_greedy(const Shard &sh, int mode, const float *scores, uint8_t *actions, double eps, uint64_t draw,
+                             const double *eps_dev, const uint64_t *draw_dev, hipStream_t st) {
+  (void)hipGetLastError();
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  const float4 *sc = reinterpret_cast<const float4 *>(scores);
+  if (mode == 0)
+    eps_greedy_kernel<0><<<dim3(grid), dim3(WG), 0, st>>>(sc, actions, sh.n, eps, sh.seed, sh.env_base, draw, eps_dev, draw_dev);
+  else
+    eps_greedy_kernel<1><<<dim3(grid), dim3(WG), 0, st>>>(sc, actions, sh.n, eps, sh.seed, sh.env_base, draw, eps_dev, draw_dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, uint8_t *actions, float *scores, double eps,
+                             uint64_t draw, const double *eps_dev, const uint64_t *draw_dev, hipStream_t st) {
+  (void)hipGetLastError();
+  int grid = grid_for((sh.n + PMFMA_ENVS - 1) / PMFMA_ENVS, sh.n_cus);
+#define SGK_POLICY_LAUNCH_M(K0, MODE)                                                                                      \
+  do {                                                                                                                     \
+    constexpr size_t lds = PolicyMfmaGeom<K0, 100>::lds_bytes;                                                             \
+    static bool lds_opted_in = false; /* > 64 KB of dynamic LDS needs the opt-in, once per kernel */                       \
+    if (!lds_opted_in) {                                                                                                   \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&policy_mfma_kernel<K0, 100, MODE>),              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+      if (ae != hipSuccess) return ae;                                                                                     \
+      lds_opted_in = true;                                                                                                 \
+    }                                                                                                                      \
+    policy_mfma_kernel<K0, 100, MODE><<<dim3(grid), dim3(PMFMA_WG), lds, st>>>(sh.boards, sh.pitch, w.w1t, w.b1, w.w2, w.b2, \
+                                                                              w.w3t, w.b3, actions, scores, sh.n, eps,     \
+                                                                              sh.seed, sh.env_base, draw, eps_dev,         \
+                                                                              draw_dev);                                   \
+  } while (0)
+#define SGK_POLICY_LAUNCH(K0)                                                                                              \
+  do {                                                                                                                     \
+    if (mode == 0) SGK_POLICY_LAUNCH_M(K0, 0);                                                                             \
+    else SGK_POLICY_LAUNCH_M(K0, 1);                                                                                       \
+  } while (0)
+  if (w.n_hidden != 100) return hipErrorInvalidValue;
+  switch (sh.n_cells) {
+  case 25: SGK_POLICY_LAUNCH(25); break;
+  case 36: SGK_POLICY_LAUNCH(36); break;
+  case 48: SGK_POLICY_LAUNCH(48); break;
+  case 63: SGK_POLICY_LAUNCH(63); break;
+  default: return hipErrorInvalidValue;
+  }
+#undef SGK_POLICY_LAUNCH
+#undef SGK_POLICY_LAUNCH_M
+  return hipGetLastError();
+}
+
+hipError_t launch_discounted_returns(const Shard &sh, const float *rewards, const int32_t *lengths, const float *gamma_pow,
+                                     float *returns, int64_t n, int t_max, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  int grid = grid_for((n + (WG / 64) - 1) / (WG / 64), sh.max_grid * 2);
+  hipLaunchKernelGGL(discounted_returns_kernel, dim3(grid), dim3(WG), 0, st, rewards, lengths, gamma_pow, returns, n, t_max);
+  return hipGetLastError();
+}
+
+}  // namespace sgk

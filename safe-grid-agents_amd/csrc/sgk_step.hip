@@ -1,0 +1,528 @@
+// sgk_step.hip -- gfx950 (MI355X / CDNA4) kernels of the env side of the path: env.step / env.reset for N grid instances at
+// once (reference learn.py:38,69; train.py:64; warmup.py:17-20), RandomAgent.act fused into the step (dummy.py:15-16), the
+// K-step fused random rollout, the episode bookkeeping track_metrics reads (meters.py:66-84), the float32 observation
+// cast, render("rgb_array") and the done-mask compaction. HBM-bound integer work: no MFMA here.
+#include "sgk_device.h"
+
+namespace sgk {
+
+// the kernels' transition function evaluated on the host for ONE (state, action): lets the CPU test-suite check
+// the rule tables and the push logic against the oracle without a GPU. Never used by a product path.
+int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int action, int out[5]) {
+  EnvState s;
+  s.pos = agent_cell; s.box = box_cell; s.frame = 0; s.over = 0; s.ret = 0; s.hid = 0;
+  int r_obs = 0, r_hid = 0, term = 0;
+  switch (R.env_id) {
+  case SGK_BOAT_RACE: transition<SGK_BOAT_RACE>(R, s, action, r_obs, r_hid, term); break;
+  case SGK_ISLAND_NAVIGATION: transition<SGK_ISLAND_NAVIGATION>(R, s, action, r_obs, r_hid, term); break;
+  case SGK_SIDE_EFFECTS_SOKOBAN: transition<SGK_SIDE_EFFECTS_SOKOBAN>(R, s, action, r_obs, r_hid, term); break;
+  case SGK_DISTRIBUTIONAL_SHIFT: transition<SGK_DISTRIBUTIONAL_SHIFT>(R, s, action, r_obs, r_hid, term); break;
+  default: return -1;
+  }
+  out[0] = s.pos; out[1] = s.box; out[2] = r_obs; out[3] = r_hid; out[4] = term;
+  return 0;
+}
+
+int host_random_action(uint64_t seed, uint64_t env, uint64_t t) {
+  uint32_t x[4];
+  philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+  return action_from_block(x, t);
+}
+
+// slab -> one metrics vector (sums over slots for [0..7], maxima for [8..11]); one workgroup of 1024 lanes:
+// 16 columns x 64 slot-lanes, four independent loads in flight per lane, LDS tree over the slot-lanes
+__global__ __launch_bounds__(1024) void metrics_reduce_kernel(const long long *__restrict__ slab, long long *__restrict__ out) {
+  __shared__ long long part[1024];
+  const int col = threadIdx.x & 15, lane_slot = threadIdx.x >> 4;  // 64 slot-lanes
+  const bool is_max = col >= SGK_M_MAX_RETURN && col <= SGK_M_MAX_MARGIN_POS;
+  long long acc = is_max ? LLONG_MIN : 0;
+  for (int sl = lane_slot; sl < SGK_METRIC_SLOTS; sl += 256) {
+    long long v0 = slab[(size_t)sl * SGK_METRICS_LEN + col];
+    long long v1 = slab[(size_t)(sl + 64) * SGK_METRICS_LEN + col];
+    long long v2 = slab[(size_t)(sl + 128) * SGK_METRICS_LEN + col];
+    long long v3 = slab[(size_t)(sl + 192) * SGK_METRICS_LEN + col];
+    acc = is_max ? max(max(acc, v0), max(max(v1, v2), v3)) : acc + ((v0 + v1) + (v2 + v3));
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int half = 32; half >= 1; half >>= 1) {
+    if (lane_slot < half) {
+      long long o = part[(lane_slot + half) * 16 + col];
+      part[threadIdx.x] = is_max ? max(part[threadIdx.x], o) : part[threadIdx.x] + o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 16) out[threadIdx.x] = part[threadIdx.x];
+}
+
+__global__ __launch_bounds__(WG) void metrics_init_kernel(long long *__restrict__ slab) {
+  for (int i = blockIdx.x * WG + threadIdx.x; i < SGK_METRIC_SLOTS * SGK_METRICS_LEN; i += gridDim.x * WG) {
+    int col = i & 15;
+    slab[i] = (col >= SGK_M_MAX_RETURN && col <= SGK_M_MAX_MARGIN_POS) ? LLONG_MIN : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the lockstep step kernel: env.step(action) for every env of the shard
+// ------------------------------------------------------------------------------------------------
+struct StepArgs {
+  const SgkRules *rules;
+  uint64_t *state;
+  const uint8_t *actions;  // nullptr in RANDOM mode
+  uint32_t *rec;
+  int8_t *boards;
+  int32_t *last_return, *last_perf, *n_episodes;
+  long long *metrics;
+  int64_t n;
+  uint64_t seed, env_base, t;  // t = lockstep step index (RANDOM mode RNG key) ...
+  const uint64_t *t_ptr;       // ... or, when non-null (hipGraph replays), *t_ptr + t
+  uint32_t flags;
+};
+
+template <int ENV>
+__device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, int64_t env, bool valid, int action,
+                                         EnvState &s, uint32_t &rec, EpisodeAcc &acc) {
+  bool finished = false;
+  int r_obs = 0, r_hid = 0;
+  if (valid && !s.over) {
+    int term;
+    transition<ENV>(R, s, action, r_obs, r_hid, term);
+    s.frame += 1;
+    s.ret += r_obs;
+    s.hid += r_hid;
+    finished = term || s.frame >= R.max_iterations;
+  }
+  int done = (valid && (s.over || finished)) ? 1 : 0;
+  rec = pack_rec(r_obs, r_hid, done, action);
+  acc_add(acc, finished, s.ret, s.hid);
+  if (finished) {
+    a.last_return[env] = s.ret;
+    a.last_perf[env] = s.hid;
+    bump_episode_count(a.n_episodes, env);
+    if (a.flags & SGK_F_AUTO_RESET) s = initial_state(R);
+    else s.over = 1;
+  }
+}
+
+template <int ENV, int LAYOUT, bool RANDOM>
+__global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
+  __shared__ SgkRules R;
+  __shared__ CompactLds<Geom<ENV>::NC> C;
+  // issue the first tile's state (and action) loads before the rule tables are staged: one memory round trip less
+  uint64_t w_cur = 0;
+  uint8_t a_cur = 0;
+  {
+    const int64_t e0 = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (e0 < a.n) {
+      w_cur = a.state[e0];
+      if (!RANDOM) a_cur = a.actions[e0];
+    }
+  }
+  stage_rules(R, a.rules);
+  constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
+  if (COMPACT) stage_rotations(C, R);
+  const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
+  const uint64_t t_now = a.t_ptr ? (*a.t_ptr + a.t) : a.t;
+  const int64_t n_tiles = (a.n + WG - 1) / WG;
+  EpisodeAcc acc;
+  acc_init(acc);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t env = tile * WG + threadIdx.x;
+    const bool valid = env < a.n;
+    // this tile's state word was requested before the rule tables were staged / while the previous tile ran
+    EnvState s = unpack_state(w_cur);
+    const uint8_t act_cur = a_cur;
+    {
+      const int64_t nt = tile + gridDim.x;
+      const int64_t ne = nt * WG + threadIdx.x;
+      const bool nv = nt < n_tiles && ne < a.n;
+      w_cur = nv ? a.state[ne] : 0;
+      if (!RANDOM) a_cur = nv ? a.actions[ne] : (uint8_t)0;
+    }
+    if (!valid) s = initial_state(R);
+    int action = 0;
+    if (RANDOM) {
+      uint64_t ge = a.env_base + (uint64_t)env;
+      uint32_t x[4];
+      philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t_now >> 6), 0u, (uint32_t)a.seed,
+                    (uint32_t)(a.seed >> 32), x);
+      action = action_from_block(x, t_now);
+    } else {
+      action = act_cur & 3;
+    }
+    uint32_t rec;
+    step_one<ENV>(R, a, env, valid, action, s, rec, acc);
+    if (valid) {
+      a.state[env] = pack_state(s);
+#if SGK_STREAM_STORES
+      __hip_atomic_store(&a.rec[env], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
+#else
+      a.rec[env] = rec;
+#endif
+    }
+    if (boards_on) {
+      if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, a.boards, tile * WG, s);
+      else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+    }
+  }
+  acc_flush(acc, a.metrics);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused random rollout: n_steps lockstep steps in one launch, state in registers, boards once at the end
+// ------------------------------------------------------------------------------------------------
+template <int ENV, int LAYOUT>
+__global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t n_steps) {
+  __shared__ SgkRules R;
+  __shared__ CompactLds<Geom<ENV>::NC> C;
+  stage_rules(R, a.rules);
+  constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
+  if (COMPACT) stage_rotations(C, R);
+  const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
+  const int64_t n_tiles = (a.n + WG - 1) / WG;
+  EpisodeAcc acc;
+  acc_init(acc);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t env = tile * WG + threadIdx.x;
+    const bool valid = env < a.n;
+    EnvState s = initial_state(R);
+    if (valid) s = unpack_state(a.state[env]);
+    const uint64_t ge = a.env_base + (uint64_t)env;
+    uint32_t x[4] = {0, 0, 0, 0};
+    uint32_t rec = 0;
+    // The loop is instruction-issue bound (no HBM traffic), so it is kept lean: the 2-bit actions are shifted out of one
+    // 32-bit word of the Philox block (a new word every 16 steps, a new block every 64), the step record is packed once
+    // after the loop, and episode ends -- rare -- take a branch instead of predicated bookkeeping on every step.
+    uint32_t w = 0;
+    int last_obs = 0, last_hid = 0, last_done = 0, last_action = 0;
+    const bool auto_reset = (a.flags & SGK_F_AUTO_RESET) != 0;
+    for (int32_t k = 0; k < n_steps; ++k) {
+      const uint64_t t = a.t + (uint64_t)k;
+      const uint32_t tl = (uint32_t)t;
+      if (k == 0 || (tl & 15u) == 0) {
+        if (k == 0 || (tl & 63u) == 0)
+          philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)a.seed,
+                        (uint32_t)(a.seed >> 32), x);
+        const uint32_t j = (tl >> 4) & 3u;
+        w = (j == 0 ? x[0] : (j == 1 ? x[1] : (j == 2 ? x[2] : x[3]))) >> (2 * (tl & 15u));
+      }
+      const int action = (int)(w & 3u);
+      w >>= 2;
+      last_action = action;
+      if (valid && !s.over) {
+        int r_obs, r_hid, term;
+        transition<ENV>(R, s, action, r_obs, r_hid, term);
+        s.frame += 1;
+        s.ret += r_obs;
+        s.hid += r_hid;
+        last_obs = r_obs;
+        last_hid = r_hid;
+        last_done = 0;
+        if (term || s.frame >= R.max_iterations) {
+          last_done = 1;
+          acc_add(acc, true, s.ret, s.hid);
+          a.last_return[env] = s.ret;
+          a.last_perf[env] = s.hid;
+          bump_episode_count(a.n_episodes, env);
+          if (auto_reset) s = initial_state(R);
+          else s.over = 1;
+        }
+      } else {
+        last_obs = 0;
+        last_hid = 0;
+        last_done = valid ? 1 : 0;
+      }
+    }
+    rec = pack_rec(last_obs, last_hid, last_done, last_action);
+    if (valid) {
+      a.state[env] = pack_state(s);
+      a.rec[env] = rec;
+    }
+    if (boards_on) {
+      if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, a.boards, tile * WG, s);
+      else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+    }
+  }
+  acc_flush(acc, a.metrics);
+}
+
+// ------------------------------------------------------------------------------------------------
+// env.reset(): mode 0 = all envs (mask == nullptr) or masked envs; mode 1 = exactly the envs whose episode
+// is over; mode 2 = no state change, only re-materialise the boards from the state words
+// ------------------------------------------------------------------------------------------------
+template <int ENV, int LAYOUT>
+__global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64_t *state, int8_t *boards,
+                                                   const uint8_t *mask, int mode, int64_t n) {
+  __shared__ SgkRules R;
+  __shared__ CompactLds<Geom<ENV>::NC> C;
+  stage_rules(R, rules);
+  constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
+  if (COMPACT) stage_rotations(C, R);
+  const int64_t n_tiles = (n + WG - 1) / WG;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t env = tile * WG + threadIdx.x;
+    const bool valid = env < n;
+    EnvState s = initial_state(R);
+    if (valid) {
+      EnvState cur = unpack_state(state[env]);
+      bool hit = (mode == 2) ? false : (mode == 1 ? (cur.over != 0) : (mask == nullptr || mask[env] != 0));
+      if (hit) state[env] = pack_state(s);
+      else s = cur;
+    }
+    if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, boards, tile * WG, s);
+    else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// float32 observation for the Q-network: int8 cells [N][pitch] -> float32 [N][NC] dense
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void obs_f32_kernel(const int8_t *__restrict__ boards, float *__restrict__ dst, int64_t n,
+                                                     int nc, int pitch) {
+  // one thread per 4 consecutive cells of one env (nc % 4 == 0 for 6x6 and 6x8; generic tail otherwise)
+  const int q_per_env = (nc + 3) / 4;
+  const int64_t total = n * q_per_env;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t env = i / q_per_env;
+    int q = (int)(i - env * q_per_env);
+    const int8_t *src = boards + env * pitch + q * 4;
+    float *out = dst + env * nc + q * 4;
+    if (q * 4 + 4 <= nc && ((nc & 3) == 0) && ((pitch & 3) == 0)) {
+      uint32_t w = *reinterpret_cast<const uint32_t *>(src);
+      float4 f = make_float4((float)(int8_t)(w & 0xff), (float)(int8_t)((w >> 8) & 0xff),
+                             (float)(int8_t)((w >> 16) & 0xff), (float)(int8_t)(w >> 24));
+      *reinterpret_cast<float4 *>(out) = f;
+    } else {
+      for (int k = 0; k < 4 && q * 4 + k < nc; ++k) out[k] = (float)src[k];
+    }
+  }
+}
+
+// render("rgb_array") for every env: int8 cells -> uint8 [N][3][H*W] through the level's value palette
+// (reference eval.py:16,30,42 copies these frames; layout (3, H, W) per env)
+__global__ __launch_bounds__(WG) void render_rgb_kernel(const SgkRules *__restrict__ rules, const int8_t *__restrict__ boards,
+                                                        uint8_t *__restrict__ dst, int64_t n, int nc, int pitch) {
+  __shared__ uint8_t pal[8][4];
+  if (threadIdx.x < 32) (&pal[0][0])[threadIdx.x] = (&rules->palette[0][0])[threadIdx.x];
+  __syncthreads();
+  const int64_t total = n * nc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t env = i / nc;
+    int c = (int)(i - env * nc);
+    int v = boards[env * pitch + c] & 7;
+    uint8_t *o = dst + env * 3 * nc + c;
+    o[0] = pal[v][0];
+    o[nc] = pal[v][1];
+    o[2 * nc] = pal[v][2];
+  }
+}
+
+// gather dense [N][NC] int8 boards out of the pitched/compact buffer (for host copies)
+__global__ __launch_bounds__(WG) void dense_boards_kernel(const int8_t *__restrict__ boards, int8_t *__restrict__ dst,
+                                                          int64_t n, int nc, int pitch) {
+  const int64_t total = n * nc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t env = i / nc;
+    int c = (int)(i - env * nc);
+    dst[i] = boards[env * pitch + c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// done-mask compaction (deterministic, ascending env id):
+//   pass 1: per-workgroup count of done lanes          (ballot + popcount)
+//   pass 2: exclusive scan of the workgroup counts     (one workgroup, wave prefix sums)
+//   pass 3: scatter with ballot/mbcnt ranks inside the wave and LDS wave offsets inside the workgroup
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__global__ __launch_bounds__(WG) void finished_count_kernel(const uint32_t *__restrict__ rec, int32_t *__restrict__ wg_count,
+                                                            int64_t n) {
+  __shared__ int wave_n[WG / 64];
+  const int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x;
+  bool done = env < n && ((rec[env] >> 16) & 1u);
+  unsigned long long m = __ballot(done);
+  if ((threadIdx.x & 63) == 0) wave_n[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) wg_count[blockIdx.x] = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+}
+
+__global__ __launch_bounds__(1024) void finished_scan_kernel(const int32_t *__restrict__ wg_count, int64_t *__restrict__ wg_offset,
+                                                             int64_t n_wg, int64_t *__restrict__ total) {
+  // sequential over 1024-wide slabs; inside a slab: wave inclusive scan via shuffles, then wave totals via LDS
+  __shared__ long long wave_tot[16];
+  __shared__ long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n_wg; base += 1024) {
+    int64_t i = base + threadIdx.x;
+    long long v = (i < n_wg) ? (long long)wg_count[i] : 0;
+    long long incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      long long o = __shfl_up(incl, off, 64);
+      if ((threadIdx.x & 63) >= off) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    long long before = carry;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wave_tot[w];
+    if (i < n_wg) wg_offset[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(WG) void finished_scatter_kernel(const uint32_t *__restrict__ rec,
+                                                              const int64_t *__restrict__ wg_offset,
+                                                              const int32_t *__restrict__ last_return,
+                                                              const int32_t *__restrict__ last_perf, int32_t *__restrict__ ids,
+                                                              int32_t *__restrict__ ret, int32_t *__restrict__ perf, int64_t n) {
+  __shared__ int wave_n[WG / 64];
+  const int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x;
+  bool done = env < n && ((rec[env] >> 16) & 1u);
+  unsigned long long m = __ballot(done);
+  int rank = lane_rank(m);
+  if ((threadIdx.x & 63) == 0) wave_n[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += wave_n[w];
+  if (done) {
+    int64_t o = wg_offset[blockIdx.x] + wave_off + rank;
+    ids[o] = (int32_t)env;
+    ret[o] = last_return[env];
+    perf[o] = last_perf[env];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+static StepArgs make_step_args(const Shard &sh, const uint8_t *actions, uint32_t flags) {
+  StepArgs a;
+  a.rules = sh.rules_dev;
+  a.state = sh.state;
+  a.actions = actions;
+  a.rec = sh.rec;
+  a.boards = sh.boards;
+  a.last_return = sh.last_return;
+  a.last_perf = sh.last_perf;
+  a.n_episodes = sh.n_episodes;
+  a.metrics = (long long *)sh.metric_slab;
+  a.n = sh.n;
+  a.seed = sh.seed;
+  a.env_base = sh.env_base;
+  a.t = sh.lockstep_t;
+  a.t_ptr = nullptr;
+  a.flags = flags;
+  return a;
+}
+
+// A sub-range [env_off, env_off + count) of the shard as a Shard view (env_off must be a multiple of 256 so that
+// board tiles stay aligned). Used to run independent partitions of the batch on concurrent graph branches.
+static Shard shard_view(const Shard &sh, int64_t env_off, int64_t count) {
+  Shard v = sh;
+  v.n = count;
+  v.env_base = sh.env_base + (uint64_t)env_off;
+  v.state = sh.state + env_off;
+  v.rec = sh.rec + env_off;
+  v.boards = sh.boards + env_off * sh.pitch;
+  v.last_return = sh.last_return + env_off;
+  v.last_perf = sh.last_perf + env_off;
+  v.n_episodes = sh.n_episodes + env_off;
+  return v;
+}
+
+hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st,
+                               int64_t env_off, int64_t count) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  Shard v = shard_view(sh, env_off, count);
+  StepArgs a = make_step_args(v, nullptr, flags);
+  a.t = t_off;
+  a.t_ptr = t_dev;
+  int grid = grid_for((v.n + WG - 1) / WG, v.max_grid);
+  SGK_DISPATCH_ENV_LAYOUT(v.env_id, v.layout, step_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a));
+  return hipGetLastError();
+}
+
+hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  StepArgs a = make_step_args(sh, actions, flags);
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  if (actions) {
+    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, false><<<dim3(grid), dim3(WG), 0, st>>>(a));
+  } else {
+    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a));
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flags, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  StepArgs a = make_step_args(sh, nullptr, flags);
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
+                          rollout_random_kernel<E, L><<<dim3(grid), dim3(WG), 0, st>>>(a, n_steps));
+  return hipGetLastError();
+}
+
+hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
+                          reset_kernel<E, L><<<dim3(grid), dim3(WG), 0, st>>>(sh.rules_dev, sh.state,
+                                              sh.boards, mask, mode, sh.n));
+  return hipGetLastError();
+}
+
+hipError_t launch_metrics_init(const Shard &sh, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  metrics_init_kernel<<<dim3(32), dim3(WG), 0, st>>>((long long *)sh.metric_slab);
+  return hipGetLastError();
+}
+
+hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  metrics_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>((const long long *)sh.metric_slab, (long long *)sh.metrics);
+  return hipGetLastError();
+}
+
+hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  int64_t total = sh.n * ((sh.n_cells + 3) / 4);
+  int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
+  hipLaunchKernelGGL(obs_f32_kernel, dim3(grid), dim3(WG), 0, st, sh.boards, dst, sh.n, sh.n_cells, sh.pitch);
+  return hipGetLastError();
+}
+
+hipError_t launch_render_rgb(const Shard &sh, uint8_t *dst, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  int64_t total = sh.n * sh.n_cells;
+  int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
+  hipLaunchKernelGGL(render_rgb_kernel, dim3(grid), dim3(WG), 0, st, sh.rules_dev, sh.boards, dst, sh.n, sh.n_cells, sh.pitch);
+  return hipGetLastError();
+}
+
+hipError_t launch_dense_boards(const Shard &sh, int8_t *dst, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  int64_t total = sh.n * sh.n_cells;
+  int grid = grid_for((total + WG - 1) / WG, sh.max_grid * 4);
+  hipLaunchKernelGGL(dense_boards_kernel, dim3(grid), dim3(WG), 0, st, sh.boards, dst, sh.n, sh.n_cells, sh.pitch);
+  return hipGetLastError();
+}
+
+hipError_t launch_finished(const Shard &sh, int32_t *ids, int32_t *ret, int32_t *perf, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  int64_t n_wg = (sh.n + WG - 1) / WG;
+  hipLaunchKernelGGL(finished_count_kernel, dim3((unsigned)n_wg), dim3(WG), 0, st, sh.rec, sh.wg_count, sh.n);
+  hipLaunchKernelGGL(finished_scan_kernel, dim3(1), dim3(1024), 0, st, sh.wg_count, sh.wg_offset, n_wg, sh.finished_total);
+  hipLaunchKernelGGL(finished_scatter_kernel, dim3((unsigned)n_wg), dim3(WG), 0, st, sh.rec, sh.wg_offset, sh.last_return,
+                     sh.last_perf, ids, ret, perf, sh.n);
+  return hipGetLastError();
+}
+
+}  // namespace sgk

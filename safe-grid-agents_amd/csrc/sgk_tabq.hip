@@ -1,0 +1,312 @@
+// sgk_tabq.hip -- TabularQAgent.act / act_explore / learn / update_epsilon (reference value.py:33-58) for N private agents:
+// per-step kernels on HBM-resident float64 tables and the fused learning rollout with the tables resident in LDS.
+#include "sgk_device.h"
+
+namespace sgk {
+
+// ------------------------------------------------------------------------------------------------
+// Tabular Q-learning, one private float64 table per env: Q[env][state][action] (reference value.py:15-58)
+// ------------------------------------------------------------------------------------------------
+template <int ENV>
+__device__ __forceinline__ int state_index(const SgkRules &R, const EnvState &s) {
+  return (ENV == SGK_SIDE_EFFECTS_SOKOBAN) ? s.pos * R.n_cells + s.box : s.pos;
+}
+
+// np.argmax: first maximum wins
+__device__ __forceinline__ int argmax4(double q0, double q1, double q2, double q3) {
+  int best = 0;
+  double bv = q0;
+  if (q1 > bv) { bv = q1; best = 1; }
+  if (q2 > bv) { bv = q2; best = 2; }
+  if (q3 > bv) { bv = q3; best = 3; }
+  return best;
+}
+__device__ __forceinline__ double pick4(int k, double q0, double q1, double q2, double q3) {
+  return k == 0 ? q0 : (k == 1 ? q1 : (k == 2 ? q2 : q3));
+}
+
+// Stream 1 (epsilon-greedy draws): one block serves TWO consecutive agent steps of one env:
+//   x = philox4x32_10(ctr = {env_lo, env_hi, (t >> 1)_lo, 1}, key); h = t & 1
+//   u(t) = uniform53(x[2h], x[2h+1]),  explore action(t) = x[2h] & 3   (bits the 53-bit construction discards)
+__device__ __forceinline__ void explore_block(uint64_t seed, uint64_t ge, int64_t t, uint32_t x[4]) {
+  philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)((uint64_t)t >> 1), 1u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+}
+__device__ __forceinline__ void explore_draw(const uint32_t x[4], int64_t t, double &u, int &action) {
+  const bool h = (t & 1) != 0;
+  const uint32_t a = h ? x[2] : x[0], b = h ? x[3] : x[1];
+  u = uniform53(a, b);
+  action = (int)(a & 3u);
+}
+
+// epsilon in force at global agent step t (value.py:23-28,54-58): evaluated in Python's operation order
+__host__ __device__ __forceinline__ double epsilon_at(double eps0, int64_t anneal, int64_t t) {
+  if (t <= 0) return 0.0;
+  if (t > anneal - 1) t = anneal - 1;
+  if (t <= 0) return 0.0;
+  double a = (1 - eps0) * (double)t;
+  double b = a / (double)anneal;
+  return 1.0 - b;
+}
+double host_epsilon_at(double eps0, int64_t anneal, int64_t t) { return epsilon_at(eps0, anneal, t); }
+
+// Q <- Q + lr * ((r + discount * v_next) - Q), every operation rounded separately (no FMA contraction)
+__device__ __forceinline__ double q_update(double q_sa, double reward, double v_next, double lr, double discount) {
+  double target = __dadd_rn(reward, __dmul_rn(discount, v_next));
+  double differential = __dsub_rn(target, q_sa);
+  return __dadd_rn(q_sa, __dmul_rn(lr, differential));
+}
+
+struct TabqArgs {
+  const SgkRules *rules;
+  uint64_t *state;
+  uint32_t *rec;
+  int8_t *boards;
+  int32_t *last_return, *last_perf, *n_episodes;
+  long long *metrics;
+  double *table;       // [n][n_states][4]
+  uint16_t *s_prev;    // state index the last action was chosen from; 0xffff = env was over
+  int64_t n;
+  uint64_t seed, env_base;
+  int64_t t_agent;     // global agent step (same for every agent: lockstep)
+  double lr, discount, eps0;
+  int64_t anneal;
+  const double *eps_table;  // eps_table[t] for t < anneal (host-computed, bit-identical to the formula); may be null
+  int32_t n_states;
+  int32_t cheat;
+  uint32_t flags;
+};
+
+template <int ENV>
+__global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, uint8_t *__restrict__ actions_out) {
+  __shared__ SgkRules R;
+  stage_rules(R, a.rules);
+  const double eps = explore ? epsilon_at(a.eps0, a.anneal, a.t_agent) : 0.0;
+  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
+    EnvState s = unpack_state(a.state[env]);
+    int si = state_index<ENV>(R, s);
+    const double2 *row = reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + si) * 4);
+    double2 q01 = row[0], q23 = row[1];
+    int action = argmax4(q01.x, q01.y, q23.x, q23.y);
+    if (explore) {
+      uint64_t ge = a.env_base + (uint64_t)env;
+      uint32_t x[4];
+      explore_block(a.seed, ge, a.t_agent, x);
+      double u;
+      int ea;
+      explore_draw(x, a.t_agent, u, ea);
+      if (u < eps) action = ea;
+    }
+    actions_out[env] = (uint8_t)action;
+    a.s_prev[env] = s.over ? (uint16_t)0xffff : (uint16_t)si;
+  }
+}
+
+template <int ENV>
+__global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_t *__restrict__ actions) {
+  __shared__ SgkRules R;
+  stage_rules(R, a.rules);
+  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
+    int sp = a.s_prev[env];
+    if (sp == 0xffff) continue;
+    EnvState s = unpack_state(a.state[env]);
+    uint32_t rec = a.rec[env];
+    int action = a.cheat ? (int)(rec >> 24) : (int)(actions[env] & 3);
+    double reward = a.cheat ? (double)(int8_t)(rec >> 8) : (double)(int8_t)rec;
+    int sn = state_index<ENV>(R, s);
+    double *tab = a.table + (int64_t)env * a.n_states * 4;
+    const double2 *rown = reinterpret_cast<const double2 *>(tab + sn * 4);
+    double2 n01 = rown[0], n23 = rown[1];
+    int an = argmax4(n01.x, n01.y, n23.x, n23.y);
+    double v_next = pick4(an, n01.x, n01.y, n23.x, n23.y);
+    double *cell = tab + sp * 4 + action;
+    *cell = q_update(*cell, reward, v_next, a.lr, a.discount);
+  }
+}
+
+// Fused learning rollout: one wave = 64 private agents whose whole Q-tables live in LDS for the launch,
+// lane-minor ([state*4+action][lane], 8-byte elements => lanes l and l+32 are served in different LDS
+// passes and every lane hits its own bank pair: conflict-free for arbitrary per-lane states).
+template <int ENV>
+__global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_steps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SgkRules &R = *reinterpret_cast<SgkRules *>(smem);
+  double *Q = reinterpret_cast<double *>(smem + ((sizeof(SgkRules) + 15) / 16) * 16);
+  stage_rules(R, a.rules);
+  const int lane = threadIdx.x;
+  const int S4 = a.n_states * 4;  // HBM row stride: tables are indexed by cell there
+  const int L4 = R.n_slots * 4;   // LDS image: only the cells the agent can stand on
+  const int64_t n_groups = (a.n + 63) / 64;
+  EpisodeAcc acc;
+  acc_init(acc);
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t env0 = g * 64;
+    const int64_t env = env0 + lane;
+    const bool valid = env < a.n;
+    const int n_here = (int)min((int64_t)64, a.n - env0);
+    // load the 64 tables' reachable rows into the lane-minor LDS image
+    {
+      const double *src = a.table + env0 * S4;
+      const int total = n_here * L4;
+      for (int i = lane; i < total; i += 64) {
+        int e = i / L4, idx = i - e * L4;
+        Q[idx * 64 + e] = src[(int64_t)e * S4 + (int)R.slot_cell[idx >> 2] * 4 + (idx & 3)];
+      }
+    }
+    __syncthreads();
+    EnvState s = initial_state(R);
+    if (valid) s = unpack_state(a.state[env]);
+    const uint64_t ge = a.env_base + (uint64_t)env;
+    int si = R.state_slot[s.pos];
+    double q0 = Q[(si * 4 + 0) * 64 + lane], q1 = Q[(si * 4 + 1) * 64 + lane];
+    double q2 = Q[(si * 4 + 2) * 64 + lane], q3 = Q[(si * 4 + 3) * 64 + lane];
+    uint32_t rec = 0;
+    uint32_t x[4] = {0, 0, 0, 0};
+    for (int64_t k = 0; k < n_steps; ++k) {
+      const int64_t t = a.t_agent + k;
+      double eps;
+      if (a.eps_table) {
+        const int64_t tc = t < a.anneal ? t : a.anneal - 1;
+        eps = a.eps_table[tc];  // wave-uniform address: one scalar load
+      } else {
+        eps = epsilon_at(a.eps0, a.anneal, t);
+      }
+      if (k == 0 || (t & 1) == 0) explore_block(a.seed, ge, t, x);
+      double u;
+      int ea;
+      explore_draw(x, t, u, ea);
+      int action = argmax4(q0, q1, q2, q3);
+      if (u < eps) action = ea;
+      // env.step
+      bool finished = false;
+      int r_obs = 0, r_hid = 0;
+      const bool live = valid && !s.over;
+      const int si_prev = si;
+      if (live) {
+        int term;
+        uint32_t e = transition<ENV>(R, s, action, r_obs, r_hid, term);
+        si = (int)(e >> 25);  // successor's slot straight from the transition word (no box in these levels)
+        s.frame += 1;
+        s.ret += r_obs;
+        s.hid += r_hid;
+        finished = term || s.frame >= R.max_iterations;
+      }
+      rec = pack_rec(r_obs, r_hid, (valid && (s.over || finished)) ? 1 : 0, action);
+      // learn (no terminal masking: value.py:48-50 bootstraps from Q[s'] even when the episode ended)
+      double n0 = Q[(si * 4 + 0) * 64 + lane], n1 = Q[(si * 4 + 1) * 64 + lane];
+      double n2 = Q[(si * 4 + 2) * 64 + lane], n3 = Q[(si * 4 + 3) * 64 + lane];
+      if (live) {
+        int an = argmax4(n0, n1, n2, n3);
+        double v_next = pick4(an, n0, n1, n2, n3);
+        double reward = a.cheat ? (double)r_hid : (double)r_obs;
+        double q_sa = pick4(action, q0, q1, q2, q3);
+        double q_new = q_update(q_sa, reward, v_next, a.lr, a.discount);
+        Q[(si_prev * 4 + action) * 64 + lane] = q_new;
+        if (si == si_prev) {  // refused move: the successor row is the row just updated
+          if (action == 0) n0 = q_new; else if (action == 1) n1 = q_new; else if (action == 2) n2 = q_new; else n3 = q_new;
+        }
+      }
+      acc_add(acc, finished, s.ret, s.hid);
+      if (finished) {  // train.py:62-70: the next episode starts from env.reset()
+        a.last_return[env] = s.ret;
+        a.last_perf[env] = s.hid;
+        bump_episode_count(a.n_episodes, env);
+        s = initial_state(R);
+        si = R.state_slot[s.pos];
+        n0 = Q[(si * 4 + 0) * 64 + lane]; n1 = Q[(si * 4 + 1) * 64 + lane];
+        n2 = Q[(si * 4 + 2) * 64 + lane]; n3 = Q[(si * 4 + 3) * 64 + lane];
+      }
+      q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+    }
+    if (valid) {
+      a.state[env] = pack_state(s);
+      a.rec[env] = rec;  // boards are re-materialised by the caller (launch_reset mode 2)
+    }
+    __syncthreads();
+    {
+      double *dst = a.table + env0 * S4;
+      const int total = n_here * L4;
+      for (int i = lane; i < total; i += 64) {
+        int e = i / L4, idx = i - e * L4;
+        dst[(int64_t)e * S4 + (int)R.slot_cell[idx >> 2] * 4 + (idx & 3)] = Q[idx * 64 + e];
+      }
+    }
+    __syncthreads();
+  }
+  acc_flush(acc, a.metrics);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t flags) {
+  TabqArgs a;
+  a.rules = sh.rules_dev;
+  a.state = sh.state;
+  a.rec = sh.rec;
+  a.boards = sh.boards;
+  a.last_return = sh.last_return;
+  a.last_perf = sh.last_perf;
+  a.n_episodes = sh.n_episodes;
+  a.metrics = (long long *)sh.metric_slab;
+  a.table = tq.table;
+  a.s_prev = tq.s_prev;
+  a.n = sh.n;
+  a.seed = sh.seed;
+  a.env_base = sh.env_base;
+  a.t_agent = tq.t_agent;
+  a.lr = tq.lr;
+  a.discount = tq.discount;
+  a.eps0 = tq.eps0;
+  a.anneal = tq.anneal;
+  a.eps_table = tq.eps_table;
+  a.n_states = sh.n_states;
+  a.cheat = 0;
+  a.flags = flags;
+  return a;
+}
+
+hipError_t launch_tabq_act(const Shard &sh, const TabqShard &tq, int explore, uint8_t *actions_out, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  TabqArgs a = make_tabq_args(sh, tq, 0);
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  SGK_DISPATCH_ENV(sh.env_id, tabq_act_kernel<E><<<dim3(grid), dim3(WG), 0, st>>>(a, explore, actions_out));
+  return hipGetLastError();
+}
+
+hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t *actions, int cheat, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  TabqArgs a = make_tabq_args(sh, tq, 0);
+  a.cheat = cheat;
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  SGK_DISPATCH_ENV(sh.env_id, tabq_learn_kernel<E><<<dim3(grid), dim3(WG), 0, st>>>(a, actions));
+  return hipGetLastError();
+}
+
+// Sokoban's state is (agent cell, box cell): n_cells^2 rows do not fit LDS -> 0 = "use the per-step kernels"
+size_t tabq_rollout_lds_bytes(const Shard &sh) {
+  if (sh.n_states != sh.n_cells) return 0;
+  return ((sizeof(SgkRules) + 15) / 16) * 16 + (size_t)sh.rules_host.n_slots * 4 * 64 * sizeof(double);
+}
+
+hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st) {
+  (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
+  TabqArgs a = make_tabq_args(sh, tq, 0);
+  a.cheat = cheat;
+  size_t lds = tabq_rollout_lds_bytes(sh);
+  int64_t n_groups = (sh.n + 63) / 64;
+  int per_cu = (int)((160u * 1024u) / lds);  // workgroups (= waves) the LDS lets a CU hold
+  if (per_cu > 16) per_cu = 16;
+  if (per_cu < 1) per_cu = 1;
+  int grid = grid_for(n_groups, sh.n_cus * per_cu);
+  hipError_t err = hipSuccess;
+  SGK_DISPATCH_ENV(sh.env_id, {
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(&tabq_rollout_kernel<E>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err == hipSuccess)
+      hipLaunchKernelGGL((tabq_rollout_kernel<E>), dim3(grid), dim3(64), lds, st, a, n_steps);
+  });
+  if (err != hipSuccess) return err;
+  return hipGetLastError();
+}
+
+}  // namespace sgk
