@@ -11,6 +11,7 @@ from .envs import ENV_IDS, ENV_MAP, BatchedGridworldEnv, GridworldEnv, make
 from .loops import (EVAL_MAP, LEARN_MAP, WARMUP_MAP, BatchedRollout, batched_default_eval, batched_gather_rollout, batched_ppo_learn, batched_random_rollout, batched_tabq_learn,
                     default_eval,
                     dqn_learn, dqn_warmup, noop_warmup, ppo_learn, tabq_learn, whiler)
+from .eventfile import EventFileWriter, read_events
 from .metering import AverageMeter, BatchMetrics, NullWriter, RecordingWriter, make_meters, track_metrics
 from .trainer import prepare_parser, train, train_batched
 
@@ -22,6 +23,6 @@ __all__ = [
     "BatchedPPOAgent", "batched_ppo_learn", "PPOBaseAgent", "PPOMLPAgent", "PPOCNNAgent", "discounted_returns_f32",
     "whiler", "tabq_learn", "dqn_learn", "ppo_learn", "default_eval", "dqn_warmup", "noop_warmup",
     "batched_random_rollout", "batched_tabq_learn", "batched_default_eval", "batched_gather_rollout", "BatchedRollout",
-    "AverageMeter", "make_meters", "track_metrics", "BatchMetrics", "NullWriter", "RecordingWriter",
+    "EventFileWriter", "read_events", "AverageMeter", "make_meters", "track_metrics", "BatchMetrics", "NullWriter", "RecordingWriter",
     "prepare_parser", "train", "train_batched",
 ]

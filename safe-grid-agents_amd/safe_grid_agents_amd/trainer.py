@@ -87,12 +87,18 @@ def _noop(*args, **kwargs):
 
 
 def _default_writer(log_dir):
+    """tensorboardX.SummaryWriter when the user has it (reference train.py:14,44); else this repo's own event-file writer
+    (same calls, files TensorBoard reads); a null writer when there is no log directory."""
     try:
-        from tensorboardX import SummaryWriter  # not in this image; used when the user has it
+        from tensorboardX import SummaryWriter  # not in this image
 
         return SummaryWriter(log_dir)
     except ImportError:
-        return NullWriter(log_dir)
+        if not log_dir:
+            return NullWriter(log_dir)
+        from .eventfile import EventFileWriter
+
+        return EventFileWriter(log_dir)
 
 
 def train(args, config=None, reporter=_noop, env_factory=None, writer_factory=None):
