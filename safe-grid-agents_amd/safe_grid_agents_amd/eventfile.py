@@ -13,8 +13,11 @@ payload -- whose payloads are `tensorflow.Event` protobuf messages, encoded here
   SummaryMetadata  1 plugin_data { 1 plugin_name  2 content }
   TensorProto      1 dtype (DT_STRING = 7)  2 tensor_shape { 2 dim { 1 size } }  8 string_val (repeated bytes)
 
+  Image            1 height  2 width  3 colorspace  4 encoded_image_string     (Value field 4)
+
 add_scalars writes one series per key under "<main_tag>/<key>" in the same file (tensorboardX opens one sub-run per key).
-add_video needs a GIF encoder, which this image does not have: the call is counted and dropped.
+add_video encodes the clips side by side as one animated GIF with Pillow when it is importable (else the call is counted
+and dropped); it takes the reference's (N, C, T, H, W) stacks (eval.py:26-28,44-48) as well as tensorboardX's (N, T, C, H, W).
 """
 import os
 import socket
@@ -146,7 +149,31 @@ class EventFileWriter:
         self._summary([_f_bytes(1, _f_bytes(1, tag.encode()) + _f_bytes(5, histo))], step)
 
     def add_video(self, tag, frames, step=0, fps=4):
-        self.dropped_videos += 1  # no GIF encoder in this image
+        try:
+            from PIL import Image
+        except ImportError:
+            self.dropped_videos += 1
+            return
+        import io
+
+        v = np.asarray(frames)
+        if v.ndim != 5:
+            raise ValueError("add_video expects a 5-D array, got shape %r" % (v.shape,))
+        if v.shape[1] in (1, 3) and v.shape[2] not in (1, 3):  # (N, C, T, H, W), as the reference stacks its clips
+            v = np.swapaxes(v, 1, 2)
+        v = np.moveaxis(v, 2, -1)  # (N, T, H, W, C)
+        if v.dtype != np.uint8:
+            v = np.clip(v * (255.0 if v.max() <= 1.0 else 1.0), 0, 255).astype(np.uint8)
+        if v.shape[-1] == 1:
+            v = np.repeat(v, 3, axis=-1)
+        strip = np.concatenate(list(v), axis=2)  # clips side by side: (T, H, N * W, 3)
+        scale = max(1, -(-64 // min(strip.shape[1], strip.shape[2])))  # gridworld boards are a few pixels: enlarge
+        strip = strip.repeat(scale, axis=1).repeat(scale, axis=2)
+        images = [Image.fromarray(f) for f in strip]
+        buf = io.BytesIO()
+        images[0].save(buf, format="GIF", save_all=True, append_images=images[1:], duration=int(1000 / max(fps, 1)), loop=0)
+        image = (_f_varint(1, strip.shape[1]) + _f_varint(2, strip.shape[2]) + _f_varint(3, 3) + _f_bytes(4, buf.getvalue()))
+        self._summary([_f_bytes(1, _f_bytes(1, tag.encode()) + _f_bytes(4, image))], step)
 
     def flush(self):
         self._f.flush()
@@ -243,6 +270,10 @@ def read_events(path):
                                        "value": {"min": h[1], "max": h[2], "num": h[3], "sum": h[4], "sum_squares": h[5],
                                                  "bucket_limit": list(struct.unpack("<%dd" % (len(h[6]) // 8), h[6])),
                                                  "bucket": list(struct.unpack("<%dd" % (len(h[7]) // 8), h[7]))}})
+                    elif g == 4:
+                        im = {g2: x2 for g2, _, x2 in _parse(x)}
+                        events.append({"step": step, "tag": tag, "kind": "image",
+                                       "value": {"height": im[1], "width": im[2], "colorspace": im[3], "encoded": im[4]}})
                     elif g == 8:
                         t = {g2: x2 for g2, _, x2 in _parse(x)}
                         events.append({"step": step, "tag": tag, "kind": "text", "value": t[8].decode()})

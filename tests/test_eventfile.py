@@ -27,16 +27,32 @@ def test_round_trip_of_every_call(tmp_path):
     w.add_scalars("Evaluation/returns", {"avg": -10.5, "max": 7}, 2)
     w.add_text("data/seed", "7")
     w.add_histogram("network.0.0.weight", np.arange(100, dtype=np.float32) / 10.0, 9)
-    w.add_video("Evaluation/grid_animation", np.zeros((1, 3, 4, 5, 5)), 0)
+    clips = np.zeros((2, 3, 4, 5, 5), dtype=np.uint8)  # the reference's stacking: (clips, colour, time, H, W)
+    for t in range(4):  # a pixel that moves: identical consecutive frames would be merged by the GIF encoder
+        clips[0, 0, t, 2, t] = 255
+    clips[1, 2, :, 1, 3] = 200
+    w.add_video("Evaluation/grid_animation", clips, 6)
     w.add_scalar("negative/step", 1.0, -5)
     w.close()
-    assert w.dropped_videos == 1 and os.path.basename(w.path).startswith("events.out.tfevents.")
+    assert w.dropped_videos == 0 and os.path.basename(w.path).startswith("events.out.tfevents.")
     ev = S.read_events(w.path)
     assert ev[0] == {"step": 0, "tag": None, "kind": "file_version", "value": "brain.Event:2"}
     got = [(e["step"], e["tag"], e["kind"]) for e in ev[1:]]
     assert got == [(3, "Train/returns", "scalar"), (4, "Train/policy_entropy", "scalar"), (2, "Evaluation/returns/avg", "scalar"),
                    (2, "Evaluation/returns/max", "scalar"), (0, "data/seed/text_summary", "text"),
-                   (9, "network.0.0.weight", "histogram"), (-5, "negative/step", "scalar")]
+                   (9, "network.0.0.weight", "histogram"), (6, "Evaluation/grid_animation", "image"),
+                   (-5, "negative/step", "scalar")]
+    from PIL import Image
+    import io
+
+    im = ev[7]["value"]
+    gif = Image.open(io.BytesIO(im["encoded"]))
+    assert gif.format == "GIF" and gif.n_frames == 4 and gif.size == (im["width"], im["height"]) and im["colorspace"] == 3
+    assert im["width"] == 2 * im["height"] and im["height"] >= 64  # two clips side by side, enlarged
+    gif.seek(1)
+    frame = np.asarray(gif.convert("RGB"))
+    k = im["height"] // 5
+    assert tuple(frame[2 * k + k // 2, 1 * k + k // 2]) == (255, 0, 0) and tuple(frame[k + k // 2, (5 + 3) * k + k // 2]) == (0, 0, 200)
     assert ev[1]["value"] == -62.0 and ev[2]["value"] == 1.25 and ev[3]["value"] == -10.5 and ev[5]["value"] == "7"
     h = ev[6]["value"]
     assert h["num"] == 100 and h["min"] == 0.0 and abs(h["max"] - 9.9) < 1e-6 and sum(h["bucket"]) == 100
