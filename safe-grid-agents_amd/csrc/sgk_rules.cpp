@@ -156,10 +156,18 @@ extern "C" int sgk_build_rules(int env_id, SgkRules *r) {
         if (!seen[nxt]) { seen[nxt] = true; queue[tail++] = nxt; }
       }
     }
+    // dense slots: the live cells first; every absorbing cell shares ONE extra slot. An absorbing cell's Q row is read by the
+    // bootstrap of the step that ends the episode there (value.py:48-50 has no terminal masking) but never written -- the
+    // agent never acts from it -- so it keeps its initial zeros and the LDS image needs a single zero row for all of them
+    // (IslandNavigation: 29 reachable cells, 9 of them water or goal -> 21 rows -> three resident waves per CU instead of two).
     int k = 0;
     for (int c = 0; c < n; ++c)
-      if (seen[c]) { r->state_slot[c] = (uint8_t)k; r->slot_cell[k] = (uint8_t)c; ++k; }
-    r->n_slots = k;
+      if (seen[c] && !absorbing[c]) { r->state_slot[c] = (uint8_t)k; r->slot_cell[k] = (uint8_t)c; ++k; }
+    r->n_live_slots = k;
+    bool any_absorbing = false;
+    for (int c = 0; c < n; ++c)
+      if (seen[c] && absorbing[c]) { r->state_slot[c] = (uint8_t)k; any_absorbing = true; }
+    r->n_slots = k + (any_absorbing ? 1 : 0);
     // bits 25..31 of every transition word: the slot of the next cell, so the LDS-resident tabular-Q kernel gets the
     // successor's row index from the lookup it already does (one dependent LDS round trip less per step)
     for (int i = 0; i < n * SGK_ACTIONS; ++i) {

@@ -29,10 +29,11 @@ struct SgkRules {
   int8_t box_penalty[SGK_CELLS];   // sokoban: hidden wall/corner penalty while the box rests on this cell
   uint8_t box_blocked[SGK_CELLS];  // sokoban: 1 when a box cannot be pushed onto this cell
   uint8_t safety[SGK_CELLS];       // island: Manhattan distance from this cell to the nearest water
-  uint8_t state_slot[SGK_CELLS];   // agent cell -> dense index among the cells the agent can ever stand on (255: never)
-  uint8_t slot_cell[SGK_CELLS];    // inverse of state_slot
-  int32_t n_slots, pad1[3];
-  uint8_t palette[8][4];           // observation value -> RGB (uint8) for render("rgb_array"); [v][3] unused        // number of reachable agent cells (LDS-resident tabular-Q uses n_slots rows)
+  uint8_t state_slot[SGK_CELLS];   // agent cell -> row of the LDS-resident Q image (255: the agent can never stand there)
+  uint8_t slot_cell[SGK_CELLS];    // row -> cell, for the n_live_slots rows of non-terminal cells
+  int32_t n_slots, n_live_slots, pad1[2];  // rows of the LDS-resident Q image; the first n_live_slots map to slot_cell[],
+                                           // one more (when the level has terminal cells) is the shared all-zero row
+  uint8_t palette[8][4];           // observation value -> RGB (uint8) for render("rgb_array"); [v][3] unused
 };
 
 #ifdef __cplusplus

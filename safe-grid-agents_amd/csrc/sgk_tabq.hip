@@ -134,7 +134,8 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
   stage_rules(R, a.rules);
   const int lane = threadIdx.x;
   const int S4 = a.n_states * 4;  // HBM row stride: tables are indexed by cell there
-  const int L4 = R.n_slots * 4;   // LDS image: only the cells the agent can stand on
+  const int L4 = R.n_live_slots * 4;  // LDS image: one row per non-terminal cell the agent can stand on ...
+  const int Z4 = R.n_slots * 4;       // ... plus, when the level has terminal cells, one shared all-zero row (sgk_rules.cpp)
   const int64_t n_groups = (a.n + 63) / 64;
   EpisodeAcc acc;
   acc_init(acc);
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
         int e = i / L4, idx = i - e * L4;
         Q[idx * 64 + e] = src[(int64_t)e * S4 + (int)R.slot_cell[idx >> 2] * 4 + (idx & 3)];
       }
+      for (int i = L4 * 64 + lane; i < Z4 * 64; i += 64) Q[i] = 0.0;  // rows of terminal cells are never written: zeros
     }
     __syncthreads();
     EnvState s = initial_state(R);

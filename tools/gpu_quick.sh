@@ -1,6 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
-for g in 1280 1408 1536 1664 1792 2048; do
-  echo "SGK_MAX_GRID=$g"
-  SGK_MAX_GRID=$g timeout 600 python tools/sweep.py BoatRace-v0 IslandNavigation-v0 262144 1048576 4194304 2>&1 | grep compact | cut -c1-130
-done
+timeout 1200 python -m pytest tests -q -m gpu -x -k "tabq or tabular or train or smoke or demo" 2>&1 | tail -3
+timeout 900 python tools/bench_configs.py 2>&1 | grep '"config": 3' | cut -c1-220
