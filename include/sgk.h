@@ -214,7 +214,8 @@ SGK_API int sgk_epsilon_greedy_ex(sgk_env *h, const float *scores_dev, double ep
                                   const double *epsilon_dev, const uint64_t *draw_index_dev, uint8_t *actions_out_dev);
 
 /* ---- DeepQAgent: Q-network forward + act_explore in one launch (reference value.py:89-111,148-158) ------------------- */
-/* The reference's default topology (n_layers = 2): Linear(n_cells, H) + ReLU, Linear(H, H) + ReLU, Linear(H, 4); H = 100.
+/* The reference's default topology (n_layers = 2): Linear(n_cells, H) + ReLU, Linear(H, H) + ReLU, Linear(H, 4); H = 100
+ * (the reference default, agent_parser_configs.yaml:45-49), 64 or 128.
  * Device pointers into the (PyTorch) parameters, float32: w1t = W1 transposed [n_cells][H]; b1 [H]; w2 = W2 [H][H] as torch
  * stores it ([out][in]); b2 [H]; w3t = W3 transposed [H][4]; b3 [4]. Reads the env's int8 boards directly. */
 typedef struct sgk_mlp_weights {
@@ -236,7 +237,7 @@ SGK_API int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon,
  * epsilon = 0. */
 SGK_API int sgk_categorical_sample(sgk_env *h, const float *logits_dev, uint64_t draw_index, const uint64_t *draw_index_dev,
                                    uint8_t *actions_out_dev);
-/* PPOMLPAgent with the default topology (n_layers = 2, n_hidden = 100): trunk + actor head forward + the draw above in one
+/* PPOMLPAgent with the default topology (n_layers = 2, n_hidden = 100; also 64 / 128): trunk + actor head forward + the draw above in one
  * launch, straight from the int8 boards. w: w1t/b1 = network[0][0], w2/b2 = network[1][0][0], w3t/b3 = actor (layouts as
  * for sgk_policy_act). logits_out_dev: float32 [n_envs][4] or NULL. */
 SGK_API int sgk_policy_sample(sgk_env *h, const sgk_mlp_weights *w, uint64_t draw_index, const uint64_t *draw_index_dev,

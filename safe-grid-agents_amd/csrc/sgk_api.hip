@@ -576,7 +576,8 @@ int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon, uint64_
   SGK_CHECK_HANDLE(h);
   if (!w || !actions_out_dev || !w->w1t || !w->b1 || !w->w2 || !w->b2 || !w->w3t || !w->b3)
     return fail(SGK_ERR_INVALID, "NULL argument");
-  if (w->n_hidden != 100) return fail(SGK_ERR_INVALID, "sgk_policy_act is built for n_hidden = 100 (the reference default)");
+  if (w->n_hidden != 64 && w->n_hidden != 100 && w->n_hidden != 128)
+    return fail(SGK_ERR_INVALID, "sgk_policy_act is built for n_hidden in {64, 100 (the reference default), 128}");
   if (scores_out_dev && ((uintptr_t)scores_out_dev & 15u)) return fail(SGK_ERR_INVALID, "scores_out_dev must be 16-byte aligned");
   sgk::PolicyWeights pw{w->w1t, w->b1, w->w2, w->b2, w->w3t, w->b3, w->n_hidden};
   SGK_HIP(sgk::launch_policy_act(h->sh, 0, pw, actions_out_dev, scores_out_dev, epsilon, draw_index, epsilon_dev, draw_index_dev,
@@ -589,7 +590,8 @@ int sgk_policy_sample(sgk_env *h, const sgk_mlp_weights *w, uint64_t draw_index,
   SGK_CHECK_HANDLE(h);
   if (!w || !actions_out_dev || !w->w1t || !w->b1 || !w->w2 || !w->b2 || !w->w3t || !w->b3)
     return fail(SGK_ERR_INVALID, "NULL argument");
-  if (w->n_hidden != 100) return fail(SGK_ERR_INVALID, "sgk_policy_sample is built for n_hidden = 100 (the reference default)");
+  if (w->n_hidden != 64 && w->n_hidden != 100 && w->n_hidden != 128)
+    return fail(SGK_ERR_INVALID, "sgk_policy_sample is built for n_hidden in {64, 100 (the reference default), 128}");
   if (logits_out_dev && ((uintptr_t)logits_out_dev & 15u)) return fail(SGK_ERR_INVALID, "logits_out_dev must be 16-byte aligned");
   sgk::PolicyWeights pw{w->w1t, w->b1, w->w2, w->b2, w->w3t, w->b3, w->n_hidden};
   SGK_HIP(sgk::launch_policy_act(h->sh, 1, pw, actions_out_dev, logits_out_dev, 0.0, draw_index, nullptr, draw_index_dev,

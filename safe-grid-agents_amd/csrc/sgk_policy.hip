@@ -367,27 +367,36 @@ hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, 
                              uint64_t draw, const double *eps_dev, const uint64_t *draw_dev, hipStream_t st) {
   (void)hipGetLastError();
   int grid = grid_for((sh.n + PMFMA_ENVS - 1) / PMFMA_ENVS, sh.n_cus);
-#define SGK_POLICY_LAUNCH_M(K0, MODE)                                                                                      \
+#define SGK_POLICY_LAUNCH_M(K0, HID, MODE)                                                                                 \
   do {                                                                                                                     \
-    constexpr size_t lds = PolicyMfmaGeom<K0, 100>::lds_bytes;                                                             \
+    constexpr size_t lds = PolicyMfmaGeom<K0, HID>::lds_bytes;                                                             \
     static bool lds_opted_in = false; /* > 64 KB of dynamic LDS needs the opt-in, once per kernel */                       \
     if (!lds_opted_in) {                                                                                                   \
-      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&policy_mfma_kernel<K0, 100, MODE>),              \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&policy_mfma_kernel<K0, HID, MODE>),              \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
       if (ae != hipSuccess) return ae;                                                                                     \
       lds_opted_in = true;                                                                                                 \
     }                                                                                                                      \
-    policy_mfma_kernel<K0, 100, MODE><<<dim3(grid), dim3(PMFMA_WG), lds, st>>>(sh.boards, sh.pitch, w.w1t, w.b1, w.w2, w.b2, \
+    policy_mfma_kernel<K0, HID, MODE><<<dim3(grid), dim3(PMFMA_WG), lds, st>>>(sh.boards, sh.pitch, w.w1t, w.b1, w.w2, w.b2, \
                                                                               w.w3t, w.b3, actions, scores, sh.n, eps,     \
                                                                               sh.seed, sh.env_base, draw, eps_dev,         \
                                                                               draw_dev);                                   \
   } while (0)
+#define SGK_POLICY_LAUNCH_H(K0, HID)                                                                                       \
+  do {                                                                                                                     \
+    if (mode == 0) SGK_POLICY_LAUNCH_M(K0, HID, 0);                                                                        \
+    else SGK_POLICY_LAUNCH_M(K0, HID, 1);                                                                                  \
+  } while (0)
+  // hidden widths with an instantiation: the reference default (100) and the two common powers of two
 #define SGK_POLICY_LAUNCH(K0)                                                                                              \
   do {                                                                                                                     \
-    if (mode == 0) SGK_POLICY_LAUNCH_M(K0, 0);                                                                             \
-    else SGK_POLICY_LAUNCH_M(K0, 1);                                                                                       \
+    switch (w.n_hidden) {                                                                                                  \
+    case 64: SGK_POLICY_LAUNCH_H(K0, 64); break;                                                                           \
+    case 100: SGK_POLICY_LAUNCH_H(K0, 100); break;                                                                         \
+    case 128: SGK_POLICY_LAUNCH_H(K0, 128); break;                                                                         \
+    default: return hipErrorInvalidValue;                                                                                  \
+    }                                                                                                                      \
   } while (0)
-  if (w.n_hidden != 100) return hipErrorInvalidValue;
   switch (sh.n_cells) {
   case 25: SGK_POLICY_LAUNCH(25); break;
   case 36: SGK_POLICY_LAUNCH(36); break;
@@ -396,6 +405,7 @@ hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, 
   default: return hipErrorInvalidValue;
   }
 #undef SGK_POLICY_LAUNCH
+#undef SGK_POLICY_LAUNCH_H
 #undef SGK_POLICY_LAUNCH_M
   return hipGetLastError();
 }

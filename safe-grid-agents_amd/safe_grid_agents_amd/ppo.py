@@ -234,7 +234,7 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
     (N episodes gathered in lockstep, loops.batched_gather_rollout), the epochs draw minibatches from that rollout where
     it lies in HBM, and acting under the old policy is one HIP launch per lockstep step:
 
-      * ppo-mlp with the default topology (n_layers 2, n_hidden 100): sgk_policy_sample -- trunk + actor forward from the
+      * ppo-mlp with two layers of 100 (the reference default), 64 or 128 units: sgk_policy_sample -- trunk + actor forward from the
         int8 boards and the Categorical draw fused (no observation tensor, no softmax/multinomial kernels);
       * any other body (ppo-cnn, other widths): the torch forward on the float32 observation (sgk_obs_f32) followed by
         sgk_categorical_sample on the logits.
@@ -267,13 +267,14 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         self._stats = torch.zeros((self.epochs, 3), dtype=torch.float32, device=self.device)  # policy loss, value loss, entropy
         self._actions = torch.empty(env.n_envs, dtype=torch.uint8, device=self.device)
         self._obs = torch.empty((env.n_envs, env.n_cells), dtype=torch.float32, device=self.device)
-        self.fused_policy = (body == "mlp" and int(args.n_layers) == 2 and int(args.n_hidden) == 100 and self.action_n == 4
+        hidden = int(getattr(args, "n_hidden", 0))  # ppo-cnn has no such flag
+        self.fused_policy = (body == "mlp" and int(args.n_layers) == 2 and hidden in (64, 100, 128) and self.action_n == 4
                              and env.n_cells in (25, 36, 48, 63))
         if self.fused_policy:
             old = self.net.old_policy
             l1, l2, head = old.network[0][0], old.network[1][0][0], old.actor
-            self._fw = {"w1t": torch.empty((env.n_cells, 100), device=self.device), "b1": l1.bias.data,
-                        "w2": l2.weight.data, "b2": l2.bias.data, "w3t": torch.empty((100, 4), device=self.device),
+            self._fw = {"w1t": torch.empty((env.n_cells, hidden), device=self.device), "b1": l1.bias.data,
+                        "w2": l2.weight.data, "b2": l2.bias.data, "w3t": torch.empty((hidden, 4), device=self.device),
                         "b3": head.bias.data}
             self._refresh_fused_weights()
 

@@ -220,3 +220,41 @@ def test_fused_policy_kernel_matches_torch_forward(name, layout):
     agent.t = 0
     assert abs((agent.act_explore().cpu().numpy() != greedy).mean() - 0.75) < 0.04
     env.close()
+
+
+@pytest.mark.parametrize("name,hidden", [("SideEffectsSokoban-v0", 64), ("DistributionalShift-v0", 128), ("BoatRace-v0", 128),
+                                         ("IslandNavigation-v0", 64)])
+def test_fused_policy_kernel_other_hidden_widths(name, hidden):
+    """The MFMA policy kernel is instantiated for 64 and 128 hidden units besides the reference's 100: scores vs the torch
+    network on the CPU in fp32 (rtol 1e-4 / atol 1e-4), draws bit-exact vs the oracle on the kernel's own scores."""
+    import torch
+
+    torch.manual_seed(9)
+    n, seed = 1777, 5
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    env.bind_torch_stream()
+    env.step_random(11, auto_reset=True)
+    agent = S.BatchedDeepQAgent(env, _args(n_hidden=hidden))
+    assert agent.fused_policy
+    with torch.no_grad():
+        for p in agent.Q.parameters():
+            p.mul_(3.0)
+    agent._fw_stale = True
+    agent._refresh_fused_weights()
+    scores = torch.zeros(n, 4, device="cuda")
+    a = env.policy_act(agent._fw, 0.3, 21, scores_out=scores).cpu().numpy()
+    cpu_net = agent.build_Q(env.n_cells, 2, hidden)
+    cpu_net.load_state_dict({k: v.cpu() for k, v in agent.Q.state_dict().items()})
+    obs = torch.as_tensor(env.boards_host().reshape(n, -1).astype(np.float32))
+    with torch.no_grad():
+        want = cpu_net(obs).numpy()
+    got = scores.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    assert (a == O.eps_greedy(got, 0.3, seed, 0, 21)).all()
+    sampled = env.policy_sample(agent._fw, 8).cpu().numpy()
+    want_s, margin = O.categorical_sample(got, seed, 0, 8)
+    clear = margin > 1e-6
+    assert clear.mean() > 0.999 and (sampled[clear] == want_s[clear]).all()
+    bad = types.SimpleNamespace(**{**vars(_args()), "n_hidden": 72})
+    assert not S.BatchedDeepQAgent(env, bad).fused_policy  # other widths take the torch forward + sgk_epsilon_greedy
+    env.close()

@@ -1,4 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
-timeout 1200 python -m pytest tests -q -m gpu -x -k "tabq or tabular or train or smoke or demo" 2>&1 | tail -3
-timeout 900 python tools/bench_configs.py 2>&1 | grep '"config": 3' | cut -c1-220
+timeout 1200 python -m pytest tests/test_gpu_deepq.py tests/test_gpu_ppo.py -q -m gpu -x 2>&1 | tail -4
