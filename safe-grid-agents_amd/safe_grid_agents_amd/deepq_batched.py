@@ -12,7 +12,6 @@ a parameter here: `sgd_steps` SGD steps of `batch_size` samples per LOCKSTEP ste
 transitions (a ring of whole lockstep slices). The [B,1]-vs-[B] mse_loss broadcast of value.py:119-123 is NOT kept here
 (shapes are squeezed): this is a different training schedule anyway, parity is claimed only for forward / argmax / policy.
 """
-import numpy as np
 
 
 class DeviceReplay:
@@ -100,8 +99,9 @@ class BatchedDeepQAgent:
         self._prev_boards = torch.empty((env.n_envs, env.n_cells), dtype=torch.int8, device=self.device)
         self.last_loss = None
         self._actions = torch.empty(env.n_envs, dtype=torch.uint8, device=self.device)
-        # fused forward + act_explore kernel (sgk_policy_act): the reference's default topology only
-        self.fused_policy = (n_layers == 2 and n_hidden in (64, 100, 128) and self.action_n == 4 and env.n_cells in (25, 36, 48, 63))
+        # fused forward + act_explore kernel (sgk_policy_act): two layers of 100 (the reference default), 64 or 128 units
+        self.fused_policy = (n_layers == 2 and n_hidden in (64, 100, 128) and self.action_n == 4
+                             and env.n_cells in (25, 36, 48, 63))
         if self.fused_policy:
             l1, l2, l3 = self.Q[0][0], self.Q[1][0][0], self.Q[2]
             self._fw = {"w1t": torch.empty((env.n_cells, n_hidden), device=self.device), "b1": l1.bias.data,

@@ -1,7 +1,6 @@
 """Size / layout / mode sweep of the step path (runs on the GPU box). Prints one line per configuration."""
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
