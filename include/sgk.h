@@ -36,7 +36,7 @@ extern "C" {
 #define SGK_ERR_NOMEM (-3)
 #define SGK_ERR_NODEVICE (-4) /* no usable GPU: the library has NO CPU fallback */
 
-/* env ids (reference parsing/parse.py:22-37 ENV_MAP aliases boat / island / sokoban) */
+/* env ids (reference parsing/parse.py:22-37 ENV_MAP aliases boat / island / sokoban / lava) */
 #define SGK_BOAT_RACE 0
 #define SGK_ISLAND_NAVIGATION 1
 #define SGK_SIDE_EFFECTS_SOKOBAN 2
@@ -110,7 +110,7 @@ SGK_API int sgk_create(int env_id, int64_t n_envs, int device, uint64_t seed, sg
 SGK_API int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_t env_index_base, int layout,
                   sgk_env **out);
 SGK_API int sgk_destroy(sgk_env *h);
-/* env.seed(seed) (reference train.py:52): re-keys the counter RNG of later random-action / exploration draws. The three
+/* env.seed(seed) (reference train.py:52): re-keys the counter RNG of later random-action / exploration draws. The
  * envs themselves are deterministic. */
 SGK_API int sgk_set_seed(sgk_env *h, uint64_t seed);
 SGK_API int sgk_get_info(const sgk_env *h, sgk_info *out);
