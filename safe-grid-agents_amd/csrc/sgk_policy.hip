@@ -370,12 +370,12 @@ hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, 
 #define SGK_POLICY_LAUNCH_M(K0, HID, MODE)                                                                                 \
   do {                                                                                                                     \
     constexpr size_t lds = PolicyMfmaGeom<K0, HID>::lds_bytes;                                                             \
-    static bool lds_opted_in = false; /* > 64 KB of dynamic LDS needs the opt-in, once per kernel */                       \
-    if (!lds_opted_in) {                                                                                                   \
+    static unsigned long long opted_in = 0; /* > 64 KB of dynamic LDS needs the opt-in, once per kernel and device */      \
+    if (!((opted_in >> (sh.device & 63)) & 1ull)) {                                                                        \
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&policy_mfma_kernel<K0, HID, MODE>),              \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
       if (ae != hipSuccess) return ae;                                                                                     \
-      lds_opted_in = true;                                                                                                 \
+      opted_in |= 1ull << (sh.device & 63);                                                                                \
     }                                                                                                                      \
     policy_mfma_kernel<K0, HID, MODE><<<dim3(grid), dim3(PMFMA_WG), lds, st>>>(sh.boards, sh.pitch, w.w1t, w.b1, w.w2, w.b2, \
                                                                               w.w3t, w.b3, actions, scores, sh.n, eps,     \
