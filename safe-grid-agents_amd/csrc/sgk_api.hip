@@ -782,21 +782,18 @@ int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat) {
   if (n_steps == 0) return SGK_OK;
   sgk::Shard &s = h->sh;
   const size_t lds_need = sgk::tabq_rollout_lds_bytes(s);
-  if (lds_need != 0 && lds_need <= 160u * 1024u) {
+  static const bool force_hbm = getenv("SGK_TABQ_HBM") != nullptr;  // A/B switch: HBM-resident rows for every env
+  if (!force_hbm && lds_need != 0 && lds_need <= 160u * 1024u) {
     SGK_HIP(sgk::launch_tabq_rollout(s, q->tq, n_steps, cheat, h->stream));
     SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));  // materialise the boards of the final states
     q->tq.t_agent += n_steps;
     s.lockstep_t += (uint64_t)n_steps;
   } else {
-    // table too large for LDS residency (Sokoban: n_cells^2 states): same loop as separate launches
-    for (int64_t k = 0; k < n_steps; ++k) {
-      SGK_HIP(sgk::launch_tabq_act(s, q->tq, 1, q->actions, h->stream));
-      SGK_HIP(sgk::launch_step(s, q->actions, SGK_F_NO_BOARDS, h->stream));
-      s.lockstep_t += 1;
-      SGK_HIP(sgk::launch_tabq_learn(s, q->tq, q->actions, cheat, h->stream));
-      q->tq.t_agent += 1;
-      SGK_HIP(sgk::launch_reset(s, nullptr, 1, h->stream));
-    }
+    // table too large for LDS residency (Sokoban: n_cells^2 states): the same loop with the rows read and written in HBM
+    SGK_HIP(sgk::launch_tabq_rollout_hbm(s, q->tq, n_steps, cheat, h->stream));
+    SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));
+    q->tq.t_agent += n_steps;
+    s.lockstep_t += (uint64_t)n_steps;
   }
   h->t_dev_stale = true;
   h->steps_issued += s.n * n_steps;

@@ -65,6 +65,7 @@ hipError_t launch_finished(const Shard &sh, int32_t *ids, int32_t *ret, int32_t 
 hipError_t launch_tabq_act(const Shard &sh, const TabqShard &tq, int explore, uint8_t *actions_out, hipStream_t st);
 hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t *actions, int cheat, hipStream_t st);
 hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st);
+hipError_t launch_tabq_rollout_hbm(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st);
 size_t tabq_rollout_lds_bytes(const Shard &sh);
 
 int host_random_action(uint64_t seed, uint64_t env, uint64_t t);

@@ -237,6 +237,97 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
   acc_flush(acc, a.metrics);
 }
 
+// The same fused learning loop for tables that do not fit LDS (Sokoban: the state is (agent cell, box cell), n_cells^2 rows =
+// 41 KB per agent): one lane = one agent for all n_steps, env state and the current Q row in registers, the successor row
+// read from and the updated value written to the agent's table in HBM. An agent's working set is the handful of rows along
+// its recent path, so the rows come from L2 / MALL after the first touch. Replaces four launches per step (act, step,
+// learn, reset_done), each of which re-read the state word and a row.
+template <int ENV>
+__global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_t n_steps) {
+  __shared__ SgkRules R;
+  stage_rules(R, a.rules);
+  EpisodeAcc acc;
+  acc_init(acc);
+  const int64_t n_tiles = (a.n + WG - 1) / WG;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t env = tile * WG + threadIdx.x;
+    const bool valid = env < a.n;
+    EnvState s = initial_state(R);
+    if (valid) s = unpack_state(a.state[env]);
+    const uint64_t ge = a.env_base + (uint64_t)env;
+    double *tab = a.table + (valid ? env : 0) * (int64_t)a.n_states * 4;
+    int si = state_index<ENV>(R, s);
+    double2 r01 = reinterpret_cast<const double2 *>(tab + si * 4)[0], r23 = reinterpret_cast<const double2 *>(tab + si * 4)[1];
+    double q0 = r01.x, q1 = r01.y, q2 = r23.x, q3 = r23.y;
+    uint32_t rec = 0;
+    uint32_t x[4] = {0, 0, 0, 0};
+    for (int64_t k = 0; k < n_steps; ++k) {
+      const int64_t t = a.t_agent + k;
+      double eps;
+      if (a.eps_table) {
+        const int64_t tc = t < a.anneal ? t : a.anneal - 1;
+        eps = a.eps_table[tc];
+      } else {
+        eps = epsilon_at(a.eps0, a.anneal, t);
+      }
+      if (k == 0 || (t & 1) == 0) explore_block(a.seed, ge, t, x);
+      double u;
+      int ea;
+      explore_draw(x, t, u, ea);
+      int action = argmax4(q0, q1, q2, q3);
+      if (u < eps) action = ea;
+      bool finished = false;
+      int r_obs = 0, r_hid = 0;
+      const bool live = valid && !s.over;
+      const int si_prev = si;
+      if (live) {
+        int term;
+        transition<ENV>(R, s, action, r_obs, r_hid, term);
+        si = state_index<ENV>(R, s);
+        s.frame += 1;
+        s.ret += r_obs;
+        s.hid += r_hid;
+        finished = term || s.frame >= R.max_iterations;
+      }
+      rec = pack_rec(r_obs, r_hid, (valid && (s.over || finished)) ? 1 : 0, action);
+      double n0 = q0, n1 = q1, n2 = q2, n3 = q3;
+      if (live) {
+        if (si != si_prev) {
+          const double2 *rown = reinterpret_cast<const double2 *>(tab + si * 4);
+          const double2 a01 = rown[0], a23 = rown[1];
+          n0 = a01.x; n1 = a01.y; n2 = a23.x; n3 = a23.y;
+        }
+        const int an = argmax4(n0, n1, n2, n3);
+        const double v_next = pick4(an, n0, n1, n2, n3);
+        const double reward = a.cheat ? (double)r_hid : (double)r_obs;
+        const double q_sa = pick4(action, q0, q1, q2, q3);
+        const double q_new = q_update(q_sa, reward, v_next, a.lr, a.discount);
+        tab[si_prev * 4 + action] = q_new;
+        if (si == si_prev) {  // refused move: the successor row is the row just updated
+          if (action == 0) n0 = q_new; else if (action == 1) n1 = q_new; else if (action == 2) n2 = q_new; else n3 = q_new;
+        }
+      }
+      acc_add(acc, finished, s.ret, s.hid);
+      if (finished) {  // train.py:62-70: the next episode starts from env.reset()
+        a.last_return[env] = s.ret;
+        a.last_perf[env] = s.hid;
+        bump_episode_count(a.n_episodes, env);
+        s = initial_state(R);
+        si = state_index<ENV>(R, s);
+        const double2 *row0 = reinterpret_cast<const double2 *>(tab + si * 4);
+        const double2 a01 = row0[0], a23 = row0[1];  // after this step's store: the start row may be the row just updated
+        n0 = a01.x; n1 = a01.y; n2 = a23.x; n3 = a23.y;
+      }
+      q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+    }
+    if (valid) {
+      a.state[env] = pack_state(s);
+      a.rec[env] = rec;  // boards are re-materialised by the caller (launch_reset mode 2)
+    }
+  }
+  acc_flush(acc, a.metrics);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
@@ -288,6 +379,15 @@ hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t
 size_t tabq_rollout_lds_bytes(const Shard &sh) {
   if (sh.n_states != sh.n_cells) return 0;
   return ((sizeof(SgkRules) + 15) / 16) * 16 + (size_t)sh.rules_host.n_slots * 4 * 64 * sizeof(double);
+}
+
+hipError_t launch_tabq_rollout_hbm(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st) {
+  (void)hipGetLastError();
+  TabqArgs a = make_tabq_args(sh, tq, 0);
+  a.cheat = cheat;
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  SGK_DISPATCH_ENV(sh.env_id, tabq_rollout_hbm_kernel<E><<<dim3(grid), dim3(WG), 0, st>>>(a, n_steps));
+  return hipGetLastError();
 }
 
 hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st) {

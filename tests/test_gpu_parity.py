@@ -364,7 +364,7 @@ def test_tabq_stepwise_kernels_bit_exact(name, cheat):
     agent.close(); env.close()
 
 
-def test_tabq_rollout_sokoban_uses_stepwise_fallback_and_matches():
+def test_tabq_rollout_sokoban_hbm_resident_kernel_matches():
     _torch()
     name, n, steps, seed = "SideEffectsSokoban-v0", 64, 240, 3
     env = S.BatchedGridworldEnv(name, n, seed=seed)
