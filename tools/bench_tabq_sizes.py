@@ -1,0 +1,21 @@
+"""Fused tabular-Q rollout per env and agent count (run with and without SGK_TABQ_HBM=1 to compare the two kernels)."""
+import os, sys, time, types
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
+    sys.path.insert(0, p)
+import safe_grid_agents_amd as S
+
+tag = "hbm" if os.environ.get("SGK_TABQ_HBM") else "lds"
+for name in ("IslandNavigation-v0", "BoatRace-v0", "DistributionalShift-v0"):
+    for n in (4096, 16384, 65536, 262144, 1048576):
+        args = types.SimpleNamespace(lr=0.5, discount=0.99, epsilon=0.01, epsilon_anneal=100000)
+        env = S.BatchedGridworldEnv(name, n, seed=0x5AFE)
+        agent = S.BatchedTabularQAgent(env, args)
+        agent.rollout(200)
+        env.synchronize()
+        t0 = time.perf_counter()
+        agent.rollout(1000)
+        env.synchronize()
+        dt = (time.perf_counter() - t0) / 1000
+        print(f"{tag} {name} n={n}: {dt * 1e6:.2f} us/step = {n / dt:.3e} agent-steps/s", flush=True)
+        agent.close(); env.close()
