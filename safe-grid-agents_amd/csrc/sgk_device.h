@@ -341,6 +341,48 @@ __device__ __forceinline__ double uniform53(uint32_t a, uint32_t b) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// one env.step for one lane, shared by the step kernel and the fused policy rollout
+// ------------------------------------------------------------------------------------------------
+struct StepArgs {
+  const SgkRules *rules;
+  uint64_t *state;
+  const uint8_t *actions;  // nullptr in RANDOM mode
+  uint32_t *rec;
+  int8_t *boards;
+  int32_t *last_return, *last_perf, *n_episodes;
+  long long *metrics;
+  int64_t n;
+  uint64_t seed, env_base, t;  // t = lockstep step index (RANDOM mode RNG key) ...
+  const uint64_t *t_ptr;       // ... or, when non-null (hipGraph replays), *t_ptr + t
+  uint32_t flags;
+};
+
+template <int ENV>
+__device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, int64_t env, bool valid, int action,
+                                         EnvState &s, uint32_t &rec, EpisodeAcc &acc) {
+  bool finished = false;
+  int r_obs = 0, r_hid = 0;
+  if (valid && !s.over) {
+    int term;
+    transition<ENV>(R, s, action, r_obs, r_hid, term);
+    s.frame += 1;
+    s.ret += r_obs;
+    s.hid += r_hid;
+    finished = term || s.frame >= R.max_iterations;
+  }
+  int done = (valid && (s.over || finished)) ? 1 : 0;
+  rec = pack_rec(r_obs, r_hid, done, action);
+  acc_add(acc, finished, s.ret, s.hid);
+  if (finished) {
+    a.last_return[env] = s.ret;
+    a.last_perf[env] = s.hid;
+    bump_episode_count(a.n_episodes, env);
+    if (a.flags & SGK_F_AUTO_RESET) s = initial_state(R);
+    else s.over = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_tiles < 1 ? 1 : n_tiles) : cap); }
@@ -374,4 +416,26 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
     }                                                                                    \
   } while (0)
 
+static inline StepArgs make_step_args(const Shard &sh, const uint8_t *actions, uint32_t flags) {
+  StepArgs a;
+  a.rules = sh.rules_dev;
+  a.state = sh.state;
+  a.actions = actions;
+  a.rec = sh.rec;
+  a.boards = sh.boards;
+  a.last_return = sh.last_return;
+  a.last_perf = sh.last_perf;
+  a.n_episodes = sh.n_episodes;
+  a.metrics = (long long *)sh.metric_slab;
+  a.n = sh.n;
+  a.seed = sh.seed;
+  a.env_base = sh.env_base;
+  a.t = sh.lockstep_t;
+  a.t_ptr = nullptr;
+  a.flags = flags;
+  return a;
+}
+
+// A sub-range [env_off, env_off + count) of the shard as a Shard view (env_off must be a multiple of 256 so that
+// board tiles stay aligned). Used to run independent partitions of the batch on concurrent graph branches.
 }  // namespace sgk

@@ -109,6 +109,93 @@ struct PolicyMfmaGeom {
   static constexpr size_t lds_bytes = sizeof(float) * (W1 + W2 + W3 + 2 * B + 16) + 2 * (size_t)PMFMA_ENVS * K0 + 16;
 };
 
+// The three layers for the 32 envs of one wave, from the board bytes in `tile` to the four scores of env (lane & 31) in
+// lanes 0..31. `between_layers()` runs after layer 1 (the single-launch kernel commits W2 / W3 to LDS there on its first pass).
+template <int K0, int H, class Between>
+__device__ __forceinline__ __attribute__((ext_vector_type(4))) float policy_forward(
+    const float *lw1, const float *lw2, const float *lw3, const float *lb1, const float *lb2, const float *lb3,
+    const int8_t *tile, int wave_env, int lane, Between between_layers) {
+  typedef PolicyMfmaGeom<K0, H> G;
+  constexpr int MT = G::MT, KS1 = G::KS1, NT = PMFMA_NT;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int col = lane & 15, grp = lane >> 4;
+  // ---- layer 1: h1^T = relu(W1 x^T + b1) --------------------------------------------------------------
+  f4 h1[NT][MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const f4 bias = *reinterpret_cast<const f4 *>(lb1 + 16 * mt + 4 * grp);
+#pragma unroll
+    for (int e = 0; e < NT; ++e) h1[e][mt] = bias;
+  }
+#pragma unroll
+  for (int s = 0; s < KS1; ++s) {
+    float x[NT];
+    const int k = 4 * s + grp;
+#pragma unroll
+    for (int e = 0; e < NT; ++e) x[e] = (k < K0) ? (float)tile[(wave_env + 16 * e + col) * K0 + k] : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float a = lw1[(mt * KS1 + s) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < NT; ++e) h1[e][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x[e], h1[e][mt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < NT; ++e)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) h1[e][mt] = __builtin_elementwise_max(h1[e][mt], (f4){0.0f, 0.0f, 0.0f, 0.0f});
+  between_layers();
+  // ---- layer 2: h2^T = relu(W2 h1^T + b2); k-step (mk, r) reads register r of h1 tile mk --------------------
+  f4 h2[NT][MT];
+#pragma unroll
+  for (int mo = 0; mo < MT; ++mo) {
+    const f4 bias = *reinterpret_cast<const f4 *>(lb2 + 16 * mo + 4 * grp);
+#pragma unroll
+    for (int e = 0; e < NT; ++e) h2[e][mo] = bias;
+  }
+#pragma unroll
+  for (int mk = 0; mk < MT; ++mk) {
+    f4 a[MT];
+#pragma unroll
+    for (int mo = 0; mo < MT; ++mo) a[mo] = *reinterpret_cast<const f4 *>(lw2 + ((mo * MT + mk) * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+        for (int e = 0; e < NT; ++e)
+          h2[e][mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mo][r], h1[e][mk][r], h2[e][mo], 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < NT; ++e)
+#pragma unroll
+    for (int mo = 0; mo < MT; ++mo) h2[e][mo] = __builtin_elementwise_max(h2[e][mo], (f4){0.0f, 0.0f, 0.0f, 0.0f});
+  // ---- layer 3: scores^T = W3 h2^T + b3; rows 0..3 of the tile = lanes 0..15, registers 0..3 ---------------
+  f4 sc[NT];
+  {
+    const f4 bias = *reinterpret_cast<const f4 *>(lb3 + 4 * grp);
+#pragma unroll
+    for (int e = 0; e < NT; ++e) sc[e] = bias;
+  }
+#pragma unroll
+  for (int mk = 0; mk < MT; ++mk) {
+    const f4 a = *reinterpret_cast<const f4 *>(lw3 + (mk * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int e = 0; e < NT; ++e) sc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], h2[e][mk][r], sc[e], 0, 0, 0);
+  }
+  // lanes 0..15 hold the four scores of env tile e; bring tile 1 to lanes 16..31 so that 32 lanes pick 32 actions at once
+  static_assert(NT == 2, "the epilogue pairs two env tiles");
+  f4 mine;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float other = __shfl(sc[1][r], lane - 16, 64);
+    mine[r] = grp == 1 ? other : sc[0][r];
+  }
+  return mine;
+}
+
 template <int K0, int H, int MODE>
 __global__ __launch_bounds__(PMFMA_WG) void policy_mfma_kernel(const int8_t *__restrict__ boards, int pitch,
                                                                const float *__restrict__ w1t, const float *__restrict__ b1,
@@ -207,7 +294,6 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_mfma_kernel(const int8_t *__r
   if (eps_ptr) eps = *eps_ptr;
   if (draw_ptr) draw = *draw_ptr;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = lane & 15, grp = lane >> 4;
   if ((int64_t)blockIdx.x < n_tiles) tile_commit(tiles, blockIdx.x);
   __syncthreads();
   int buf = 0;
@@ -221,92 +307,21 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_mfma_kernel(const int8_t *__r
     double u;
     uint32_t x2;
     draw_block<MODE>(env_base + (uint64_t)env, draw, seed, u, x2);  // VALU work in the shadow of the MFMAs below
-    // ---- layer 1: h1^T = relu(W1 x^T + b1) --------------------------------------------------------------
-    f4 h1[NT][MT];
+    const f4 mine = policy_forward<K0, H>(lw1, lw2, lw3, lb1, lb2, lb3, tile, wave_env, lane, [&]() {
+      if (t == (int64_t)blockIdx.x) {  // first pass: W2 / W3 have arrived by now
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const f4 bias = *reinterpret_cast<const f4 *>(lb1 + 16 * mt + 4 * grp);
+        for (int it = 0; it < N2; ++it) {
+          const int i = it * PMFMA_WG + threadIdx.x;
+          if (i < G::W2 / 4) reinterpret_cast<f4 *>(lw2)[i] = r2[it];
+        }
 #pragma unroll
-      for (int e = 0; e < NT; ++e) h1[e][mt] = bias;
-    }
-#pragma unroll
-    for (int s = 0; s < KS1; ++s) {
-      float x[NT];
-      const int k = 4 * s + grp;
-#pragma unroll
-      for (int e = 0; e < NT; ++e) x[e] = (k < K0) ? (float)tile[(wave_env + 16 * e + col) * K0 + k] : 0.0f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float a = lw1[(mt * KS1 + s) * 64 + lane];
-#pragma unroll
-        for (int e = 0; e < NT; ++e) h1[e][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x[e], h1[e][mt], 0, 0, 0);
+        for (int it = 0; it < N3; ++it) {
+          const int i = it * PMFMA_WG + threadIdx.x;
+          if (i < G::W3) lw3[i] = r3[it];
+        }
+        __syncthreads();
       }
-    }
-#pragma unroll
-    for (int e = 0; e < NT; ++e)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) h1[e][mt] = __builtin_elementwise_max(h1[e][mt], (f4){0.0f, 0.0f, 0.0f, 0.0f});
-    if (t == (int64_t)blockIdx.x) {  // first pass: W2 / W3 have arrived by now
-#pragma unroll
-      for (int it = 0; it < N2; ++it) {
-        const int i = it * PMFMA_WG + threadIdx.x;
-        if (i < G::W2 / 4) reinterpret_cast<f4 *>(lw2)[i] = r2[it];
-      }
-#pragma unroll
-      for (int it = 0; it < N3; ++it) {
-        const int i = it * PMFMA_WG + threadIdx.x;
-        if (i < G::W3) lw3[i] = r3[it];
-      }
-      __syncthreads();
-    }
-    // ---- layer 2: h2^T = relu(W2 h1^T + b2); k-step (mk, r) reads register r of h1 tile mk --------------------
-    f4 h2[NT][MT];
-#pragma unroll
-    for (int mo = 0; mo < MT; ++mo) {
-      const f4 bias = *reinterpret_cast<const f4 *>(lb2 + 16 * mo + 4 * grp);
-#pragma unroll
-      for (int e = 0; e < NT; ++e) h2[e][mo] = bias;
-    }
-#pragma unroll
-    for (int mk = 0; mk < MT; ++mk) {
-      f4 a[MT];
-#pragma unroll
-      for (int mo = 0; mo < MT; ++mo) a[mo] = *reinterpret_cast<const f4 *>(lw2 + ((mo * MT + mk) * 64 + lane) * 4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int mo = 0; mo < MT; ++mo)
-#pragma unroll
-          for (int e = 0; e < NT; ++e)
-            h2[e][mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mo][r], h1[e][mk][r], h2[e][mo], 0, 0, 0);
-    }
-#pragma unroll
-    for (int e = 0; e < NT; ++e)
-#pragma unroll
-      for (int mo = 0; mo < MT; ++mo) h2[e][mo] = __builtin_elementwise_max(h2[e][mo], (f4){0.0f, 0.0f, 0.0f, 0.0f});
-    // ---- layer 3: scores^T = W3 h2^T + b3; rows 0..3 of the tile = lanes 0..15, registers 0..3 ---------------
-    f4 sc[NT];
-    {
-      const f4 bias = *reinterpret_cast<const f4 *>(lb3 + 4 * grp);
-#pragma unroll
-      for (int e = 0; e < NT; ++e) sc[e] = bias;
-    }
-#pragma unroll
-    for (int mk = 0; mk < MT; ++mk) {
-      const f4 a = *reinterpret_cast<const f4 *>(lw3 + (mk * 64 + lane) * 4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int e = 0; e < NT; ++e) sc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], h2[e][mk][r], sc[e], 0, 0, 0);
-    }
-    // lanes 0..15 hold the four scores of env tile e; bring tile 1 to lanes 16..31 so that 32 lanes pick 32 actions at once
-    static_assert(NT == 2, "the epilogue pairs two env tiles");
-    f4 mine;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float other = __shfl(sc[1][r], lane - 16, 64);
-      mine[r] = grp == 1 ? other : sc[0][r];
-    }
+    });
     if (lane < 32 && env < n) {
       actions[env] = (uint8_t)select_action<MODE>(mine[0], mine[1], mine[2], mine[3], u, x2, eps);
       if (scores_out) reinterpret_cast<float4 *>(scores_out)[env] = make_float4(mine[0], mine[1], mine[2], mine[3]);

@@ -65,45 +65,6 @@ __global__ __launch_bounds__(WG) void metrics_init_kernel(long long *__restrict_
 // ------------------------------------------------------------------------------------------------
 // the lockstep step kernel: env.step(action) for every env of the shard
 // ------------------------------------------------------------------------------------------------
-struct StepArgs {
-  const SgkRules *rules;
-  uint64_t *state;
-  const uint8_t *actions;  // nullptr in RANDOM mode
-  uint32_t *rec;
-  int8_t *boards;
-  int32_t *last_return, *last_perf, *n_episodes;
-  long long *metrics;
-  int64_t n;
-  uint64_t seed, env_base, t;  // t = lockstep step index (RANDOM mode RNG key) ...
-  const uint64_t *t_ptr;       // ... or, when non-null (hipGraph replays), *t_ptr + t
-  uint32_t flags;
-};
-
-template <int ENV>
-__device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, int64_t env, bool valid, int action,
-                                         EnvState &s, uint32_t &rec, EpisodeAcc &acc) {
-  bool finished = false;
-  int r_obs = 0, r_hid = 0;
-  if (valid && !s.over) {
-    int term;
-    transition<ENV>(R, s, action, r_obs, r_hid, term);
-    s.frame += 1;
-    s.ret += r_obs;
-    s.hid += r_hid;
-    finished = term || s.frame >= R.max_iterations;
-  }
-  int done = (valid && (s.over || finished)) ? 1 : 0;
-  rec = pack_rec(r_obs, r_hid, done, action);
-  acc_add(acc, finished, s.ret, s.hid);
-  if (finished) {
-    a.last_return[env] = s.ret;
-    a.last_perf[env] = s.hid;
-    bump_episode_count(a.n_episodes, env);
-    if (a.flags & SGK_F_AUTO_RESET) s = initial_state(R);
-    else s.over = 1;
-  }
-}
-
 template <int ENV, int LAYOUT, bool RANDOM>
 __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
   __shared__ SgkRules R;
@@ -402,28 +363,6 @@ __global__ __launch_bounds__(WG) void finished_scatter_kernel(const uint32_t *__
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-static StepArgs make_step_args(const Shard &sh, const uint8_t *actions, uint32_t flags) {
-  StepArgs a;
-  a.rules = sh.rules_dev;
-  a.state = sh.state;
-  a.actions = actions;
-  a.rec = sh.rec;
-  a.boards = sh.boards;
-  a.last_return = sh.last_return;
-  a.last_perf = sh.last_perf;
-  a.n_episodes = sh.n_episodes;
-  a.metrics = (long long *)sh.metric_slab;
-  a.n = sh.n;
-  a.seed = sh.seed;
-  a.env_base = sh.env_base;
-  a.t = sh.lockstep_t;
-  a.t_ptr = nullptr;
-  a.flags = flags;
-  return a;
-}
-
-// A sub-range [env_off, env_off + count) of the shard as a Shard view (env_off must be a multiple of 256 so that
-// board tiles stay aligned). Used to run independent partitions of the batch on concurrent graph branches.
 static Shard shard_view(const Shard &sh, int64_t env_off, int64_t count) {
   Shard v = sh;
   v.n = count;
