@@ -243,6 +243,18 @@ SGK_API int sgk_categorical_sample(sgk_env *h, const float *logits_dev, uint64_t
 SGK_API int sgk_policy_sample(sgk_env *h, const sgk_mlp_weights *w, uint64_t draw_index, const uint64_t *draw_index_dev,
                               uint8_t *actions_out_dev, float *logits_out_dev);
 
+/* n_steps of {forward, action draw, env.step} for every env in ONE launch, the weights staged once and the env state kept
+ * in registers: the inner loop of PPOBaseAgent.gather_rollout (reference policy_base.py:142-163; mode 1, the old policy's
+ * weights) or acting with a frozen Q-network (eval.py:33-36, warmup-style data collection; mode 0 with a fixed epsilon).
+ * Step k draws with index draw_index0 + k, so the actions equal those of n_steps calls of sgk_policy_sample / sgk_policy_act
+ * + sgk_step. flags: SGK_F_AUTO_RESET or 0 (finished envs idle, as gather_rollout's per-env episodes need). Optional
+ * trajectory outputs in device memory: states_out int8 [n_steps][n_envs][n_cells] (the board each action was chosen on),
+ * actions_out uint8 [n_steps][n_envs], recs_out sgk_step_rec [n_steps][n_envs]. Episode arrays, metrics, state words, the
+ * last step records and the boards are left as after the equivalent sequence of calls. */
+SGK_API int sgk_policy_rollout(sgk_env *h, const sgk_mlp_weights *w, int32_t mode, double epsilon, uint64_t draw_index0,
+                               int32_t n_steps, uint32_t flags, int8_t *states_out_dev, uint8_t *actions_out_dev,
+                               sgk_step_rec *recs_out_dev);
+
 /* ---- PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186), batched ------------------------------ */
 /* rewards_dev / returns_dev: float32 [n_trajectories][t_max] row-major; lengths_dev: int32 [n_trajectories] or NULL
  * (every trajectory t_max long). returns[i][t] = sum_{k >= t} float32(discount ** k) * rewards[i][k], accumulated left

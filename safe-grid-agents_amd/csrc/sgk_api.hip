@@ -599,6 +599,27 @@ int sgk_policy_sample(sgk_env *h, const sgk_mlp_weights *w, uint64_t draw_index,
   return SGK_OK;
 }
 
+int sgk_policy_rollout(sgk_env *h, const sgk_mlp_weights *w, int32_t mode, double epsilon, uint64_t draw_index0, int32_t n_steps,
+                       uint32_t flags, int8_t *states_out_dev, uint8_t *actions_out_dev, sgk_step_rec *recs_out_dev) {
+  SGK_CHECK_HANDLE(h);
+  if (!w || !w->w1t || !w->b1 || !w->w2 || !w->b2 || !w->w3t || !w->b3) return fail(SGK_ERR_INVALID, "NULL argument");
+  if (w->n_hidden != 64 && w->n_hidden != 100 && w->n_hidden != 128)
+    return fail(SGK_ERR_INVALID, "sgk_policy_rollout is built for n_hidden in {64, 100 (the reference default), 128}");
+  if (mode != 0 && mode != 1) return fail(SGK_ERR_INVALID, "mode must be 0 (epsilon-greedy) or 1 (categorical)");
+  if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
+  if (flags & ~(uint32_t)SGK_F_AUTO_RESET) return fail(SGK_ERR_INVALID, "only SGK_F_AUTO_RESET is meaningful here");
+  if (n_steps == 0) return SGK_OK;
+  sgk::Shard &s = h->sh;
+  sgk::PolicyWeights pw{w->w1t, w->b1, w->w2, w->b2, w->w3t, w->b3, w->n_hidden};
+  SGK_HIP(sgk::launch_policy_rollout(s, mode, pw, epsilon, draw_index0, n_steps, flags, states_out_dev, actions_out_dev,
+                                     reinterpret_cast<uint32_t *>(recs_out_dev), h->stream));
+  SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));  // materialise the boards of the final states
+  s.lockstep_t += (uint64_t)n_steps;
+  h->t_dev_stale = true;
+  h->steps_issued += s.n * n_steps;
+  return SGK_OK;
+}
+
 int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const int32_t *lengths_dev, float *returns_dev,
                            int64_t n_trajectories, int32_t t_max, double discount) {
   SGK_CHECK_HANDLE(h);

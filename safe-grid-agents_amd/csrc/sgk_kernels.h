@@ -55,6 +55,9 @@ struct PolicyWeights {
 // mode 0: epsilon-greedy over the scores (DeepQAgent.act_explore); mode 1: Categorical(logits = scores).sample() (PPO)
 hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, uint8_t *actions, float *scores, double eps,
                              uint64_t draw, const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
+// n_steps of {forward, draw, env.step} in one launch; trajectory outputs optional ([n_steps][n]...); SGK_F_AUTO_RESET in flags
+hipError_t launch_policy_rollout(const Shard &sh, int mode, const PolicyWeights &w, double eps, uint64_t draw0, int32_t n_steps,
+                                 uint32_t flags, int8_t *states_out, uint8_t *actions_out, uint32_t *recs_out, hipStream_t st);
 hipError_t launch_eps_greedy(const Shard &sh, int mode, const float *scores, uint8_t *actions, double eps, uint64_t draw,
                              const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
 hipError_t launch_discounted_returns(const Shard &sh, const float *rewards, const int32_t *lengths, const float *gamma_pow,

@@ -332,6 +332,135 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_mfma_kernel(const int8_t *__r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// n_steps of {policy forward, action draw, env.step} in ONE launch: PPOBaseAgent.gather_rollout's inner loop (reference
+// policy_base.py:142-163: old_policy.act_explore -> env.step -> store state / action / reward) or DeepQAgent acting with
+// frozen weights (eval.py:33-36), for every env, with the network weights staged in LDS once and the env state in registers
+// for the whole rollout. A wave owns 32 envs (lanes 0..31 hold their state words); their boards live as rows of the
+// workgroup's LDS tile -- the MFMA forward reads them there -- and are kept current by re-drawing only the cells a step
+// changed. Everything a wave touches in the loop is its own (its 32 tile rows, its lanes' registers), so the step loop has
+// no workgroup barrier. Per step and wave: 574 MFMAs (H = 100), one Philox block, one table lookup, <= 4 LDS byte writes,
+// and the optional trajectory stores (board rows as dwords, one action byte, one 4-byte record per env).
+// ------------------------------------------------------------------------------------------------
+struct RolloutArgs {
+  StepArgs env;              // state / rec / episode arrays / metrics / rules / n / seed / env_base / flags
+  PolicyWeights w;
+  double eps;                // MODE 0
+  uint64_t draw0;            // draw index of the first step; step k uses draw0 + k
+  int32_t n_steps;
+  int8_t *states_out;        // [n_steps][n][K0] boards the policy acted on, or null
+  uint8_t *actions_out;      // [n_steps][n] or null
+  uint32_t *recs_out;        // [n_steps][n] step records or null
+};
+
+template <int ENV, int H, int MODE>
+__global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a) {
+  constexpr int K0 = Geom<ENV>::NC;
+  typedef PolicyMfmaGeom<K0, H> G;
+  constexpr int MT = G::MT, KS1 = G::KS1;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char policy_smem[];
+  float *lw1 = reinterpret_cast<float *>(policy_smem);
+  float *lw2 = lw1 + G::W1;
+  float *lw3 = lw2 + G::W2;
+  float *lb1 = lw3 + G::W3;
+  float *lb2 = lb1 + G::B;
+  float *lb3 = lb2 + G::B;
+  int8_t *tile = reinterpret_cast<int8_t *>(lb3 + 16);                      // [PMFMA_ENVS][K0]
+  SgkRules &R = *reinterpret_cast<SgkRules *>(tile + 2 * PMFMA_ENVS * K0);  // behind the (here unused) second tile buffer
+  const PolicyWeights &w = a.w;
+  // weights in operand order (same arrangement as policy_mfma_kernel; staged once per launch, so plainly)
+  for (int i = threadIdx.x; i < G::W1; i += PMFMA_WG) {
+    const int l = i & 63, s = (i >> 6) % KS1, mt = (i >> 6) / KS1;
+    const int nrn = 16 * mt + (l & 15), k = 4 * s + (l >> 4);
+    lw1[i] = (nrn < H && k < K0) ? w.w1t[k * H + nrn] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < G::W2 / 4; i += PMFMA_WG) {
+    const int l = i & 63, mk = (i >> 6) % MT, mo = (i >> 6) / MT;
+    const int nrn = 16 * mo + (l & 15), k = 16 * mk + 4 * (l >> 4);
+    f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (nrn < H && k < H) v = *reinterpret_cast<const f4 *>(w.w2 + nrn * H + k);
+    reinterpret_cast<f4 *>(lw2)[i] = v;
+  }
+  for (int i = threadIdx.x; i < G::W3; i += PMFMA_WG) {
+    const int r = i & 3, l = (i >> 2) & 63, mk = i >> 8;
+    const int ac = l & 15, k = 16 * mk + 4 * (l >> 4) + r;
+    lw3[i] = (ac < 4 && k < H) ? w.w3t[k * 4 + ac] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < G::B; i += PMFMA_WG) {
+    lb1[i] = i < H ? w.b1[i] : 0.0f;
+    lb2[i] = i < H ? w.b2[i] : 0.0f;
+  }
+  if (threadIdx.x < 16) lb3[threadIdx.x] = threadIdx.x < 4 ? w.b3[threadIdx.x] : 0.0f;
+  stage_rules(R, a.env.rules);  // ends with a workgroup barrier: weights and rules are in place
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_env = wave * PMFMA_NT * 16;
+  const bool owner = lane < 32;  // lanes 32..63 only take part in the MFMAs and the row stores
+  const int64_t n = a.env.n;
+  const int64_t n_tiles = (n + PMFMA_ENVS - 1) / PMFMA_ENVS;
+  EpisodeAcc acc;
+  acc_init(acc);
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int64_t env = t * PMFMA_ENVS + wave_env + (lane & 31);
+    const bool valid = owner && env < n;
+    EnvState s = initial_state(R);
+    if (valid) s = unpack_state(a.env.state[env]);
+    int8_t *row = tile + (wave_env + (lane & 31)) * K0;
+    if (owner) {  // draw this env's board from its state word
+      for (int c = 0; c < K0; ++c) row[c] = (int8_t)R.templ[c];
+      if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) row[s.box] = (int8_t)R.value_box;
+      row[s.pos] = (int8_t)R.agent_value[s.pos];
+    }
+    uint32_t rec = 0;
+    for (int k = 0; k < a.n_steps; ++k) {
+      __builtin_amdgcn_wave_barrier();  // the rows written by lanes 0..31 are read by all 64 lanes below
+      if (a.states_out) {  // the boards the policy is about to act on: this wave's 32 rows are contiguous in the output
+        const int64_t first = t * PMFMA_ENVS + wave_env;
+        const int rows = (int)max((int64_t)0, min((int64_t)32, n - first));
+        int8_t *dst = a.states_out + ((int64_t)k * n + first) * K0;
+        const int8_t *src = tile + wave_env * K0;
+        if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+          for (int i = lane; i < rows * K0 / 4; i += 64) reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+          for (int i = (rows * K0 / 4) * 4 + lane; i < rows * K0; i += 64) dst[i] = src[i];
+        } else {
+          for (int i = lane; i < rows * K0; i += 64) dst[i] = src[i];
+        }
+      }
+      double u;
+      uint32_t x2;
+      draw_block<MODE>(a.env.env_base + (uint64_t)env, a.draw0 + (uint64_t)k, a.env.seed, u, x2);
+      const f4 sc = policy_forward<K0, H>(lw1, lw2, lw3, lb1, lb2, lb3, tile, wave_env, lane, []() {});
+      const int action = select_action<MODE>(sc[0], sc[1], sc[2], sc[3], u, x2, a.eps);
+      const int old_pos = s.pos, old_box = s.box;
+      step_one<ENV>(R, a.env, env, valid, action, s, rec, acc);
+      if (valid) {
+        if (a.actions_out) a.actions_out[(int64_t)k * n + env] = (uint8_t)action;
+        if (a.recs_out) a.recs_out[(int64_t)k * n + env] = rec;
+      }
+      if (owner && (s.pos != old_pos || s.box != old_box)) {  // re-draw the cells this step changed (a reset included)
+        row[old_pos] = (int8_t)R.templ[old_pos];
+        if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
+          row[old_box] = (int8_t)R.templ[old_box];
+          row[s.box] = (int8_t)R.value_box;
+        }
+        row[s.pos] = (int8_t)R.agent_value[s.pos];
+      }
+    }
+    if (valid) {
+      a.env.state[env] = pack_state(s);
+      a.env.rec[env] = rec;  // the env's own boards are re-materialised by the caller (launch_reset mode 2)
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  acc_flush(acc, a.env.metrics);
+}
+
+template <int ENV, int H>
+constexpr size_t policy_rollout_lds_bytes() {
+  return PolicyMfmaGeom<Geom<ENV>::NC, H>::lds_bytes + sizeof(SgkRules) + 16;
+}
+
 // PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186) for a batch of trajectories.
 // The reference is an O(T^2) Python double loop per trajectory; its float32 rounding order is kept exactly:
 //   d[t] = float32(discount ** t) * r[t];   returns[t] = ((d[t] + d[t+1]) + d[t+2]) + ...   (Python sum(): left to right)
@@ -422,6 +551,49 @@ hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, 
 #undef SGK_POLICY_LAUNCH
 #undef SGK_POLICY_LAUNCH_H
 #undef SGK_POLICY_LAUNCH_M
+  return hipGetLastError();
+}
+
+hipError_t launch_policy_rollout(const Shard &sh, int mode, const PolicyWeights &w, double eps, uint64_t draw0, int32_t n_steps,
+                                 uint32_t flags, int8_t *states_out, uint8_t *actions_out, uint32_t *recs_out, hipStream_t st) {
+  (void)hipGetLastError();
+  RolloutArgs a;
+  a.env = make_step_args(sh, nullptr, flags);
+  a.w = w;
+  a.eps = eps;
+  a.draw0 = draw0;
+  a.n_steps = n_steps;
+  a.states_out = states_out;
+  a.actions_out = actions_out;
+  a.recs_out = recs_out;
+  int grid = grid_for((sh.n + PMFMA_ENVS - 1) / PMFMA_ENVS, sh.n_cus);
+#define SGK_ROLLOUT_LAUNCH_M(E, HID, MODE)                                                                                 \
+  do {                                                                                                                     \
+    constexpr size_t lds = policy_rollout_lds_bytes<E, HID>();                                                             \
+    static unsigned long long opted_in = 0;                                                                                \
+    if (!((opted_in >> (sh.device & 63)) & 1ull)) {                                                                        \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&policy_rollout_kernel<E, HID, MODE>),            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+      if (ae != hipSuccess) return ae;                                                                                     \
+      opted_in |= 1ull << (sh.device & 63);                                                                                \
+    }                                                                                                                      \
+    policy_rollout_kernel<E, HID, MODE><<<dim3(grid), dim3(PMFMA_WG), lds, st>>>(a);                                       \
+  } while (0)
+#define SGK_ROLLOUT_LAUNCH_H(E, HID)                                                                                       \
+  do {                                                                                                                     \
+    if (mode == 0) SGK_ROLLOUT_LAUNCH_M(E, HID, 0);                                                                        \
+    else SGK_ROLLOUT_LAUNCH_M(E, HID, 1);                                                                                  \
+  } while (0)
+  SGK_DISPATCH_ENV(sh.env_id, {
+    switch (w.n_hidden) {
+    case 64: SGK_ROLLOUT_LAUNCH_H(E, 64); break;
+    case 100: SGK_ROLLOUT_LAUNCH_H(E, 100); break;
+    case 128: SGK_ROLLOUT_LAUNCH_H(E, 128); break;
+    default: return hipErrorInvalidValue;
+    }
+  });
+#undef SGK_ROLLOUT_LAUNCH_H
+#undef SGK_ROLLOUT_LAUNCH_M
   return hipGetLastError();
 }
 

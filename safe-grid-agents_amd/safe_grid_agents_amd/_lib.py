@@ -93,6 +93,8 @@ _SIGNATURES = {
     "sgk_policy_act": (ctypes.c_int, [_V, ctypes.POINTER(SgkMlpWeights), ctypes.c_double, ctypes.c_uint64, _V, _V, _V, _V]),
     "sgk_categorical_sample": (ctypes.c_int, [_V, _V, ctypes.c_uint64, _V, _V]),
     "sgk_policy_sample": (ctypes.c_int, [_V, ctypes.POINTER(SgkMlpWeights), ctypes.c_uint64, _V, _V, _V]),
+    "sgk_policy_rollout": (ctypes.c_int, [_V, ctypes.POINTER(SgkMlpWeights), ctypes.c_int32, ctypes.c_double, ctypes.c_uint64,
+                                          ctypes.c_int32, ctypes.c_uint32, _V, _V, _V]),
     "sgk_discounted_returns": (ctypes.c_int, [_V, _V, _V, _V, ctypes.c_int64, ctypes.c_int32, ctypes.c_double]),
     "sgk_copy_boards": (ctypes.c_int, [_V, _V]),
     "sgk_copy_step_records": (ctypes.c_int, [_V, _V]),

@@ -132,6 +132,22 @@ class BatchedDeepQAgent:
     def sync_target_Q(self):
         self.target_Q.load_state_dict(self.Q.state_dict())
 
+    def greedy_weights(self):
+        """Q-network weights in the fused kernels' layout (greedy evaluation, batched_default_eval), or None."""
+        if not self.fused_policy:
+            return None
+        if self._fw_stale:
+            self._refresh_fused_weights()
+        return self._fw
+
+    def act_rollout(self, n_steps, epsilon=0.0, auto_reset=True):
+        """n_steps of acting with the current (frozen) Q-network in one launch: forward, epsilon-greedy draw with a FIXED
+        epsilon, env.step (evaluation and data collection; learning schedules epsilon per step and uses step())."""
+        weights = self.greedy_weights()
+        assert weights is not None, "act_rollout needs the fused policy kernel (two layers of 64 / 100 / 128 units)"
+        self.env.policy_rollout(weights, n_steps, mode="greedy", epsilon=epsilon, draw_index0=self.t, auto_reset=auto_reset)
+        self.t += int(n_steps)
+
     def _refresh_fused_weights(self):
         """The kernel wants W1 and W3 transposed (rows of W1^T / W3^T are what one input cell / one hidden unit multiplies);
         the other four tensors are read in place from the torch parameters (optimiser steps update them in place)."""

@@ -355,6 +355,29 @@ class BatchedGridworldEnv:
         self._sync_lib_to_torch()
         return out
 
+    def policy_rollout(self, weights, n_steps, mode="sample", epsilon=0.0, draw_index0=0, auto_reset=False, states=None,
+                       actions=None, recs=None):
+        """n_steps of {MLP forward, action draw, env.step} in ONE HIP launch (sgk_policy_rollout): `weights` as for
+        policy_act / policy_sample; mode "sample" = Categorical(logits) (PPO), "greedy" = epsilon-greedy with a fixed
+        epsilon (DeepQ acting with frozen weights). Optional device outputs: states int8 [n_steps, N, cells] (the board
+        each action was chosen on), actions uint8 [n_steps, N], recs int8 [n_steps, N, 4]."""
+        w = _lib.SgkMlpWeights(*(ctypes.c_void_p(weights[k].data_ptr()) for k in ("w1t", "b1", "w2", "b2", "w3t", "b3")),
+                               int(weights["b1"].numel()))
+
+        def ptr(t, shape, what):
+            if t is None:
+                return None
+            assert t.is_cuda and t.is_contiguous() and tuple(t.shape) == shape, "%s: expected contiguous %r" % (what, shape)
+            return ctypes.c_void_p(t.data_ptr())
+
+        n = self.n_envs
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_policy_rollout(
+            self._h.ptr, ctypes.byref(w), {"greedy": 0, "sample": 1}[mode], float(epsilon), int(draw_index0), int(n_steps),
+            _lib.F_AUTO_RESET if auto_reset else 0, ptr(states, (n_steps, n, self.n_cells), "states"),
+            ptr(actions, (n_steps, n), "actions"), ptr(recs, (n_steps, n, 4), "recs")))
+        self._sync_lib_to_torch()
+
     def discounted_returns(self, rewards, discount, lengths=None, out=None):
         """PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186) for a batch: rewards float32
         [n_trajectories, T] on this GPU (lengths int32 [n_trajectories] optional) -> returns of the same shape, with the

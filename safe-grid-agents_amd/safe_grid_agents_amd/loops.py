@@ -179,6 +179,12 @@ def batched_default_eval(agent, env, eval_timesteps):
     boards = bool(getattr(agent, "reads_boards", False))  # table agents act on the state word; networks need the cells
     env.metrics_reset()
     env.reset()
+    weights = agent.greedy_weights() if hasattr(agent, "greedy_weights") else None
+    if weights is not None:  # fused MLP policy: each phase is one sgk_policy_rollout launch (auto-reset == step + reset_done)
+        if int(eval_timesteps) > 1:
+            env.policy_rollout(weights, int(eval_timesteps) - 1, mode="greedy", epsilon=0.0, auto_reset=True)
+        env.policy_rollout(weights, int(env.info.max_iterations), mode="greedy", epsilon=0.0, auto_reset=False)
+        return BatchMetrics(env.metrics())
     for _ in range(max(int(eval_timesteps) - 1, 0)):
         env.step(agent.act(), auto_reset=False, write_boards=boards)
         env.reset_done()
@@ -207,7 +213,8 @@ def rollout_buffers(env, horizon=None):
 def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None, buffers=None):
     """PPOBaseAgent.gather_rollout (reference policy_base.py:133-177) with one rollout = one episode PER ENV, all envs in
     lockstep: `policy(boards) -> uint8 actions [N]` acts on the int8 board view (a policy with the attribute
-    `writes_out = True` is called as policy(boards, out=row) instead), finished envs idle until the horizon, and
+    `writes_out = True` is called as policy(boards, out=row) instead; one with `fused_rollout() -> (weights, draw0)` hands
+    the whole loop to sgk_policy_rollout, one launch), finished envs idle until the horizon, and
     the discounted returns come from the bit-exact batched kernel (policy_base.py:179-186). Everything stays in HBM.
 
     Returns BatchedRollout(states int8 [T, N, cells], actions uint8 [T, N], rewards float32 [N, T], returns float32 [N, T],
@@ -222,17 +229,23 @@ def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None, buf
     T, n = actions.shape
     dev = actions.device
     env.reset()
-    record = env._device_views()["rec"]
-    direct = bool(getattr(policy, "writes_out", False))  # policy(boards, out=row) stores its actions itself
-    for t in range(T):  # four launches per lockstep step: policy, board copy, env step, record copy
-        boards = env.boards().reshape(n, -1)
-        if direct:
-            policy(boards, out=actions[t])
-        else:
-            actions[t].copy_(policy(boards))
-        states[t].copy_(boards)
-        env.step(actions[t], auto_reset=False)
-        recs[t].copy_(record)
+    fused = getattr(policy, "fused_rollout", None)  # -> (MLP weights, first draw index): the whole loop is one launch
+    if fused is not None:
+        weights, draw0 = fused()
+        env.policy_rollout(weights, T, mode="sample", draw_index0=draw0, auto_reset=False, states=states, actions=actions,
+                           recs=recs)
+    else:
+        record = env._device_views()["rec"]
+        direct = bool(getattr(policy, "writes_out", False))  # policy(boards, out=row) stores its actions itself
+        for t in range(T):  # four launches per lockstep step: policy, board copy, env step, record copy
+            boards = env.boards().reshape(n, -1)
+            if direct:
+                policy(boards, out=actions[t])
+            else:
+                actions[t].copy_(policy(boards))
+            states[t].copy_(boards)
+            env.step(actions[t], auto_reset=False)
+            recs[t].copy_(record)
     # a finished env idles: its later records read (0, 0, done, .), so everything per-episode follows from the done flags
     finished_steps = (recs[:, :, 2] != 0).sum(0, dtype=torch.int32)  # done stays set from the last step of the episode on
     lengths.copy_(torch.clamp(T - finished_steps + 1, max=T))

@@ -263,6 +263,7 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         own = [p for name, p in self.net.named_parameters() if not name.startswith("old_policy.")]
         self.net.optim = torch.optim.Adam(own, self.net.lr, capturable=True, fused=True)
         self.graph_epochs = bool(graph_epochs)
+        self.fused_rollout = True  # gather with sgk_policy_rollout when the fused policy kernel applies
         self._buffers = None   # rollout tensors, allocated once: the captured epochs read fixed addresses
         self._graph = None
         self._stats = torch.zeros((self.epochs, 3), dtype=torch.float32, device=self.device)  # policy loss, value loss, entropy
@@ -294,6 +295,16 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
             out, _ = (self.net.old_policy if old else self.net)(self._observe())
         return out
 
+    def greedy_weights(self):
+        """The CURRENT policy's trunk + actor weights in the fused kernels' layout (greedy evaluation, batched_default_eval),
+        or None when the fused kernels do not apply."""
+        if not self.fused_policy:
+            return None
+        net = self.net
+        l1, l2, head = net.network[0][0], net.network[1][0][0], net.actor
+        return {"w1t": l1.weight.data.t().contiguous(), "b1": l1.bias.data, "w2": l2.weight.data, "b2": l2.bias.data,
+                "w3t": head.weight.data.t().contiguous(), "b3": head.bias.data}
+
     def act(self, boards=None):
         """PPOBaseAgent.act for every env: argmax of the current policy's logits (reference policy_base.py:47-52)."""
         return self.logits().argmax(-1).to(torch.uint8)
@@ -317,6 +328,11 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         policy.writes_out = True  # the draw kernel stores straight into the rollout's action row
         if self._buffers is None or (horizon is not None and int(horizon) != self._buffers["actions"].shape[0]):
             self._buffers, self._graph = rollout_buffers(self.env, horizon), None
+        steps = self._buffers["actions"].shape[0]
+        if self.fused_policy and self.fused_rollout:  # forward + draw + env.step of all steps in ONE launch
+            first_draw = self.draws
+            policy.fused_rollout = lambda: (self._fw, first_draw)
+            self.draws += steps
         return batched_gather_rollout(policy, self.env, self.discount, cheat=cheat, horizon=horizon, buffers=self._buffers)
 
     def _minibatch(self, rollout, pick=None):

@@ -258,3 +258,43 @@ def test_fused_policy_kernel_other_hidden_widths(name, hidden):
     bad = types.SimpleNamespace(**{**vars(_args()), "n_hidden": 72})
     assert not S.BatchedDeepQAgent(env, bad).fused_policy  # other widths take the torch forward + sgk_epsilon_greedy
     env.close()
+
+
+def test_fused_greedy_eval_and_act_rollout_equal_the_stepwise_paths():
+    """batched_default_eval through sgk_policy_rollout (two launches) == the per-step loop (act, step, reset_done) on the same
+    agent; act_rollout(n, eps) == n calls of policy_act + step with the same draw indices. Integer results: exact."""
+    import torch
+
+    torch.manual_seed(5)
+    name, n, seed = "SideEffectsSokoban-v0", 777, 9
+    outs = []
+    for fused in (True, False):
+        env = S.BatchedGridworldEnv(name, n, seed=seed)
+        env.bind_torch_stream()
+        torch.manual_seed(5)
+        agent = S.BatchedDeepQAgent(env, _args())
+        with torch.no_grad():
+            for p in agent.Q.parameters():
+                p.mul_(3.0)
+        agent._fw_stale = True
+        if not fused:
+            agent.greedy_weights = lambda: None  # force the per-step loop
+        bm = S.batched_default_eval(agent, env, 57)
+        outs.append((np.asarray(bm.vec).copy(), env.boards_host().copy(), {k: v.copy() for k, v in env.episode_state_host().items()}))
+        # epsilon-greedy acting with frozen weights: one launch vs the per-step calls
+        env.reset()
+        env.metrics_reset()
+        agent.t = 1000
+        if fused:
+            agent.act_rollout(40, epsilon=0.3, auto_reset=True)
+        else:
+            agent._refresh_fused_weights()
+            for k in range(40):
+                a = env.policy_act(agent._fw, 0.3, 1000 + k)
+                env.step(a, auto_reset=True)
+        outs[-1] += (np.asarray(env.metrics()).copy(), env.boards_host().copy(), env.episode_state_host()["episode_return"].copy())
+        env.close()
+    f, s = outs
+    assert (f[0] == s[0]).all() and f[0][S.metering.M_EPISODES] >= n
+    assert (f[1] == s[1]).all() and all((f[2][k] == s[2][k]).all() for k in f[2])
+    assert (f[3] == s[3]).all() and (f[4] == s[4]).all() and (f[5] == s[5]).all()

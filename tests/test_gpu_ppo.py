@@ -212,3 +212,42 @@ def test_train_batched_cli_ppo():
     tags = [c[1] for c in writers[0].calls]
     assert tags.count("Train/policy_loss") == 4 and "Evaluation/returns" in tags
     env.close()
+
+
+@pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", False), ("SideEffectsSokoban-v0", True),
+                                         ("DistributionalShift-v0", False)])
+def test_fused_policy_rollout_equals_the_stepwise_gather(name, cheat):
+    """sgk_policy_rollout (forward + draw + env.step of every step in one launch, env state in registers, boards kept in
+    LDS) must produce exactly what the per-step launches produce: same draws, same MFMA arithmetic, same transitions --
+    states, actions, rewards, returns, lengths, final env state, episode arrays and metrics, bit for bit."""
+    import torch
+
+    n, seed = 1000, 17  # not a multiple of the 128-env workgroup tile nor of the 32-env wave tile
+    results = []
+    for fused in (False, True):
+        torch.manual_seed(21)
+        env = S.BatchedGridworldEnv(name, n, seed=seed)
+        env.bind_torch_stream()
+        agent = S.BatchedPPOAgent(env, _args(discount=0.95))
+        agent.fused_rollout = fused
+        with torch.no_grad():
+            for p in agent.net.parameters():
+                p.mul_(2.0)
+        agent.sync()
+        env.metrics_reset()
+        ro = agent.gather_rollout(cheat=cheat)
+        ro2 = agent.gather_rollout(cheat=cheat)  # a second rollout continues the draw stream
+        results.append({"ro": [x.cpu().numpy().copy() for x in ro2], "metrics": np.asarray(env.metrics()).copy(),
+                        "state": {k: v.copy() for k, v in env.episode_state_host().items()},
+                        "last": {k: v.copy() for k, v in env.last_episode_host().items()},
+                        "boards": env.boards_host().copy(), "draws": agent.draws})
+        env.close()
+    a, b = results
+    assert a["draws"] == b["draws"] == 200
+    for x, y, what in zip(a["ro"], b["ro"], ("states", "actions", "rewards", "returns", "lengths")):
+        assert x.shape == y.shape and (x.view(np.uint8) == y.view(np.uint8)).all(), what
+    assert (a["metrics"] == b["metrics"]).all() and (a["boards"] == b["boards"]).all()
+    for key in a["state"]:
+        assert (a["state"][key] == b["state"][key]).all(), key
+    for key in a["last"]:
+        assert (a["last"][key] == b["last"][key]).all(), key

@@ -112,6 +112,10 @@ for _ in range(20):
 dt = wall_time(lambda: dq.step(learn=False), 300)
 out.append({"config": 4, "what": "Sokoban + deep-q MLP, 32768 envs: obs kernel + policy forward + eps-greedy + env.step + reset_done (no learning)",
             "us_per_step": dt * 1e6, "env_steps_per_s": n / dt})
+dq.act_rollout(100, epsilon=0.01)
+dt = wall_time(lambda: dq.act_rollout(1000, epsilon=0.01), 3) / 1000
+out.append({"config": 4, "what": "acting with frozen weights, fused rollout: 1000 x {forward + eps-greedy + env.step + auto-reset} per launch (sgk_policy_rollout)",
+            "us_per_step": dt * 1e6, "env_steps_per_s": n / dt})
 for _ in range(20):
     dq.step(learn=True)
 dt = wall_time(lambda: dq.step(learn=True), 300)
