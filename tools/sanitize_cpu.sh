@@ -17,8 +17,9 @@ void* orc_tabq_new(int, double, double, double, int64_t); void orc_tabq_free(voi
 void orc_tabq_rollout(void*, void**, int64_t, uint64_t, uint64_t, int64_t, int, int64_t*, uint8_t*);
 void orc_discounted_returns(const float*, int, double, float*);
 int orc_render_rgb(const void*, uint8_t*);
+int orc_categorical_sample(const float*, uint64_t, uint64_t, uint64_t, double*);
 int main(void) {
-  for (int env = 0; env < 3; ++env) {
+  for (int env = 0; env < 4; ++env) {
     int64_t n = 97; size_t sz = orc_sizeof();
     char* envs = malloc(sz * n);
     for (int i = 0; i < n; ++i) { orc_init(envs + i * sz, env); orc_reset(envs + i * sz); }
@@ -27,7 +28,7 @@ int main(void) {
     orc_rollout(envs, n, 5, 77, 0, 333, 1, NULL, rec, m);
     orc_rollout_mt(envs, n, 5, 77, 333, 200, 1, m, 7);
     void** ag = malloc(sizeof(void*) * n);
-    for (int i = 0; i < n; ++i) ag[i] = orc_tabq_new(env == 0 ? 25 : env == 1 ? 48 : 36, 0.5, 0.99, 0.05, 300);
+    for (int i = 0; i < n; ++i) ag[i] = orc_tabq_new(env == 0 ? 25 : env == 1 ? 48 : env == 2 ? 36 : 63, 0.5, 0.99, 0.05, 300);
     uint8_t* acts = malloc(400 * n);
     orc_tabq_rollout(envs, ag, n, 0, 3, 400, env == 2, m, acts);
     uint8_t rgb[3 * 64]; orc_render_rgb(envs, rgb);
@@ -36,6 +37,9 @@ int main(void) {
     printf("oracle env %d: %lld episodes, clean\n", env, (long long)m[4]);
   }
   float r[100], out[100]; for (int i = 0; i < 100; ++i) r[i] = (float)(i % 7) - 3; orc_discounted_returns(r, 100, 0.97, out);
+  float lg[4] = {0.5f, -1.0f, 2.0f, 0.0f}; double margin; int hist[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 1000; ++i) hist[orc_categorical_sample(lg, 7, (uint64_t)i, 3, &margin)]++;
+  printf("categorical draws %d %d %d %d, clean\n", hist[0], hist[1], hist[2], hist[3]);
   return 0;
 }
 C
