@@ -229,6 +229,34 @@ SGK_API int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon,
                            const double *epsilon_dev, const uint64_t *draw_index_dev, uint8_t *actions_out_dev,
                            float *scores_out_dev);
 
+/* ---- DeepQAgent.learn (reference value.py:113-136) for the default topology as ONE kernel --------------------------- */
+/* Minibatch sampling from a device replay ring (uniform with replacement, contain.py:19-22; counter RNG stream 4 keyed by
+ * the Adam step), Q-network and target-network forward, TD target r + discount * max_a' Q_target(s', a') * (1 - terminal),
+ * mse_loss, backward, clip_grad_norm_(max_grad_norm), Adam(amsgrad) update -- the Linear(n_cells, H)-ReLU-Linear(H, H)-ReLU-
+ * Linear(H, 4) network of value.py:148-158 with H <= 128, batch <= 64. All pointers are device pointers; float32.
+ *   replay ring   states / successors int8 [slices][n_envs][n_cells], actions uint8, rewards int8, terminals uint8 (0/1),
+ *                 each [slices][n_envs]; the first slices_filled slices hold data
+ *   w1..b3        the Q-network's parameters in torch layout ([out][in]), UPDATED IN PLACE
+ *   w1t, w2t, w3t transposed copies ([in][out]) the kernel reads and keeps current (w1t / w3t are what sgk_policy_* take)
+ *   m, v, vmax    Adam's exp_avg, exp_avg_sq, max_exp_avg_sq for w1, b1, w2, b2, w3, b3 (same shapes), updated
+ *   tw1t, tw2t    the target network's hidden weights transposed; tb1, tb2, tw3 ([4][H]), tb3 as they are
+ *   step          Adam's step counter (int64, device), incremented;   loss_out: float, or NULL
+ * fp32 with a different summation order than rocBLAS: equal to torch's step to fp32 tolerance, not bit for bit. */
+typedef struct sgk_dqn_learner {
+  const int8_t *states, *successors;
+  const uint8_t *actions;
+  const int8_t *rewards;
+  const uint8_t *terminals;
+  int32_t slices_filled, n_hidden, batch, pad0;
+  float *w1, *b1, *w2, *b2, *w3, *b3, *w1t, *w2t, *w3t;
+  float *m[6], *v[6], *vmax[6];
+  const float *tw1t, *tb1, *tw2t, *tb2, *tw3, *tb3;
+  int64_t *step;
+  float *loss_out;
+  double lr, beta1, beta2, eps, discount, max_grad_norm;
+} sgk_dqn_learner;
+SGK_API int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *learner);
+
 /* ---- PPOBaseAgent.act_explore for every env (reference policy_base.py:54-64: Categorical(logits).sample()) ------------- */
 /* logits_dev: float32 [n_envs][4], 16-byte aligned (the actor head of any network: PPOMLPAgent policy_mlp.py:29-43,
  * PPOCNNAgent policy_cnn.py:66-81). Inverse-CDF draw with the counter RNG (Philox stream 3, keyed by global env index and

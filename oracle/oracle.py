@@ -67,6 +67,8 @@ def lib():
         L.orc_rollout_mt.restype = ctypes.c_int
         L.orc_eps_greedy.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
         L.orc_eps_greedy.restype = ctypes.c_int
+        L.orc_minibatch_index.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
+        L.orc_minibatch_index.restype = ctypes.c_int64
         L.orc_categorical_sample.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
         L.orc_categorical_sample.restype = ctypes.c_int
         L.orc_discounted_returns.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
@@ -217,6 +219,12 @@ def eps_greedy(scores, eps, seed, env_begin, draw):
     L = lib()
     return np.array([L.orc_eps_greedy(sc[i].ctypes.data, float(eps), seed, env_begin + i, draw) for i in range(sc.shape[0])],
                     dtype=np.uint8)
+
+
+def minibatch_indices(seed, step, batch, total):
+    """Flat replay indices the fused DeepQ learner samples for the SGD step that starts at Adam step `step`."""
+    L = lib()
+    return np.array([L.orc_minibatch_index(seed, b, step, total) for b in range(batch)], dtype=np.int64)
 
 
 def categorical_sample(logits, seed, env_begin, draw):

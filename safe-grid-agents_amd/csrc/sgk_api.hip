@@ -620,6 +620,34 @@ int sgk_policy_rollout(sgk_env *h, const sgk_mlp_weights *w, int32_t mode, doubl
   return SGK_OK;
 }
 
+int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) {
+  SGK_CHECK_HANDLE(h);
+  if (!L) return fail(SGK_ERR_INVALID, "learner is NULL");
+  const void *need[] = {L->states, L->successors, L->actions, L->rewards, L->terminals, L->w1, L->b1, L->w2, L->b2, L->w3, L->b3,
+                        L->w1t, L->w2t, L->w3t, L->tw1t, L->tb1, L->tw2t, L->tb2, L->tw3, L->tb3, L->step};
+  for (const void *p : need)
+    if (!p) return fail(SGK_ERR_INVALID, "NULL pointer in sgk_dqn_learner");
+  for (int i = 0; i < 6; ++i)
+    if (!L->m[i] || !L->v[i] || !L->vmax[i]) return fail(SGK_ERR_INVALID, "NULL Adam state in sgk_dqn_learner");
+  if (L->n_hidden < 4 || L->n_hidden > 128 || (L->n_hidden & 3) || L->batch < 1 || L->batch > 64 || L->slices_filled < 1)
+    return fail(SGK_ERR_INVALID, "sgk_dqn_sgd_step needs n_hidden in 4..128 and a multiple of 4, 1 <= batch <= 64, slices_filled >= 1");
+  if (sgk::dqn_sgd_lds_bytes(h->sh.n_cells, L->n_hidden) > 160u * 1024u)
+    return fail(SGK_ERR_INVALID, "this n_cells / n_hidden does not fit the 160 KB of LDS the kernel works in");
+  sgk::DqnLearner d;
+  d.states = L->states; d.successors = L->successors; d.actions = L->actions; d.rewards = L->rewards; d.terminals = L->terminals;
+  d.slices_filled = L->slices_filled;
+  d.w1 = L->w1; d.b1 = L->b1; d.w2 = L->w2; d.b2 = L->b2; d.w3 = L->w3; d.b3 = L->b3;
+  d.w1t = L->w1t; d.w2t = L->w2t; d.w3t = L->w3t;
+  for (int i = 0; i < 6; ++i) { d.m[i] = L->m[i]; d.v[i] = L->v[i]; d.vmax[i] = L->vmax[i]; }
+  d.tw1t = L->tw1t; d.tb1 = L->tb1; d.tw2t = L->tw2t; d.tb2 = L->tb2; d.tw3 = L->tw3; d.tb3 = L->tb3;
+  d.step = reinterpret_cast<long long *>(L->step);
+  d.loss_out = L->loss_out;
+  d.n_hidden = L->n_hidden; d.batch = L->batch;
+  d.lr = L->lr; d.beta1 = L->beta1; d.beta2 = L->beta2; d.eps = L->eps; d.discount = L->discount; d.max_grad_norm = L->max_grad_norm;
+  SGK_HIP(sgk::launch_dqn_sgd(h->sh, d, h->stream));
+  return SGK_OK;
+}
+
 int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const int32_t *lengths_dev, float *returns_dev,
                            int64_t n_trajectories, int32_t t_max, double discount) {
   SGK_CHECK_HANDLE(h);

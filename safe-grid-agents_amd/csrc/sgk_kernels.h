@@ -60,6 +60,23 @@ hipError_t launch_policy_rollout(const Shard &sh, int mode, const PolicyWeights 
                                  uint32_t flags, int8_t *states_out, uint8_t *actions_out, uint32_t *recs_out, hipStream_t st);
 hipError_t launch_eps_greedy(const Shard &sh, int mode, const float *scores, uint8_t *actions, double eps, uint64_t draw,
                              const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
+// DeepQAgent.learn as one kernel (sgk_learn.hip); all pointers are device pointers
+struct DqnLearner {
+  const int8_t *states, *successors;
+  const uint8_t *actions;
+  const int8_t *rewards;
+  const uint8_t *terminals;
+  int slices_filled;
+  float *w1, *b1, *w2, *b2, *w3, *b3, *w1t, *w2t, *w3t;
+  float *m[6], *v[6], *vmax[6];
+  const float *tw1t, *tb1, *tw2t, *tb2, *tw3, *tb3;
+  long long *step;
+  float *loss_out;
+  int n_hidden, batch;
+  double lr, beta1, beta2, eps, discount, max_grad_norm;
+};
+size_t dqn_sgd_lds_bytes(int n_cells, int n_hidden);
+hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st);
 hipError_t launch_discounted_returns(const Shard &sh, const float *rewards, const int32_t *lengths, const float *gamma_pow,
                                      float *returns, int64_t n, int t_max, hipStream_t st);
 hipError_t launch_render_rgb(const Shard &sh, uint8_t *dst, hipStream_t st);

@@ -1,0 +1,435 @@
+// sgk_learn.hip -- DeepQAgent.learn (reference value.py:113-136) for the reference's default topology as ONE kernel:
+// sample a minibatch from the device replay ring, forward the Q-network and the target network, the TD target and the MSE
+// loss, the backward pass, clip_grad_norm_(10) and the Adam(amsgrad) update -- what PyTorch runs as ~80 small kernels
+// (a 64-sample minibatch through a 36-100-100-4 MLP: every kernel is launch latency). One workgroup of 1 024 lanes; the
+// minibatch, both networks' activations and the two back-propagated activations live in LDS, every lane keeps the
+// gradients of the parameters it owns in registers, and the weights are read from L2 in the orientation that makes the
+// lanes' addresses consecutive (a transposed copy of W1 / W2 / W3 is kept current by the update itself; the fused policy
+// kernels read W1^T and W3^T from it).
+//
+// fp32 throughout, same formulas as torch (mse_loss mean reduction, clip coefficient max_norm / (norm + 1e-6) clamped to 1,
+// Adam with bias corrections and amsgrad); the summation order inside the dot products differs from rocBLAS, so parity with
+// torch's step is to fp32 tolerance (tests: 1e-5 relative after one step), not bit for bit.
+#include "sgk_device.h"
+
+extern "C" __device__ float __ockl_wfred_add_f32(float);
+
+namespace sgk {
+
+constexpr int LWG = 1024;    // lanes of the one workgroup
+constexpr int LB = 64;       // samples per minibatch handled (batch <= 64)
+
+struct LearnArgs {
+  // replay ring [slices][n_envs][...]
+  const int8_t *states, *successors;
+  const uint8_t *actions;
+  const int8_t *rewards;
+  const uint8_t *terminals;
+  int64_t n_envs, total;  // sampling range: total = filled slices * n_envs
+  int32_t n_cells;
+  // Q-network (torch layouts [out][in]) updated in place; transposed copies kept current; Adam state per tensor
+  float *w1, *b1, *w2, *b2, *w3, *b3;
+  float *w1t, *w2t, *w3t;
+  float *m[6], *v[6], *vmax[6];  // order: w1, b1, w2, b2, w3, b3
+  // target network: transposed hidden weights, output weights as they are [4][H]
+  const float *tw1t, *tb1, *tw2t, *tb2, *tw3, *tb3;
+  long long *step;   // Adam step counter on the device
+  float *loss_out;   // may be null
+  int32_t n_hidden, batch;
+  uint64_t seed;  // minibatch indices: Philox stream 4, ctr = {sample, 0, Adam step before this update, 4}
+  float lr, beta1, beta2, eps, discount, max_norm;
+};
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// Cooperative global -> LDS copy of n floats (n % 4 == 0, both 16-byte aligned): every lane's loads are in flight together,
+// ONE memory round trip for the whole block. The kernel is a chain of dependent phases run by a single workgroup, so what
+// it costs is (number of exposed round trips) x (latency): reading the weights straight from L2 inside the dot-product
+// loops was 80 round trips = 85-180 us; staged like this the kernel has about ten.
+__device__ __forceinline__ void stage(float *dst, const float *__restrict__ src, int n) {
+  for (int i = threadIdx.x * 4; i < n; i += LWG * 4) *reinterpret_cast<f4 *>(dst + i) = *reinterpret_cast<const f4 *>(src + i);
+}
+
+__device__ __forceinline__ f4 load_x4(const float *row, int k) { return *reinterpret_cast<const f4 *>(row + k); }
+__device__ __forceinline__ f4 load_x4(const int8_t *row, int k) {  // four board cells -> four floats
+  const uint32_t w = *reinterpret_cast<const uint32_t *>(row + k);
+  return (f4){(float)(int8_t)(w & 0xff), (float)(int8_t)((w >> 8) & 0xff), (float)(int8_t)((w >> 16) & 0xff), (float)(int8_t)(w >> 24)};
+}
+
+// out[b][j] = epilogue(bias[j] + sum_k in[b][k] * wt[k][j]) for the LB samples and j < H, everything in LDS. Lane (jq, sg) owns
+// the four neurons 4 jq .. 4 jq + 3 for the two samples 2 sg, 2 sg + 1: per four k it reads two pieces of `in` and four 16-byte
+// weight rows (32 lanes x 16 B contiguous: conflict-free) for 32 FMAs. KP = row stride of `in` in elements (K rounded up to
+// 4; the padding holds zeros); weight rows k >= K are not read. `mask` zeroes out[b][j] where mask[b][j] <= 0 (ReLU').
+template <class T>
+__device__ __forceinline__ void dense_layer(const T *in, int K, int KP, const float *wt, const float *bias, int H, float *out,
+                                            bool relu, const float *mask) {
+  const int jq = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  if (4 * jq < H) {
+    const int b0 = 2 * sg;
+    f4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (bias) acc0 = *reinterpret_cast<const f4 *>(bias + 4 * jq);
+    f4 acc1 = acc0;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      const f4 x0 = load_x4(in + b0 * KP, k0), x1 = load_x4(in + (b0 + 1) * KP, k0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k0 + u < K) {
+          const f4 w = *reinterpret_cast<const f4 *>(wt + (k0 + u) * H + 4 * jq);
+          acc0 = __builtin_elementwise_fma(w, (f4){x0[u], x0[u], x0[u], x0[u]}, acc0);
+          acc1 = __builtin_elementwise_fma(w, (f4){x1[u], x1[u], x1[u], x1[u]}, acc1);
+        }
+      }
+    }
+    const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (relu) {
+      acc0 = __builtin_elementwise_max(acc0, zero);
+      acc1 = __builtin_elementwise_max(acc1, zero);
+    }
+    if (mask) {
+      const f4 m0 = *reinterpret_cast<const f4 *>(mask + b0 * H + 4 * jq), m1 = *reinterpret_cast<const f4 *>(mask + (b0 + 1) * H + 4 * jq);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc0[c] = m0[c] > 0.0f ? acc0[c] : 0.0f;
+        acc1[c] = m1[c] > 0.0f ? acc1[c] : 0.0f;
+      }
+    }
+    *reinterpret_cast<f4 *>(out + b0 * H + 4 * jq) = acc0;
+    *reinterpret_cast<f4 *>(out + (b0 + 1) * H + 4 * jq) = acc1;
+  }
+}
+
+// q[b][a] = b3[a] + sum_k h[b][k] * w3[a][k] (all LDS): one lane per (b, a)
+__device__ __forceinline__ void head_forward(const float *h, int H, const float *w3, const float *b3, float *q) {
+  if (threadIdx.x < LB * 4) {
+    const int b = threadIdx.x >> 2, a = threadIdx.x & 3;
+    float acc = b3[a];
+    for (int k0 = 0; k0 < H; k0 += 4) {  // H % 4 == 0 (checked by the launcher)
+      const f4 w = *reinterpret_cast<const f4 *>(w3 + a * H + k0);
+      const f4 x = *reinterpret_cast<const f4 *>(h + b * H + k0);
+      acc = fmaf(x[0], w[0], acc);
+      acc = fmaf(x[1], w[1], acc);
+      acc = fmaf(x[2], w[2], acc);
+      acc = fmaf(x[3], w[3], acc);
+    }
+    q[b * 4 + a] = acc;
+  }
+}
+
+// grad[r][c] = sum_b d[b][row0 + r] * x[b][col0 + c] for a 4 x 4 tile (the weight gradient of a dense layer): two LDS reads
+// per sample for 16 FMAs
+template <class T>
+__device__ __forceinline__ void weight_grad_tile(const float *d, int DS, int row0, const T *x, int XS, int col0, f4 g[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) g[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+  for (int b = 0; b < LB; ++b) {
+    const f4 dv = *reinterpret_cast<const f4 *>(d + b * DS + row0);
+    const f4 xv = load_x4(x + b * XS, col0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g[r] = __builtin_elementwise_fma((f4){dv[r], dv[r], dv[r], dv[r]}, xv, g[r]);
+  }
+}
+
+__device__ __forceinline__ float block_sum(float x, float *scratch) {  // scratch: LWG / 64 floats
+  x = __ockl_wfred_add_f32(x);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = x;
+  __syncthreads();
+  float total = 0.0f;
+  for (int w = 0; w < LWG / 64; ++w) total += scratch[w];
+  return total;
+}
+
+struct AdamCoef {
+  float lr_bc1, bc2_sqrt, beta1, beta2, eps;
+};
+
+__device__ __forceinline__ float adam_scalar(float p, float &m, float &v, float &vmax, float g, const AdamCoef &c) {
+  m = m + (1.0f - c.beta1) * (g - m);  // exp_avg.lerp_(grad, 1 - beta1)
+  v = c.beta2 * v + (1.0f - c.beta2) * g * g;
+  vmax = fmaxf(vmax, v);
+  return p - c.lr_bc1 * (m / (sqrtf(vmax) / c.bc2_sqrt + c.eps));
+}
+
+// Adam on four consecutive parameters (16-byte aligned); returns the updated values
+__device__ __forceinline__ f4 adam_row(float *p, float *m, float *v, float *vmax, f4 g, const AdamCoef &c) {
+  f4 pv = *reinterpret_cast<f4 *>(p), mv = *reinterpret_cast<f4 *>(m), vv = *reinterpret_cast<f4 *>(v), xv = *reinterpret_cast<f4 *>(vmax);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float mi = mv[i], vi = vv[i], xi = xv[i];
+    pv[i] = adam_scalar(pv[i], mi, vi, xi, g[i], c);
+    mv[i] = mi; vv[i] = vi; xv[i] = xi;
+  }
+  *reinterpret_cast<f4 *>(p) = pv;
+  *reinterpret_cast<f4 *>(m) = mv;
+  *reinterpret_cast<f4 *>(v) = vv;
+  *reinterpret_cast<f4 *>(vmax) = xv;
+  return pv;
+}
+
+// LDS plan (floats unless noted): A, Bq, C, D [LB][H] -- A = Q hidden 1, Bq = Q hidden 2, C = target hidden 1 then dL/dh2,
+// D = target hidden 2 then dL/dh1; ST [H][H] the weight matrix of the running phase; SM the small tensors (W3, target W3, the
+// biases); S, S2 int8 [LB][KP] the boards; the per-sample scalars.
+struct LearnLds {
+  float *A, *Bq, *C, *D, *ST, *w3, *tw3, *b1, *b2, *b3, *tb1, *tb2, *tb3, *q, *tq, *y, *scratch, *rew;
+  int8_t *S, *S2;
+  int *idx, *act, *term;
+};
+
+__device__ __forceinline__ LearnLds carve(unsigned char *base, int KP, int H) {
+  LearnLds L;
+  float *f = reinterpret_cast<float *>(base);
+  L.A = f; f += LB * H;
+  L.Bq = f; f += LB * H;
+  L.C = f; f += LB * H;
+  L.D = f; f += LB * H;
+  L.ST = f; f += H * H;
+  L.w3 = f; f += 4 * H;
+  L.tw3 = f; f += 4 * H;
+  L.b1 = f; f += H;
+  L.b2 = f; f += H;
+  L.tb1 = f; f += H;
+  L.tb2 = f; f += H;
+  L.b3 = f; f += 4;
+  L.tb3 = f; f += 4;
+  L.q = f; f += LB * 4;
+  L.tq = f; f += LB * 4;
+  L.y = f; f += LB;
+  L.scratch = f; f += 32;
+  L.rew = f; f += LB;
+  L.idx = reinterpret_cast<int *>(f); f += LB;
+  L.act = reinterpret_cast<int *>(f); f += LB;
+  L.term = reinterpret_cast<int *>(f); f += LB;
+  L.S = reinterpret_cast<int8_t *>(f);
+  L.S2 = L.S + LB * KP;
+  return L;
+}
+
+__global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char learn_smem[];
+  const int K0 = a.n_cells, H = a.n_hidden, B = a.batch;
+  const int KP = (K0 + 3) & ~3;  // row stride of the board matrices (padding columns hold zeros)
+  const LearnLds L = carve(learn_smem, KP, H);
+  const int t = threadIdx.x;
+
+  // ---- minibatch: uniform with replacement over the stored transitions (contain.py:19-22), counter RNG ----
+  if (t < LB) {
+    int id = 0;
+    if (t < B) {
+      uint32_t x[4];
+      philox4x32_10((uint32_t)t, 0u, (uint32_t)*a.step, 4u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
+      const unsigned long long r = ((unsigned long long)x[0] << 32) | x[1];
+      id = (int)__umul64hi(r, (unsigned long long)a.total);
+    }
+    L.idx[t] = id;
+    L.act[t] = a.actions[id] & 3;
+    L.rew[t] = (float)a.rewards[id];
+    L.term[t] = a.terminals[id] ? 1 : 0;
+  }
+  // the small tensors and the first weight matrix travel meanwhile
+  stage(L.ST, a.tw1t, K0 * H);
+  stage(L.w3, a.w3, 4 * H);
+  stage(L.tw3, a.tw3, 4 * H);
+  stage(L.b1, a.b1, H);
+  stage(L.b2, a.b2, H);
+  stage(L.tb1, a.tb1, H);
+  stage(L.tb2, a.tb2, H);
+  if (t < 4) { L.b3[t] = a.b3[t]; L.tb3[t] = a.tb3[t]; }
+  __syncthreads();
+  for (int i = t; i < LB * KP; i += LWG) {
+    const int b = i / KP, k = i - b * KP;
+    const bool live = b < B && k < K0;
+    L.S[i] = live ? a.states[(int64_t)L.idx[b] * K0 + k] : (int8_t)0;
+    L.S2[i] = live ? a.successors[(int64_t)L.idx[b] * K0 + k] : (int8_t)0;
+  }
+  __syncthreads();
+  // ---- target network on the successors ----
+  dense_layer(L.S2, K0, KP, L.ST, L.tb1, H, L.C, true, nullptr);
+  __syncthreads();
+  stage(L.ST, a.tw2t, H * H);
+  __syncthreads();
+  dense_layer(L.C, H, H, L.ST, L.tb2, H, L.D, true, nullptr);
+  __syncthreads();
+  head_forward(L.D, H, L.tw3, L.tb3, L.tq);
+  // ---- Q-network on the states ----
+  stage(L.ST, a.w1t, K0 * H);
+  __syncthreads();
+  dense_layer(L.S, K0, KP, L.ST, L.b1, H, L.A, true, nullptr);
+  __syncthreads();
+  stage(L.ST, a.w2t, H * H);
+  __syncthreads();
+  dense_layer(L.A, H, H, L.ST, L.b2, H, L.Bq, true, nullptr);
+  __syncthreads();
+  head_forward(L.Bq, H, L.w3, L.b3, L.q);
+  stage(L.ST, a.w2, H * H);  // W2 as it is ([j][k]): the back-propagation through layer 2 wants it in this orientation
+  __syncthreads();
+  // ---- loss = mean((q_sa - y)^2) with y = r + discount * max_a' Q_target(s', a') * (1 - terminal); dL/dq on the taken action ----
+  float sq = 0.0f;
+  if (t < LB) {
+    float g = 0.0f;
+    if (t < B) {
+      const float nq = fmaxf(fmaxf(L.tq[t * 4], L.tq[t * 4 + 1]), fmaxf(L.tq[t * 4 + 2], L.tq[t * 4 + 3]));
+      const float target = a.discount * (L.term[t] ? 0.0f : nq) + L.rew[t];
+      const float d = L.q[t * 4 + L.act[t]] - target;
+      sq = d * d;
+      g = 2.0f * d / (float)B;
+    }
+    L.y[t] = g;
+  }
+  const float loss = block_sum(sq, L.scratch) / (float)B;  // (has barriers: y[] is visible afterwards)
+  if (t < LB * 4) L.q[t] = ((t & 3) == L.act[t >> 2]) ? L.y[t >> 2] : 0.0f;  // q now holds dL/dq
+  __syncthreads();
+
+  // ---- backward; every lane keeps the gradients of the parameters it owns in registers ----------------------------
+  const int HQ = H / 4, KQ = KP / 4;
+  // dL/dh2 = relu'(h2) * (dq W3) -> C   (dense_layer with K = 4, "wt" = W3 [4][H])
+  dense_layer(L.q, 4, 4, L.w3, nullptr, H, L.C, false, L.Bq);
+  // W3 [4][H]: lane k < H owns column k of all four rows; b3: lanes H .. H + 3
+  f4 gw3 = {0.0f, 0.0f, 0.0f, 0.0f};
+  float gb3 = 0.0f;
+  if (t < H) {
+    for (int b = 0; b < LB; ++b) {
+      const f4 dv = *reinterpret_cast<const f4 *>(L.q + b * 4);
+      const float hv = L.Bq[b * H + t];
+      gw3 = __builtin_elementwise_fma(dv, (f4){hv, hv, hv, hv}, gw3);
+    }
+  } else if (t < H + 4) {
+    for (int b = 0; b < LB; ++b) gb3 += L.q[b * 4 + (t - H)];
+  }
+  __syncthreads();
+  // dL/dh1 = relu'(h1) * (dh2 W2) -> D   ("wt" = W2 as it is)
+  dense_layer(L.C, H, H, L.ST, nullptr, H, L.D, false, L.A);
+  // W2 [H][H] in 4 x 4 tiles: lane t < HQ * HQ owns tile (t / HQ, t % HQ); b2[j]: lanes LWG - 1 - j
+  f4 gw2[4];
+  float gb2 = 0.0f;
+  const bool own2 = t < HQ * HQ;
+  if (own2) weight_grad_tile(L.C, H, 4 * (t / HQ), L.A, H, 4 * (t % HQ), gw2);
+  else if (LWG - 1 - t < H)
+    for (int b = 0; b < LB; ++b) gb2 += L.C[b * H + (LWG - 1 - t)];
+  __syncthreads();
+  // W1 [H][K0] in 4 x 4 tiles over the padded columns: lane t < HQ * KQ; b1[j]: lanes LWG - 1 - j
+  f4 gw1[4];
+  float gb1 = 0.0f;
+  const bool own1 = t < HQ * KQ;
+  if (own1) weight_grad_tile(L.D, H, 4 * (t / KQ), L.S, KP, 4 * (t % KQ), gw1);
+  else if (LWG - 1 - t < H)
+    for (int b = 0; b < LB; ++b) gb1 += L.D[b * H + (LWG - 1 - t)];
+  // ---- clip_grad_norm_(max_norm): coefficient from the global 2-norm of all gradients -----------------------------
+  float ss = gb3 * gb3 + gb2 * gb2 + gb1 * gb1;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) ss = fmaf(gw3[c], gw3[c], ss);
+  if (own2)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ss = fmaf(gw2[r][c], gw2[r][c], ss);
+  if (own1)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (4 * (t % KQ) + c < K0) ss = fmaf(gw1[r][c], gw1[r][c], ss);  // padding columns carry no parameter
+  const float norm = sqrtf(block_sum(ss, L.scratch));
+  const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
+  // ---- Adam (amsgrad) on the owned parameters; the transposed copies follow ---------------------------------------
+  const long long step = *a.step + 1;
+  AdamCoef ac;
+  ac.lr_bc1 = a.lr / (float)(1.0 - pow((double)a.beta1, (double)step));
+  ac.bc2_sqrt = sqrtf((float)(1.0 - pow((double)a.beta2, (double)step)));
+  ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
+  __syncthreads();  // every lane has read *a.step
+  if (t == 0) {
+    *a.step = step;
+    if (a.loss_out) *a.loss_out = loss;
+  }
+  if (t < H) {  // W3 column t (stride H between the four rows), W3^T row t
+    f4 nw;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = r * H + t;
+      float m = a.m[4][i], v = a.v[4][i], x = a.vmax[4][i];
+      nw[r] = adam_scalar(a.w3[i], m, v, x, gw3[r] * coef, ac);
+      a.w3[i] = nw[r]; a.m[4][i] = m; a.v[4][i] = v; a.vmax[4][i] = x;
+    }
+    *reinterpret_cast<f4 *>(a.w3t + 4 * t) = nw;
+  } else if (t < H + 4) {
+    const int i = t - H;
+    float m = a.m[5][i], v = a.v[5][i], x = a.vmax[5][i];
+    a.b3[i] = adam_scalar(a.b3[i], m, v, x, gb3 * coef, ac);
+    a.m[5][i] = m; a.v[5][i] = v; a.vmax[5][i] = x;
+  }
+  if (!own2 && !own1 && LWG - 1 - t < H) {  // the bias lanes (the launcher guarantees they are not tile lanes)
+    const int i = LWG - 1 - t;
+    float m = a.m[3][i], v = a.v[3][i], x = a.vmax[3][i];
+    a.b2[i] = adam_scalar(a.b2[i], m, v, x, gb2 * coef, ac);
+    a.m[3][i] = m; a.v[3][i] = v; a.vmax[3][i] = x;
+    m = a.m[1][i]; v = a.v[1][i]; x = a.vmax[1][i];
+    a.b1[i] = adam_scalar(a.b1[i], m, v, x, gb1 * coef, ac);
+    a.m[1][i] = m; a.v[1][i] = v; a.vmax[1][i] = x;
+  }
+  if (own2) {
+    const int j0 = 4 * (t / HQ), k0 = 4 * (t % HQ);
+    f4 rows[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (j0 + r) * H + k0;
+      rows[r] = adam_row(a.w2 + i, a.m[2] + i, a.v[2] + i, a.vmax[2] + i, gw2[r] * coef, ac);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      *reinterpret_cast<f4 *>(a.w2t + (size_t)(k0 + c) * H + j0) = (f4){rows[0][c], rows[1][c], rows[2][c], rows[3][c]};
+  }
+  if (own1) {
+    const int j0 = 4 * (t / KQ), k0 = 4 * (t % KQ);
+    float nw[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        nw[r][c] = 0.0f;
+        if (k0 + c < K0) {  // W1 rows are K0 long (not padded): element-wise
+          const int i = (j0 + r) * K0 + k0 + c;
+          float m = a.m[0][i], v = a.v[0][i], x = a.vmax[0][i];
+          nw[r][c] = adam_scalar(a.w1[i], m, v, x, gw1[r][c] * coef, ac);
+          a.w1[i] = nw[r][c]; a.m[0][i] = m; a.v[0][i] = v; a.vmax[0][i] = x;
+        }
+      }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (k0 + c < K0) *reinterpret_cast<f4 *>(a.w1t + (size_t)(k0 + c) * H + j0) = (f4){nw[0][c], nw[1][c], nw[2][c], nw[3][c]};
+  }
+}
+
+size_t dqn_sgd_lds_bytes(int n_cells, int n_hidden) {
+  const size_t kp = (size_t)((n_cells + 3) & ~3), h = (size_t)n_hidden;
+  return sizeof(float) * (4 * LB * h + h * h + 8 * h + 4 * h + 8 + 2 * LB * 4 + LB + 32 + LB + 3 * LB) + 2 * LB * kp + 64;
+}
+
+hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) {
+  (void)hipGetLastError();
+  if (L.n_hidden > 128 || L.n_hidden < 4 || (L.n_hidden & 3) || L.batch < 1 || L.batch > LB || sh.n_cells > 64) return hipErrorInvalidValue;
+  if ((L.n_hidden / 4) * (L.n_hidden / 4) + L.n_hidden > LWG) return hipErrorInvalidValue;  // tile lanes + bias lanes
+  const size_t lds = dqn_sgd_lds_bytes(sh.n_cells, L.n_hidden);
+  if (lds > 160u * 1024u) return hipErrorInvalidValue;
+  LearnArgs a;
+  a.states = L.states; a.successors = L.successors; a.actions = L.actions; a.rewards = L.rewards; a.terminals = L.terminals;
+  a.n_envs = sh.n; a.total = (int64_t)L.slices_filled * sh.n; a.n_cells = sh.n_cells;
+  a.w1 = L.w1; a.b1 = L.b1; a.w2 = L.w2; a.b2 = L.b2; a.w3 = L.w3; a.b3 = L.b3;
+  a.w1t = L.w1t; a.w2t = L.w2t; a.w3t = L.w3t;
+  for (int i = 0; i < 6; ++i) { a.m[i] = L.m[i]; a.v[i] = L.v[i]; a.vmax[i] = L.vmax[i]; }
+  a.tw1t = L.tw1t; a.tb1 = L.tb1; a.tw2t = L.tw2t; a.tb2 = L.tb2; a.tw3 = L.tw3; a.tb3 = L.tb3;
+  a.step = L.step; a.loss_out = L.loss_out; a.n_hidden = L.n_hidden; a.batch = L.batch;
+  a.seed = sh.seed;
+  a.lr = (float)L.lr; a.beta1 = (float)L.beta1; a.beta2 = (float)L.beta2; a.eps = (float)L.eps; a.discount = (float)L.discount;
+  a.max_norm = (float)L.max_grad_norm;
+  static unsigned long long opted_in = 0;
+  if (!((opted_in >> (sh.device & 63)) & 1ull)) {
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&dqn_sgd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024);
+    if (ae != hipSuccess) return ae;
+    opted_in |= 1ull << (sh.device & 63);
+  }
+  dqn_sgd_kernel<<<dim3(1), dim3(LWG), lds, st>>>(a);
+  return hipGetLastError();
+}
+
+}  // namespace sgk

@@ -45,6 +45,16 @@ class SgkMlpWeights(ctypes.Structure):
                 ("w3t", ctypes.c_void_p), ("b3", ctypes.c_void_p), ("n_hidden", ctypes.c_int32)]
 
 
+class SgkDqnLearner(ctypes.Structure):
+    _V6 = ctypes.c_void_p * 6
+    _fields_ = ([(k, ctypes.c_void_p) for k in ("states", "successors", "actions", "rewards", "terminals")]
+                + [(k, ctypes.c_int32) for k in ("slices_filled", "n_hidden", "batch", "pad0")]
+                + [(k, ctypes.c_void_p) for k in ("w1", "b1", "w2", "b2", "w3", "b3", "w1t", "w2t", "w3t")]
+                + [("m", _V6), ("v", _V6), ("vmax", _V6)]
+                + [(k, ctypes.c_void_p) for k in ("tw1t", "tb1", "tw2t", "tb2", "tw3", "tb3", "step", "loss_out")]
+                + [(k, ctypes.c_double) for k in ("lr", "beta1", "beta2", "eps", "discount", "max_grad_norm")])
+
+
 def build(force=False, verbose=False):
     """Compile libsgk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
@@ -91,6 +101,7 @@ _SIGNATURES = {
     "sgk_epsilon_greedy": (ctypes.c_int, [_V, _V, ctypes.c_double, ctypes.c_uint64, _V]),
     "sgk_epsilon_greedy_ex": (ctypes.c_int, [_V, _V, ctypes.c_double, ctypes.c_uint64, _V, _V, _V]),
     "sgk_policy_act": (ctypes.c_int, [_V, ctypes.POINTER(SgkMlpWeights), ctypes.c_double, ctypes.c_uint64, _V, _V, _V, _V]),
+    "sgk_dqn_sgd_step": (ctypes.c_int, [_V, ctypes.POINTER(SgkDqnLearner)]),
     "sgk_categorical_sample": (ctypes.c_int, [_V, _V, ctypes.c_uint64, _V, _V]),
     "sgk_policy_sample": (ctypes.c_int, [_V, ctypes.POINTER(SgkMlpWeights), ctypes.c_uint64, _V, _V, _V]),
     "sgk_policy_rollout": (ctypes.c_int, [_V, ctypes.POINTER(SgkMlpWeights), ctypes.c_int32, ctypes.c_double, ctypes.c_uint64,

@@ -75,7 +75,7 @@ class DeviceReplay:
 class BatchedDeepQAgent:
     reads_boards = True  # acts on the materialised cells (batched_default_eval must keep writing them)
 
-    def __init__(self, env, args, sgd_steps=1, replay_slices=8):
+    def __init__(self, env, args, sgd_steps=1, replay_slices=8, fused_learn=True):
         import torch
 
         self.torch = torch
@@ -89,6 +89,7 @@ class BatchedDeepQAgent:
         self.eps0, self.anneal = float(args.epsilon), int(args.epsilon_anneal)
         self.t = 0  # lockstep steps taken == update_epsilon() calls
         n_layers, n_hidden = int(args.n_layers), int(args.n_hidden)
+        self.fused_learn = False  # set below; sync_target_Q looks at it
         self.Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
         self.target_Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
         self.sync_target_Q()
@@ -109,6 +110,23 @@ class BatchedDeepQAgent:
                         "w2": l2.weight.data, "b2": l2.bias.data, "w3t": torch.empty((n_hidden, 4), device=self.device),
                         "b3": l3.bias.data}
             self._fw_stale = True
+        # DeepQAgent.learn as ONE kernel (sgk_dqn_sgd_step: sampling, both forwards, TD target, backward, grad clip, Adam
+        # amsgrad) for the two-layer topology with up to 128 units and minibatches up to 64; else torch autograd + Adam
+        lds_need = 4 * (4 * 64 * n_hidden + n_hidden * n_hidden + 12 * n_hidden + 872) + 128 * ((env.n_cells + 3) & ~3) + 64
+        lanes_need = (n_hidden // 4) ** 2 + n_hidden  # one lane per 4 x 4 tile of W2 plus the bias lanes, of 1 024
+        if (fused_learn and self.fused_policy and n_hidden % 4 == 0 and lanes_need <= 1024 and self.batch_size <= 64
+                and lds_need <= 160 * 1024):
+            params = [p.data for p in self.Q.parameters()]  # w1, b1, w2, b2, w3, b3 (torch registration order)
+            zeros = lambda: [torch.zeros_like(p) for p in params]  # noqa: E731
+            self._fl = {"w2t": torch.empty((n_hidden, n_hidden), device=self.device), "m": zeros(), "v": zeros(), "vmax": zeros(),
+                        "tw1t": torch.empty((env.n_cells, n_hidden), device=self.device),
+                        "tw2t": torch.empty((n_hidden, n_hidden), device=self.device),
+                        "step": torch.zeros(1, dtype=torch.int64, device=self.device),
+                        "loss": torch.zeros(1, dtype=torch.float32, device=self.device)}
+            self._refresh_fused_weights()
+            self._fl["w2t"].copy_(self.Q[1][0][0].weight.data.t())
+            self.fused_learn = True
+            self._refresh_target_transposes()
         self._eps_dev = torch.ones(1, dtype=torch.float64, device=self.device)
         self._draw_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._graphs = {}
@@ -131,6 +149,40 @@ class BatchedDeepQAgent:
 
     def sync_target_Q(self):
         self.target_Q.load_state_dict(self.Q.state_dict())
+        if self.fused_learn:
+            self._refresh_target_transposes()
+
+    def _refresh_target_transposes(self):
+        self._fl["tw1t"].copy_(self.target_Q[0][0].weight.data.t())
+        self._fl["tw2t"].copy_(self.target_Q[1][0][0].weight.data.t())
+
+    def _learn_batch_fused(self):
+        """One call of sgk_dqn_sgd_step; the kernel also keeps W1^T / W2^T / W3^T current, so the fused policy kernel needs no
+        refresh afterwards."""
+        import ctypes
+
+        from . import _lib
+
+        rp, fl, fw = self.replay, self._fl, self._fw
+        q = [p.data for p in self.Q.parameters()]
+        t1, t2, t3 = self.target_Q[0][0], self.target_Q[1][0][0], self.target_Q[2]
+        ptr = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
+        arr = lambda xs: (ctypes.c_void_p * 6)(*[x.data_ptr() for x in xs])  # noqa: E731
+        L = _lib.SgkDqnLearner(
+            states=ptr(rp.states), successors=ptr(rp.successors), actions=ptr(rp.actions), rewards=ptr(rp.rewards),
+            terminals=ptr(rp.terminals), slices_filled=int(rp.filled), n_hidden=int(q[1].numel()), batch=int(self.batch_size),
+            pad0=0, w1=ptr(q[0]), b1=ptr(q[1]), w2=ptr(q[2]), b2=ptr(q[3]), w3=ptr(q[4]), b3=ptr(q[5]), w1t=ptr(fw["w1t"]),
+            w2t=ptr(fl["w2t"]), w3t=ptr(fw["w3t"]), m=arr(fl["m"]), v=arr(fl["v"]), vmax=arr(fl["vmax"]), tw1t=ptr(fl["tw1t"]),
+            tb1=ptr(t1.bias.data), tw2t=ptr(fl["tw2t"]), tb2=ptr(t2.bias.data), tw3=ptr(t3.weight.data), tb3=ptr(t3.bias.data),
+            step=ptr(fl["step"]), loss_out=ptr(fl["loss"]), lr=self.lr, beta1=0.9, beta2=0.999, eps=1e-8,
+            discount=self.discount, max_grad_norm=10.0)
+        env = self.env
+        env._sync_torch_to_lib()
+        _lib.check(env.lib.sgk_dqn_sgd_step(env._h.ptr, ctypes.byref(L)))
+        env._sync_lib_to_torch()
+        self._fw_stale = False
+        self.last_loss = fl["loss"]
+        return self.last_loss
 
     def greedy_weights(self):
         """Q-network weights in the fused kernels' layout (greedy evaluation, batched_default_eval), or None."""
@@ -186,6 +238,8 @@ class BatchedDeepQAgent:
 
     def learn_batch(self):
         torch = self.torch
+        if self.fused_learn:
+            return self._learn_batch_fused()
         states, actions, rewards, successors, terminals = self.replay.sample(self.batch_size)
         self.Q.train()
         q_sa = self.Q(states.float()).gather(1, actions.long().unsqueeze(1)).squeeze(1)
@@ -242,8 +296,8 @@ class BatchedDeepQAgent:
         if learn:
             self._prev_boards.copy_(env.boards().reshape(env.n_envs, -1))
         if self.fused_policy:  # epsilon and the draw index are read from device memory: they advance between replays
-            if learn or self._fw_stale:
-                self._refresh_fused_weights()  # recorded in the learn graph: the weights change every replay
+            if (learn and not self.fused_learn) or self._fw_stale:
+                self._refresh_fused_weights()  # recorded in the learn graph: torch's update leaves the transposes behind
             actions = env.policy_act(self._fw, self._eps_dev, self._draw_dev, out=self._actions)
         elif self.action_n == 4:
             env.obs_f32(self._obs)

@@ -298,3 +298,58 @@ def test_fused_greedy_eval_and_act_rollout_equal_the_stepwise_paths():
     assert (f[0] == s[0]).all() and f[0][S.metering.M_EPISODES] >= n
     assert (f[1] == s[1]).all() and all((f[2][k] == s[2][k]).all() for k in f[2])
     assert (f[3] == s[3]).all() and (f[4] == s[4]).all() and (f[5] == s[5]).all()
+
+
+@pytest.mark.parametrize("name,hidden,batch", [("SideEffectsSokoban-v0", 100, 64), ("BoatRace-v0", 64, 32), ("DistributionalShift-v0", 100, 48)])
+def test_fused_dqn_sgd_step_equals_torch_autograd_adam(name, hidden, batch):
+    """sgk_dqn_sgd_step (sampling, both forwards, TD target, MSE, backward, clip_grad_norm_(10), Adam amsgrad in ONE kernel)
+    vs the same update by torch on the CPU in fp32 with the minibatch the kernel's counter RNG selects (indices restated by
+    the oracle). Floating point, different summation order: parameters and loss agree to rtol 2e-4 / atol 2e-6 over three
+    consecutive steps; the transposed copies the kernel maintains equal the updated weights exactly."""
+    import torch
+
+    torch.manual_seed(13)
+    n, seed, slices = 600, 41, 4
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    env.bind_torch_stream()
+    agent = S.BatchedDeepQAgent(env, _args(n_hidden=hidden, batch_size=batch, lr=1e-2, discount=0.9), replay_slices=slices)
+    assert agent.fused_learn
+    with torch.no_grad():
+        for p in agent.Q.parameters():
+            p.mul_(2.0)
+        for p in agent.target_Q.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    agent._refresh_fused_weights()
+    agent._fl["w2t"].copy_(agent.Q[1][0][0].weight.data.t())
+    agent._refresh_target_transposes()
+    agent.warmup(slices)  # random-action slices fill the ring
+    rp = agent.replay
+    flat = lambda t: t.reshape(slices * n, *t.shape[2:]).cpu()  # noqa: E731
+    st, ac, rw, su, te = flat(rp.states), flat(rp.actions), flat(rp.rewards), flat(rp.successors), flat(rp.terminals)
+    # the reference update on the CPU
+    cpu_q = agent.build_Q(env.n_cells, 2, hidden)
+    cpu_t = agent.build_Q(env.n_cells, 2, hidden)
+    cpu_q.load_state_dict({k: v.cpu() for k, v in agent.Q.state_dict().items()})
+    cpu_t.load_state_dict({k: v.cpu() for k, v in agent.target_Q.state_dict().items()})
+    opt = torch.optim.Adam(cpu_q.parameters(), lr=1e-2, amsgrad=True)
+    for step in range(3):
+        loss_gpu = float(agent.learn_batch().cpu())
+        ix = torch.as_tensor(O.minibatch_indices(seed, step, batch, slices * n))
+        q_sa = cpu_q(st[ix].float()).gather(1, ac[ix].long().unsqueeze(1)).squeeze(1)
+        with torch.no_grad():
+            nq = cpu_t(su[ix].float()).max(1)[0]
+            nq = torch.where(te[ix], torch.zeros_like(nq), nq)
+            expected = 0.9 * nq + rw[ix].float()
+        loss = torch.nn.functional.mse_loss(q_sa, expected)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(cpu_q.parameters(), 10.0)
+        opt.step()
+        assert abs(loss_gpu - float(loss.detach())) <= 2e-4 * abs(float(loss.detach())) + 2e-6, (step, loss_gpu, float(loss.detach()))
+        for (k, v), (k2, v2) in zip(agent.Q.state_dict().items(), cpu_q.state_dict().items()):
+            np.testing.assert_allclose(v.cpu().numpy(), v2.numpy(), rtol=2e-4, atol=2e-6, err_msg="%s step %d" % (k, step))
+    assert int(agent._fl["step"].cpu()) == 3
+    assert (agent._fw["w1t"].cpu() == agent.Q[0][0].weight.data.t().cpu()).all()
+    assert (agent._fl["w2t"].cpu() == agent.Q[1][0][0].weight.data.t().cpu()).all()
+    assert (agent._fw["w3t"].cpu() == agent.Q[2].weight.data.t().cpu()).all()
+    env.close()
