@@ -256,6 +256,14 @@ typedef struct sgk_dqn_learner {
   double lr, beta1, beta2, eps, discount, max_grad_norm;
 } sgk_dqn_learner;
 SGK_API int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *learner);
+/* ReplayBuffer.add for every env (reference contain.py:15-17 via value.py:114) into ring slice `slice` (or *slice_dev when
+ * non-NULL, so that the call can be recorded in a graph) of rings laid out [slices][n_envs][...]: phase 0, called before
+ * sgk_step, stores the current boards as the transitions' state; phase 1, called after it, stores the boards as successor
+ * and action / reward / terminal from the step records (cheat != 0: the actual action and the hidden reward, learn.py:41-47;
+ * else actions_dev, the uint8 [n_envs] actions that were stepped, and the observed reward). */
+SGK_API int sgk_replay_store(sgk_env *h, int32_t phase, const uint8_t *actions_dev, int32_t cheat, int64_t slice,
+                             const int64_t *slice_dev, int8_t *states_ring, int8_t *successors_ring, uint8_t *actions_ring,
+                             int8_t *rewards_ring, uint8_t *terminals_ring);
 
 /* ---- PPOBaseAgent.act_explore for every env (reference policy_base.py:54-64: Categorical(logits).sample()) ------------- */
 /* logits_dev: float32 [n_envs][4], 16-byte aligned (the actor head of any network: PPOMLPAgent policy_mlp.py:29-43,

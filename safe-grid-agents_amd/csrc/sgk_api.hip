@@ -620,6 +620,20 @@ int sgk_policy_rollout(sgk_env *h, const sgk_mlp_weights *w, int32_t mode, doubl
   return SGK_OK;
 }
 
+int sgk_replay_store(sgk_env *h, int32_t phase, const uint8_t *actions_dev, int32_t cheat, int64_t slice, const int64_t *slice_dev,
+                     int8_t *states_ring, int8_t *successors_ring, uint8_t *actions_ring, int8_t *rewards_ring,
+                     uint8_t *terminals_ring) {
+  SGK_CHECK_HANDLE(h);
+  if (phase != 0 && phase != 1) return fail(SGK_ERR_INVALID, "phase must be 0 (before env.step) or 1 (after)");
+  if (!states_ring || !successors_ring) return fail(SGK_ERR_INVALID, "NULL ring pointer");
+  if (phase == 1 && (!actions_ring || !rewards_ring || !terminals_ring || (!cheat && !actions_dev)))
+    return fail(SGK_ERR_INVALID, "phase 1 needs the action / reward / terminal rings and, unless cheat, the actions");
+  if (slice < 0) return fail(SGK_ERR_INVALID, "slice < 0");
+  SGK_HIP(sgk::launch_replay_store(h->sh, phase, actions_dev, cheat, slice, reinterpret_cast<const long long *>(slice_dev),
+                                   states_ring, successors_ring, actions_ring, rewards_ring, terminals_ring, h->stream));
+  return SGK_OK;
+}
+
 int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) {
   SGK_CHECK_HANDLE(h);
   if (!L) return fail(SGK_ERR_INVALID, "learner is NULL");

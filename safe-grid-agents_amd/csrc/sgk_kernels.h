@@ -75,6 +75,9 @@ struct DqnLearner {
   int n_hidden, batch;
   double lr, beta1, beta2, eps, discount, max_grad_norm;
 };
+hipError_t launch_replay_store(const Shard &sh, int phase, const uint8_t *actions, int cheat, int64_t head, const long long *head_dev,
+                               int8_t *states, int8_t *successors, uint8_t *r_actions, int8_t *r_rewards, uint8_t *r_terminals,
+                               hipStream_t st);
 size_t dqn_sgd_lds_bytes(int n_cells, int n_hidden);
 hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st);
 hipError_t launch_discounted_returns(const Shard &sh, const float *rewards, const int32_t *lengths, const float *gamma_pow,

@@ -399,6 +399,45 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   }
 }
 
+// ReplayBuffer.add for every env (reference contain.py:15-17, called from value.py:114): phase 0, before env.step, stores the
+// boards as the transitions' `state`; phase 1, after it, stores the boards as `successor` and the action / reward /
+// terminal flag from the step records. One launch per phase instead of seven tensor copies per lockstep step.
+__global__ __launch_bounds__(WG) void replay_store_kernel(const int8_t *__restrict__ boards, int pitch, int nc, int64_t n,
+                                                          const uint32_t *__restrict__ rec, const uint8_t *__restrict__ actions,
+                                                          int phase, int cheat, int64_t head, const long long *__restrict__ head_dev,
+                                                          int8_t *__restrict__ states, int8_t *__restrict__ successors,
+                                                          uint8_t *__restrict__ r_actions, int8_t *__restrict__ r_rewards,
+                                                          uint8_t *__restrict__ r_terminals) {
+  const int64_t slice = head_dev ? (int64_t)*head_dev : head;
+  int8_t *dst = (phase == 0 ? states : successors) + slice * n * nc;
+  const int64_t gtid = (int64_t)blockIdx.x * WG + threadIdx.x, gsz = (int64_t)gridDim.x * WG;
+  if (pitch == nc && ((n * nc) & 3) == 0) {  // rows back to back: copy dwords
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(boards);
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
+    for (int64_t i = gtid; i < n * nc / 4; i += gsz) d32[i] = s32[i];
+  } else {
+    for (int64_t i = gtid; i < n * nc; i += gsz) dst[i] = boards[(i / nc) * pitch + i % nc];
+  }
+  if (phase == 1) {
+    for (int64_t env = gtid; env < n; env += gsz) {
+      const uint32_t r = rec[env];  // reward | hidden << 8 | done << 16 | actual action << 24
+      r_actions[slice * n + env] = cheat ? (uint8_t)(r >> 24) : actions[env];
+      r_rewards[slice * n + env] = cheat ? (int8_t)(r >> 8) : (int8_t)r;
+      r_terminals[slice * n + env] = (uint8_t)((r >> 16) & 1u);
+    }
+  }
+}
+
+hipError_t launch_replay_store(const Shard &sh, int phase, const uint8_t *actions, int cheat, int64_t head, const long long *head_dev,
+                               int8_t *states, int8_t *successors, uint8_t *r_actions, int8_t *r_rewards, uint8_t *r_terminals,
+                               hipStream_t st) {
+  (void)hipGetLastError();
+  int grid = grid_for((sh.n * sh.n_cells / 4 + WG - 1) / WG, sh.max_grid);
+  replay_store_kernel<<<dim3(grid), dim3(WG), 0, st>>>(sh.boards, sh.pitch, sh.n_cells, sh.n, sh.rec, actions, phase, cheat, head,
+                                                      head_dev, states, successors, r_actions, r_rewards, r_terminals);
+  return hipGetLastError();
+}
+
 size_t dqn_sgd_lds_bytes(int n_cells, int n_hidden) {
   const size_t kp = (size_t)((n_cells + 3) & ~3), h = (size_t)n_hidden;
   return sizeof(float) * (4 * LB * h + h * h + 8 * h + 4 * h + 8 + 2 * LB * 4 + LB + 32 + LB + 3 * LB) + 2 * LB * kp + 64;

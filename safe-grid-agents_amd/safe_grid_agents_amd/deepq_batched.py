@@ -29,6 +29,7 @@ class DeviceReplay:
         self.head = 0      # next slice to write
         self.filled = 0    # slices holding data
         self.head_dev = torch.zeros(1, dtype=torch.long, device=device)  # the same head, for graph-captured adds
+        self.head_dev_stale = False
 
     def __len__(self):
         return self.filled * self.n
@@ -41,11 +42,30 @@ class DeviceReplay:
         self.successors[k].copy_(successors)
         self.terminals[k].copy_(terminals)
         self._advance()
-        self.head_dev.fill_(self.head)
+        self.head_dev_stale = True
 
     def _advance(self):
         self.head = (self.head + 1) % self.slices
         self.filled = min(self.filled + 1, self.slices)
+
+    def store(self, env, phase, actions=None, cheat=False, captured=False):
+        """ReplayBuffer.add for every env as two kernel launches (sgk_replay_store): phase 0 before env.step (boards ->
+        states[head]), phase 1 after it (boards -> successors[head]; action, reward, terminal from the step records). With
+        `captured` the slice index is read from device memory (head_dev) so that the launch can be recorded in a graph; the
+        caller advances the heads (phase 1 of the eager form advances the host head itself)."""
+        import ctypes
+
+        from . import _lib
+
+        ptr = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())  # noqa: E731
+        env._sync_torch_to_lib()
+        _lib.check(env.lib.sgk_replay_store(env._h.ptr, int(phase), ptr(actions), int(bool(cheat)), int(self.head),
+                                            ptr(self.head_dev) if captured else None, ptr(self.states), ptr(self.successors),
+                                            ptr(self.actions), ptr(self.rewards), ptr(self.terminals)))
+        env._sync_lib_to_torch()
+        if phase == 1 and not captured:
+            self._advance()
+            self.head_dev_stale = True
 
     def add_slice_captured(self, states, actions, rewards, successors, terminals):
         """The same write with the slice index read from device memory: safe to record in a CUDA/HIP graph (a Python
@@ -98,7 +118,6 @@ class BatchedDeepQAgent:
         self.optim = torch.optim.Adam(self.Q.parameters(), lr=self.lr, amsgrad=True, capturable=True, fused=True)
         self.replay = DeviceReplay(env.n_envs, env.n_cells, replay_slices, self.device)
         self._obs = torch.empty((env.n_envs, env.n_cells), dtype=torch.float32, device=self.device)
-        self._prev_boards = torch.empty((env.n_envs, env.n_cells), dtype=torch.int8, device=self.device)
         self.last_loss = None
         self._actions = torch.empty(env.n_envs, dtype=torch.uint8, device=self.device)
         # fused forward + act_explore kernel (sgk_policy_act): two layers of 100 (the reference default), 64 or 128 units
@@ -263,7 +282,7 @@ class BatchedDeepQAgent:
         update_epsilon -> (sync target) -> reset finished envs (the episode loop of train.py:62-70)."""
         env = self.env
         if learn:
-            self._prev_boards.copy_(env.boards().reshape(env.n_envs, -1))
+            self.replay.store(env, 0)  # the boards the agents act on are the transitions' states
         if self.fused_policy:
             if self._fw_stale:
                 self._refresh_fused_weights()
@@ -271,11 +290,9 @@ class BatchedDeepQAgent:
         else:
             env.obs_f32(self._obs)
             actions = self.act_explore(self._obs) if explore else self.act(self._obs)
-        succ, reward, done, info = env.step(actions, auto_reset=False)
+        env.step(actions, auto_reset=False)
         if learn:
-            r = info["hidden_reward"] if cheat else reward
-            a = info["extra_observations"]["actual_actions"].to(self.torch.uint8) if cheat else actions
-            self.replay.add_slice(self._prev_boards, a, r, succ.reshape(env.n_envs, -1), done.bool())
+            self.replay.store(env, 1, actions, cheat)  # successor boards, action, reward (hidden when cheating), terminal
             for _ in range(self.sgd_steps):
                 self.learn_batch()
         t = self.t
@@ -294,7 +311,7 @@ class BatchedDeepQAgent:
         torch = self.torch
         env = self.env
         if learn:
-            self._prev_boards.copy_(env.boards().reshape(env.n_envs, -1))
+            self.replay.store(env, 0, captured=True)
         if self.fused_policy:  # epsilon and the draw index are read from device memory: they advance between replays
             if (learn and not self.fused_learn) or self._fw_stale:
                 self._refresh_fused_weights()  # recorded in the learn graph: torch's update leaves the transposes behind
@@ -313,9 +330,10 @@ class BatchedDeepQAgent:
             explore = torch.rand(n, device=self.device) < self._eps_dev
             rand_a = torch.randint(0, self.action_n, (n,), device=self.device)
             actions = torch.where(explore, rand_a, greedy).to(torch.uint8)
-        succ, reward, done, info = env.step(actions, auto_reset=False)
+        env.step(actions, auto_reset=False)
         if learn:
-            self.replay.add_slice_captured(self._prev_boards, actions, reward, succ.reshape(env.n_envs, -1), done.bool())
+            self.replay.store(env, 1, actions, captured=True)
+            self.replay.head_dev.add_(1).remainder_(self.replay.slices)
             for _ in range(self.sgd_steps):
                 self.learn_batch()
         env.reset_done()
@@ -329,6 +347,9 @@ class BatchedDeepQAgent:
         if learn:
             assert self.replay.filled == self.replay.slices, "fill the replay ring (warmup) before capturing the learn graph"
         env = self.env
+        if learn:
+            self.replay.head_dev.fill_(self.replay.head)
+            self.replay.head_dev_stale = False
         with torch.no_grad() if not learn else torch.enable_grad():
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
@@ -351,6 +372,9 @@ class BatchedDeepQAgent:
         """One lockstep iteration = one graph replay (+ two scalar updates)."""
         self._eps_dev.fill_(self.epsilon)
         self._draw_dev.fill_(self.t)
+        if learn and self.replay.head_dev_stale:  # eager adds moved the host-side head since the last replay
+            self.replay.head_dev.fill_(self.replay.head)
+            self.replay.head_dev_stale = False
         if self.fused_policy and self._fw_stale and not learn:
             self._refresh_fused_weights()  # the no-learning graph does not record the transposes
         self._graphs[learn].replay()
@@ -367,8 +391,8 @@ class BatchedDeepQAgent:
         torch = self.torch
         env = self.env
         for _ in range(n_steps):
-            self._prev_boards.copy_(env.boards().reshape(env.n_envs, -1))
+            self.replay.store(env, 0)
             actions = torch.randint(0, self.action_n, (env.n_envs,), device=self.device).to(torch.uint8)
-            succ, reward, done, info = env.step(actions, auto_reset=False)
-            self.replay.add_slice(self._prev_boards, actions, reward, succ.reshape(env.n_envs, -1), done.bool())
+            env.step(actions, auto_reset=False)
+            self.replay.store(env, 1, actions)
             env.reset_done()
