@@ -67,17 +67,6 @@ class DeviceReplay:
             self._advance()
             self.head_dev_stale = True
 
-    def add_slice_captured(self, states, actions, rewards, successors, terminals):
-        """The same write with the slice index read from device memory: safe to record in a CUDA/HIP graph (a Python
-        int would be frozen into the graph). The caller advances the host-side head with note_replayed_add()."""
-        k = self.head_dev
-        self.states.index_copy_(0, k, states.unsqueeze(0))
-        self.actions.index_copy_(0, k, actions.unsqueeze(0))
-        self.rewards.index_copy_(0, k, rewards.unsqueeze(0))
-        self.successors.index_copy_(0, k, successors.unsqueeze(0))
-        self.terminals.index_copy_(0, k, terminals.unsqueeze(0))
-        self.head_dev.add_(1).remainder_(self.slices)
-
     def note_replayed_add(self):
         self._advance()
 
