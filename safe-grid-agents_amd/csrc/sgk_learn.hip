@@ -56,45 +56,54 @@ __device__ __forceinline__ f4 load_x4(const int8_t *row, int k) {  // four board
   return (f4){(float)(int8_t)(w & 0xff), (float)(int8_t)((w >> 8) & 0xff), (float)(int8_t)((w >> 16) & 0xff), (float)(int8_t)(w >> 24)};
 }
 
-// out[b][j] = epilogue(bias[j] + sum_k in[b][k] * wt[k][j]) for the LB samples and j < H, everything in LDS. Lane (jq, sg) owns
-// the four neurons 4 jq .. 4 jq + 3 for the two samples 2 sg, 2 sg + 1: per four k it reads two pieces of `in` and four 16-byte
-// weight rows (32 lanes x 16 B contiguous: conflict-free) for 32 FMAs. KP = row stride of `in` in elements (K rounded up to
-// 4; the padding holds zeros); weight rows k >= K are not read. `mask` zeroes out[b][j] where mask[b][j] <= 0 (ReLU').
+__device__ __forceinline__ float load_x1(const float *row, int k) { return row[k]; }
+__device__ __forceinline__ float load_x1(const int8_t *row, int k) { return (float)row[k]; }
+
+// out[b][n] = epilogue(bias[n] + sum_k in[b][k] * wt[k][n]) for the LB samples and n < H, everything in LDS, on the matrix
+// cores (v_mfma_f32_16x16x4_f32: exact fp32): out^T = W in^T in 16 x 16 tiles, A operand = 16 neurons x 4 k of wt (lanes
+// along n: consecutive words), B operand = 4 k x 16 samples of `in`, C = 16 neurons x 16 samples. Two 4-byte LDS reads feed
+// 1 024 FMAs; the VALU form before it (4 neurons x 2 samples per lane) moved 3 bytes of LDS per FMA and spent 8.6 us per
+// 100 x 100 layer on LDS bandwidth alone. The ceil(H / 16) x 4 output tiles are dealt round-robin to the 16 waves.
+// KP = row stride of `in` in elements; `mask` zeroes out[b][n] where mask[b][n] <= 0 (ReLU'); neuron rows >= H of the last
+// tile are computed from whatever lies behind the row (still inside LDS) and dropped.
 template <class T>
 __device__ __forceinline__ void dense_layer(const T *in, int K, int KP, const float *wt, const float *bias, int H, float *out,
                                             bool relu, const float *mask) {
-  const int jq = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  if (4 * jq < H) {
-    const int b0 = 2 * sg;
-    f4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (bias) acc0 = *reinterpret_cast<const f4 *>(bias + 4 * jq);
-    f4 acc1 = acc0;
-    for (int k0 = 0; k0 < K; k0 += 4) {
-      const f4 x0 = load_x4(in + b0 * KP, k0), x1 = load_x4(in + (b0 + 1) * KP, k0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const int col = lane & 15, grp = lane >> 4;
+  const int MT = (H + 15) / 16;
+  for (int tile = wave; tile < MT * (LB / 16); tile += n_waves) {
+    const int n0 = 16 * (tile % MT), b0 = 16 * (tile / MT);
+    f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (bias && n0 + 4 * grp < H) acc = *reinterpret_cast<const f4 *>(bias + n0 + 4 * grp);
+    const T *xrow = in + (b0 + col) * KP;
+    const float *wcol = wt + n0 + col;
+    // four k-steps per trip (the operands of k >= K are zero). Measured in-kernel: a 100 x 100 layer takes ~15 k cycles
+    // where the MFMA issue bound of its 28 tiles x 25 k-steps on four SIMDs is 6.4 k: the compiler still waits out each
+    // LDS read before the MFMA that uses it (runtime K). Compile-time K / H with the loads hoisted is the next step.
+    for (int k0 = 0; k0 < K; k0 += 16) {
+      float av[4], bv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (k0 + u < K) {
-          const f4 w = *reinterpret_cast<const f4 *>(wt + (k0 + u) * H + 4 * jq);
-          acc0 = __builtin_elementwise_fma(w, (f4){x0[u], x0[u], x0[u], x0[u]}, acc0);
-          acc1 = __builtin_elementwise_fma(w, (f4){x1[u], x1[u], x1[u], x1[u]}, acc1);
-        }
+        const int k = k0 + 4 * u + grp;
+        const int kc = min(k, K - 1);
+        av[u] = wcol[kc * H];
+        bv[u] = load_x1(xrow, kc);
+        if (k >= K) { av[u] = 0.0f; bv[u] = 0.0f; }
       }
-    }
-    const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (relu) {
-      acc0 = __builtin_elementwise_max(acc0, zero);
-      acc1 = __builtin_elementwise_max(acc1, zero);
-    }
-    if (mask) {
-      const f4 m0 = *reinterpret_cast<const f4 *>(mask + b0 * H + 4 * jq), m1 = *reinterpret_cast<const f4 *>(mask + (b0 + 1) * H + 4 * jq);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc0[c] = m0[c] > 0.0f ? acc0[c] : 0.0f;
-        acc1[c] = m1[c] > 0.0f ? acc1[c] : 0.0f;
-      }
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
     }
-    *reinterpret_cast<f4 *>(out + b0 * H + 4 * jq) = acc0;
-    *reinterpret_cast<f4 *>(out + (b0 + 1) * H + 4 * jq) = acc1;
+    const int n = n0 + 4 * grp;  // this lane's four neurons, sample b0 + col
+    if (n < H) {
+      if (relu) acc = __builtin_elementwise_max(acc, (f4){0.0f, 0.0f, 0.0f, 0.0f});
+      if (mask) {
+        const f4 m = *reinterpret_cast<const f4 *>(mask + (b0 + col) * H + n);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = m[c] > 0.0f ? acc[c] : 0.0f;
+      }
+      *reinterpret_cast<f4 *>(out + (b0 + col) * H + n) = acc;
+    }
   }
 }
 
@@ -331,16 +340,20 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   const float norm = sqrtf(block_sum(ss, L.scratch));
   const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
   // ---- Adam (amsgrad) on the owned parameters; the transposed copies follow ---------------------------------------
-  const long long step = *a.step + 1;
-  AdamCoef ac;
-  ac.lr_bc1 = a.lr / (float)(1.0 - pow((double)a.beta1, (double)step));
-  ac.bc2_sqrt = sqrtf((float)(1.0 - pow((double)a.beta2, (double)step)));
-  ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
-  __syncthreads();  // every lane has read *a.step
+  // the bias corrections need two double-precision pow(): one lane computes them for all (1 024 lanes each doing it cost
+  // ~15 k cycles), and bumps the step counter
   if (t == 0) {
+    const long long step = *a.step + 1;
+    L.scratch[16] = a.lr / (float)(1.0 - pow((double)a.beta1, (double)step));
+    L.scratch[17] = sqrtf((float)(1.0 - pow((double)a.beta2, (double)step)));
     *a.step = step;
     if (a.loss_out) *a.loss_out = loss;
   }
+  __syncthreads();
+  AdamCoef ac;
+  ac.lr_bc1 = L.scratch[16];
+  ac.bc2_sqrt = L.scratch[17];
+  ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
   if (t < H) {  // W3 column t (stride H between the four rows), W3^T row t
     f4 nw;
 #pragma unroll
