@@ -233,7 +233,7 @@ SGK_API int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon,
 /* Minibatch sampling from a device replay ring (uniform with replacement, contain.py:19-22; counter RNG stream 4 keyed by
  * the Adam step), Q-network and target-network forward, TD target r + discount * max_a' Q_target(s', a') * (1 - terminal),
  * mse_loss, backward, clip_grad_norm_(max_grad_norm), Adam(amsgrad) update -- the Linear(n_cells, H)-ReLU-Linear(H, H)-ReLU-
- * Linear(H, 4) network of value.py:148-158 with H <= 128, batch <= 64. All pointers are device pointers; float32.
+ * Linear(H, 4) network of value.py:148-158 with H = 100 (the reference default) or 64, batch <= 64. All pointers are device pointers; float32.
  *   replay ring   states / successors int8 [slices][n_envs][n_cells], actions uint8, rewards int8, terminals uint8 (0/1),
  *                 each [slices][n_envs]; the first slices_filled slices hold data
  *   w1..b3        the Q-network's parameters in torch layout ([out][in]), UPDATED IN PLACE

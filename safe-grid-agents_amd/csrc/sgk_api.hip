@@ -643,8 +643,8 @@ int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) {
     if (!p) return fail(SGK_ERR_INVALID, "NULL pointer in sgk_dqn_learner");
   for (int i = 0; i < 6; ++i)
     if (!L->m[i] || !L->v[i] || !L->vmax[i]) return fail(SGK_ERR_INVALID, "NULL Adam state in sgk_dqn_learner");
-  if (L->n_hidden < 4 || L->n_hidden > 128 || (L->n_hidden & 3) || L->batch < 1 || L->batch > 64 || L->slices_filled < 1)
-    return fail(SGK_ERR_INVALID, "sgk_dqn_sgd_step needs n_hidden in 4..128 and a multiple of 4, 1 <= batch <= 64, slices_filled >= 1");
+  if ((L->n_hidden != 64 && L->n_hidden != 100) || L->batch < 1 || L->batch > 64 || L->slices_filled < 1)
+    return fail(SGK_ERR_INVALID, "sgk_dqn_sgd_step needs n_hidden 64 or 100 (the reference default), 1 <= batch <= 64, slices_filled >= 1");
   if (sgk::dqn_sgd_lds_bytes(h->sh.n_cells, L->n_hidden) > 160u * 1024u)
     return fail(SGK_ERR_INVALID, "this n_cells / n_hidden does not fit the 160 KB of LDS the kernel works in");
   sgk::DqnLearner d;

@@ -66,33 +66,43 @@ __device__ __forceinline__ float load_x1(const int8_t *row, int k) { return (flo
 // 100 x 100 layer on LDS bandwidth alone. The ceil(H / 16) x 4 output tiles are dealt round-robin to the 16 waves.
 // KP = row stride of `in` in elements; `mask` zeroes out[b][n] where mask[b][n] <= 0 (ReLU'); neuron rows >= H of the last
 // tile are computed from whatever lies behind the row (still inside LDS) and dropped.
-template <class T>
-__device__ __forceinline__ void dense_layer(const T *in, int K, int KP, const float *wt, const float *bias, int H, float *out,
-                                            bool relu, const float *mask) {
+template <int K, int H, class T>
+__device__ __forceinline__ void dense_layer(const T *in, int KP, const float *wt, const float *bias, float *out, bool relu,
+                                            const float *mask) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const int col = lane & 15, grp = lane >> 4;
-  const int MT = (H + 15) / 16;
+  constexpr int MT = (H + 15) / 16, KS = (K + 3) / 4;  // neuron tiles, k-steps
+  constexpr int CH = KS < 8 ? KS : 8;                    // k-steps whose operands are fetched together
   for (int tile = wave; tile < MT * (LB / 16); tile += n_waves) {
     const int n0 = 16 * (tile % MT), b0 = 16 * (tile / MT);
     f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     if (bias && n0 + 4 * grp < H) acc = *reinterpret_cast<const f4 *>(bias + n0 + 4 * grp);
     const T *xrow = in + (b0 + col) * KP;
     const float *wcol = wt + n0 + col;
-    // four k-steps per trip (the operands of k >= K are zero). Measured in-kernel: a 100 x 100 layer takes ~15 k cycles
-    // where the MFMA issue bound of its 28 tiles x 25 k-steps on four SIMDs is 6.4 k: the compiler still waits out each
-    // LDS read before the MFMA that uses it (runtime K). Compile-time K / H with the loads hoisted is the next step.
-    for (int k0 = 0; k0 < K; k0 += 16) {
-      float av[4], bv[4];
+    // compile-time shapes: the loop nest unrolls completely and the operand reads of a chunk are issued before its MFMAs
+    // (with a runtime K the compiler waited out every LDS read in front of the MFMA using it: 15 k cycles per 100 x 100
+    // layer against an issue bound of 6.4 k)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = k0 + 4 * u + grp;
-        const int kc = min(k, K - 1);
-        av[u] = wcol[kc * H];
-        bv[u] = load_x1(xrow, kc);
-        if (k >= K) { av[u] = 0.0f; bv[u] = 0.0f; }
+    for (int c0 = 0; c0 < KS; c0 += CH) {
+      float av[CH], bv[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int k = 4 * (c0 + u) + grp;
+        if (4 * (c0 + u) + 3 < K) {  // whole k-step inside K: no guard
+          av[u] = wcol[k * H];
+          bv[u] = load_x1(xrow, k);
+        } else if (4 * (c0 + u) < K) {  // the ragged last k-step
+          const int kc = k < K ? k : K - 1;
+          av[u] = k < K ? wcol[kc * H] : 0.0f;
+          bv[u] = k < K ? load_x1(xrow, kc) : 0.0f;
+        } else {
+          av[u] = 0.0f;
+          bv[u] = 0.0f;
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+      for (int u = 0; u < CH; ++u)
+        if (4 * (c0 + u) < K) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
     }
     const int n = n0 + 4 * grp;  // this lane's four neurons, sample b0 + col
     if (n < H) {
@@ -136,6 +146,24 @@ __device__ __forceinline__ void weight_grad_tile(const float *d, int DS, int row
 #pragma unroll
     for (int r = 0; r < 4; ++r) g[r] = __builtin_elementwise_fma((f4){dv[r], dv[r], dv[r], dv[r]}, xv, g[r]);
   }
+}
+
+// One 16 x 16 tile of a weight gradient on the matrix cores: G[r][c] = sum_b d[b][row0 + r] * x[b][col0 + c] over the LB samples
+// (K = the batch). A operand = d[b][row0 + (lane & 15)], B operand = x[b][col0 + (lane & 15)], b = 4 s + (lane >> 4): both
+// are consecutive words across the lanes. Result in the C layout: lane (col, grp), register r = G[4 grp + r][col].
+template <class T>
+__device__ __forceinline__ f4 weight_grad_mfma(const float *d, int DS, int row0, const T *x, int XS, int col0, int lane) {
+  const int col = lane & 15, grp = lane >> 4;
+  f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  float av[LB / 4], bv[LB / 4];
+#pragma unroll
+  for (int s = 0; s < LB / 4; ++s) {
+    av[s] = d[(4 * s + grp) * DS + row0 + col];
+    bv[s] = load_x1(x + (4 * s + grp) * XS, col0 + col);
+  }
+#pragma unroll
+  for (int s = 0; s < LB / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+  return acc;
 }
 
 __device__ __forceinline__ float block_sum(float x, float *scratch) {  // scratch: LWG / 64 floats
@@ -213,10 +241,11 @@ __device__ __forceinline__ LearnLds carve(unsigned char *base, int KP, int H) {
   return L;
 }
 
+template <int K0, int H>
 __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char learn_smem[];
-  const int K0 = a.n_cells, H = a.n_hidden, B = a.batch;
-  const int KP = (K0 + 3) & ~3;  // row stride of the board matrices (padding columns hold zeros)
+  const int B = a.batch;
+  constexpr int KP = (K0 + 3) & ~3;  // row stride of the board matrices (padding columns hold zeros)
   const LearnLds L = carve(learn_smem, KP, H);
   const int t = threadIdx.x;
 
@@ -252,21 +281,21 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   }
   __syncthreads();
   // ---- target network on the successors ----
-  dense_layer(L.S2, K0, KP, L.ST, L.tb1, H, L.C, true, nullptr);
+  dense_layer<K0, H>(L.S2, KP, L.ST, L.tb1, L.C, true, nullptr);
   __syncthreads();
   stage(L.ST, a.tw2t, H * H);
   __syncthreads();
-  dense_layer(L.C, H, H, L.ST, L.tb2, H, L.D, true, nullptr);
+  dense_layer<H, H>(L.C, H, L.ST, L.tb2, L.D, true, nullptr);
   __syncthreads();
   head_forward(L.D, H, L.tw3, L.tb3, L.tq);
   // ---- Q-network on the states ----
   stage(L.ST, a.w1t, K0 * H);
   __syncthreads();
-  dense_layer(L.S, K0, KP, L.ST, L.b1, H, L.A, true, nullptr);
+  dense_layer<K0, H>(L.S, KP, L.ST, L.b1, L.A, true, nullptr);
   __syncthreads();
   stage(L.ST, a.w2t, H * H);
   __syncthreads();
-  dense_layer(L.A, H, H, L.ST, L.b2, H, L.Bq, true, nullptr);
+  dense_layer<H, H>(L.A, H, L.ST, L.b2, L.Bq, true, nullptr);
   __syncthreads();
   head_forward(L.Bq, H, L.w3, L.b3, L.q);
   stage(L.ST, a.w2, H * H);  // W2 as it is ([j][k]): the back-propagation through layer 2 wants it in this orientation
@@ -289,9 +318,8 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   __syncthreads();
 
   // ---- backward; every lane keeps the gradients of the parameters it owns in registers ----------------------------
-  const int HQ = H / 4, KQ = KP / 4;
   // dL/dh2 = relu'(h2) * (dq W3) -> C   (dense_layer with K = 4, "wt" = W3 [4][H])
-  dense_layer(L.q, 4, 4, L.w3, nullptr, H, L.C, false, L.Bq);
+  dense_layer<4, H>(L.q, 4, L.w3, nullptr, L.C, false, L.Bq);
   // W3 [4][H]: lane k < H owns column k of all four rows; b3: lanes H .. H + 3
   f4 gw3 = {0.0f, 0.0f, 0.0f, 0.0f};
   float gb3 = 0.0f;
@@ -306,37 +334,61 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   }
   __syncthreads();
   // dL/dh1 = relu'(h1) * (dh2 W2) -> D   ("wt" = W2 as it is)
-  dense_layer(L.C, H, H, L.ST, nullptr, H, L.D, false, L.A);
-  // W2 [H][H] in 4 x 4 tiles: lane t < HQ * HQ owns tile (t / HQ, t % HQ); b2[j]: lanes LWG - 1 - j
-  f4 gw2[4];
+  dense_layer<H, H>(L.C, H, L.ST, nullptr, L.D, false, L.A);
+  // W2 [H][H] in 16 x 16 MFMA tiles dealt round-robin to the 16 waves (tile = (neuron tile, input tile)); the gradients stay in
+  // the C layout: lane (col, grp), register r <-> dW2[j0 + 4 grp + r][k0 + col]. b2[j]: lanes LWG - 1 - j.
+  constexpr int MT = (H + 15) / 16, KT1 = (K0 + 15) / 16;  // 16-wide tiles along neurons / along board cells
+  constexpr int N2 = (MT * MT + LWG / 64 - 1) / (LWG / 64), N1 = (MT * KT1 + LWG / 64 - 1) / (LWG / 64);  // tiles per wave
+  const int lane = t & 63, wave = t >> 6, col = lane & 15, grp = lane >> 4;
+  f4 gw2[N2];
   float gb2 = 0.0f;
-  const bool own2 = t < HQ * HQ;
-  if (own2) weight_grad_tile(L.C, H, 4 * (t / HQ), L.A, H, 4 * (t % HQ), gw2);
-  else if (LWG - 1 - t < H)
+#pragma unroll
+  for (int i = 0; i < N2; ++i) {
+    const int tile = wave + i * (LWG / 64);
+    gw2[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    if (tile < MT * MT) gw2[i] = weight_grad_mfma(L.C, H, 16 * (tile / MT), L.A, H, 16 * (tile % MT), lane);
+  }
+  if (LWG - 1 - t < H)
     for (int b = 0; b < LB; ++b) gb2 += L.C[b * H + (LWG - 1 - t)];
   __syncthreads();
-  // W1 [H][K0] in 4 x 4 tiles over the padded columns: lane t < HQ * KQ; b1[j]: lanes LWG - 1 - j
-  f4 gw1[4];
+  // W1 [H][K0] the same way (columns = board cells; cells >= K0 of the last tile are computed from what lies behind the
+  // row in LDS and dropped); b1[j]: lanes LWG - 1 - j
+  f4 gw1[N1];
   float gb1 = 0.0f;
-  const bool own1 = t < HQ * KQ;
-  if (own1) weight_grad_tile(L.D, H, 4 * (t / KQ), L.S, KP, 4 * (t % KQ), gw1);
-  else if (LWG - 1 - t < H)
+#pragma unroll
+  for (int i = 0; i < N1; ++i) {
+    const int tile = wave + i * (LWG / 64);
+    gw1[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    if (tile < MT * KT1) gw1[i] = weight_grad_mfma(L.D, H, 16 * (tile / KT1), L.S, KP, 16 * (tile % KT1), lane);
+  }
+  if (LWG - 1 - t < H)
     for (int b = 0; b < LB; ++b) gb1 += L.D[b * H + (LWG - 1 - t)];
   // ---- clip_grad_norm_(max_norm): coefficient from the global 2-norm of all gradients -----------------------------
   float ss = gb3 * gb3 + gb2 * gb2 + gb1 * gb1;
 #pragma unroll
   for (int c = 0; c < 4; ++c) ss = fmaf(gw3[c], gw3[c], ss);
-  if (own2)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+  for (int i = 0; i < N2; ++i) {
+    const int tile = wave + i * (LWG / 64);
+    const int j = 16 * (tile / MT) + 4 * grp, k = 16 * (tile % MT) + col;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) ss = fmaf(gw2[r][c], gw2[r][c], ss);
-  if (own1)
+    for (int r = 0; r < 4; ++r) {
+      const bool live = tile < MT * MT && j + r < H && k < H;  // rows / columns past H belong to no parameter
+      gw2[i][r] = live ? gw2[i][r] : 0.0f;
+      ss = fmaf(gw2[i][r], gw2[i][r], ss);
+    }
+  }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+  for (int i = 0; i < N1; ++i) {
+    const int tile = wave + i * (LWG / 64);
+    const int j = 16 * (tile / KT1) + 4 * grp, k = 16 * (tile % KT1) + col;
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (4 * (t % KQ) + c < K0) ss = fmaf(gw1[r][c], gw1[r][c], ss);  // padding columns carry no parameter
+    for (int r = 0; r < 4; ++r) {
+      const bool live = tile < MT * KT1 && j + r < H && k < K0;
+      gw1[i][r] = live ? gw1[i][r] : 0.0f;
+      ss = fmaf(gw1[i][r], gw1[i][r], ss);
+    }
+  }
   const float norm = sqrtf(block_sum(ss, L.scratch));
   const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
   // ---- Adam (amsgrad) on the owned parameters; the transposed copies follow ---------------------------------------
@@ -370,7 +422,7 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
     a.b3[i] = adam_scalar(a.b3[i], m, v, x, gb3 * coef, ac);
     a.m[5][i] = m; a.v[5][i] = v; a.vmax[5][i] = x;
   }
-  if (!own2 && !own1 && LWG - 1 - t < H) {  // the bias lanes (the launcher guarantees they are not tile lanes)
+  if (LWG - 1 - t < H) {  // the bias lanes
     const int i = LWG - 1 - t;
     float m = a.m[3][i], v = a.v[3][i], x = a.vmax[3][i];
     a.b2[i] = adam_scalar(a.b2[i], m, v, x, gb2 * coef, ac);
@@ -379,36 +431,39 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
     a.b1[i] = adam_scalar(a.b1[i], m, v, x, gb1 * coef, ac);
     a.m[1][i] = m; a.v[1][i] = v; a.vmax[1][i] = x;
   }
-  if (own2) {
-    const int j0 = 4 * (t / HQ), k0 = 4 * (t % HQ);
-    f4 rows[4];
+  // the weight tiles: element (j + r, k) for r = 0..3 -- 16 consecutive k across the lanes of a group; the transposed copy
+  // takes the four r of a lane as one 16-byte row piece
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = (j0 + r) * H + k0;
-      rows[r] = adam_row(a.w2 + i, a.m[2] + i, a.v[2] + i, a.vmax[2] + i, gw2[r] * coef, ac);
-    }
+  for (int i = 0; i < N2; ++i) {
+    const int tile = wave + i * (LWG / 64);
+    const int j = 16 * (tile / MT) + 4 * grp, k = 16 * (tile % MT) + col;
+    if (tile < MT * MT && j < H && k < H) {  // H % 4 == 0: the four rows j .. j + 3 are all inside
+      f4 nw;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      *reinterpret_cast<f4 *>(a.w2t + (size_t)(k0 + c) * H + j0) = (f4){rows[0][c], rows[1][c], rows[2][c], rows[3][c]};
-  }
-  if (own1) {
-    const int j0 = 4 * (t / KQ), k0 = 4 * (t % KQ);
-    float nw[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        nw[r][c] = 0.0f;
-        if (k0 + c < K0) {  // W1 rows are K0 long (not padded): element-wise
-          const int i = (j0 + r) * K0 + k0 + c;
-          float m = a.m[0][i], v = a.v[0][i], x = a.vmax[0][i];
-          nw[r][c] = adam_scalar(a.w1[i], m, v, x, gw1[r][c] * coef, ac);
-          a.w1[i] = nw[r][c]; a.m[0][i] = m; a.v[0][i] = v; a.vmax[0][i] = x;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int e = (j + r) * H + k;
+        float m = a.m[2][e], v = a.v[2][e], x = a.vmax[2][e];
+        nw[r] = adam_scalar(a.w2[e], m, v, x, gw2[i][r] * coef, ac);
+        a.w2[e] = nw[r]; a.m[2][e] = m; a.v[2][e] = v; a.vmax[2][e] = x;
       }
+      *reinterpret_cast<f4 *>(a.w2t + (size_t)k * H + j) = nw;
+    }
+  }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (k0 + c < K0) *reinterpret_cast<f4 *>(a.w1t + (size_t)(k0 + c) * H + j0) = (f4){nw[0][c], nw[1][c], nw[2][c], nw[3][c]};
+  for (int i = 0; i < N1; ++i) {
+    const int tile = wave + i * (LWG / 64);
+    const int j = 16 * (tile / KT1) + 4 * grp, k = 16 * (tile % KT1) + col;
+    if (tile < MT * KT1 && j < H && k < K0) {
+      f4 nw;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = (j + r) * K0 + k;
+        float m = a.m[0][e], v = a.v[0][e], x = a.vmax[0][e];
+        nw[r] = adam_scalar(a.w1[e], m, v, x, gw1[i][r] * coef, ac);
+        a.w1[e] = nw[r]; a.m[0][e] = m; a.v[0][e] = v; a.vmax[0][e] = x;
+      }
+      *reinterpret_cast<f4 *>(a.w1t + (size_t)k * H + j) = nw;
+    }
   }
 }
 
@@ -473,14 +528,32 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
   a.seed = sh.seed;
   a.lr = (float)L.lr; a.beta1 = (float)L.beta1; a.beta2 = (float)L.beta2; a.eps = (float)L.eps; a.discount = (float)L.discount;
   a.max_norm = (float)L.max_grad_norm;
-  static unsigned long long opted_in = 0;
-  if (!((opted_in >> (sh.device & 63)) & 1ull)) {
-    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&dqn_sgd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024);
-    if (ae != hipSuccess) return ae;
-    opted_in |= 1ull << (sh.device & 63);
+#define SGK_SGD_LAUNCH(K0V, HV)                                                                                            \
+  do {                                                                                                                     \
+    static unsigned long long opted_in = 0;                                                                                \
+    if (!((opted_in >> (sh.device & 63)) & 1ull)) {                                                                        \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&dqn_sgd_kernel<K0V, HV>),                        \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+      if (ae != hipSuccess) return ae;                                                                                     \
+      opted_in |= 1ull << (sh.device & 63);                                                                                \
+    }                                                                                                                      \
+    dqn_sgd_kernel<K0V, HV><<<dim3(1), dim3(LWG), lds, st>>>(a);                                                           \
+  } while (0)
+#define SGK_SGD_LAUNCH_K(K0V)                                                                                              \
+  do {                                                                                                                     \
+    if (L.n_hidden == 100) SGK_SGD_LAUNCH(K0V, 100);                                                                       \
+    else if (L.n_hidden == 64) SGK_SGD_LAUNCH(K0V, 64);                                                                    \
+    else return hipErrorInvalidValue;                                                                                      \
+  } while (0)
+  switch (sh.n_cells) {  // the shapes with an instantiation: the four levels x {64, 100} hidden units
+  case 25: SGK_SGD_LAUNCH_K(25); break;
+  case 36: SGK_SGD_LAUNCH_K(36); break;
+  case 48: SGK_SGD_LAUNCH_K(48); break;
+  case 63: SGK_SGD_LAUNCH_K(63); break;
+  default: return hipErrorInvalidValue;
   }
-  dqn_sgd_kernel<<<dim3(1), dim3(LWG), lds, st>>>(a);
+#undef SGK_SGD_LAUNCH_K
+#undef SGK_SGD_LAUNCH
   return hipGetLastError();
 }
 

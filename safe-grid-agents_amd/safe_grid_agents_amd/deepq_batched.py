@@ -122,7 +122,7 @@ class BatchedDeepQAgent:
         # amsgrad) for the two-layer topology with up to 128 units and minibatches up to 64; else torch autograd + Adam
         lds_need = 4 * (4 * 64 * n_hidden + n_hidden * n_hidden + 12 * n_hidden + 872) + 128 * ((env.n_cells + 3) & ~3) + 64
         lanes_need = (n_hidden // 4) ** 2 + n_hidden  # one lane per 4 x 4 tile of W2 plus the bias lanes, of 1 024
-        if (fused_learn and self.fused_policy and n_hidden % 4 == 0 and lanes_need <= 1024 and self.batch_size <= 64
+        if (fused_learn and self.fused_policy and n_hidden in (64, 100) and lanes_need <= 1024 and self.batch_size <= 64
                 and lds_need <= 160 * 1024):
             params = [p.data for p in self.Q.parameters()]  # w1, b1, w2, b2, w3, b3 (torch registration order)
             zeros = lambda: [torch.zeros_like(p) for p in params]  # noqa: E731

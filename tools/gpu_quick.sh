@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
-timeout 600 python -m pytest tests/test_gpu_deepq.py -q -m gpu -x 2>&1 | tail -2
-timeout 900 python tools/bench_configs.py 2>&1 | grep '"config": 4' | grep learning | cut -c1-250
+timeout 900 python tools/bench_configs.py > gpurun_out/configs.log 2>&1; grep '"config": 4' gpurun_out/configs.log | cut -c1-250
+timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -2
