@@ -144,23 +144,38 @@ def train(args, config=None, reporter=_noop, env_factory=None, writer_factory=No
 
 
 def train_batched(args, writer_factory=None, reporter=_noop):
-    """The same experiment for `args.n_envs` independent (env, agent) pairs in lockstep on one GPU.
+    """The same experiment for `args.n_envs` independent (env, agent) pairs in lockstep, on one GPU -- or, launched by
+    torch.distributed.run with one process per GPU, sharded over the GPUs of a node: rank r owns the contiguous env-id block
+    dist.shard_range gives it (the counter RNG is keyed by global env id, so the trajectories do not depend on the number of
+    ranks), nothing but the 16-word metrics vector crosses xGMI (one RCCL all-reduce per reporting period), rank 0 writes.
+    The shared-policy agents (ppo-*) would need a gradient all-reduce and stay single-GPU.
 
     Keeps train()'s cadence in units of lockstep steps: one "episode" = `max_iterations` steps (every env finishes at least
     one episode in that span), an evaluation (greedy, batched_default_eval) after every `eval_every` of them and once at
     the end; metrics are the aggregate meters (BatchMetrics) written under the reference's tensorboard tags. Supports the
     agents whose learning runs on the device: tabular-q (private tables), ppo-mlp / ppo-cnn (one shared policy; an
     "episode" is one PPO iteration = one episode per env + the epochs) and random."""
+    import os
+
+    from . import dist as sdist
     from .agents import BatchedTabularQAgent
     from .loops import batched_default_eval, batched_ppo_learn
-    from .metering import BatchMetrics
     from .ppo import BatchedPPOAgent
 
+    rank, local_rank, world = sdist.env_from_torchrun()
+    if world > 1:
+        if args.agent_alias in ("ppo-mlp", "ppo-cnn"):
+            raise KeyError("train_batched shards independent agents (tabular-q, random) over GPUs; %r shares one policy"
+                           % (args.agent_alias,))
+        sdist.init_process_group(os.environ.get("SGK_DIST_BACKEND"))  # nccl (= RCCL) unless the test knob says gloo
+    if os.environ.get("SGK_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0  # test knob: every rank on the one GPU of the box
+    begin, end = sdist.shard_range(args.n_envs, rank, world)
     env_name = ENV_MAP[args.env_alias]
-    writer = (writer_factory or _default_writer)(getattr(args, "log_dir", None))
+    writer = (writer_factory or _default_writer)(getattr(args, "log_dir", None)) if rank == 0 else NullWriter(None)
     for key, value in vars(args).items():
         writer.add_text("data/{}".format(key), str(value))
-    env = _envs.make(env_name, n_envs=args.n_envs, seed=args.seed or 0)
+    env = _envs.make(env_name, n_envs=end - begin, seed=args.seed or 0, device=local_rank, env_index_base=begin)
     horizon = int(env.info.max_iterations)
     if args.agent_alias == "tabular-q":
         agent = BatchedTabularQAgent(env, args)
@@ -186,14 +201,16 @@ def train_batched(args, writer_factory=None, reporter=_noop):
                 env.step_random(horizon, auto_reset=True)
             else:
                 agent.rollout(horizon, cheat=args.cheat)
-            bm = BatchMetrics(env.metrics())
+            bm = sdist.global_metrics(env)  # this shard's metrics, all-reduced over the ranks when there are several
         bm.write(writer, episode, prefix="Train/")
         if agent is not None and not ppo:
             writer.add_scalar("Train/epsilon", agent.epsilon, agent.t)
         reporter(hidden_reward=bm.meter("safeties")["avg"], obs_reward=bm.meter("returns")["avg"])
         if agent is not None and (episode % args.eval_every == args.eval_every - 1 or episode == args.episodes):
-            print("#### EVAL ####")
-            batched_default_eval(agent, env, args.eval_timesteps).write(writer, period, prefix="Evaluation/")
+            if rank == 0:
+                print("#### EVAL ####")
+            batched_default_eval(agent, env, args.eval_timesteps)
+            sdist.global_metrics(env).write(writer, period, prefix="Evaluation/")
             period += 1
             env.reset()
     return agent, env

@@ -735,3 +735,31 @@ def test_island_safety_side_information_and_reseeding():
     orc.rollout(70, seed=99, auto_reset=True)
     assert_same_state(b, orc, "after seed()")
     b.close()
+
+
+def test_train_batched_sharded_over_two_ranks_equals_one_rank(tmp_path):
+    """`python -m safe_grid_agents_amd -N ...` under torch.distributed.run with two ranks (both on this box's one GPU, gloo
+    collectives -- the knobs the multi-rank bench test uses) writes the same scalars as the single-process run: contiguous
+    env-id shards, RNG keyed by global env id, integer metrics all-reduced."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = ["-S", "3", "-E", "3", "-EE", "2", "-V", "120", "-N", "1501", "island", "tabular-q", "-l", ".5", "-e", "0.1", "-dl", "200"]
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "safe-grid-agents_amd") + os.pathsep + root)
+    one = str(tmp_path / "one")
+    subprocess.run([sys.executable, "-m", "safe_grid_agents_amd", "-L", one] + argv, check=True, env=env, cwd=root, timeout=600,
+                   stdout=subprocess.DEVNULL)
+    two = str(tmp_path / "two")
+    env2 = dict(env, SGK_DIST_BACKEND="gloo", SGK_BENCH_ONE_DEVICE="1")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29655", "-m", "safe_grid_agents_amd", "-L", two] + argv, check=True, env=env2, cwd=root,
+                   timeout=600, stdout=subprocess.DEVNULL)
+
+    def scalars(d):
+        files = [f for f in os.listdir(d) if f.startswith("events.out.tfevents.")]
+        assert len(files) == 1  # only rank 0 writes
+        return [(e["step"], e["tag"], e["value"]) for e in S.read_events(os.path.join(d, files[0])) if e["kind"] == "scalar"]
+
+    a, b = scalars(one), scalars(two)
+    assert len(a) > 20 and a == b
