@@ -153,8 +153,9 @@ def train_batched(args, writer_factory=None, reporter=_noop):
     Keeps train()'s cadence in units of lockstep steps: one "episode" = `max_iterations` steps (every env finishes at least
     one episode in that span), an evaluation (greedy, batched_default_eval) after every `eval_every` of them and once at
     the end; metrics are the aggregate meters (BatchMetrics) written under the reference's tensorboard tags. Supports the
-    agents whose learning runs on the device: tabular-q (private tables), ppo-mlp / ppo-cnn (one shared policy; an
-    "episode" is one PPO iteration = one episode per env + the epochs) and random."""
+    agents whose learning runs on the device: tabular-q (private tables), deep-q (one shared Q-network, one SGD step per
+    lockstep step), ppo-mlp / ppo-cnn (one shared policy; an "episode" is one PPO iteration = one episode per env + the
+    epochs) and random."""
     import os
 
     from . import dist as sdist
@@ -184,11 +185,25 @@ def train_batched(args, writer_factory=None, reporter=_noop):
 
         torch.manual_seed(args.seed or 0)
         agent = BatchedPPOAgent(env, args, body=args.agent_alias[4:])
+    elif args.agent_alias == "deep-q":
+        import torch
+
+        from .deepq_batched import BatchedDeepQAgent
+
+        if world > 1:
+            raise KeyError("train_batched shards independent agents over GPUs; deep-q shares one network")
+        torch.manual_seed(args.seed or 0)
+        # the replay holds whole lockstep slices: as many as cover the reference's capacity, at least 2
+        slices = max(2, -(-int(args.replay_capacity) // env.n_envs))
+        agent = BatchedDeepQAgent(env, args, sgd_steps=1, replay_slices=slices)
+        agent.warmup(slices)  # dqn_warmup (warmup.py:8-23): random-action transitions fill the replay
+        env.reset()
     elif args.agent_alias == "random":
         agent = None
     else:
-        raise KeyError("train_batched supports tabular-q, ppo-mlp, ppo-cnn and random, not %r" % (args.agent_alias,))
+        raise KeyError("train_batched supports tabular-q, deep-q, ppo-mlp, ppo-cnn and random, not %r" % (args.agent_alias,))
     ppo = isinstance(agent, BatchedPPOAgent)
+    deepq = args.agent_alias == "deep-q"
     history = {"writer": writer, "t": 0, "t_learn": 0}
     period = 0
     for episode in range(1, args.episodes + 1):
@@ -199,12 +214,17 @@ def train_batched(args, writer_factory=None, reporter=_noop):
             env.metrics_reset()
             if agent is None:
                 env.step_random(horizon, auto_reset=True)
+            elif deepq:
+                for _ in range(horizon):  # dqn_learn for every env: act_explore, step, replay add, one SGD step, epsilon, sync
+                    agent.step(learn=True, cheat=args.cheat)
             else:
                 agent.rollout(horizon, cheat=args.cheat)
             bm = sdist.global_metrics(env)  # this shard's metrics, all-reduced over the ranks when there are several
         bm.write(writer, episode, prefix="Train/")
         if agent is not None and not ppo:
             writer.add_scalar("Train/epsilon", agent.epsilon, agent.t)
+        if deepq and agent.last_loss is not None:
+            writer.add_scalar("Train/value_loss", float(agent.last_loss.reshape(-1)[0]), agent.t)
         reporter(hidden_reward=bm.meter("safeties")["avg"], obs_reward=bm.meter("returns")["avg"])
         if agent is not None and (episode % args.eval_every == args.eval_every - 1 or episode == args.episodes):
             if rank == 0:

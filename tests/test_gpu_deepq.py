@@ -353,3 +353,22 @@ def test_fused_dqn_sgd_step_equals_torch_autograd_adam(name, hidden, batch):
     assert (agent._fl["w2t"].cpu() == agent.Q[1][0][0].weight.data.t().cpu()).all()
     assert (agent._fw["w3t"].cpu() == agent.Q[2].weight.data.t().cpu()).all()
     env.close()
+
+
+def test_train_batched_cli_deepq():
+    """`python -m safe_grid_agents_amd -N 512 sokoban deep-q ...`: warm-up fills the slice replay, every lockstep step learns
+    (the fused SGD kernel), the evaluation is greedy through the fused rollout."""
+    args = S.prepare_parser().parse_args(["-S", "2", "-E", "2", "-EE", "2", "-V", "110", "-N", "512", "sokoban", "deep-q", "-l", "0.001",
+                                          "-r", "2000", "-s", "50", "-b", "32", "-dl", "300"])
+    writers = []
+
+    def wf(d):
+        writers.append(S.RecordingWriter(d))
+        return writers[-1]
+
+    agent, env = S.train_batched(args, writer_factory=wf)
+    assert isinstance(agent, S.BatchedDeepQAgent) and agent.fused_learn and agent.replay.slices == 4
+    tags = [c[1] for c in writers[0].calls]
+    assert tags.count("Train/returns") == 2 and "Train/value_loss" in tags and "Evaluation/returns" in tags
+    assert agent.t == 200 and int(agent._fl["step"].cpu()) == 200  # one SGD step per lockstep step
+    env.close()
