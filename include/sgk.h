@@ -256,6 +256,43 @@ typedef struct sgk_dqn_learner {
   double lr, beta1, beta2, eps, discount, max_grad_norm;
 } sgk_dqn_learner;
 SGK_API int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *learner);
+
+/* ---- PPOBaseAgent.learn (reference policy_base.py:64-131) for PPOMLPAgent's default topology as ONE kernel ---------- */
+/* All `n_epochs` minibatch updates of one learn() call: per epoch `batch` rows drawn uniformly with replacement from the
+ * (step, trajectory) pairs inside an episode (policy_base.py:77-80; counter RNG stream 5 keyed by the Adam step, or the
+ * caller's `rows`), current and old policy forward, advantages r - V(s) normalised over the minibatch, clipped surrogate
+ * + critic_coeff * mse_loss - entropy_bonus * entropy (policy_base.py:82-106; the advantage is NOT detached there, so the
+ * policy loss also back-propagates into the critic -- reproduced), backward, Adam (torch defaults) -- the
+ * Linear(n_cells, H)-ReLU-Linear(H, H)-ReLU trunk with Linear(H, 4) actor and Linear(H, 1) critic of policy_mlp.py:14-33,
+ * H = 100 (the reference default) or 64, 2 <= batch <= 64. All pointers are device pointers; float32.
+ *   rollout     states int8 [horizon][n_trajectories][n_cells], actions uint8 [horizon][n_trajectories],
+ *               returns float [n_trajectories][horizon], lengths int32 [n_trajectories] (sgk_policy_rollout's outputs)
+ *   w1..bc      the current network in torch layout ([out][in]), UPDATED IN PLACE;  w1t, w2t: transposed trunk copies the
+ *               kernel reads and keeps current
+ *   m, v        Adam's exp_avg / exp_avg_sq for w1, b1, w2, b2, wa, ba, wc, bc
+ *   ow1t, ow2t  the old policy's trunk weights transposed; ob1, ob2, owa ([4][H]), oba as they are (read only)
+ *   step        Adam's step counter (int64, device), advanced by n_epochs
+ *   stats_out   float [n_epochs][3]: policy loss, value loss, entropy of each epoch before its update; or NULL
+ *   rows        int64 [n_epochs][batch] rows step * n_trajectories + trajectory replacing the draws; or NULL
+ *   rows_out    int64 [n_epochs][batch] receives the rows each epoch used; or NULL
+ * fp32 with a different summation order than rocBLAS: equal to torch's updates to fp32 tolerance, not bit for bit. */
+typedef struct sgk_ppo_learner {
+  const int8_t *states;
+  const uint8_t *actions;
+  const float *returns;
+  const int32_t *lengths;
+  int32_t horizon, n_hidden, batch, n_epochs;
+  int64_t n_trajectories;
+  float *w1, *b1, *w2, *b2, *wa, *ba, *wc, *bc, *w1t, *w2t;
+  float *m[8], *v[8];
+  const float *ow1t, *ob1, *ow2t, *ob2, *owa, *oba;
+  int64_t *step;
+  float *stats_out;
+  const int64_t *rows;
+  int64_t *rows_out;
+  double lr, beta1, beta2, eps, clipping, critic_coeff, entropy_bonus;
+} sgk_ppo_learner;
+SGK_API int sgk_ppo_epochs(sgk_env *h, const sgk_ppo_learner *learner);
 /* ReplayBuffer.add for every env (reference contain.py:15-17 via value.py:114) into ring slice `slice` (or *slice_dev when
  * non-NULL, so that the call can be recorded in a graph) of rings laid out [slices][n_envs][...]: phase 0, called before
  * sgk_step, stores the current boards as the transitions' state; phase 1, called after it, stores the boards as successor

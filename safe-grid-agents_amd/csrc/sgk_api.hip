@@ -662,6 +662,39 @@ int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) {
   return SGK_OK;
 }
 
+int sgk_ppo_epochs(sgk_env *h, const sgk_ppo_learner *L) {
+  SGK_CHECK_HANDLE(h);
+  if (!L) return fail(SGK_ERR_INVALID, "learner is NULL");
+  const void *need[] = {L->states, L->actions, L->returns, L->lengths, L->w1, L->b1, L->w2, L->b2, L->wa, L->ba, L->wc, L->bc,
+                        L->w1t, L->w2t, L->ow1t, L->ob1, L->ow2t, L->ob2, L->owa, L->oba, L->step};
+  for (const void *p : need)
+    if (!p) return fail(SGK_ERR_INVALID, "NULL pointer in sgk_ppo_learner");
+  for (int i = 0; i < 8; ++i)
+    if (!L->m[i] || !L->v[i]) return fail(SGK_ERR_INVALID, "NULL Adam state in sgk_ppo_learner");
+  if ((L->n_hidden != 64 && L->n_hidden != 100) || L->batch < 2 || L->batch > 64 || L->n_epochs < 1 || L->horizon < 1 ||
+      L->n_trajectories < 1 || L->n_trajectories >= (1ll << 31))
+    return fail(SGK_ERR_INVALID, "sgk_ppo_epochs needs n_hidden 64 or 100 (the reference default), 2 <= batch <= 64, n_epochs >= 1, "
+                                 "horizon >= 1, 1 <= n_trajectories < 2^31");
+  if (sgk::ppo_epochs_lds_bytes(h->sh.n_cells, L->n_hidden) > 160u * 1024u)
+    return fail(SGK_ERR_INVALID, "this n_cells / n_hidden does not fit the 160 KB of LDS the kernel works in");
+  sgk::PpoLearner d;
+  d.states = L->states; d.actions = L->actions; d.returns = L->returns; d.lengths = L->lengths;
+  d.horizon = L->horizon; d.n_hidden = L->n_hidden; d.batch = L->batch; d.n_epochs = L->n_epochs;
+  d.n_trajectories = L->n_trajectories;
+  d.w1 = L->w1; d.b1 = L->b1; d.w2 = L->w2; d.b2 = L->b2; d.wa = L->wa; d.ba = L->ba; d.wc = L->wc; d.bc = L->bc;
+  d.w1t = L->w1t; d.w2t = L->w2t;
+  for (int i = 0; i < 8; ++i) { d.m[i] = L->m[i]; d.v[i] = L->v[i]; }
+  d.ow1t = L->ow1t; d.ob1 = L->ob1; d.ow2t = L->ow2t; d.ob2 = L->ob2; d.owa = L->owa; d.oba = L->oba;
+  d.step = reinterpret_cast<long long *>(L->step);
+  d.stats_out = L->stats_out;
+  d.rows = reinterpret_cast<const long long *>(L->rows);
+  d.rows_out = reinterpret_cast<long long *>(L->rows_out);
+  d.lr = L->lr; d.beta1 = L->beta1; d.beta2 = L->beta2; d.eps = L->eps;
+  d.clipping = L->clipping; d.critic_coeff = L->critic_coeff; d.entropy_bonus = L->entropy_bonus;
+  SGK_HIP(sgk::launch_ppo_epochs(h->sh, d, h->stream));
+  return SGK_OK;
+}
+
 int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const int32_t *lengths_dev, float *returns_dev,
                            int64_t n_trajectories, int32_t t_max, double discount) {
   SGK_CHECK_HANDLE(h);

@@ -80,6 +80,24 @@ hipError_t launch_replay_store(const Shard &sh, int phase, const uint8_t *action
                                hipStream_t st);
 size_t dqn_sgd_lds_bytes(int n_cells, int n_hidden);
 hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st);
+struct PpoLearner {
+  const int8_t *states;
+  const uint8_t *actions;
+  const float *returns;
+  const int32_t *lengths;
+  int horizon, n_hidden, batch, n_epochs;
+  int64_t n_trajectories;
+  float *w1, *b1, *w2, *b2, *wa, *ba, *wc, *bc, *w1t, *w2t;
+  float *m[8], *v[8];
+  const float *ow1t, *ob1, *ow2t, *ob2, *owa, *oba;
+  long long *step;
+  float *stats_out;
+  const long long *rows;
+  long long *rows_out;
+  double lr, beta1, beta2, eps, clipping, critic_coeff, entropy_bonus;
+};
+size_t ppo_epochs_lds_bytes(int n_cells, int n_hidden);
+hipError_t launch_ppo_epochs(const Shard &sh, const PpoLearner &P, hipStream_t st);
 hipError_t launch_discounted_returns(const Shard &sh, const float *rewards, const int32_t *lengths, const float *gamma_pow,
                                      float *returns, int64_t n, int t_max, hipStream_t st);
 hipError_t launch_render_rgb(const Shard &sh, uint8_t *dst, hipStream_t st);

@@ -467,6 +467,363 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PPOBaseAgent.learn (reference policy_base.py:64-131) for PPOMLPAgent's default topology, ALL epochs in one launch: per
+// epoch a minibatch of rows drawn with replacement from the gathered rollout, the current network (trunk, actor, critic)
+// and the old policy (trunk, actor) forward, the clipped surrogate with batch-normalised advantages, critic MSE and entropy
+// bonus, the backward pass (including the path of the policy loss into the critic through the normalised advantage, which
+// the reference's autograd graph has) and Adam. Same structure as dqn_sgd_kernel: one workgroup, activations in LDS, weight
+// matrices staged per phase, dense layers and weight gradients on fp32 MFMA.
+// ------------------------------------------------------------------------------------------------
+struct PpoArgs {
+  // rollout: states int8 [T][N][K0], actions uint8 [T][N], returns float [N][T], lengths int32 [N]
+  const int8_t *states;
+  const uint8_t *actions;
+  const float *returns;
+  const int32_t *lengths;
+  int32_t T;
+  int64_t N;
+  // current network (torch layouts), updated in place; transposed trunk copies kept current; Adam state per tensor
+  float *w1, *b1, *w2, *b2, *wa, *ba, *wc, *bc;  // wa [4][H], ba [4], wc [1][H], bc [1]
+  float *w1t, *w2t;
+  float *m[8], *v[8];  // order: w1, b1, w2, b2, wa, ba, wc, bc
+  // old policy: transposed trunk weights, actor as it is
+  const float *ow1t, *ob1, *ow2t, *ob2, *owa, *oba;
+  long long *step;   // Adam step counter (device); also the key of the minibatch draws
+  float *stats_out;  // [n_epochs][3]: policy loss, value loss, entropy; or null
+  const long long *rows;  // [n_epochs][batch] rows t * N + env to use instead of the random draws; or null
+  long long *rows_out;    // [n_epochs][batch] the rows each epoch used; or null
+  int32_t batch, n_epochs;
+  uint64_t seed;
+  float lr, beta1, beta2, eps, clipping, critic_coeff, entropy_bonus;
+};
+
+struct PpoLds {
+  float *A, *Bq, *C, *D, *ST, *wh, *owa, *b1, *b2, *ob1, *ob2, *bh, *oba, *out, *oout, *dout, *ret, *scratch;
+  int8_t *S;
+  int *act;
+};
+
+template <int KP, int H>
+__device__ __forceinline__ PpoLds carve_ppo(unsigned char *base) {
+  PpoLds L;
+  float *f = reinterpret_cast<float *>(base);
+  L.A = f; f += LB * H;      // current hidden 1
+  L.Bq = f; f += LB * H;     // current hidden 2
+  L.C = f; f += LB * H;      // old hidden 1, then dL/dh2
+  L.D = f; f += LB * H;      // old hidden 2, then dL/dh1
+  L.ST = f; f += H * H;      // the weight matrix of the running phase
+  L.wh = f; f += 8 * H;      // current heads: rows 0..3 actor, row 4 critic, rows 5..7 zero
+  L.owa = f; f += 4 * H;     // old actor
+  L.b1 = f; f += H;
+  L.b2 = f; f += H;
+  L.ob1 = f; f += H;
+  L.ob2 = f; f += H;
+  L.bh = f; f += 8;          // actor biases, critic bias, zeros
+  L.oba = f; f += 4;
+  L.out = f; f += LB * 8;    // current logits [0..3], value [4]
+  L.oout = f; f += LB * 4;   // old logits
+  L.dout = f; f += LB * 8;   // dL/d(logits, value), zero-padded to 8
+  L.ret = f; f += LB;
+  L.scratch = f; f += 32;
+  L.act = reinterpret_cast<int *>(f); f += LB;
+  L.S = reinterpret_cast<int8_t *>(f);
+  return L;
+}
+
+constexpr size_t ppo_lds_bytes(int KP, int H) {
+  return sizeof(float) * ((size_t)4 * LB * H + (size_t)H * H + 12 * H + 4 * H + 12 + LB * 8 + LB * 4 + LB * 8 + LB + 32 + LB) +
+         (size_t)LB * KP + 64;
+}
+
+// heads: out[b][o] = bh[o] + sum_k h[b][k] * wh[o][k] for o < NOUT (all LDS): one lane per (b, o)
+template <int NOUT, int OS>
+__device__ __forceinline__ void heads_forward(const float *h, int H, const float *wh, const float *bh, float *out) {
+  if (threadIdx.x < LB * NOUT) {
+    const int b = threadIdx.x / NOUT, o = threadIdx.x % NOUT;
+    float acc = bh[o];
+    for (int k0 = 0; k0 < H; k0 += 4) {
+      const f4 w = *reinterpret_cast<const f4 *>(wh + o * H + k0);
+      const f4 x = *reinterpret_cast<const f4 *>(h + b * H + k0);
+      acc = fmaf(x[0], w[0], acc);
+      acc = fmaf(x[1], w[1], acc);
+      acc = fmaf(x[2], w[2], acc);
+      acc = fmaf(x[3], w[3], acc);
+    }
+    out[b * OS + o] = acc;
+  }
+}
+
+__device__ __forceinline__ float adam_plain(float p, float &m, float &v, float g, const AdamCoef &c) {
+  m = m + (1.0f - c.beta1) * (g - m);
+  v = c.beta2 * v + (1.0f - c.beta2) * g * g;
+  return p - c.lr_bc1 * (m / (sqrtf(v) / c.bc2_sqrt + c.eps));
+}
+
+template <int K0, int H>
+__global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char learn_smem[];
+  constexpr int KP = (K0 + 3) & ~3;
+  const PpoLds L = carve_ppo<KP, H>(learn_smem);
+  const int t0 = threadIdx.x, B = a.batch;
+  constexpr int MT = (H + 15) / 16, KT1 = (K0 + 15) / 16;
+  constexpr int N2 = (MT * MT + LWG / 64 - 1) / (LWG / 64), N1 = (MT * KT1 + LWG / 64 - 1) / (LWG / 64);
+  const long long step0 = *a.step;
+  {
+    const int t = t0;
+  // the old policy does not change during the call: its small tensors are staged once
+  stage(L.owa, a.owa, 4 * H);
+  stage(L.ob1, a.ob1, H);
+  stage(L.ob2, a.ob2, H);
+  if (t < 4) L.oba[t] = a.oba[t];
+  for (int i = t; i < 3 * H; i += LWG) L.wh[5 * H + i] = 0.0f;  // rows 5..7 of the padded head matrix
+  if (t < 3) L.bh[5 + t] = 0.0f;
+  }
+
+  for (int epoch = 0; epoch < a.n_epochs; ++epoch) {
+    const long long step = step0 + epoch;  // Adam steps done before this epoch; keys the minibatch draws
+    // the lane id is re-derived through an opaque move every epoch: with a loop-invariant id the compiler hoists the ~100
+    // per-lane 64-bit addresses of the Adam phase out of the loop and keeps them live across it (261 VGPRs spilled)
+    int t = t0;
+    asm volatile("" : "+v"(t));
+    const int lane = t & 63, wave = t >> 6, col = lane & 15, grp = lane >> 4;
+    __syncthreads();                       // the previous epoch's update is complete before anything of it is re-read
+    // ---- minibatch: a row = a (t, env) pair inside that env's episode, uniform with replacement. Each sample tries 16
+    // candidates per round (16 lanes), the first valid one in lane order wins; another round only if all 16 miss. ----
+    {
+      const int b = t >> 4, c = t & 15;  // 64 samples x 16 candidate lanes
+      int tt = 0;
+      long long nn = 0;
+      bool found = a.rows != nullptr;
+      if (found && b < B) {
+        const long long row = a.rows[(long long)epoch * B + b];
+        tt = (int)(row / a.N);
+        nn = row - (long long)tt * a.N;
+      }
+      for (int round = 0; round < 64 && !found; ++round) {
+        uint32_t x[4];
+        philox4x32_10((uint32_t)(b * 16 + c), (uint32_t)round, (uint32_t)step, 5u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
+        const long long n_c = (long long)__umul64hi(((unsigned long long)x[0] << 32) | x[1], (unsigned long long)a.N);
+        const int t_c = (int)__umulhi(x[2], (uint32_t)a.T);
+        const bool ok = t_c < a.lengths[n_c];
+        const unsigned long long mask = __ballot(ok);
+        const unsigned int mine = (unsigned int)((mask >> (lane & 48)) & 0xffffull);  // this sample's 16 candidate lanes
+        if (mine) {
+          const int win = (lane & 48) + __ffs(mine) - 1;
+          tt = __shfl(t_c, win, 64);
+          nn = __shfl((int)n_c, win, 64);  // N < 2^31 (checked by the launcher)
+          found = true;
+        }
+      }
+      if (c == 0) {
+        const long long row = (long long)tt * a.N + nn;
+        L.act[b] = b < B ? (int)(a.actions[row] & 3) : 0;
+        L.ret[b] = b < B ? a.returns[nn * a.T + tt] : 0.0f;
+        reinterpret_cast<long long *>(L.dout)[b] = row;  // parked for the gather below (dout is rewritten later)
+        if (a.rows_out && b < B) a.rows_out[(long long)epoch * B + b] = row;
+      }
+    }
+    stage(L.ST, a.ow1t, K0 * H);
+    stage(L.wh, a.wa, 4 * H);
+    stage(L.wh + 4 * H, a.wc, H);
+    stage(L.b1, a.b1, H);
+    stage(L.b2, a.b2, H);
+    if (t < 4) L.bh[t] = a.ba[t];
+    if (t == 4) L.bh[4] = a.bc[0];
+    __syncthreads();
+    for (int i = t; i < LB * KP; i += LWG) {
+      const int b = i / KP, k = i - b * KP;
+      const long long row = reinterpret_cast<const long long *>(L.dout)[b];
+      L.S[i] = (b < B && k < K0) ? a.states[row * K0 + k] : (int8_t)0;
+    }
+    __syncthreads();
+    // ---- old policy, then current network, on the same states ----
+    dense_layer<K0, H>(L.S, KP, L.ST, L.ob1, L.C, true, nullptr);
+    __syncthreads();
+    stage(L.ST, a.ow2t, H * H);
+    __syncthreads();
+    dense_layer<H, H>(L.C, H, L.ST, L.ob2, L.D, true, nullptr);
+    __syncthreads();
+    heads_forward<4, 4>(L.D, H, L.owa, L.oba, L.oout);
+    stage(L.ST, a.w1t, K0 * H);
+    __syncthreads();
+    dense_layer<K0, H>(L.S, KP, L.ST, L.b1, L.A, true, nullptr);
+    __syncthreads();
+    stage(L.ST, a.w2t, H * H);
+    __syncthreads();
+    dense_layer<H, H>(L.A, H, L.ST, L.b2, L.Bq, true, nullptr);
+    __syncthreads();
+    heads_forward<5, 8>(L.Bq, H, L.wh, L.bh, L.out);
+    stage(L.ST, a.w2, H * H);  // W2 as it is, for the back-propagation
+    __syncthreads();
+    // ---- losses and dL/d(logits, value): the 64 samples are the 64 lanes of wave 0, batch statistics by wave reductions ----
+    if (wave == 0) {
+      const int b = lane;
+      const bool live = b < B;
+      const float invB = 1.0f / (float)B;
+      float l[4], lo[4], p[4], logp[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { l[k] = L.out[b * 8 + k]; lo[k] = L.oout[b * 4 + k]; }
+      const float v = L.out[b * 8 + 4], r = L.ret[b];
+      const int ac = L.act[b];
+      const float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3])), mxo = fmaxf(fmaxf(lo[0], lo[1]), fmaxf(lo[2], lo[3]));
+      const float lse = mx + logf(expf(l[0] - mx) + expf(l[1] - mx) + expf(l[2] - mx) + expf(l[3] - mx));
+      const float lseo = mxo + logf(expf(lo[0] - mxo) + expf(lo[1] - mxo) + expf(lo[2] - mxo) + expf(lo[3] - mxo));
+      float ent = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { logp[k] = l[k] - lse; p[k] = expf(logp[k]); ent -= p[k] * logp[k]; }
+      const float logp_a = ac == 0 ? logp[0] : ac == 1 ? logp[1] : ac == 2 ? logp[2] : logp[3];
+      const float lo_a = (ac == 0 ? lo[0] : ac == 1 ? lo[1] : ac == 2 ? lo[2] : lo[3]) - lseo;
+      const float ratio = expf(logp_a - lo_a);
+      // advantages normalised over the minibatch (unbiased std, as torch.std)
+      const float adv = live ? r - v : 0.0f;
+      const float mu = __ockl_wfred_add_f32(adv) * invB;
+      const float dev = live ? adv - mu : 0.0f;
+      const float sigma = sqrtf(__ockl_wfred_add_f32(dev * dev) / (float)(B - 1));
+      const float advn = dev / sigma;
+      const float lo_c = 1.0f - a.clipping, hi_c = 1.0f + a.clipping;
+      const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+      const float s1 = advn * ratio, s2 = advn * rc;
+      const float w1 = s1 < s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f), w2 = 1.0f - w1;  // torch.min's gradient: halves on a tie
+      const float inrange = (ratio >= lo_c && ratio <= hi_c) ? 1.0f : 0.0f;
+      const float g_advn = live ? -invB * (w1 * ratio + w2 * rc) : 0.0f;
+      const float g_ratio = live ? -invB * advn * (w1 + w2 * inrange) : 0.0f;
+      const float g_logp = g_ratio * ratio;
+      // back through the normalisation: dL/dadv_j = (g_j - mean g) / sigma - (adv_j - mu) * S / ((B - 1) sigma^3)
+      const float gbar = __ockl_wfred_add_f32(g_advn) * invB;
+      const float S = __ockl_wfred_add_f32(g_advn * dev);
+      const float g_adv = live ? (g_advn - gbar) / sigma - dev * S / ((float)(B - 1) * sigma * sigma * sigma) : 0.0f;
+      const float dv = live ? a.critic_coeff * 2.0f * (v - r) * invB - g_adv : 0.0f;
+      float dl[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float onehot = k == ac ? 1.0f : 0.0f;
+        dl[k] = live ? g_logp * (onehot - p[k]) + a.entropy_bonus * invB * p[k] * (logp[k] + ent) : 0.0f;
+      }
+      *reinterpret_cast<f4 *>(L.dout + b * 8) = (f4){dl[0], dl[1], dl[2], dl[3]};
+      *reinterpret_cast<f4 *>(L.dout + b * 8 + 4) = (f4){dv, 0.0f, 0.0f, 0.0f};
+      if (a.stats_out) {
+        const float pl = -__ockl_wfred_add_f32(live ? fminf(s1, s2) : 0.0f) * invB;
+        const float vl = __ockl_wfred_add_f32(live ? (v - r) * (v - r) : 0.0f) * invB;
+        const float en = __ockl_wfred_add_f32(live ? ent : 0.0f) * invB;
+        if (lane == 0) { a.stats_out[epoch * 3] = pl; a.stats_out[epoch * 3 + 1] = vl; a.stats_out[epoch * 3 + 2] = en; }
+      }
+    }
+    __syncthreads();
+    // ---- backward ----
+    dense_layer<8, H>(L.dout, 8, L.wh, nullptr, L.C, false, L.Bq);  // dL/dh2 = relu'(h2) * (dout W_heads) -> C
+    float gh[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                   // head weights: lane k < H owns column k of the five rows
+    float gbh = 0.0f;                                                // head biases: lanes H .. H + 4
+    if (t < H) {
+      for (int b = 0; b < LB; ++b) {
+        const float hv = L.Bq[b * H + t];
+#pragma unroll
+        for (int o = 0; o < 5; ++o) gh[o] = fmaf(L.dout[b * 8 + o], hv, gh[o]);
+      }
+    } else if (t < H + 5) {
+      for (int b = 0; b < LB; ++b) gbh += L.dout[b * 8 + (t - H)];
+    }
+    __syncthreads();
+    dense_layer<H, H>(L.C, H, L.ST, nullptr, L.D, false, L.A);  // dL/dh1 -> D
+    f4 gw2[N2];
+    float gb2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+      const int tile = wave + i * (LWG / 64);
+      gw2[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+      if (tile < MT * MT) gw2[i] = weight_grad_mfma(L.C, H, 16 * (tile / MT), L.A, H, 16 * (tile % MT), lane);
+    }
+    if (LWG - 1 - t < H)
+      for (int b = 0; b < LB; ++b) gb2 += L.C[b * H + (LWG - 1 - t)];
+    __syncthreads();
+    f4 gw1[N1];
+    float gb1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int tile = wave + i * (LWG / 64);
+      gw1[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+      if (tile < MT * KT1) gw1[i] = weight_grad_mfma(L.D, H, 16 * (tile / KT1), L.S, KP, 16 * (tile % KT1), lane);
+    }
+    if (LWG - 1 - t < H)
+      for (int b = 0; b < LB; ++b) gb1 += L.D[b * H + (LWG - 1 - t)];
+    // ---- Adam (torch defaults: no amsgrad, no gradient clipping) ----
+    if (t == 0) {
+      L.scratch[16] = a.lr / (float)(1.0 - pow((double)a.beta1, (double)(step + 1)));
+      L.scratch[17] = sqrtf((float)(1.0 - pow((double)a.beta2, (double)(step + 1))));
+    }
+    __syncthreads();
+    AdamCoef ac;
+    ac.lr_bc1 = L.scratch[16];
+    ac.bc2_sqrt = L.scratch[17];
+    ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
+    if (t < H) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int e = o * H + t;
+        float m = a.m[4][e], v = a.v[4][e];
+        a.wa[e] = adam_plain(a.wa[e], m, v, gh[o], ac);
+        a.m[4][e] = m; a.v[4][e] = v;
+      }
+      float m = a.m[6][t], v = a.v[6][t];
+      a.wc[t] = adam_plain(a.wc[t], m, v, gh[4], ac);
+      a.m[6][t] = m; a.v[6][t] = v;
+    } else if (t < H + 4) {
+      const int e = t - H;
+      float m = a.m[5][e], v = a.v[5][e];
+      a.ba[e] = adam_plain(a.ba[e], m, v, gbh, ac);
+      a.m[5][e] = m; a.v[5][e] = v;
+    } else if (t == H + 4) {
+      float m = a.m[7][0], v = a.v[7][0];
+      a.bc[0] = adam_plain(a.bc[0], m, v, gbh, ac);
+      a.m[7][0] = m; a.v[7][0] = v;
+    }
+    if (LWG - 1 - t < H) {
+      const int e = LWG - 1 - t;
+      float m = a.m[3][e], v = a.v[3][e];
+      a.b2[e] = adam_plain(a.b2[e], m, v, gb2, ac);
+      a.m[3][e] = m; a.v[3][e] = v;
+      m = a.m[1][e]; v = a.v[1][e];
+      a.b1[e] = adam_plain(a.b1[e], m, v, gb1, ac);
+      a.m[1][e] = m; a.v[1][e] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+      const int tile = wave + i * (LWG / 64);
+      const int j = 16 * (tile / MT) + 4 * grp, k = 16 * (tile % MT) + col;
+      if (tile < MT * MT && j < H && k < H) {
+        f4 nw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = (j + r) * H + k;
+          float m = a.m[2][e], v = a.v[2][e];
+          nw[r] = adam_plain(a.w2[e], m, v, gw2[i][r], ac);
+          a.w2[e] = nw[r]; a.m[2][e] = m; a.v[2][e] = v;
+        }
+        *reinterpret_cast<f4 *>(a.w2t + (size_t)k * H + j) = nw;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int tile = wave + i * (LWG / 64);
+      const int j = 16 * (tile / KT1) + 4 * grp, k = 16 * (tile % KT1) + col;
+      if (tile < MT * KT1 && j < H && k < K0) {
+        f4 nw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = (j + r) * K0 + k;
+          float m = a.m[0][e], v = a.v[0][e];
+          nw[r] = adam_plain(a.w1[e], m, v, gw1[i][r], ac);
+          a.w1[e] = nw[r]; a.m[0][e] = m; a.v[0][e] = v;
+        }
+        *reinterpret_cast<f4 *>(a.w1t + (size_t)k * H + j) = nw;
+      }
+    }
+    __threadfence();  // the next epoch stages these weights from global memory
+  }
+  __syncthreads();
+  if (t0 == 0) *a.step = step0 + a.n_epochs;
+}
+
 // ReplayBuffer.add for every env (reference contain.py:15-17, called from value.py:114): phase 0, before env.step, stores the
 // boards as the transitions' `state`; phase 1, after it, stores the boards as `successor` and the action / reward /
 // terminal flag from the step records. One launch per phase instead of seven tensor copies per lockstep step.
@@ -556,5 +913,54 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
 #undef SGK_SGD_LAUNCH
   return hipGetLastError();
 }
+
+size_t ppo_epochs_lds_bytes(int n_cells, int n_hidden) { return ppo_lds_bytes((n_cells + 3) & ~3, n_hidden); }
+
+hipError_t launch_ppo_epochs(const Shard &sh, const PpoLearner &P, hipStream_t st) {
+  (void)hipGetLastError();
+  if (P.batch < 2 || P.batch > LB || P.n_epochs < 1 || P.horizon < 1 || P.n_trajectories < 1 || P.n_trajectories >= (1ll << 31))
+    return hipErrorInvalidValue;
+  const size_t lds = ppo_epochs_lds_bytes(sh.n_cells, P.n_hidden);
+  if (lds > 160u * 1024u) return hipErrorInvalidValue;
+  PpoArgs a;
+  a.states = P.states; a.actions = P.actions; a.returns = P.returns; a.lengths = P.lengths;
+  a.T = P.horizon; a.N = P.n_trajectories;
+  a.w1 = P.w1; a.b1 = P.b1; a.w2 = P.w2; a.b2 = P.b2; a.wa = P.wa; a.ba = P.ba; a.wc = P.wc; a.bc = P.bc;
+  a.w1t = P.w1t; a.w2t = P.w2t;
+  for (int i = 0; i < 8; ++i) { a.m[i] = P.m[i]; a.v[i] = P.v[i]; }
+  a.ow1t = P.ow1t; a.ob1 = P.ob1; a.ow2t = P.ow2t; a.ob2 = P.ob2; a.owa = P.owa; a.oba = P.oba;
+  a.step = P.step; a.stats_out = P.stats_out; a.rows = P.rows; a.rows_out = P.rows_out;
+  a.batch = P.batch; a.n_epochs = P.n_epochs; a.seed = sh.seed;
+  a.lr = (float)P.lr; a.beta1 = (float)P.beta1; a.beta2 = (float)P.beta2; a.eps = (float)P.eps;
+  a.clipping = (float)P.clipping; a.critic_coeff = (float)P.critic_coeff; a.entropy_bonus = (float)P.entropy_bonus;
+#define SGK_PPO_LAUNCH(K0V, HV)                                                                                            \
+  do {                                                                                                                     \
+    static unsigned long long opted_in = 0;                                                                                \
+    if (!((opted_in >> (sh.device & 63)) & 1ull)) {                                                                        \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&ppo_epochs_kernel<K0V, HV>),                     \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+      if (ae != hipSuccess) return ae;                                                                                     \
+      opted_in |= 1ull << (sh.device & 63);                                                                                \
+    }                                                                                                                      \
+    ppo_epochs_kernel<K0V, HV><<<dim3(1), dim3(LWG), lds, st>>>(a);                                                        \
+  } while (0)
+#define SGK_PPO_LAUNCH_K(K0V)                                                                                              \
+  do {                                                                                                                     \
+    if (P.n_hidden == 100) SGK_PPO_LAUNCH(K0V, 100);                                                                       \
+    else if (P.n_hidden == 64) SGK_PPO_LAUNCH(K0V, 64);                                                                    \
+    else return hipErrorInvalidValue;                                                                                      \
+  } while (0)
+  switch (sh.n_cells) {
+  case 25: SGK_PPO_LAUNCH_K(25); break;
+  case 36: SGK_PPO_LAUNCH_K(36); break;
+  case 48: SGK_PPO_LAUNCH_K(48); break;
+  case 63: SGK_PPO_LAUNCH_K(63); break;
+  default: return hipErrorInvalidValue;
+  }
+#undef SGK_PPO_LAUNCH_K
+#undef SGK_PPO_LAUNCH
+  return hipGetLastError();
+}
+
 
 }  // namespace sgk

@@ -55,6 +55,17 @@ class SgkDqnLearner(ctypes.Structure):
                 + [(k, ctypes.c_double) for k in ("lr", "beta1", "beta2", "eps", "discount", "max_grad_norm")])
 
 
+class SgkPpoLearner(ctypes.Structure):
+    _V8 = ctypes.c_void_p * 8
+    _fields_ = ([(k, ctypes.c_void_p) for k in ("states", "actions", "returns", "lengths")]
+                + [(k, ctypes.c_int32) for k in ("horizon", "n_hidden", "batch", "n_epochs")]
+                + [("n_trajectories", ctypes.c_int64)]
+                + [(k, ctypes.c_void_p) for k in ("w1", "b1", "w2", "b2", "wa", "ba", "wc", "bc", "w1t", "w2t")]
+                + [("m", _V8), ("v", _V8)]
+                + [(k, ctypes.c_void_p) for k in ("ow1t", "ob1", "ow2t", "ob2", "owa", "oba", "step", "stats_out", "rows", "rows_out")]
+                + [(k, ctypes.c_double) for k in ("lr", "beta1", "beta2", "eps", "clipping", "critic_coeff", "entropy_bonus")])
+
+
 def build(force=False, verbose=False):
     """Compile libsgk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
@@ -102,6 +113,7 @@ _SIGNATURES = {
     "sgk_epsilon_greedy_ex": (ctypes.c_int, [_V, _V, ctypes.c_double, ctypes.c_uint64, _V, _V, _V]),
     "sgk_policy_act": (ctypes.c_int, [_V, ctypes.POINTER(SgkMlpWeights), ctypes.c_double, ctypes.c_uint64, _V, _V, _V, _V]),
     "sgk_dqn_sgd_step": (ctypes.c_int, [_V, ctypes.POINTER(SgkDqnLearner)]),
+    "sgk_ppo_epochs": (ctypes.c_int, [_V, ctypes.POINTER(SgkPpoLearner)]),
     "sgk_replay_store": (ctypes.c_int, [_V, ctypes.c_int32, _V, ctypes.c_int32, ctypes.c_int64, _V, _V, _V, _V, _V, _V]),
     "sgk_categorical_sample": (ctypes.c_int, [_V, _V, ctypes.c_uint64, _V, _V]),
     "sgk_policy_sample": (ctypes.c_int, [_V, ctypes.POINTER(SgkMlpWeights), ctypes.c_uint64, _V, _V, _V]),

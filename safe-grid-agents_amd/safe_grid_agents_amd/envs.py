@@ -378,6 +378,13 @@ class BatchedGridworldEnv:
             ptr(actions, (n_steps, n), "actions"), ptr(recs, (n_steps, n, 4), "recs")))
         self._sync_lib_to_torch()
 
+    def ppo_epochs(self, learner):
+        """All epochs of one PPO learn() call in ONE HIP launch (sgk_ppo_epochs); `learner` is a filled _lib.SgkPpoLearner
+        whose device pointers the caller keeps alive."""
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_ppo_epochs(self._h.ptr, ctypes.byref(learner)))
+        self._sync_lib_to_torch()
+
     def discounted_returns(self, rewards, discount, lengths=None, out=None):
         """PPOBaseAgent.get_discounted_returns (reference policy_base.py:179-186) for a batch: rewards float32
         [n_trajectories, T] on this GPU (lengths int32 [n_trajectories] optional) -> returns of the same shape, with the

@@ -272,6 +272,9 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         hidden = int(getattr(args, "n_hidden", 0))  # ppo-cnn has no such flag
         self.fused_policy = (body == "mlp" and int(args.n_layers) == 2 and hidden in (64, 100, 128) and self.action_n == 4
                              and env.n_cells in (25, 36, 48, 63))
+        # learn() as ONE launch (sgk_ppo_epochs) where that kernel applies; Adam's state then lives in self._pl
+        self.fused_learn = self.fused_policy and hidden in (64, 100) and 2 <= self.batch_size <= 64
+        self._pl = None
         if self.fused_policy:
             old = self.net.old_policy
             l1, l2, head = old.network[0][0], old.network[1][0][0], old.actor
@@ -376,11 +379,82 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
             self._epochs_on_device(rollout)
         return graph
 
+    def _own_tensors(self):
+        net = self.net
+        l1, l2 = net.network[0][0], net.network[1][0][0]
+        return [l1.weight.data, l1.bias.data, l2.weight.data, l2.bias.data, net.actor.weight.data, net.actor.bias.data,
+                net.critic.weight.data, net.critic.bias.data]
+
+    def _learn_fused(self, rollout, rows=None, rows_out=None):
+        """`epochs` updates by sgk_ppo_epochs: sampling, both forwards, loss, backward and Adam of every epoch in one
+        kernel. The transposed weight copies it reads are refreshed from the torch parameters first (four small copies), so
+        the parameters may be changed between calls by anything else."""
+        from . import _lib
+        import ctypes
+
+        own, old = self._own_tensors(), self.net.old_policy
+        if self._pl is None:
+            self._pl = {"m": [torch.zeros_like(p) for p in own], "v": [torch.zeros_like(p) for p in own],
+                        "w1t": torch.empty_like(own[0].t().contiguous()), "w2t": torch.empty_like(own[2]),
+                        "ow2t": torch.empty_like(own[2]), "step": torch.zeros(1, dtype=torch.int64, device=self.device)}
+        pl = self._pl
+        pl["w1t"].copy_(own[0].t())
+        pl["w2t"].copy_(own[2].t())
+        pl["ow2t"].copy_(old.network[1][0][0].weight.data.t())
+        self._refresh_fused_weights()
+        T, n = rollout.actions.shape
+        L = _lib.SgkPpoLearner()
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+        for t in (rollout.states, rollout.actions, rollout.returns, rollout.lengths):
+            assert t.is_cuda and t.is_contiguous()
+        assert rollout.states.dtype == torch.int8 and rollout.returns.dtype == torch.float32 and rollout.lengths.dtype == torch.int32
+        L.states, L.actions, L.returns, L.lengths = ptr(rollout.states), ptr(rollout.actions), ptr(rollout.returns), ptr(rollout.lengths)
+        L.horizon, L.n_hidden, L.batch, L.n_epochs, L.n_trajectories = T, own[1].numel(), self.batch_size, self.epochs, n
+        for k, t in zip(("w1", "b1", "w2", "b2", "wa", "ba", "wc", "bc"), own):
+            assert t.is_contiguous()
+            setattr(L, k, ptr(t))
+        L.w1t, L.w2t = ptr(pl["w1t"]), ptr(pl["w2t"])
+        for i in range(8):
+            L.m[i], L.v[i] = pl["m"][i].data_ptr(), pl["v"][i].data_ptr()
+        L.ow1t, L.ob1, L.ow2t, L.ob2 = ptr(self._fw["w1t"]), ptr(self._fw["b1"]), ptr(pl["ow2t"]), ptr(self._fw["b2"])
+        L.owa, L.oba = ptr(old.actor.weight.data), ptr(old.actor.bias.data)
+        L.step, L.stats_out = ptr(pl["step"]), ptr(self._stats)
+        keep = None
+        if rows is not None:  # one tensor of (t, env)-ordered valid-pair indices per epoch -> flat rows t * N + env
+            valid = torch.arange(T, device=self.device).unsqueeze(1) < rollout.lengths.unsqueeze(0)
+            t_ix, n_ix = valid.nonzero(as_tuple=True)
+            flat = t_ix * n + n_ix
+            keep = torch.stack([flat[torch.as_tensor(r, device=self.device)] for r in rows]).to(torch.int64).contiguous()
+            assert tuple(keep.shape) == (self.epochs, self.batch_size)
+            L.rows = ptr(keep)
+        if rows_out is not None:  # int64 [epochs, batch_size] on the device: receives the flat rows t * N + env used
+            assert rows_out.dtype == torch.int64 and rows_out.is_contiguous() and tuple(rows_out.shape) == (self.epochs, self.batch_size)
+            L.rows_out = ptr(rows_out)
+        g = self.net.optim.param_groups[0]
+        L.lr, (L.beta1, L.beta2), L.eps = float(g["lr"]), g["betas"], float(g["eps"])
+        L.clipping, L.critic_coeff, L.entropy_bonus = float(self.net.clipping), float(self.net.critic_coeff), float(self.net.entropy_bonus)
+        self.env.ppo_epochs(L)
+        return keep
+
+    def _log_stats(self, history):
+        stats = self._stats.cpu().numpy()
+        writer = history["writer"]
+        for epoch in range(self.epochs):  # the reference's three scalars per epoch (policy_base.py:108-119)
+            writer.add_scalar("Train/policy_loss", float(stats[epoch, 0]), history["t_learn"])
+            writer.add_scalar("Train/value_loss", float(stats[epoch, 1]), history["t_learn"])
+            writer.add_scalar("Train/policy_entropy", float(stats[epoch, 2]), history["t_learn"])
+            history["t_learn"] += 1
+
     def learn(self, rollout, history=None, rows=None):
         """`epochs` minibatch updates (reference policy_base.py:64-131) on a BatchedRollout; `rows` (one index tensor per
         epoch) replaces the random draws, for reproducing an update elsewhere. With graph_epochs (default) and the agent's
         own rollout buffers, the whole call is ONE hipGraph replay -- sampling, gathers, forward, backward and Adam of every
         epoch (~100 launches each) -- plus one read-back of the logged scalars when a history is given."""
+        if self.fused_learn:
+            self._learn_fused(rollout, rows)
+            if history is not None:
+                self._log_stats(history)
+            return history
         own = self._buffers is not None and rollout.states is self._buffers["states"]
         if rows is not None or not (self.graph_epochs and own):
             for epoch in range(self.epochs):
@@ -398,13 +472,7 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         else:
             self._graph.replay()
         if history is not None:
-            stats = self._stats.cpu().numpy()
-            writer = history["writer"]
-            for epoch in range(self.epochs):  # the reference's three scalars per epoch (policy_base.py:108-119)
-                writer.add_scalar("Train/policy_loss", float(stats[epoch, 0]), history["t_learn"])
-                writer.add_scalar("Train/value_loss", float(stats[epoch, 1]), history["t_learn"])
-                writer.add_scalar("Train/policy_entropy", float(stats[epoch, 2]), history["t_learn"])
-                history["t_learn"] += 1
+            self._log_stats(history)
         return history
 
     def sync(self):

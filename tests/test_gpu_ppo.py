@@ -173,6 +173,114 @@ def test_batched_ppo_update_equals_the_single_env_agents_update():
     env.close()
 
 
+@pytest.mark.parametrize("name,hidden,batch", [("IslandNavigation-v0", 100, 64), ("BoatRace-v0", 64, 48),
+                                               ("SideEffectsSokoban-v0", 100, 33), ("DistributionalShift-v0", 100, 64)])
+def test_fused_ppo_epochs_kernel_equals_the_single_env_agents_update(name, hidden, batch):
+    """sgk_ppo_epochs (every epoch of learn() in one kernel: both forwards, clipped surrogate with minibatch-normalised
+    advantages, critic MSE, entropy bonus, backward incl. the advantage's path into the critic, Adam) == PPOBaseAgent's
+    update on the same minibatch rows, computed by the golden-pinned CPU PPOMLPAgent with torch autograd + torch.optim.Adam.
+    The current network is perturbed away from the old policy so that ratios leave the clipping range. fp32 with a
+    different summation order: rtol 2e-3 / atol 2e-5 on the logged scalars and on every parameter after 5 Adam steps."""
+    import torch
+
+    torch.manual_seed(13)
+    n, epochs = 256, 5
+    env = S.BatchedGridworldEnv(name, n, seed=4)
+    env.bind_torch_stream()
+    kw = dict(lr=1e-3, batch_size=batch, epochs=epochs, n_hidden=hidden, entropy_bonus=0.02, critic_coeff=0.5, clipping=0.1)
+    agent = S.BatchedPPOAgent(env, _args(**kw))
+    assert agent.fused_learn
+    ro = agent.gather_rollout()
+    with torch.no_grad():
+        for k, p in agent.net.named_parameters():
+            if not k.startswith("old_policy."):
+                p.add_(0.05 * torch.randn_like(p))
+    cpu = S.PPOMLPAgent(env, _args(device="cpu", **kw))
+    cpu.load_state_dict({k: v.cpu() for k, v in agent.net.state_dict().items()})
+    lengths = ro.lengths.cpu().numpy()
+    T = ro.actions.shape[0]
+    t_ix, n_ix = np.nonzero(np.arange(T)[:, None] < lengths[None, :])
+    rng = np.random.RandomState(1)
+    rows = [rng.randint(0, t_ix.size, size=batch) for _ in range(epochs)]
+    w_gpu, w_cpu = S.RecordingWriter(), S.RecordingWriter()
+    agent.learn(ro, {"writer": w_gpu, "t": 0, "t_learn": 0}, rows=rows)
+    states, actions, returns = ro.states.cpu().numpy(), ro.actions.cpu().numpy(), ro.returns.cpu().numpy()
+    hist = {"writer": w_cpu, "t": 0, "t_learn": 0}
+    clipped = 0
+    for pick in rows:
+        t_sel, n_sel = t_ix[pick], n_ix[pick]
+        s = torch.as_tensor(states[t_sel, n_sel].astype(np.float32)).reshape((-1,) + tuple(env.observation_space.shape))
+        a = torch.as_tensor(actions[t_sel, n_sel].astype(np.int64))
+        with torch.no_grad():
+            ratio = torch.exp(torch.distributions.Categorical(logits=cpu(s)[0]).log_prob(a)
+                              - torch.distributions.Categorical(logits=cpu.old_policy(s)[0]).log_prob(a))
+            clipped += int(((ratio < 0.9) | (ratio > 1.1)).sum())
+        cpu._epoch(s, a, torch.as_tensor(returns[n_sel, t_sel]), hist)
+    assert clipped > 0  # the clamp branch of the gradient is exercised
+    got = [float.fromhex(c[2]) for c in w_gpu.calls]
+    want = [float.fromhex(c[2]) for c in w_cpu.calls]
+    assert [c[1] for c in w_gpu.calls] == [c[1] for c in w_cpu.calls] and len(got) == 3 * epochs
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-5)
+    for (k, v), (k2, v2) in zip(agent.net.state_dict().items(), cpu.state_dict().items()):
+        assert k == k2
+        np.testing.assert_allclose(v.cpu().numpy(), v2.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+    assert int(agent._pl["step"].item()) == epochs
+    # the transposed copies the kernel keeps are those of the updated weights
+    assert torch.equal(agent._pl["w1t"], agent.net.network[0][0].weight.data.t())
+    assert torch.equal(agent._pl["w2t"], agent.net.network[1][0][0].weight.data.t())
+    env.close()
+
+
+def test_fused_ppo_epochs_kernel_draws_valid_rows_uniformly():
+    """Without `rows` the kernel draws its minibatches itself (counter RNG stream 5 keyed by the Adam step): every drawn row
+    lies inside an episode, successive epochs and calls draw different rows, the draws are uniform over the valid
+    (step, env) pairs (an env is hit in proportion to its episode length), and feeding the reported rows back through `rows`
+    reproduces the update bit for bit."""
+    import torch
+
+    torch.manual_seed(2)
+    n, epochs, batch = 300, 40, 64
+    env = S.BatchedGridworldEnv("IslandNavigation-v0", n, seed=9)
+    env.bind_torch_stream()
+    agent = S.BatchedPPOAgent(env, _args(lr=1e-4, batch_size=batch, epochs=epochs, n_hidden=100))
+    ro = agent.gather_rollout()
+    T = ro.actions.shape[0]
+    lengths = ro.lengths.cpu().numpy().astype(np.int64)
+    start = {k: v.clone() for k, v in agent.net.state_dict().items()}
+    used = torch.zeros((epochs, batch), dtype=torch.int64, device=agent.device)
+    agent._learn_fused(ro, rows_out=used)
+    first = used.cpu().numpy().copy()
+    after_first = {k: v.clone() for k, v in agent.net.state_dict().items()}
+    t_sel, n_sel = first // n, first % n
+    assert (t_sel < lengths[n_sel]).all() and (t_sel >= 0).all()
+    assert len(np.unique(first)) > 0.5 * first.size  # ~1e4 valid pairs, 2 560 draws with replacement
+    agent._learn_fused(ro, rows_out=used)  # Adam step 40..79: another part of the stream
+    second = used.cpu().numpy().copy()
+    assert (second != first).mean() > 0.99
+    # uniform over valid pairs: envs in the longer half of the episodes get their share of the draws (binomial, 5 sigma)
+    both = np.concatenate([first.ravel(), second.ravel()])
+    long_envs = lengths >= np.median(lengths)
+    p = lengths[long_envs].sum() / lengths.sum()
+    hits = long_envs[both % n].sum()
+    assert abs(hits - p * both.size) < 5 * np.sqrt(both.size * p * (1 - p)), (hits, p * both.size)
+    # and within an env the step is uniform over its episode: mean of t / length is 1/2 - 1/(2 length) on average
+    frac = ((both // n) + 0.5) / lengths[both % n]
+    assert abs(frac.mean() - 0.5) < 5 * np.sqrt(1.0 / 12 / both.size)
+    # replay: same start, same rows through `rows` -> the same bits
+    agent.net.load_state_dict(start)
+    for k in ("m", "v"):
+        for t in agent._pl[k]:
+            t.zero_()
+    agent._pl["step"].zero_()
+    valid = np.arange(T)[:, None] < lengths[None, :]
+    index_of = np.full(T * n, -1, dtype=np.int64)
+    index_of[np.flatnonzero(valid.ravel())] = np.arange(int(valid.sum()))
+    agent._learn_fused(ro, rows=[index_of[r] for r in first])
+    for k, v in agent.net.state_dict().items():
+        assert torch.equal(v, after_first[k]), k
+    env.close()
+
+
 def test_batched_ppo_learns_boat_race():
     """30 PPO iterations on BoatRace with 2 048 envs (critic coefficient scaled down to the size of the returns): the mean
     observed return climbs from the random policy's -62 to well above zero (measured: +34 / +40 for two seeds)."""

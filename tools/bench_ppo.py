@@ -28,6 +28,34 @@ def run(name, n, body, hidden=100):
           f"one hipGraph {learn_ms[True]:.2f} ms", flush=True)
     env.close()
 
+def run_reference_batch(name, n, hidden=100, epochs=16):
+    """The reference's own minibatch size (batch-size 64, its default): learn() as ONE kernel (sgk_ppo_epochs) against the
+    same update as torch launches, eager and as one hipGraph."""
+    torch.manual_seed(0)
+    env = S.BatchedGridworldEnv(name, n, seed=5)
+    env.bind_torch_stream()
+    a = types.SimpleNamespace(discount=0.99, lr=1e-3, batch_size=64, rollouts=1, epochs=epochs, clipping=0.2, entropy_bonus=0.01,
+                              critic_coeff=1.0, n_layers=2, n_hidden=hidden, n_channels=5, device=0, log_gradients=False, cheat=False)
+    agent = S.BatchedPPOAgent(env, a)
+    ms = {}
+    for mode in ("eager", "graph", "kernel"):
+        agent.fused_learn = mode == "kernel"
+        agent.graph_epochs = mode != "eager"
+        for it in range(5):
+            ro = agent.gather_rollout()
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            agent.learn(ro)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            agent.sync()
+        ms[mode] = 1e3 * (t2 - t1)
+    print(f"{name} n={n} H={hidden}: learn ({epochs} epochs x 64 rows) eager {ms['eager']:.2f} ms, one hipGraph {ms['graph']:.2f} ms, "
+          f"sgk_ppo_epochs {ms['kernel']:.3f} ms ({1e3 * ms['kernel'] / epochs:.1f} us/epoch)", flush=True)
+    env.close()
+
+for name in ("BoatRace-v0", "SideEffectsSokoban-v0", "IslandNavigation-v0", "DistributionalShift-v0"):
+    run_reference_batch(name, 32768)
+run_reference_batch("BoatRace-v0", 32768, hidden=64)
+run_reference_batch("BoatRace-v0", 32768, epochs=1)
 for n in (4096, 32768, 262144):
     run("BoatRace-v0", n, "mlp")
 run("BoatRace-v0", 32768, "mlp", hidden=64)

@@ -1,3 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
-for i in 1 2 3; do timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -1; done
+mkdir -p gpurun_out
+timeout 900 python tools/bench_ppo.py 2>&1 | tee gpurun_out/bench_ppo.log | tail -40
