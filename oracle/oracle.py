@@ -69,6 +69,8 @@ def lib():
         L.orc_eps_greedy.restype = ctypes.c_int
         L.orc_minibatch_index.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
         L.orc_minibatch_index.restype = ctypes.c_int64
+        L.orc_ppo_row.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64]
+        L.orc_ppo_row.restype = ctypes.c_int64
         L.orc_categorical_sample.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
         L.orc_categorical_sample.restype = ctypes.c_int
         L.orc_discounted_returns.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
@@ -225,6 +227,13 @@ def minibatch_indices(seed, step, batch, total):
     """Flat replay indices the fused DeepQ learner samples for the SGD step that starts at Adam step `step`."""
     L = lib()
     return np.array([L.orc_minibatch_index(seed, b, step, total) for b in range(batch)], dtype=np.int64)
+
+
+def ppo_rows(seed, step, batch, lengths, horizon):
+    """Flat rollout rows t * N + env the fused PPO learner draws for the epoch that starts at Adam step `step`."""
+    L = lib()
+    ln = np.ascontiguousarray(lengths, dtype=np.int32)
+    return np.array([L.orc_ppo_row(seed, b, step, ln.ctypes.data, horizon, ln.size) for b in range(batch)], dtype=np.int64)
 
 
 def categorical_sample(logits, seed, env_begin, draw):

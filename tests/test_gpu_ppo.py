@@ -253,10 +253,13 @@ def test_fused_ppo_epochs_kernel_draws_valid_rows_uniformly():
     after_first = {k: v.clone() for k, v in agent.net.state_dict().items()}
     t_sel, n_sel = first // n, first % n
     assert (t_sel < lengths[n_sel]).all() and (t_sel >= 0).all()
+    for epoch in (0, 1, 17, epochs - 1):  # index work: bit-exact against the oracle's restatement of the draw
+        assert (first[epoch] == O.ppo_rows(9, epoch, batch, lengths, T)).all(), epoch
     assert len(np.unique(first)) > 0.5 * first.size  # ~1e4 valid pairs, 2 560 draws with replacement
     agent._learn_fused(ro, rows_out=used)  # Adam step 40..79: another part of the stream
     second = used.cpu().numpy().copy()
     assert (second != first).mean() > 0.99
+    assert (second[3] == O.ppo_rows(9, epochs + 3, batch, lengths, T)).all()
     # uniform over valid pairs: envs in the longer half of the episodes get their share of the draws (binomial, 5 sigma)
     both = np.concatenate([first.ravel(), second.ravel()])
     long_envs = lengths >= np.median(lengths)

@@ -3,6 +3,8 @@
 Env scenarios are derived by hand from the published rules restated in include/sgk_levels.h (PARITY UNPINNED vs the
 upstream env: the reference holds no env tests or fixtures).
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -199,6 +201,34 @@ def test_env_traces_are_frozen(golden_dir):
                 assert e.board(0).ravel().tolist() == tr["boards"][str(t)]
             if d:
                 e.reset(0)
+
+
+def test_ppo_row_draw_is_uniform_over_the_valid_pairs():
+    """orc_ppo_row (the PPO learner's minibatch draw, counter RNG stream 5): rows always inside an episode, an env hit in
+    proportion to its length, steps uniform within the episode, first candidate = a plain restatement in Python."""
+    lengths = np.array([3, 1, 5, 2, 10, 10, 7], dtype=np.int32)
+    T, n = 10, lengths.size
+    rows = np.concatenate([O.ppo_rows(21, step, 64, lengths, T) for step in range(150)])
+    t, e = rows // n, rows % n
+    assert (t < lengths[e]).all()
+    share = np.bincount(e, minlength=n) / rows.size
+    assert np.abs(share - lengths / lengths.sum()).max() < 5 * np.sqrt(0.25 / rows.size)
+    assert abs(((t + 0.5) / lengths[e]).mean() - 0.5) < 5 * np.sqrt(1 / 12 / rows.size)
+    # the candidate order, restated: ctr = {16 b + c, round, step, 5}, n from x0:x1, t from x2
+    L = O.lib()
+    out = (ctypes.c_uint32 * 4)()
+    for b, step in ((0, 0), (5, 3), (63, 149)):
+        want = None
+        for rnd in range(64):
+            for c in range(16):
+                ctr = (ctypes.c_uint32 * 4)(16 * b + c, rnd, step, 5)
+                key = (ctypes.c_uint32 * 2)(21, 0)
+                L.orc_philox4x32_10(ctr, key, out)
+                e_c = (((out[0] << 32) | out[1]) * n) >> 64
+                t_c = (out[2] * T) >> 32
+                if want is None and t_c < lengths[e_c]:
+                    want = t_c * n + e_c
+        assert O.ppo_rows(21, step, 64, lengths, T)[b] == want
 
 
 def test_render_rgb_palette():

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 900 python tools/bench_ppo.py 2>&1 | tee gpurun_out/bench_ppo.log | tail -40
+timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -15
