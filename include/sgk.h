@@ -45,6 +45,7 @@ extern "C" {
 /* flags for sgk_step / sgk_step_random / sgk_rollout_random */
 #define SGK_F_AUTO_RESET 1u /* an env whose episode ends is reset in the same step (after its episode is recorded) */
 #define SGK_F_NO_BOARDS 2u  /* do not materialise observation boards this call (they go stale until the next writing call) */
+#define SGK_F_MASK_FINISHED 4u /* sgk_policy_rollout: rows of states_out / actions_out of an env whose episode is over are zeros */
 
 /* board layouts (sgk_create_ex) */
 #define SGK_LAYOUT_PITCHED 0 /* env-major rows padded to a multiple of 16 B: one lane writes its row with 16-B stores */
@@ -320,7 +321,8 @@ SGK_API int sgk_policy_sample(sgk_env *h, const sgk_mlp_weights *w, uint64_t dra
  * in registers: the inner loop of PPOBaseAgent.gather_rollout (reference policy_base.py:142-163; mode 1, the old policy's
  * weights) or acting with a frozen Q-network (eval.py:33-36, warmup-style data collection; mode 0 with a fixed epsilon).
  * Step k draws with index draw_index0 + k, so the actions equal those of n_steps calls of sgk_policy_sample / sgk_policy_act
- * + sgk_step. flags: SGK_F_AUTO_RESET or 0 (finished envs idle, as gather_rollout's per-env episodes need). Optional
+ * + sgk_step. flags: SGK_F_AUTO_RESET or 0 (finished envs idle, as gather_rollout's per-env episodes need), optionally
+ * | SGK_F_MASK_FINISHED (an idle env's states_out / actions_out entries are written as zeros instead of its last board). Optional
  * trajectory outputs in device memory: states_out int8 [n_steps][n_envs][n_cells] (the board each action was chosen on),
  * actions_out uint8 [n_steps][n_envs], recs_out sgk_step_rec [n_steps][n_envs]. Episode arrays, metrics, state words, the
  * last step records and the boards are left as after the equivalent sequence of calls. */

@@ -607,7 +607,8 @@ int sgk_policy_rollout(sgk_env *h, const sgk_mlp_weights *w, int32_t mode, doubl
     return fail(SGK_ERR_INVALID, "sgk_policy_rollout is built for n_hidden in {64, 100 (the reference default), 128}");
   if (mode != 0 && mode != 1) return fail(SGK_ERR_INVALID, "mode must be 0 (epsilon-greedy) or 1 (categorical)");
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
-  if (flags & ~(uint32_t)SGK_F_AUTO_RESET) return fail(SGK_ERR_INVALID, "only SGK_F_AUTO_RESET is meaningful here");
+  if (flags & ~(uint32_t)(SGK_F_AUTO_RESET | SGK_F_MASK_FINISHED))
+    return fail(SGK_ERR_INVALID, "only SGK_F_AUTO_RESET and SGK_F_MASK_FINISHED are meaningful here");
   if (n_steps == 0) return SGK_OK;
   sgk::Shard &s = h->sh;
   sgk::PolicyWeights pw{w->w1t, w->b1, w->w2, w->b2, w->w3t, w->b3, w->n_hidden};

@@ -420,13 +420,25 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a)
         const int rows = (int)max((int64_t)0, min((int64_t)32, n - first));
         int8_t *dst = a.states_out + ((int64_t)k * n + first) * K0;
         const int8_t *src = tile + wave_env * K0;
-        if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+        // SGK_F_MASK_FINISHED: rows of envs whose episode is over (bit r = row r of this wave) are stored as zeros
+        const uint32_t over = (a.env.flags & SGK_F_MASK_FINISHED) ? (uint32_t)__ballot(owner && s.over) : 0u;
+        if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0 && over == 0u) {
           for (int i = lane; i < rows * K0 / 4; i += 64) reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
           for (int i = (rows * K0 / 4) * 4 + lane; i < rows * K0; i += 64) dst[i] = src[i];
+        } else if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+          for (int i = lane; i < rows * K0 / 4; i += 64) {
+            uint32_t v = reinterpret_cast<const uint32_t *>(src)[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if ((over >> ((4 * i + j) / K0)) & 1u) v &= ~(0xffu << (8 * j));
+            reinterpret_cast<uint32_t *>(dst)[i] = v;
+          }
+          for (int i = (rows * K0 / 4) * 4 + lane; i < rows * K0; i += 64) dst[i] = ((over >> (i / K0)) & 1u) ? (int8_t)0 : src[i];
         } else {
-          for (int i = lane; i < rows * K0; i += 64) dst[i] = src[i];
+          for (int i = lane; i < rows * K0; i += 64) dst[i] = ((over >> (i / K0)) & 1u) ? (int8_t)0 : src[i];
         }
       }
+      const bool was_over = (a.env.flags & SGK_F_MASK_FINISHED) && s.over;
       double u;
       uint32_t x2;
       draw_block<MODE>(a.env.env_base + (uint64_t)env, a.draw0 + (uint64_t)k, a.env.seed, u, x2);
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a)
       const int old_pos = s.pos, old_box = s.box;
       step_one<ENV>(R, a.env, env, valid, action, s, rec, acc);
       if (valid) {
-        if (a.actions_out) a.actions_out[(int64_t)k * n + env] = (uint8_t)action;
+        if (a.actions_out) a.actions_out[(int64_t)k * n + env] = was_over ? (uint8_t)0 : (uint8_t)action;
         if (a.recs_out) a.recs_out[(int64_t)k * n + env] = rec;
       }
       if (owner && (s.pos != old_pos || s.box != old_box)) {  // re-draw the cells this step changed (a reset included)

@@ -15,7 +15,7 @@ INCLUDE = os.path.join(os.path.dirname(_DIST), "include")
 
 SGK_OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE = -1, -2, -3, -4
-F_AUTO_RESET, F_NO_BOARDS = 1, 2
+F_AUTO_RESET, F_NO_BOARDS, F_MASK_FINISHED = 1, 2, 4
 LAYOUT_PITCHED, LAYOUT_COMPACT = 0, 1
 MEM_HOST_VISIBLE = 0x100
 BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN, DISTRIBUTIONAL_SHIFT = 0, 1, 2, 3

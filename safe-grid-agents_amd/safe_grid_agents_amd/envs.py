@@ -356,11 +356,12 @@ class BatchedGridworldEnv:
         return out
 
     def policy_rollout(self, weights, n_steps, mode="sample", epsilon=0.0, draw_index0=0, auto_reset=False, states=None,
-                       actions=None, recs=None):
+                       actions=None, recs=None, mask_finished=False):
         """n_steps of {MLP forward, action draw, env.step} in ONE HIP launch (sgk_policy_rollout): `weights` as for
         policy_act / policy_sample; mode "sample" = Categorical(logits) (PPO), "greedy" = epsilon-greedy with a fixed
         epsilon (DeepQ acting with frozen weights). Optional device outputs: states int8 [n_steps, N, cells] (the board
-        each action was chosen on), actions uint8 [n_steps, N], recs int8 [n_steps, N, 4]."""
+        each action was chosen on), actions uint8 [n_steps, N], recs int8 [n_steps, N, 4]; with mask_finished the states /
+        actions entries of an env whose episode is over are zeros (it idles when auto_reset is off)."""
         w = _lib.SgkMlpWeights(*(ctypes.c_void_p(weights[k].data_ptr()) for k in ("w1t", "b1", "w2", "b2", "w3t", "b3")),
                                int(weights["b1"].numel()))
 
@@ -374,7 +375,8 @@ class BatchedGridworldEnv:
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_policy_rollout(
             self._h.ptr, ctypes.byref(w), {"greedy": 0, "sample": 1}[mode], float(epsilon), int(draw_index0), int(n_steps),
-            _lib.F_AUTO_RESET if auto_reset else 0, ptr(states, (n_steps, n, self.n_cells), "states"),
+            (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_MASK_FINISHED if mask_finished else 0),
+            ptr(states, (n_steps, n, self.n_cells), "states"),
             ptr(actions, (n_steps, n), "actions"), ptr(recs, (n_steps, n, 4), "recs")))
         self._sync_lib_to_torch()
 

@@ -233,7 +233,7 @@ def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None, buf
     if fused is not None:
         weights, draw0 = fused()
         env.policy_rollout(weights, T, mode="sample", draw_index0=draw0, auto_reset=False, states=states, actions=actions,
-                           recs=recs)
+                           recs=recs, mask_finished=True)  # entries past an episode's end are stored as zeros by the kernel
     else:
         record = env._device_views()["rec"]
         direct = bool(getattr(policy, "writes_out", False))  # policy(boards, out=row) stores its actions itself
@@ -249,12 +249,14 @@ def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None, buf
     # a finished env idles: its later records read (0, 0, done, .), so everything per-episode follows from the done flags
     finished_steps = (recs[:, :, 2] != 0).sum(0, dtype=torch.int32)  # done stays set from the last step of the episode on
     lengths.copy_(torch.clamp(T - finished_steps + 1, max=T))
-    live = torch.arange(T, device=dev).unsqueeze(1) < lengths.unsqueeze(0)  # [T, N]
     rewards.copy_(recs[:, :, 1 if cheat else 0].t())
-    if cheat:
-        actions.copy_(recs[:, :, 3].view(torch.uint8))
-    actions.mul_(live)
-    states.mul_(live.unsqueeze(2))
+    if cheat or fused is None:
+        live = torch.arange(T, device=dev).unsqueeze(1) < lengths.unsqueeze(0)  # [T, N]
+        if cheat:
+            actions.copy_(recs[:, :, 3].view(torch.uint8))
+        actions.mul_(live)
+        if fused is None:
+            states.mul_(live.unsqueeze(2))
     returns.zero_()
     env.discounted_returns(rewards, discount, lengths=lengths, out=returns)
     env.reset()
