@@ -214,7 +214,8 @@ def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None, buf
     """PPOBaseAgent.gather_rollout (reference policy_base.py:133-177) with one rollout = one episode PER ENV, all envs in
     lockstep: `policy(boards) -> uint8 actions [N]` acts on the int8 board view (a policy with the attribute
     `writes_out = True` is called as policy(boards, out=row) instead; one with `fused_rollout() -> (weights, draw0)` hands
-    the whole loop to sgk_policy_rollout, one launch), finished envs idle until the horizon, and
+    the whole loop to sgk_policy_rollout, one launch; one with `run_steps()` runs the T steps itself into `buffers`, e.g. by
+    replaying a recorded hipGraph), finished envs idle until the horizon, and
     the discounted returns come from the bit-exact batched kernel (policy_base.py:179-186). Everything stays in HBM.
 
     Returns BatchedRollout(states int8 [T, N, cells], actions uint8 [T, N], rewards float32 [N, T], returns float32 [N, T],
@@ -234,6 +235,8 @@ def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None, buf
         weights, draw0 = fused()
         env.policy_rollout(weights, T, mode="sample", draw_index0=draw0, auto_reset=False, states=states, actions=actions,
                            recs=recs, mask_finished=True)  # entries past an episode's end are stored as zeros by the kernel
+    elif getattr(policy, "run_steps", None) is not None:  # the policy runs the T steps itself (a recorded hipGraph)
+        policy.run_steps()
     else:
         record = env._device_views()["rec"]
         direct = bool(getattr(policy, "writes_out", False))  # policy(boards, out=row) stores its actions itself

@@ -284,6 +284,41 @@ def test_fused_ppo_epochs_kernel_draws_valid_rows_uniformly():
     env.close()
 
 
+@pytest.mark.parametrize("body,hidden", [("cnn", 0), ("mlp", 48)])
+def test_graph_replayed_gather_equals_the_eager_step_loop(body, hidden):
+    """Bodies without a fused kernel (ppo-cnn, other MLP widths): from the second rollout on the T lockstep steps are one
+    hipGraph replay. Same draws (the index advances in device memory), same kernels: rollouts, env state and metrics equal
+    the eager loop's bit for bit over three consecutive rollouts."""
+    import torch
+
+    n = 300
+    results = []
+    for graphed in (False, True):
+        torch.manual_seed(4)
+        env = S.BatchedGridworldEnv("IslandNavigation-v0", n, seed=12)
+        env.bind_torch_stream()
+        agent = S.BatchedPPOAgent(env, _args(n_hidden=hidden, n_channels=4, discount=0.9), body=body)
+        assert not agent.fused_policy
+        agent.graph_gather = graphed
+        env.metrics_reset()
+        out = []
+        for _ in range(3):
+            ro = agent.gather_rollout()
+            out.append([x.cpu().numpy().copy() for x in ro])
+        assert (agent._gather_graph is not None) == graphed
+        results.append({"ro": out, "metrics": np.asarray(env.metrics()).copy(), "draws": agent.draws,
+                        "state": {k: v.copy() for k, v in env.episode_state_host().items()}})
+        env.close()
+    a, b = results
+    assert a["draws"] == b["draws"] == 300
+    for ra, rb in zip(a["ro"], b["ro"]):
+        for x, y, what in zip(ra, rb, ("states", "actions", "rewards", "returns", "lengths")):
+            assert (x.view(np.uint8) == y.view(np.uint8)).all(), what
+    assert (a["metrics"] == b["metrics"]).all()
+    for key in a["state"]:
+        assert (a["state"][key] == b["state"][key]).all(), key
+
+
 def test_batched_ppo_learns_boat_race():
     """30 PPO iterations on BoatRace with 2 048 envs (critic coefficient scaled down to the size of the returns): the mean
     observed return climbs from the random policy's -62 to well above zero (measured: +34 / +40 for two seeds)."""

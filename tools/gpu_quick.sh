@@ -1,5 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_ppo.py tests/test_gpu_deepq.py -q -m gpu -p no:cacheprovider -x 2>&1 | tail -8
-timeout 900 python tools/bench_ppo.py 2>&1 | tee gpurun_out/bench_ppo.log | grep "body=mlp"
+timeout 900 python tools/bench_ppo.py 2>&1 | tee gpurun_out/bench_ppo.log | grep "unfused"
