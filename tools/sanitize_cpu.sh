@@ -18,6 +18,7 @@ void orc_tabq_rollout(void*, void**, int64_t, uint64_t, uint64_t, int64_t, int, 
 void orc_discounted_returns(const float*, int, double, float*);
 int orc_render_rgb(const void*, uint8_t*);
 int orc_categorical_sample(const float*, uint64_t, uint64_t, uint64_t, double*);
+int64_t orc_ppo_row(uint64_t, uint64_t, uint64_t, const int32_t*, int32_t, int64_t);
 int main(void) {
   for (int env = 0; env < 4; ++env) {
     int64_t n = 97; size_t sz = orc_sizeof();
@@ -40,6 +41,9 @@ int main(void) {
   float lg[4] = {0.5f, -1.0f, 2.0f, 0.0f}; double margin; int hist[4] = {0, 0, 0, 0};
   for (int i = 0; i < 1000; ++i) hist[orc_categorical_sample(lg, 7, (uint64_t)i, 3, &margin)]++;
   printf("categorical draws %d %d %d %d, clean\n", hist[0], hist[1], hist[2], hist[3]);
+  int32_t lengths[5] = {1, 100, 3, 40, 7}; long long rows = 0;
+  for (int b = 0; b < 64; ++b) for (int step = 0; step < 50; ++step) rows += orc_ppo_row(9, (uint64_t)b, (uint64_t)step, lengths, 100, 5);
+  printf("ppo rows checksum %lld, clean\n", rows);
   return 0;
 }
 C
