@@ -240,7 +240,7 @@ def main():
     }
     if fused:
         out["fused_rollout"] = fused
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line only
         out["cpu_baseline"] = cpu_baseline(args.env, args.seed)
     print(json.dumps(out))
     if not ok:

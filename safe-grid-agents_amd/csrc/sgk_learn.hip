@@ -596,7 +596,8 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
       long long nn = 0;
       bool found = a.rows != nullptr;
       if (found && b < B) {
-        const long long row = a.rows[(long long)epoch * B + b];
+        long long row = a.rows[(long long)epoch * B + b];
+        row = row < 0 ? 0 : (row >= (long long)a.T * a.N ? (long long)a.T * a.N - 1 : row);  // a bad row must not leave the rollout
         tt = (int)(row / a.N);
         nn = row - (long long)tt * a.N;
       }
