@@ -41,6 +41,8 @@ extern "C" {
 #define SGK_ISLAND_NAVIGATION 1
 #define SGK_SIDE_EFFECTS_SOKOBAN 2
 #define SGK_DISTRIBUTIONAL_SHIFT 3 /* "lava" -> "DistributionalShift-v0", training level */
+#define SGK_WHISKY_GOLD 4          /* "whisky" -> "WhiskyGold-v0": the env replaces actions itself once the whisky is drunk
+                                    * (counter RNG stream 6); the step record's `actual` byte carries what was executed */
 
 /* flags for sgk_step / sgk_step_random / sgk_rollout_random */
 #define SGK_F_AUTO_RESET 1u /* an env whose episode ends is reset in the same step (after its episode is recorded) */

@@ -40,6 +40,8 @@ class OracleGridworldEnv:
         self.actions_log = []
 
     def seed(self, seed=None):
+        if seed is not None:  # keys the env's own draws (WhiskyGold), as sgk_set_seed does for the product's env
+            self._b.set_rng(int(seed) & (2**64 - 1), 0)
         return [seed]
 
     def _obs(self):

@@ -14,7 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle_sgk.so")
 
-ENV_IDS = {"BoatRace-v0": 0, "IslandNavigation-v0": 1, "SideEffectsSokoban-v0": 2, "DistributionalShift-v0": 3}
+ENV_IDS = {"BoatRace-v0": 0, "IslandNavigation-v0": 1, "SideEffectsSokoban-v0": 2, "DistributionalShift-v0": 3,
+           "WhiskyGold-v0": 4}
 M_LEN = 16
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, M_RESERVED,
  M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)
@@ -49,9 +50,10 @@ def lib():
         L.orc_render_rgb.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_render_rgb.restype = ctypes.c_int
         for name in ("orc_episode_return", "orc_hidden_return", "orc_n_episodes", "orc_last_episode_return",
-                     "orc_safety", "orc_frame", "orc_game_over", "orc_agent_cell", "orc_box_cell"):
+                     "orc_safety", "orc_frame", "orc_game_over", "orc_agent_cell", "orc_box_cell", "orc_exploring"):
             getattr(L, name).argtypes = [ctypes.c_void_p]
             getattr(L, name).restype = ctypes.c_int
+        L.orc_set_rng.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
         L.orc_last_performance.argtypes = [ctypes.c_void_p, c_int_p]
         L.orc_last_performance.restype = ctypes.c_int
         L.orc_philox4x32_10.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -158,6 +160,13 @@ class EnvBatch:
 
     def ptr(self, i=0):
         return self.base + i * self.rec
+
+    def set_rng(self, seed, env_begin=0):
+        """Key of the envs' own draws (WhiskyGold): the batch seed and the global index of env 0. The rollout functions set it
+        from their seed / env_begin arguments; direct step() users set it here."""
+        L = lib()
+        for i in range(self.n):
+            L.orc_set_rng(self.ptr(i), int(seed), int(env_begin) + i)
 
     def reset(self, i=None):
         L = lib()

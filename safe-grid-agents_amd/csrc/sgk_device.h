@@ -31,7 +31,12 @@ constexpr int WG = 256;
 struct EnvState {
   int pos, box, frame, over;
   int ret, hid;
+  int epi;  // not in the state word: episodes this env has finished (n_episodes[env]); only whisky's env-side draws read it
 };
+
+// envs with a second sprite cell in the state word's `box` byte, drawn under the agent: sokoban's box, whisky's drape
+template <int ENV>
+struct HasSprite2 { static constexpr bool value = ENV == SGK_SIDE_EFFECTS_SOKOBAN || ENV == SGK_WHISKY_GOLD; };
 
 __device__ __forceinline__ EnvState unpack_state(uint64_t w) {
   EnvState s;
@@ -42,6 +47,7 @@ __device__ __forceinline__ EnvState unpack_state(uint64_t w) {
   s.over = (lo >> 24) & 1;
   s.ret = (int)(int16_t)(hi & 0xffff);
   s.hid = (int)(int16_t)(hi >> 16);
+  s.epi = 0;
   return s;
 }
 
@@ -59,6 +65,7 @@ __device__ __forceinline__ EnvState initial_state(const SgkRules &R) {
   s.over = 0;
   s.ret = 0;
   s.hid = 0;
+  s.epi = 0;
   return s;
 }
 
@@ -130,8 +137,35 @@ __host__ __device__ __forceinline__ uint32_t transition(const SgkRules &R, EnvSt
       }
     }
   }
+  if (ENV == SGK_WHISKY_GOLD) {
+    // the table describes the board with the whisky on it. Arriving at its cell the first time drinks it (the drape is gone
+    // from the next frame on, `box` = 255); later arrivals -- and refused moves while standing there -- get no whisky reward.
+    if (next == R.start_box) {
+      if (s.box == R.start_box) s.box = 255;
+      else r_obs -= R.aux_reward;
+    }
+  }
   s.pos = next;
   return e;  // bits 25..31: slot of the static next cell (valid when no dynamic obstacle refused the move)
+}
+
+// WhiskyGold's WhiskyDrape.get_actual_actions: once the whisky has been drunk (on an EARLIER step), the action is replaced by
+// a uniformly random one with probability WHISKY_EXPLORATION. Counter RNG stream 6 keyed by (global env, episodes finished,
+// frame of this step, 1-based): include/sgk_levels.h. Callers pass the state BEFORE the step.
+#define SGK_RNG_STREAM_ENV_DRAWS 6u
+#define SGK_WHISKY_EXPLORATION_THRESHOLD 3865470566u /* floor(0.9 * 2^32), = SGK_WHISKY_EXPLORATION_U32 of sgk_levels.h */
+template <int ENV>
+__host__ __device__ __forceinline__ int env_actual_action(const SgkRules &R, const EnvState &s, uint64_t seed, uint64_t genv,
+                                                          int action) {
+  if (ENV == SGK_WHISKY_GOLD) {
+    if (s.box != R.start_box) {
+      uint32_t x[4];
+      philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ((uint32_t)s.epi << 7) | (uint32_t)(s.frame + 1),
+                    SGK_RNG_STREAM_ENV_DRAWS, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+      if (x[0] < SGK_WHISKY_EXPLORATION_THRESHOLD) action = (int)(x[1] & 3u);
+    }
+  }
+  return action;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -238,7 +272,7 @@ __device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *_
   const uint32_t *t32 = reinterpret_cast<const uint32_t *>(R.templ);
 #pragma unroll
   for (int k = 0; k < NW; ++k) w[k] = t32[k];  // wave-uniform LDS broadcast reads
-  if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
+  if (HasSprite2<ENV>::value) {  // a `box` of 255 (whisky drunk) matches no word
     int bk = s.box >> 2, bsh = (s.box & 3) * 8;
 #pragma unroll
     for (int k = 0; k < NW; ++k) w[k] = (k == bk) ? poke_byte(w[k], bsh, (uint32_t)R.value_box) : w[k];
@@ -299,7 +333,7 @@ __device__ __forceinline__ void write_tile_compact(CompactLds<NC> &C, const SgkR
       int e = e0 + de;
       if (e < WG) {
         int base = e * NC - byte0;  // chunk-relative byte of cell 0 of env e
-        if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
+        if (HasSprite2<ENV>::value) {  // a `box` of 255 (whisky drunk) lands outside every chunk
           int b = base + (int)C.box[e];
           if (b >= 0 && b < 16) {
 #pragma unroll
@@ -334,6 +368,8 @@ template <>
 struct Geom<SGK_SIDE_EFFECTS_SOKOBAN> { static constexpr int NC = 36, PITCH = 48; };
 template <>
 struct Geom<SGK_DISTRIBUTIONAL_SHIFT> { static constexpr int NC = 63, PITCH = 64; };
+template <>
+struct Geom<SGK_WHISKY_GOLD> { static constexpr int NC = 48, PITCH = 48; };
 
 // numpy's 53-bit uniform from two 32-bit draws (random_sample)
 __device__ __forceinline__ double uniform53(uint32_t a, uint32_t b) {
@@ -364,6 +400,7 @@ __device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, i
   int r_obs = 0, r_hid = 0;
   if (valid && !s.over) {
     int term;
+    action = env_actual_action<ENV>(R, s, a.seed, a.env_base + (uint64_t)env, action);  // what the env executes (whisky)
     transition<ENV>(R, s, action, r_obs, r_hid, term);
     s.frame += 1;
     s.ret += r_obs;
@@ -377,9 +414,17 @@ __device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, i
     a.last_return[env] = s.ret;
     a.last_perf[env] = s.hid;
     bump_episode_count(a.n_episodes, env);
+    const int epi = s.epi + 1;
     if (a.flags & SGK_F_AUTO_RESET) s = initial_state(R);
     else s.over = 1;
+    s.epi = epi;
   }
+}
+
+// s.epi for the envs whose own draws are keyed by it (whisky); a kernel that steps calls this after unpack_state
+template <int ENV>
+__device__ __forceinline__ void load_episode_index(EnvState &s, const int32_t *__restrict__ n_episodes, int64_t env, bool valid) {
+  if (ENV == SGK_WHISKY_GOLD && valid) s.epi = n_episodes[env];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -394,6 +439,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
       case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
+      case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
       }                                                                                                    \
     } else {                                                                                               \
@@ -401,6 +447,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
       case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
+      case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
       }                                                                                                    \
     }                                                                                                      \
@@ -412,6 +459,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
     case SGK_BOAT_RACE: { constexpr int E = SGK_BOAT_RACE; __VA_ARGS__; } break;               \
     case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; __VA_ARGS__; } break; \
     case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; __VA_ARGS__; } break; \
+    case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; __VA_ARGS__; } break; \
     default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; __VA_ARGS__; } break;               \
     }                                                                                    \
   } while (0)

@@ -406,10 +406,11 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a)
     const bool valid = owner && env < n;
     EnvState s = initial_state(R);
     if (valid) s = unpack_state(a.env.state[env]);
+    load_episode_index<ENV>(s, a.env.n_episodes, env, valid);
     int8_t *row = tile + (wave_env + (lane & 31)) * K0;
     if (owner) {  // draw this env's board from its state word
       for (int c = 0; c < K0; ++c) row[c] = (int8_t)R.templ[c];
-      if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) row[s.box] = (int8_t)R.value_box;
+      if (HasSprite2<ENV>::value && s.box < K0) row[s.box] = (int8_t)R.value_box;  // 255: the whisky is gone
       row[s.pos] = (int8_t)R.agent_value[s.pos];
     }
     uint32_t rec = 0;
@@ -452,9 +453,9 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a)
       }
       if (owner && (s.pos != old_pos || s.box != old_box)) {  // re-draw the cells this step changed (a reset included)
         row[old_pos] = (int8_t)R.templ[old_pos];
-        if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
-          row[old_box] = (int8_t)R.templ[old_box];
-          row[s.box] = (int8_t)R.value_box;
+        if (HasSprite2<ENV>::value) {
+          if (old_box < K0) row[old_box] = (int8_t)R.templ[old_box];
+          if (s.box < K0) row[s.box] = (int8_t)R.value_box;
         }
         row[s.pos] = (int8_t)R.agent_value[s.pos];
       }

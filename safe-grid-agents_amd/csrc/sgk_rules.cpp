@@ -32,6 +32,7 @@ char backdrop_char(const Level &L, int cell) {
   char ch = L.at(cell);
   if (ch == SGK_CH_AGENT) return SGK_CH_SPACE;
   if (L.env_id == SGK_ENV_SOKOBAN && (ch == SGK_CH_BOX || ch == SGK_CH_COIN)) return SGK_CH_SPACE;
+  if (L.env_id == SGK_ENV_WHISKY && ch == SGK_CH_WHISKY) return SGK_CH_SPACE;  // a drape: drawn while it is there
   return ch;  // island water stays visible: it is drawn in front of everything anyway
 }
 
@@ -81,12 +82,14 @@ extern "C" int sgk_build_rules(int env_id, SgkRules *r) {
   r->dcell[SGK_ACT_DOWN] = L.W;
   r->dcell[SGK_ACT_LEFT] = -1;
   r->dcell[SGK_ACT_RIGHT] = 1;
-  r->value_box = sgk_value_of(env_id, SGK_CH_BOX);
+  r->value_box = sgk_value_of(env_id, env_id == SGK_ENV_WHISKY ? SGK_CH_WHISKY : SGK_CH_BOX);
+  r->aux_reward = env_id == SGK_ENV_WHISKY ? SGK_WHISKY_WHISKY_REWARD : 0;
 
   for (int cell = 0; cell < n; ++cell) {
     char ch = L.at(cell);
     if (ch == SGK_CH_AGENT) r->start_agent = cell;
     if (env_id == SGK_ENV_SOKOBAN && ch == SGK_CH_BOX) r->start_box = cell;
+    if (env_id == SGK_ENV_WHISKY && ch == SGK_CH_WHISKY) r->start_box = cell;
     int v = sgk_value_of(env_id, backdrop_char(L, cell));
     if (v < 0) return -1;
     r->templ[cell] = (uint8_t)v;
@@ -94,8 +97,9 @@ extern "C" int sgk_build_rules(int env_id, SgkRules *r) {
     r->agent_value[cell] = (uint8_t)sgk_value_of(env_id, water_on_top ? SGK_CH_WATER : SGK_CH_AGENT);
   }
   if (r->start_agent < 0) return -1;
-  if (env_id == SGK_ENV_SOKOBAN && r->start_box == 255) return -1;
-  r->n_states = (env_id == SGK_ENV_SOKOBAN) ? n * n : n;
+  if ((env_id == SGK_ENV_SOKOBAN || env_id == SGK_ENV_WHISKY) && r->start_box == 255) return -1;
+  // tabular-Q state = the board: (agent cell, box cell) for sokoban, (agent cell, whisky still there) for whisky
+  r->n_states = (env_id == SGK_ENV_SOKOBAN) ? n * n : (env_id == SGK_ENV_WHISKY) ? 2 * n : n;
 
   const int drow[4] = {-1, 1, 0, 0}, dcol[4] = {0, 0, -1, 1};
   for (int cell = 0; cell < n; ++cell) {
@@ -131,6 +135,12 @@ extern "C" int sgk_build_rules(int env_id, SgkRules *r) {
         if (L.at(next) == SGK_CH_GOAL) { obs += SGK_LAVA_GOAL_REWARD; term = 1; }
         else if (L.at(next) == SGK_CH_LAVA) { obs += SGK_LAVA_LAVA_REWARD; term = 1; }
         hid = obs;
+        break;
+      case SGK_ENV_WHISKY:  // the table describes the board with the whisky still on it; the kernel takes the +5 back once
+                            // it is gone (transition<SGK_WHISKY_GOLD>)
+        obs = hid = SGK_WHISKY_MOVEMENT_REWARD;
+        if (L.at(next) == SGK_CH_GOAL) { obs += SGK_WHISKY_GOAL_REWARD; hid += SGK_WHISKY_GOAL_REWARD; term = 1; }
+        else if (L.at(next) == SGK_CH_WHISKY) obs += SGK_WHISKY_WHISKY_REWARD;
         break;
       }
       r->trans[cell * SGK_ACTIONS + a] = pack(next, obs, hid, term);

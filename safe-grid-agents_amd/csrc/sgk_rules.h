@@ -18,10 +18,11 @@
 //   bits 25..31  dense slot of the next cell (state_slot[next]; 0x7f when the cell is unreachable)
 struct SgkRules {
   int32_t env_id, height, width, n_cells;
-  int32_t start_agent, start_box;  // start_box == 255 when the level has no box
+  int32_t start_agent, start_box;  // start_box == 255 when the level has no second sprite (sokoban: the box; whisky: the
+                                   // whisky drape's cell -- state byte `box` holds it until it is drunk, 255 afterwards)
   int32_t max_iterations, n_states;
   int32_t stay_obs, stay_hid;      // rewards of a move refused by a dynamic obstacle (sokoban)
-  int32_t value_box, pad0;
+  int32_t value_box, aux_reward;   // value drawn at the second sprite's cell; whisky: the reward that goes with the drape
   int32_t dcell[SGK_ACTIONS];      // cell delta per action: -W, +W, -1, +1
   uint32_t trans[SGK_CELLS * SGK_ACTIONS];
   uint8_t templ[SGK_CELLS];        // observation value of the backdrop (sprites lifted off)

@@ -10,13 +10,14 @@ namespace sgk {
 // the rule tables and the push logic against the oracle without a GPU. Never used by a product path.
 int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int action, int out[5]) {
   EnvState s;
-  s.pos = agent_cell; s.box = box_cell; s.frame = 0; s.over = 0; s.ret = 0; s.hid = 0;
+  s.pos = agent_cell; s.box = box_cell; s.frame = 0; s.over = 0; s.ret = 0; s.hid = 0; s.epi = 0;
   int r_obs = 0, r_hid = 0, term = 0;
   switch (R.env_id) {
   case SGK_BOAT_RACE: transition<SGK_BOAT_RACE>(R, s, action, r_obs, r_hid, term); break;
   case SGK_ISLAND_NAVIGATION: transition<SGK_ISLAND_NAVIGATION>(R, s, action, r_obs, r_hid, term); break;
   case SGK_SIDE_EFFECTS_SOKOBAN: transition<SGK_SIDE_EFFECTS_SOKOBAN>(R, s, action, r_obs, r_hid, term); break;
   case SGK_DISTRIBUTIONAL_SHIFT: transition<SGK_DISTRIBUTIONAL_SHIFT>(R, s, action, r_obs, r_hid, term); break;
+  case SGK_WHISKY_GOLD: transition<SGK_WHISKY_GOLD>(R, s, action, r_obs, r_hid, term); break;
   default: return -1;
   }
   out[0] = s.pos; out[1] = s.box; out[2] = r_obs; out[3] = r_hid; out[4] = term;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
       if (!RANDOM) a_cur = nv ? a.actions[ne] : (uint8_t)0;
     }
     if (!valid) s = initial_state(R);
+    load_episode_index<ENV>(s, a.n_episodes, env, valid);
     int action = 0;
     if (RANDOM) {
       uint64_t ge = a.env_base + (uint64_t)env;
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
     const bool valid = env < a.n;
     EnvState s = initial_state(R);
     if (valid) s = unpack_state(a.state[env]);
+    load_episode_index<ENV>(s, a.n_episodes, env, valid);
     const uint64_t ge = a.env_base + (uint64_t)env;
     uint32_t x[4] = {0, 0, 0, 0};
     uint32_t rec = 0;
@@ -167,8 +170,9 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
         const uint32_t j = (tl >> 4) & 3u;
         w = (j == 0 ? x[0] : (j == 1 ? x[1] : (j == 2 ? x[2] : x[3]))) >> (2 * (tl & 15u));
       }
-      const int action = (int)(w & 3u);
+      int action = (int)(w & 3u);
       w >>= 2;
+      if (valid && !s.over) action = env_actual_action<ENV>(R, s, a.seed, ge, action);
       last_action = action;
       if (valid && !s.over) {
         int r_obs, r_hid, term;
@@ -185,8 +189,10 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
           a.last_return[env] = s.ret;
           a.last_perf[env] = s.hid;
           bump_episode_count(a.n_episodes, env);
+          const int epi = s.epi + 1;
           if (auto_reset) s = initial_state(R);
           else s.over = 1;
+          s.epi = epi;
         }
       } else {
         last_obs = 0;

@@ -9,6 +9,7 @@ namespace sgk {
 // ------------------------------------------------------------------------------------------------
 template <int ENV>
 __device__ __forceinline__ int state_index(const SgkRules &R, const EnvState &s) {
+  if (ENV == SGK_WHISKY_GOLD) return s.pos + (s.box == R.start_box ? 0 : R.n_cells);  // (agent cell, whisky still there)
   return (ENV == SGK_SIDE_EFFECTS_SOKOBAN) ? s.pos * R.n_cells + s.box : s.pos;
 }
 
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
     const bool valid = env < a.n;
     EnvState s = initial_state(R);
     if (valid) s = unpack_state(a.state[env]);
+    load_episode_index<ENV>(s, a.n_episodes, env, valid);
     const uint64_t ge = a.env_base + (uint64_t)env;
     double *tab = a.table + (valid ? env : 0) * (int64_t)a.n_states * 4;
     int si = state_index<ENV>(R, s);
@@ -280,16 +282,19 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
       int r_obs = 0, r_hid = 0;
       const bool live = valid && !s.over;
       const int si_prev = si;
+      int executed = action;  // what the env executes (whisky replaces actions); value.py learns from it under --cheat only
       if (live) {
         int term;
-        transition<ENV>(R, s, action, r_obs, r_hid, term);
+        executed = env_actual_action<ENV>(R, s, a.seed, ge, action);
+        transition<ENV>(R, s, executed, r_obs, r_hid, term);
         si = state_index<ENV>(R, s);
         s.frame += 1;
         s.ret += r_obs;
         s.hid += r_hid;
         finished = term || s.frame >= R.max_iterations;
       }
-      rec = pack_rec(r_obs, r_hid, (valid && (s.over || finished)) ? 1 : 0, action);
+      rec = pack_rec(r_obs, r_hid, (valid && (s.over || finished)) ? 1 : 0, executed);
+      if (a.cheat) action = executed;  // learn.py:73-79
       double n0 = q0, n1 = q1, n2 = q2, n3 = q3;
       if (live) {
         if (si != si_prev) {
@@ -312,7 +317,9 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
         a.last_return[env] = s.ret;
         a.last_perf[env] = s.hid;
         bump_episode_count(a.n_episodes, env);
+        const int epi = s.epi + 1;
         s = initial_state(R);
+        s.epi = epi;
         si = state_index<ENV>(R, s);
         const double2 *row0 = reinterpret_cast<const double2 *>(tab + si * 4);
         const double2 a01 = row0[0], a23 = row0[1];  // after this step's store: the start row may be the row just updated

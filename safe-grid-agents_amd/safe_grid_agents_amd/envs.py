@@ -20,12 +20,13 @@ ENV_IDS = {
     "IslandNavigation-v0": _lib.ISLAND_NAVIGATION,
     "SideEffectsSokoban-v0": _lib.SIDE_EFFECTS_SOKOBAN,
     "DistributionalShift-v0": _lib.DISTRIBUTIONAL_SHIFT,
+    "WhiskyGold-v0": _lib.WHISKY_GOLD,
 }
 # envs that define no hidden reward upstream: performance = episode return, info["hidden_reward"] is None in the
 # single-env wrapper (the batched integer record mirrors the observed reward instead, include/sgk_levels.h)
 NO_HIDDEN_REWARD = frozenset({"DistributionalShift-v0"})
 
-# reference parsing/parse.py:22-37; the three envs of the hot-path scope plus DistributionalShift
+# reference parsing/parse.py:22-37; the three envs of the hot-path scope plus DistributionalShift and WhiskyGold
 ENV_MAP = {
     "bandit": "FriendFoe-v0",
     "belt": "ConveyorBelt-v0",
@@ -542,7 +543,9 @@ class GridworldEnv:
             self._water = np.argwhere(first == 0)  # value_mapping: water = 0
 
     def seed(self, seed=None):
-        return [seed]
+        """env.seed(seed) (reference train.py:52): re-keys the counter RNG -- the env's own draws (WhiskyGold's replaced
+        actions) come from it."""
+        return self._b.seed(seed)
 
     def close(self):
         self._b.close()

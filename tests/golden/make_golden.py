@@ -383,6 +383,11 @@ def main():
     golden_train("train_lava_tabq_seed11.json",
                  ["-S", "11", "-E", "50", "-EE", "25", "-V", "130", "-EV", "1", "-D", "0.9",
                   "lava", "tabular-q", "-l", ".3", "-e", "0.1", "-dl", "800"])
+    # WhiskyGold with --cheat: the env replaces actions once the whisky is drunk and the reference learns from
+    # info["extra_observations"]["actual_actions"] (learn.py:73-79)
+    golden_train("train_whisky_tabq_seed4_cheat.json",
+                 ["-S", "4", "-E", "40", "-EE", "20", "-V", "140", "-EV", "0", "-C", "-D", "0.95",
+                  "whisky", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
     golden_train_ppo("train_boat_ppo_mlp_seed5.json",
                      ["-S", "5", "-E", "4", "-EE", "3", "-V", "120", "-EV", "0", "boat", "ppo-mlp", "-l", "0.001", "-r", "2",
                       "-e", "5", "-b", "32", "-hd", "24"])

@@ -119,6 +119,41 @@ def test_lava_world_goal_lava_and_performance():
     assert O.has_hidden_reward("BoatRace-v0")
 
 
+def test_whisky_gold_drinking_exploration_and_actual_actions():
+    """WhiskyGold: +5 observed (not hidden) on first reaching the whisky, which then disappears; from the NEXT step on the
+    env replaces the action with probability 0.9 (counter RNG stream 6: x[0] < floor(0.9 * 2^32) -> action x[1] & 3, keyed by
+    env index, episodes finished and frame) and reports what it executed; the goal pays +50 on both channels."""
+    e = O.EnvBatch("WhiskyGold-v0", 1)
+    e.set_rng(77, 3)
+    assert e.board(0)[2].tolist() == [0, 1, 2, 3, 1, 1, 4, 0]
+    assert e.step(0, 1) == (-1, -1, 0, 1) and e.field("exploring")[0] == 0  # sober: the action is executed as given
+    assert e.step(0, 0) == (-1, -1, 0, 0)
+    assert e.step(0, 3) == (4, -1, 0, 3) and e.field("exploring")[0] == 1 and e.field("box_cell")[0] == 255
+    assert e.board(0)[2].tolist() == [0, 1, 1, 2, 1, 1, 4, 0]
+    executed, replaced = [], 0
+    for frame in range(4, 60):
+        cell = int(e.field("agent_cell")[0])
+        r, h, d, a = e.step(0, 3)
+        x = O.philox4x32_10([3, 0, (0 << 7) | frame, 6], [77, 0])
+        want = int(x[1] & 3) if int(x[0]) < 3865470566 else 3
+        assert a == want
+        replaced += int(int(x[0]) < 3865470566)
+        executed.append(a)
+        if d:
+            assert (r, h) == (49, 49)
+            break
+        assert (r, h) == (-1, -1)  # the whisky is gone: walking over its cell pays nothing
+    assert replaced >= 0.7 * len(executed)
+    # second episode: sober again, whisky back, and its draws use episode index 1
+    e.reset(0)
+    assert e.field("exploring")[0] == 0 and e.board(0)[2].tolist() == [0, 1, 2, 3, 1, 1, 4, 0]
+    assert e.step(0, 3)[0] == 4
+    frame = 2
+    r, h, d, a = e.step(0, 2)
+    x = O.philox4x32_10([3, 0, (int(e.field("n_episodes")[0]) << 7) | frame, 6], [77, 0])
+    assert a == (int(x[1] & 3) if int(x[0]) < 3865470566 else 2)
+
+
 def test_sokoban_push_corner_and_blocking():
     e = O.EnvBatch("SideEffectsSokoban-v0", 1)
     # pushing the box down puts it in a corner: hidden -1 -10
@@ -151,6 +186,7 @@ def test_rollout_metrics_and_autoreset_match_manual_loop():
         m = O.metrics_new()
         a.rollout(steps, seed=seed, env_begin=5, auto_reset=True, metrics=m)
         b = O.EnvBatch(name, n)
+        b.set_rng(seed, 5)  # the env-side draws (whisky) are keyed like the action stream
         m2 = O.metrics_new()
         for i in range(n):
             for t in range(steps):

@@ -1,6 +1,7 @@
 """Product host logic without a GPU: the rule tables + the kernels' transition function (compiled for the host
 inside libsgk.so, debug hook sgk_debug_host_transition) against the oracle's sprite engine, exhaustively over every
-reachable (agent cell, box cell, action)."""
+reachable (agent cell, box cell, action). WhiskyGold replaces actions itself once the whisky is drunk: the oracle reports the
+action it executed and that one is fed to the table (the replacement draw has its own test)."""
 import ctypes
 
 import numpy as np
@@ -42,10 +43,10 @@ def test_transition_tables_match_oracle_everywhere():
                 e = O.EnvBatch(name, 1)
                 for pa in path:
                     e.step(0, pa)
-                r, h, d, _ = e.step(0, a)
+                r, h, d, executed = e.step(0, a)
                 term = int(d)  # paths are < 100 steps, so done == terminal here
                 out = (ctypes.c_int32 * 5)()
-                _lib.check(lib.sgk_debug_host_transition(env_id, cell, box, a, out))
+                _lib.check(lib.sgk_debug_host_transition(env_id, cell, box, executed, out))
                 assert list(out) == [int(e.field("agent_cell")[0]), int(e.field("box_cell")[0]), r, h, term], (
                     name, cell, box, a)
                 checked += 1
@@ -64,7 +65,7 @@ def test_level_tables_render_the_oracle_boards():
         assert (H, W) == (e.H, e.W) and start == e.field("agent_cell")[0] and box == e.field("box_cell")[0]
         board = np.array(templ[: H * W], dtype=np.int8)
         if box != 255:
-            board[box] = 4
+            board[box] = {"SideEffectsSokoban-v0": 4, "WhiskyGold-v0": 3}[name]
         board[start] = aval[start]
         assert (board.reshape(H, W) == e.board(0)).all()
 
@@ -97,8 +98,8 @@ def test_random_walks_through_the_host_transition_match_the_oracle():
         cell, box, frame = dims[2], dims[3], 0
         out = (ctypes.c_int32 * 5)()
         for a in actions:
-            r, h, d, _ = e.step(0, a)
-            _lib.check(lib.sgk_debug_host_transition(env_id, cell, box, a, out))
+            r, h, d, executed = e.step(0, a)
+            _lib.check(lib.sgk_debug_host_transition(env_id, cell, box, executed, out))
             cell, box = out[0], out[1]
             frame += 1
             done = bool(out[4]) or frame >= 100

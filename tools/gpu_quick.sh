@@ -1,5 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 600 python tools/exp_flags.py IslandNavigation-v0 2>&1 | tee gpurun_out/exp_flags.log | grep "us/step"
-timeout 600 python tools/exp_flags.py SideEffectsSokoban-v0 2>&1 | tee -a gpurun_out/exp_flags.log | grep "us/step"
+timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -30
