@@ -1,4 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -30
+timeout 900 python tools/sweep.py WhiskyGold-v0 2>&1 | tee gpurun_out/sweep_whisky.log | tail -12
+timeout 300 python bench.py --env WhiskyGold-v0 --steps 500 --warmup 100 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-900
