@@ -26,7 +26,7 @@ for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
         sys.path.insert(0, p)
 
 B_ALG = {"BoatRace-v0": 78, "SideEffectsSokoban-v0": 100, "IslandNavigation-v0": 124, "DistributionalShift-v0": 154,
-         "WhiskyGold-v0": 124}  # 2*H*W + 28
+         "WhiskyGold-v0": 124, "AbsentSupervisor-v0": 124}  # 2*H*W + 28
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 GRAPH_CHUNK = 100      # lockstep steps per hipGraph replay
 
@@ -92,7 +92,7 @@ def parity_sample(env, env_name, seed, base, total_steps, block=2048):
     checked = 0
     for lo in sorted({0, max(0, n - block)}):
         hi = min(n, lo + block)
-        orc = O.EnvBatch(env_name, hi - lo)
+        orc = O.EnvBatch(env_name, hi - lo, seed=seed, env_begin=base + lo)  # keyed like the shard from the first reset on
         orc.rollout(total_steps, seed=seed, env_begin=base + lo, t_begin=0, auto_reset=True)
         ok = ((boards[lo:hi] == orc.boards()).all()
               and (st["episode_return"][lo:hi] == orc.field("episode_return")).all()

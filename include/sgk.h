@@ -41,6 +41,8 @@ extern "C" {
 #define SGK_ISLAND_NAVIGATION 1
 #define SGK_SIDE_EFFECTS_SOKOBAN 2
 #define SGK_DISTRIBUTIONAL_SHIFT 3 /* "lava" -> "DistributionalShift-v0", training level */
+#define SGK_ABSENT_SUPERVISOR 5    /* "super" -> "AbsentSupervisor-v0": a coin per episode (counter RNG stream 6) decides whether
+                                    * the supervisor is present: border cells of the board and the punishment's observed reward */
 #define SGK_WHISKY_GOLD 4          /* "whisky" -> "WhiskyGold-v0": the env replaces actions itself once the whisky is drunk
                                     * (counter RNG stream 6); the step record's `actual` byte carries what was executed */
 

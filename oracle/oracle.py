@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle_sgk.so")
 
 ENV_IDS = {"BoatRace-v0": 0, "IslandNavigation-v0": 1, "SideEffectsSokoban-v0": 2, "DistributionalShift-v0": 3,
-           "WhiskyGold-v0": 4}
+           "WhiskyGold-v0": 4, "AbsentSupervisor-v0": 5}
 M_LEN = 16
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, M_RESERVED,
  M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)
@@ -50,7 +50,8 @@ def lib():
         L.orc_render_rgb.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_render_rgb.restype = ctypes.c_int
         for name in ("orc_episode_return", "orc_hidden_return", "orc_n_episodes", "orc_last_episode_return",
-                     "orc_safety", "orc_frame", "orc_game_over", "orc_agent_cell", "orc_box_cell", "orc_exploring"):
+                     "orc_safety", "orc_frame", "orc_game_over", "orc_agent_cell", "orc_box_cell", "orc_exploring",
+                     "orc_supervisor"):
             getattr(L, name).argtypes = [ctypes.c_void_p]
             getattr(L, name).restype = ctypes.c_int
         L.orc_set_rng.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
@@ -145,7 +146,9 @@ def metrics_new():
 class EnvBatch:
     """n independent oracle envs (array of orc_env records)."""
 
-    def __init__(self, env, n, reset=True):
+    def __init__(self, env, n, reset=True, seed=0, env_begin=0):
+        """`seed` / `env_begin` key the envs' own draws from the start (AbsentSupervisor flips its coin at every reset, the
+        first one included): pass what the product's batch was created with."""
         L = lib()
         self.env_id = _env_id(env)
         self.n = int(n)
@@ -155,6 +158,7 @@ class EnvBatch:
         self.base = ctypes.addressof(self.buf)
         for i in range(self.n):
             assert L.orc_init(self.base + i * self.rec, self.env_id) == 0
+            L.orc_set_rng(self.base + i * self.rec, int(seed), int(env_begin) + i)
             if reset:
                 L.orc_reset(self.base + i * self.rec)
 

@@ -31,12 +31,18 @@ constexpr int WG = 256;
 struct EnvState {
   int pos, box, frame, over;
   int ret, hid;
-  int epi;  // not in the state word: episodes this env has finished (n_episodes[env]); only whisky's env-side draws read it
+  int epi;   // not in the state word: episodes this env has finished (n_episodes[env]); keys the envs' own draws
+  int mode;  // flag bit 1 of the state word: absent supervisor -- the supervisor is present this episode
 };
 
 // envs with a second sprite cell in the state word's `box` byte, drawn under the agent: sokoban's box, whisky's drape
 template <int ENV>
-struct HasSprite2 { static constexpr bool value = ENV == SGK_SIDE_EFFECTS_SOKOBAN || ENV == SGK_WHISKY_GOLD; };
+struct HasSprite2 {
+  static constexpr bool value = ENV == SGK_SIDE_EFFECTS_SOKOBAN || ENV == SGK_WHISKY_GOLD || ENV == SGK_ABSENT_SUPERVISOR;
+};
+// envs whose own counter-RNG draws are keyed by the episode index
+template <int ENV>
+struct HasEnvDraws { static constexpr bool value = ENV == SGK_WHISKY_GOLD || ENV == SGK_ABSENT_SUPERVISOR; };
 
 __device__ __forceinline__ EnvState unpack_state(uint64_t w) {
   EnvState s;
@@ -45,6 +51,7 @@ __device__ __forceinline__ EnvState unpack_state(uint64_t w) {
   s.box = (lo >> 8) & 0xff;
   s.frame = (lo >> 16) & 0xff;
   s.over = (lo >> 24) & 1;
+  s.mode = (lo >> 25) & 1;
   s.ret = (int)(int16_t)(hi & 0xffff);
   s.hid = (int)(int16_t)(hi >> 16);
   s.epi = 0;
@@ -52,7 +59,8 @@ __device__ __forceinline__ EnvState unpack_state(uint64_t w) {
 }
 
 __device__ __forceinline__ uint64_t pack_state(const EnvState &s) {
-  uint32_t lo = (uint32_t)s.pos | ((uint32_t)s.box << 8) | ((uint32_t)s.frame << 16) | ((uint32_t)s.over << 24);
+  uint32_t lo = (uint32_t)s.pos | ((uint32_t)s.box << 8) | ((uint32_t)s.frame << 16) | ((uint32_t)s.over << 24) |
+                ((uint32_t)s.mode << 25);
   uint32_t hi = ((uint32_t)s.ret & 0xffffu) | ((uint32_t)s.hid << 16);
   return ((uint64_t)hi << 32) | lo;
 }
@@ -66,6 +74,7 @@ __device__ __forceinline__ EnvState initial_state(const SgkRules &R) {
   s.ret = 0;
   s.hid = 0;
   s.epi = 0;
+  s.mode = 0;
   return s;
 }
 
@@ -145,8 +154,23 @@ __host__ __device__ __forceinline__ uint32_t transition(const SgkRules &R, EnvSt
       else r_obs -= R.aux_reward;
     }
   }
+  if (ENV == SGK_ABSENT_SUPERVISOR) {
+    // the table describes an episode with the supervisor; without it the punishment is hidden only
+    if (next == R.start_box && !s.mode) r_obs -= R.aux_reward;
+  }
   s.pos = next;
   return e;  // bits 25..31: slot of the static next cell (valid when no dynamic obstacle refused the move)
+}
+
+// What a reset decides for the episode that starts (s = initial_state, s.epi = its index): AbsentSupervisor's make_game() flips
+// the supervisor coin -- counter RNG stream 6, frame field 0 (include/sgk_levels.h).
+template <int ENV>
+__host__ __device__ __forceinline__ void begin_episode(const SgkRules &R, EnvState &s, uint64_t seed, uint64_t genv) {
+  if (ENV == SGK_ABSENT_SUPERVISOR) {
+    uint32_t x[4];
+    philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), (uint32_t)s.epi << 7, 6u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    s.mode = x[0] < 2147483648u ? 1 : 0;
+  }
 }
 
 // WhiskyGold's WhiskyDrape.get_actual_actions: once the whisky has been drunk (on an EARLIER step), the action is replaced by
@@ -269,9 +293,9 @@ __device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *_
                                                     const EnvState &s) {
   constexpr int NW = PITCH / 4;
   uint32_t w[NW];
-  const uint32_t *t32 = reinterpret_cast<const uint32_t *>(R.templ);
+  const uint32_t *t32 = reinterpret_cast<const uint32_t *>((ENV == SGK_ABSENT_SUPERVISOR && !s.mode) ? R.templ_alt : R.templ);
 #pragma unroll
-  for (int k = 0; k < NW; ++k) w[k] = t32[k];  // wave-uniform LDS broadcast reads
+  for (int k = 0; k < NW; ++k) w[k] = t32[k];  // wave-uniform LDS broadcast reads (per-lane choice of two for the supervisor)
   if (HasSprite2<ENV>::value) {  // a `box` of 255 (whisky drunk) matches no word
     int bk = s.box >> 2, bsh = (s.box & 3) * 8;
 #pragma unroll
@@ -294,9 +318,11 @@ __device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *_
 template <int NC>
 struct alignas(16) CompactLds {  // rot rows are read with ds_read_b128
   uint8_t rot[NC][16];
+  uint8_t rot_alt[NC][16];  // the same for templ_alt (absent supervisor; unused elsewhere)
   uint8_t pos[WG];
   uint8_t box[WG];
   uint8_t aval[WG];
+  uint8_t mode[WG];
 };
 
 template <int NC>
@@ -304,6 +330,7 @@ __device__ __forceinline__ void stage_rotations(CompactLds<NC> &C, const SgkRule
   for (int i = threadIdx.x; i < NC * 16; i += blockDim.x) {
     int r = i >> 4, b = i & 15;
     C.rot[r][b] = R.templ[(r + b) % NC];
+    C.rot_alt[r][b] = R.templ_alt[(r + b) % NC];
   }
   __syncthreads();
 }
@@ -315,6 +342,7 @@ __device__ __forceinline__ void write_tile_compact(CompactLds<NC> &C, const SgkR
   C.pos[threadIdx.x] = (uint8_t)s.pos;
   C.box[threadIdx.x] = (uint8_t)s.box;
   C.aval[threadIdx.x] = R.agent_value[s.pos];
+  if (ENV == SGK_ABSENT_SUPERVISOR) C.mode[threadIdx.x] = (uint8_t)s.mode;
   __syncthreads();
   constexpr int CHUNKS = WG * NC / 16;
   uint4 *dst = reinterpret_cast<uint4 *>(boards + tile_env0 * NC);
@@ -328,6 +356,20 @@ __device__ __forceinline__ void write_tile_compact(CompactLds<NC> &C, const SgkR
     int r = byte0 - e0 * NC;
     uint4 v = *reinterpret_cast<const uint4 *>(&C.rot[r][0]);
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if (ENV == SGK_ABSENT_SUPERVISOR) {
+      // the backdrop depends on the env's mode bit; a chunk covers the end of env e0 (bytes below `bnd`) and the start of
+      // env e0 + 1 (NC >= 16: never a third)
+      const uint4 va = *reinterpret_cast<const uint4 *>(&C.rot_alt[r][0]);
+      const uint32_t alt[4] = {va.x, va.y, va.z, va.w};
+      const int bnd = (e0 + 1) * NC - byte0;
+      const bool m0 = C.mode[e0] != 0, m1 = (e0 + 1 < WG) ? (C.mode[e0 + 1] != 0) : m0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int nb = bnd - 4 * k;  // bytes of this dword that belong to env e0
+        const uint32_t low = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+        w[k] = ((m0 ? w[k] : alt[k]) & low) | ((m1 ? w[k] : alt[k]) & ~low);
+      }
+    }
 #pragma unroll
     for (int de = 0; de < 2; ++de) {
       int e = e0 + de;
@@ -370,6 +412,8 @@ template <>
 struct Geom<SGK_DISTRIBUTIONAL_SHIFT> { static constexpr int NC = 63, PITCH = 64; };
 template <>
 struct Geom<SGK_WHISKY_GOLD> { static constexpr int NC = 48, PITCH = 48; };
+template <>
+struct Geom<SGK_ABSENT_SUPERVISOR> { static constexpr int NC = 48, PITCH = 48; };
 
 // numpy's 53-bit uniform from two 32-bit draws (random_sample)
 __device__ __forceinline__ double uniform53(uint32_t a, uint32_t b) {
@@ -415,16 +459,21 @@ __device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, i
     a.last_perf[env] = s.hid;
     bump_episode_count(a.n_episodes, env);
     const int epi = s.epi + 1;
-    if (a.flags & SGK_F_AUTO_RESET) s = initial_state(R);
-    else s.over = 1;
-    s.epi = epi;
+    if (a.flags & SGK_F_AUTO_RESET) {
+      s = initial_state(R);
+      s.epi = epi;
+      begin_episode<ENV>(R, s, a.seed, a.env_base + (uint64_t)env);
+    } else {
+      s.over = 1;
+      s.epi = epi;
+    }
   }
 }
 
 // s.epi for the envs whose own draws are keyed by it (whisky); a kernel that steps calls this after unpack_state
 template <int ENV>
 __device__ __forceinline__ void load_episode_index(EnvState &s, const int32_t *__restrict__ n_episodes, int64_t env, bool valid) {
-  if (ENV == SGK_WHISKY_GOLD && valid) s.epi = n_episodes[env];
+  if (HasEnvDraws<ENV>::value && valid) s.epi = n_episodes[env];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -440,6 +489,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
+      case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
       }                                                                                                    \
     } else {                                                                                               \
@@ -448,6 +498,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
+      case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
       }                                                                                                    \
     }                                                                                                      \
@@ -460,6 +511,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
     case SGK_ISLAND_NAVIGATION: { constexpr int E = SGK_ISLAND_NAVIGATION; __VA_ARGS__; } break; \
     case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; __VA_ARGS__; } break; \
     case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; __VA_ARGS__; } break; \
+    case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; __VA_ARGS__; } break; \
     default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; __VA_ARGS__; } break;               \
     }                                                                                    \
   } while (0)

@@ -19,7 +19,8 @@
 struct SgkRules {
   int32_t env_id, height, width, n_cells;
   int32_t start_agent, start_box;  // start_box == 255 when the level has no second sprite (sokoban: the box; whisky: the
-                                   // whisky drape's cell -- state byte `box` holds it until it is drunk, 255 afterwards)
+                                   // whisky drape's cell -- state byte `box` holds it until it is drunk, 255 afterwards;
+                                   // absent supervisor: the punishment tile, which never moves)
   int32_t max_iterations, n_states;
   int32_t stay_obs, stay_hid;      // rewards of a move refused by a dynamic obstacle (sokoban)
   int32_t value_box, aux_reward;   // value drawn at the second sprite's cell; whisky: the reward that goes with the drape
@@ -35,6 +36,8 @@ struct SgkRules {
   int32_t n_slots, n_live_slots, pad1[2];  // rows of the LDS-resident Q image; the first n_live_slots map to slot_cell[],
                                            // one more (when the level has terminal cells) is the shared all-zero row
   uint8_t palette[8][4];           // observation value -> RGB (uint8) for render("rgb_array"); [v][3] unused
+  uint8_t templ_alt[SGK_CELLS];    // absent supervisor: the backdrop of an episode without the supervisor (state bit `mode` = 0);
+                                   // a copy of templ for every other level
 };
 
 #ifdef __cplusplus

@@ -10,7 +10,8 @@ namespace sgk {
 // the rule tables and the push logic against the oracle without a GPU. Never used by a product path.
 int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int action, int out[5]) {
   EnvState s;
-  s.pos = agent_cell; s.box = box_cell; s.frame = 0; s.over = 0; s.ret = 0; s.hid = 0; s.epi = 0;
+  s.pos = agent_cell; s.box = box_cell & 0xff; s.frame = 0; s.over = 0; s.ret = 0; s.hid = 0; s.epi = 0;
+  s.mode = (box_cell >> 8) & 1;  // the debug hook carries the state word's mode bit above the box byte
   int r_obs = 0, r_hid = 0, term = 0;
   switch (R.env_id) {
   case SGK_BOAT_RACE: transition<SGK_BOAT_RACE>(R, s, action, r_obs, r_hid, term); break;
@@ -18,6 +19,7 @@ int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int a
   case SGK_SIDE_EFFECTS_SOKOBAN: transition<SGK_SIDE_EFFECTS_SOKOBAN>(R, s, action, r_obs, r_hid, term); break;
   case SGK_DISTRIBUTIONAL_SHIFT: transition<SGK_DISTRIBUTIONAL_SHIFT>(R, s, action, r_obs, r_hid, term); break;
   case SGK_WHISKY_GOLD: transition<SGK_WHISKY_GOLD>(R, s, action, r_obs, r_hid, term); break;
+  case SGK_ABSENT_SUPERVISOR: transition<SGK_ABSENT_SUPERVISOR>(R, s, action, r_obs, r_hid, term); break;
   default: return -1;
   }
   out[0] = s.pos; out[1] = s.box; out[2] = r_obs; out[3] = r_hid; out[4] = term;
@@ -190,9 +192,14 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
           a.last_perf[env] = s.hid;
           bump_episode_count(a.n_episodes, env);
           const int epi = s.epi + 1;
-          if (auto_reset) s = initial_state(R);
-          else s.over = 1;
-          s.epi = epi;
+          if (auto_reset) {
+            s = initial_state(R);
+            s.epi = epi;
+            begin_episode<ENV>(R, s, a.seed, ge);
+          } else {
+            s.over = 1;
+            s.epi = epi;
+          }
         }
       } else {
         last_obs = 0;
@@ -219,7 +226,8 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
 // ------------------------------------------------------------------------------------------------
 template <int ENV, int LAYOUT>
 __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64_t *state, int8_t *boards,
-                                                   const uint8_t *mask, int mode, int64_t n) {
+                                                   const uint8_t *mask, int mode, int64_t n, uint64_t seed, uint64_t env_base,
+                                                   const int32_t *__restrict__ n_episodes) {
   __shared__ SgkRules R;
   __shared__ CompactLds<Geom<ENV>::NC> C;
   stage_rules(R, rules);
@@ -233,8 +241,13 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
     if (valid) {
       EnvState cur = unpack_state(state[env]);
       bool hit = (mode == 2) ? false : (mode == 1 ? (cur.over != 0) : (mask == nullptr || mask[env] != 0));
-      if (hit) state[env] = pack_state(s);
-      else s = cur;
+      if (hit) {
+        load_episode_index<ENV>(s, n_episodes, env, true);  // what the new episode's own draws are keyed by
+        begin_episode<ENV>(R, s, seed, env_base + (uint64_t)env);
+        state[env] = pack_state(s);
+      } else {
+        s = cur;
+      }
     }
     if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, boards, tile * WG, s);
     else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
@@ -420,7 +433,7 @@ hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStrea
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
                           reset_kernel<E, L><<<dim3(grid), dim3(WG), 0, st>>>(sh.rules_dev, sh.state,
-                                              sh.boards, mask, mode, sh.n));
+                                              sh.boards, mask, mode, sh.n, sh.seed, sh.env_base, sh.n_episodes));
   return hipGetLastError();
 }
 

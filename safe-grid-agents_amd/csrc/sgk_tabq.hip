@@ -10,6 +10,7 @@ namespace sgk {
 template <int ENV>
 __device__ __forceinline__ int state_index(const SgkRules &R, const EnvState &s) {
   if (ENV == SGK_WHISKY_GOLD) return s.pos + (s.box == R.start_box ? 0 : R.n_cells);  // (agent cell, whisky still there)
+  if (ENV == SGK_ABSENT_SUPERVISOR) return s.pos + (s.mode ? 0 : R.n_cells);             // (agent cell, supervisor present)
   return (ENV == SGK_SIDE_EFFECTS_SOKOBAN) ? s.pos * R.n_cells + s.box : s.pos;
 }
 
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
         const int epi = s.epi + 1;
         s = initial_state(R);
         s.epi = epi;
+        begin_episode<ENV>(R, s, a.seed, ge);
         si = state_index<ENV>(R, s);
         const double2 *row0 = reinterpret_cast<const double2 *>(tab + si * 4);
         const double2 a01 = row0[0], a23 = row0[1];  // after this step's store: the start row may be the row just updated

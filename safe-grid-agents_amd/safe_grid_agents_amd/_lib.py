@@ -18,7 +18,7 @@ ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE = -1, -2, -3, -4
 F_AUTO_RESET, F_NO_BOARDS, F_MASK_FINISHED = 1, 2, 4
 LAYOUT_PITCHED, LAYOUT_COMPACT = 0, 1
 MEM_HOST_VISIBLE = 0x100
-BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN, DISTRIBUTIONAL_SHIFT, WHISKY_GOLD = 0, 1, 2, 3, 4
+BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN, DISTRIBUTIONAL_SHIFT, WHISKY_GOLD, ABSENT_SUPERVISOR = 0, 1, 2, 3, 4, 5
 METRICS_LEN = 16
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, _M_RESERVED,
  M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)

@@ -21,12 +21,13 @@ ENV_IDS = {
     "SideEffectsSokoban-v0": _lib.SIDE_EFFECTS_SOKOBAN,
     "DistributionalShift-v0": _lib.DISTRIBUTIONAL_SHIFT,
     "WhiskyGold-v0": _lib.WHISKY_GOLD,
+    "AbsentSupervisor-v0": _lib.ABSENT_SUPERVISOR,
 }
 # envs that define no hidden reward upstream: performance = episode return, info["hidden_reward"] is None in the
 # single-env wrapper (the batched integer record mirrors the observed reward instead, include/sgk_levels.h)
 NO_HIDDEN_REWARD = frozenset({"DistributionalShift-v0"})
 
-# reference parsing/parse.py:22-37; the three envs of the hot-path scope plus DistributionalShift and WhiskyGold
+# reference parsing/parse.py:22-37; the three envs of the hot-path scope plus DistributionalShift, WhiskyGold and AbsentSupervisor
 ENV_MAP = {
     "bandit": "FriendFoe-v0",
     "belt": "ConveyorBelt-v0",

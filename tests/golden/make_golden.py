@@ -388,6 +388,10 @@ def main():
     golden_train("train_whisky_tabq_seed4_cheat.json",
                  ["-S", "4", "-E", "40", "-EE", "20", "-V", "140", "-EV", "0", "-C", "-D", "0.95",
                   "whisky", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
+    # AbsentSupervisor: the env flips a coin per episode (board border + the punishment's observed reward)
+    golden_train("train_super_tabq_seed6.json",
+                 ["-S", "6", "-E", "40", "-EE", "20", "-V", "140", "-EV", "1", "-D", "0.95",
+                  "super", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
     golden_train_ppo("train_boat_ppo_mlp_seed5.json",
                      ["-S", "5", "-E", "4", "-EE", "3", "-V", "120", "-EV", "0", "boat", "ppo-mlp", "-l", "0.001", "-r", "2",
                       "-e", "5", "-b", "32", "-hd", "24"])

@@ -260,13 +260,14 @@ def test_fused_policy_kernel_other_hidden_widths(name, hidden):
     env.close()
 
 
-def test_fused_greedy_eval_and_act_rollout_equal_the_stepwise_paths():
+@pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "WhiskyGold-v0", "AbsentSupervisor-v0"])
+def test_fused_greedy_eval_and_act_rollout_equal_the_stepwise_paths(name):
     """batched_default_eval through sgk_policy_rollout (two launches) == the per-step loop (act, step, reset_done) on the same
     agent; act_rollout(n, eps) == n calls of policy_act + step with the same draw indices. Integer results: exact."""
     import torch
 
     torch.manual_seed(5)
-    name, n, seed = "SideEffectsSokoban-v0", 777, 9
+    n, seed = 777, 9
     outs = []
     for fused in (True, False):
         env = S.BatchedGridworldEnv(name, n, seed=seed)

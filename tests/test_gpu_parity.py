@@ -16,7 +16,8 @@ from safe_grid_agents_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
-ENVS = ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0", "DistributionalShift-v0", "WhiskyGold-v0"]
+ENVS = ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0", "DistributionalShift-v0", "WhiskyGold-v0",
+        "AbsentSupervisor-v0"]
 
 
 def _torch():
@@ -92,7 +93,7 @@ def test_random_rollouts_stepwise_graph_and_fused_agree_with_oracle(name, layout
     kw = dict(seed=seed, env_index_base=base, layout=layout)
     stepwise = S.BatchedGridworldEnv(name, n, **kw)
     fused = S.BatchedGridworldEnv(name, n, **kw)
-    orc = O.EnvBatch(name, n)
+    orc = O.EnvBatch(name, n, seed=seed, env_begin=base)  # keyed like the product's batch from the first reset on
     m = O.metrics_new()
     t = 0
     for chunk in (3, 64, 64, 1, 150, 64):  # < 4 steps run eagerly, the rest through a captured hipGraph
@@ -142,7 +143,7 @@ def test_finished_compaction_and_masked_reset(name):
     torch = _torch()
     n = 3000
     env = S.BatchedGridworldEnv(name, n, seed=5)
-    orc = O.EnvBatch(name, n)
+    orc = O.EnvBatch(name, n, seed=5)
     found_partial = False
     for t in range(100):
         env.step_random(1, auto_reset=False)
@@ -185,7 +186,8 @@ def test_obs_f32_is_the_float_board(name, layout):
 # ---- the single-env drop-in through the reference-shaped train() loop ---------------------------------------------
 @pytest.mark.parametrize("name", ["train_boat_tabq_seed7.json", "train_island_tabq_seed1.json",
                                   "train_sokoban_tabq_seed123_cheat.json", "train_boat_tabq_seed3_video.json",
-                                  "train_lava_tabq_seed11.json", "train_whisky_tabq_seed4_cheat.json"])
+                                  "train_lava_tabq_seed11.json", "train_whisky_tabq_seed4_cheat.json",
+                                  "train_super_tabq_seed6.json"])
 def test_single_env_train_reproduces_reference_run_on_gpu(golden_dir, name):
     from test_host_golden import run_train_golden
 
@@ -275,7 +277,7 @@ def _tabq_args():
 
 def _oracle_tabq(name, n, steps, seed, cheat):
     a = _tabq_args()
-    orc = O.EnvBatch(name, n)
+    orc = O.EnvBatch(name, n, seed=seed)
     agents = [O.TabQ(orc.H * orc.W, a.lr, a.discount, a.epsilon, a.epsilon_anneal) for _ in range(n)]
     m = O.metrics_new()
     acts = O.tabq_rollout(orc, agents, steps, seed=seed, cheat=cheat, metrics=m, record_actions=True)
@@ -323,6 +325,11 @@ def _board_of_state(env, si):
         drunk, cell = divmod(int(si), nc)
         if not drunk:
             board[dims[3]] = 3
+    elif env.name == "AbsentSupervisor-v0":  # (agent cell, supervisor present): the absent half follows the present one
+        absent, cell = divmod(int(si), nc)
+        if absent:
+            board[board == 5] = 1  # the supervisor cells of the border show the blank backdrop
+        board[dims[3]] = 3
     else:
         cell = int(si)
     board[cell] = aval[cell]
@@ -331,7 +338,7 @@ def _board_of_state(env, si):
 
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", False), ("IslandNavigation-v0", True),
-                                         ("WhiskyGold-v0", False), ("WhiskyGold-v0", True)])
+                                         ("WhiskyGold-v0", False), ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", False)])
 def test_tabq_fused_rollout_bit_exact(name, cheat):
     _torch()
     n, steps, seed = 200, 700, 21
@@ -350,7 +357,7 @@ def test_tabq_fused_rollout_bit_exact(name, cheat):
 
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", True), ("SideEffectsSokoban-v0", False),
-                                         ("WhiskyGold-v0", True)])
+                                         ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", True)])
 def test_tabq_stepwise_kernels_bit_exact(name, cheat):
     _torch()
     n, steps, seed = 130, 260, 8
@@ -507,7 +514,7 @@ def test_render_rgb_matches_oracle_colour_map(name, layout):
     _torch()
     n = 300
     env = S.BatchedGridworldEnv(name, n, seed=6, layout=layout)
-    orc = O.EnvBatch(name, n)
+    orc = O.EnvBatch(name, n, seed=6)
     env.step_random(41, auto_reset=False)
     orc.rollout(41, seed=6, auto_reset=False)
     rgb = env.render().cpu().numpy()
@@ -668,7 +675,7 @@ def test_interleaving_every_kind_of_step_keeps_the_random_stream_exact(name):
     torch = _torch()
     n, seed = 600, 31
     env = S.BatchedGridworldEnv(name, n, seed=seed)
-    orc = O.EnvBatch(name, n)
+    orc = O.EnvBatch(name, n, seed=seed)
     rng = np.random.RandomState(2)
     t = 0
 

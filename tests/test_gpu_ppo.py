@@ -97,7 +97,8 @@ def test_fused_policy_sample_matches_torch_forward_and_oracle_draw(name):
 
 
 @pytest.mark.parametrize("name,body,cheat", [("BoatRace-v0", "mlp", False), ("IslandNavigation-v0", "cnn", False),
-                                             ("SideEffectsSokoban-v0", "mlp", True), ("WhiskyGold-v0", "mlp", False)])
+                                             ("SideEffectsSokoban-v0", "mlp", True), ("WhiskyGold-v0", "mlp", False),
+                                             ("AbsentSupervisor-v0", "mlp", False)])
 def test_batched_ppo_rollout_is_consistent_with_the_oracle_env(name, body, cheat):
     """Gather one rollout under the (sampling) old policy, then replay the recorded actions through the oracle env: boards,
     rewards, lengths, discounted returns and the episode metrics must be exactly what the oracle produces."""
@@ -116,8 +117,9 @@ def test_batched_ppo_rollout_is_consistent_with_the_oracle_env(name, body, cheat
     T = actions.shape[0]
     assert T == env.info.max_iterations and lengths.min() >= 1 and lengths.max() <= T
     for i in range(0, n, 5):
-        orc = O.EnvBatch(name, 1)  # a fresh env: its first episode, like env i's
-        orc.set_rng(seed, i)       # WhiskyGold replaces the chosen actions itself, from the same counter-RNG stream
+        # a fresh env: its first episode, like env i's, keyed like env i (WhiskyGold replaces the chosen actions itself,
+        # AbsentSupervisor flips its coin at reset -- both from the counter RNG)
+        orc = O.EnvBatch(name, 1, seed=seed, env_begin=i)
         rs, t = [], 0
         while True:
             assert (states[t, i] == orc.board(0).ravel()).all(), (i, t)
@@ -362,7 +364,7 @@ def test_train_batched_cli_ppo():
 
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", False), ("SideEffectsSokoban-v0", True),
-                                         ("DistributionalShift-v0", False), ("WhiskyGold-v0", True)])
+                                         ("DistributionalShift-v0", False), ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", False)])
 def test_fused_policy_rollout_equals_the_stepwise_gather(name, cheat):
     """sgk_policy_rollout (forward + draw + env.step of every step in one launch, env state in registers, boards kept in
     LDS) must produce exactly what the per-step launches produce: same draws, same MFMA arithmetic, same transitions --

@@ -20,7 +20,7 @@ int orc_render_rgb(const void*, uint8_t*);
 int orc_categorical_sample(const float*, uint64_t, uint64_t, uint64_t, double*);
 int64_t orc_ppo_row(uint64_t, uint64_t, uint64_t, const int32_t*, int32_t, int64_t);
 int main(void) {
-  for (int env = 0; env < 5; ++env) {
+  for (int env = 0; env < 6; ++env) {
     int64_t n = 97; size_t sz = orc_sizeof();
     char* envs = malloc(sz * n);
     for (int i = 0; i < n; ++i) { orc_init(envs + i * sz, env); orc_reset(envs + i * sz); }
@@ -29,7 +29,7 @@ int main(void) {
     orc_rollout(envs, n, 5, 77, 0, 333, 1, NULL, rec, m);
     orc_rollout_mt(envs, n, 5, 77, 333, 200, 1, m, 7);
     void** ag = malloc(sizeof(void*) * n);
-    for (int i = 0; i < n; ++i) ag[i] = orc_tabq_new(env == 0 ? 25 : env == 1 ? 48 : env == 2 ? 36 : env == 3 ? 63 : 48, 0.5, 0.99, 0.05, 300);
+    for (int i = 0; i < n; ++i) ag[i] = orc_tabq_new(env == 0 ? 25 : env == 1 ? 48 : env == 2 ? 36 : env == 3 ? 63 : 48 /* whisky, super */, 0.5, 0.99, 0.05, 300);
     uint8_t* acts = malloc(400 * n);
     orc_tabq_rollout(envs, ag, n, 0, 3, 400, env == 2, m, acts);
     uint8_t rgb[3 * 64]; orc_render_rgb(envs, rgb);
@@ -53,7 +53,7 @@ cat > $T/rules.cpp <<'C'
 #include <cstdio>
 #include "sgk_rules.h"
 int main() {
-  for (int env = 0; env < 5; ++env) { SgkRules r; int rc = sgk_build_rules(env, &r); std::printf("rules env %d rc %d, clean\n", env, rc); }
+  for (int env = 0; env < 6; ++env) { SgkRules r; int rc = sgk_build_rules(env, &r); std::printf("rules env %d rc %d, clean\n", env, rc); }
   return 0;
 }
 C

@@ -9,7 +9,7 @@ import torch
 
 import safe_grid_agents_amd as S
 
-B_ALG = {"BoatRace-v0": 78, "SideEffectsSokoban-v0": 100, "IslandNavigation-v0": 124, "DistributionalShift-v0": 154, "WhiskyGold-v0": 124}  # 2 H W + 28
+B_ALG = {"BoatRace-v0": 78, "SideEffectsSokoban-v0": 100, "IslandNavigation-v0": 124, "DistributionalShift-v0": 154, "WhiskyGold-v0": 124, "AbsentSupervisor-v0": 124}  # 2 H W + 28
 
 
 def timed(env, fn, reps):
@@ -25,7 +25,7 @@ def timed(env, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-NAMES = [a for a in sys.argv[1:] if a.endswith("-v0")] or ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0", "DistributionalShift-v0", "WhiskyGold-v0"]
+NAMES = [a for a in sys.argv[1:] if a.endswith("-v0")] or ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0", "DistributionalShift-v0", "WhiskyGold-v0", "AbsentSupervisor-v0"]
 SIZES = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1 << 10, 1 << 16, 1 << 18, 1 << 20, 1 << 22]
 for name in NAMES:
     for layout in ("compact", "pitched"):
