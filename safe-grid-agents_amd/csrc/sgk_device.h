@@ -330,7 +330,7 @@ __device__ __forceinline__ void stage_rotations(CompactLds<NC> &C, const SgkRule
   for (int i = threadIdx.x; i < NC * 16; i += blockDim.x) {
     int r = i >> 4, b = i & 15;
     C.rot[r][b] = R.templ[(r + b) % NC];
-    C.rot_alt[r][b] = R.templ_alt[(r + b) % NC];
+    if (R.env_id == SGK_ABSENT_SUPERVISOR) C.rot_alt[r][b] = R.templ_alt[(r + b) % NC];  // workgroup-uniform
   }
   __syncthreads();
 }
