@@ -398,6 +398,10 @@ def main():
     golden_train_ppo("train_boat_ppo_cnn_seed9_cheat.json",
                      ["-S", "9", "-E", "3", "-EE", "2", "-V", "110", "-EV", "0", "-C", "-D", "0.9", "boat", "ppo-cnn", "-l", "0.002",
                       "-r", "3", "-e", "4", "-b", "16", "-ch", "3", "-c", "0.1", "-eb", "0.02", "-cc", "0.5"])
+    # PPO on WhiskyGold with --cheat: gather_rollout stores the action the env executed (policy_base.py:147-154)
+    golden_train_ppo("train_whisky_ppo_mlp_seed2_cheat.json",
+                     ["-S", "2", "-E", "5", "-EE", "3", "-V", "110", "-EV", "0", "-C", "whisky", "ppo-mlp", "-l", "0.001", "-r", "1",
+                      "-e", "4", "-b", "32", "-hd", "24"])  # -r 1: the reference cannot stack rollouts of different lengths
     # the reference tree must be left untouched
     leaked = [os.path.join(d, f) for d, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
     assert not leaked, leaked

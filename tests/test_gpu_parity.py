@@ -214,7 +214,8 @@ def test_single_env_train_reproduces_reference_run_on_gpu(golden_dir, name):
     assert out["Q"] == g["final_Q"]
 
 
-@pytest.mark.parametrize("name", ["train_boat_ppo_mlp_seed5.json", "train_boat_ppo_cnn_seed9_cheat.json"])
+@pytest.mark.parametrize("name", ["train_boat_ppo_mlp_seed5.json", "train_boat_ppo_cnn_seed9_cheat.json",
+                                  "train_whisky_ppo_mlp_seed2_cheat.json"])
 def test_single_env_ppo_train_reproduces_reference_run_on_gpu(golden_dir, name):
     """The reference's PPO run (CPU torch networks, as in the fixture) with the HIP-backed env in place of the oracle's."""
     from test_host_golden import _same, run_ppo_golden

@@ -342,7 +342,8 @@ def run_ppo_golden(g, env_factory):
             "env": envs[0], "next_randint": int(torch.randint(1 << 30, (1,)).item()), "history": history}
 
 
-@pytest.mark.parametrize("name", ["train_boat_ppo_mlp_seed5.json", "train_boat_ppo_cnn_seed9_cheat.json"])
+@pytest.mark.parametrize("name", ["train_boat_ppo_mlp_seed5.json", "train_boat_ppo_cnn_seed9_cheat.json",
+                                  "train_whisky_ppo_mlp_seed2_cheat.json"])
 def test_ppo_train_reproduces_reference_run(golden_dir, name):
     """Seeded CPU run of train() with the PPO agents == the reference's own run: same actions (torch Categorical draws),
     same losses/entropies written per epoch, same final weights, same number of torch RNG draws."""
