@@ -879,8 +879,23 @@ int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat) {
   if (n_steps == 0) return SGK_OK;
   sgk::Shard &s = h->sh;
   const size_t lds_need = sgk::tabq_rollout_lds_bytes(s);
-  static const bool force_hbm = getenv("SGK_TABQ_HBM") != nullptr;  // A/B switch: HBM-resident rows for every env
-  if (!force_hbm && lds_need != 0 && lds_need <= 160u * 1024u) {
+  static const bool force_hbm = getenv("SGK_TABQ_HBM") != nullptr;  // A/B switches: one kernel for every env that allows it
+  static const bool force_lds = getenv("SGK_TABQ_LDS") != nullptr;
+  bool use_lds = lds_need != 0 && lds_need <= 160u * 1024u;
+  if (use_lds && !force_lds) {
+    // The LDS-resident kernel runs in rounds of n_cus * per_cu workgroups of 64 agents. With big tables (<= 3 workgroups per
+    // CU) a second round costs a whole ~0.9 us, while the HBM-resident kernel serves every agent in one wave of workgroups
+    // and its rows stay in L2 / MALL as long as all tables together are small: measured ahead by 25-35 % exactly there
+    // (IslandNavigation 65 536 agents 1.30 vs 1.75 us per step, DistributionalShift 49 152 / 65 536: 1.26 / 1.36 vs 1.73 /
+    // 1.79; profiles/r01/bench_tabq.log), behind everywhere else.
+    const int per_cu = (int)((160u * 1024u) / lds_need);
+    const int64_t groups = (s.n + 63) / 64, slots = (int64_t)s.n_cus * per_cu;
+    const int64_t table_bytes = s.n * (int64_t)s.n_states * 4 * (int64_t)sizeof(double);
+    const int64_t fits = per_cu <= 2 ? (270ll << 20) : (140ll << 20);  // two resident waves per CU lose earlier (lava: 1.9-2.7 vs
+                                                                       // 2.6-3.5 us up to 131 072 agents)
+    if (per_cu <= 3 && groups > slots && table_bytes <= fits) use_lds = false;
+  }
+  if (!force_hbm && use_lds) {
     SGK_HIP(sgk::launch_tabq_rollout(s, q->tq, n_steps, cheat, h->stream));
     SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));  // materialise the boards of the final states
     q->tq.t_agent += n_steps;

@@ -379,6 +379,24 @@ def test_tabq_stepwise_kernels_bit_exact(name, cheat):
     agent.close(); env.close()
 
 
+def test_tabq_rollout_picks_the_hbm_resident_kernel_at_mid_sizes_and_stays_bit_exact():
+    """65 536 IslandNavigation agents: the LDS-resident kernel would need two rounds of workgroups, so sgk_tabq_rollout runs the
+    HBM-resident one (tables still fit L2 / MALL). Same arithmetic: state, metrics and a sample of the f64 tables equal the
+    oracle's bit for bit."""
+    _torch()
+    name, n, steps, seed = "IslandNavigation-v0", 65536, 90, 5
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    agent = S.BatchedTabularQAgent(env, _tabq_args())
+    agent.rollout(steps)
+    orc, agents, m, _ = _oracle_tabq(name, n, steps, seed, False)
+    assert_same_state(env, orc, "tabq mid-size")
+    want = m.copy()
+    want[O.M_STEPS] = n * steps
+    assert env.metrics().tolist() == want.tolist()
+    _assert_tables_equal(env, agent, orc, agents)
+    agent.close(); env.close()
+
+
 def test_tabq_rollout_sokoban_hbm_resident_kernel_matches():
     _torch()
     name, n, steps, seed = "SideEffectsSokoban-v0", 64, 240, 3

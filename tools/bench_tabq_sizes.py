@@ -9,7 +9,7 @@ tag = "hbm" if os.environ.get("SGK_TABQ_HBM") else "lds"
 names = [a for a in sys.argv[1:] if a.endswith("-v0")] or ["IslandNavigation-v0", "BoatRace-v0", "DistributionalShift-v0",
                                                            "WhiskyGold-v0", "AbsentSupervisor-v0"]  # the last two: HBM-resident rows
 for name in names:
-    for n in (4096, 16384, 65536, 262144, 1048576):
+    for n in ([int(x) for x in os.environ["SGK_BENCH_SIZES"].split(",")] if os.environ.get("SGK_BENCH_SIZES") else (4096, 16384, 65536, 262144, 1048576)):
         args = types.SimpleNamespace(lr=0.5, discount=0.99, epsilon=0.01, epsilon_anneal=100000)
         env = S.BatchedGridworldEnv(name, n, seed=0x5AFE)
         agent = S.BatchedTabularQAgent(env, args)
