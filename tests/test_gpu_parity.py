@@ -117,9 +117,12 @@ def test_random_rollouts_stepwise_graph_and_fused_agree_with_oracle(name, layout
     stepwise.close(); fused.close()
 
 
-def test_sharding_reproduces_the_unsharded_batch():
+@pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "WhiskyGold-v0", "AbsentSupervisor-v0"])
+def test_sharding_reproduces_the_unsharded_batch(name):
+    """Contiguous env-id blocks with env_index_base reproduce the unsharded batch: the action stream AND the envs' own draws
+    (WhiskyGold's replaced actions, AbsentSupervisor's coins) are keyed by the global env index."""
     _torch()
-    name, n, seed = "SideEffectsSokoban-v0", 2048, 11
+    n, seed = 2048, 11
     whole = S.BatchedGridworldEnv(name, n, seed=seed)
     whole.step_random(137, auto_reset=True)
     ref_boards = whole.boards_host()
