@@ -166,6 +166,20 @@ __device__ __forceinline__ f4 weight_grad_mfma(const float *d, int DS, int row0,
   return acc;
 }
 
+// Column sums on the matrix cores (a bias gradient): S[r] = sum_b d[b][row0 + r] over the LB samples -- the same tile product
+// with a B operand of ones. Lane (col, grp), register r = S[4 grp + r], the same in every column. A 64-iteration serial loop
+// per bias lane (64 dependent LDS reads, two waves busy, fourteen idle) cost 2-3 us per layer.
+__device__ __forceinline__ f4 column_sum_mfma(const float *d, int DS, int row0, int lane) {
+  const int col = lane & 15, grp = lane >> 4;
+  f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  float av[LB / 4];
+#pragma unroll
+  for (int s = 0; s < LB / 4; ++s) av[s] = d[(4 * s + grp) * DS + row0 + col];
+#pragma unroll
+  for (int s = 0; s < LB / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], 1.0f, acc, 0, 0, 0);
+  return acc;
+}
+
 __device__ __forceinline__ float block_sum(float x, float *scratch) {  // scratch: LWG / 64 floats
   x = __ockl_wfred_add_f32(x);
   __syncthreads();
@@ -248,6 +262,8 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   constexpr int KP = (K0 + 3) & ~3;  // row stride of the board matrices (padding columns hold zeros)
   const LearnLds L = carve(learn_smem, KP, H);
   const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6, col = lane & 15, grp = lane >> 4;
+  constexpr int MT = (H + 15) / 16, KT1 = (K0 + 15) / 16;  // 16-wide tiles along neurons / along board cells
 
   // ---- minibatch: uniform with replacement over the stored transitions (contain.py:19-22), counter RNG ----
   if (t < LB) {
@@ -320,60 +336,56 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   // ---- backward; every lane keeps the gradients of the parameters it owns in registers ----------------------------
   // dL/dh2 = relu'(h2) * (dq W3) -> C   (dense_layer with K = 4, "wt" = W3 [4][H])
   dense_layer<4, H>(L.q, 4, L.w3, nullptr, L.C, false, L.Bq);
-  // W3 [4][H]: lane k < H owns column k of all four rows; b3: lanes H .. H + 3
-  f4 gw3 = {0.0f, 0.0f, 0.0f, 0.0f};
-  float gb3 = 0.0f;
-  if (t < H) {
-    for (int b = 0; b < LB; ++b) {
-      const f4 dv = *reinterpret_cast<const f4 *>(L.q + b * 4);
-      const float hv = L.Bq[b * H + t];
-      gw3 = __builtin_elementwise_fma(dv, (f4){hv, hv, hv, hv}, gw3);
-    }
-  } else if (t < H + 4) {
-    for (int b = 0; b < LB; ++b) gb3 += L.q[b * 4 + (t - H)];
-  }
+  // W3 [4][H] on the matrix cores: wave w < MT takes the 16 columns k = 16 w .. of dq^T h2 (A = dq [b][4]: the tile's rows
+  // 4 .. 15 are neighbouring samples' values and are dropped); the lanes of group 0 hold the four actions of column k.
+  // b3 = column sums of dq: wave MT, lane 0 holds all four.
+  f4 gw3 = {0.0f, 0.0f, 0.0f, 0.0f}, gb3 = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (wave < MT) gw3 = weight_grad_mfma(L.q, 4, 0, L.Bq, H, 16 * wave, lane);
+  else if (wave == MT) gb3 = column_sum_mfma(L.q, 4, 0, lane);
+  const bool own_w3 = wave < MT && grp == 0 && 16 * wave + col < H;
+  const bool own_b3 = wave == MT && lane == 0;
+  if (!own_w3) gw3 = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+  if (!own_b3) gb3 = (f4){0.0f, 0.0f, 0.0f, 0.0f};
   __syncthreads();
   // dL/dh1 = relu'(h1) * (dh2 W2) -> D   ("wt" = W2 as it is)
   dense_layer<H, H>(L.C, H, L.ST, nullptr, L.D, false, L.A);
   // W2 [H][H] in 16 x 16 MFMA tiles dealt round-robin to the 16 waves (tile = (neuron tile, input tile)); the gradients stay in
-  // the C layout: lane (col, grp), register r <-> dW2[j0 + 4 grp + r][k0 + col]. b2[j]: lanes LWG - 1 - j.
-  constexpr int MT = (H + 15) / 16, KT1 = (K0 + 15) / 16;  // 16-wide tiles along neurons / along board cells
-  constexpr int N2 = (MT * MT + LWG / 64 - 1) / (LWG / 64), N1 = (MT * KT1 + LWG / 64 - 1) / (LWG / 64);  // tiles per wave
-  const int lane = t & 63, wave = t >> 6, col = lane & 15, grp = lane >> 4;
+  // the C layout: lane (col, grp), register r <-> dW2[j0 + 4 grp + r][k0 + col]. MT more tiles are b2's column sums of dL/dh2
+  // (rows j0 + 4 grp + r, the same in every column: the lanes of column 0 own them).
+  constexpr int T2 = MT * MT + MT, T1 = MT * KT1 + MT;
+  constexpr int N2 = (T2 + LWG / 64 - 1) / (LWG / 64), N1 = (T1 + LWG / 64 - 1) / (LWG / 64);  // tiles per wave
   f4 gw2[N2];
-  float gb2 = 0.0f;
 #pragma unroll
   for (int i = 0; i < N2; ++i) {
     const int tile = wave + i * (LWG / 64);
     gw2[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
     if (tile < MT * MT) gw2[i] = weight_grad_mfma(L.C, H, 16 * (tile / MT), L.A, H, 16 * (tile % MT), lane);
+    else if (tile < T2) gw2[i] = column_sum_mfma(L.C, H, 16 * (tile - MT * MT), lane);
   }
-  if (LWG - 1 - t < H)
-    for (int b = 0; b < LB; ++b) gb2 += L.C[b * H + (LWG - 1 - t)];
   __syncthreads();
   // W1 [H][K0] the same way (columns = board cells; cells >= K0 of the last tile are computed from what lies behind the
-  // row in LDS and dropped); b1[j]: lanes LWG - 1 - j
+  // row in LDS and dropped), then b1's column sums of dL/dh1
   f4 gw1[N1];
-  float gb1 = 0.0f;
 #pragma unroll
   for (int i = 0; i < N1; ++i) {
     const int tile = wave + i * (LWG / 64);
     gw1[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
     if (tile < MT * KT1) gw1[i] = weight_grad_mfma(L.D, H, 16 * (tile / KT1), L.S, KP, 16 * (tile % KT1), lane);
+    else if (tile < T1) gw1[i] = column_sum_mfma(L.D, H, 16 * (tile - MT * KT1), lane);
   }
-  if (LWG - 1 - t < H)
-    for (int b = 0; b < LB; ++b) gb1 += L.D[b * H + (LWG - 1 - t)];
   // ---- clip_grad_norm_(max_norm): coefficient from the global 2-norm of all gradients -----------------------------
-  float ss = gb3 * gb3 + gb2 * gb2 + gb1 * gb1;
+  float ss = 0.0f;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) ss = fmaf(gw3[c], gw3[c], ss);
+  for (int c = 0; c < 4; ++c) ss = fmaf(gw3[c], gw3[c], fmaf(gb3[c], gb3[c], ss));
 #pragma unroll
   for (int i = 0; i < N2; ++i) {
     const int tile = wave + i * (LWG / 64);
-    const int j = 16 * (tile / MT) + 4 * grp, k = 16 * (tile % MT) + col;
+    const bool bias = tile >= MT * MT;
+    const int j = 16 * (bias ? tile - MT * MT : tile / MT) + 4 * grp, k = bias ? col : 16 * (tile % MT) + col;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool live = tile < MT * MT && j + r < H && k < H;  // rows / columns past H belong to no parameter
+      // rows / columns past H belong to no parameter; a bias tile counts once, in its column 0
+      const bool live = tile < T2 && j + r < H && (bias ? col == 0 : k < H);
       gw2[i][r] = live ? gw2[i][r] : 0.0f;
       ss = fmaf(gw2[i][r], gw2[i][r], ss);
     }
@@ -381,10 +393,11 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
 #pragma unroll
   for (int i = 0; i < N1; ++i) {
     const int tile = wave + i * (LWG / 64);
-    const int j = 16 * (tile / KT1) + 4 * grp, k = 16 * (tile % KT1) + col;
+    const bool bias = tile >= MT * KT1;
+    const int j = 16 * (bias ? tile - MT * KT1 : tile / KT1) + 4 * grp, k = bias ? col : 16 * (tile % KT1) + col;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool live = tile < MT * KT1 && j + r < H && k < K0;
+      const bool live = tile < T1 && j + r < H && (bias ? col == 0 : k < K0);
       gw1[i][r] = live ? gw1[i][r] : 0.0f;
       ss = fmaf(gw1[i][r], gw1[i][r], ss);
     }
@@ -406,30 +419,24 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   ac.lr_bc1 = L.scratch[16];
   ac.bc2_sqrt = L.scratch[17];
   ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
-  if (t < H) {  // W3 column t (stride H between the four rows), W3^T row t
+  if (own_w3) {  // W3 column k (stride H between the four rows), W3^T row k
+    const int k = 16 * wave + col;
     f4 nw;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = r * H + t;
+      const int i = r * H + k;
       float m = a.m[4][i], v = a.v[4][i], x = a.vmax[4][i];
       nw[r] = adam_scalar(a.w3[i], m, v, x, gw3[r] * coef, ac);
       a.w3[i] = nw[r]; a.m[4][i] = m; a.v[4][i] = v; a.vmax[4][i] = x;
     }
-    *reinterpret_cast<f4 *>(a.w3t + 4 * t) = nw;
-  } else if (t < H + 4) {
-    const int i = t - H;
-    float m = a.m[5][i], v = a.v[5][i], x = a.vmax[5][i];
-    a.b3[i] = adam_scalar(a.b3[i], m, v, x, gb3 * coef, ac);
-    a.m[5][i] = m; a.v[5][i] = v; a.vmax[5][i] = x;
-  }
-  if (LWG - 1 - t < H) {  // the bias lanes
-    const int i = LWG - 1 - t;
-    float m = a.m[3][i], v = a.v[3][i], x = a.vmax[3][i];
-    a.b2[i] = adam_scalar(a.b2[i], m, v, x, gb2 * coef, ac);
-    a.m[3][i] = m; a.v[3][i] = v; a.vmax[3][i] = x;
-    m = a.m[1][i]; v = a.v[1][i]; x = a.vmax[1][i];
-    a.b1[i] = adam_scalar(a.b1[i], m, v, x, gb1 * coef, ac);
-    a.m[1][i] = m; a.v[1][i] = v; a.vmax[1][i] = x;
+    *reinterpret_cast<f4 *>(a.w3t + 4 * k) = nw;
+  } else if (own_b3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float m = a.m[5][i], v = a.v[5][i], x = a.vmax[5][i];
+      a.b3[i] = adam_scalar(a.b3[i], m, v, x, gb3[i] * coef, ac);
+      a.m[5][i] = m; a.v[5][i] = v; a.vmax[5][i] = x;
+    }
   }
   // the weight tiles: element (j + r, k) for r = 0..3 -- 16 consecutive k across the lanes of a group; the transposed copy
   // takes the four r of a lane as one 16-byte row piece
@@ -437,7 +444,10 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   for (int i = 0; i < N2; ++i) {
     const int tile = wave + i * (LWG / 64);
     const int j = 16 * (tile / MT) + 4 * grp, k = 16 * (tile % MT) + col;
-    if (tile < MT * MT && j < H && k < H) {  // H % 4 == 0: the four rows j .. j + 3 are all inside
+    if (tile >= MT * MT && tile < T2) {  // b2 rows 16 (tile - MT MT) + 4 grp + r, owned by the lanes of column 0
+      const int jb = 16 * (tile - MT * MT) + 4 * grp;
+      if (col == 0 && jb < H) adam_row(a.b2 + jb, a.m[3] + jb, a.v[3] + jb, a.vmax[3] + jb, gw2[i] * coef, ac);
+    } else if (tile < MT * MT && j < H && k < H) {  // H % 4 == 0: the four rows j .. j + 3 are all inside
       f4 nw;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -453,7 +463,10 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   for (int i = 0; i < N1; ++i) {
     const int tile = wave + i * (LWG / 64);
     const int j = 16 * (tile / KT1) + 4 * grp, k = 16 * (tile % KT1) + col;
-    if (tile < MT * KT1 && j < H && k < K0) {
+    if (tile >= MT * KT1 && tile < T1) {
+      const int jb = 16 * (tile - MT * KT1) + 4 * grp;
+      if (col == 0 && jb < H) adam_row(a.b1 + jb, a.m[1] + jb, a.v[1] + jb, a.vmax[1] + jb, gw1[i] * coef, ac);
+    } else if (tile < MT * KT1 && j < H && k < K0) {
       f4 nw;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -567,7 +580,8 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
   const PpoLds L = carve_ppo<KP, H>(learn_smem);
   const int t0 = threadIdx.x, B = a.batch;
   constexpr int MT = (H + 15) / 16, KT1 = (K0 + 15) / 16;
-  constexpr int N2 = (MT * MT + LWG / 64 - 1) / (LWG / 64), N1 = (MT * KT1 + LWG / 64 - 1) / (LWG / 64);
+  constexpr int T2 = MT * MT + MT, T1 = MT * KT1 + MT;  // weight tiles + the bias tiles (column sums)
+  constexpr int N2 = (T2 + LWG / 64 - 1) / (LWG / 64), N1 = (T1 + LWG / 64 - 1) / (LWG / 64);
   const long long step0 = *a.step;
   {
     const int t = t0;
@@ -580,6 +594,49 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
   if (t < 3) L.bh[5 + t] = 0.0f;
   }
 
+  // The rows of an epoch depend only on (seed, Adam step, lengths): they are drawn one epoch AHEAD -- behind the backward pass,
+  // in front of the Adam stores -- so that the three dependent memory round trips (lengths, then action / return, then the
+  // board gather's addresses) are off the critical path. `t`, `lane`: this lane's ids (laundered per epoch, see below).
+  auto draw_rows = [&](int e_ix, long long e_step, int t, int lane) {
+  // ---- minibatch: a row = a (t, env) pair inside that env's episode, uniform with replacement. Each sample tries 16
+  // candidates per round (16 lanes), the first valid one in lane order wins; another round only if all 16 miss. ----
+  {
+    const int b = t >> 4, c = t & 15;  // 64 samples x 16 candidate lanes
+    int tt = 0;
+    long long nn = 0;
+    bool found = a.rows != nullptr;
+    if (found && b < B) {
+      long long row = a.rows[(long long)e_ix * B + b];
+      row = row < 0 ? 0 : (row >= (long long)a.T * a.N ? (long long)a.T * a.N - 1 : row);  // a bad row must not leave the rollout
+      tt = (int)(row / a.N);
+      nn = row - (long long)tt * a.N;
+    }
+    for (int round = 0; round < 64 && !found; ++round) {
+      uint32_t x[4];
+      philox4x32_10((uint32_t)(b * 16 + c), (uint32_t)round, (uint32_t)e_step, 5u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
+      const long long n_c = (long long)__umul64hi(((unsigned long long)x[0] << 32) | x[1], (unsigned long long)a.N);
+      const int t_c = (int)__umulhi(x[2], (uint32_t)a.T);
+      const bool ok = t_c < a.lengths[n_c];
+      const unsigned long long mask = __ballot(ok);
+      const unsigned int mine = (unsigned int)((mask >> (lane & 48)) & 0xffffull);  // this sample's 16 candidate lanes
+      if (mine) {
+        const int win = (lane & 48) + __ffs(mine) - 1;
+        tt = __shfl(t_c, win, 64);
+        nn = __shfl((int)n_c, win, 64);  // N < 2^31 (checked by the launcher)
+        found = true;
+      }
+    }
+    if (c == 0) {
+      const long long row = (long long)tt * a.N + nn;
+      L.act[b] = b < B ? (int)(a.actions[row] & 3) : 0;
+      L.ret[b] = b < B ? a.returns[nn * a.T + tt] : 0.0f;
+      reinterpret_cast<long long *>(L.oout)[b] = row;  // parked for the gather at the top of that epoch (oout is free until then)
+      if (a.rows_out && b < B) a.rows_out[(long long)e_ix * B + b] = row;
+    }
+  }
+  };
+  draw_rows(0, step0, t0, t0 & 63);
+
   for (int epoch = 0; epoch < a.n_epochs; ++epoch) {
     const long long step = step0 + epoch;  // Adam steps done before this epoch; keys the minibatch draws
     // the lane id is re-derived through an opaque move every epoch: with a loop-invariant id the compiler hoists the ~100
@@ -588,42 +645,6 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
     asm volatile("" : "+v"(t));
     const int lane = t & 63, wave = t >> 6, col = lane & 15, grp = lane >> 4;
     __syncthreads();                       // the previous epoch's update is complete before anything of it is re-read
-    // ---- minibatch: a row = a (t, env) pair inside that env's episode, uniform with replacement. Each sample tries 16
-    // candidates per round (16 lanes), the first valid one in lane order wins; another round only if all 16 miss. ----
-    {
-      const int b = t >> 4, c = t & 15;  // 64 samples x 16 candidate lanes
-      int tt = 0;
-      long long nn = 0;
-      bool found = a.rows != nullptr;
-      if (found && b < B) {
-        long long row = a.rows[(long long)epoch * B + b];
-        row = row < 0 ? 0 : (row >= (long long)a.T * a.N ? (long long)a.T * a.N - 1 : row);  // a bad row must not leave the rollout
-        tt = (int)(row / a.N);
-        nn = row - (long long)tt * a.N;
-      }
-      for (int round = 0; round < 64 && !found; ++round) {
-        uint32_t x[4];
-        philox4x32_10((uint32_t)(b * 16 + c), (uint32_t)round, (uint32_t)step, 5u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
-        const long long n_c = (long long)__umul64hi(((unsigned long long)x[0] << 32) | x[1], (unsigned long long)a.N);
-        const int t_c = (int)__umulhi(x[2], (uint32_t)a.T);
-        const bool ok = t_c < a.lengths[n_c];
-        const unsigned long long mask = __ballot(ok);
-        const unsigned int mine = (unsigned int)((mask >> (lane & 48)) & 0xffffull);  // this sample's 16 candidate lanes
-        if (mine) {
-          const int win = (lane & 48) + __ffs(mine) - 1;
-          tt = __shfl(t_c, win, 64);
-          nn = __shfl((int)n_c, win, 64);  // N < 2^31 (checked by the launcher)
-          found = true;
-        }
-      }
-      if (c == 0) {
-        const long long row = (long long)tt * a.N + nn;
-        L.act[b] = b < B ? (int)(a.actions[row] & 3) : 0;
-        L.ret[b] = b < B ? a.returns[nn * a.T + tt] : 0.0f;
-        reinterpret_cast<long long *>(L.dout)[b] = row;  // parked for the gather below (dout is rewritten later)
-        if (a.rows_out && b < B) a.rows_out[(long long)epoch * B + b] = row;
-      }
-    }
     stage(L.ST, a.ow1t, K0 * H);
     stage(L.wh, a.wa, 4 * H);
     stage(L.wh + 4 * H, a.wc, H);
@@ -634,7 +655,7 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
     __syncthreads();
     for (int i = t; i < LB * KP; i += LWG) {
       const int b = i / KP, k = i - b * KP;
-      const long long row = reinterpret_cast<const long long *>(L.dout)[b];
+      const long long row = reinterpret_cast<const long long *>(L.oout)[b];
       L.S[i] = (b < B && k < K0) ? a.states[row * K0 + k] : (int8_t)0;
     }
     __syncthreads();
@@ -713,40 +734,33 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
     __syncthreads();
     // ---- backward ----
     dense_layer<8, H>(L.dout, 8, L.wh, nullptr, L.C, false, L.Bq);  // dL/dh2 = relu'(h2) * (dout W_heads) -> C
-    float gh[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                   // head weights: lane k < H owns column k of the five rows
-    float gbh = 0.0f;                                                // head biases: lanes H .. H + 4
-    if (t < H) {
-      for (int b = 0; b < LB; ++b) {
-        const float hv = L.Bq[b * H + t];
-#pragma unroll
-        for (int o = 0; o < 5; ++o) gh[o] = fmaf(L.dout[b * 8 + o], hv, gh[o]);
-      }
-    } else if (t < H + 5) {
-      for (int b = 0; b < LB; ++b) gbh += L.dout[b * 8 + (t - H)];
-    }
+    // head weights [5][H] on the matrix cores: wave w < MT takes the columns k = 16 w ..; A = dout [b][8], so the tile's rows
+    // 0..3 are the actor (registers of group 0), row 4 the critic (register 0 of group 1), rows 8..15 the next sample's values
+    // (dropped). Head biases = column sums of dout: wave MT (lane 0: actor, lane 16: critic).
+    f4 gh = {0.0f, 0.0f, 0.0f, 0.0f}, gbh = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (wave < MT) gh = weight_grad_mfma(L.dout, 8, 0, L.Bq, H, 16 * wave, lane);
+    else if (wave == MT) gbh = column_sum_mfma(L.dout, 8, 0, lane);
     __syncthreads();
     dense_layer<H, H>(L.C, H, L.ST, nullptr, L.D, false, L.A);  // dL/dh1 -> D
+    // W2 tiles, then MT more tiles with b2's column sums of dL/dh2 (owned by the lanes of column 0); W1 / b1 the same way
     f4 gw2[N2];
-    float gb2 = 0.0f;
 #pragma unroll
     for (int i = 0; i < N2; ++i) {
       const int tile = wave + i * (LWG / 64);
       gw2[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
       if (tile < MT * MT) gw2[i] = weight_grad_mfma(L.C, H, 16 * (tile / MT), L.A, H, 16 * (tile % MT), lane);
+      else if (tile < T2) gw2[i] = column_sum_mfma(L.C, H, 16 * (tile - MT * MT), lane);
     }
-    if (LWG - 1 - t < H)
-      for (int b = 0; b < LB; ++b) gb2 += L.C[b * H + (LWG - 1 - t)];
     __syncthreads();
     f4 gw1[N1];
-    float gb1 = 0.0f;
 #pragma unroll
     for (int i = 0; i < N1; ++i) {
       const int tile = wave + i * (LWG / 64);
       gw1[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
       if (tile < MT * KT1) gw1[i] = weight_grad_mfma(L.D, H, 16 * (tile / KT1), L.S, KP, 16 * (tile % KT1), lane);
+      else if (tile < T1) gw1[i] = column_sum_mfma(L.D, H, 16 * (tile - MT * KT1), lane);
     }
-    if (LWG - 1 - t < H)
-      for (int b = 0; b < LB; ++b) gb1 += L.D[b * H + (LWG - 1 - t)];
+    if (epoch + 1 < a.n_epochs) draw_rows(epoch + 1, step + 1, t, lane);  // act / ret / oout are free from here on
     // ---- Adam (torch defaults: no amsgrad, no gradient clipping) ----
     if (t == 0) {
       L.scratch[16] = a.lr / (float)(1.0 - pow((double)a.beta1, (double)(step + 1)));
@@ -757,41 +771,48 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
     ac.lr_bc1 = L.scratch[16];
     ac.bc2_sqrt = L.scratch[17];
     ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
-    if (t < H) {
+    if (wave < MT && 16 * wave + col < H) {
+      const int k = 16 * wave + col;
+      if (grp == 0) {
 #pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        const int e = o * H + t;
-        float m = a.m[4][e], v = a.v[4][e];
-        a.wa[e] = adam_plain(a.wa[e], m, v, gh[o], ac);
-        a.m[4][e] = m; a.v[4][e] = v;
+        for (int o = 0; o < 4; ++o) {
+          const int e = o * H + k;
+          float m = a.m[4][e], v = a.v[4][e];
+          a.wa[e] = adam_plain(a.wa[e], m, v, gh[o], ac);
+          a.m[4][e] = m; a.v[4][e] = v;
+        }
+      } else if (grp == 1) {
+        float m = a.m[6][k], v = a.v[6][k];
+        a.wc[k] = adam_plain(a.wc[k], m, v, gh[0], ac);
+        a.m[6][k] = m; a.v[6][k] = v;
       }
-      float m = a.m[6][t], v = a.v[6][t];
-      a.wc[t] = adam_plain(a.wc[t], m, v, gh[4], ac);
-      a.m[6][t] = m; a.v[6][t] = v;
-    } else if (t < H + 4) {
-      const int e = t - H;
-      float m = a.m[5][e], v = a.v[5][e];
-      a.ba[e] = adam_plain(a.ba[e], m, v, gbh, ac);
-      a.m[5][e] = m; a.v[5][e] = v;
-    } else if (t == H + 4) {
+    } else if (wave == MT && lane == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float m = a.m[5][e], v = a.v[5][e];
+        a.ba[e] = adam_plain(a.ba[e], m, v, gbh[e], ac);
+        a.m[5][e] = m; a.v[5][e] = v;
+      }
+    } else if (wave == MT && lane == 16) {
       float m = a.m[7][0], v = a.v[7][0];
-      a.bc[0] = adam_plain(a.bc[0], m, v, gbh, ac);
+      a.bc[0] = adam_plain(a.bc[0], m, v, gbh[0], ac);
       a.m[7][0] = m; a.v[7][0] = v;
-    }
-    if (LWG - 1 - t < H) {
-      const int e = LWG - 1 - t;
-      float m = a.m[3][e], v = a.v[3][e];
-      a.b2[e] = adam_plain(a.b2[e], m, v, gb2, ac);
-      a.m[3][e] = m; a.v[3][e] = v;
-      m = a.m[1][e]; v = a.v[1][e];
-      a.b1[e] = adam_plain(a.b1[e], m, v, gb1, ac);
-      a.m[1][e] = m; a.v[1][e] = v;
     }
 #pragma unroll
     for (int i = 0; i < N2; ++i) {
       const int tile = wave + i * (LWG / 64);
       const int j = 16 * (tile / MT) + 4 * grp, k = 16 * (tile % MT) + col;
-      if (tile < MT * MT && j < H && k < H) {
+      if (tile >= MT * MT && tile < T2) {
+        const int jb = 16 * (tile - MT * MT) + 4 * grp;
+        if (col == 0 && jb < H) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float m = a.m[3][jb + r], v = a.v[3][jb + r];
+            a.b2[jb + r] = adam_plain(a.b2[jb + r], m, v, gw2[i][r], ac);
+            a.m[3][jb + r] = m; a.v[3][jb + r] = v;
+          }
+        }
+      } else if (tile < MT * MT && j < H && k < H) {
         f4 nw;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -807,7 +828,17 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
     for (int i = 0; i < N1; ++i) {
       const int tile = wave + i * (LWG / 64);
       const int j = 16 * (tile / KT1) + 4 * grp, k = 16 * (tile % KT1) + col;
-      if (tile < MT * KT1 && j < H && k < K0) {
+      if (tile >= MT * KT1 && tile < T1) {
+        const int jb = 16 * (tile - MT * KT1) + 4 * grp;
+        if (col == 0 && jb < H) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float m = a.m[1][jb + r], v = a.v[1][jb + r];
+            a.b1[jb + r] = adam_plain(a.b1[jb + r], m, v, gw1[i][r], ac);
+            a.m[1][jb + r] = m; a.v[1][jb + r] = v;
+          }
+        }
+      } else if (tile < MT * KT1 && j < H && k < K0) {
         f4 nw;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -819,7 +850,8 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
         *reinterpret_cast<f4 *>(a.w1t + (size_t)k * H + j) = nw;
       }
     }
-    __threadfence();  // the next epoch stages these weights from global memory
+    // no device-scope fence: the next epoch's staging loads are ordered behind these stores by the workgroup barrier at the top
+    // of the loop (same CU, one L1), and nobody else reads the parameters before the kernel ends (it cost ~4 us per epoch)
   }
   __syncthreads();
   if (t0 == 0) *a.step = step0 + a.n_epochs;
