@@ -50,6 +50,22 @@ __device__ __forceinline__ void stage(float *dst, const float *__restrict__ src,
   for (int i = threadIdx.x * 4; i < n; i += LWG * 4) *reinterpret_cast<f4 *>(dst + i) = *reinterpret_cast<const f4 *>(src + i);
 }
 
+// Row stride of a staged weight matrix [rows][H]: H padded so that stride % 32 == 8. The MFMA A operand of dense_layer is
+// wt[(4 u + grp) * stride + n0 + col] over the lanes (col = 0..15, grp = 0..3): with stride 100 the four groups start 4 banks
+// apart and overlap (up to 4 lanes per bank: four LDS passes), with stride % 32 == 8 they tile the 32 banks exactly (two
+// lanes per bank, the minimum for 64 lanes).
+constexpr int weight_stride(int h) { return h + (40 - h % 32) % 32; }
+
+// stage() for a [rows][H] matrix into rows of weight_stride(H) floats
+template <int H>
+__device__ __forceinline__ void stage_rows(float *dst, const float *__restrict__ src, int rows) {
+  constexpr int WS = weight_stride(H);
+  for (int i = threadIdx.x * 4; i < rows * H; i += LWG * 4) {
+    const int r = i / H, c = i - r * H;
+    *reinterpret_cast<f4 *>(dst + r * WS + c) = *reinterpret_cast<const f4 *>(src + i);
+  }
+}
+
 __device__ __forceinline__ f4 load_x4(const float *row, int k) { return *reinterpret_cast<const f4 *>(row + k); }
 __device__ __forceinline__ f4 load_x4(const int8_t *row, int k) {  // four board cells -> four floats
   const uint32_t w = *reinterpret_cast<const uint32_t *>(row + k);
@@ -66,13 +82,15 @@ __device__ __forceinline__ float load_x1(const int8_t *row, int k) { return (flo
 // 100 x 100 layer on LDS bandwidth alone. The ceil(H / 16) x 4 output tiles are dealt round-robin to the 16 waves.
 // KP = row stride of `in` in elements; `mask` zeroes out[b][n] where mask[b][n] <= 0 (ReLU'); neuron rows >= H of the last
 // tile are computed from whatever lies behind the row (still inside LDS) and dropped.
-template <int K, int H, class T>
+template <int K, int H, int WST = H, class T>
 __device__ __forceinline__ void dense_layer(const T *in, int KP, const float *wt, const float *bias, float *out, bool relu,
-                                            const float *mask) {
+                                            const float *mask) {  // WST = row stride of wt
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const int col = lane & 15, grp = lane >> 4;
   constexpr int MT = (H + 15) / 16, KS = (K + 3) / 4;  // neuron tiles, k-steps
   constexpr int CH = KS < 8 ? KS : 8;                    // k-steps whose operands are fetched together
+  // (two tiles per wave in flight -- two independent accumulator chains behind one batch of 32 LDS reads -- was slower:
+  // 41.5 -> 44.5 us for the DeepQ step, 653 -> 727 us for 16 PPO epochs)
   for (int tile = wave; tile < MT * (LB / 16); tile += n_waves) {
     const int n0 = 16 * (tile % MT), b0 = 16 * (tile / MT);
     f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -89,11 +107,11 @@ __device__ __forceinline__ void dense_layer(const T *in, int KP, const float *wt
       for (int u = 0; u < CH; ++u) {
         const int k = 4 * (c0 + u) + grp;
         if (4 * (c0 + u) + 3 < K) {  // whole k-step inside K: no guard
-          av[u] = wcol[k * H];
+          av[u] = wcol[k * WST];
           bv[u] = load_x1(xrow, k);
         } else if (4 * (c0 + u) < K) {  // the ragged last k-step
           const int kc = k < K ? k : K - 1;
-          av[u] = k < K ? wcol[kc * H] : 0.0f;
+          av[u] = k < K ? wcol[kc * WST] : 0.0f;
           bv[u] = k < K ? load_x1(xrow, kc) : 0.0f;
         } else {
           av[u] = 0.0f;
@@ -233,7 +251,7 @@ __device__ __forceinline__ LearnLds carve(unsigned char *base, int KP, int H) {
   L.Bq = f; f += LB * H;
   L.C = f; f += LB * H;
   L.D = f; f += LB * H;
-  L.ST = f; f += H * H;
+  L.ST = f; f += H * weight_stride(H);
   L.w3 = f; f += 4 * H;
   L.tw3 = f; f += 4 * H;
   L.b1 = f; f += H;
@@ -280,7 +298,7 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
     L.term[t] = a.terminals[id] ? 1 : 0;
   }
   // the small tensors and the first weight matrix travel meanwhile
-  stage(L.ST, a.tw1t, K0 * H);
+  stage_rows<H>(L.ST, a.tw1t, K0);
   stage(L.w3, a.w3, 4 * H);
   stage(L.tw3, a.tw3, 4 * H);
   stage(L.b1, a.b1, H);
@@ -297,24 +315,24 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   }
   __syncthreads();
   // ---- target network on the successors ----
-  dense_layer<K0, H>(L.S2, KP, L.ST, L.tb1, L.C, true, nullptr);
+  dense_layer<K0, H, weight_stride(H)>(L.S2, KP, L.ST, L.tb1, L.C, true, nullptr);
   __syncthreads();
-  stage(L.ST, a.tw2t, H * H);
+  stage_rows<H>(L.ST, a.tw2t, H);
   __syncthreads();
-  dense_layer<H, H>(L.C, H, L.ST, L.tb2, L.D, true, nullptr);
+  dense_layer<H, H, weight_stride(H)>(L.C, H, L.ST, L.tb2, L.D, true, nullptr);
   __syncthreads();
   head_forward(L.D, H, L.tw3, L.tb3, L.tq);
   // ---- Q-network on the states ----
-  stage(L.ST, a.w1t, K0 * H);
+  stage_rows<H>(L.ST, a.w1t, K0);
   __syncthreads();
-  dense_layer<K0, H>(L.S, KP, L.ST, L.b1, L.A, true, nullptr);
+  dense_layer<K0, H, weight_stride(H)>(L.S, KP, L.ST, L.b1, L.A, true, nullptr);
   __syncthreads();
-  stage(L.ST, a.w2t, H * H);
+  stage_rows<H>(L.ST, a.w2t, H);
   __syncthreads();
-  dense_layer<H, H>(L.A, H, L.ST, L.b2, L.Bq, true, nullptr);
+  dense_layer<H, H, weight_stride(H)>(L.A, H, L.ST, L.b2, L.Bq, true, nullptr);
   __syncthreads();
   head_forward(L.Bq, H, L.w3, L.b3, L.q);
-  stage(L.ST, a.w2, H * H);  // W2 as it is ([j][k]): the back-propagation through layer 2 wants it in this orientation
+  stage_rows<H>(L.ST, a.w2, H);  // W2 as it is ([j][k]): the back-propagation through layer 2 wants it in this orientation
   __syncthreads();
   // ---- loss = mean((q_sa - y)^2) with y = r + discount * max_a' Q_target(s', a') * (1 - terminal); dL/dq on the taken action ----
   float sq = 0.0f;
@@ -348,7 +366,7 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   if (!own_b3) gb3 = (f4){0.0f, 0.0f, 0.0f, 0.0f};
   __syncthreads();
   // dL/dh1 = relu'(h1) * (dh2 W2) -> D   ("wt" = W2 as it is)
-  dense_layer<H, H>(L.C, H, L.ST, nullptr, L.D, false, L.A);
+  dense_layer<H, H, weight_stride(H)>(L.C, H, L.ST, nullptr, L.D, false, L.A);
   // W2 [H][H] in 16 x 16 MFMA tiles dealt round-robin to the 16 waves (tile = (neuron tile, input tile)); the gradients stay in
   // the C layout: lane (col, grp), register r <-> dW2[j0 + 4 grp + r][k0 + col]. MT more tiles are b2's column sums of dL/dh2
   // (rows j0 + 4 grp + r, the same in every column: the lanes of column 0 own them).
@@ -525,7 +543,7 @@ __device__ __forceinline__ PpoLds carve_ppo(unsigned char *base) {
   L.Bq = f; f += LB * H;     // current hidden 2
   L.C = f; f += LB * H;      // old hidden 1, then dL/dh2
   L.D = f; f += LB * H;      // old hidden 2, then dL/dh1
-  L.ST = f; f += H * H;      // the weight matrix of the running phase
+  L.ST = f; f += H * weight_stride(H);  // the weight matrix of the running phase (padded rows)
   L.wh = f; f += 8 * H;      // current heads: rows 0..3 actor, row 4 critic, rows 5..7 zero
   L.owa = f; f += 4 * H;     // old actor
   L.b1 = f; f += H;
@@ -545,7 +563,7 @@ __device__ __forceinline__ PpoLds carve_ppo(unsigned char *base) {
 }
 
 constexpr size_t ppo_lds_bytes(int KP, int H) {
-  return sizeof(float) * ((size_t)4 * LB * H + (size_t)H * H + 12 * H + 4 * H + 12 + LB * 8 + LB * 4 + LB * 8 + LB + 32 + LB) +
+  return sizeof(float) * ((size_t)4 * LB * H + (size_t)H * weight_stride(H) + 12 * H + 4 * H + 12 + LB * 8 + LB * 4 + LB * 8 + LB + 32 + LB) +
          (size_t)LB * KP + 64;
 }
 
@@ -645,7 +663,7 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
     asm volatile("" : "+v"(t));
     const int lane = t & 63, wave = t >> 6, col = lane & 15, grp = lane >> 4;
     __syncthreads();                       // the previous epoch's update is complete before anything of it is re-read
-    stage(L.ST, a.ow1t, K0 * H);
+    stage_rows<H>(L.ST, a.ow1t, K0);
     stage(L.wh, a.wa, 4 * H);
     stage(L.wh + 4 * H, a.wc, H);
     stage(L.b1, a.b1, H);
@@ -660,23 +678,23 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
     }
     __syncthreads();
     // ---- old policy, then current network, on the same states ----
-    dense_layer<K0, H>(L.S, KP, L.ST, L.ob1, L.C, true, nullptr);
+    dense_layer<K0, H, weight_stride(H)>(L.S, KP, L.ST, L.ob1, L.C, true, nullptr);
     __syncthreads();
-    stage(L.ST, a.ow2t, H * H);
+    stage_rows<H>(L.ST, a.ow2t, H);
     __syncthreads();
-    dense_layer<H, H>(L.C, H, L.ST, L.ob2, L.D, true, nullptr);
+    dense_layer<H, H, weight_stride(H)>(L.C, H, L.ST, L.ob2, L.D, true, nullptr);
     __syncthreads();
     heads_forward<4, 4>(L.D, H, L.owa, L.oba, L.oout);
-    stage(L.ST, a.w1t, K0 * H);
+    stage_rows<H>(L.ST, a.w1t, K0);
     __syncthreads();
-    dense_layer<K0, H>(L.S, KP, L.ST, L.b1, L.A, true, nullptr);
+    dense_layer<K0, H, weight_stride(H)>(L.S, KP, L.ST, L.b1, L.A, true, nullptr);
     __syncthreads();
-    stage(L.ST, a.w2t, H * H);
+    stage_rows<H>(L.ST, a.w2t, H);
     __syncthreads();
-    dense_layer<H, H>(L.A, H, L.ST, L.b2, L.Bq, true, nullptr);
+    dense_layer<H, H, weight_stride(H)>(L.A, H, L.ST, L.b2, L.Bq, true, nullptr);
     __syncthreads();
     heads_forward<5, 8>(L.Bq, H, L.wh, L.bh, L.out);
-    stage(L.ST, a.w2, H * H);  // W2 as it is, for the back-propagation
+    stage_rows<H>(L.ST, a.w2, H);  // W2 as it is, for the back-propagation
     __syncthreads();
     // ---- losses and dL/d(logits, value): the 64 samples are the 64 lanes of wave 0, batch statistics by wave reductions ----
     if (wave == 0) {
@@ -741,7 +759,7 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
     if (wave < MT) gh = weight_grad_mfma(L.dout, 8, 0, L.Bq, H, 16 * wave, lane);
     else if (wave == MT) gbh = column_sum_mfma(L.dout, 8, 0, lane);
     __syncthreads();
-    dense_layer<H, H>(L.C, H, L.ST, nullptr, L.D, false, L.A);  // dL/dh1 -> D
+    dense_layer<H, H, weight_stride(H)>(L.C, H, L.ST, nullptr, L.D, false, L.A);  // dL/dh1 -> D
     // W2 tiles, then MT more tiles with b2's column sums of dL/dh2 (owned by the lanes of column 0); W1 / b1 the same way
     f4 gw2[N2];
 #pragma unroll
@@ -898,7 +916,7 @@ hipError_t launch_replay_store(const Shard &sh, int phase, const uint8_t *action
 
 size_t dqn_sgd_lds_bytes(int n_cells, int n_hidden) {
   const size_t kp = (size_t)((n_cells + 3) & ~3), h = (size_t)n_hidden;
-  return sizeof(float) * (4 * LB * h + h * h + 8 * h + 4 * h + 8 + 2 * LB * 4 + LB + 32 + LB + 3 * LB) + 2 * LB * kp + 64;
+  return sizeof(float) * (4 * LB * h + h * (size_t)weight_stride((int)h) + 8 * h + 4 * h + 8 + 2 * LB * 4 + LB + 32 + LB + 3 * LB) + 2 * LB * kp + 64;
 }
 
 hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) {
