@@ -9,8 +9,9 @@ A "step" is one lockstep pass of the hot path over the whole env batch: every en
 RandomAgent action (counter RNG, in-kernel) through the HIP step kernel -- transition, observed reward, hidden
 safety reward, episode bookkeeping, auto-reset, and the successor board MATERIALISED in HBM -- one kernel launch
 per step and GPU, replayed from a hipGraph. Workload = BASELINE.json's metric config: BoatRace, 1 048 576 concurrent
-envs per GPU (weak scaling: the batch shards by env id, one contiguous block per rank, no data-path collective; the
-only exchange is one int64 metrics all-reduce at the end of the timed region).
+envs in the whole job at every GPU count (the batch shards by env id, one contiguous block per rank, no data-path
+collective; the only exchange is one int64 metrics all-reduce at the end of the timed region). At N > 1 a secondary
+object reports the weak-scaling form (1 048 576 envs on every GPU) measured in the same run.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects added.
 """
@@ -107,18 +108,82 @@ def parity_sample(env, env_name, seed, base, total_steps, block=2048):
     return True, checked
 
 
+def chunk_schedule(k):
+    """Chunk sizes `run(k)` issues, in order: GRAPH_CHUNK-step hipGraph replays and one tail."""
+    out = [GRAPH_CHUNK] * (k // GRAPH_CHUNK)
+    if k % GRAPH_CHUNK:
+        out.append(k % GRAPH_CHUNK)
+    return out
+
+
+def timed_steps(env, steps, warmup, barrier, global_metrics):
+    """W untimed warm-up steps, then EXACTLY `steps` lockstep steps + the metrics flush between barrier + synchronize pairs.
+    Every hipGraph the timed region replays is captured and instantiated BEFORE the region (sgk_step_random_prepare for each
+    chunk size of the schedule), and the first HIP event is recorded immediately before the first replay, so neither the
+    host clock nor the device clock sees a capture. Returns (elapsed_s, kernel_ms, BatchMetrics)."""
+    import torch
+
+    stream = env.torch_stream()
+
+    def run(k):
+        for c in chunk_schedule(k):
+            env.step_random(c, auto_reset=True)
+
+    for c in sorted(set(chunk_schedule(warmup) + chunk_schedule(steps))):
+        env.prepare_step_random(c, auto_reset=True)
+    run(warmup)
+    env.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # ---- timed region ---------------------------------------------------------------------------------------------------
+    barrier()
+    torch.cuda.synchronize()
+    env.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run(steps)
+    ev1.record(stream)
+    gm = global_metrics(env)  # syncs the stream; one int64 all-reduce (RCCL over xGMI) when world > 1
+    env.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # ---------------------------------------------------------------------------------------------------------------------
+    return elapsed, ev0.elapsed_time(ev1), gm  # HIP events on the stream the step kernels run on
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks with torch.distributed.run as a CHILD process, before
+    anything in this process has touched the GPU, and exit with its code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--env", default="BoatRace-v0")
-    ap.add_argument("--envs-per-gpu", type=int, default=1 << 20)
+    ap.add_argument("--total-envs", type=int, default=1 << 20,
+                    help="env batch of the whole job, sharded over the GPUs (BASELINE.json: 1 048 576 at every GPU count)")
+    ap.add_argument("--envs-per-gpu", type=int, default=0,
+                    help="weak-scaling form instead: this many envs on EVERY GPU (total = N times it)")
     ap.add_argument("--layout", default=os.environ.get("SGK_BENCH_LAYOUT", "compact"), choices=["pitched", "compact"])
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5AFE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--no-weak-line", action="store_true", help="skip the secondary 1M-envs-per-GPU measurement at N > 1")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))  # nothing here has initialised the GPU yet
 
     import torch
 
@@ -126,7 +191,9 @@ def main():
     from safe_grid_agents_amd import dist as sdist
 
     rank, local_rank, world = sdist.env_from_torchrun()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node == --gpus"
+                 % (args.gpus, world))
     # test-only knobs for exercising the multi-rank control flow on a 1-GPU box: every rank on GPU 0, gloo collectives
     backend = os.environ.get("SGK_BENCH_BACKEND", "nccl")
     if os.environ.get("SGK_BENCH_ONE_DEVICE") == "1":
@@ -136,45 +203,31 @@ def main():
     import torch.distributed as tdist
 
     torch.cuda.set_device(local_rank)
-    n_local = args.envs_per_gpu
-    base = rank * n_local
-    env = S.BatchedGridworldEnv(args.env, n_local, device=local_rank, seed=args.seed, env_index_base=base,
-                                layout=args.layout)
-    stream = env.torch_stream()
-
-    def run(k):
-        done = 0
-        while done < k:
-            c = min(GRAPH_CHUNK, k - done)
-            env.step_random(c, auto_reset=True)
-            done += c
+    weak = args.envs_per_gpu > 0
+    if weak:
+        n_total = args.envs_per_gpu * world
+        base, end = rank * args.envs_per_gpu, (rank + 1) * args.envs_per_gpu
+    else:  # the metric's configuration: ONE batch of --total-envs, contiguous env-id blocks per rank (dist.shard_range)
+        n_total = args.total_envs
+        base, end = sdist.shard_range(n_total, rank, world)
+    n_local = end - base
 
     def barrier():
         if world > 1:
             tdist.barrier()
 
-    run(args.warmup)
-    env.synchronize()
-    # ---- timed region: EXACTLY --steps lockstep steps + the metrics flush ------------------------------------------
-    barrier()
-    torch.cuda.synchronize()
-    env.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    run(args.steps)
-    ev1.record(stream)
-    gm = sdist.global_metrics(env)  # syncs the stream; one int64 all-reduce (RCCL over xGMI) when world > 1
-    env.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # ------------------------------------------------------------------------------------------------------------------
-    kernel_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the step kernels run on
-    if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    def max_over_ranks(*vals):
+        if world == 1:
+            return vals
+        t = torch.tensor(vals, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+        return tuple(float(x) for x in t)
+
+    env = S.BatchedGridworldEnv(args.env, n_local, device=local_rank, seed=args.seed, env_index_base=base,
+                                layout=args.layout)
+    stream = env.torch_stream()
+    elapsed, kernel_ms, gm = timed_steps(env, args.steps, args.warmup, barrier, sdist.global_metrics)
+    elapsed, kernel_ms = max_over_ranks(elapsed, kernel_ms)
 
     total_steps = args.warmup + args.steps
     fused = None
@@ -190,26 +243,52 @@ def main():
         env.synchronize()
         fms = f0.elapsed_time(f1)
         total_steps += 100 + fused_steps
-        fused = {"value": n_local * world * fused_steps / (fms / 1e3), "unit": "env-steps/s",
+        fused = {"value": n_total * fused_steps / (fms / 1e3), "unit": "env-steps/s",
                  "ms_per_launch": fms, "steps_per_launch": fused_steps,
-                 "note": "sgk_rollout_random: %d lockstep steps in ONE launch; per-rank device time" % fused_steps}
+                 "note": "sgk_rollout_random: %d lockstep steps in ONE launch; rank 0's device time" % fused_steps}
+    ok, n_checked = parity_sample(env, args.env, args.seed, base, total_steps)
+
+    weak_line = None
+    if world > 1 and not weak and not args.no_weak_line:
+        # secondary: the weak-scaling form (1 048 576 envs on EVERY GPU), same K / W, same bracket
+        env.close()
+        per = 1 << 20
+        wenv = S.BatchedGridworldEnv(args.env, per, device=local_rank, seed=args.seed, env_index_base=rank * per,
+                                     layout=args.layout)
+        w_el, w_ms, _ = timed_steps(wenv, args.steps, args.warmup, barrier, sdist.global_metrics)
+        w_el, w_ms = max_over_ranks(w_el, w_ms)
+        weak_line = {"value": per * world * args.steps / w_el, "unit": "env-steps/s", "envs_per_gpu": per,
+                     "total_envs": per * world, "ms_per_step": w_el * 1e3 / args.steps,
+                     "avg_launch_us": w_ms * 1e3 / args.steps, "scaling": "weak"}
+        wenv.close()
 
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()
     if rank != 0:
         return
-    n_total = n_local * world
     value = n_total * args.steps / elapsed
     launch_s = kernel_ms / 1e3 / args.steps  # average duration of one step launch incl. its dependent-launch gap
-    achieved = B_ALG[args.env] * n_local / launch_s / 1e9
+    b_alg = B_ALG[args.env]
+    achieved = b_alg * n_local / launch_s / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
         traffic = tj.get("%s/%s/%d" % (args.env, args.layout, n_local))
-    ok, n_checked = parity_sample(env, args.env, args.seed, base, total_steps)
+    roofline = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        # what the fabric really moved (rocprofv3 FETCH_SIZE x calibration + WRITE_SIZE per launch, profiles/traffic.json)
+        # over the same launch time: the UTILISATION figure. `frac` is algorithmic (2 H W + 28 bytes per env-step,
+        # which charges a board read this design never makes) and can exceed 1.
+        "traffic_gbs": None if traffic is None else traffic / launch_s / 1e9,
+        "traffic_frac": None if traffic is None else traffic / launch_s / 1e9 / HBM_PEAK_GBS,
+        "kernel": "sgk::step_kernel<%s>" % args.env, "algorithmic_bytes_per_env_step": b_alg,
+        "algorithmic_bytes_per_launch": b_alg * n_local,
+        "avg_launch_us": launch_s * 1e6, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+    }
     out = {
         "metric": "env-steps/sec at 1M concurrent BoatRace envs" if args.env == "BoatRace-v0" else "env-steps/sec",
         "value": value,
@@ -219,28 +298,26 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if (weak or world == 1) else "strong",
         "vs_baseline": None,
         "dtype": "int8",
         "data": "synthetic",
         "config": {
-            "workload": "%s random-action rollout, %d envs per GPU in lockstep, step kernel (one launch per step, "
-                        "hipGraph x%d), auto-reset, boards materialised every step" % (args.env, n_local, GRAPH_CHUNK),
+            "workload": "%s random-action rollout, %d concurrent envs in lockstep (%d per GPU), step kernel (one launch "
+                        "per step, hipGraph x%d), auto-reset, boards materialised every step"
+                        % (args.env, n_total, n_local, GRAPH_CHUNK),
             "envs_per_gpu": n_local, "total_envs": n_total, "board_layout": args.layout,
             "parallelism": "env-sharded x%d, int64 metrics all-reduce" % world,
         },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "kernel": "sgk::step_kernel<%s>" % args.env, "algorithmic_bytes_per_env_step": B_ALG[args.env],
-            "avg_launch_us": launch_s * 1e6, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-        },
+        "roofline": roofline,
         "episodes_finished": gm.episodes,
         "mean_return": gm.meter("returns")["avg"], "mean_safety": gm.meter("safeties")["avg"],
         "parity_sample_bit_exact": ok, "parity_sample_envs": n_checked,
     }
     if fused:
         out["fused_rollout"] = fused
+    if weak_line:
+        out["weak_1m_per_gpu"] = weak_line
     if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line only
         out["cpu_baseline"] = cpu_baseline(args.env, args.seed)
     print(json.dumps(out))

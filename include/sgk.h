@@ -149,6 +149,10 @@ SGK_API int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flag
 /* RandomAgent.act + env.step (reference dummy.py:15-16, warmup.py:19-20): n_steps lockstep steps, one
  * launch per step (replayed from a hipGraph), actions from the counter RNG (Philox-4x32-10, stream 0). */
 SGK_API int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags);
+/* Builds (captures + instantiates) the hipGraph sgk_step_random(n_steps, flags) replays and uploads the lockstep counter,
+ * WITHOUT stepping: a caller that times a region calls this for every chunk size it is going to use, so that no capture
+ * falls inside the region. A no-op for chunk sizes that run as eager launches (n_steps < 4, SGK_NO_GRAPH=1). */
+SGK_API int sgk_step_random_prepare(sgk_env *h, int32_t n_steps, uint32_t flags);
 /* SingleActionAgent.act + env.step (reference dummy.py:19-30): every env repeats ITS action actions_dev[i] for n_steps
  * lockstep steps (one launch per step). */
 SGK_API int sgk_step_repeat(sgk_env *h, const uint8_t *actions_dev, int32_t n_steps, uint32_t flags);
@@ -202,6 +206,13 @@ SGK_API int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat);
 /* n_steps of {act_explore, env.step, learn, update_epsilon, reset on done} in one launch
  * (reference learn.py:61-85 inside train.py:62-70) */
 SGK_API int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat);
+/* the same with the kernel named: AUTO picks by table size and agent count; LDS = the tables of 64 agents resident in a
+ * workgroup's LDS for the launch (envs whose state is the agent cell only; SGK_ERR_INVALID otherwise); HBM = rows read and
+ * written in HBM (any env). Same arithmetic, same results. */
+#define SGK_TABQ_KERNEL_AUTO 0
+#define SGK_TABQ_KERNEL_LDS 1
+#define SGK_TABQ_KERNEL_HBM 2
+SGK_API int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel);
 SGK_API int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64_t *n_actions); /* [n_envs][n_states][n_actions] */
 SGK_API int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, double *table_host);
 SGK_API int sgk_tabq_global_step(const sgk_tabq *q, int64_t *t_out);

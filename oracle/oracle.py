@@ -27,6 +27,8 @@ def build(force=False):
     hdr = os.path.join(_HERE, "..", "include", "sgk_levels.h")
     stale = (not os.path.exists(_SO)) or any(
         os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr))
+    if (force or stale) and os.environ.get("SGK_NO_BUILD") == "1":  # profiler runs: never spawn a compiler from here
+        raise RuntimeError("liboracle_sgk.so is missing or stale and SGK_NO_BUILD=1 forbids building it here")
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_sgk.so"], stdout=subprocess.DEVNULL)
     return _SO

@@ -414,22 +414,10 @@ int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_s
   return SGK_OK;
 }
 
-int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
-  SGK_CHECK_HANDLE(h);
-  if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
-  if (n_steps == 0) return SGK_OK;
+// Capture + instantiate the hipGraph of `n_steps` dependent step launches for (n_steps, flags), once per key. The launch-bound
+// inner loop is replayed from it; the lockstep counter lives in device memory so replays need no new arguments.
+static int ensure_step_graph(sgk_env *h, int32_t n_steps, uint32_t flags, hipGraphExec_t *out) {
   sgk::Shard &s = h->sh;
-  if (!h->use_graph || n_steps < 4) {
-    for (int32_t k = 0; k < n_steps; ++k) {
-      SGK_HIP(sgk::launch_step(s, nullptr, flags, h->stream));
-      s.lockstep_t += 1;
-    }
-    h->t_dev_stale = true;
-    h->steps_issued += s.n * (int64_t)n_steps;
-    return SGK_OK;
-  }
-  // hipGraph path: the launch-bound inner loop (n_steps dependent step kernels) is captured once per
-  // (n_steps, flags) and replayed; the lockstep counter lives in device memory so replays need no new arguments.
   auto key = std::make_pair(n_steps, flags);
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
@@ -477,13 +465,50 @@ int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
     if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate");
     it = h->graphs.emplace(key, exec).first;
   }
+  *out = it->second;
+  return SGK_OK;
+}
+
+int sgk_step_random_prepare(sgk_env *h, int32_t n_steps, uint32_t flags) {
+  SGK_CHECK_HANDLE(h);
+  if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
+  if (!h->use_graph || n_steps < 4) return SGK_OK;  // these run as eager launches: nothing to prepare
+  hipGraphExec_t exec = nullptr;
+  int rc = ensure_step_graph(h, n_steps, flags, &exec);
+  if (rc != SGK_OK) return rc;
+  if (h->t_dev_stale) {  // the counter upload a first replay would otherwise do
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, h->sh.lockstep_t);
+    SGK_HIP(hipGetLastError());
+    h->t_dev_stale = false;
+  }
+  return SGK_OK;
+}
+
+int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
+  SGK_CHECK_HANDLE(h);
+  if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
+  if (n_steps == 0) return SGK_OK;
+  sgk::Shard &s = h->sh;
+  if (!h->use_graph || n_steps < 4) {
+    for (int32_t k = 0; k < n_steps; ++k) {
+      SGK_HIP(sgk::launch_step(s, nullptr, flags, h->stream));
+      s.lockstep_t += 1;
+    }
+    h->t_dev_stale = true;
+    h->steps_issued += s.n * (int64_t)n_steps;
+    return SGK_OK;
+  }
+  hipGraphExec_t exec = nullptr;
+  int rc = ensure_step_graph(h, n_steps, flags, &exec);
+  if (rc != SGK_OK) return rc;
   if (h->t_dev_stale) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, s.lockstep_t);
     SGK_HIP(hipGetLastError());
     h->t_dev_stale = false;
   }
-  SGK_HIP(hipGraphLaunch(it->second, h->stream));
+  SGK_HIP(hipGraphLaunch(exec, h->stream));
   s.lockstep_t += (uint64_t)n_steps;
   h->steps_issued += s.n * (int64_t)n_steps;
   return SGK_OK;
@@ -811,6 +836,7 @@ int sgk_tabq_destroy(sgk_tabq *q) {
   }
   (void)hipFree(q->tq.table);
   (void)hipFree(q->tq.s_prev);
+  (void)hipFree(q->tq.eps_table);
   (void)hipFree(q->actions);
   delete q;
   return SGK_OK;
@@ -871,18 +897,24 @@ int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat) {
   return SGK_OK;
 }
 
-int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat) {
+int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel) {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   sgk_env *h = q->env;
   SGK_CHECK_HANDLE(h);
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
+  if (kernel < SGK_TABQ_KERNEL_AUTO || kernel > SGK_TABQ_KERNEL_HBM) return fail(SGK_ERR_INVALID, "unknown kernel choice");
   if (n_steps == 0) return SGK_OK;
   sgk::Shard &s = h->sh;
   const size_t lds_need = sgk::tabq_rollout_lds_bytes(s);
-  static const bool force_hbm = getenv("SGK_TABQ_HBM") != nullptr;  // A/B switches: one kernel for every env that allows it
-  static const bool force_lds = getenv("SGK_TABQ_LDS") != nullptr;
-  bool use_lds = lds_need != 0 && lds_need <= 160u * 1024u;
-  if (use_lds && !force_lds) {
+  const bool lds_possible = lds_need != 0 && lds_need <= 160u * 1024u;
+  if (kernel == SGK_TABQ_KERNEL_LDS && !lds_possible)
+    return fail(SGK_ERR_INVALID, "this env's tables do not fit LDS: the LDS-resident kernel cannot run");
+  if (kernel == SGK_TABQ_KERNEL_AUTO) {  // A/B switches of the tools: one kernel for every env that allows it
+    if (getenv("SGK_TABQ_HBM")) kernel = SGK_TABQ_KERNEL_HBM;
+    else if (getenv("SGK_TABQ_LDS") && lds_possible) kernel = SGK_TABQ_KERNEL_LDS;
+  }
+  bool use_lds = lds_possible;
+  if (kernel == SGK_TABQ_KERNEL_AUTO && use_lds) {
     // The LDS-resident kernel runs in rounds of n_cus * per_cu workgroups of 64 agents. With big tables (<= 3 workgroups per
     // CU) a second round costs a whole ~0.9 us, while the HBM-resident kernel serves every agent in one wave of workgroups
     // and its rows stay in L2 / MALL as long as all tables together are small: measured ahead by 25-35 % exactly there
@@ -895,22 +927,23 @@ int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat) {
                                                                        // 2.6-3.5 us up to 131 072 agents)
     if (per_cu <= 3 && groups > slots && table_bytes <= fits) use_lds = false;
   }
-  if (!force_hbm && use_lds) {
+  if (kernel == SGK_TABQ_KERNEL_HBM) use_lds = false;
+  if (use_lds) {
     SGK_HIP(sgk::launch_tabq_rollout(s, q->tq, n_steps, cheat, h->stream));
-    SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));  // materialise the boards of the final states
-    q->tq.t_agent += n_steps;
-    s.lockstep_t += (uint64_t)n_steps;
   } else {
-    // table too large for LDS residency (Sokoban: n_cells^2 states): the same loop with the rows read and written in HBM
+    // table too large for LDS residency (Sokoban: n_cells^2 states), or the mid-size case above: the same loop with the
+    // rows read and written in HBM
     SGK_HIP(sgk::launch_tabq_rollout_hbm(s, q->tq, n_steps, cheat, h->stream));
-    SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));
-    q->tq.t_agent += n_steps;
-    s.lockstep_t += (uint64_t)n_steps;
   }
+  SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));  // materialise the boards of the final states
+  q->tq.t_agent += n_steps;
+  s.lockstep_t += (uint64_t)n_steps;
   h->t_dev_stale = true;
   h->steps_issued += s.n * n_steps;
   return SGK_OK;
 }
+
+int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat) { return sgk_tabq_rollout_ex(q, n_steps, cheat, SGK_TABQ_KERNEL_AUTO); }
 
 int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64_t *n_actions) {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");

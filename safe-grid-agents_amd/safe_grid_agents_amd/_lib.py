@@ -17,6 +17,7 @@ SGK_OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE = -1, -2, -3, -4
 F_AUTO_RESET, F_NO_BOARDS, F_MASK_FINISHED = 1, 2, 4
 LAYOUT_PITCHED, LAYOUT_COMPACT = 0, 1
+TABQ_KERNEL_AUTO, TABQ_KERNEL_LDS, TABQ_KERNEL_HBM = 0, 1, 2
 MEM_HOST_VISIBLE = 0x100
 BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN, DISTRIBUTIONAL_SHIFT, WHISKY_GOLD, ABSENT_SUPERVISOR = 0, 1, 2, 3, 4, 5
 METRICS_LEN = 16
@@ -68,10 +69,16 @@ class SgkPpoLearner(ctypes.Structure):
 
 def build(force=False, verbose=False):
     """Compile libsgk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
+    srcs = ([os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))]
+            + [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)])
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in srcs)
+    if (force or stale) and os.environ.get("SGK_NO_BUILD") == "1":
+        # set by the profiler scripts: a build here would spawn make / hipcc as children of a process the profiler's preload
+        # has already initialised the GPU in (an exec from a GPU-initialised process takes the box down)
+        raise RuntimeError("libsgk.so is missing or stale and SGK_NO_BUILD=1 forbids building it here; run "
+                           "`python -c 'import __graft_entry__ as g; g.build()'` first")
     if force or stale:
-        cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+        cmd = ["make", "-j6", "-C", CSRC] + (["-B"] if force else [])
         subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
     return LIB_PATH
 
@@ -99,6 +106,7 @@ _SIGNATURES = {
     "sgk_step": (ctypes.c_int, [_V, _V, ctypes.c_uint32]),
     "sgk_step_host": (ctypes.c_int, [_V, _V, ctypes.c_uint32, _V, _V, _V]),
     "sgk_step_random": (ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_uint32]),
+    "sgk_step_random_prepare": (ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_uint32]),
     "sgk_account_steps": (ctypes.c_int, [_V, ctypes.c_int64]),
     "sgk_rollout_random": (ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_uint32]),
     "sgk_step_repeat": (ctypes.c_int, [_V, _V, ctypes.c_int32, ctypes.c_uint32]),
@@ -133,6 +141,7 @@ _SIGNATURES = {
     "sgk_tabq_act": (ctypes.c_int, [_V, ctypes.c_int, _V]),
     "sgk_tabq_learn": (ctypes.c_int, [_V, _V, ctypes.c_int]),
     "sgk_tabq_rollout": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int]),
+    "sgk_tabq_rollout_ex": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "sgk_tabq_table_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V), ctypes.POINTER(ctypes.c_int64),
                                           ctypes.POINTER(ctypes.c_int64)]),
     "sgk_tabq_copy_table": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int64, _V]),
@@ -152,7 +161,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) and os.environ.get("SGK_NO_BUILD") != "1":
         try:  # a build step, not a fallback: compile the HIP library in-tree when hipcc is at hand
             build()
         except Exception:

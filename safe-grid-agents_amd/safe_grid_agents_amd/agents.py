@@ -291,9 +291,11 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         self.env._sync_torch_to_lib()
         _lib.check(self.lib.sgk_tabq_learn(self._h, ctypes.c_void_p(actions.data_ptr()), int(cheat)))
 
-    def rollout(self, n_steps, cheat=False):
-        """n_steps of {act_explore, env.step, learn, update_epsilon, reset on done} fused on the GPU."""
-        _lib.check(self.lib.sgk_tabq_rollout(self._h, int(n_steps), int(cheat)))
+    def rollout(self, n_steps, cheat=False, kernel="auto"):
+        """n_steps of {act_explore, env.step, learn, update_epsilon, reset on done} fused on the GPU. `kernel`: "auto", or
+        "lds" / "hbm" to name the kernel (tables resident in LDS / rows in HBM; same results)."""
+        k = {"auto": _lib.TABQ_KERNEL_AUTO, "lds": _lib.TABQ_KERNEL_LDS, "hbm": _lib.TABQ_KERNEL_HBM}[kernel]
+        _lib.check(self.lib.sgk_tabq_rollout_ex(self._h, int(n_steps), int(cheat), k))
 
     def table_host(self, env_begin=0, env_count=None):
         env_count = self.env.n_envs - env_begin if env_count is None else env_count

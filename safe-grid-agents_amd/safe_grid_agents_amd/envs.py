@@ -275,6 +275,12 @@ class BatchedGridworldEnv:
         _lib.check(fn(self._h.ptr, int(n_steps), flags))
         return self._step_outputs()
 
+    def prepare_step_random(self, n_steps, auto_reset=True, write_boards=True):
+        """Build the hipGraph step_random(n_steps, ...) replays without stepping (sgk_step_random_prepare): callers that time
+        a region prepare every chunk size they will use first."""
+        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
+        _lib.check(self.lib.sgk_step_random_prepare(self._h.ptr, int(n_steps), flags))
+
     def epsilon_greedy(self, scores, epsilon, draw_index, out=None):
         """DeepQAgent.act_explore for every env (reference value.py:94-111): scores float32 [N, 4] -> uint8 actions [N].
         `epsilon` / `draw_index` may be 1-element device tensors (float64 / int64): the launch then reads them from HBM."""
