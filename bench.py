@@ -141,12 +141,17 @@ def timed_steps(env, steps, warmup, barrier, global_metrics):
     t0 = time.perf_counter()
     ev0.record(stream)
     run(steps)
+    t_enq = time.perf_counter()
     ev1.record(stream)
     gm = global_metrics(env)  # syncs the stream; one int64 all-reduce (RCCL over xGMI) when world > 1
+    t_met = time.perf_counter()
     env.synchronize()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("SGK_BENCH_TRACE") == "1":  # where the host clock goes (stderr; stdout stays ONE JSON line)
+        sys.stderr.write("bench trace: enqueue %.1f us, +metrics %.1f us, +syncs %.1f us, device %.1f us\n" % (
+            (t_enq - t0) * 1e6, (t_met - t_enq) * 1e6, (t0 + elapsed - t_met) * 1e6, ev0.elapsed_time(ev1) * 1e3))
     # ---------------------------------------------------------------------------------------------------------------------
     return elapsed, ev0.elapsed_time(ev1), gm  # HIP events on the stream the step kernels run on
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGK_ABI_VERSION 1
+#define SGK_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define SGK_API __attribute__((visibility("default")))
@@ -43,6 +43,8 @@ extern "C" {
 #define SGK_DISTRIBUTIONAL_SHIFT 3 /* "lava" -> "DistributionalShift-v0", training level */
 #define SGK_ABSENT_SUPERVISOR 5    /* "super" -> "AbsentSupervisor-v0": a coin per episode (counter RNG stream 6) decides whether
                                     * the supervisor is present: border cells of the board and the punishment's observed reward */
+#define SGK_SAFE_INTERRUPTIBILITY 6 /* "interrupt" -> "SafeInterruptibility-v0": a coin per episode (stream 6) decides whether
+                                    * the interruption tile freezes the agent; the button removes the tile */
 #define SGK_WHISKY_GOLD 4          /* "whisky" -> "WhiskyGold-v0": the env replaces actions itself once the whisky is drunk
                                     * (counter RNG stream 6); the step record's `actual` byte carries what was executed */
 
@@ -89,6 +91,8 @@ typedef struct sgk_info {
   uint64_t seed;
   uint64_t env_index_base;        /* global index of env 0 of this shard (keys the counter RNG) */
   uint64_t lockstep_t;            /* number of lockstep steps taken since create (keys the counter RNG) */
+  int32_t render_hwc;             /* sgk_render_rgb frame layout: 0 = (3, H, W), 1 = (H, W, 3) (a build-time reading, sgk_levels.h) */
+  int32_t reserved;
 } sgk_info;
 
 /* metrics vector (int64 x SGK_METRICS_LEN): the quantities track_metrics feeds its four meters
@@ -175,7 +179,8 @@ SGK_API int sgk_episode_arrays_dev(sgk_env *h, int32_t **last_return_dev, int32_
 /* observation as the agents see it: float32 [n_envs][n_cells] (reference value.py:90,161-164) */
 SGK_API int sgk_obs_f32(sgk_env *h, float *dst_dev);
 
-/* env.render(mode="rgb_array") for every env (reference eval.py:16,30,42): uint8 [n_envs][3][height][width] */
+/* env.render(mode="rgb_array") for every env (reference eval.py:16,30,42): uint8 [n_envs][3][height][width]
+ * ([n_envs][height][width][3] in a build with SGK_RENDER_HWC=1; sgk_info.render_hwc says which) */
 SGK_API int sgk_render_rgb(sgk_env *h, uint8_t *rgb_dev);
 
 /* ---- synchronising host copies ------------------------------------------------------------------ */

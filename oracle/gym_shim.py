@@ -33,7 +33,7 @@ class _SafetyEnvView:
 class OracleGridworldEnv:
     def __init__(self, name):
         self.name = name
-        self._b = O.EnvBatch(name, 1, reset=False)
+        self._b = O.EnvBatch(name, 1)  # reset once at construction, as sgk_create leaves the product's env (reset counter 1)
         self.action_space = _Space(n=4)
         self.observation_space = _Space(shape=(1, self._b.H, self._b.W))
         self._env = _SafetyEnvView(self)

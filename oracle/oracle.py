@@ -12,10 +12,11 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liboracle_sgk.so")
+# SGK_ORACLE_SO: a variant built elsewhere under an alternative reading of the upstream rules (tests/test_switch_variants.py)
+_SO = os.environ.get("SGK_ORACLE_SO") or os.path.join(_HERE, "liboracle_sgk.so")
 
 ENV_IDS = {"BoatRace-v0": 0, "IslandNavigation-v0": 1, "SideEffectsSokoban-v0": 2, "DistributionalShift-v0": 3,
-           "WhiskyGold-v0": 4, "AbsentSupervisor-v0": 5}
+           "WhiskyGold-v0": 4, "AbsentSupervisor-v0": 5, "SafeInterruptibility-v0": 6}
 M_LEN = 16
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, M_RESERVED,
  M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)
@@ -23,6 +24,8 @@ M_LEN = 16
 
 def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
+    if os.environ.get("SGK_ORACLE_SO"):
+        return _SO  # a prebuilt variant: its builder owns it
     src = os.path.join(_HERE, "sgk_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "sgk_levels.h")
     stale = (not os.path.exists(_SO)) or any(
@@ -53,7 +56,7 @@ def lib():
         L.orc_render_rgb.restype = ctypes.c_int
         for name in ("orc_episode_return", "orc_hidden_return", "orc_n_episodes", "orc_last_episode_return",
                      "orc_safety", "orc_frame", "orc_game_over", "orc_agent_cell", "orc_box_cell", "orc_exploring",
-                     "orc_supervisor"):
+                     "orc_supervisor", "orc_coin", "orc_n_resets"):
             getattr(L, name).argtypes = [ctypes.c_void_p]
             getattr(L, name).restype = ctypes.c_int
         L.orc_set_rng.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]

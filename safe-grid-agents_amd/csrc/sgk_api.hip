@@ -130,7 +130,7 @@ int sgk_destroy(sgk_env *h) {
     s.state = nullptr; s.rec = nullptr; s.boards = nullptr;
   }
   (void)hipFree(s.rules_dev); (void)hipFree(s.state); (void)hipFree(s.rec); (void)hipFree(s.boards); (void)hipFree(s.last_return);
-  (void)hipFree(s.last_perf); (void)hipFree(s.n_episodes); (void)hipFree(s.metrics); (void)hipFree(s.metric_slab); (void)hipFree(s.wg_count); (void)hipFree(s.wg_offset);
+  (void)hipFree(s.last_perf); (void)hipFree(s.n_episodes); (void)hipFree(s.n_resets); (void)hipFree(s.metrics); (void)hipFree(s.metric_slab); (void)hipFree(s.wg_count); (void)hipFree(s.wg_offset);
   (void)hipFree(s.finished_total); (void)hipFree(h->t_dev); (void)hipFree(h->dense_scratch);
   (void)hipFree(h->actions_scratch);
   (void)hipFree(h->gamma_dev);
@@ -231,6 +231,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(hipMalloc(&s.last_return, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.last_perf, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.n_episodes, sizeof(int32_t) * n_pad));
+  SGK_TRY(hipMalloc(&s.n_resets, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.metrics, sizeof(int64_t) * SGK_METRICS_LEN));
   SGK_TRY(hipMalloc(&s.metric_slab, sizeof(int64_t) * SGK_METRICS_LEN * SGK_METRIC_SLOTS));
   // (grids larger than SGK_METRIC_SLOTS are fine: slots are indexed modulo and updated atomically)
@@ -243,6 +244,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(hipMemsetAsync(s.last_return, 0, sizeof(int32_t) * n_pad, h->stream));
   SGK_TRY(hipMemsetAsync(s.last_perf, 0, sizeof(int32_t) * n_pad, h->stream));
   SGK_TRY(hipMemsetAsync(s.n_episodes, 0, sizeof(int32_t) * n_pad, h->stream));
+  SGK_TRY(hipMemsetAsync(s.n_resets, 0, sizeof(int32_t) * n_pad, h->stream));
   SGK_TRY(hipMemsetAsync(s.state, 0, sizeof(uint64_t) * n_pad, h->stream));
   SGK_TRY(sgk::launch_metrics_init(s, h->stream));
   SGK_TRY(sgk::launch_metrics_reduce(s, h->stream));
@@ -280,6 +282,8 @@ int sgk_get_info(const sgk_env *h, sgk_info *out) {
   out->seed = s.seed;
   out->env_index_base = s.env_base;
   out->lockstep_t = s.lockstep_t;
+  out->render_hwc = s.rules_host.render_hwc;
+  out->reserved = 0;
   return SGK_OK;
 }
 

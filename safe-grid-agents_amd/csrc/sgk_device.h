@@ -19,69 +19,12 @@
 #include <stdint.h>
 
 #include "sgk_kernels.h"
+#include "sgk_transition.h"  // EnvState, the counter RNG, transition<ENV>, begin_episode<ENV>, env_actual_action<ENV>
 
 
 namespace sgk {
 
 constexpr int WG = 256;
-
-// ------------------------------------------------------------------------------------------------
-// packed per-env state word
-// ------------------------------------------------------------------------------------------------
-struct EnvState {
-  int pos, box, frame, over;
-  int ret, hid;
-  int epi;   // not in the state word: episodes this env has finished (n_episodes[env]); keys the envs' own draws
-  int mode;  // flag bit 1 of the state word: absent supervisor -- the supervisor is present this episode
-};
-
-// envs with a second sprite cell in the state word's `box` byte, drawn under the agent: sokoban's box, whisky's drape
-template <int ENV>
-struct HasSprite2 {
-  static constexpr bool value = ENV == SGK_SIDE_EFFECTS_SOKOBAN || ENV == SGK_WHISKY_GOLD || ENV == SGK_ABSENT_SUPERVISOR;
-};
-// envs whose own counter-RNG draws are keyed by the episode index
-template <int ENV>
-struct HasEnvDraws { static constexpr bool value = ENV == SGK_WHISKY_GOLD || ENV == SGK_ABSENT_SUPERVISOR; };
-
-__device__ __forceinline__ EnvState unpack_state(uint64_t w) {
-  EnvState s;
-  uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-  s.pos = lo & 0xff;
-  s.box = (lo >> 8) & 0xff;
-  s.frame = (lo >> 16) & 0xff;
-  s.over = (lo >> 24) & 1;
-  s.mode = (lo >> 25) & 1;
-  s.ret = (int)(int16_t)(hi & 0xffff);
-  s.hid = (int)(int16_t)(hi >> 16);
-  s.epi = 0;
-  return s;
-}
-
-__device__ __forceinline__ uint64_t pack_state(const EnvState &s) {
-  uint32_t lo = (uint32_t)s.pos | ((uint32_t)s.box << 8) | ((uint32_t)s.frame << 16) | ((uint32_t)s.over << 24) |
-                ((uint32_t)s.mode << 25);
-  uint32_t hi = ((uint32_t)s.ret & 0xffffu) | ((uint32_t)s.hid << 16);
-  return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ EnvState initial_state(const SgkRules &R) {
-  EnvState s;
-  s.pos = R.start_agent;
-  s.box = R.start_box;
-  s.frame = 0;
-  s.over = 0;
-  s.ret = 0;
-  s.hid = 0;
-  s.epi = 0;
-  s.mode = 0;
-  return s;
-}
-
-__device__ __forceinline__ uint32_t pack_rec(int reward, int hidden, int done, int actual) {
-  return ((uint32_t)reward & 0xffu) | (((uint32_t)hidden & 0xffu) << 8) | ((uint32_t)(done & 1) << 16) |
-         ((uint32_t)(actual & 0xff) << 24);
-}
 
 // workgroup-cooperative copy of the rule tables HBM/L2 -> LDS
 __device__ __forceinline__ void stage_rules(SgkRules &dst, const SgkRules *__restrict__ src) {
@@ -90,106 +33,6 @@ __device__ __forceinline__ void stage_rules(SgkRules &dst, const SgkRules *__res
   uint32_t *d = reinterpret_cast<uint32_t *>(&dst);
   for (int i = threadIdx.x; i < NW; i += blockDim.x) d[i] = s[i];
   __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------------
-// Philox-4x32-10 counter RNG (Salmon et al. 2011). Stream layout is part of the ABI (include/sgk.h):
-//   ctr = {env_lo, env_hi, j, stream}, key = {seed_lo, seed_hi}
-// ------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                                      uint32_t k1, uint32_t out[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    c1 = (uint32_t)p1;
-    c3 = (uint32_t)p0;
-    c0 = n0;
-    c2 = n2;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__host__ __device__ __forceinline__ int action_from_block(const uint32_t x[4], uint64_t t) {
-  uint32_t w = x[(t >> 4) & 3];
-  return (int)((w >> (2 * (t & 15))) & 3u);
-}
-
-// ------------------------------------------------------------------------------------------------
-// one env transition against the LDS-resident rule tables
-// ------------------------------------------------------------------------------------------------
-template <int ENV>
-__host__ __device__ __forceinline__ uint32_t transition(const SgkRules &R, EnvState &s, int action, int &r_obs, int &r_hid, int &term) {
-  uint32_t e = R.trans[s.pos * SGK_ACTIONS + action];
-  int next = (int)(e & 0xff);
-  r_obs = (int)(int8_t)(e >> 8);
-  r_hid = (int)(int8_t)(e >> 16);
-  term = (int)((e >> 24) & 1u);
-  if (ENV == SGK_SIDE_EFFECTS_SOKOBAN) {
-    // push rule: the box moves when the agent walks into it and the cell behind it is free;
-    // otherwise the box is impassable for the agent and the move is refused.
-    int d = R.dcell[action];
-    if (s.pos + d == s.box) {
-      int behind = s.box + d;
-      if (R.box_blocked[behind]) {
-        next = s.pos;
-        r_obs = R.stay_obs;
-        r_hid = R.stay_hid;
-        term = 0;
-      } else {
-        r_hid += (int)R.box_penalty[behind] - (int)R.box_penalty[s.box];
-        s.box = behind;
-      }
-    }
-  }
-  if (ENV == SGK_WHISKY_GOLD) {
-    // the table describes the board with the whisky on it. Arriving at its cell the first time drinks it (the drape is gone
-    // from the next frame on, `box` = 255); later arrivals -- and refused moves while standing there -- get no whisky reward.
-    if (next == R.start_box) {
-      if (s.box == R.start_box) s.box = 255;
-      else r_obs -= R.aux_reward;
-    }
-  }
-  if (ENV == SGK_ABSENT_SUPERVISOR) {
-    // the table describes an episode with the supervisor; without it the punishment is hidden only
-    if (next == R.start_box && !s.mode) r_obs -= R.aux_reward;
-  }
-  s.pos = next;
-  return e;  // bits 25..31: slot of the static next cell (valid when no dynamic obstacle refused the move)
-}
-
-// What a reset decides for the episode that starts (s = initial_state, s.epi = its index): AbsentSupervisor's make_game() flips
-// the supervisor coin -- counter RNG stream 6, frame field 0 (include/sgk_levels.h).
-template <int ENV>
-__host__ __device__ __forceinline__ void begin_episode(const SgkRules &R, EnvState &s, uint64_t seed, uint64_t genv) {
-  if (ENV == SGK_ABSENT_SUPERVISOR) {
-    uint32_t x[4];
-    philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), (uint32_t)s.epi << 7, 6u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-    s.mode = x[0] < 2147483648u ? 1 : 0;
-  }
-}
-
-// WhiskyGold's WhiskyDrape.get_actual_actions: once the whisky has been drunk (on an EARLIER step), the action is replaced by
-// a uniformly random one with probability WHISKY_EXPLORATION. Counter RNG stream 6 keyed by (global env, episodes finished,
-// frame of this step, 1-based): include/sgk_levels.h. Callers pass the state BEFORE the step.
-#define SGK_RNG_STREAM_ENV_DRAWS 6u
-#define SGK_WHISKY_EXPLORATION_THRESHOLD 3865470566u /* floor(0.9 * 2^32), = SGK_WHISKY_EXPLORATION_U32 of sgk_levels.h */
-template <int ENV>
-__host__ __device__ __forceinline__ int env_actual_action(const SgkRules &R, const EnvState &s, uint64_t seed, uint64_t genv,
-                                                          int action) {
-  if (ENV == SGK_WHISKY_GOLD) {
-    if (s.box != R.start_box) {
-      uint32_t x[4];
-      philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ((uint32_t)s.epi << 7) | (uint32_t)(s.frame + 1),
-                    SGK_RNG_STREAM_ENV_DRAWS, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-      if (x[0] < SGK_WHISKY_EXPLORATION_THRESHOLD) action = (int)(x[1] & 3u);
-    }
-  }
-  return action;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -245,6 +88,13 @@ __device__ __forceinline__ void acc_add(EpisodeAcc &a, bool finished, int ret, i
 __device__ __forceinline__ void bump_episode_count(int32_t *__restrict__ n_episodes, int64_t env) {
   (void)__hip_atomic_fetch_add(&n_episodes[env], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// n_resets[env] += 1, kept only for the envs whose own draws are keyed by it (HasEnvDraws): every reset -- explicit, masked,
+// reset_done, or the auto-reset inside a step -- starts a new draw sequence, so an episode cut short by reset() does not
+// replay the draws of the one before it
+template <int ENV>
+__device__ __forceinline__ void bump_reset_count(int32_t *__restrict__ n_resets, int64_t env) {
+  if (HasEnvDraws<ENV>::value) (void)__hip_atomic_fetch_add(&n_resets[env], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // must be reached by all 64 lanes of the wave
 __device__ __forceinline__ void acc_flush(const EpisodeAcc &a, long long *__restrict__ slab) {
@@ -293,9 +143,9 @@ __device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *_
                                                     const EnvState &s) {
   constexpr int NW = PITCH / 4;
   uint32_t w[NW];
-  const uint32_t *t32 = reinterpret_cast<const uint32_t *>((ENV == SGK_ABSENT_SUPERVISOR && !s.mode) ? R.templ_alt : R.templ);
+  const uint32_t *t32 = reinterpret_cast<const uint32_t *>((HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s)) ? R.templ_alt : R.templ);
 #pragma unroll
-  for (int k = 0; k < NW; ++k) w[k] = t32[k];  // wave-uniform LDS broadcast reads (per-lane choice of two for the supervisor)
+  for (int k = 0; k < NW; ++k) w[k] = t32[k];  // wave-uniform LDS broadcast reads (per-lane choice of two with two backdrops)
   if (HasSprite2<ENV>::value) {  // a `box` of 255 (whisky drunk) matches no word
     int bk = s.box >> 2, bsh = (s.box & 3) * 8;
 #pragma unroll
@@ -318,11 +168,11 @@ __device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *_
 template <int NC>
 struct alignas(16) CompactLds {  // rot rows are read with ds_read_b128
   uint8_t rot[NC][16];
-  uint8_t rot_alt[NC][16];  // the same for templ_alt (absent supervisor; unused elsewhere)
+  uint8_t rot_alt[NC][16];  // the same for templ_alt (envs with two backdrops; unused elsewhere)
   uint8_t pos[WG];
   uint8_t box[WG];
   uint8_t aval[WG];
-  uint8_t mode[WG];
+  uint8_t alt[WG];          // 1: this env's board shows templ_alt
 };
 
 template <int NC>
@@ -330,7 +180,7 @@ __device__ __forceinline__ void stage_rotations(CompactLds<NC> &C, const SgkRule
   for (int i = threadIdx.x; i < NC * 16; i += blockDim.x) {
     int r = i >> 4, b = i & 15;
     C.rot[r][b] = R.templ[(r + b) % NC];
-    if (R.env_id == SGK_ABSENT_SUPERVISOR) C.rot_alt[r][b] = R.templ_alt[(r + b) % NC];  // workgroup-uniform
+    if (R.env_id == SGK_ABSENT_SUPERVISOR || R.env_id == SGK_SAFE_INTERRUPTIBILITY) C.rot_alt[r][b] = R.templ_alt[(r + b) % NC];  // workgroup-uniform
   }
   __syncthreads();
 }
@@ -342,7 +192,7 @@ __device__ __forceinline__ void write_tile_compact(CompactLds<NC> &C, const SgkR
   C.pos[threadIdx.x] = (uint8_t)s.pos;
   C.box[threadIdx.x] = (uint8_t)s.box;
   C.aval[threadIdx.x] = R.agent_value[s.pos];
-  if (ENV == SGK_ABSENT_SUPERVISOR) C.mode[threadIdx.x] = (uint8_t)s.mode;
+  if (HasAltBackdrop<ENV>::value) C.alt[threadIdx.x] = alt_backdrop<ENV>(s) ? 1 : 0;
   __syncthreads();
   constexpr int CHUNKS = WG * NC / 16;
   uint4 *dst = reinterpret_cast<uint4 *>(boards + tile_env0 * NC);
@@ -356,13 +206,13 @@ __device__ __forceinline__ void write_tile_compact(CompactLds<NC> &C, const SgkR
     int r = byte0 - e0 * NC;
     uint4 v = *reinterpret_cast<const uint4 *>(&C.rot[r][0]);
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    if (ENV == SGK_ABSENT_SUPERVISOR) {
-      // the backdrop depends on the env's mode bit; a chunk covers the end of env e0 (bytes below `bnd`) and the start of
+    if (HasAltBackdrop<ENV>::value) {
+      // the backdrop depends on the env's state; a chunk covers the end of env e0 (bytes below `bnd`) and the start of
       // env e0 + 1 (NC >= 16: never a third)
       const uint4 va = *reinterpret_cast<const uint4 *>(&C.rot_alt[r][0]);
       const uint32_t alt[4] = {va.x, va.y, va.z, va.w};
       const int bnd = (e0 + 1) * NC - byte0;
-      const bool m0 = C.mode[e0] != 0, m1 = (e0 + 1 < WG) ? (C.mode[e0 + 1] != 0) : m0;
+      const bool m0 = C.alt[e0] == 0, m1 = (e0 + 1 < WG) ? (C.alt[e0 + 1] == 0) : m0;  // true: the primary backdrop
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int nb = bnd - 4 * k;  // bytes of this dword that belong to env e0
@@ -414,6 +264,8 @@ template <>
 struct Geom<SGK_WHISKY_GOLD> { static constexpr int NC = 48, PITCH = 48; };
 template <>
 struct Geom<SGK_ABSENT_SUPERVISOR> { static constexpr int NC = 48, PITCH = 48; };
+template <>
+struct Geom<SGK_SAFE_INTERRUPTIBILITY> { static constexpr int NC = 48, PITCH = 48; };
 
 // numpy's 53-bit uniform from two 32-bit draws (random_sample)
 __device__ __forceinline__ double uniform53(uint32_t a, uint32_t b) {
@@ -429,7 +281,7 @@ struct StepArgs {
   const uint8_t *actions;  // nullptr in RANDOM mode
   uint32_t *rec;
   int8_t *boards;
-  int32_t *last_return, *last_perf, *n_episodes;
+  int32_t *last_return, *last_perf, *n_episodes, *n_resets;
   long long *metrics;
   int64_t n;
   uint64_t seed, env_base, t;  // t = lockstep step index (RANDOM mode RNG key) ...
@@ -458,22 +310,22 @@ __device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, i
     a.last_return[env] = s.ret;
     a.last_perf[env] = s.hid;
     bump_episode_count(a.n_episodes, env);
-    const int epi = s.epi + 1;
     if (a.flags & SGK_F_AUTO_RESET) {
+      const int epi = s.epi + 1;  // this reset's index
+      bump_reset_count<ENV>(a.n_resets, env);
       s = initial_state(R);
       s.epi = epi;
       begin_episode<ENV>(R, s, a.seed, a.env_base + (uint64_t)env);
     } else {
       s.over = 1;
-      s.epi = epi;
     }
   }
 }
 
-// s.epi for the envs whose own draws are keyed by it (whisky); a kernel that steps calls this after unpack_state
+// s.epi (the env's reset counter) for the envs whose own draws are keyed by it; a kernel that steps calls this after unpack_state
 template <int ENV>
-__device__ __forceinline__ void load_episode_index(EnvState &s, const int32_t *__restrict__ n_episodes, int64_t env, bool valid) {
-  if (HasEnvDraws<ENV>::value && valid) s.epi = n_episodes[env];
+__device__ __forceinline__ void load_episode_index(EnvState &s, const int32_t *__restrict__ n_resets, int64_t env, bool valid) {
+  if (HasEnvDraws<ENV>::value && valid) s.epi = n_resets[env];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -490,6 +342,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
+      case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
       }                                                                                                    \
     } else {                                                                                               \
@@ -499,6 +352,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
+      case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
       }                                                                                                    \
     }                                                                                                      \
@@ -512,6 +366,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
     case SGK_DISTRIBUTIONAL_SHIFT: { constexpr int E = SGK_DISTRIBUTIONAL_SHIFT; __VA_ARGS__; } break; \
     case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; __VA_ARGS__; } break; \
     case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; __VA_ARGS__; } break; \
+    case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; __VA_ARGS__; } break; \
     default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; __VA_ARGS__; } break;               \
     }                                                                                    \
   } while (0)
@@ -526,6 +381,7 @@ static inline StepArgs make_step_args(const Shard &sh, const uint8_t *actions, u
   a.last_return = sh.last_return;
   a.last_perf = sh.last_perf;
   a.n_episodes = sh.n_episodes;
+  a.n_resets = sh.n_resets;
   a.metrics = (long long *)sh.metric_slab;
   a.n = sh.n;
   a.seed = sh.seed;

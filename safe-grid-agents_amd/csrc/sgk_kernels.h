@@ -25,6 +25,8 @@ struct Shard {
   int32_t *last_return = nullptr; // [n] episode_return of the last finished episode
   int32_t *last_perf = nullptr;   // [n] get_last_performance()
   int32_t *n_episodes = nullptr;  // [n]
+  int32_t *n_resets = nullptr;    // [n] how often the env has been reset (create included); maintained for the envs with
+                                  // draws of their own (whisky, absent supervisor, safe interruptibility), whose key it is
   int64_t *metrics = nullptr;     // [SGK_METRICS_LEN] reduced vector (valid after launch_metrics_reduce)
   int64_t *metric_slab = nullptr; // [SGK_METRIC_SLOTS][SGK_METRICS_LEN] per-workgroup partials
   int32_t *wg_count = nullptr;    // compaction scratch
@@ -109,7 +111,7 @@ hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_s
 hipError_t launch_tabq_rollout_hbm(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st);
 size_t tabq_rollout_lds_bytes(const Shard &sh);
 
-int host_random_action(uint64_t seed, uint64_t env, uint64_t t);
+int host_random_action(uint64_t seed, uint64_t env, uint64_t t);  // sgk_host_debug.cpp
 int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int action, int out[5]);
 double host_epsilon_at(double eps0, int64_t anneal, int64_t t);
 

@@ -20,7 +20,8 @@ struct SgkRules {
   int32_t env_id, height, width, n_cells;
   int32_t start_agent, start_box;  // start_box == 255 when the level has no second sprite (sokoban: the box; whisky: the
                                    // whisky drape's cell -- state byte `box` holds it until it is drunk, 255 afterwards;
-                                   // absent supervisor: the punishment tile, which never moves)
+                                   // absent supervisor: the punishment tile, which never moves; safe interruptibility:
+                                   // the interruption tile, 255 once the button has been pressed)
   int32_t max_iterations, n_states;
   int32_t stay_obs, stay_hid;      // rewards of a move refused by a dynamic obstacle (sokoban)
   int32_t value_box, aux_reward;   // value drawn at the second sprite's cell; whisky: the reward that goes with the drape
@@ -33,10 +34,17 @@ struct SgkRules {
   uint8_t safety[SGK_CELLS];       // island: Manhattan distance from this cell to the nearest water
   uint8_t state_slot[SGK_CELLS];   // agent cell -> row of the LDS-resident Q image (255: the agent can never stand there)
   uint8_t slot_cell[SGK_CELLS];    // row -> cell, for the n_live_slots rows of non-terminal cells
-  int32_t n_slots, n_live_slots, pad1[2];  // rows of the LDS-resident Q image; the first n_live_slots map to slot_cell[],
-                                           // one more (when the level has terminal cells) is the shared all-zero row
+  int32_t n_slots, n_live_slots;   // rows of the LDS-resident Q image; the first n_live_slots map to slot_cell[],
+                                   // one more (when the level has terminal cells) is the shared all-zero row
+  int32_t aux_cell;                // safe interruptibility: the button's cell (255 elsewhere)
+  int32_t forced_action;           // safe interruptibility: the action the interruption drape substitutes (4 = stay)
   uint8_t palette[8][4];           // observation value -> RGB (uint8) for render("rgb_array"); [v][3] unused
+  uint32_t draw_threshold;         // the env's own draw happens / comes out true when x[0] < this (whisky: exploration rate;
+                                   // absent supervisor: supervisor present; safe interruptibility: to be interrupted)
+  int32_t render_hwc;              // render("rgb_array") frame layout: 0 = (3, H, W), 1 = (H, W, 3)  (sgk_levels.h switch)
+  int32_t pad2[2];
   uint8_t templ_alt[SGK_CELLS];    // absent supervisor: the backdrop of an episode without the supervisor (state bit `mode` = 0);
+                                   // safe interruptibility: the backdrop once the button is pressed (top row of B's);
                                    // a copy of templ for every other level
 };
 

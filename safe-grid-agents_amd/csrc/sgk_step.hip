@@ -6,32 +6,6 @@
 
 namespace sgk {
 
-// the kernels' transition function evaluated on the host for ONE (state, action): lets the CPU test-suite check
-// the rule tables and the push logic against the oracle without a GPU. Never used by a product path.
-int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int action, int out[5]) {
-  EnvState s;
-  s.pos = agent_cell; s.box = box_cell & 0xff; s.frame = 0; s.over = 0; s.ret = 0; s.hid = 0; s.epi = 0;
-  s.mode = (box_cell >> 8) & 1;  // the debug hook carries the state word's mode bit above the box byte
-  int r_obs = 0, r_hid = 0, term = 0;
-  switch (R.env_id) {
-  case SGK_BOAT_RACE: transition<SGK_BOAT_RACE>(R, s, action, r_obs, r_hid, term); break;
-  case SGK_ISLAND_NAVIGATION: transition<SGK_ISLAND_NAVIGATION>(R, s, action, r_obs, r_hid, term); break;
-  case SGK_SIDE_EFFECTS_SOKOBAN: transition<SGK_SIDE_EFFECTS_SOKOBAN>(R, s, action, r_obs, r_hid, term); break;
-  case SGK_DISTRIBUTIONAL_SHIFT: transition<SGK_DISTRIBUTIONAL_SHIFT>(R, s, action, r_obs, r_hid, term); break;
-  case SGK_WHISKY_GOLD: transition<SGK_WHISKY_GOLD>(R, s, action, r_obs, r_hid, term); break;
-  case SGK_ABSENT_SUPERVISOR: transition<SGK_ABSENT_SUPERVISOR>(R, s, action, r_obs, r_hid, term); break;
-  default: return -1;
-  }
-  out[0] = s.pos; out[1] = s.box; out[2] = r_obs; out[3] = r_hid; out[4] = term;
-  return 0;
-}
-
-int host_random_action(uint64_t seed, uint64_t env, uint64_t t) {
-  uint32_t x[4];
-  philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-  return action_from_block(x, t);
-}
-
 // slab -> one metrics vector (sums over slots for [0..7], maxima for [8..11]); one workgroup of 1024 lanes:
 // 16 columns x 64 slot-lanes, four independent loads in flight per lane, LDS tree over the slot-lanes
 __global__ __launch_bounds__(1024) void metrics_reduce_kernel(const long long *__restrict__ slab, long long *__restrict__ out) {
@@ -104,7 +78,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
       if (!RANDOM) a_cur = nv ? a.actions[ne] : (uint8_t)0;
     }
     if (!valid) s = initial_state(R);
-    load_episode_index<ENV>(s, a.n_episodes, env, valid);
+    load_episode_index<ENV>(s, a.n_resets, env, valid);
     int action = 0;
     if (RANDOM) {
       uint64_t ge = a.env_base + (uint64_t)env;
@@ -152,7 +126,7 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
     const bool valid = env < a.n;
     EnvState s = initial_state(R);
     if (valid) s = unpack_state(a.state[env]);
-    load_episode_index<ENV>(s, a.n_episodes, env, valid);
+    load_episode_index<ENV>(s, a.n_resets, env, valid);
     const uint64_t ge = a.env_base + (uint64_t)env;
     uint32_t x[4] = {0, 0, 0, 0};
     uint32_t rec = 0;
@@ -191,14 +165,13 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
           a.last_return[env] = s.ret;
           a.last_perf[env] = s.hid;
           bump_episode_count(a.n_episodes, env);
-          const int epi = s.epi + 1;
           if (auto_reset) {
+            const int epi = s.epi + 1;  // this reset's index; n_resets[env] is brought up to date once, after the loop
             s = initial_state(R);
             s.epi = epi;
             begin_episode<ENV>(R, s, a.seed, ge);
           } else {
             s.over = 1;
-            s.epi = epi;
           }
         }
       } else {
@@ -211,6 +184,7 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
     if (valid) {
       a.state[env] = pack_state(s);
       a.rec[env] = rec;
+      if (HasEnvDraws<ENV>::value) a.n_resets[env] = s.epi;  // this lane is the env's only writer
     }
     if (boards_on) {
       if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, a.boards, tile * WG, s);
@@ -227,7 +201,7 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
 template <int ENV, int LAYOUT>
 __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64_t *state, int8_t *boards,
                                                    const uint8_t *mask, int mode, int64_t n, uint64_t seed, uint64_t env_base,
-                                                   const int32_t *__restrict__ n_episodes) {
+                                                   int32_t *__restrict__ n_resets) {
   __shared__ SgkRules R;
   __shared__ CompactLds<Geom<ENV>::NC> C;
   stage_rules(R, rules);
@@ -242,7 +216,10 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
       EnvState cur = unpack_state(state[env]);
       bool hit = (mode == 2) ? false : (mode == 1 ? (cur.over != 0) : (mask == nullptr || mask[env] != 0));
       if (hit) {
-        load_episode_index<ENV>(s, n_episodes, env, true);  // what the new episode's own draws are keyed by
+        if (HasEnvDraws<ENV>::value) {  // every reset opens a new draw sequence: the counter is the key
+          s.epi = n_resets[env] + 1;
+          n_resets[env] = s.epi;
+        }
         begin_episode<ENV>(R, s, seed, env_base + (uint64_t)env);
         state[env] = pack_state(s);
       } else {
@@ -285,15 +262,17 @@ __global__ __launch_bounds__(WG) void render_rgb_kernel(const SgkRules *__restri
   __shared__ uint8_t pal[8][4];
   if (threadIdx.x < 32) (&pal[0][0])[threadIdx.x] = (&rules->palette[0][0])[threadIdx.x];
   __syncthreads();
+  const bool hwc = rules->render_hwc != 0;  // frame layout (H, W, 3) instead of (3, H, W): an include/sgk_levels.h switch
   const int64_t total = n * nc;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t env = i / nc;
     int c = (int)(i - env * nc);
     int v = boards[env * pitch + c] & 7;
-    uint8_t *o = dst + env * 3 * nc + c;
+    uint8_t *o = dst + env * 3 * nc + (hwc ? 3 * c : c);
+    const int plane = hwc ? 1 : nc;
     o[0] = pal[v][0];
-    o[nc] = pal[v][1];
-    o[2 * nc] = pal[v][2];
+    o[plane] = pal[v][1];
+    o[2 * plane] = pal[v][2];
   }
 }
 
@@ -392,6 +371,7 @@ static Shard shard_view(const Shard &sh, int64_t env_off, int64_t count) {
   v.last_return = sh.last_return + env_off;
   v.last_perf = sh.last_perf + env_off;
   v.n_episodes = sh.n_episodes + env_off;
+  v.n_resets = sh.n_resets + env_off;
   return v;
 }
 
@@ -433,7 +413,7 @@ hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStrea
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
                           reset_kernel<E, L><<<dim3(grid), dim3(WG), 0, st>>>(sh.rules_dev, sh.state,
-                                              sh.boards, mask, mode, sh.n, sh.seed, sh.env_base, sh.n_episodes));
+                                              sh.boards, mask, mode, sh.n, sh.seed, sh.env_base, sh.n_resets));
   return hipGetLastError();
 }
 

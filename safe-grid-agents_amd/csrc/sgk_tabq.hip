@@ -11,6 +11,7 @@ template <int ENV>
 __device__ __forceinline__ int state_index(const SgkRules &R, const EnvState &s) {
   if (ENV == SGK_WHISKY_GOLD) return s.pos + (s.box == R.start_box ? 0 : R.n_cells);  // (agent cell, whisky still there)
   if (ENV == SGK_ABSENT_SUPERVISOR) return s.pos + (s.mode ? 0 : R.n_cells);             // (agent cell, supervisor present)
+  if (ENV == SGK_SAFE_INTERRUPTIBILITY) return s.pos + (s.box == 255 ? R.n_cells : 0);   // (agent cell, button pressed): the coin does not show on the board
   return (ENV == SGK_SIDE_EFFECTS_SOKOBAN) ? s.pos * R.n_cells + s.box : s.pos;
 }
 
@@ -63,7 +64,7 @@ struct TabqArgs {
   uint64_t *state;
   uint32_t *rec;
   int8_t *boards;
-  int32_t *last_return, *last_perf, *n_episodes;
+  int32_t *last_return, *last_perf, *n_episodes, *n_resets;
   long long *metrics;
   double *table;       // [n][n_states][4]
   uint16_t *s_prev;    // state index the last action was chosen from; 0xffff = env was over
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
     const bool valid = env < a.n;
     EnvState s = initial_state(R);
     if (valid) s = unpack_state(a.state[env]);
-    load_episode_index<ENV>(s, a.n_episodes, env, valid);
+    load_episode_index<ENV>(s, a.n_resets, env, valid);
     const uint64_t ge = a.env_base + (uint64_t)env;
     double *tab = a.table + (valid ? env : 0) * (int64_t)a.n_states * 4;
     int si = state_index<ENV>(R, s);
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
         a.last_return[env] = s.ret;
         a.last_perf[env] = s.hid;
         bump_episode_count(a.n_episodes, env);
-        const int epi = s.epi + 1;
+        const int epi = s.epi + 1;  // this reset's index; n_resets[env] is brought up to date once, after the loop
         s = initial_state(R);
         s.epi = epi;
         begin_episode<ENV>(R, s, a.seed, ge);
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
     if (valid) {
       a.state[env] = pack_state(s);
       a.rec[env] = rec;  // boards are re-materialised by the caller (launch_reset mode 2)
+      if (HasEnvDraws<ENV>::value) a.n_resets[env] = s.epi;
     }
   }
   acc_flush(acc, a.metrics);
@@ -349,6 +351,7 @@ static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t fl
   a.last_return = sh.last_return;
   a.last_perf = sh.last_perf;
   a.n_episodes = sh.n_episodes;
+  a.n_resets = sh.n_resets;
   a.metrics = (long long *)sh.metric_slab;
   a.table = tq.table;
   a.s_prev = tq.s_prev;

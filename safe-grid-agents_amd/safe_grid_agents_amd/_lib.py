@@ -20,6 +20,7 @@ LAYOUT_PITCHED, LAYOUT_COMPACT = 0, 1
 TABQ_KERNEL_AUTO, TABQ_KERNEL_LDS, TABQ_KERNEL_HBM = 0, 1, 2
 MEM_HOST_VISIBLE = 0x100
 BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN, DISTRIBUTIONAL_SHIFT, WHISKY_GOLD, ABSENT_SUPERVISOR = 0, 1, 2, 3, 4, 5
+SAFE_INTERRUPTIBILITY = 6
 METRICS_LEN = 16
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, _M_RESERVED,
  M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)
@@ -37,7 +38,7 @@ class SgkInfo(ctypes.Structure):
         ("n_actions", ctypes.c_int32), ("board_pitch", ctypes.c_int32), ("layout", ctypes.c_int32),
         ("max_iterations", ctypes.c_int32), ("n_states", ctypes.c_int32), ("device", ctypes.c_int32),
         ("n_envs", ctypes.c_int64), ("seed", ctypes.c_uint64), ("env_index_base", ctypes.c_uint64),
-        ("lockstep_t", ctypes.c_uint64),
+        ("lockstep_t", ctypes.c_uint64), ("render_hwc", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -179,7 +180,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError here == ABI drift; tests/test_abi.py checks every symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.sgk_abi_version() != 1:
+    if lib.sgk_abi_version() != 2:
         raise ImportError("libsgk ABI version mismatch")
     _lib = lib
     return lib

@@ -22,12 +22,14 @@ ENV_IDS = {
     "DistributionalShift-v0": _lib.DISTRIBUTIONAL_SHIFT,
     "WhiskyGold-v0": _lib.WHISKY_GOLD,
     "AbsentSupervisor-v0": _lib.ABSENT_SUPERVISOR,
+    "SafeInterruptibility-v0": _lib.SAFE_INTERRUPTIBILITY,
 }
 # envs that define no hidden reward upstream: performance = episode return, info["hidden_reward"] is None in the
 # single-env wrapper (the batched integer record mirrors the observed reward instead, include/sgk_levels.h)
 NO_HIDDEN_REWARD = frozenset({"DistributionalShift-v0"})
 
-# reference parsing/parse.py:22-37; the three envs of the hot-path scope plus DistributionalShift, WhiskyGold and AbsentSupervisor
+# reference parsing/parse.py:22-37; the three envs of the hot-path scope plus DistributionalShift, WhiskyGold, AbsentSupervisor
+# and SafeInterruptibility
 ENV_MAP = {
     "bandit": "FriendFoe-v0",
     "belt": "ConveyorBelt-v0",
@@ -436,7 +438,8 @@ class BatchedGridworldEnv:
         import torch
 
         if out is None:
-            out = torch.empty((self.n_envs, 3, self.H, self.W), dtype=torch.uint8, device="cuda:%d" % self.device)
+            shape = (self.n_envs, self.H, self.W, 3) if self.info.render_hwc else (self.n_envs, 3, self.H, self.W)
+            out = torch.empty(shape, dtype=torch.uint8, device="cuda:%d" % self.device)
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_render_rgb(self._h.ptr, ctypes.c_void_p(out.data_ptr())))
         self._sync_lib_to_torch()

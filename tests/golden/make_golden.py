@@ -392,6 +392,11 @@ def main():
     golden_train("train_super_tabq_seed6.json",
                  ["-S", "6", "-E", "40", "-EE", "20", "-V", "140", "-EV", "1", "-D", "0.95",
                   "super", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
+    # SafeInterruptibility: a coin per episode decides whether the interruption tile freezes the agent; with --cheat the
+    # reference learns from the hidden reward (zero throughout an interrupted episode) and the action the env executed
+    golden_train("train_interrupt_tabq_seed8_cheat.json",
+                 ["-S", "8", "-E", "40", "-EE", "20", "-V", "140", "-EV", "1", "-C", "-D", "0.95",
+                  "interrupt", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
     golden_train_ppo("train_boat_ppo_mlp_seed5.json",
                      ["-S", "5", "-E", "4", "-EE", "3", "-V", "120", "-EV", "0", "boat", "ppo-mlp", "-l", "0.001", "-r", "2",
                       "-e", "5", "-b", "32", "-hd", "24"])

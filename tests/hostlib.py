@@ -1,0 +1,48 @@
+"""The product's rule builder + the kernels' transition code as a HOST-ONLY library (g++, no HIP): what the CPU test-suite
+checks against the oracle's sprite engine. `SGK_HOST_LIB` names a variant built elsewhere under an alternative reading of the
+upstream rules (tests/test_switch_variants.py); otherwise the default build is made in-tree (make -C csrc host)."""
+import ctypes
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "safe-grid-agents_amd", "csrc")
+DEFAULT = os.path.join(ROOT, "safe-grid-agents_amd", "lib", "libsgk_host.so")
+ERR_INVALID = -1
+
+_lib = None
+
+
+def build(out=None, defs=""):
+    """make -C csrc host [HOST_OUT=... HOST_DEFS=...]; returns the path of the library."""
+    cmd = ["make", "-C", CSRC, "host"]
+    if out:
+        cmd += ["HOST_OUT=" + out, "HOST_DEFS=" + defs]
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return out or DEFAULT
+
+
+def load(path=None):
+    global _lib
+    if path is None and _lib is not None:
+        return _lib
+    p = path or os.environ.get("SGK_HOST_LIB")
+    if p is None:
+        p = build()
+    L = ctypes.CDLL(p)
+    V = ctypes.c_void_p
+    L.sgk_debug_host_transition.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, V]
+    L.sgk_debug_level.argtypes = [ctypes.c_int, V, V, V]
+    L.sgk_debug_rules.argtypes = [ctypes.c_int, V]
+    L.sgk_random_action.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
+    L.sgk_debug_episode_coin.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
+    if path is None:
+        _lib = L
+    return L
+
+
+def rules_bytes(L, env_id):
+    """The whole SgkRules record of a level as bytes (for comparing two builds)."""
+    buf = ctypes.create_string_buffer(L.sgk_debug_rules_size())
+    assert L.sgk_debug_rules(env_id, buf) == 0
+    return buf.raw

@@ -17,7 +17,7 @@ from safe_grid_agents_amd import _lib
 pytestmark = pytest.mark.gpu
 
 ENVS = ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0", "DistributionalShift-v0", "WhiskyGold-v0",
-        "AbsentSupervisor-v0"]
+        "AbsentSupervisor-v0", "SafeInterruptibility-v0"]
 
 
 def _torch():
@@ -117,7 +117,7 @@ def test_random_rollouts_stepwise_graph_and_fused_agree_with_oracle(name, layout
     stepwise.close(); fused.close()
 
 
-@pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "WhiskyGold-v0", "AbsentSupervisor-v0"])
+@pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "WhiskyGold-v0", "AbsentSupervisor-v0", "SafeInterruptibility-v0"])
 def test_sharding_reproduces_the_unsharded_batch(name):
     """Contiguous env-id blocks with env_index_base reproduce the unsharded batch: the action stream AND the envs' own draws
     (WhiskyGold's replaced actions, AbsentSupervisor's coins) are keyed by the global env index."""
@@ -190,7 +190,7 @@ def test_obs_f32_is_the_float_board(name, layout):
 @pytest.mark.parametrize("name", ["train_boat_tabq_seed7.json", "train_island_tabq_seed1.json",
                                   "train_sokoban_tabq_seed123_cheat.json", "train_boat_tabq_seed3_video.json",
                                   "train_lava_tabq_seed11.json", "train_whisky_tabq_seed4_cheat.json",
-                                  "train_super_tabq_seed6.json"])
+                                  "train_super_tabq_seed6.json", "train_interrupt_tabq_seed8_cheat.json"])
 def test_single_env_train_reproduces_reference_run_on_gpu(golden_dir, name):
     from test_host_golden import run_train_golden
 
@@ -334,6 +334,12 @@ def _board_of_state(env, si):
         if absent:
             board[board == 5] = 1  # the supervisor cells of the border show the blank backdrop
         board[dims[3]] = 3
+    elif env.name == "SafeInterruptibility-v0":  # (agent cell, button pressed): the pressed half follows the other
+        pressed, cell = divmod(int(si), nc)
+        if pressed:
+            board[: env.W] = 4  # the top row of B's; the interruption tile is gone
+        else:
+            board[dims[3]] = 5
     else:
         cell = int(si)
     board[cell] = aval[cell]
@@ -342,7 +348,8 @@ def _board_of_state(env, si):
 
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", False), ("IslandNavigation-v0", True),
-                                         ("WhiskyGold-v0", False), ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", False)])
+                                         ("WhiskyGold-v0", False), ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", False),
+                                         ("SafeInterruptibility-v0", False), ("SafeInterruptibility-v0", True)])
 def test_tabq_fused_rollout_bit_exact(name, cheat):
     _torch()
     n, steps, seed = 200, 700, 21
@@ -361,7 +368,7 @@ def test_tabq_fused_rollout_bit_exact(name, cheat):
 
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", True), ("SideEffectsSokoban-v0", False),
-                                         ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", True)])
+                                         ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", True), ("SafeInterruptibility-v0", True)])
 def test_tabq_stepwise_kernels_bit_exact(name, cheat):
     _torch()
     n, steps, seed = 130, 260, 8

@@ -1,24 +1,41 @@
-"""Product host logic without a GPU: the rule tables + the kernels' transition function (compiled for the host
-inside libsgk.so, debug hook sgk_debug_host_transition) against the oracle's sprite engine, exhaustively over every
-reachable (agent cell, box cell, action). WhiskyGold replaces actions itself once the whisky is drunk: the oracle reports the
-action it executed and that one is fed to the table (the replacement draw has its own test)."""
+"""Product host logic without a GPU: the rule tables + the kernels' transition function (sgk_transition.h, the very code the
+kernels compile, built for the host by g++: tests/hostlib.py) against the oracle's sprite engine, exhaustively over every
+reachable (agent cell, second sprite cell, per-episode coin, action). WhiskyGold replaces actions itself once the whisky is
+drunk: the oracle reports the action it executed and that one is fed to the table (the replacement draw has its own test);
+SafeInterruptibility's substitution is deterministic and part of the product code under test, so there the agent's own action
+is fed.
+
+This module also runs, unchanged, under every alternative reading of an uncertain upstream detail: test_switch_variants.py
+builds both sides with -DSGK_...=... and points SGK_HOST_LIB / SGK_ORACLE_SO at the variant libraries."""
 import ctypes
+import os
 
 import numpy as np
 
+import hostlib
 from oracle import oracle as O
-from safe_grid_agents_amd import _lib
+
+ERR_INVALID = hostlib.ERR_INVALID
+COIN_ENVS = ("AbsentSupervisor-v0", "SafeInterruptibility-v0")
+
+
+def check(rc):
+    assert rc == 0, rc
 
 
 def _seeds(name):
-    """Seeds to build the oracle env with: one, or for AbsentSupervisor one per outcome of its per-episode coin."""
-    if name != "AbsentSupervisor-v0":
+    """Seeds to build the oracle env with: one, or for the envs with a per-episode coin one per outcome."""
+    if name not in COIN_ENVS:
         return [0]
     found = {}
     for seed in range(64):
-        found.setdefault(int(O.EnvBatch(name, 1, seed=seed).field("supervisor")[0]), seed)
+        found.setdefault(int(O.EnvBatch(name, 1, seed=seed).field("coin")[0]), seed)
     assert sorted(found) == [0, 1]
     return [found[0], found[1]]
+
+
+def _hook_action(name, chosen, executed):
+    return chosen if name == "SafeInterruptibility-v0" else executed
 
 
 def _reachable_states(name, seed=0):
@@ -44,7 +61,7 @@ def _reachable_states(name, seed=0):
 
 
 def test_transition_tables_match_oracle_everywhere():
-    lib = _lib.load()
+    lib = hostlib.load()
     for name, env_id in O.ENV_IDS.items():
         for seed in _seeds(name):
             states = _reachable_states(name, seed)
@@ -53,43 +70,114 @@ def test_transition_tables_match_oracle_everywhere():
             for (cell, box), path in states.items():
                 for a in range(4):
                     e = O.EnvBatch(name, 1, seed=seed)
-                    mode = int(e.field("supervisor")[0])  # the state word's mode bit rides above the box byte in the hook
+                    mode = int(e.field("coin")[0])  # the state word's mode bit rides above the box byte in the hook
                     for pa in path:
                         e.step(0, pa)
                     r, h, d, executed = e.step(0, a)
                     term = int(d)  # paths are < 100 steps, so done == terminal here
                     out = (ctypes.c_int32 * 5)()
-                    _lib.check(lib.sgk_debug_host_transition(env_id, cell, box | (mode << 8), executed, out))
+                    check(lib.sgk_debug_host_transition(env_id, cell, box | (mode << 8), _hook_action(name, a, executed), out))
                     assert list(out) == [int(e.field("agent_cell")[0]), int(e.field("box_cell")[0]), r, h, term], (
                         name, cell, box, a)
                     checked += 1
             assert checked == 4 * len(states)
 
 
-def test_level_tables_render_the_oracle_boards():
-    lib = _lib.load()
+def _product_board(name, templ, templ_alt, aval, nc, cell, box, coin, value_box):
+    """The board the product's writers materialise for a state: backdrop (one of two), second sprite, agent on top."""
+    alt = (name == "AbsentSupervisor-v0" and not coin) or (name == "SafeInterruptibility-v0" and box == 255)
+    board = np.array((templ_alt if alt else templ)[:nc], dtype=np.int8)
+    if box != 255:
+        board[box] = value_box
+    board[cell] = aval[cell]
+    return board
+
+
+class _Rules(ctypes.Structure):
+    """Prefix of SgkRules (safe-grid-agents_amd/csrc/sgk_rules.h) up to the fields this module reads."""
+    _fields_ = [("env_id", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32), ("n_cells", ctypes.c_int32),
+                ("start_agent", ctypes.c_int32), ("start_box", ctypes.c_int32), ("max_iterations", ctypes.c_int32),
+                ("n_states", ctypes.c_int32), ("stay_obs", ctypes.c_int32), ("stay_hid", ctypes.c_int32),
+                ("value_box", ctypes.c_int32), ("aux_reward", ctypes.c_int32), ("dcell", ctypes.c_int32 * 4),
+                ("trans", ctypes.c_uint32 * 256), ("templ", ctypes.c_uint8 * 64), ("agent_value", ctypes.c_uint8 * 64),
+                ("box_penalty", ctypes.c_int8 * 64), ("box_blocked", ctypes.c_uint8 * 64), ("safety", ctypes.c_uint8 * 64),
+                ("state_slot", ctypes.c_uint8 * 64), ("slot_cell", ctypes.c_uint8 * 64), ("n_slots", ctypes.c_int32),
+                ("n_live_slots", ctypes.c_int32), ("aux_cell", ctypes.c_int32), ("forced_action", ctypes.c_int32),
+                ("palette", (ctypes.c_uint8 * 4) * 8), ("draw_threshold", ctypes.c_uint32), ("render_hwc", ctypes.c_int32),
+                ("pad2", ctypes.c_int32 * 2), ("templ_alt", ctypes.c_uint8 * 64)]
+
+
+def _rules(lib, env_id):
+    assert lib.sgk_debug_rules_size() == ctypes.sizeof(_Rules), "tests/test_tables_cpu.py: _Rules is out of date with sgk_rules.h"
+    R = _Rules()
+    check(lib.sgk_debug_rules(env_id, ctypes.byref(R)))
+    return R
+
+
+def test_level_tables_render_the_oracle_boards_in_every_reachable_state():
+    """Backdrop(s) + second sprite + agent value, composed the way the board writers do, equal the oracle's rendered board in
+    EVERY reachable state (both outcomes of a per-episode coin), not just after reset."""
+    lib = hostlib.load()
     for name, env_id in O.ENV_IDS.items():
-        dims = (ctypes.c_int32 * 4)()
-        templ = (ctypes.c_uint8 * 64)()
-        aval = (ctypes.c_uint8 * 64)()
-        _lib.check(lib.sgk_debug_level(env_id, dims, templ, aval))
-        H, W, start, box = list(dims)
-        e = O.EnvBatch(name, 1, seed=_seeds(name)[-1])  # AbsentSupervisor: the episode with the supervisor (templ)
-        assert (H, W) == (e.H, e.W) and start == e.field("agent_cell")[0] and box == e.field("box_cell")[0]
-        board = np.array(templ[: H * W], dtype=np.int8)
-        if box != 255:
-            board[box] = {"SideEffectsSokoban-v0": 4, "WhiskyGold-v0": 3, "AbsentSupervisor-v0": 3}[name]
-        board[start] = aval[start]
-        assert (board.reshape(H, W) == e.board(0)).all()
+        R = _rules(lib, env_id)
+        nc = R.n_cells
+        for seed in _seeds(name):
+            e0 = O.EnvBatch(name, 1, seed=seed)
+            assert (R.height, R.width) == (e0.H, e0.W)
+            assert R.start_agent == e0.field("agent_cell")[0] and R.start_box == e0.field("box_cell")[0]
+            for (cell, box), path in _reachable_states(name, seed).items():
+                e = O.EnvBatch(name, 1, seed=seed)
+                coin = int(e.field("coin")[0])
+                for pa in path:
+                    e.step(0, pa)
+                got = _product_board(name, R.templ, R.templ_alt, R.agent_value, nc, cell, box, coin, R.value_box)
+                assert (got.reshape(e.H, e.W) == e.board(0)).all(), (name, cell, box, coin)
+
+
+def test_palette_renders_the_oracle_frame():
+    """render("rgb_array") in the product is palette[value] per cell, laid out per SgkRules.render_hwc: equal to the oracle's
+    character-colour rendering in every reachable state. (An alternative value map that gives two differently coloured
+    characters ONE value cannot be rendered from values: such levels are named in SGK_SKIP_PALETTE by the variant test.)"""
+    lib = hostlib.load()
+    skip = os.environ.get("SGK_SKIP_PALETTE", "").split(",")
+    for name, env_id in O.ENV_IDS.items():
+        if name in skip:
+            continue
+        R = _rules(lib, env_id)
+        nc = R.n_cells
+        pal = np.array([[R.palette[v][k] for k in range(3)] for v in range(8)], dtype=np.uint8)
+        for seed in _seeds(name):
+            for (cell, box), path in list(_reachable_states(name, seed).items())[::3]:
+                e = O.EnvBatch(name, 1, seed=seed)
+                coin = int(e.field("coin")[0])
+                for pa in path:
+                    e.step(0, pa)
+                board = _product_board(name, R.templ, R.templ_alt, R.agent_value, nc, cell, box, coin, R.value_box)
+                frame = pal[board & 7]  # [cell][3]
+                got = frame.reshape(-1) if R.render_hwc else frame.T.reshape(-1)
+                assert (got == e.render_rgb(0).reshape(-1)).all(), (name, cell, box)
 
 
 def test_bad_arguments_are_rejected():
-    lib = _lib.load()
+    lib = hostlib.load()
     out = (ctypes.c_int32 * 5)()
-    assert lib.sgk_debug_host_transition(9, 0, 0, 0, out) == _lib.ERR_INVALID
-    assert lib.sgk_debug_host_transition(0, 99, 0, 0, out) == _lib.ERR_INVALID
-    assert lib.sgk_debug_host_transition(0, 6, 255, 4, out) == _lib.ERR_INVALID
-    assert b"bad" in lib.sgk_last_error()
+    assert lib.sgk_debug_host_transition(9, 0, 0, 0, out) == ERR_INVALID
+    assert lib.sgk_debug_host_transition(0, 99, 0, 0, out) == ERR_INVALID
+    assert lib.sgk_debug_host_transition(0, 6, 255, 4, out) == ERR_INVALID
+
+
+def test_random_action_stream_and_episode_coins_match_the_oracle():
+    lib = hostlib.load()
+    for seed, env, t in [(0, 0, 0), (0x5AFE, 7, 63), (0x5AFE, 7, 64), (99, (1 << 40) + 5, 12345), (2**63 + 1, 3, 2**33 + 17)]:
+        assert lib.sgk_random_action(seed, env, t) == O.random_action(seed, env, t)
+    for name in COIN_ENVS:
+        e = O.EnvBatch(name, 40, seed=17, env_begin=1000)
+        for k in range(1, 6):  # reset number k (the create-time reset is number 1)
+            want = e.field("coin")
+            got = [lib.sgk_debug_episode_coin(O.ENV_IDS[name], 17, 1000 + i, k) for i in range(40)]
+            assert got == want.tolist(), (name, k)
+            e.reset()
+        assert 0 < sum(got) < 40
 
 
 def test_random_walks_through_the_host_transition_match_the_oracle():
@@ -97,26 +185,27 @@ def test_random_walks_through_the_host_transition_match_the_oracle():
     (state carried in Python), gives the oracle's rewards, terminations and positions."""
     from hypothesis import given, settings, strategies as st
 
-    lib = _lib.load()
+    lib = hostlib.load()
 
-    @settings(max_examples=150, deadline=None)
+    @settings(max_examples=int(os.environ.get("SGK_WALK_EXAMPLES", "150")), deadline=None)
     @given(env_name=st.sampled_from(sorted(O.ENV_IDS)), actions=st.lists(st.integers(0, 3), min_size=1, max_size=120))
     def run(env_name, actions):
         env_id = O.ENV_IDS[env_name]
-        e = O.EnvBatch(env_name, 1, seed=len(actions))  # the seed varies AbsentSupervisor's coins
+        e = O.EnvBatch(env_name, 1, seed=len(actions))  # the seed varies the per-episode coins
         dims = (ctypes.c_int32 * 4)()
         templ = (ctypes.c_uint8 * 64)()
         aval = (ctypes.c_uint8 * 64)()
-        _lib.check(lib.sgk_debug_level(env_id, dims, templ, aval))
+        check(lib.sgk_debug_level(env_id, dims, templ, aval))
         cell, box, frame = dims[2], dims[3], 0
+        horizon = _rules(lib, env_id).max_iterations
         out = (ctypes.c_int32 * 5)()
         for a in actions:
-            mode = int(e.field("supervisor")[0])
+            mode = int(e.field("coin")[0])
             r, h, d, executed = e.step(0, a)
-            _lib.check(lib.sgk_debug_host_transition(env_id, cell, box | (mode << 8), executed, out))
+            check(lib.sgk_debug_host_transition(env_id, cell, box | (mode << 8), _hook_action(env_name, a, executed), out))
             cell, box = out[0], out[1]
             frame += 1
-            done = bool(out[4]) or frame >= 100
+            done = bool(out[4]) or frame >= horizon
             assert (out[2], out[3], int(done)) == (r, h, d)
             assert cell == e.field("agent_cell")[0] and box == e.field("box_cell")[0]
             if d:
