@@ -162,6 +162,18 @@ SGK_API int sgk_step_random_prepare(sgk_env *h, int32_t n_steps, uint32_t flags)
 SGK_API int sgk_step_repeat(sgk_env *h, const uint8_t *actions_dev, int32_t n_steps, uint32_t flags);
 /* the same n_steps inside ONE launch: state stays in registers, boards are materialised once at the end */
 SGK_API int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags);
+/* The same n_steps in ONE launch with EVERY step's outputs materialised in HBM, as n_steps calls of sgk_step would leave them
+ * one after the other: the successor board of every env (streaming tile stores) and its step record. The batched
+ * dqn_warmup / random data collection (reference warmup.py:14-21: every random-action transition is kept). Destinations:
+ *   boards_ring_dev == NULL and recs_ring_dev == NULL   the env's own board / record buffers (sgk_boards_dev,
+ *       sgk_step_records_dev): each step overwrites the previous one's, the last step's outputs remain;
+ *   otherwise trajectory rings the caller owns: boards int8 [ring_slices][n_envs][n_cells] (dense rows, 16-byte aligned),
+ *       records sgk_step_rec [ring_slices][n_envs] (either may be NULL); step k of this call goes to slice
+ *       (first_slice + k) % ring_slices. The env's own buffers then show the final state, as after sgk_rollout_random.
+ * What a per-step launch pays and this does not: the launch boundary and the state word's round trip through HBM. Results
+ * (state, records, boards, episode arrays, metrics) equal n_steps calls of sgk_step_random(1), bit for bit. */
+SGK_API int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flags, int8_t *boards_ring_dev,
+                                      sgk_step_rec *recs_ring_dev, int32_t ring_slices, int32_t first_slice);
 /* Book n_steps lockstep steps that were issued OUTSIDE the library's sight: a caller that captured sgk_step() into its
  * own hipGraph (e.g. torch.cuda.CUDAGraph around policy + env.step) replays it without re-entering sgk_step, so the
  * host-side lockstep counter and SGK_M_STEPS must be advanced by hand after each replay (n_steps < 0 un-counts the

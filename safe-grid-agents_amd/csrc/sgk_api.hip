@@ -210,6 +210,12 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
     int v = atoi(mg);
     if (v >= 64) s.max_grid = v;
   }
+  // the streaming rollout keeps a wave on its tile for a whole launch: up to 8 workgroups (32 waves) per CU in flight
+  s.stream_grid = s.n_cus * 8;
+  if (const char *sg = getenv("SGK_STREAM_GRID")) {
+    int v = atoi(sg);
+    if (v >= 64) s.stream_grid = v;
+  }
   SGK_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   const int64_t n_pad = ((s.n + 255) / 256) * 256;
@@ -536,6 +542,22 @@ int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
   if (n_steps == 0) return SGK_OK;
   SGK_HIP(sgk::launch_rollout_random(h->sh, n_steps, flags, h->stream));
+  h->sh.lockstep_t += (uint64_t)n_steps;
+  h->t_dev_stale = true;
+  h->steps_issued += h->sh.n * (int64_t)n_steps;
+  return SGK_OK;
+}
+
+int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flags, int8_t *boards_ring_dev, sgk_step_rec *recs_ring_dev,
+                              int32_t ring_slices, int32_t first_slice) {
+  SGK_CHECK_HANDLE(h);
+  if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
+  if ((boards_ring_dev || recs_ring_dev) && (ring_slices < 1 || first_slice < 0 || first_slice >= ring_slices))
+    return fail(SGK_ERR_INVALID, "a trajectory ring needs ring_slices >= 1 and 0 <= first_slice < ring_slices");
+  if (n_steps == 0) return SGK_OK;
+  const bool rings = boards_ring_dev || recs_ring_dev;
+  SGK_HIP(sgk::launch_rollout_stream(h->sh, n_steps, flags, boards_ring_dev, reinterpret_cast<uint32_t *>(recs_ring_dev),
+                                     rings ? ring_slices : 1, rings ? first_slice : 0, h->stream));
   h->sh.lockstep_t += (uint64_t)n_steps;
   h->t_dev_stale = true;
   h->steps_issued += h->sh.n * (int64_t)n_steps;

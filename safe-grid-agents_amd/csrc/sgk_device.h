@@ -160,19 +160,14 @@ __device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *_
   for (int q = 0; q < NW / 4; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
-// COMPACT: rows of exactly NC bytes. The workgroup's tile (256 envs x NC bytes, 16-byte aligned and
-// contiguous in HBM) is written as 16-byte chunks, lane i taking chunks i, i+256, ...: each store
-// instruction covers 1 KiB of contiguous memory. A chunk is the backdrop rotated to the chunk's phase
-// (precomputed in LDS: rot[r][b] = templ[(r + b) % NC]) with the agent/box cells of the (at most two,
-// NC >= 16) envs it overlaps poked in from the LDS-staged positions of the neighbouring lanes.
+// COMPACT: rows of exactly NC bytes, written tile-wise as 16-byte chunks so that each store instruction covers up to 1 KiB of
+// contiguous memory. A chunk is the backdrop rotated to the chunk's phase (tabulated once per workgroup in LDS:
+// rot[r][b] = templ[(r + b) % NC]) with the agent / second-sprite cells of the (at most two, NC >= 16) envs it overlaps poked
+// in (WaveTileWriter below).
 template <int NC>
 struct alignas(16) CompactLds {  // rot rows are read with ds_read_b128
   uint8_t rot[NC][16];
   uint8_t rot_alt[NC][16];  // the same for templ_alt (envs with two backdrops; unused elsewhere)
-  uint8_t pos[WG];
-  uint8_t box[WG];
-  uint8_t aval[WG];
-  uint8_t alt[WG];          // 1: this env's board shows templ_alt
 };
 
 template <int NC>
@@ -185,69 +180,119 @@ __device__ __forceinline__ void stage_rotations(CompactLds<NC> &C, const SgkRule
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------
+// WAVE-PRIVATE compact tiles. One wave = 64 consecutive envs = 64 * NC contiguous bytes (a multiple of 16), written as 4 * NC
+// 16-byte chunks, lane l taking chunks l, l + 64, ...: every store instruction still covers up to 1 KiB of contiguous HBM, but
+// a wave assembles its OWN chunks -- the sprite cells of the (at most two) envs a chunk overlaps come from the owning lanes by
+// ds_bpermute (the LDS crossbar, no LDS memory), the backdrop rotated to each chunk's phase sits in registers for the whole
+// kernel -- so there is no workgroup barrier and no LDS traffic per tile (the workgroup-tile writer above needs two barriers
+// and six LDS byte reads per chunk). What a lane contributes is one packed word: agent cell | second sprite cell << 8 | value
+// drawn at the agent's cell << 16 | (board shows templ_alt) << 24.
+// ------------------------------------------------------------------------------------------------
+template <int ENV>
+__device__ __forceinline__ uint32_t sprite_info(const SgkRules &R, const EnvState &s) {
+  return (uint32_t)s.pos | ((uint32_t)s.box << 8) | ((uint32_t)R.agent_value[s.pos] << 16) |
+         ((HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s)) ? (1u << 24) : 0u);
+}
+
+// byte b (0..15) of the 16-byte chunk w <- v; a b outside the chunk changes nothing
+__device__ __forceinline__ void poke16(uint32_t (&w)[4], int b, uint32_t v) {
+  const bool in = (unsigned)b < 16u;
+  const int k = b >> 2, sh = (b & 3) * 8;
+  const uint32_t keep = ~(0xffu << sh), val = v << sh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = (in && k == q) ? ((w[q] & keep) | val) : w[q];
+}
+
 template <int ENV, int NC>
-__device__ __forceinline__ void write_tile_compact(CompactLds<NC> &C, const SgkRules &R, int8_t *__restrict__ boards,
-                                                   int64_t tile_env0, const EnvState &s) {
-  // publish this lane's sprite cells to the workgroup
-  C.pos[threadIdx.x] = (uint8_t)s.pos;
-  C.box[threadIdx.x] = (uint8_t)s.box;
-  C.aval[threadIdx.x] = R.agent_value[s.pos];
-  if (HasAltBackdrop<ENV>::value) C.alt[threadIdx.x] = alt_backdrop<ENV>(s) ? 1 : 0;
-  __syncthreads();
-  constexpr int CHUNKS = WG * NC / 16;
-  uint4 *dst = reinterpret_cast<uint4 *>(boards + tile_env0 * NC);
-#if SGK_STREAM_STORES
-  // one buffer descriptor per tile, built from wave-uniform values (the tile base); per-lane part in the offset
-  const __amdgpu_buffer_rsrc_t tile_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, WG * NC, 0x00020000);
-#endif
-  for (int j = threadIdx.x; j < CHUNKS; j += WG) {
-    int byte0 = j * 16;
-    int e0 = byte0 / NC;
-    int r = byte0 - e0 * NC;
-    uint4 v = *reinterpret_cast<const uint4 *>(&C.rot[r][0]);
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    if (HasAltBackdrop<ENV>::value) {
-      // the backdrop depends on the env's state; a chunk covers the end of env e0 (bytes below `bnd`) and the start of
-      // env e0 + 1 (NC >= 16: never a third)
-      const uint4 va = *reinterpret_cast<const uint4 *>(&C.rot_alt[r][0]);
-      const uint32_t alt[4] = {va.x, va.y, va.z, va.w};
-      const int bnd = (e0 + 1) * NC - byte0;
-      const bool m0 = C.alt[e0] == 0, m1 = (e0 + 1 < WG) ? (C.alt[e0 + 1] == 0) : m0;  // true: the primary backdrop
+struct WaveTileWriter {
+  static constexpr int CHUNKS = 4 * NC;  // 64 envs * NC bytes / 16
+  static constexpr int ITS = (CHUNKS + 63) / 64;
+  static constexpr bool ALT = HasAltBackdrop<ENV>::value;
+  uint32_t rot[ITS][4];                 // the backdrop rotated to this lane's chunk phases
+  uint32_t rot_alt[ALT ? ITS : 1][4];   // the same for templ_alt
+  int e0[ITS];                          // first env (lane of this wave) chunk `it` overlaps
+  int base0[ITS];                       // chunk-relative byte of cell 0 of env e0 (<= 0); env e0 + 1 starts NC later
+  uint32_t value_box;
+
+  // C: the rotation tables staged in LDS once per workgroup (stage_rotations)
+  __device__ __forceinline__ void init(const CompactLds<NC> &C, const SgkRules &R) {
+    const int lane = threadIdx.x & 63;
+    value_box = (uint32_t)R.value_box;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int nb = bnd - 4 * k;  // bytes of this dword that belong to env e0
-        const uint32_t low = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
-        w[k] = ((m0 ? w[k] : alt[k]) & low) | ((m1 ? w[k] : alt[k]) & ~low);
+    for (int it = 0; it < ITS; ++it) {
+      int j = lane + 64 * it;
+      if (j >= CHUNKS) j = CHUNKS - 1;  // inactive lanes of the last round keep valid indices
+      const int byte0 = 16 * j;
+      e0[it] = byte0 / NC;
+      const int r = byte0 - e0[it] * NC;
+      base0[it] = -r;
+      const uint4 v = *reinterpret_cast<const uint4 *>(&C.rot[r][0]);
+      rot[it][0] = v.x; rot[it][1] = v.y; rot[it][2] = v.z; rot[it][3] = v.w;
+      if (ALT) {
+        const uint4 va = *reinterpret_cast<const uint4 *>(&C.rot_alt[r][0]);
+        rot_alt[it][0] = va.x; rot_alt[it][1] = va.y; rot_alt[it][2] = va.z; rot_alt[it][3] = va.w;
       }
     }
-#pragma unroll
-    for (int de = 0; de < 2; ++de) {
-      int e = e0 + de;
-      if (e < WG) {
-        int base = e * NC - byte0;  // chunk-relative byte of cell 0 of env e
-        if (HasSprite2<ENV>::value) {  // a `box` of 255 (whisky drunk) lands outside every chunk
-          int b = base + (int)C.box[e];
-          if (b >= 0 && b < 16) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] = (k == (b >> 2)) ? poke_byte(w[k], (b & 3) * 8, (uint32_t)R.value_box) : w[k];
-          }
-        }
-        int b = base + (int)C.pos[e];
-        if (b >= 0 && b < 16) {
-          uint32_t av = C.aval[e];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) w[k] = (k == (b >> 2)) ? poke_byte(w[k], (b & 3) * 8, av) : w[k];
-        }
-      }
-    }
-#if SGK_STREAM_STORES
-    sgk_u32x4 v4 = {w[0], w[1], w[2], w[3]};
-    __builtin_amdgcn_raw_buffer_store_b128(v4, tile_rsrc, j * 16, 0, /*aux: sc1*/ 16);
-#else
-    dst[j] = make_uint4(w[0], w[1], w[2], w[3]);
-#endif
   }
-  __syncthreads();  // pos/box/aval are rewritten by the next tile
+
+  // Assemble and store this wave's tile. All 64 lanes must call (the exchange is a wave operation). `tile` is wave-uniform and
+  // 16-byte aligned; all 64 * NC bytes are written (callers point it at memory that has them).
+  __device__ __forceinline__ void write(uint32_t info, int8_t *tile) const {
+    const int lane = threadIdx.x & 63;
+#if SGK_STREAM_STORES
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tile, 0, 64 * NC, 0x00020000);
+#endif
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      const int j = lane + 64 * it;
+      const uint32_t i0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * e0[it], (int)info);
+      const uint32_t i1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * min(e0[it] + 1, 63), (int)info);
+      uint32_t w[4];
+      if (ALT) {
+        // the backdrop depends on the env: bytes below `bnd` belong to env e0, the rest to env e0 + 1 (NC >= 16: never a third)
+        const int bnd = NC + base0[it];
+        const bool a0 = (i0 >> 24) & 1u, a1 = (e0[it] + 1 < 64) ? ((i1 >> 24) & 1u) : a0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int nb = bnd - 4 * k;  // bytes of this dword that belong to env e0
+          const uint32_t low = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+          w[k] = ((a0 ? rot_alt[it][k] : rot[it][k]) & low) | ((a1 ? rot_alt[it][k] : rot[it][k]) & ~low);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = rot[it][k];
+      }
+      // sprites of env e0, then of env e0 + 1 (the second sprite under the agent; a cell of 255 lands outside every chunk)
+      if (HasSprite2<ENV>::value) poke16(w, base0[it] + (int)((i0 >> 8) & 0xffu), value_box);
+      poke16(w, base0[it] + (int)(i0 & 0xffu), (i0 >> 16) & 0xffu);
+      if (e0[it] + 1 < 64) {
+        if (HasSprite2<ENV>::value) poke16(w, base0[it] + NC + (int)((i1 >> 8) & 0xffu), value_box);
+        poke16(w, base0[it] + NC + (int)(i1 & 0xffu), (i1 >> 16) & 0xffu);
+      }
+      if (ITS * 64 == CHUNKS || j < CHUNKS) {
+#if SGK_STREAM_STORES
+        sgk_u32x4 v4 = {w[0], w[1], w[2], w[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, j * 16, 0, /*aux: sc1*/ 16);
+#else
+        reinterpret_cast<uint4 *>(tile)[j] = make_uint4(w[0], w[1], w[2], w[3]);
+#endif
+      }
+    }
+  }
+};
+
+// one env's NC-byte row written byte by byte from its own state: the slow path for destinations the tile writer cannot take
+// (a trajectory slice whose last tile is partial or whose rows are not 16-byte aligned)
+template <int ENV, int NC>
+__device__ __noinline__ void write_row_bytes(const SgkRules &R, int8_t *__restrict__ row, const EnvState &s) {
+  const uint8_t *backdrop = (HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s)) ? R.templ_alt : R.templ;
+  for (int c = 0; c < NC; ++c) {
+    uint8_t v = backdrop[c];
+    if (HasSprite2<ENV>::value && c == s.box) v = (uint8_t)R.value_box;
+    if (c == s.pos) v = R.agent_value[c];
+    row[c] = (int8_t)v;
+  }
 }
 
 template <int ENV>

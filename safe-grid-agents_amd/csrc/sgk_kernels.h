@@ -14,7 +14,7 @@ namespace sgk {
 struct Shard {
   int env_id = 0, layout = 0, device = 0;
   int n_cells = 0, pitch = 0, n_states = 0;
-  int n_cus = 256, max_grid = 2048;
+  int n_cus = 256, max_grid = 2048, stream_grid = 2048;
   int64_t n = 0;
   uint64_t seed = 0, env_base = 0, lockstep_t = 0;
   SgkRules rules_host;
@@ -45,6 +45,10 @@ struct TabqShard {
 
 hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, hipStream_t st);
 hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flags, hipStream_t st);
+// the same loop with every step's board tile and step record materialised: into the env's own buffers (rings == nullptr) or
+// into trajectory rings boards [ring][n][n_cells] / recs [ring][n], step k -> slice (slice0 + k) % ring
+hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flags, int8_t *boards_ring, uint32_t *recs_ring,
+                                 int32_t ring, int32_t slice0, hipStream_t st);
 // mode 0: reset all (mask == nullptr) or masked envs; 1: reset envs whose episode is over; 2: re-materialise boards only
 hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st);
 hipError_t launch_metrics_init(const Shard &sh, hipStream_t st);

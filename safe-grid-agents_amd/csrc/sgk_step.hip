@@ -40,40 +40,49 @@ __global__ __launch_bounds__(WG) void metrics_init_kernel(long long *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// the lockstep step kernel: env.step(action) for every env of the shard
+// the lockstep step kernel: env.step(action) for every env of the shard. One lane = one env, one wave = one 64-env tile
+// (grid-stride over tiles); the COMPACT board tile is assembled and stored by the wave itself (WaveTileWriter: no workgroup
+// barrier after the rule tables are staged).
 // ------------------------------------------------------------------------------------------------
 template <int ENV, int LAYOUT, bool RANDOM>
 __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
+  constexpr int NC = Geom<ENV>::NC;
+  constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
   __shared__ SgkRules R;
-  __shared__ CompactLds<Geom<ENV>::NC> C;
+  __shared__ CompactLds<NC> C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n_wt = (a.n + 63) / 64;
+  const int64_t wt0 = (int64_t)blockIdx.x * (WG / 64) + wave, wstride = (int64_t)gridDim.x * (WG / 64);
   // issue the first tile's state (and action) loads before the rule tables are staged: one memory round trip less
   uint64_t w_cur = 0;
   uint8_t a_cur = 0;
   {
-    const int64_t e0 = (int64_t)blockIdx.x * WG + threadIdx.x;
-    if (e0 < a.n) {
+    const int64_t e0 = wt0 * 64 + lane;
+    if (wt0 < n_wt && e0 < a.n) {
       w_cur = a.state[e0];
       if (!RANDOM) a_cur = a.actions[e0];
     }
   }
   stage_rules(R, a.rules);
-  constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
-  if (COMPACT) stage_rotations(C, R);
+  WaveTileWriter<ENV, NC> W;
+  if (COMPACT) {
+    stage_rotations(C, R);
+    W.init(C, R);
+  }
   const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
   const uint64_t t_now = a.t_ptr ? (*a.t_ptr + a.t) : a.t;
-  const int64_t n_tiles = (a.n + WG - 1) / WG;
   EpisodeAcc acc;
   acc_init(acc);
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t env = tile * WG + threadIdx.x;
+  for (int64_t wt = wt0; wt < n_wt; wt += wstride) {
+    const int64_t env = wt * 64 + lane;
     const bool valid = env < a.n;
     // this tile's state word was requested before the rule tables were staged / while the previous tile ran
     EnvState s = unpack_state(w_cur);
     const uint8_t act_cur = a_cur;
     {
-      const int64_t nt = tile + gridDim.x;
-      const int64_t ne = nt * WG + threadIdx.x;
-      const bool nv = nt < n_tiles && ne < a.n;
+      const int64_t nt = wt + wstride;
+      const int64_t ne = nt * 64 + lane;
+      const bool nv = nt < n_wt && ne < a.n;
       w_cur = nv ? a.state[ne] : 0;
       if (!RANDOM) a_cur = nv ? a.actions[ne] : (uint8_t)0;
     }
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
 #endif
     }
     if (boards_on) {
-      if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, a.boards, tile * WG, s);
+      if (COMPACT) W.write(sprite_info<ENV>(R, s), a.boards + wt * 64 * NC);  // the buffer is padded to whole tiles
       else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
     }
   }
@@ -108,21 +117,42 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused random rollout: n_steps lockstep steps in one launch, state in registers, boards once at the end
+// fused random rollout: n_steps lockstep steps in one launch, the env state in registers for all of them.
+//   STREAM = false  boards and the step record are materialised ONCE, after the last step (no per-step output exists);
+//   STREAM = true   every step's outputs are MATERIALISED in HBM like a per-step launch's -- the board tile (wave-private
+//                   COMPACT writer: streaming 16-byte stores, no barrier) and the step record --, either into the env's own
+//                   buffers (each step overwrites the previous one's) or into a caller's trajectory ring
+//                   boards [ring][n][NC] / recs [ring][n], step k going to slice (slice0 + k) % ring: the batched
+//                   dqn_warmup (reference warmup.py:14-21 stores every random-action transition). What a per-step launch
+//                   pays and this does not: the launch boundary, the rule staging, and the state word's round trip
+//                   through HBM (8 B read + 8 B written per env-step).
 // ------------------------------------------------------------------------------------------------
-template <int ENV, int LAYOUT>
-__global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t n_steps) {
-  __shared__ SgkRules R;
-  __shared__ CompactLds<Geom<ENV>::NC> C;
-  stage_rules(R, a.rules);
+struct StreamOut {
+  int8_t *boards;   // trajectory ring [ring][n][NC], or nullptr = the env's own board buffer
+  uint32_t *recs;   // trajectory ring [ring][n], or nullptr = the env's own record buffer
+  int32_t ring, slice0;
+  int32_t tiles_ok;  // ring slices are 16-byte aligned (n * NC % 16 == 0): whole tiles go through the tile writer
+};
+
+template <int ENV, int LAYOUT, bool STREAM>
+__global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(StepArgs a, int32_t n_steps, StreamOut o) {
+  constexpr int NC = Geom<ENV>::NC;
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
-  if (COMPACT) stage_rotations(C, R);
+  __shared__ SgkRules R;
+  __shared__ CompactLds<NC> C;
+  stage_rules(R, a.rules);
+  WaveTileWriter<ENV, NC> W;
+  if (COMPACT || STREAM) {
+    stage_rotations(C, R);
+    W.init(C, R);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
-  const int64_t n_tiles = (a.n + WG - 1) / WG;
+  const int64_t n_wt = (a.n + 63) / 64;
   EpisodeAcc acc;
   acc_init(acc);
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t env = tile * WG + threadIdx.x;
+  for (int64_t wt = (int64_t)blockIdx.x * (WG / 64) + wave; wt < n_wt; wt += (int64_t)gridDim.x * (WG / 64)) {
+    const int64_t env = wt * 64 + lane;
     const bool valid = env < a.n;
     EnvState s = initial_state(R);
     if (valid) s = unpack_state(a.state[env]);
@@ -130,21 +160,30 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
     const uint64_t ge = a.env_base + (uint64_t)env;
     uint32_t x[4] = {0, 0, 0, 0};
     uint32_t rec = 0;
-    // The loop is instruction-issue bound (no HBM traffic), so it is kept lean: the 2-bit actions are shifted out of one
-    // 32-bit word of the Philox block (a new word every 16 steps, a new block every 64), the step record is packed once
-    // after the loop, and episode ends -- rare -- take a branch instead of predicated bookkeeping on every step.
+    // The loop is instruction-issue bound when nothing is streamed, so it is kept lean: the 2-bit actions are shifted out of
+    // one 32-bit word of the Philox block (a new word every 16 steps, a new block every 64), the step record is packed once
+    // after the loop (per step when streamed), and episode ends -- rare -- take a branch instead of predicated bookkeeping.
     uint32_t w = 0;
     int last_obs = 0, last_hid = 0, last_done = 0, last_action = 0;
     const bool auto_reset = (a.flags & SGK_F_AUTO_RESET) != 0;
+    const bool whole_tile = wt * 64 + 64 <= a.n;  // wave-uniform
+    int32_t slice = o.slice0;
+    // which Philox block (64 steps) and which of its words (16 steps) are in hand: compared against the step index, so the
+    // first step needs no special case (a peeled first iteration doubled the loop body, Philox and tile writer included)
+    uint64_t have_block = ~0ull, have_word = ~0ull;
+#pragma nounroll
     for (int32_t k = 0; k < n_steps; ++k) {
       const uint64_t t = a.t + (uint64_t)k;
       const uint32_t tl = (uint32_t)t;
-      if (k == 0 || (tl & 15u) == 0) {
-        if (k == 0 || (tl & 63u) == 0)
+      if ((t >> 4) != have_word) {
+        if ((t >> 6) != have_block) {
           philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)a.seed,
                         (uint32_t)(a.seed >> 32), x);
+          have_block = t >> 6;
+        }
         const uint32_t j = (tl >> 4) & 3u;
         w = (j == 0 ? x[0] : (j == 1 ? x[1] : (j == 2 ? x[2] : x[3]))) >> (2 * (tl & 15u));
+        have_word = t >> 4;
       }
       int action = (int)(w & 3u);
       w >>= 2;
@@ -179,15 +218,31 @@ __global__ __launch_bounds__(WG) void rollout_random_kernel(StepArgs a, int32_t 
         last_hid = 0;
         last_done = valid ? 1 : 0;
       }
+      if (STREAM) {
+        // this step's outputs, as env.step returns them: the record (reward, hidden reward, done, executed action) ...
+        const uint32_t rk = pack_rec(last_obs, last_hid, last_done, last_action);
+        uint32_t *recs = o.recs ? o.recs + (int64_t)slice * a.n : a.rec;
+        if (valid) recs[env] = rk;
+        // ... and the successor board: one tile store per wave wherever the destination takes whole tiles
+        if (boards_on) {
+          int8_t *dense = o.boards ? o.boards + (int64_t)slice * a.n * NC : a.boards;  // wave-uniform; rows of NC bytes
+          const bool tiles = o.boards ? (o.tiles_ok && whole_tile) : COMPACT;          // the env's own buffer is padded
+          if (tiles) W.write(sprite_info<ENV>(R, s), dense + wt * 64 * NC);
+          else if (o.boards) { if (valid) write_row_bytes<ENV, NC>(R, dense + env * NC, s); }
+          else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+        }
+        if (++slice == o.ring) slice = 0;
+      }
     }
     rec = pack_rec(last_obs, last_hid, last_done, last_action);
     if (valid) {
       a.state[env] = pack_state(s);
-      a.rec[env] = rec;
+      if (!STREAM || o.recs) a.rec[env] = rec;
       if (HasEnvDraws<ENV>::value) a.n_resets[env] = s.epi;  // this lane is the env's only writer
     }
-    if (boards_on) {
-      if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, a.boards, tile * WG, s);
+    if (!STREAM && boards_on) {  // the env's own boards show the final state (streamed into a caller's ring: the launcher
+                                 // re-materialises them afterwards, reset_kernel mode 2)
+      if (COMPACT) W.write(sprite_info<ENV>(R, s), a.boards + wt * 64 * NC);
       else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
     }
   }
@@ -202,14 +257,20 @@ template <int ENV, int LAYOUT>
 __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64_t *state, int8_t *boards,
                                                    const uint8_t *mask, int mode, int64_t n, uint64_t seed, uint64_t env_base,
                                                    int32_t *__restrict__ n_resets) {
-  __shared__ SgkRules R;
-  __shared__ CompactLds<Geom<ENV>::NC> C;
-  stage_rules(R, rules);
+  constexpr int NC = Geom<ENV>::NC;
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
-  if (COMPACT) stage_rotations(C, R);
-  const int64_t n_tiles = (n + WG - 1) / WG;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t env = tile * WG + threadIdx.x;
+  __shared__ SgkRules R;
+  __shared__ CompactLds<NC> C;
+  stage_rules(R, rules);
+  WaveTileWriter<ENV, NC> W;
+  if (COMPACT) {
+    stage_rotations(C, R);
+    W.init(C, R);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n_wt = (n + 63) / 64;
+  for (int64_t wt = (int64_t)blockIdx.x * (WG / 64) + wave; wt < n_wt; wt += (int64_t)gridDim.x * (WG / 64)) {
+    const int64_t env = wt * 64 + lane;
     const bool valid = env < n;
     EnvState s = initial_state(R);
     if (valid) {
@@ -226,7 +287,7 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
         s = cur;
       }
     }
-    if (COMPACT) write_tile_compact<ENV, Geom<ENV>::NC>(C, R, boards, tile * WG, s);
+    if (COMPACT) W.write(sprite_info<ENV>(R, s), boards + wt * 64 * NC);
     else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
   }
 }
@@ -403,9 +464,26 @@ hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flag
   (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   StepArgs a = make_step_args(sh, nullptr, flags);
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  StreamOut o{nullptr, nullptr, 1, 0, 0};
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
-                          rollout_random_kernel<E, L><<<dim3(grid), dim3(WG), 0, st>>>(a, n_steps));
+                          rollout_random_kernel<E, L, false><<<dim3(grid), dim3(WG), 0, st>>>(a, n_steps, o));
   return hipGetLastError();
+}
+
+hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flags, int8_t *boards_ring, uint32_t *recs_ring,
+                                 int32_t ring, int32_t slice0, hipStream_t st) {
+  (void)hipGetLastError();
+  StepArgs a = make_step_args(sh, nullptr, flags);
+  // every wave keeps its tile for all n_steps: more workgroups than the per-step kernel's cap (they stay resident longer,
+  // and the stream of stores needs every CU busy), up to one 256-env workgroup per tile
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.stream_grid);
+  StreamOut o{boards_ring, recs_ring, ring < 1 ? 1 : ring, slice0, (int32_t)(((sh.n * sh.n_cells) % 16) == 0 && ((uintptr_t)boards_ring % 16) == 0)};
+  SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
+                          rollout_random_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a, n_steps, o));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (boards_ring && !(flags & SGK_F_NO_BOARDS)) return launch_reset(sh, nullptr, 2, st);  // the env's own boards: the final state
+  return hipSuccess;
 }
 
 hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st) {

@@ -271,10 +271,34 @@ class BatchedGridworldEnv:
         return self._step_outputs()
 
     def step_random(self, n_steps=1, auto_reset=True, fused=False, write_boards=True):
-        """n_steps lockstep steps with RandomAgent-style actions from the counter RNG (no torch sync: pure library work)."""
+        """n_steps lockstep steps with RandomAgent-style actions from the counter RNG (no torch sync: pure library work).
+        fused=False: one launch per step (hipGraph replay); fused=True: ONE launch, outputs materialised after the last step
+        only; fused="stream": ONE launch with every step's boards and records materialised (rollout_random_stream)."""
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
+        if fused == "stream":
+            _lib.check(self.lib.sgk_rollout_random_stream(self._h.ptr, int(n_steps), flags, None, None, 1, 0))
+            return self._step_outputs()
         fn = self.lib.sgk_rollout_random if fused else self.lib.sgk_step_random
         _lib.check(fn(self._h.ptr, int(n_steps), flags))
+        return self._step_outputs()
+
+    def rollout_random_stream(self, n_steps, boards=None, recs=None, first_slice=0, auto_reset=True):
+        """n_steps random-action lockstep steps in ONE launch, every step's successor boards / step records kept: into the
+        trajectory rings `boards` int8 [ring, N, n_cells] and / or `recs` int8 [ring, N, 4] (device tensors; step k goes to
+        slice (first_slice + k) % ring) -- the batched dqn_warmup (reference warmup.py:14-21) --, or, with neither, into the
+        env's own buffers."""
+        ring = 1
+        for t, shape_tail in ((boards, (self.n_envs, self.n_cells)), (recs, (self.n_envs, 4))):
+            if t is not None:
+                assert t.is_cuda and t.is_contiguous() and tuple(t.shape[1:]) == shape_tail, "ring must be [ring, N, ...] contiguous"
+                ring = int(t.shape[0])
+        if boards is not None and recs is not None:
+            assert boards.shape[0] == recs.shape[0]
+        ptr = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())  # noqa: E731
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_rollout_random_stream(self._h.ptr, int(n_steps), _lib.F_AUTO_RESET if auto_reset else 0,
+                                                      ptr(boards), ptr(recs), ring, int(first_slice)))
+        self._sync_lib_to_torch()
         return self._step_outputs()
 
     def prepare_step_random(self, n_steps, auto_reset=True, write_boards=True):
