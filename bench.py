@@ -6,9 +6,14 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one lockstep pass of the hot path over the whole env batch: every env of every rank takes one
-RandomAgent action (counter RNG, in-kernel) through the HIP step kernel -- transition, observed reward, hidden
-safety reward, episode bookkeeping, auto-reset, and the successor board MATERIALISED in HBM -- one kernel launch
-per step and GPU, replayed from a hipGraph. Workload = BASELINE.json's metric config: BoatRace, 1 048 576 concurrent
+RandomAgent action (counter RNG, in-kernel) -- transition, observed reward, hidden safety reward, episode bookkeeping,
+auto-reset -- and its outputs are MATERIALISED in HBM every step: the successor board (int8 cells, streaming tile
+stores) and the step record. Default path ("stream"): the streaming rollout kernel, 100 lockstep steps per launch with
+the env state words in registers between them (sgk_rollout_random_stream into the env's own buffers: each step
+overwrites the previous one's outputs, exactly what 100 per-step launches leave). `--path launch`: one step-kernel
+launch per step replayed from a hipGraph (the state word makes a round trip through HBM per step); reported as a
+secondary object by the default run, as is the streamed rollout into a TRAJECTORY RING (every step's boards and records
+kept: the batched dqn_warmup). Workload = BASELINE.json's metric config: BoatRace, 1 048 576 concurrent
 envs in the whole job at every GPU count (the batch shards by env id, one contiguous block per rank, no data-path
 collective; the only exchange is one int64 metrics all-reduce at the end of the timed region). At N > 1 a secondary
 object reports the weak-scaling form (1 048 576 envs on every GPU) measured in the same run.
@@ -109,14 +114,14 @@ def parity_sample(env, env_name, seed, base, total_steps, block=2048):
 
 
 def chunk_schedule(k):
-    """Chunk sizes `run(k)` issues, in order: GRAPH_CHUNK-step hipGraph replays and one tail."""
+    """Chunk sizes `run(k)` issues, in order: GRAPH_CHUNK-step launches (stream) / hipGraph replays (launch) and one tail."""
     out = [GRAPH_CHUNK] * (k // GRAPH_CHUNK)
     if k % GRAPH_CHUNK:
         out.append(k % GRAPH_CHUNK)
     return out
 
 
-def timed_steps(env, steps, warmup, barrier, global_metrics):
+def timed_steps(env, steps, warmup, barrier, global_metrics, path="stream", ring=None):
     """W untimed warm-up steps, then EXACTLY `steps` lockstep steps + the metrics flush between barrier + synchronize pairs.
     Every hipGraph the timed region replays is captured and instantiated BEFORE the region (sgk_step_random_prepare for each
     chunk size of the schedule), and the first HIP event is recorded immediately before the first replay, so neither the
@@ -125,12 +130,21 @@ def timed_steps(env, steps, warmup, barrier, global_metrics):
 
     stream = env.torch_stream()
 
+    slice_next = [0]
+
     def run(k):
         for c in chunk_schedule(k):
-            env.step_random(c, auto_reset=True)
+            if ring is not None:  # every step's boards + records kept in the caller's trajectory ring
+                env.rollout_random_stream(c, boards=ring[0], recs=ring[1], first_slice=slice_next[0])
+                slice_next[0] = (slice_next[0] + c) % ring[0].shape[0]
+            elif path == "stream":
+                env.step_random(c, auto_reset=True, fused="stream")
+            else:
+                env.step_random(c, auto_reset=True)
 
-    for c in sorted(set(chunk_schedule(warmup) + chunk_schedule(steps))):
-        env.prepare_step_random(c, auto_reset=True)
+    if path == "launch" and ring is None:
+        for c in sorted(set(chunk_schedule(warmup) + chunk_schedule(steps))):
+            env.prepare_step_random(c, auto_reset=True)
     run(warmup)
     env.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -184,6 +198,10 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5AFE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--path", default="stream", choices=["stream", "launch"],
+                    help="stream: 100 lockstep steps per launch, every step's outputs materialised (default); launch: one "
+                         "step-kernel launch per step (hipGraph)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the per-step-launch and trajectory-ring measurements")
     ap.add_argument("--no-weak-line", action="store_true", help="skip the secondary 1M-envs-per-GPU measurement at N > 1")
     args = ap.parse_args()
 
@@ -231,10 +249,38 @@ def main():
     env = S.BatchedGridworldEnv(args.env, n_local, device=local_rank, seed=args.seed, env_index_base=base,
                                 layout=args.layout)
     stream = env.torch_stream()
-    elapsed, kernel_ms, gm = timed_steps(env, args.steps, args.warmup, barrier, sdist.global_metrics)
+    elapsed, kernel_ms, gm = timed_steps(env, args.steps, args.warmup, barrier, sdist.global_metrics, path=args.path)
     elapsed, kernel_ms = max_over_ranks(elapsed, kernel_ms)
 
     total_steps = args.warmup + args.steps
+    secondary = {}
+    if not args.no_secondary:
+        # the other path and the trajectory-ring form, same bracket, a bounded number of steps (device time per step is what
+        # these report; the host-clock figure of the primary path is `value`)
+        k2 = min(args.steps, 400)
+        w2 = min(args.warmup, 100)
+        other = "launch" if args.path == "stream" else "stream"
+        o_el, o_ms, _ = timed_steps(env, k2, w2, barrier, sdist.global_metrics, path=other)
+        o_el, o_ms = max_over_ranks(o_el, o_ms)
+        total_steps += k2 + w2
+        secondary["per_step_launches" if other == "launch" else "streamed"] = {
+            "value": n_total * k2 / o_el, "unit": "env-steps/s", "steps": k2, "ms_per_step": o_el * 1e3 / k2,
+            "device_us_per_step": o_ms * 1e3 / k2,
+            "note": ("sgk_step_random: one step-kernel launch per lockstep step (hipGraph x%d), state words through HBM every step"
+                     % GRAPH_CHUNK) if other == "launch" else "sgk_rollout_random_stream: %d steps per launch" % GRAPH_CHUNK}
+        slices = GRAPH_CHUNK
+        ring = (torch.empty((slices, n_local, env.n_cells), dtype=torch.int8, device="cuda:%d" % local_rank),
+                torch.empty((slices, n_local, 4), dtype=torch.int8, device="cuda:%d" % local_rank))
+        r_el, r_ms, _ = timed_steps(env, k2, w2, barrier, sdist.global_metrics, ring=ring)
+        r_el, r_ms = max_over_ranks(r_el, r_ms)
+        total_steps += k2 + w2
+        secondary["streamed_into_trajectory_ring"] = {
+            "value": n_total * k2 / r_el, "unit": "env-steps/s", "steps": k2, "ms_per_step": r_el * 1e3 / k2,
+            "device_us_per_step": r_ms * 1e3 / k2, "ring_slices": slices,
+            "ring_bytes": int(ring[0].numel() + ring[1].numel()),
+            "note": "sgk_rollout_random_stream into boards [%d][n][cells] + records [%d][n]: every step's outputs KEPT "
+                    "(the batched dqn_warmup, reference warmup.py:14-21); nothing is overwritten within a launch" % (slices, slices)}
+        del ring
     fused = None
     if not args.no_fused:
         # same workload through the fused rollout kernel (state in registers, boards materialised once per launch)
@@ -260,7 +306,7 @@ def main():
         per = 1 << 20
         wenv = S.BatchedGridworldEnv(args.env, per, device=local_rank, seed=args.seed, env_index_base=rank * per,
                                      layout=args.layout)
-        w_el, w_ms, _ = timed_steps(wenv, args.steps, args.warmup, barrier, sdist.global_metrics)
+        w_el, w_ms, _ = timed_steps(wenv, args.steps, args.warmup, barrier, sdist.global_metrics, path=args.path)
         w_el, w_ms = max_over_ranks(w_el, w_ms)
         weak_line = {"value": per * world * args.steps / w_el, "unit": "env-steps/s", "envs_per_gpu": per,
                      "total_envs": per * world, "ms_per_step": w_el * 1e3 / args.steps,
@@ -273,15 +319,21 @@ def main():
     if rank != 0:
         return
     value = n_total * args.steps / elapsed
-    launch_s = kernel_ms / 1e3 / args.steps  # average duration of one step launch incl. its dependent-launch gap
+    launches = len(chunk_schedule(args.steps)) if args.path == "stream" else args.steps
+    steps_per_launch = args.steps / launches
+    launch_s = kernel_ms / 1e3 / launches  # average duration of one launch of the dominant kernel incl. its launch gap
     b_alg = B_ALG[args.env]
-    achieved = b_alg * n_local / launch_s / 1e9
+    achieved = b_alg * n_local * steps_per_launch / launch_s / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        traffic = tj.get("%s/%s/%d" % (args.env, args.layout, n_local))
+        if args.path == "stream":  # measured per 100-step launch; scaled to this run's steps per launch
+            per100 = tj.get("%s/%s/%d/stream%d" % (args.env, args.layout, n_local, GRAPH_CHUNK))
+            traffic = None if per100 is None else per100 * steps_per_launch / GRAPH_CHUNK
+        else:
+            traffic = tj.get("%s/%s/%d" % (args.env, args.layout, n_local))
     roofline = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic,
@@ -290,9 +342,11 @@ def main():
         # which charges a board read this design never makes) and can exceed 1.
         "traffic_gbs": None if traffic is None else traffic / launch_s / 1e9,
         "traffic_frac": None if traffic is None else traffic / launch_s / 1e9 / HBM_PEAK_GBS,
-        "kernel": "sgk::step_kernel<%s>" % args.env, "algorithmic_bytes_per_env_step": b_alg,
-        "algorithmic_bytes_per_launch": b_alg * n_local,
-        "avg_launch_us": launch_s * 1e6, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+        "kernel": ("sgk::rollout_random_kernel<%s, stream>" if args.path == "stream" else "sgk::step_kernel<%s>") % args.env,
+        "algorithmic_bytes_per_env_step": b_alg, "steps_per_launch": steps_per_launch,
+        "algorithmic_bytes_per_launch": b_alg * n_local * steps_per_launch,
+        "avg_launch_us": launch_s * 1e6, "device_us_per_step": launch_s * 1e6 / steps_per_launch,
+        "frac_of_measured_copy_peak_6290": achieved / 6290.0,
     }
     out = {
         "metric": "env-steps/sec at 1M concurrent BoatRace envs" if args.env == "BoatRace-v0" else "env-steps/sec",
@@ -308,9 +362,11 @@ def main():
         "dtype": "int8",
         "data": "synthetic",
         "config": {
-            "workload": "%s random-action rollout, %d concurrent envs in lockstep (%d per GPU), step kernel (one launch "
-                        "per step, hipGraph x%d), auto-reset, boards materialised every step"
-                        % (args.env, n_total, n_local, GRAPH_CHUNK),
+            "workload": ("%s random-action rollout, %d concurrent envs in lockstep (%d per GPU), " % (args.env, n_total, n_local))
+                        + ("streaming rollout kernel (%d steps per launch, env state in registers between steps)" % GRAPH_CHUNK
+                           if args.path == "stream" else "step kernel (one launch per step, hipGraph x%d)" % GRAPH_CHUNK)
+                        + ", auto-reset, every step's board and step record materialised in HBM",
+            "path": args.path,
             "envs_per_gpu": n_local, "total_envs": n_total, "board_layout": args.layout,
             "parallelism": "env-sharded x%d, int64 metrics all-reduce" % world,
         },
@@ -319,6 +375,7 @@ def main():
         "mean_return": gm.meter("returns")["avg"], "mean_safety": gm.meter("safeties")["avg"],
         "parity_sample_bit_exact": ok, "parity_sample_envs": n_checked,
     }
+    out.update(secondary)
     if fused:
         out["fused_rollout"] = fused
     if weak_line:

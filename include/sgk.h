@@ -207,6 +207,23 @@ SGK_API int sgk_copy_last_episode(sgk_env *h, int32_t *last_return_host, int32_t
 SGK_API int sgk_metrics(sgk_env *h, int64_t out_host[SGK_METRICS_LEN]);
 SGK_API int sgk_metrics_reset(sgk_env *h);
 
+/* ---- multi-GPU: the path's ONE collective ---------------------------------------------------------------------
+ * Every env is independent (reference train.py:51-54: one env, one agent), so a node's GPUs each own a contiguous env-id block
+ * (sgk_create_ex's env_index_base keys the counter RNG by GLOBAL env index: a sharded run reproduces the unsharded streams) and
+ * nothing but the 16-word metrics vector is ever exchanged: one RCCL all-reduce over xGMI per metrics flush -- SUM on words
+ * [0..7], MAX on [8..11] (integer: the result does not depend on the number of ranks). RCCL is bound at run time
+ * (librccl.so.1); SGK_ERR_NODEVICE when it cannot be loaded. One process per GPU: rank 0 obtains the id and ships its 128
+ * bytes to the other ranks over any channel (MPI, a file, torch.distributed's store), then every rank creates its end. */
+#define SGK_COMM_ID_BYTES 128
+typedef struct sgk_comm sgk_comm;
+SGK_API int sgk_comm_unique_id(uint8_t id_out[SGK_COMM_ID_BYTES]);
+SGK_API int sgk_comm_create(const uint8_t id[SGK_COMM_ID_BYTES], int rank, int world_size, int device, sgk_comm **out);
+SGK_API int sgk_comm_destroy(sgk_comm *comm);
+/* in place on a DEVICE vector of SGK_METRICS_LEN int64 (e.g. sgk_metrics_dev's), ordered on hip_stream */
+SGK_API int sgk_allreduce_metrics(sgk_comm *comm, int64_t *inout_dev, void *hip_stream);
+/* sgk_metrics of this shard, all-reduced over the communicator's ranks (SGK_M_STEPS included); synchronises */
+SGK_API int sgk_metrics_allreduced(sgk_env *h, sgk_comm *comm, int64_t out_host[SGK_METRICS_LEN]);
+
 /* done-mask compaction: ids (ascending) of the envs whose LAST step record has done != 0, with the
  * episode_return / performance track_metrics would read for them (reference meters.py:76-77).
  * Outputs are device arrays of capacity n_envs; *n_host receives the count (synchronises). */
@@ -220,6 +237,11 @@ SGK_API int sgk_tabq_act(sgk_tabq *q, int explore, uint8_t *actions_out_dev);
 /* learn + update_epsilon after sgk_step (value.py:44-58; learn.py:72-82). cheat != 0 learns from the hidden
  * reward and the actual action. */
 SGK_API int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat);
+/* n_steps of the drop-in call sequence {sgk_tabq_act(explore), sgk_step, sgk_tabq_learn, sgk_reset_done} -- tabq_learn's loop
+ * body (reference learn.py:61-85) with train.py:62-70's reset after done -- as four launches per lockstep step replayed from
+ * ONE hipGraph per (n_steps, cheat, flags): the agent step counter lives in device memory. flags: SGK_F_NO_BOARDS or 0.
+ * Same results as the four calls made n_steps times. */
+SGK_API int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags);
 /* n_steps of {act_explore, env.step, learn, update_epsilon, reset on done} in one launch
  * (reference learn.py:61-85 inside train.py:62-70) */
 SGK_API int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat);

@@ -65,7 +65,10 @@ struct sgk_env {
 struct sgk_tabq {
   sgk_env *env = nullptr;
   sgk::TabqShard tq;
-  uint8_t *actions = nullptr;  // scratch for the per-step fallback of sgk_tabq_rollout
+  uint8_t *actions = nullptr;  // the actions of the captured act_explore -> step -> learn -> reset_done sequence
+  long long *t_dev = nullptr;  // device copy of tq.t_agent for graph replays
+  bool t_dev_stale = true;
+  std::map<std::pair<int32_t, uint32_t>, hipGraphExec_t> graphs;  // (n_steps, cheat | flags << 1) -> captured sequence
 };
 
 namespace sgk {
@@ -77,6 +80,7 @@ hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t 
 extern "C" {
 
 const char *sgk_last_error(void) { return g_last_error.c_str(); }
+int sgk_set_error(int code, const char *msg) { return fail(code, msg ? msg : "?"); }  // for the other translation units
 int sgk_abi_version(void) { return SGK_ABI_VERSION; }
 
 int sgk_device_count(int *n_out) {
@@ -836,6 +840,22 @@ int sgk_metrics(sgk_env *h, int64_t out_host[SGK_METRICS_LEN]) {
   return SGK_OK;
 }
 
+int sgk_metrics_allreduced(sgk_env *h, sgk_comm *comm, int64_t out_host[SGK_METRICS_LEN]) {
+  SGK_CHECK_HANDLE(h);
+  if (!comm || !out_host) return fail(SGK_ERR_INVALID, "NULL argument");
+  SGK_HIP(sgk::launch_metrics_reduce(h->sh, h->stream));
+  // SGK_M_STEPS is counted on the host (steps issued): put it into the device vector so that it is summed with the rest
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, h->stream, reinterpret_cast<uint64_t *>(h->sh.metrics) + SGK_M_STEPS,
+                     (uint64_t)h->steps_issued);
+  SGK_HIP(hipGetLastError());
+  int rc = sgk_allreduce_metrics(comm, h->sh.metrics, (void *)h->stream);
+  if (rc != SGK_OK) return rc;
+  SGK_HIP(hipMemcpyAsync(out_host, h->sh.metrics, sizeof(int64_t) * SGK_METRICS_LEN, hipMemcpyDeviceToHost, h->stream));
+  SGK_HIP(hipStreamSynchronize(h->stream));
+  return SGK_OK;
+}
+
 int sgk_metrics_reset(sgk_env *h) {
   SGK_CHECK_HANDLE(h);
   SGK_HIP(sgk::launch_metrics_init(h->sh, h->stream));
@@ -860,10 +880,12 @@ int sgk_tabq_destroy(sgk_tabq *q) {
     (void)hipSetDevice(q->env->sh.device);
     (void)hipStreamSynchronize(q->env->stream);
   }
+  for (auto &kv : q->graphs) (void)hipGraphExecDestroy(kv.second);
   (void)hipFree(q->tq.table);
   (void)hipFree(q->tq.s_prev);
   (void)hipFree(q->tq.eps_table);
   (void)hipFree(q->actions);
+  (void)hipFree(q->t_dev);
   delete q;
   return SGK_OK;
 }
@@ -885,6 +907,7 @@ int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, in
   hipError_t e = hipMalloc(&q->tq.table, tbytes);
   if (e == hipSuccess) e = hipMalloc(&q->tq.s_prev, sizeof(uint16_t) * (size_t)env->sh.n);
   if (e == hipSuccess) e = hipMalloc(&q->actions, (size_t)env->sh.n);
+  if (e == hipSuccess) e = hipMalloc(&q->t_dev, sizeof(long long));
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.table, 0, tbytes, env->stream);  // defaultdict(zeros) (value.py:31)
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.s_prev, 0xff, sizeof(uint16_t) * (size_t)env->sh.n, env->stream);
   if (e == hipSuccess && epsilon_anneal <= (int64_t)(4 << 20)) {
@@ -920,6 +943,62 @@ int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat) {
   if (!actions_dev) return fail(SGK_ERR_INVALID, "actions_dev is NULL");
   SGK_HIP(sgk::launch_tabq_learn(q->env->sh, q->tq, actions_dev, cheat, q->env->stream));
   q->tq.t_agent += 1;  // update_epsilon(), learn.py:82
+  q->t_dev_stale = true;
+  return SGK_OK;
+}
+
+int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags) {
+  if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
+  sgk_env *h = q->env;
+  SGK_CHECK_HANDLE(h);
+  if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
+  if (flags & ~(uint32_t)SGK_F_NO_BOARDS) return fail(SGK_ERR_INVALID, "only SGK_F_NO_BOARDS is meaningful here");
+  if (n_steps == 0) return SGK_OK;
+  sgk::Shard &s = h->sh;
+  // tabq_learn's loop body (reference learn.py:61-85 inside train.py:62-70) as the four launches of the drop-in call sequence --
+  // act_explore, env.step, learn (+ update_epsilon), reset of the finished envs -- captured ONCE per (n_steps, cheat, flags) and
+  // replayed: the agent step counter lives in device memory, so a replay needs no new arguments.
+  auto key = std::make_pair(n_steps, (uint32_t)(cheat ? 1u : 0u) | (flags << 1));
+  auto it = q->graphs.find(key);
+  if (it == q->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap = h->own_stream;
+    sgk::TabqShard tq = q->tq;
+    tq.t_ptr = q->t_dev;
+    SGK_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    hipError_t le = hipSuccess;
+    for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k) {
+      tq.t_agent = k;  // offset from *t_dev
+      le = sgk::launch_tabq_act(s, tq, 1, q->actions, cap);
+      if (le == hipSuccess) le = sgk::launch_step(s, q->actions, flags, cap);
+      if (le == hipSuccess) le = sgk::launch_tabq_learn(s, tq, q->actions, cheat, cap);
+      if (le == hipSuccess) le = sgk::launch_reset(s, nullptr, 1, cap);
+    }
+    if (le == hipSuccess) {
+      (void)hipGetLastError();
+      hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, cap, reinterpret_cast<uint64_t *>(q->t_dev), (uint64_t)n_steps);
+      le = hipGetLastError();
+    }
+    hipError_t ce = hipStreamEndCapture(cap, &graph);
+    if (le != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); return hip_fail(le, "capture the tabular-Q step sequence"); }
+    if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture");
+    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate");
+    it = q->graphs.emplace(key, exec).first;
+  }
+  if (q->t_dev_stale) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, h->stream, reinterpret_cast<uint64_t *>(q->t_dev), (uint64_t)q->tq.t_agent);
+    SGK_HIP(hipGetLastError());
+    q->t_dev_stale = false;
+  }
+  SGK_HIP(hipGraphLaunch(it->second, h->stream));
+  q->tq.t_agent += n_steps;
+  s.lockstep_t += (uint64_t)n_steps;
+  h->t_dev_stale = true;
+  h->steps_issued += s.n * (int64_t)n_steps;
   return SGK_OK;
 }
 
@@ -963,6 +1042,7 @@ int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel) {
   }
   SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));  // materialise the boards of the final states
   q->tq.t_agent += n_steps;
+  q->t_dev_stale = true;
   s.lockstep_t += (uint64_t)n_steps;
   h->t_dev_stale = true;
   h->steps_issued += s.n * n_steps;

@@ -41,6 +41,7 @@ struct TabqShard {
   double lr = 0, discount = 0, eps0 = 0;
   int64_t anneal = 0;
   int64_t t_agent = 0;
+  const long long *t_ptr = nullptr;  // when set (hipGraph replays): the global agent step is *t_ptr + t_agent
 };
 
 hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, hipStream_t st);

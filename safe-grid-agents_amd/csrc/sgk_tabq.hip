@@ -70,7 +70,8 @@ struct TabqArgs {
   uint16_t *s_prev;    // state index the last action was chosen from; 0xffff = env was over
   int64_t n;
   uint64_t seed, env_base;
-  int64_t t_agent;     // global agent step (same for every agent: lockstep)
+  int64_t t_agent;     // global agent step (same for every agent: lockstep) ...
+  const long long *t_ptr;  // ... or, when non-null (hipGraph replays), *t_ptr + t_agent
   double lr, discount, eps0;
   int64_t anneal;
   const double *eps_table;  // eps_table[t] for t < anneal (host-computed, bit-identical to the formula); may be null
@@ -83,7 +84,8 @@ template <int ENV>
 __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, uint8_t *__restrict__ actions_out) {
   __shared__ SgkRules R;
   stage_rules(R, a.rules);
-  const double eps = explore ? epsilon_at(a.eps0, a.anneal, a.t_agent) : 0.0;
+  const int64_t t_agent = a.t_ptr ? (int64_t)*a.t_ptr + a.t_agent : a.t_agent;
+  const double eps = explore ? epsilon_at(a.eps0, a.anneal, t_agent) : 0.0;
   for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
     EnvState s = unpack_state(a.state[env]);
     int si = state_index<ENV>(R, s);
@@ -93,10 +95,10 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
     if (explore) {
       uint64_t ge = a.env_base + (uint64_t)env;
       uint32_t x[4];
-      explore_block(a.seed, ge, a.t_agent, x);
+      explore_block(a.seed, ge, t_agent, x);
       double u;
       int ea;
-      explore_draw(x, a.t_agent, u, ea);
+      explore_draw(x, t_agent, u, ea);
       if (u < eps) action = ea;
     }
     actions_out[env] = (uint8_t)action;
@@ -359,6 +361,7 @@ static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t fl
   a.seed = sh.seed;
   a.env_base = sh.env_base;
   a.t_agent = tq.t_agent;
+  a.t_ptr = tq.t_ptr;
   a.lr = tq.lr;
   a.discount = tq.discount;
   a.eps0 = tq.eps0;

@@ -22,6 +22,7 @@ MEM_HOST_VISIBLE = 0x100
 BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN, DISTRIBUTIONAL_SHIFT, WHISKY_GOLD, ABSENT_SUPERVISOR = 0, 1, 2, 3, 4, 5
 SAFE_INTERRUPTIBILITY = 6
 METRICS_LEN = 16
+COMM_ID_BYTES = 128
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, _M_RESERVED,
  M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)
 
@@ -136,12 +137,18 @@ _SIGNATURES = {
     "sgk_copy_last_episode": (ctypes.c_int, [_V, _V, _V, _V]),
     "sgk_metrics": (ctypes.c_int, [_V, _V]),
     "sgk_metrics_reset": (ctypes.c_int, [_V]),
+    "sgk_comm_unique_id": (ctypes.c_int, [_V]),
+    "sgk_comm_create": (ctypes.c_int, [_V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_V)]),
+    "sgk_comm_destroy": (ctypes.c_int, [_V]),
+    "sgk_allreduce_metrics": (ctypes.c_int, [_V, _V, _V]),
+    "sgk_metrics_allreduced": (ctypes.c_int, [_V, _V, _V]),
     "sgk_finished": (ctypes.c_int, [_V, _V, _V, _V, ctypes.POINTER(ctypes.c_int64)]),
     "sgk_tabq_create": (ctypes.c_int, [_V, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
                                        ctypes.POINTER(_V)]),
     "sgk_tabq_destroy": (ctypes.c_int, [_V]),
     "sgk_tabq_act": (ctypes.c_int, [_V, ctypes.c_int, _V]),
     "sgk_tabq_learn": (ctypes.c_int, [_V, _V, ctypes.c_int]),
+    "sgk_tabq_learn_steps": (ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_int, ctypes.c_uint32]),
     "sgk_tabq_rollout": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int]),
     "sgk_tabq_rollout_ex": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "sgk_tabq_table_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V), ctypes.POINTER(ctypes.c_int64),

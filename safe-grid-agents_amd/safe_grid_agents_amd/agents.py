@@ -291,6 +291,12 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         self.env._sync_torch_to_lib()
         _lib.check(self.lib.sgk_tabq_learn(self._h, ctypes.c_void_p(actions.data_ptr()), int(cheat)))
 
+    def learn_steps(self, n_steps, cheat=False, write_boards=False):
+        """n_steps of the drop-in call sequence act_explore -> env.step -> learn -> reset_done (four launches per lockstep
+        step) replayed from one hipGraph (sgk_tabq_learn_steps): no Python, no host round trip between the launches."""
+        flags = 0 if write_boards else _lib.F_NO_BOARDS
+        _lib.check(self.lib.sgk_tabq_learn_steps(self._h, int(n_steps), int(cheat), flags))
+
     def rollout(self, n_steps, cheat=False, kernel="auto"):
         """n_steps of {act_explore, env.step, learn, update_epsilon, reset on done} fused on the GPU. `kernel`: "auto", or
         "lds" / "hbm" to name the kernel (tables resident in LDS / rows in HBM; same results)."""

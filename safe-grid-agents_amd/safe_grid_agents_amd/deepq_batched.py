@@ -296,7 +296,7 @@ class BatchedDeepQAgent:
     # 32 768 envs the GPU idles most of the time. Capturing the iteration (the library's obs / step / reset kernels are
     # plain launches on the capture stream) removes that: everything that varies between replays lives in device memory
     # (epsilon scalar, replay ring head, Adam's capturable step counter).
-    def _captured_iteration(self, learn):
+    def _captured_iteration(self, learn, cheat=False):
         torch = self.torch
         env = self.env
         if learn:
@@ -321,17 +321,19 @@ class BatchedDeepQAgent:
             actions = torch.where(explore, rand_a, greedy).to(torch.uint8)
         env.step(actions, auto_reset=False)
         if learn:
-            self.replay.store(env, 1, actions, captured=True)
+            self.replay.store(env, 1, actions, cheat, captured=True)  # --cheat: hidden reward + executed action (learn.py:41-47)
             self.replay.head_dev.add_(1).remainder_(self.replay.slices)
             for _ in range(self.sgd_steps):
                 self.learn_batch()
         env.reset_done()
 
-    def enable_graphs(self, learn=True):
+    def enable_graphs(self, learn=True, cheat=False):
         """Capture one lockstep iteration. Needs a full replay ring (run warmup(replay_slices) first) so that the sampling
-        range is a constant, and Adam(capturable=True)."""
+        range is a constant, and Adam(capturable=True). `cheat` (learn.py:41-47: learn from the hidden reward and the action
+        the env executed) is part of what is recorded: graphs are kept per (learn, cheat)."""
         torch = self.torch
-        if learn in self._graphs:
+        cheat = bool(cheat) and bool(learn)
+        if (learn, cheat) in self._graphs:
             return
         if learn:
             assert self.replay.filled == self.replay.slices, "fill the replay ring (warmup) before capturing the learn graph"
@@ -345,20 +347,21 @@ class BatchedDeepQAgent:
             with torch.cuda.stream(side):
                 env.bind_torch_stream(side)
                 for _ in range(3):  # warm-up on the side stream (allocator, lazy init), as the capture recipe requires
-                    self._captured_iteration(learn)
+                    self._captured_iteration(learn, cheat)
                     if learn:
                         self.replay.note_replayed_add()
             torch.cuda.current_stream(self.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 env.bind_torch_stream(torch.cuda.current_stream(self.device))  # the capture stream
-                self._captured_iteration(learn)
+                self._captured_iteration(learn, cheat)
             env.bind_torch_stream(torch.cuda.current_stream(self.device))
         env.account_steps(-1)  # the recorded (not executed) sgk_step bumped the host-side counters once
-        self._graphs[learn] = graph
+        self._graphs[(learn, cheat)] = graph
 
-    def step_graphed(self, learn=True):
-        """One lockstep iteration = one graph replay (+ two scalar updates)."""
+    def step_graphed(self, learn=True, cheat=False):
+        """One lockstep iteration = one graph replay (+ two scalar updates); enable_graphs(learn, cheat) first."""
+        cheat = bool(cheat) and bool(learn)
         self._eps_dev.fill_(self.epsilon)
         self._draw_dev.fill_(self.t)
         if learn and self.replay.head_dev_stale:  # eager adds moved the host-side head since the last replay
@@ -366,7 +369,7 @@ class BatchedDeepQAgent:
             self.replay.head_dev_stale = False
         if self.fused_policy and self._fw_stale and not learn:
             self._refresh_fused_weights()  # the no-learning graph does not record the transposes
-        self._graphs[learn].replay()
+        self._graphs[(learn, cheat)].replay()
         self.env.account_steps(1)
         if learn:
             self.replay.note_replayed_add()

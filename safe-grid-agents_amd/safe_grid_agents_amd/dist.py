@@ -64,11 +64,71 @@ def allreduce_metrics(vec):
     return out
 
 
-def global_metrics(env):
-    """BatchMetrics over all ranks for a BatchedGridworldEnv shard."""
+_COMMS = {}  # device -> sgk_comm* (one RCCL communicator per process and GPU, made on first use)
+
+
+def library_comm(env):
+    """The C-ABI's RCCL communicator (sgk_comm_create) for this process: rank 0 draws the unique id, torch.distributed ships
+    its 128 bytes to the other ranks, every rank creates its end on its own GPU. None when the process group is not RCCL-backed
+    (gloo tests, single rank) or the library cannot set one up -- the caller then reduces through torch.distributed, which is
+    the same RCCL underneath. SGK_METRICS_COLLECTIVE=torch forces that path."""
+    import ctypes
+    import sys
+
     import torch
     import torch.distributed as dist
 
+    from . import _lib
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or dist.get_backend() != "nccl":
+        return None
+    if os.environ.get("SGK_METRICS_COLLECTIVE", "sgk") == "torch":
+        return None
+    if env.device in _COMMS:
+        return _COMMS[env.device]
+    lib = _lib.load()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ident = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)()
+    ok = 1
+    if rank == 0:
+        ok = int(lib.sgk_comm_unique_id(ident) == _lib.SGK_OK)
+    t = torch.tensor([ok] + list(ident), dtype=torch.uint8, device="cuda:%d" % env.device)
+    dist.broadcast(t, src=0)
+    vals = t.cpu().tolist()
+    comm = ctypes.c_void_p()
+    made = 0
+    if vals[0]:
+        ident = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)(*vals[1:])
+        made = int(lib.sgk_comm_create(ident, rank, world, env.device, ctypes.byref(comm)) == _lib.SGK_OK)
+    agree = torch.tensor([made], dtype=torch.int32, device="cuda:%d" % env.device)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)  # all ranks take the same path
+    if int(agree.item()) != 1:
+        if made:
+            lib.sgk_comm_destroy(comm)
+        if rank == 0:
+            sys.stderr.write("safe_grid_agents_amd.dist: sgk_comm_create failed (%s); metrics go through torch.distributed\n"
+                             % (lib.sgk_last_error() or b"?").decode())
+        _COMMS[env.device] = None
+        return None
+    _COMMS[env.device] = comm
+    return comm
+
+
+def global_metrics(env):
+    """BatchMetrics over all ranks for a BatchedGridworldEnv shard: the library's own RCCL all-reduce
+    (sgk_metrics_allreduced) when the process group is RCCL-backed, torch.distributed otherwise (gloo in the CPU tests)."""
+    import ctypes
+
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib
+
+    comm = library_comm(env)
+    if comm is not None:
+        out = np.zeros(METRICS_LEN, dtype=np.int64)
+        _lib.check(env.lib.sgk_metrics_allreduced(env.handle, comm, out.ctypes.data_as(ctypes.c_void_p)))
+        return BatchMetrics(out)
     local = np.asarray(env.metrics(), dtype=np.int64)  # device sums + the host-side step counter
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         device = "cuda:%d" % env.device if dist.get_backend() == "nccl" else "cpu"

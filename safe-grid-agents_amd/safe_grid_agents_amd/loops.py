@@ -277,16 +277,24 @@ def batched_ppo_learn(agent, env, history=None, cheat=False):
     return bm
 
 
-def batched_tabq_learn(agent, env, n_steps, cheat=False, fused=True):
+def batched_tabq_learn(agent, env, n_steps, cheat=False, fused=True, chunk=100):
     """tabq_learn for N private agents in lockstep: act_explore -> env.step -> learn -> update_epsilon, with the
     episode loop of train.py:62-70 (reset after done) folded in. fused=True runs all n_steps in one launch with the
-    Q-tables resident in LDS; fused=False issues the three kernels per step (the drop-in call sequence)."""
-    if fused:
+    Q-tables resident in LDS (or their rows in HBM); fused=False keeps the drop-in call sequence -- four launches per lockstep
+    step (act_explore, step, learn, reset_done) -- and replays it from a hipGraph, `chunk` steps per replay; fused="calls" makes
+    the four calls from Python (what the graph records)."""
+    if fused is True:
         agent.rollout(n_steps, cheat=cheat)
-    else:
+    elif fused == "calls":
         for _ in range(n_steps):
             actions = agent.act_explore()
             env.step(actions, auto_reset=False, write_boards=False)
             agent.learn(action=actions, cheat=cheat)
             env.reset_done()
+    else:
+        done = 0
+        while done < n_steps:
+            k = min(int(chunk), n_steps - done)
+            agent.learn_steps(k, cheat=cheat)
+            done += k
     return BatchMetrics(env.metrics())

@@ -30,6 +30,10 @@ _CORE_FLAGS = [
     ("disable-cuda", "dc", dict(action="store_true")),
     # extension: N > 0 runs N envs with N private agents in lockstep on the GPU (train_batched)
     ("n-envs", "N", dict(type=int, default=0)),
+    # extension: shard the -N env batch over this many GPUs of the node, one process per GPU (contiguous env-id blocks, one
+    # RCCL metrics all-reduce per reporting period). `python -m safe_grid_agents_amd --devices G ...` starts the G ranks itself;
+    # under torch.distributed.run the launcher's WORLD_SIZE decides and this flag is only checked against it.
+    ("devices", "G", dict(type=int, default=1)),
 ]
 _LR = ("lr", "l", dict(type=float, required=True))
 _EPS = ("epsilon", "e", dict(type=float, default=0.01))
@@ -164,6 +168,10 @@ def train_batched(args, writer_factory=None, reporter=_noop):
     from .ppo import BatchedPPOAgent
 
     rank, local_rank, world = sdist.env_from_torchrun()
+    if getattr(args, "devices", 1) > 1 and world != args.devices:
+        raise SystemExit("--devices %d needs %d ranks (WORLD_SIZE is %d): run `python -m safe_grid_agents_amd --devices %d ...`, "
+                         "which starts them, or torch.distributed.run --nproc-per-node %d" % (
+                             args.devices, args.devices, world, args.devices, args.devices))
     if world > 1:
         if args.agent_alias in ("ppo-mlp", "ppo-cnn"):
             raise KeyError("train_batched shards independent agents (tabular-q, random) over GPUs; %r shares one policy"
@@ -226,11 +234,26 @@ def train_batched(args, writer_factory=None, reporter=_noop):
         if deepq and agent.last_loss is not None:
             writer.add_scalar("Train/value_loss", float(agent.last_loss.reshape(-1)[0]), agent.t)
         reporter(hidden_reward=bm.meter("safeties")["avg"], obs_reward=bm.meter("returns")["avg"])
-        if agent is not None and (episode % args.eval_every == args.eval_every - 1 or episode == args.episodes):
-            if rank == 0:
-                print("#### EVAL ####")
-            batched_default_eval(agent, env, args.eval_timesteps)
-            sdist.global_metrics(env).write(writer, period, prefix="Evaluation/")
-            period += 1
-            env.reset()
+        # evaluation cadence exactly as the reference's loops decide it: whiler (tabular-q / deep-q, learn.py:21-22) evaluates
+        # after the episodes with episode % eval_every == eval_every - 1; ppo_learn (learn.py:100) after those with
+        # episode % eval_every == 0 (episode > 0)
+        if ppo:
+            eval_next = episode > 0 and episode % args.eval_every == 0
+        else:
+            eval_next = episode % args.eval_every == args.eval_every - 1
+        if agent is not None and eval_next:
+            period = _batched_eval(agent, env, args, writer, period, rank, sdist)
+    if agent is not None:  # train.py:81: one more evaluation after the loop, unconditionally (also when the last episode had one)
+        period = _batched_eval(agent, env, args, writer, period, rank, sdist)
     return agent, env
+
+
+def _batched_eval(agent, env, args, writer, period, rank, sdist):
+    from .loops import batched_default_eval
+
+    if rank == 0:
+        print("#### EVAL ####")
+    batched_default_eval(agent, env, args.eval_timesteps)
+    sdist.global_metrics(env).write(writer, period, prefix="Evaluation/")
+    env.reset()
+    return period + 1

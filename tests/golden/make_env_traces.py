@@ -19,6 +19,8 @@ out = {}
 for name in O.ENV_IDS:
     rng = np.random.RandomState(2024)
     e = O.EnvBatch(name, 1)
+    e.reset(0)  # gym usage: make(), then reset() -- the env's own draws are keyed by its reset counter
+    initial = e.board(0).ravel().tolist()
     actions = rng.randint(0, 4, size=400).tolist()
     steps, boards = [], {}
     for t, a in enumerate(actions):
@@ -28,7 +30,7 @@ for name in O.ENV_IDS:
             boards[str(t)] = e.board(0).ravel().tolist()
         if d:
             e.reset(0)
-    out[name] = {"actions": actions, "steps": steps, "boards": boards, "initial_board": O.EnvBatch(name, 1).board(0).ravel().tolist()}
+    out[name] = {"actions": actions, "steps": steps, "boards": boards, "initial_board": initial}
 with open(os.path.join(HERE, "env_traces.json"), "w") as f:
     json.dump(out, f, separators=(",", ":"))
 print("episodes:", {k: sum(s[2] for s in v["steps"]) for k, v in out.items()})

@@ -31,19 +31,23 @@ def test_c_example_compiles_links_and_fails_loudly_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_id,name", [(0, "BoatRace-v0"), (1, "IslandNavigation-v0"), (2, "SideEffectsSokoban-v0"), (3, "DistributionalShift-v0")])
+@pytest.mark.parametrize("env_id,name", [(0, "BoatRace-v0"), (1, "IslandNavigation-v0"), (2, "SideEffectsSokoban-v0"), (3, "DistributionalShift-v0"),
+                                         (6, "SafeInterruptibility-v0")])
 def test_c_example_matches_oracle_on_gpu(tmp_path, env_id, name):
     from oracle import oracle as O
 
     exe = _build(tmp_path)
     n, steps, seed = 3000, 140, 77
     out = json.loads(subprocess.check_output([exe, str(env_id), str(n), str(steps), str(seed)], text=True))
-    orc = O.EnvBatch(name, n)
+    # two and three contiguous env-id shards (env_index_base), metrics through the library's RCCL all-reduce: the same line
+    for shards in (2, 3):
+        assert json.loads(subprocess.check_output([exe, str(env_id), str(n), str(steps), str(seed), str(shards)], text=True)) == out
+    orc = O.EnvBatch(name, n, seed=seed)
     m = O.metrics_new()
-    orc.rollout(2 * steps, seed=seed, auto_reset=True, metrics=m)
+    orc.rollout(3 * steps, seed=seed, auto_reset=True, metrics=m)  # step kernel + fused rollout + streamed rollout
     assert out["episodes"] == m[O.M_EPISODES] and out["sum_return"] == m[O.M_SUM_RETURN]
     assert out["sum_safety"] == m[O.M_SUM_SAFETY] and out["max_return"] == m[O.M_MAX_RETURN]
-    assert out["steps"] == 2 * steps * n and (out["height"], out["width"]) == (orc.H, orc.W)
+    assert out["steps"] == 3 * steps * n and (out["height"], out["width"]) == (orc.H, orc.W)
     h = 1469598103934665603
     for b in orc.boards().astype(np.uint8).ravel().tolist():
         h = ((h ^ b) * 1099511628211) & (2**64 - 1)

@@ -436,6 +436,43 @@ def test_tabq_stepwise_kernels_bit_exact(name, cheat):
     agent.close(); env.close()
 
 
+@pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", True), ("SideEffectsSokoban-v0", False),
+                                         ("WhiskyGold-v0", True), ("SafeInterruptibility-v0", True)])
+def test_tabq_drop_in_sequence_replayed_from_a_graph_is_bit_exact(name, cheat):
+    """sgk_tabq_learn_steps: act_explore -> step -> learn -> reset_done captured once and replayed (agent step counter in device
+    memory) == the same four calls made from Python == the oracle's literal agents; interleaved with Python-made steps and
+    fused rollouts the counters stay in step."""
+    _torch()
+    n, seed = 130, 8
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    agent = S.BatchedTabularQAgent(env, _tabq_args())
+    plan = [("graph", 100), ("calls", 3), ("graph", 100), ("graph", 7), ("fused", 20), ("graph", 30)]
+    steps = sum(k for _, k in plan)
+    orc, agents, m, acts = _oracle_tabq(name, n, steps, seed, cheat)
+    for how, k in plan:
+        if how == "graph":
+            agent.learn_steps(k, cheat=cheat)
+        elif how == "fused":
+            agent.rollout(k, cheat=cheat)
+        else:
+            for _ in range(k):
+                a = agent.act_explore()
+                env.step(a, auto_reset=False, write_boards=False)
+                agent.learn(action=a, cheat=cheat)
+                env.reset_done()
+    assert agent.t == steps and env.lockstep_t == steps
+    st = env.episode_state_host()  # (the graph runs with SGK_F_NO_BOARDS: state words, not boards, are compared)
+    assert (st["agent_cell"] == orc.field("agent_cell")).all() and (st["box_cell"] == orc.field("box_cell")).all()
+    assert (st["episode_return"] == orc.field("episode_return")).all() and (st["frame"] == orc.field("frame")).all()
+    le = env.last_episode_host()
+    assert (le["n_episodes"] == orc.field("n_episodes")).all()
+    want = m.copy()
+    want[O.M_STEPS] = n * steps
+    assert env.metrics().tolist() == want.tolist()
+    _assert_tables_equal(env, agent, orc, agents)
+    agent.close(); env.close()
+
+
 def test_tabq_rollout_picks_the_hbm_resident_kernel_at_mid_sizes_and_stays_bit_exact():
     """65 536 IslandNavigation agents: the LDS-resident kernel would need two rounds of workgroups, so sgk_tabq_rollout runs the
     HBM-resident one (tables still fit L2 / MALL). Same arithmetic: state, metrics and a sample of the f64 tables equal the
@@ -605,7 +642,9 @@ def test_render_rgb_matches_oracle_colour_map(name, layout):
     single = S.make(name)
     single.reset()
     frame = single.render(mode="rgb_array")
-    assert frame.shape == (3, env.H, env.W) and (frame == O.EnvBatch(name, 1).render_rgb(0)).all()
+    ref = O.EnvBatch(name, 1)
+    ref.reset(0)  # make() + reset(): the second reset of the env, and so the second coin of the envs that flip one
+    assert frame.shape == (3, env.H, env.W) and (frame == ref.render_rgb(0)).all()
     single.close()
 
 
@@ -857,3 +896,35 @@ def test_train_batched_sharded_over_two_ranks_equals_one_rank(tmp_path):
 
     a, b = scalars(one), scalars(two)
     assert len(a) > 20 and a == b
+
+
+def test_rccl_metrics_allreduce_through_the_c_abi_world_of_one():
+    """sgk_comm_* + sgk_metrics_allreduced on the one GPU of the box: RCCL is found and bound at run time, a communicator of one
+    rank is created from the unique id, and the all-reduced vector (SUM on [0..7], MAX on [8..11], SGK_M_STEPS included) equals
+    sgk_metrics. (More ranks need more GPUs: RCCL refuses two ranks on one device; tests/test_dist_gloo.py covers the
+    multi-rank reduction semantics on the CPU.)"""
+    import ctypes
+
+    _torch()
+    lib = _lib.load()
+    ident = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)()
+    _lib.check(lib.sgk_comm_unique_id(ident))
+    assert any(ident)
+    comm = ctypes.c_void_p()
+    _lib.check(lib.sgk_comm_create(ident, 0, 1, 0, ctypes.byref(comm)))
+    env = S.BatchedGridworldEnv("IslandNavigation-v0", 5000, seed=3)
+    env.step_random(150, auto_reset=True)
+    want = env.metrics()
+    got = np.zeros(_lib.METRICS_LEN, dtype=np.int64)
+    _lib.check(lib.sgk_metrics_allreduced(env.handle, comm, got.ctypes.data_as(ctypes.c_void_p)))
+    assert got.tolist() == want.tolist() and got[_lib.M_STEPS] == 150 * 5000 and got[_lib.M_EPISODES] > 0
+    # the device-vector form, in place, on the env's stream
+    dev = env.metrics_device()
+    before = dev.cpu().numpy().copy()
+    _lib.check(lib.sgk_allreduce_metrics(comm, ctypes.c_void_p(dev.data_ptr()), ctypes.c_void_p(env.stream_ptr)))
+    env.synchronize()
+    assert (dev.cpu().numpy() == before).all()
+    assert lib.sgk_comm_create(ident, 3, 2, 0, ctypes.byref(ctypes.c_void_p())) == _lib.ERR_INVALID
+    assert lib.sgk_allreduce_metrics(None, None, None) == _lib.ERR_INVALID
+    _lib.check(lib.sgk_comm_destroy(comm))
+    env.close()

@@ -320,6 +320,7 @@ def test_env_traces_are_frozen(golden_dir):
         traces = json.load(f)
     for name, tr in traces.items():
         e = O.EnvBatch(name, 1)
+        e.reset(0)  # make(), then reset(): as the traces were recorded
         assert e.board(0).ravel().tolist() == tr["initial_board"]
         for t, (a, want) in enumerate(zip(tr["actions"], tr["steps"])):
             r, h, d, _ = e.step(0, a)

@@ -1,6 +1,11 @@
-"""Workload for the rocprofv3 --pmc passes (run on the GPU box): eager step launches (no hipGraph) at the bench size,
-plus reset_kernel launches whose HBM reads are a known byte count in the SAME access pattern (8 B/lane state words),
-used to calibrate FETCH_SIZE as MI355X_MICROARCH.md prescribes."""
+"""Workload for the rocprofv3 --pmc passes (run on the GPU box): the bench's kernels at the bench size, plus reset_kernel
+launches whose HBM reads are a known byte count in the SAME access pattern (8 B/lane state words), used to calibrate
+FETCH_SIZE as MI355X_MICROARCH.md prescribes.
+
+    python3 tools/pmc_run.py <env> <layout> <n_envs> [launch|stream|ring]
+
+launch: eager per-step launches (step_kernel);  stream: 100-step streaming rollout launches into the env's own buffers;
+ring: the same into a 100-slice trajectory ring."""
 import os
 import sys
 
@@ -13,12 +18,30 @@ import safe_grid_agents_amd as S
 name = sys.argv[1] if len(sys.argv) > 1 else "BoatRace-v0"
 layout = sys.argv[2] if len(sys.argv) > 2 else "compact"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
+mode = sys.argv[4] if len(sys.argv) > 4 else "launch"
 env = S.BatchedGridworldEnv(name, n, seed=0x5AFE, layout=layout)
-for _ in range(30):
-    env.step_random(1, auto_reset=True)
+
+
+def work(reps):
+    if mode == "launch":
+        for _ in range(reps):
+            env.step_random(1, auto_reset=True)
+    elif mode == "stream":
+        for _ in range(max(1, reps // 6)):
+            env.step_random(100, auto_reset=True, fused="stream")
+    else:
+        import torch
+
+        boards = torch.empty((100, n, env.n_cells), dtype=torch.int8, device="cuda")
+        recs = torch.empty((100, n, 4), dtype=torch.int8, device="cuda")
+        for _ in range(max(1, reps // 6)):
+            env.rollout_random_stream(100, boards=boards, recs=recs)
+        env.synchronize()
+
+
+work(30)
 for _ in range(10):
     env.reset_done()  # reads n state words (8 B each), writes n boards; nothing is over -> no state writes
-for _ in range(30):
-    env.step_random(1, auto_reset=True)
+work(30)
 env.synchronize()
-print("done", name, layout, n)
+print("done", name, layout, n, mode)
