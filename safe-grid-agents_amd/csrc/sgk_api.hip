@@ -50,6 +50,7 @@ struct sgk_env {
   uint8_t *actions_scratch = nullptr;
   uint8_t *pinned = nullptr;         // host staging for sgk_step_host: [actions n][rec 4n][state 8n][boards n*n_cells]
   hipEvent_t order_events[2] = {nullptr, nullptr};  // sgk_stream_wait / sgk_stream_signal
+  long long *metrics_pinned = nullptr;  // [SGK_METRICS_LEN] pinned device-mapped host words the reduce kernel also writes
   float *gamma_dev = nullptr;        // [1024] float32(discount ** t) for sgk_discounted_returns
   double gamma_discount = -1.0;
   bool host_visible = false;         // SGK_MEM_HOST_VISIBLE: state/rec/boards/actions live in pinned device-mapped host memory
@@ -139,6 +140,7 @@ int sgk_destroy(sgk_env *h) {
   (void)hipFree(h->actions_scratch);
   (void)hipFree(h->gamma_dev);
   if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->metrics_pinned) (void)hipHostFree(h->metrics_pinned);
   for (int i = 0; i < 3; ++i) {
     if (h->side_streams[i]) (void)hipStreamDestroy(h->side_streams[i]);
     if (h->join_events[i]) (void)hipEventDestroy(h->join_events[i]);
@@ -337,9 +339,11 @@ int sgk_stream_signal(sgk_env *h, void *other_stream) {
   return SGK_OK;
 }
 
+static hipError_t wait_stream_low_latency(hipStream_t st);
+
 int sgk_synchronize(sgk_env *h) {
   SGK_CHECK_HANDLE(h);
-  SGK_HIP(hipStreamSynchronize(h->stream));
+  SGK_HIP(wait_stream_low_latency(h->stream));
   return SGK_OK;
 }
 
@@ -830,12 +834,23 @@ int sgk_copy_last_episode(sgk_env *h, int32_t *last_return_host, int32_t *last_p
   return SGK_OK;
 }
 
+// Wait for the handle's stream with latency in mind: poll for a bounded time (a blocking wait sleeps on an interrupt and
+// wakes tens of microseconds late), then fall back to the blocking form.
+static hipError_t wait_stream_low_latency(hipStream_t st) {
+  hipError_t q = hipErrorNotReady;
+  for (int spin = 0; spin < 200000 && q == hipErrorNotReady; ++spin) q = hipStreamQuery(st);  // ~0.1 s at most
+  if (q == hipErrorNotReady) q = hipStreamSynchronize(st);
+  return q;
+}
+
 int sgk_metrics(sgk_env *h, int64_t out_host[SGK_METRICS_LEN]) {
   SGK_CHECK_HANDLE(h);
   if (!out_host) return fail(SGK_ERR_INVALID, "out_host is NULL");
-  SGK_HIP(sgk::launch_metrics_reduce(h->sh, h->stream));
-  SGK_HIP(hipMemcpyAsync(out_host, h->sh.metrics, sizeof(int64_t) * SGK_METRICS_LEN, hipMemcpyDeviceToHost, h->stream));
-  SGK_HIP(hipStreamSynchronize(h->stream));
+  // the fold's 16 words land in pinned device-mapped host memory as well: one launch, one wait, no copy command
+  if (!h->metrics_pinned) SGK_HIP(hipHostMalloc((void **)&h->metrics_pinned, sizeof(long long) * SGK_METRICS_LEN, hipHostMallocMapped));
+  SGK_HIP(sgk::launch_metrics_reduce(h->sh, h->stream, h->metrics_pinned));
+  SGK_HIP(wait_stream_low_latency(h->stream));
+  for (int i = 0; i < SGK_METRICS_LEN; ++i) out_host[i] = (int64_t)h->metrics_pinned[i];
   out_host[SGK_M_STEPS] = h->steps_issued;
   return SGK_OK;
 }

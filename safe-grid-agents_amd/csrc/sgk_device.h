@@ -282,6 +282,108 @@ struct WaveTileWriter {
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// The same wave-private tile kept as an IMAGE IN LDS (64 * NC bytes per wave). A lane owns row `lane` of the image and
+// (re)draws it with byte stores -- backdrop, second sprite, agent on top --; then the wave reads the image back as 16-byte chunks
+// and streams them to HBM (up to 1 KiB of contiguous memory per store instruction, as above). LDS operations of one wave execute
+// in issue order, so no barrier is needed (a compiler-only wave barrier keeps the order in the instruction stream). Against the
+// register / ds_bpermute assembly above this needs no cross-lane exchange and no byte-poking ALU chains: a kernel that keeps
+// the image across steps (the streaming rollout) re-draws only the cells a step changed -- two byte stores per sprite -- which
+// took the streamed BoatRace step from ~110 to ~15 instructions of board work per lane (the bpermute form was VALU-issue-bound:
+// profiles/r02/01_stream_v1_*).
+// ------------------------------------------------------------------------------------------------
+template <int ENV, int NC>
+struct WaveTileLds {
+  static constexpr int BYTES = 64 * NC, CHUNKS = 4 * NC, ITS = (CHUNKS + 63) / 64;
+  static constexpr bool ALT = HasAltBackdrop<ENV>::value;
+  static_assert(!ALT || NC % 16 == 0, "two-backdrop levels re-draw whole rows with 16-byte LDS stores");
+  uint8_t *tile;  // this wave's image: tile[lane * NC + cell]
+
+  __device__ __forceinline__ void bind(uint8_t *wave_tile) { tile = wave_tile; }
+
+  // draw every row from scratch: the backdrop (chunk-wise from the rotation table; row-wise where each env picks one of two),
+  // then the sprites of `info` (sprite_info of this lane's env)
+  __device__ __forceinline__ void draw_all(const CompactLds<NC> &C, const SgkRules &R, uint32_t info) const {
+    const int lane = threadIdx.x & 63;
+    if (ALT) {
+      const uint8_t *t = ((info >> 24) & 1u) ? R.templ_alt : R.templ;
+#pragma unroll
+      for (int q = 0; q < NC / 16; ++q)
+        *reinterpret_cast<uint4 *>(tile + lane * NC + 16 * q) = *reinterpret_cast<const uint4 *>(t + 16 * q);
+    } else {
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        const int j = lane + 64 * it;
+        if (ITS * 64 == CHUNKS || j < CHUNKS) {
+          const int r = (16 * j) % NC;
+          *reinterpret_cast<uint4 *>(tile + 16 * j) = *reinterpret_cast<const uint4 *>(&C.rot[r][0]);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    poke(R, info);
+  }
+
+  // the sprites of this lane's env onto its row: the second sprite first, the agent on top
+  __device__ __forceinline__ void poke(const SgkRules &R, uint32_t info) const {
+    uint8_t *row = tile + (threadIdx.x & 63) * NC;
+    if (HasSprite2<ENV>::value) {
+      const int box = (info >> 8) & 0xffu;
+      if (box < NC) row[box] = (uint8_t)R.value_box;  // 255: the whisky is drunk / the interruption tile is gone
+    }
+    row[info & 0xffu] = (uint8_t)(info >> 16);
+  }
+
+  // a step changed this lane's env from `was` to `now`: re-draw what differs (the whole row when the backdrop changed)
+  __device__ __forceinline__ void update(const SgkRules &R, uint32_t was, uint32_t now) const {
+    uint8_t *row = tile + (threadIdx.x & 63) * NC;
+    if (ALT && (((was ^ now) >> 24) & 1u)) {
+      const uint8_t *t = ((now >> 24) & 1u) ? R.templ_alt : R.templ;
+#pragma unroll
+      for (int q = 0; q < NC / 16; ++q) *reinterpret_cast<uint4 *>(row + 16 * q) = *reinterpret_cast<const uint4 *>(t + 16 * q);
+    } else if (was != now) {
+      const uint8_t *t = (ALT && ((now >> 24) & 1u)) ? R.templ_alt : R.templ;
+      const int pos = was & 0xffu;
+      row[pos] = t[pos];
+      if (HasSprite2<ENV>::value) {
+        const int box = (was >> 8) & 0xffu;
+        if (box < NC) row[box] = t[box];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (was != now) poke(R, now);
+  }
+
+  // image -> HBM: all 64 * NC bytes, `dst` wave-uniform and 16-byte aligned
+  __device__ __forceinline__ void flush(int8_t *dst) const {
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_wave_barrier();
+#if SGK_STREAM_STORES
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, BYTES, 0x00020000);
+#endif
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      const int j = lane + 64 * it;
+      if (ITS * 64 == CHUNKS || j < CHUNKS) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(tile + 16 * j);
+#if SGK_STREAM_STORES
+        sgk_u32x4 v4 = {v.x, v.y, v.z, v.w};
+        __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, j * 16, 0, /*aux: sc1*/ 16);
+#else
+        reinterpret_cast<uint4 *>(dst)[j] = v;
+#endif
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the next re-draw comes after these reads in the instruction stream
+  }
+
+  // one-shot form (per-launch kernels): draw, store
+  __device__ __forceinline__ void write(const CompactLds<NC> &C, const SgkRules &R, uint32_t info, int8_t *dst) const {
+    draw_all(C, R, info);
+    flush(dst);
+  }
+};
+
 // one env's NC-byte row written byte by byte from its own state: the slow path for destinations the tile writer cannot take
 // (a trajectory slice whose last tile is partial or whose rows are not 16-byte aligned)
 template <int ENV, int NC>

@@ -53,7 +53,8 @@ hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flag
 // mode 0: reset all (mask == nullptr) or masked envs; 1: reset envs whose episode is over; 2: re-materialise boards only
 hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st);
 hipError_t launch_metrics_init(const Shard &sh, hipStream_t st);
-hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st);
+// out_host: optional second destination in pinned device-mapped host memory (the synchronising reader then needs no copy)
+hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st, long long *out_host = nullptr);
 hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st);
 struct PolicyWeights {
   const float *w1t, *b1, *w2, *b2, *w3t, *b3;

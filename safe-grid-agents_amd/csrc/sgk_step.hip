@@ -6,9 +6,32 @@
 
 namespace sgk {
 
+// Which wave-private tile writer the kernels of this file use: the LDS image (default) or the register / ds_bpermute assembly
+// (SGK_TILE_IN_LDS=0; kept for the A/B in profiles/r02). Both produce the same bytes.
+#ifndef SGK_TILE_IN_LDS
+#define SGK_TILE_IN_LDS 1
+#endif
+#if SGK_TILE_IN_LDS
+#define SGK_TILE_DECLARE(ENV, NC, ON)                                                 \
+  __shared__ __attribute__((aligned(16))) uint8_t tile_images[WG / 64][64 * (NC)];    \
+  WaveTileLds<ENV, NC> W;                                                             \
+  W.bind(tile_images[threadIdx.x >> 6]);                                              \
+  if (ON) stage_rotations(C, R)
+#define SGK_TILE_WRITE(INFO, DST) W.write(C, R, (INFO), (DST))
+#else
+#define SGK_TILE_DECLARE(ENV, NC, ON)  \
+  WaveTileWriter<ENV, NC> W;           \
+  if (ON) {                            \
+    stage_rotations(C, R);             \
+    W.init(C, R);                      \
+  }
+#define SGK_TILE_WRITE(INFO, DST) W.write((INFO), (DST))
+#endif
+
 // slab -> one metrics vector (sums over slots for [0..7], maxima for [8..11]); one workgroup of 1024 lanes:
 // 16 columns x 64 slot-lanes, four independent loads in flight per lane, LDS tree over the slot-lanes
-__global__ __launch_bounds__(1024) void metrics_reduce_kernel(const long long *__restrict__ slab, long long *__restrict__ out) {
+__global__ __launch_bounds__(1024) void metrics_reduce_kernel(const long long *__restrict__ slab, long long *__restrict__ out,
+                                                              long long *__restrict__ out_host) {
   __shared__ long long part[1024];
   const int col = threadIdx.x & 15, lane_slot = threadIdx.x >> 4;  // 64 slot-lanes
   const bool is_max = col >= SGK_M_MAX_RETURN && col <= SGK_M_MAX_MARGIN_POS;
@@ -29,7 +52,10 @@ __global__ __launch_bounds__(1024) void metrics_reduce_kernel(const long long *_
     }
     __syncthreads();
   }
-  if (threadIdx.x < 16) out[threadIdx.x] = part[threadIdx.x];
+  if (threadIdx.x < 16) {
+    out[threadIdx.x] = part[threadIdx.x];
+    if (out_host) out_host[threadIdx.x] = part[threadIdx.x];  // pinned, device-mapped host memory: no copy command afterwards
+  }
 }
 
 __global__ __launch_bounds__(WG) void metrics_init_kernel(long long *__restrict__ slab) {
@@ -64,11 +90,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
     }
   }
   stage_rules(R, a.rules);
-  WaveTileWriter<ENV, NC> W;
-  if (COMPACT) {
-    stage_rotations(C, R);
-    W.init(C, R);
-  }
+  SGK_TILE_DECLARE(ENV, NC, COMPACT);
   const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
   const uint64_t t_now = a.t_ptr ? (*a.t_ptr + a.t) : a.t;
   EpisodeAcc acc;
@@ -109,7 +131,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
 #endif
     }
     if (boards_on) {
-      if (COMPACT) W.write(sprite_info<ENV>(R, s), a.boards + wt * 64 * NC);  // the buffer is padded to whole tiles
+      if (COMPACT) SGK_TILE_WRITE(sprite_info<ENV>(R, s), a.boards + wt * 64 * NC);  // the buffer is padded to whole tiles
       else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
     }
   }
@@ -141,11 +163,7 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
   __shared__ SgkRules R;
   __shared__ CompactLds<NC> C;
   stage_rules(R, a.rules);
-  WaveTileWriter<ENV, NC> W;
-  if (COMPACT || STREAM) {
-    stage_rotations(C, R);
-    W.init(C, R);
-  }
+  SGK_TILE_DECLARE(ENV, NC, (COMPACT || STREAM));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
   const int64_t n_wt = (a.n + 63) / 64;
@@ -168,6 +186,11 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
     const bool auto_reset = (a.flags & SGK_F_AUTO_RESET) != 0;
     const bool whole_tile = wt * 64 + 64 <= a.n;  // wave-uniform
     int32_t slice = o.slice0;
+#if SGK_TILE_IN_LDS
+    // the tile image lives in LDS for all n_steps: drawn once here, then only the cells a step changes are re-drawn
+    uint32_t drawn = sprite_info<ENV>(R, s);
+    if (STREAM && boards_on) W.draw_all(C, R, drawn);
+#endif
     // which Philox block (64 steps) and which of its words (16 steps) are in hand: compared against the step index, so the
     // first step needs no special case (a peeled first iteration doubled the loop body, Philox and tile writer included)
     uint64_t have_block = ~0ull, have_word = ~0ull;
@@ -227,7 +250,14 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
         if (boards_on) {
           int8_t *dense = o.boards ? o.boards + (int64_t)slice * a.n * NC : a.boards;  // wave-uniform; rows of NC bytes
           const bool tiles = o.boards ? (o.tiles_ok && whole_tile) : COMPACT;          // the env's own buffer is padded
+#if SGK_TILE_IN_LDS
+          const uint32_t now = sprite_info<ENV>(R, s);
+          W.update(R, drawn, now);
+          drawn = now;
+          if (tiles) W.flush(dense + wt * 64 * NC);
+#else
           if (tiles) W.write(sprite_info<ENV>(R, s), dense + wt * 64 * NC);
+#endif
           else if (o.boards) { if (valid) write_row_bytes<ENV, NC>(R, dense + env * NC, s); }
           else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
         }
@@ -242,7 +272,7 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
     }
     if (!STREAM && boards_on) {  // the env's own boards show the final state (streamed into a caller's ring: the launcher
                                  // re-materialises them afterwards, reset_kernel mode 2)
-      if (COMPACT) W.write(sprite_info<ENV>(R, s), a.boards + wt * 64 * NC);
+      if (COMPACT) SGK_TILE_WRITE(sprite_info<ENV>(R, s), a.boards + wt * 64 * NC);
       else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
     }
   }
@@ -262,11 +292,7 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
   __shared__ SgkRules R;
   __shared__ CompactLds<NC> C;
   stage_rules(R, rules);
-  WaveTileWriter<ENV, NC> W;
-  if (COMPACT) {
-    stage_rotations(C, R);
-    W.init(C, R);
-  }
+  SGK_TILE_DECLARE(ENV, NC, COMPACT);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n_wt = (n + 63) / 64;
   for (int64_t wt = (int64_t)blockIdx.x * (WG / 64) + wave; wt < n_wt; wt += (int64_t)gridDim.x * (WG / 64)) {
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
         s = cur;
       }
     }
-    if (COMPACT) W.write(sprite_info<ENV>(R, s), boards + wt * 64 * NC);
+    if (COMPACT) SGK_TILE_WRITE(sprite_info<ENV>(R, s), boards + wt * 64 * NC);
     else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
   }
 }
@@ -501,9 +527,9 @@ hipError_t launch_metrics_init(const Shard &sh, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st) {
+hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st, long long *out_host) {
   (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
-  metrics_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>((const long long *)sh.metric_slab, (long long *)sh.metrics);
+  metrics_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>((const long long *)sh.metric_slab, (long long *)sh.metrics, out_host);
   return hipGetLastError();
 }
 

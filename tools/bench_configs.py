@@ -61,8 +61,11 @@ env.step_random(200, auto_reset=True)
 dt = ev_time(env, lambda: env.step_random(100, auto_reset=True), 20) / 100
 out.append({"config": 2, "what": "BoatRace random rollout, 65536 envs, step kernel, hipGraph x100", "us_per_step": dt * 1e6,
             "env_steps_per_s": n / dt, "alg_GBs": 78 * n / dt / 1e9})
+dt = ev_time(env, lambda: env.step_random(100, auto_reset=True, fused="stream"), 20) / 100
+out.append({"config": 2, "what": "same, streaming rollout kernel (100 steps/launch, every step's boards + records materialised)",
+            "us_per_step": dt * 1e6, "env_steps_per_s": n / dt, "alg_GBs": 78 * n / dt / 1e9})
 dt = ev_time(env, lambda: env.step_random(1000, auto_reset=True, fused=True), 5) / 1000
-out.append({"config": 2, "what": "same, fused rollout kernel (1000 steps/launch)", "us_per_step": dt * 1e6, "env_steps_per_s": n / dt})
+out.append({"config": 2, "what": "same, fused rollout kernel (1000 steps/launch, outputs once per launch)", "us_per_step": dt * 1e6, "env_steps_per_s": n / dt})
 env.close()
 
 # config 5 (per GPU share): 1 048 576 envs over 8 GPUs = 131 072 envs per GPU
@@ -71,6 +74,9 @@ env = S.BatchedGridworldEnv("BoatRace-v0", n, seed=0x5AFE, layout="compact")
 env.step_random(200, auto_reset=True)
 dt = ev_time(env, lambda: env.step_random(100, auto_reset=True), 20) / 100
 out.append({"config": 5, "what": "BoatRace random rollout, 131072 envs per GPU (1M over 8), step kernel, hipGraph x100",
+            "us_per_step": dt * 1e6, "env_steps_per_s": n / dt, "alg_GBs": 78 * n / dt / 1e9})
+dt = ev_time(env, lambda: env.step_random(100, auto_reset=True, fused="stream"), 20) / 100
+out.append({"config": 5, "what": "same, streaming rollout kernel (100 steps/launch, every step's boards + records materialised)",
             "us_per_step": dt * 1e6, "env_steps_per_s": n / dt, "alg_GBs": 78 * n / dt / 1e9})
 env.close()
 
@@ -95,7 +101,11 @@ def stepwise():
 for _ in range(20):
     stepwise()
 dt = wall_time(stepwise, 200)
-out.append({"config": 3, "what": "same, drop-in call sequence act_explore/step/learn/reset_done (4 launches per step, HBM tables)",
+out.append({"config": 3, "what": "same, drop-in call sequence act_explore/step/learn/reset_done made from Python (4 launches per step, HBM tables)",
+            "us_per_step": dt * 1e6, "env_steps_per_s": n / dt, "alg_GBs": 196 * n / dt / 1e9})
+agent.learn_steps(100)
+dt = ev_time(env, lambda: agent.learn_steps(100), 10) / 100
+out.append({"config": 3, "what": "same four launches per step replayed from one hipGraph per 100 steps (sgk_tabq_learn_steps)",
             "us_per_step": dt * 1e6, "env_steps_per_s": n / dt, "alg_GBs": 196 * n / dt / 1e9})
 agent.close(); env.close()
 
