@@ -252,7 +252,9 @@ SGK_API int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat);
 #define SGK_TABQ_KERNEL_LDS 1
 #define SGK_TABQ_KERNEL_HBM 2
 SGK_API int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel);
-SGK_API int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64_t *n_actions); /* [n_envs][n_states][n_actions] */
+/* [n_envs][n_states][n_actions]. A caller that WRITES through the pointer calls this again afterwards, before the next
+ * sgk_tabq_act / _learn / _learn_steps: those keep a per-env copy of one row, which this call invalidates. */
+SGK_API int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64_t *n_actions);
 SGK_API int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, double *table_host);
 SGK_API int sgk_tabq_global_step(const sgk_tabq *q, int64_t *t_out);
 SGK_API double sgk_tabq_epsilon(double epsilon, int64_t epsilon_anneal, int64_t t); /* epsilon in force at global step t */

@@ -30,12 +30,17 @@ class _SafetyEnvView:
         return self._o._b.last_performance(0)
 
 
+TRANSITION_ENVS = {"TransitionBoatRace-v0": "BoatRace-v0"}  # use_transitions=True: observation = [last board, board]
+
+
 class OracleGridworldEnv:
     def __init__(self, name):
         self.name = name
-        self._b = O.EnvBatch(name, 1)  # reset once at construction, as sgk_create leaves the product's env (reset counter 1)
+        self.use_transitions = name in TRANSITION_ENVS
+        self._b = O.EnvBatch(TRANSITION_ENVS.get(name, name), 1)  # reset once at construction, as sgk_create leaves the product's env (reset counter 1)
         self.action_space = _Space(n=4)
-        self.observation_space = _Space(shape=(1, self._b.H, self._b.W))
+        self.observation_space = _Space(shape=(2 if self.use_transitions else 1, self._b.H, self._b.W))
+        self._last = None
         self._env = _SafetyEnvView(self)
         self.actions_log = []
 
@@ -49,7 +54,11 @@ class OracleGridworldEnv:
 
     def reset(self):
         self._b.reset(0)
-        return self._obs()
+        obs = self._obs()
+        if self.use_transitions:
+            self._last = obs
+            return np.concatenate([obs, obs], axis=0)
+        return obs
 
     def step(self, action):
         if hasattr(action, "item"):
@@ -67,7 +76,10 @@ class OracleGridworldEnv:
             info["extra_observations"]["safety"] = int(self._b.field("safety")[0])
         if not O.has_hidden_reward(self._b.env_id):
             info["hidden_reward"] = None  # safe_grid_gym reports None for envs that define no hidden reward
-        return self._obs(), r, bool(d), info
+        obs = self._obs()
+        if self.use_transitions:
+            obs, self._last = np.concatenate([self._last, obs], axis=0), obs
+        return obs, r, bool(d), info
 
     def render(self, mode="rgb_array"):
         return self._b.render_rgb(0)

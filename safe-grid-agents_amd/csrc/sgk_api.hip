@@ -69,6 +69,7 @@ struct sgk_tabq {
   uint8_t *actions = nullptr;  // the actions of the captured act_explore -> step -> learn -> reset_done sequence
   long long *t_dev = nullptr;  // device copy of tq.t_agent for graph replays
   bool t_dev_stale = true;
+  bool rows_stale = false;     // the table was written outside the per-step kernels: their row slots must be re-tagged invalid
   std::map<std::pair<int32_t, uint32_t>, hipGraphExec_t> graphs;  // (n_steps, cheat | flags << 1) -> captured sequence
 };
 
@@ -217,7 +218,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
     if (v >= 64) s.max_grid = v;
   }
   // the streaming rollout keeps a wave on its tile for a whole launch: up to 8 workgroups (32 waves) per CU in flight
-  s.stream_grid = s.n_cus * 8;
+  s.stream_grid = s.n_cus * 16;  // measured at 1 M envs: 8 per CU 3.94 us per step, 16 per CU 3.82 (profiles/r02)
   if (const char *sg = getenv("SGK_STREAM_GRID")) {
     int v = atoi(sg);
     if (v >= 64) s.stream_grid = v;
@@ -251,6 +252,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(hipMalloc(&s.wg_offset, sizeof(int64_t) * n_wg));
   SGK_TRY(hipMalloc(&s.finished_total, sizeof(int64_t)));
   SGK_TRY(hipMalloc(&h->t_dev, sizeof(uint64_t)));
+  SGK_TRY(hipHostMalloc((void **)&h->metrics_pinned, sizeof(long long) * SGK_METRICS_LEN, hipHostMallocMapped));
   SGK_TRY(hipMemcpyAsync(s.rules_dev, &s.rules_host, sizeof(SgkRules), hipMemcpyHostToDevice, h->stream));
   SGK_TRY(hipMemsetAsync(s.rec, 0, sizeof(uint32_t) * n_pad, h->stream));
   SGK_TRY(hipMemsetAsync(s.last_return, 0, sizeof(int32_t) * n_pad, h->stream));
@@ -847,7 +849,6 @@ int sgk_metrics(sgk_env *h, int64_t out_host[SGK_METRICS_LEN]) {
   SGK_CHECK_HANDLE(h);
   if (!out_host) return fail(SGK_ERR_INVALID, "out_host is NULL");
   // the fold's 16 words land in pinned device-mapped host memory as well: one launch, one wait, no copy command
-  if (!h->metrics_pinned) SGK_HIP(hipHostMalloc((void **)&h->metrics_pinned, sizeof(long long) * SGK_METRICS_LEN, hipHostMallocMapped));
   SGK_HIP(sgk::launch_metrics_reduce(h->sh, h->stream, h->metrics_pinned));
   SGK_HIP(wait_stream_low_latency(h->stream));
   for (int i = 0; i < SGK_METRICS_LEN; ++i) out_host[i] = (int64_t)h->metrics_pinned[i];
@@ -898,6 +899,8 @@ int sgk_tabq_destroy(sgk_tabq *q) {
   for (auto &kv : q->graphs) (void)hipGraphExecDestroy(kv.second);
   (void)hipFree(q->tq.table);
   (void)hipFree(q->tq.s_prev);
+  (void)hipFree(q->tq.row_cache);
+  (void)hipFree(q->tq.row_tag);
   (void)hipFree(q->tq.eps_table);
   (void)hipFree(q->actions);
   (void)hipFree(q->t_dev);
@@ -923,6 +926,9 @@ int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, in
   if (e == hipSuccess) e = hipMalloc(&q->tq.s_prev, sizeof(uint16_t) * (size_t)env->sh.n);
   if (e == hipSuccess) e = hipMalloc(&q->actions, (size_t)env->sh.n);
   if (e == hipSuccess) e = hipMalloc(&q->t_dev, sizeof(long long));
+  if (e == hipSuccess) e = hipMalloc(&q->tq.row_cache, sizeof(double) * 4 * (size_t)env->sh.n);
+  if (e == hipSuccess) e = hipMalloc(&q->tq.row_tag, sizeof(uint16_t) * (size_t)env->sh.n);
+  if (e == hipSuccess) e = hipMemsetAsync(q->tq.row_tag, 0xff, sizeof(uint16_t) * (size_t)env->sh.n, env->stream);
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.table, 0, tbytes, env->stream);  // defaultdict(zeros) (value.py:31)
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.s_prev, 0xff, sizeof(uint16_t) * (size_t)env->sh.n, env->stream);
   if (e == hipSuccess && epsilon_anneal <= (int64_t)(4 << 20)) {
@@ -944,10 +950,18 @@ int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, in
   return SGK_OK;
 }
 
+// the per-step kernels' row slots (sgk_tabq.hip) mirror table rows: after anything else wrote the table they are re-tagged invalid
+static hipError_t refresh_row_tags(sgk_tabq *q) {
+  if (!q->rows_stale) return hipSuccess;
+  q->rows_stale = false;
+  return hipMemsetAsync(q->tq.row_tag, 0xff, sizeof(uint16_t) * (size_t)q->env->sh.n, q->env->stream);
+}
+
 int sgk_tabq_act(sgk_tabq *q, int explore, uint8_t *actions_out_dev) {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   SGK_CHECK_HANDLE(q->env);
   if (!actions_out_dev) return fail(SGK_ERR_INVALID, "actions_out_dev is NULL");
+  SGK_HIP(refresh_row_tags(q));
   SGK_HIP(sgk::launch_tabq_act(q->env->sh, q->tq, explore, actions_out_dev, q->env->stream));
   return SGK_OK;
 }
@@ -956,6 +970,7 @@ int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat) {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   SGK_CHECK_HANDLE(q->env);
   if (!actions_dev) return fail(SGK_ERR_INVALID, "actions_dev is NULL");
+  SGK_HIP(refresh_row_tags(q));
   SGK_HIP(sgk::launch_tabq_learn(q->env->sh, q->tq, actions_dev, cheat, q->env->stream));
   q->tq.t_agent += 1;  // update_epsilon(), learn.py:82
   q->t_dev_stale = true;
@@ -988,7 +1003,7 @@ int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags
       le = sgk::launch_tabq_act(s, tq, 1, q->actions, cap);
       if (le == hipSuccess) le = sgk::launch_step(s, q->actions, flags, cap);
       if (le == hipSuccess) le = sgk::launch_tabq_learn(s, tq, q->actions, cheat, cap);
-      if (le == hipSuccess) le = sgk::launch_reset(s, nullptr, 1, cap);
+      if (le == hipSuccess) le = sgk::launch_reset(s, nullptr, 1 | ((flags & SGK_F_NO_BOARDS) ? 4 : 0), cap);
     }
     if (le == hipSuccess) {
       (void)hipGetLastError();
@@ -1003,6 +1018,7 @@ int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags
     if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate");
     it = q->graphs.emplace(key, exec).first;
   }
+  SGK_HIP(refresh_row_tags(q));
   if (q->t_dev_stale) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, h->stream, reinterpret_cast<uint64_t *>(q->t_dev), (uint64_t)q->tq.t_agent);
@@ -1058,6 +1074,7 @@ int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel) {
   SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));  // materialise the boards of the final states
   q->tq.t_agent += n_steps;
   q->t_dev_stale = true;
+  q->rows_stale = true;  // the rollout kernels write the table directly
   s.lockstep_t += (uint64_t)n_steps;
   h->t_dev_stale = true;
   h->steps_issued += s.n * n_steps;
@@ -1068,6 +1085,7 @@ int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat) { return sgk_tabq_
 
 int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64_t *n_actions) {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
+  q->rows_stale = true;  // the caller may write through the pointer: the per-step kernels re-read the table afterwards
   if (table_dev) *table_dev = q->tq.table;
   if (n_states) *n_states = q->env->sh.n_states;
   if (n_actions) *n_actions = SGK_ACTIONS;

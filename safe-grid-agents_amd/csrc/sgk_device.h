@@ -129,6 +129,10 @@ __device__ __forceinline__ void acc_flush(const EpisodeAcc &a, long long *__rest
 #define SGK_STREAM_STORES 1
 #endif
 typedef uint32_t sgk_u32x4 __attribute__((ext_vector_type(4)));
+// cache policy of the board-tile stores (raw buffer store aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1). Default: sc1.
+#ifndef SGK_BOARD_STORE_AUX
+#define SGK_BOARD_STORE_AUX 16
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // observation materialisation
@@ -273,7 +277,7 @@ struct WaveTileWriter {
       if (ITS * 64 == CHUNKS || j < CHUNKS) {
 #if SGK_STREAM_STORES
         sgk_u32x4 v4 = {w[0], w[1], w[2], w[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, j * 16, 0, /*aux: sc1*/ 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, j * 16, 0, SGK_BOARD_STORE_AUX);
 #else
         reinterpret_cast<uint4 *>(tile)[j] = make_uint4(w[0], w[1], w[2], w[3]);
 #endif
@@ -368,7 +372,7 @@ struct WaveTileLds {
         const uint4 v = *reinterpret_cast<const uint4 *>(tile + 16 * j);
 #if SGK_STREAM_STORES
         sgk_u32x4 v4 = {v.x, v.y, v.z, v.w};
-        __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, j * 16, 0, /*aux: sc1*/ 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, j * 16, 0, SGK_BOARD_STORE_AUX);
 #else
         reinterpret_cast<uint4 *>(dst)[j] = v;
 #endif

@@ -37,6 +37,8 @@ struct Shard {
 struct TabqShard {
   double *table = nullptr;   // [n][n_states][4] float64
   uint16_t *s_prev = nullptr;
+  double *row_cache = nullptr;  // [n][4] the Q row of the state named by row_tag: what the per-step kernels hand each other
+  uint16_t *row_tag = nullptr;  // [n] state index of the cached row, 0xffff = none (see sgk_tabq.hip)
   double *eps_table = nullptr;  // [anneal] epsilon schedule (null when anneal is too long to tabulate)
   double lr = 0, discount = 0, eps0 = 0;
   int64_t anneal = 0;
@@ -50,7 +52,8 @@ hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flag
 // into trajectory rings boards [ring][n][n_cells] / recs [ring][n], step k -> slice (slice0 + k) % ring
 hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flags, int8_t *boards_ring, uint32_t *recs_ring,
                                  int32_t ring, int32_t slice0, hipStream_t st);
-// mode 0: reset all (mask == nullptr) or masked envs; 1: reset envs whose episode is over; 2: re-materialise boards only
+// mode 0: reset all (mask == nullptr) or masked envs; 1: reset envs whose episode is over; 2: re-materialise boards only;
+// | 4: touch no boards (state words only)
 hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st);
 hipError_t launch_metrics_init(const Shard &sh, hipStream_t st);
 // out_host: optional second destination in pinned device-mapped host memory (the synchronising reader then needs no copy)

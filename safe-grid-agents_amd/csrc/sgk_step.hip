@@ -11,6 +11,9 @@ namespace sgk {
 #ifndef SGK_TILE_IN_LDS
 #define SGK_TILE_IN_LDS 1
 #endif
+#ifndef SGK_STREAM_REC_SC1
+#define SGK_STREAM_REC_SC1 0  // the streamed rollout's per-step records: plain stores (A/B: write-through dwords)
+#endif
 #if SGK_TILE_IN_LDS
 #define SGK_TILE_DECLARE(ENV, NC, ON)                                                 \
   __shared__ __attribute__((aligned(16))) uint8_t tile_images[WG / 64][64 * (NC)];    \
@@ -245,7 +248,11 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
         // this step's outputs, as env.step returns them: the record (reward, hidden reward, done, executed action) ...
         const uint32_t rk = pack_rec(last_obs, last_hid, last_done, last_action);
         uint32_t *recs = o.recs ? o.recs + (int64_t)slice * a.n : a.rec;
+#if SGK_STREAM_REC_SC1
+        if (valid) __hip_atomic_store(&recs[env], rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
+#else
         if (valid) recs[env] = rk;
+#endif
         // ... and the successor board: one tile store per wave wherever the destination takes whole tiles
         if (boards_on) {
           int8_t *dense = o.boards ? o.boards + (int64_t)slice * a.n * NC : a.boards;  // wave-uniform; rows of NC bytes
@@ -285,8 +292,10 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
 // ------------------------------------------------------------------------------------------------
 template <int ENV, int LAYOUT>
 __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64_t *state, int8_t *boards,
-                                                   const uint8_t *mask, int mode, int64_t n, uint64_t seed, uint64_t env_base,
+                                                   const uint8_t *mask, int mode_flags, int64_t n, uint64_t seed, uint64_t env_base,
                                                    int32_t *__restrict__ n_resets) {
+  const int mode = mode_flags & 3;
+  const bool no_boards = (mode_flags & 4) != 0;  // state words only (the caller steps with SGK_F_NO_BOARDS)
   constexpr int NC = Geom<ENV>::NC;
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
   __shared__ SgkRules R;
@@ -299,9 +308,10 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
     const int64_t env = wt * 64 + lane;
     const bool valid = env < n;
     EnvState s = initial_state(R);
+    bool hit = false;
     if (valid) {
       EnvState cur = unpack_state(state[env]);
-      bool hit = (mode == 2) ? false : (mode == 1 ? (cur.over != 0) : (mask == nullptr || mask[env] != 0));
+      hit = (mode == 2) ? false : (mode == 1 ? (cur.over != 0) : (mask == nullptr || mask[env] != 0));
       if (hit) {
         if (HasEnvDraws<ENV>::value) {  // every reset opens a new draw sequence: the counter is the key
           s.epi = n_resets[env] + 1;
@@ -313,8 +323,15 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
         s = cur;
       }
     }
-    if (COMPACT) SGK_TILE_WRITE(sprite_info<ENV>(R, s), boards + wt * 64 * NC);
-    else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
+    // boards: every tile when re-materialising (mode 2) or resetting everything; otherwise only the tiles (rows) a reset
+    // touched -- the others already show their envs' states, and rewriting them is most of this kernel's traffic
+    const bool all = mode == 2 || (mode == 0 && mask == nullptr);
+    if (no_boards) continue;
+    if (COMPACT) {
+      if (all || __ballot(hit) != 0ull) SGK_TILE_WRITE(sprite_info<ENV>(R, s), boards + wt * 64 * NC);
+    } else if (valid && (all || hit)) {
+      write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
+    }
   }
 }
 

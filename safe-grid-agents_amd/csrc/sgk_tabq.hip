@@ -68,6 +68,8 @@ struct TabqArgs {
   long long *metrics;
   double *table;       // [n][n_states][4]
   uint16_t *s_prev;    // state index the last action was chosen from; 0xffff = env was over
+  double *row_cache;   // [n][4] per-env copy of ONE table row, coalesced (32 B per env) ...
+  uint16_t *row_tag;   // ... and which state's row it is (0xffff: none)
   int64_t n;
   uint64_t seed, env_base;
   int64_t t_agent;     // global agent step (same for every agent: lockstep) ...
@@ -80,6 +82,28 @@ struct TabqArgs {
   uint32_t flags;
 };
 
+// The per-step kernels' row hand-off. A table row is 32 B inside a 0.8-41 KB private table: every agent's access is a separate
+// DRAM line, and at 262 144 IslandNavigation agents the two gathers of a step (act: the row of s; learn: the row of s') ran at
+// 1.7 TB/s of line traffic -- 19.7 + 13.4 us of a 44 us step (profiles/r02/tabq_learn_steps_kernel_stats_before_row_cache.csv).
+// But the row learn gathers for s' IS the row the next act needs (the agent is in s' then), and the row act used is the one
+// learn updates. So each kernel leaves the row it ends with in a per-env 32-byte slot (coalesced) tagged with its state index;
+// the next kernel uses the slot when the tag matches the state it needs and gathers from the table otherwise (after a reset,
+// or after the table was written by another kernel: the API invalidates the tags then). The table itself is always written
+// through: it stays the state of record.
+__device__ __forceinline__ void load_row(const TabqArgs &a, int64_t env, int si, double &q0, double &q1, double &q2, double &q3) {
+  const double2 *row = (a.row_tag[env] == (uint16_t)si)
+                           ? reinterpret_cast<const double2 *>(a.row_cache + env * 4)
+                           : reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + si) * 4);
+  const double2 q01 = row[0], q23 = row[1];
+  q0 = q01.x; q1 = q01.y; q2 = q23.x; q3 = q23.y;
+}
+__device__ __forceinline__ void keep_row(const TabqArgs &a, int64_t env, int si, double q0, double q1, double q2, double q3) {
+  double2 *slot = reinterpret_cast<double2 *>(a.row_cache + env * 4);
+  slot[0] = make_double2(q0, q1);
+  slot[1] = make_double2(q2, q3);
+  a.row_tag[env] = (uint16_t)si;
+}
+
 template <int ENV>
 __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, uint8_t *__restrict__ actions_out) {
   __shared__ SgkRules R;
@@ -89,9 +113,9 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
   for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
     EnvState s = unpack_state(a.state[env]);
     int si = state_index<ENV>(R, s);
-    const double2 *row = reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + si) * 4);
-    double2 q01 = row[0], q23 = row[1];
-    int action = argmax4(q01.x, q01.y, q23.x, q23.y);
+    double q0, q1, q2, q3;
+    load_row(a, env, si, q0, q1, q2, q3);
+    int action = argmax4(q0, q1, q2, q3);
     if (explore) {
       uint64_t ge = a.env_base + (uint64_t)env;
       uint32_t x[4];
@@ -103,6 +127,7 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
     }
     actions_out[env] = (uint8_t)action;
     a.s_prev[env] = s.over ? (uint16_t)0xffff : (uint16_t)si;
+    keep_row(a, env, si, q0, q1, q2, q3);  // learn() reads Q[s][.] from here
   }
 }
 
@@ -118,13 +143,22 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
     int action = a.cheat ? (int)(rec >> 24) : (int)(actions[env] & 3);
     double reward = a.cheat ? (double)(int8_t)(rec >> 8) : (double)(int8_t)rec;
     int sn = state_index<ENV>(R, s);
-    double *tab = a.table + (int64_t)env * a.n_states * 4;
-    const double2 *rown = reinterpret_cast<const double2 *>(tab + sn * 4);
-    double2 n01 = rown[0], n23 = rown[1];
-    int an = argmax4(n01.x, n01.y, n23.x, n23.y);
-    double v_next = pick4(an, n01.x, n01.y, n23.x, n23.y);
-    double *cell = tab + sp * 4 + action;
-    *cell = q_update(*cell, reward, v_next, a.lr, a.discount);
+    double p0, p1, p2, p3, n0, n1, n2, n3;
+    load_row(a, env, sp, p0, p1, p2, p3);  // the row act() chose from (its slot, unless something intervened)
+    if (sn == sp) { n0 = p0; n1 = p1; n2 = p2; n3 = p3; }
+    else {
+      const double2 *rown = reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + sn) * 4);
+      const double2 n01 = rown[0], n23 = rown[1];
+      n0 = n01.x; n1 = n01.y; n2 = n23.x; n3 = n23.y;
+    }
+    int an = argmax4(n0, n1, n2, n3);
+    double v_next = pick4(an, n0, n1, n2, n3);  // from the row BEFORE this update (value.py:47-50)
+    const double q_new = q_update(pick4(action, p0, p1, p2, p3), reward, v_next, a.lr, a.discount);
+    a.table[((int64_t)env * a.n_states + sp) * 4 + action] = q_new;
+    if (sn == sp) {  // the agent did not move: its next row is the row just updated
+      if (action == 0) n0 = q_new; else if (action == 1) n1 = q_new; else if (action == 2) n2 = q_new; else n3 = q_new;
+    }
+    keep_row(a, env, sn, n0, n1, n2, n3);  // the next act() is in s'
   }
 }
 
@@ -357,6 +391,8 @@ static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t fl
   a.metrics = (long long *)sh.metric_slab;
   a.table = tq.table;
   a.s_prev = tq.s_prev;
+  a.row_cache = tq.row_cache;
+  a.row_tag = tq.row_tag;
   a.n = sh.n;
   a.seed = sh.seed;
   a.env_base = sh.env_base;

@@ -24,6 +24,11 @@ ENV_IDS = {
     "AbsentSupervisor-v0": _lib.ABSENT_SUPERVISOR,
     "SafeInterruptibility-v0": _lib.SAFE_INTERRUPTIBILITY,
 }
+# safe-grid-gym registers some envs a second time with use_transitions=True: the observation stacks the PREVIOUS board and the
+# current one, (2, H, W) (consistent with reference spiky/agents.py:43-44, which indexes channel 0 / 1 of such observations).
+# name -> the env whose rules it shares
+TRANSITION_ENVS = {"TransitionBoatRace-v0": "BoatRace-v0"}
+
 # envs that define no hidden reward upstream: performance = episode return, info["hidden_reward"] is None in the
 # single-env wrapper (the batched integer record mirrors the observed reward instead, include/sgk_levels.h)
 NO_HIDDEN_REWARD = frozenset({"DistributionalShift-v0"})
@@ -559,10 +564,14 @@ class GridworldEnv:
     """
 
     def __init__(self, name, device=0):
-        self._b = BatchedGridworldEnv(name, 1, device=device, host_visible=True, layout="pitched")
+        self.use_transitions = name in TRANSITION_ENVS  # observation = [last board, board], shape (2, H, W)
+        self._b = BatchedGridworldEnv(TRANSITION_ENVS.get(name, name), 1, device=device, host_visible=True, layout="pitched")
         self.name = name
         self.action_space = self._b.action_space
         self.observation_space = self._b.observation_space
+        if self.use_transitions:
+            self.observation_space = _Space(shape=(2, self._b.H, self._b.W))
+        self._last_board = None
         self._env = _SafetyEnvView(self)
         self._episode_return = 0
         self._last_performance = None
@@ -588,7 +597,11 @@ class GridworldEnv:
         _lib.check(self._b.lib.sgk_reset(self._b.handle, None))  # host-visible memory: no torch views involved
         self._episode_return = 0
         self._over = False
-        return self._b.boards_host()[0].astype(np.float32)
+        board = self._b.boards_host()[0].astype(np.float32)
+        if self.use_transitions:  # at reset the "last board" is the board itself
+            self._last_board = board
+            return np.concatenate([board, board], axis=0)
+        return board
 
     def step(self, action):
         if hasattr(action, "item"):  # np.int64 (value.py:35) or a 1-element tensor (value.py:92 via eval.py:35-36)
@@ -613,6 +626,8 @@ class GridworldEnv:
             "extra_observations": {"actual_actions": actual},
         }
         state = self._board.reshape(1, self._b.H, self._b.W).astype(np.float32)
+        if self.use_transitions:
+            state, self._last_board = np.concatenate([self._last_board, state], axis=0), state
         if self.name in NO_HIDDEN_REWARD:
             info["hidden_reward"] = None  # as safe_grid_gym reports it for an env without a hidden reward
         if self._water is not None:  # IslandNavigation's side information: Manhattan distance to the nearest water cell
@@ -630,8 +645,12 @@ def make(name, n_envs=None, **kwargs):
     """gym.make(name) (reference train.py:51). n_envs=None -> the single-env drop-in; an int -> the batched env."""
     if name in ENV_MAP:
         name = ENV_MAP[name]
-    if name not in ENV_IDS:
-        raise KeyError("env %r is not implemented (hot-path scope: %s)" % (name, sorted(ENV_IDS)))
+    if name not in ENV_IDS and name not in TRANSITION_ENVS:
+        raise KeyError("env %r is not implemented (hot-path scope: %s)" % (name, sorted(ENV_IDS) + sorted(TRANSITION_ENVS)))
     if n_envs is None:
         return GridworldEnv(name, **kwargs)
+    if name in TRANSITION_ENVS:
+        # batched: the same kernels; the two-board observation is what a 2-slice trajectory ring holds
+        # (rollout_random_stream(..., boards=ring) with ring.shape[0] == 2: slice k % 2 = board after step k)
+        name = TRANSITION_ENVS[name]
     return BatchedGridworldEnv(name, n_envs, **kwargs)

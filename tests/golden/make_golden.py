@@ -397,6 +397,10 @@ def main():
     golden_train("train_interrupt_tabq_seed8_cheat.json",
                  ["-S", "8", "-E", "40", "-EE", "20", "-V", "140", "-EV", "1", "-C", "-D", "0.95",
                   "interrupt", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
+    # TransitionBoatRace: the observation stacks [last board, board] (2, H, W): the Q dictionary is keyed by both
+    golden_train("train_transboat_tabq_seed5.json",
+                 ["-S", "5", "-E", "20", "-EE", "10", "-V", "120", "-EV", "0", "trans-boat", "tabular-q", "-l", ".5", "-e", "0.1",
+                  "-dl", "700"])
     golden_train_ppo("train_boat_ppo_mlp_seed5.json",
                      ["-S", "5", "-E", "4", "-EE", "3", "-V", "120", "-EV", "0", "boat", "ppo-mlp", "-l", "0.001", "-r", "2",
                       "-e", "5", "-b", "32", "-hd", "24"])

@@ -237,7 +237,8 @@ def test_obs_f32_is_the_float_board(name, layout):
 @pytest.mark.parametrize("name", ["train_boat_tabq_seed7.json", "train_island_tabq_seed1.json",
                                   "train_sokoban_tabq_seed123_cheat.json", "train_boat_tabq_seed3_video.json",
                                   "train_lava_tabq_seed11.json", "train_whisky_tabq_seed4_cheat.json",
-                                  "train_super_tabq_seed6.json", "train_interrupt_tabq_seed8_cheat.json"])
+                                  "train_super_tabq_seed6.json", "train_interrupt_tabq_seed8_cheat.json",
+                                  "train_transboat_tabq_seed5.json"])
 def test_single_env_train_reproduces_reference_run_on_gpu(golden_dir, name):
     from test_host_golden import run_train_golden
 

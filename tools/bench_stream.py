@@ -33,20 +33,28 @@ def main():
     ap.add_argument("--sizes", default="65536,131072,262144,1048576")
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--ring", type=int, default=0, help="also stream into a trajectory ring of this many slices")
+    ap.add_argument("--modes", default="launch,stream,fused", help="which forms to time (ring is added by --ring)")
+    ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
+    modes = args.modes.split(",")
     for name in args.envs.split(","):
         for n in (int(x) for x in args.sizes.split(",")):
             env = S.BatchedGridworldEnv(name, n, seed=1)
             K = args.k
-            g = timed(env, lambda: env.step_random(K, auto_reset=True), 5) / K
-            s = timed(env, lambda: env.step_random(K, auto_reset=True, fused="stream"), 5) / K
-            f = timed(env, lambda: env.step_random(K, auto_reset=True, fused=True), 5) / K
-            line = "%s n=%d: per-step launches %.2f us/step | streamed %.2f us/step (%.3g env-steps/s) | fused %.3f us/step" % (
-                name, n, g, s, n / s * 1e6, f)
+            line = "%s n=%d:" % (name, n)
+            if "launch" in modes:
+                g = timed(env, lambda: env.step_random(K, auto_reset=True), args.reps) / K
+                line += " per-step launches %.2f us/step |" % g
+            if "stream" in modes:
+                s = timed(env, lambda: env.step_random(K, auto_reset=True, fused="stream"), args.reps) / K
+                line += " streamed %.2f us/step (%.3g env-steps/s) |" % (s, n / s * 1e6)
+            if "fused" in modes:
+                f = timed(env, lambda: env.step_random(K, auto_reset=True, fused=True), args.reps) / K
+                line += " fused %.3f us/step" % f
             if args.ring:
                 boards = torch.empty((args.ring, n, env.n_cells), dtype=torch.int8, device="cuda")
                 recs = torch.empty((args.ring, n, 4), dtype=torch.int8, device="cuda")
-                r = timed(env, lambda: env.rollout_random_stream(K, boards=boards, recs=recs), 5) / K
+                r = timed(env, lambda: env.rollout_random_stream(K, boards=boards, recs=recs), args.reps) / K
                 line += " | streamed into a %d-slice ring %.2f us/step" % (args.ring, r)
             print(line, flush=True)
             env.close()
