@@ -898,9 +898,8 @@ int sgk_tabq_destroy(sgk_tabq *q) {
   }
   for (auto &kv : q->graphs) (void)hipGraphExecDestroy(kv.second);
   (void)hipFree(q->tq.table);
-  (void)hipFree(q->tq.s_prev);
+  (void)hipFree(q->tq.tags);
   (void)hipFree(q->tq.row_cache);
-  (void)hipFree(q->tq.row_tag);
   (void)hipFree(q->tq.eps_table);
   (void)hipFree(q->actions);
   (void)hipFree(q->t_dev);
@@ -923,14 +922,13 @@ int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, in
   q->tq.t_agent = 0;
   const size_t tbytes = sizeof(double) * (size_t)env->sh.n * env->sh.n_states * SGK_ACTIONS;
   hipError_t e = hipMalloc(&q->tq.table, tbytes);
-  if (e == hipSuccess) e = hipMalloc(&q->tq.s_prev, sizeof(uint16_t) * (size_t)env->sh.n);
+  if (e == hipSuccess) e = hipMalloc(&q->tq.tags, sizeof(uint32_t) * (size_t)env->sh.n);
   if (e == hipSuccess) e = hipMalloc(&q->actions, (size_t)env->sh.n);
   if (e == hipSuccess) e = hipMalloc(&q->t_dev, sizeof(long long));
   if (e == hipSuccess) e = hipMalloc(&q->tq.row_cache, sizeof(double) * 4 * (size_t)env->sh.n);
-  if (e == hipSuccess) e = hipMalloc(&q->tq.row_tag, sizeof(uint16_t) * (size_t)env->sh.n);
-  if (e == hipSuccess) e = hipMemsetAsync(q->tq.row_tag, 0xff, sizeof(uint16_t) * (size_t)env->sh.n, env->stream);
+
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.table, 0, tbytes, env->stream);  // defaultdict(zeros) (value.py:31)
-  if (e == hipSuccess) e = hipMemsetAsync(q->tq.s_prev, 0xff, sizeof(uint16_t) * (size_t)env->sh.n, env->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(q->tq.tags, 0xff, sizeof(uint32_t) * (size_t)env->sh.n, env->stream);
   if (e == hipSuccess && epsilon_anneal <= (int64_t)(4 << 20)) {
     // the schedule the reference keeps as a Python list (value.py:23-26), tabulated once: the fused kernel reads
     // eps(t) with one scalar load instead of a float64 divide per step
@@ -954,7 +952,9 @@ int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, in
 static hipError_t refresh_row_tags(sgk_tabq *q) {
   if (!q->rows_stale) return hipSuccess;
   q->rows_stale = false;
-  return hipMemsetAsync(q->tq.row_tag, 0xff, sizeof(uint16_t) * (size_t)q->env->sh.n, q->env->stream);
+  // every tag back to "no row kept, no action pending" (a learn() without an act() after this finds nothing to learn from, as
+  // after sgk_tabq_create)
+  return hipMemsetAsync(q->tq.tags, 0xff, sizeof(uint32_t) * (size_t)q->env->sh.n, q->env->stream);
 }
 
 int sgk_tabq_act(sgk_tabq *q, int explore, uint8_t *actions_out_dev) {

@@ -31,12 +31,17 @@ __device__ __forceinline__ double pick4(int k, double q0, double q1, double q2, 
 // Stream 1 (epsilon-greedy draws): one block serves TWO consecutive agent steps of one env:
 //   x = philox4x32_10(ctr = {env_lo, env_hi, (t >> 1)_lo, 1}, key); h = t & 1
 //   u(t) = uniform53(x[2h], x[2h+1]),  explore action(t) = x[2h] & 3   (bits the 53-bit construction discards)
-__device__ __forceinline__ void explore_block(uint64_t seed, uint64_t ge, int64_t t, uint32_t x[4]) {
-  philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)((uint64_t)t >> 1), 1u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+// The block is held as four SCALARS, never as an array: `h ? x[2] : x[0]` on a local array is folded by the compiler into ONE
+// load with a run-time index, the array is then promoted to LDS, and the promoted array's addressing reads the workgroup size
+// from the AQL dispatch packet -- a scalar load from host-visible queue memory that cost every launch of the two kernels using
+// it a flat 13-25 us (tabq_act_kernel 18 -> ~4 us: profiles/r02/exp_tabq_act_dispatch_packet.log).
+typedef Philox4 ExploreBlock;
+__device__ __forceinline__ ExploreBlock explore_block(uint64_t seed, uint64_t ge, int64_t t) {
+  return philox4x32_10_v((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)((uint64_t)t >> 1), 1u, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
-__device__ __forceinline__ void explore_draw(const uint32_t x[4], int64_t t, double &u, int &action) {
-  const bool h = (t & 1) != 0;
-  const uint32_t a = h ? x[2] : x[0], b = h ? x[3] : x[1];
+__device__ __forceinline__ void explore_draw(const ExploreBlock &x, int64_t t, double &u, int &action) {
+  const uint32_t m = 0u - (uint32_t)(t & 1);  // all ones for the odd step of the pair: a bit-select, NOT `h ? x2 : x0`
+  const uint32_t a = x.x0 ^ ((x.x0 ^ x.x2) & m), b = x.x1 ^ ((x.x1 ^ x.x3) & m);
   u = uniform53(a, b);
   action = (int)(a & 3u);
 }
@@ -67,9 +72,9 @@ struct TabqArgs {
   int32_t *last_return, *last_perf, *n_episodes, *n_resets;
   long long *metrics;
   double *table;       // [n][n_states][4]
-  uint16_t *s_prev;    // state index the last action was chosen from; 0xffff = env was over
-  double *row_cache;   // [n][4] per-env copy of ONE table row, coalesced (32 B per env) ...
-  uint16_t *row_tag;   // ... and which state's row it is (0xffff: none)
+  uint32_t *tags;      // low half: state index the last action was chosen from (0xffff = env was over); high half: which
+                       // state's row row_cache holds (0xffff: none). One dword per env: no sub-dword stores (sgk_device.h)
+  double *row_cache;   // [n][4] per-env copy of ONE table row, coalesced (32 B per env)
   int64_t n;
   uint64_t seed, env_base;
   int64_t t_agent;     // global agent step (same for every agent: lockstep) ...
@@ -90,18 +95,18 @@ struct TabqArgs {
 // the next kernel uses the slot when the tag matches the state it needs and gathers from the table otherwise (after a reset,
 // or after the table was written by another kernel: the API invalidates the tags then). The table itself is always written
 // through: it stays the state of record.
-__device__ __forceinline__ void load_row(const TabqArgs &a, int64_t env, int si, double &q0, double &q1, double &q2, double &q3) {
-  const double2 *row = (a.row_tag[env] == (uint16_t)si)
+__device__ __forceinline__ void load_row(const TabqArgs &a, int64_t env, uint32_t tag, int si, double &q0, double &q1, double &q2,
+                                         double &q3) {
+  const double2 *row = ((tag >> 16) == (uint32_t)si)
                            ? reinterpret_cast<const double2 *>(a.row_cache + env * 4)
                            : reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + si) * 4);
   const double2 q01 = row[0], q23 = row[1];
   q0 = q01.x; q1 = q01.y; q2 = q23.x; q3 = q23.y;
 }
-__device__ __forceinline__ void keep_row(const TabqArgs &a, int64_t env, int si, double q0, double q1, double q2, double q3) {
+__device__ __forceinline__ void keep_row(const TabqArgs &a, int64_t env, double q0, double q1, double q2, double q3) {
   double2 *slot = reinterpret_cast<double2 *>(a.row_cache + env * 4);
   slot[0] = make_double2(q0, q1);
   slot[1] = make_double2(q2, q3);
-  a.row_tag[env] = (uint16_t)si;
 }
 
 template <int ENV>
@@ -110,24 +115,29 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
   stage_rules(R, a.rules);
   const int64_t t_agent = a.t_ptr ? (int64_t)*a.t_ptr + a.t_agent : a.t_agent;
   const double eps = explore ? epsilon_at(a.eps0, a.anneal, t_agent) : 0.0;
-  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
-    EnvState s = unpack_state(a.state[env]);
-    int si = state_index<ENV>(R, s);
-    double q0, q1, q2, q3;
-    load_row(a, env, si, q0, q1, q2, q3);
-    int action = argmax4(q0, q1, q2, q3);
-    if (explore) {
-      uint64_t ge = a.env_base + (uint64_t)env;
-      uint32_t x[4];
-      explore_block(a.seed, ge, t_agent, x);
-      double u;
-      int ea;
-      explore_draw(x, t_agent, u, ea);
-      if (u < eps) action = ea;
+  const int64_t n_tiles = (a.n + WG - 1) / WG;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // whole waves stay alive: the byte store is a wave op
+    const int64_t env = tile * WG + threadIdx.x;
+    const bool valid = env < a.n;
+    int action = 0;
+    if (valid) {
+      EnvState s = unpack_state(a.state[env]);
+      const int si = state_index<ENV>(R, s);
+      double q0, q1, q2, q3;
+      load_row(a, env, a.tags[env], si, q0, q1, q2, q3);
+      action = argmax4(q0, q1, q2, q3);
+      if (explore) {
+        uint64_t ge = a.env_base + (uint64_t)env;
+        const ExploreBlock x = explore_block(a.seed, ge, t_agent);
+        double u;
+        int ea;
+        explore_draw(x, t_agent, u, ea);
+        if (u < eps) action = ea;
+      }
+      a.tags[env] = (s.over ? 0xffffu : (uint32_t)si) | ((uint32_t)si << 16);
+      keep_row(a, env, q0, q1, q2, q3);  // learn() reads Q[s][.] from here
     }
-    actions_out[env] = (uint8_t)action;
-    a.s_prev[env] = s.over ? (uint16_t)0xffff : (uint16_t)si;
-    keep_row(a, env, si, q0, q1, q2, q3);  // learn() reads Q[s][.] from here
+    store_byte_per_lane(actions_out, env, a.n, (uint32_t)action);
   }
 }
 
@@ -136,7 +146,8 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
   __shared__ SgkRules R;
   stage_rules(R, a.rules);
   for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
-    int sp = a.s_prev[env];
+    const uint32_t tag = a.tags[env];
+    const int sp = (int)(tag & 0xffffu);
     if (sp == 0xffff) continue;
     EnvState s = unpack_state(a.state[env]);
     uint32_t rec = a.rec[env];
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
     double reward = a.cheat ? (double)(int8_t)(rec >> 8) : (double)(int8_t)rec;
     int sn = state_index<ENV>(R, s);
     double p0, p1, p2, p3, n0, n1, n2, n3;
-    load_row(a, env, sp, p0, p1, p2, p3);  // the row act() chose from (its slot, unless something intervened)
+    load_row(a, env, tag, sp, p0, p1, p2, p3);  // the row act() chose from (its slot, unless something intervened)
     if (sn == sp) { n0 = p0; n1 = p1; n2 = p2; n3 = p3; }
     else {
       const double2 *rown = reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + sn) * 4);
@@ -158,7 +169,8 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
     if (sn == sp) {  // the agent did not move: its next row is the row just updated
       if (action == 0) n0 = q_new; else if (action == 1) n1 = q_new; else if (action == 2) n2 = q_new; else n3 = q_new;
     }
-    keep_row(a, env, sn, n0, n1, n2, n3);  // the next act() is in s'
+    keep_row(a, env, n0, n1, n2, n3);  // the next act() is in s'
+    a.tags[env] = (uint32_t)sp | ((uint32_t)sn << 16);
   }
 }
 
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
     double q0 = Q[(si * 4 + 0) * 64 + lane], q1 = Q[(si * 4 + 1) * 64 + lane];
     double q2 = Q[(si * 4 + 2) * 64 + lane], q3 = Q[(si * 4 + 3) * 64 + lane];
     uint32_t rec = 0;
-    uint32_t x[4] = {0, 0, 0, 0};
+    ExploreBlock x = {0, 0, 0, 0};
     for (int64_t k = 0; k < n_steps; ++k) {
       const int64_t t = a.t_agent + k;
       double eps;
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
       } else {
         eps = epsilon_at(a.eps0, a.anneal, t);
       }
-      if (k == 0 || (t & 1) == 0) explore_block(a.seed, ge, t, x);
+      if (k == 0 || (t & 1) == 0) x = explore_block(a.seed, ge, t);
       double u;
       int ea;
       explore_draw(x, t, u, ea);
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
     double2 r01 = reinterpret_cast<const double2 *>(tab + si * 4)[0], r23 = reinterpret_cast<const double2 *>(tab + si * 4)[1];
     double q0 = r01.x, q1 = r01.y, q2 = r23.x, q3 = r23.y;
     uint32_t rec = 0;
-    uint32_t x[4] = {0, 0, 0, 0};
+    ExploreBlock x = {0, 0, 0, 0};
     for (int64_t k = 0; k < n_steps; ++k) {
       const int64_t t = a.t_agent + k;
       double eps;
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
       } else {
         eps = epsilon_at(a.eps0, a.anneal, t);
       }
-      if (k == 0 || (t & 1) == 0) explore_block(a.seed, ge, t, x);
+      if (k == 0 || (t & 1) == 0) x = explore_block(a.seed, ge, t);
       double u;
       int ea;
       explore_draw(x, t, u, ea);
@@ -390,9 +402,8 @@ static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t fl
   a.n_resets = sh.n_resets;
   a.metrics = (long long *)sh.metric_slab;
   a.table = tq.table;
-  a.s_prev = tq.s_prev;
+  a.tags = tq.tags;
   a.row_cache = tq.row_cache;
-  a.row_tag = tq.row_tag;
   a.n = sh.n;
   a.seed = sh.seed;
   a.env_base = sh.env_base;

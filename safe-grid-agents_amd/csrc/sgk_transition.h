@@ -96,7 +96,9 @@ SGK_HD bool alt_backdrop(const EnvState &s) {
 // Philox-4x32-10 counter RNG (Salmon et al. 2011). Stream layout is part of the ABI (include/sgk.h):
 //   ctr = {env_lo, env_hi, j, stream}, key = {seed_lo, seed_hi}
 // ------------------------------------------------------------------------------------------------
-SGK_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+struct Philox4 { uint32_t x0, x1, x2, x3; };  // a block as four scalars (see the note at explore_block, sgk_tabq.hip)
+
+SGK_HD Philox4 philox4x32_10_v(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #if defined(__HIP__)
 #pragma unroll
 #endif
@@ -112,7 +114,14 @@ SGK_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+  Philox4 o;
+  o.x0 = c0; o.x1 = c1; o.x2 = c2; o.x3 = c3;
+  return o;
+}
+
+SGK_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  const Philox4 o = philox4x32_10_v(c0, c1, c2, c3, k0, k1);
+  out[0] = o.x0; out[1] = o.x1; out[2] = o.x2; out[3] = o.x3;
 }
 
 SGK_HD int action_from_block(const uint32_t x[4], uint64_t t) {
