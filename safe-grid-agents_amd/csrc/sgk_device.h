@@ -36,28 +36,6 @@ __device__ __forceinline__ void stage_rules(SgkRules &dst, const SgkRules *__res
 }
 
 // ------------------------------------------------------------------------------------------------
-// One BYTE per env into a byte array without sub-dword global stores. A kernel that ends in `global_store_byte` /
-// `global_store_short` per lane ran ~13 us longer on MI355X than the same kernel without them, at 65 536 and at 262 144 envs
-// alike (tabq_act_kernel 18.0 -> 4.5 us: profiles/r02/exp_subdword_stores.log). So four consecutive lanes -- which hold four
-// consecutive elements -- hand their bytes to the first of them (ds_bpermute: the LDS crossbar, no LDS memory), and that lane
-// stores one dword. Falls back to byte stores for a quad that is not dword-aligned in memory or runs past `n`.
-// Must be reached by ALL 64 lanes of the wave; element index `i` = (something the same for the quad) + (lane & 3).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_byte_per_lane(uint8_t *__restrict__ p, int64_t i, int64_t n, uint32_t b) {
-  const int lane = threadIdx.x & 63, q = lane & 3;
-  const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((lane + 1) & 63), (int)b);
-  const uint32_t b2 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((lane + 2) & 63), (int)b);
-  const uint32_t b3 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((lane + 3) & 63), (int)b);
-  const int64_t i0 = i - q;  // the quad's first element
-  const bool whole = i0 + 3 < n && i0 >= 0 && ((reinterpret_cast<uintptr_t>(p) + (uintptr_t)i0) & 3u) == 0;
-  if (whole) {
-    if (q == 0) *reinterpret_cast<uint32_t *>(p + i0) = (b & 0xffu) | ((b1 & 0xffu) << 8) | ((b2 & 0xffu) << 16) | (b3 << 24);
-  } else if (i >= 0 && i < n) {
-    p[i] = (uint8_t)b;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // episode-end bookkeeping: ballot -> wave reduction -> one atomic per wave per quantity.
 // Must be called by all 64 lanes of the wave.
 // ------------------------------------------------------------------------------------------------

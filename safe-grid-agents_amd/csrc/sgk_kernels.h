@@ -37,7 +37,7 @@ struct Shard {
 struct TabqShard {
   double *table = nullptr;   // [n][n_states][4] float64
   uint32_t *tags = nullptr;     // [n] low half: state index the last action was chosen from (0xffff = env was over);
-                                //     high half: state index of the row in row_cache (0xffff = none) -- one dword per env
+                                //     high half: state index of the row in row_cache (0xffff = none)
   double *row_cache = nullptr;  // [n][4] the Q row of the state named by the tag: what the per-step kernels hand each other
   double *eps_table = nullptr;  // [anneal] epsilon schedule (null when anneal is too long to tabulate)
   double lr = 0, discount = 0, eps0 = 0;

@@ -895,14 +895,11 @@ __global__ __launch_bounds__(WG) void replay_store_kernel(const int8_t *__restri
     for (int64_t i = gtid; i < n * nc; i += gsz) dst[i] = boards[(i / nc) * pitch + i % nc];
   }
   if (phase == 1) {
-    const int64_t n_tiles = (n + WG - 1) / WG;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // whole waves stay alive: the byte stores are wave ops
-      const int64_t env = tile * WG + threadIdx.x;
-      const uint32_t r = env < n ? rec[env] : 0u;  // reward | hidden << 8 | done << 16 | actual action << 24
-      const uint32_t act = cheat ? (r >> 24) : (env < n ? (uint32_t)actions[env] : 0u);
-      store_byte_per_lane(r_actions + slice * n, env, n, act);
-      store_byte_per_lane(reinterpret_cast<uint8_t *>(r_rewards) + slice * n, env, n, cheat ? (r >> 8) & 0xffu : r & 0xffu);
-      store_byte_per_lane(r_terminals + slice * n, env, n, (r >> 16) & 1u);
+    for (int64_t env = gtid; env < n; env += gsz) {
+      const uint32_t r = rec[env];  // reward | hidden << 8 | done << 16 | actual action << 24
+      r_actions[slice * n + env] = cheat ? (uint8_t)(r >> 24) : actions[env];
+      r_rewards[slice * n + env] = cheat ? (int8_t)(r >> 8) : (int8_t)r;
+      r_terminals[slice * n + env] = (uint8_t)((r >> 16) & 1u);
     }
   }
 }

@@ -59,15 +59,9 @@ __global__ __launch_bounds__(WG) void eps_greedy_kernel(const float4 *__restrict
                                                         const uint64_t *__restrict__ draw_ptr) {
   if (eps_ptr) eps = *eps_ptr;     // device-resident scalars: the launch can be replayed from a graph
   if (draw_ptr) draw = *draw_ptr;
-  const int64_t n_tiles = (n + WG - 1) / WG;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // whole waves stay alive: the byte store is a wave op
-    const int64_t env = tile * WG + threadIdx.x;
-    int action = 0;
-    if (env < n) {
-      const float4 q = scores[env];
-      action = pick_action<MODE>(q.x, q.y, q.z, q.w, env_base + (uint64_t)env, draw, seed, eps);
-    }
-    store_byte_per_lane(actions, env, n, (uint32_t)action);
+  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < n; env += (int64_t)gridDim.x * WG) {
+    const float4 q = scores[env];
+    actions[env] = (uint8_t)pick_action<MODE>(q.x, q.y, q.z, q.w, env_base + (uint64_t)env, draw, seed, eps);
   }
 }
 
@@ -328,12 +322,9 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_mfma_kernel(const int8_t *__r
         __syncthreads();
       }
     });
-    {
-      const int action = select_action<MODE>(mine[0], mine[1], mine[2], mine[3], u, x2, eps);
-      // lanes 0..31 own the wave's 32 envs; lanes 32..63 pass an index that stores nothing (all lanes take part in the exchange)
-      store_byte_per_lane(actions, lane < 32 ? env : (int64_t)-1 - (lane & 3), n, (uint32_t)action);
-      if (lane < 32 && env < n && scores_out)
-        reinterpret_cast<float4 *>(scores_out)[env] = make_float4(mine[0], mine[1], mine[2], mine[3]);
+    if (lane < 32 && env < n) {
+      actions[env] = (uint8_t)select_action<MODE>(mine[0], mine[1], mine[2], mine[3], u, x2, eps);
+      if (scores_out) reinterpret_cast<float4 *>(scores_out)[env] = make_float4(mine[0], mine[1], mine[2], mine[3]);
     }
     if (t_next < n_tiles) tile_commit(tiles + (buf ^ 1) * (PMFMA_ENVS * K0), t_next);
     __syncthreads();  // the next tile is complete, and nobody still reads the one just used
@@ -458,9 +449,10 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a)
       const int old_pos = s.pos, old_box = s.box;
       const bool old_alt = HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s);
       step_one<ENV>(R, a.env, env, valid, action, s, rec, acc);
-      if (a.actions_out)  // (wave-uniform) one byte per env: packed into dwords by lane quads
-        store_byte_per_lane(a.actions_out + (int64_t)k * n, owner ? env : (int64_t)-1 - (lane & 3), n, was_over ? 0u : (uint32_t)action);
-      if (valid && a.recs_out) a.recs_out[(int64_t)k * n + env] = rec;
+      if (valid) {
+        if (a.actions_out) a.actions_out[(int64_t)k * n + env] = was_over ? (uint8_t)0 : (uint8_t)action;
+        if (a.recs_out) a.recs_out[(int64_t)k * n + env] = rec;
+      }
       const bool new_alt = HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s);
       if (HasAltBackdrop<ENV>::value && owner && new_alt != old_alt) {  // the other backdrop (an auto-reset flipped the
                                                                         // supervisor's coin; the button was pressed): whole row

@@ -73,7 +73,7 @@ struct TabqArgs {
   long long *metrics;
   double *table;       // [n][n_states][4]
   uint32_t *tags;      // low half: state index the last action was chosen from (0xffff = env was over); high half: which
-                       // state's row row_cache holds (0xffff: none). One dword per env: no sub-dword stores (sgk_device.h)
+                       // state's row row_cache holds (0xffff: none)
   double *row_cache;   // [n][4] per-env copy of ONE table row, coalesced (32 B per env)
   int64_t n;
   uint64_t seed, env_base;
@@ -89,7 +89,7 @@ struct TabqArgs {
 
 // The per-step kernels' row hand-off. A table row is 32 B inside a 0.8-41 KB private table: every agent's access is a separate
 // DRAM line, and at 262 144 IslandNavigation agents the two gathers of a step (act: the row of s; learn: the row of s') ran at
-// 1.7 TB/s of line traffic -- 19.7 + 13.4 us of a 44 us step (profiles/r02/tabq_learn_steps_kernel_stats_before_row_cache.csv).
+// 1.7 TB/s of line traffic (learn: 13.4 us of a step; profiles/r02/tabq_learn_steps_kernel_stats_before_row_cache.csv).
 // But the row learn gathers for s' IS the row the next act needs (the agent is in s' then), and the row act used is the one
 // learn updates. So each kernel leaves the row it ends with in a per-env 32-byte slot (coalesced) tagged with its state index;
 // the next kernel uses the slot when the tag matches the state it needs and gathers from the table otherwise (after a reset,
@@ -115,29 +115,23 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
   stage_rules(R, a.rules);
   const int64_t t_agent = a.t_ptr ? (int64_t)*a.t_ptr + a.t_agent : a.t_agent;
   const double eps = explore ? epsilon_at(a.eps0, a.anneal, t_agent) : 0.0;
-  const int64_t n_tiles = (a.n + WG - 1) / WG;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // whole waves stay alive: the byte store is a wave op
-    const int64_t env = tile * WG + threadIdx.x;
-    const bool valid = env < a.n;
-    int action = 0;
-    if (valid) {
-      EnvState s = unpack_state(a.state[env]);
-      const int si = state_index<ENV>(R, s);
-      double q0, q1, q2, q3;
-      load_row(a, env, a.tags[env], si, q0, q1, q2, q3);
-      action = argmax4(q0, q1, q2, q3);
-      if (explore) {
-        uint64_t ge = a.env_base + (uint64_t)env;
-        const ExploreBlock x = explore_block(a.seed, ge, t_agent);
-        double u;
-        int ea;
-        explore_draw(x, t_agent, u, ea);
-        if (u < eps) action = ea;
-      }
-      a.tags[env] = (s.over ? 0xffffu : (uint32_t)si) | ((uint32_t)si << 16);
-      keep_row(a, env, q0, q1, q2, q3);  // learn() reads Q[s][.] from here
+  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
+    EnvState s = unpack_state(a.state[env]);
+    const int si = state_index<ENV>(R, s);
+    double q0, q1, q2, q3;
+    load_row(a, env, a.tags[env], si, q0, q1, q2, q3);
+    int action = argmax4(q0, q1, q2, q3);
+    if (explore) {
+      uint64_t ge = a.env_base + (uint64_t)env;
+      const ExploreBlock x = explore_block(a.seed, ge, t_agent);
+      double u;
+      int ea;
+      explore_draw(x, t_agent, u, ea);
+      if (u < eps) action = ea;
     }
-    store_byte_per_lane(actions_out, env, a.n, (uint32_t)action);
+    actions_out[env] = (uint8_t)action;
+    a.tags[env] = (s.over ? 0xffffu : (uint32_t)si) | ((uint32_t)si << 16);
+    keep_row(a, env, q0, q1, q2, q3);  // learn() reads Q[s][.] from here
   }
 }
 
