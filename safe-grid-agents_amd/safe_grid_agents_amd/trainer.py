@@ -186,6 +186,7 @@ def train_batched(args, writer_factory=None, reporter=_noop):
         writer.add_text("data/{}".format(key), str(value))
     env = _envs.make(env_name, n_envs=end - begin, seed=args.seed or 0, device=local_rank, env_index_base=begin)
     horizon = int(env.info.max_iterations)
+    sdist.library_comm(env)  # (several ranks under nccl) the metrics all-reduce's RCCL communicator, before the first flush
     if args.agent_alias == "tabular-q":
         agent = BatchedTabularQAgent(env, args)
     elif args.agent_alias in ("ppo-mlp", "ppo-cnn"):

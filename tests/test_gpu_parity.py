@@ -897,6 +897,11 @@ def test_train_batched_sharded_over_two_ranks_equals_one_rank(tmp_path):
 
     a, b = scalars(one), scalars(two)
     assert len(a) > 20 and a == b
+    # and `--devices 2` starts the two ranks itself (a child torch.distributed.run, before this process touches the GPU)
+    three = str(tmp_path / "three")
+    subprocess.run([sys.executable, "-m", "safe_grid_agents_amd", "--devices", "2", "-L", three] + argv, check=True, env=env2, cwd=root,
+                   timeout=600, stdout=subprocess.DEVNULL)
+    assert scalars(three) == a
 
 
 def test_rccl_metrics_allreduce_through_the_c_abi_world_of_one():

@@ -4,6 +4,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 rm -rf gpurun_out/prof_r01 gpurun_out/pmc_*
+export SGK_NO_BUILD=1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01 -- python3 bench.py --steps 2000 --warmup 200 > gpurun_out/bench_prof.log 2>&1
 tail -1 gpurun_out/bench_prof.log
 for f in $(find gpurun_out/prof_r01 -name "*kernel_stats.csv"); do head -6 $f; done

@@ -1,7 +1,9 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1  # never let a build start under the profiler
 mkdir -p gpurun_out; rm -rf gpurun_out/pmc_policy
+export SGK_NO_BUILD=1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_policy -- python3 tools/prof_policy.py > gpurun_out/pmc_policy.log 2>&1
 tail -3 gpurun_out/pmc_policy.log
 python - <<'PY'
