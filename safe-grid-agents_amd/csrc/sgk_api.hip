@@ -71,6 +71,7 @@ struct sgk_tabq {
   bool t_dev_stale = true;
   bool rows_stale = false;     // the table was written outside the per-step kernels: their row slots must be re-tagged invalid
   std::map<std::pair<int32_t, uint32_t>, hipGraphExec_t> graphs;  // (n_steps, cheat | flags << 1) -> captured sequence
+  uint64_t graphs_seed = 0;    // the env seed the captured launches carry (sgk_set_seed after a capture drops the graphs)
 };
 
 namespace sgk {
@@ -952,9 +953,7 @@ int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, in
 static hipError_t refresh_row_tags(sgk_tabq *q) {
   if (!q->rows_stale) return hipSuccess;
   q->rows_stale = false;
-  // every tag back to "no row kept, no action pending" (a learn() without an act() after this finds nothing to learn from, as
-  // after sgk_tabq_create)
-  return hipMemsetAsync(q->tq.tags, 0xff, sizeof(uint32_t) * (size_t)q->env->sh.n, q->env->stream);
+  return sgk::launch_tabq_forget_rows(q->env->sh, q->tq, q->env->stream);
 }
 
 int sgk_tabq_act(sgk_tabq *q, int explore, uint8_t *actions_out_dev) {
@@ -988,6 +987,11 @@ int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags
   // tabq_learn's loop body (reference learn.py:61-85 inside train.py:62-70) as the four launches of the drop-in call sequence --
   // act_explore, env.step, learn (+ update_epsilon), reset of the finished envs -- captured ONCE per (n_steps, cheat, flags) and
   // replayed: the agent step counter lives in device memory, so a replay needs no new arguments.
+  if (q->graphs_seed != s.seed) {  // env.seed() re-keyed the exploration draws: the recorded kernel arguments are stale
+    for (auto &kv : q->graphs) (void)hipGraphExecDestroy(kv.second);
+    q->graphs.clear();
+    q->graphs_seed = s.seed;
+  }
   auto key = std::make_pair(n_steps, (uint32_t)(cheat ? 1u : 0u) | (flags << 1));
   auto it = q->graphs.find(key);
   if (it == q->graphs.end()) {

@@ -115,6 +115,7 @@ hipError_t launch_render_rgb(const Shard &sh, uint8_t *dst, hipStream_t st);
 hipError_t launch_dense_boards(const Shard &sh, int8_t *dst, hipStream_t st);
 hipError_t launch_finished(const Shard &sh, int32_t *ids, int32_t *ret, int32_t *perf, hipStream_t st);
 hipError_t launch_tabq_act(const Shard &sh, const TabqShard &tq, int explore, uint8_t *actions_out, hipStream_t st);
+hipError_t launch_tabq_forget_rows(const Shard &sh, const TabqShard &tq, hipStream_t st);
 hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t *actions, int cheat, hipStream_t st);
 hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st);
 hipError_t launch_tabq_rollout_hbm(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st);

@@ -381,6 +381,19 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
   acc_flush(acc, a.metrics);
 }
 
+// "no row kept" for every env (the high half of the tag); the pending-action half stays: an act() made before the table was
+// written elsewhere is still learnt from
+__global__ __launch_bounds__(WG) void tabq_forget_rows_kernel(uint32_t *__restrict__ tags, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) tags[i] |= 0xffff0000u;
+}
+
+hipError_t launch_tabq_forget_rows(const Shard &sh, const TabqShard &tq, hipStream_t st) {
+  (void)hipGetLastError();
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  tabq_forget_rows_kernel<<<dim3(grid), dim3(WG), 0, st>>>(tq.tags, sh.n);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------

@@ -2,6 +2,10 @@
 
 config 2  BoatRace random-action rollout, 65 536 envs: the WHOLE batch vs the oracle for 230 steps, hipGraph-replayed step
           kernel and fused rollout kernel.
+config 5  (the metric's own batch) BoatRace random-action rollout, 1 048 576 envs: the WHOLE batch -- every board, state word field,
+          last-episode array and the metrics vector -- vs the oracle (threaded) after 230 steps, through each of the three
+          paths (one launch per step, streamed into the env's own buffers, streamed into a trajectory ring: the last 30
+          slices slice by slice), and as two 524 288-env shards; the same for SideEffectsSokoban and WhiskyGold.
 config 3  IslandNavigation + tabular-Q, 262 144 private agents, the LDS-resident kernel FORCED (it runs ~5 rounds of 64-agent
           groups per workgroup there: the grid-stride path) -- and again at 65 536 agents forced onto the same kernel: env
           state and the f64 tables of 4 096 sampled agents (first / middle / last groups, every round of the grid-stride
@@ -10,6 +14,7 @@ config 4  SideEffectsSokoban + deep-q, 32 768 envs, 150 iterations of {policy_ac
           replayed from one graph: env state bit-exact vs the oracle on the executed actions every iteration; the fused SGD
           step vs torch autograd + Adam at the tolerance of test_gpu_deepq (rtol 2e-4) on the same minibatch rows.
 """
+import os
 import types
 
 import numpy as np
@@ -73,6 +78,92 @@ def test_config2_boatrace_65536_envs_whole_batch_vs_oracle(fused):
     assert (env2.step_records_host() == rec).all()
     assert (env2.boards_host().reshape(4096, -1) == boards[n - 4096:]).all()  # and the shard equals the batch's tail
     env.close(); env2.close()
+
+
+# ---- config 5 / the metric's batch -------------------------------------------------------------------------------------
+def _whole_batch_equal(env, orc, where):
+    boards, f = orc.export()
+    n = env.n_envs
+    assert (env.boards_host().reshape(n, -1) == boards).all(), where
+    st, le = env.episode_state_host(), env.last_episode_host()
+    for key, name in (("episode_return", "episode_return"), ("hidden_return", "hidden_return"), ("frame", "frame"),
+                      ("over", "game_over"), ("agent_cell", "agent_cell"), ("box_cell", "box_cell")):
+        assert (st[key] == f[name]).all(), (where, key)
+    assert (le["n_episodes"] == f["n_episodes"]).all(), where
+    fin = f["n_episodes"] > 0
+    assert (le["last_return"][fin] == f["last_episode_return"][fin]).all(), where
+    assert (le["last_performance"][fin] == f["last_performance"][fin]).all(), where
+
+
+@pytest.mark.parametrize("name,path", [("BoatRace-v0", "launch"), ("BoatRace-v0", "stream"), ("BoatRace-v0", "ring"),
+                                       ("SideEffectsSokoban-v0", "stream"), ("WhiskyGold-v0", "stream")])
+def test_one_million_envs_whole_batch_vs_oracle(name, path):
+    torch = _torch()
+    n, seed, T = 1 << 20, 0x5AFE, 230
+    threads = os.cpu_count() or 8
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    orc = O.EnvBatch(name, n, seed=seed)
+    m = O.metrics_new()
+    ring = 30
+    boards = recs = None
+    if path == "ring":
+        boards = torch.empty((ring, n, env.n_cells), dtype=torch.int8, device="cuda")
+        recs = torch.empty((ring, n, 4), dtype=torch.int8, device="cuda")
+    t = 0
+    for chunk in (100, 100):
+        if path == "launch":
+            env.step_random(chunk, auto_reset=True)
+        elif path == "stream":
+            env.step_random(chunk, auto_reset=True, fused="stream")
+        else:
+            env.rollout_random_stream(chunk, boards=boards, recs=recs, first_slice=t % ring)
+        O.rollout_mt(orc, chunk, threads, seed=seed, t_begin=t, auto_reset=True, metrics=m)
+        t += chunk
+    # the last 30 steps one oracle step at a time: the ring's slices are checked slice by slice
+    if path == "ring":
+        env.rollout_random_stream(T - t, boards=boards, recs=recs, first_slice=t % ring)
+        got_b = boards.cpu().numpy()
+        for k in range(T - t):
+            O.rollout_mt(orc, 1, threads, seed=seed, t_begin=t + k, auto_reset=True, metrics=m)
+            if k % 7 == 0 or k == T - t - 1:  # (a million-env export per slice costs ~0.5 s)
+                want, _ = orc.export()
+                assert (got_b[(t + k) % ring] == want).all(), ("slice", k)
+    else:
+        if path == "launch":
+            env.step_random(T - t, auto_reset=True)
+        else:
+            env.step_random(T - t, auto_reset=True, fused="stream")
+        O.rollout_mt(orc, T - t, threads, seed=seed, t_begin=t, auto_reset=True, metrics=m)
+    _whole_batch_equal(env, orc, "%s %s" % (name, path))
+    want = m.copy()
+    want[O.M_STEPS] = n * T
+    assert env.metrics().tolist() == want.tolist()
+    env.close()
+
+
+def test_one_million_boatrace_envs_as_two_shards_equal_the_whole_batch():
+    """BASELINE config 5's sharding at its size: two contiguous 524 288-env blocks (env_index_base) reproduce the unsharded batch's
+    boards, and their metrics vectors add up (SUM on [0..7], MAX on [8..11]) to the whole batch's, which equals the oracle's."""
+    _torch()
+    n, seed, T = 1 << 20, 0x5AFE, 130
+    orc = O.EnvBatch("BoatRace-v0", n, seed=seed)
+    m = O.metrics_new()
+    O.rollout_mt(orc, T, os.cpu_count() or 8, seed=seed, auto_reset=True, metrics=m)
+    want_boards, _ = orc.export()
+    total = np.zeros(16, dtype=np.int64)
+    maxs = np.full(4, -(2 ** 63), dtype=np.int64)
+    for begin in (0, n // 2):
+        shard = S.BatchedGridworldEnv("BoatRace-v0", n // 2, seed=seed, env_index_base=begin)
+        shard.step_random(100, auto_reset=True, fused="stream")
+        shard.step_random(T - 100, auto_reset=True)
+        assert (shard.boards_host().reshape(n // 2, -1) == want_boards[begin:begin + n // 2]).all()
+        mv = shard.metrics()
+        total[:8] += mv[:8]
+        maxs = np.maximum(maxs, mv[8:12])
+        shard.close()
+    want = m.copy()
+    want[O.M_STEPS] = n * T
+    assert total[:8].tolist() == want[:8].tolist() and maxs.tolist() == want[8:12].tolist()
 
 
 # ---- config 3 ------------------------------------------------------------------------------------------------------

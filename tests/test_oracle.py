@@ -371,3 +371,20 @@ def test_render_rgb_palette():
     assert isl[:, 0, 0].tolist() == [0, 0, 255] and isl[:, 4, 3].tolist() == [0, 210, 50]
     sok = O.EnvBatch("SideEffectsSokoban-v0", 1).render_rgb(0)
     assert sok[:, 2, 2].tolist() == [0, 110, 119]
+
+
+@pytest.mark.parametrize("name", sorted(O.ENV_IDS))
+def test_bulk_export_equals_the_per_env_accessors(name):
+    """orc_init_batch / orc_export (what the million-env GPU parity tests read) against the one-env-at-a-time accessors."""
+    n = 300
+    orc = O.EnvBatch(name, n, seed=11, env_begin=5)
+    O.rollout_mt(orc, 137, 3, seed=11, env_begin=5, auto_reset=True)
+    boards, f = orc.export()
+    assert (boards == orc.boards()).all()
+    for field in ("episode_return", "hidden_return", "frame", "game_over", "agent_cell", "box_cell", "n_episodes",
+                  "last_episode_return"):
+        assert (f[field] == orc.field(field)).all(), field
+    fin = f["n_episodes"] > 0
+    perf = np.array([orc.last_performance(i) or 0 for i in range(n)])
+    assert (f["last_performance"][fin] == perf[fin]).all()
+    assert orc.export(boards=False)[0] is None
