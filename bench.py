@@ -5,10 +5,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one lockstep pass of the hot path over the whole env batch: every env of every rank takes one
-RandomAgent action (counter RNG, in-kernel) -- transition, observed reward, hidden safety reward, episode bookkeeping,
-auto-reset -- and its outputs are MATERIALISED in HBM every step: the successor board (int8 cells, streaming tile
-stores) and the step record. Default path ("stream"): the streaming rollout kernel, 100 lockstep steps per launch with
+A bench "step" is one pass of the hot path over the whole env batch = one EPISODE for every env: `--lockstep-per-step`
+(default 100 = BoatRace's fixed horizon, SURVEY.md 8(d) states the measurement in whole 100-step episodes) lockstep
+steps, in each of which every env of every rank takes one RandomAgent action (counter RNG, in-kernel) -- transition,
+observed reward, hidden safety reward, episode bookkeeping, auto-reset -- and its outputs are MATERIALISED in HBM every
+lockstep step: the successor board (int8 cells, streaming tile stores) and the step record. `value` is env-steps/s
+(envs x lockstep steps / wall seconds); `ms_per_step` is per bench step, `us_per_lockstep_step` is beside it. (Round 1
+counted ONE lockstep step per bench step: `--lockstep-per-step 1` is that definition; at the driver's `--steps 20` its
+timed region is 80 us of device work behind ~70 us of launch + synchronise latency.) Default path ("stream"): the streaming rollout kernel, 100 lockstep steps per launch with
 the env state words in registers between them (sgk_rollout_random_stream into the env's own buffers: each step
 overwrites the previous one's outputs, exactly what 100 per-step launches leave). `--path launch`: one step-kernel
 launch per step replayed from a hipGraph (the state word makes a round trip through HBM per step); reported as a
@@ -32,7 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
         sys.path.insert(0, p)
 
 B_ALG = {"BoatRace-v0": 78, "SideEffectsSokoban-v0": 100, "IslandNavigation-v0": 124, "DistributionalShift-v0": 154,
-         "WhiskyGold-v0": 124, "AbsentSupervisor-v0": 124}  # 2*H*W + 28
+         "WhiskyGold-v0": 124, "AbsentSupervisor-v0": 124, "SafeInterruptibility-v0": 124}  # 2*H*W + 28
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 GRAPH_CHUNK = 100      # lockstep steps per hipGraph replay
 
@@ -187,8 +191,10 @@ def spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20, help="timed bench steps (each --lockstep-per-step lockstep steps)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--lockstep-per-step", type=int, default=GRAPH_CHUNK,
+                    help="lockstep steps in one bench step (default 100: one BoatRace episode for every env)")
     ap.add_argument("--env", default="BoatRace-v0")
     ap.add_argument("--total-envs", type=int, default=1 << 20,
                     help="env batch of the whole job, sharded over the GPUs (BASELINE.json: 1 048 576 at every GPU count)")
@@ -250,23 +256,25 @@ def main():
                                 layout=args.layout)
     stream = env.torch_stream()
     sdist.library_comm(env)  # the RCCL communicator of the metrics all-reduce is made HERE (N > 1), not inside a timed region
-    elapsed, kernel_ms, gm = timed_steps(env, args.steps, args.warmup, barrier, sdist.global_metrics, path=args.path)
+    L = max(1, args.lockstep_per_step)
+    k_lock, w_lock = args.steps * L, args.warmup * L  # the timed region / the warm-up in lockstep steps
+    elapsed, kernel_ms, gm = timed_steps(env, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path)
     elapsed, kernel_ms = max_over_ranks(elapsed, kernel_ms)
 
-    total_steps = args.warmup + args.steps
+    total_steps = w_lock + k_lock
     secondary = {}
     if not args.no_secondary:
         # the other path and the trajectory-ring form, same bracket, a bounded number of steps (device time per step is what
         # these report; the host-clock figure of the primary path is `value`)
-        k2 = min(args.steps, 400)
-        w2 = min(args.warmup, 100)
+        k2 = min(k_lock, 400)
+        w2 = min(w_lock, 100)
         other = "launch" if args.path == "stream" else "stream"
         o_el, o_ms, _ = timed_steps(env, k2, w2, barrier, sdist.global_metrics, path=other)
         o_el, o_ms = max_over_ranks(o_el, o_ms)
         total_steps += k2 + w2
         secondary["per_step_launches" if other == "launch" else "streamed"] = {
-            "value": n_total * k2 / o_el, "unit": "env-steps/s", "steps": k2, "ms_per_step": o_el * 1e3 / k2,
-            "device_us_per_step": o_ms * 1e3 / k2,
+            "value": n_total * k2 / o_el, "unit": "env-steps/s", "lockstep_steps": k2,
+            "us_per_lockstep_step": o_el * 1e6 / k2, "device_us_per_lockstep_step": o_ms * 1e3 / k2,
             "note": ("sgk_step_random: one step-kernel launch per lockstep step (hipGraph x%d), state words through HBM every step"
                      % GRAPH_CHUNK) if other == "launch" else "sgk_rollout_random_stream: %d steps per launch" % GRAPH_CHUNK}
         slices = GRAPH_CHUNK
@@ -276,8 +284,8 @@ def main():
         r_el, r_ms = max_over_ranks(r_el, r_ms)
         total_steps += k2 + w2
         secondary["streamed_into_trajectory_ring"] = {
-            "value": n_total * k2 / r_el, "unit": "env-steps/s", "steps": k2, "ms_per_step": r_el * 1e3 / k2,
-            "device_us_per_step": r_ms * 1e3 / k2, "ring_slices": slices,
+            "value": n_total * k2 / r_el, "unit": "env-steps/s", "lockstep_steps": k2,
+            "us_per_lockstep_step": r_el * 1e6 / k2, "device_us_per_lockstep_step": r_ms * 1e3 / k2, "ring_slices": slices,
             "ring_bytes": int(ring[0].numel() + ring[1].numel()),
             "note": "sgk_rollout_random_stream into boards [%d][n][cells] + records [%d][n]: every step's outputs KEPT "
                     "(the batched dqn_warmup, reference warmup.py:14-21); nothing is overwritten within a launch" % (slices, slices)}
@@ -307,11 +315,12 @@ def main():
         per = 1 << 20
         wenv = S.BatchedGridworldEnv(args.env, per, device=local_rank, seed=args.seed, env_index_base=rank * per,
                                      layout=args.layout)
-        w_el, w_ms, _ = timed_steps(wenv, args.steps, args.warmup, barrier, sdist.global_metrics, path=args.path)
+        w_el, w_ms, _ = timed_steps(wenv, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path)
         w_el, w_ms = max_over_ranks(w_el, w_ms)
-        weak_line = {"value": per * world * args.steps / w_el, "unit": "env-steps/s", "envs_per_gpu": per,
+        weak_line = {"value": per * world * k_lock / w_el, "unit": "env-steps/s", "envs_per_gpu": per,
                      "total_envs": per * world, "ms_per_step": w_el * 1e3 / args.steps,
-                     "avg_launch_us": w_ms * 1e3 / args.steps, "scaling": "weak"}
+                     "us_per_lockstep_step": w_el * 1e6 / k_lock, "device_us_per_lockstep_step": w_ms * 1e3 / k_lock,
+                     "scaling": "weak"}
         wenv.close()
 
     if world > 1:
@@ -319,9 +328,9 @@ def main():
         tdist.destroy_process_group()
     if rank != 0:
         return
-    value = n_total * args.steps / elapsed
-    launches = len(chunk_schedule(args.steps)) if args.path == "stream" else args.steps
-    steps_per_launch = args.steps / launches
+    value = n_total * k_lock / elapsed
+    launches = len(chunk_schedule(k_lock)) if args.path == "stream" else k_lock
+    steps_per_launch = k_lock / launches
     launch_s = kernel_ms / 1e3 / launches  # average duration of one launch of the dominant kernel incl. its launch gap
     b_alg = B_ALG[args.env]
     achieved = b_alg * n_local * steps_per_launch / launch_s / 1e9
@@ -357,6 +366,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps,
+        "lockstep_steps_per_step": L, "us_per_lockstep_step": elapsed * 1e6 / k_lock,
         "higher_is_better": True,
         "scaling": "weak" if (weak or world == 1) else "strong",
         "vs_baseline": None,
@@ -368,6 +378,8 @@ def main():
                            if args.path == "stream" else "step kernel (one launch per step, hipGraph x%d)" % GRAPH_CHUNK)
                         + ", auto-reset, every step's board and step record materialised in HBM",
             "path": args.path,
+            "step": "one pass over the batch = %d lockstep steps for every env (%s)" % (
+                L, "one full BoatRace episode each" if (L == 100 and args.env == "BoatRace-v0") else "--lockstep-per-step"),
             "envs_per_gpu": n_local, "total_envs": n_total, "board_layout": args.layout,
             "parallelism": "env-sharded x%d, int64 metrics all-reduce" % world,
         },

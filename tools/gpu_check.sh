@@ -6,5 +6,5 @@ python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke
 tail -5 gpurun_out/smoke.log
 timeout 2400 python -m pytest tests -m gpu -q --timeout=900 ${PYTEST_ARGS} > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 tail -40 gpurun_out/pytest_gpu.log
-timeout 600 python bench.py --steps 1000 --warmup 100 > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log
 tail -5 gpurun_out/bench.log

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 rm -rf gpurun_out/prof_r01 gpurun_out/pmc_*
 export SGK_NO_BUILD=1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01 -- python3 bench.py --steps 2000 --warmup 200 > gpurun_out/bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01 -- python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_prof.log 2>&1
 tail -1 gpurun_out/bench_prof.log
 for f in $(find gpurun_out/prof_r01 -name "*kernel_stats.csv"); do head -6 $f; done
 for ctr in FETCH_SIZE WRITE_SIZE; do
@@ -14,4 +14,4 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   python tools/pmc_summary.py gpurun_out/pmc_$ctr > gpurun_out/pmc_${ctr}_summary.json; cat gpurun_out/pmc_${ctr}_summary.json
   find gpurun_out/pmc_$ctr -name "*.csv" -size +2M -delete
 done
-python bench.py --steps 2000 --warmup 200 > gpurun_out/bench_plain.log 2>&1; tail -1 gpurun_out/bench_plain.log
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench_plain.log 2>&1; tail -1 gpurun_out/bench_plain.log
