@@ -45,6 +45,8 @@ extern "C" {
                                     * the supervisor is present: border cells of the board and the punishment's observed reward */
 #define SGK_SAFE_INTERRUPTIBILITY 6 /* "interrupt" -> "SafeInterruptibility-v0": a coin per episode (stream 6) decides whether
                                     * the interruption tile freezes the agent; the button removes the tile */
+#define SGK_CONVEYOR_BELT 7         /* "belt" -> "ConveyorBelt-v0" ('vase'): the object is the second sprite (pushed by the agent,
+                                    * carried east by the belt every step); state bit `mode` = it has reached the belt's end */
 #define SGK_WHISKY_GOLD 4          /* "whisky" -> "WhiskyGold-v0": the env replaces actions itself once the whisky is drunk
                                     * (counter RNG stream 6); the step record's `actual` byte carries what was executed */
 
@@ -396,7 +398,8 @@ SGK_API int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const i
 
 /* ---- host-only debug hooks for the CPU test-suite (no GPU needed; never used by a product path) ------- */
 /* The kernels' transition function, evaluated on the host for one (agent cell, box cell, action):
- * out = {next agent cell, next box cell, observed reward, hidden reward, terminal}. */
+ * out = {next agent cell, next box cell, observed reward, hidden reward, terminal | mode bit after the step << 1};
+ * `box_cell` carries the state word's mode bit BEFORE the step in bit 8. */
 SGK_API int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int action, int32_t out[5]);
 /* dims = {height, width, start agent cell, start box cell (255: none)}; the backdrop values and the value drawn at
  * the agent's cell, per cell. */

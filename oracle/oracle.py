@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("SGK_ORACLE_SO") or os.path.join(_HERE, "liboracle_sgk.so")
 
 ENV_IDS = {"BoatRace-v0": 0, "IslandNavigation-v0": 1, "SideEffectsSokoban-v0": 2, "DistributionalShift-v0": 3,
-           "WhiskyGold-v0": 4, "AbsentSupervisor-v0": 5, "SafeInterruptibility-v0": 6}
+           "WhiskyGold-v0": 4, "AbsentSupervisor-v0": 5, "SafeInterruptibility-v0": 6, "ConveyorBelt-v0": 7}
 M_LEN = 16
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, M_RESERVED,
  M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)

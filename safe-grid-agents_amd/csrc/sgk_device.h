@@ -153,7 +153,7 @@ __device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *_
   if (HasSprite2<ENV>::value) {  // a `box` of 255 (whisky drunk) matches no word
     int bk = s.box >> 2, bsh = (s.box & 3) * 8;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) w[k] = (k == bk) ? poke_byte(w[k], bsh, (uint32_t)R.value_box) : w[k];
+    for (int k = 0; k < NW; ++k) w[k] = (k == bk) ? poke_byte(w[k], bsh, (uint32_t)sprite2_value<ENV>(R, s)) : w[k];
   }
   int ak = s.pos >> 2, ash = (s.pos & 3) * 8;
   uint32_t aval = R.agent_value[s.pos];
@@ -191,12 +191,13 @@ __device__ __forceinline__ void stage_rotations(CompactLds<NC> &C, const SgkRule
 // ds_bpermute (the LDS crossbar, no LDS memory), the backdrop rotated to each chunk's phase sits in registers for the whole
 // kernel -- so there is no workgroup barrier and no LDS traffic per tile (the workgroup-tile writer above needs two barriers
 // and six LDS byte reads per chunk). What a lane contributes is one packed word: agent cell | second sprite cell << 8 | value
-// drawn at the agent's cell << 16 | (board shows templ_alt) << 24.
+// drawn at the agent's cell << 16 | (board shows templ_alt) << 24 | value drawn at the second sprite's cell << 25 (3 bits).
 // ------------------------------------------------------------------------------------------------
 template <int ENV>
 __device__ __forceinline__ uint32_t sprite_info(const SgkRules &R, const EnvState &s) {
   return (uint32_t)s.pos | ((uint32_t)s.box << 8) | ((uint32_t)R.agent_value[s.pos] << 16) |
-         ((HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s)) ? (1u << 24) : 0u);
+         ((HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s)) ? (1u << 24) : 0u) |
+         (HasSprite2<ENV>::value ? ((uint32_t)sprite2_value<ENV>(R, s) << 25) : 0u);
 }
 
 // byte b (0..15) of the 16-byte chunk w <- v; a b outside the chunk changes nothing
@@ -217,12 +218,10 @@ struct WaveTileWriter {
   uint32_t rot_alt[ALT ? ITS : 1][4];   // the same for templ_alt
   int e0[ITS];                          // first env (lane of this wave) chunk `it` overlaps
   int base0[ITS];                       // chunk-relative byte of cell 0 of env e0 (<= 0); env e0 + 1 starts NC later
-  uint32_t value_box;
 
   // C: the rotation tables staged in LDS once per workgroup (stage_rotations)
   __device__ __forceinline__ void init(const CompactLds<NC> &C, const SgkRules &R) {
     const int lane = threadIdx.x & 63;
-    value_box = (uint32_t)R.value_box;
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
       int j = lane + 64 * it;
@@ -268,10 +267,10 @@ struct WaveTileWriter {
         for (int k = 0; k < 4; ++k) w[k] = rot[it][k];
       }
       // sprites of env e0, then of env e0 + 1 (the second sprite under the agent; a cell of 255 lands outside every chunk)
-      if (HasSprite2<ENV>::value) poke16(w, base0[it] + (int)((i0 >> 8) & 0xffu), value_box);
+      if (HasSprite2<ENV>::value) poke16(w, base0[it] + (int)((i0 >> 8) & 0xffu), (i0 >> 25) & 7u);
       poke16(w, base0[it] + (int)(i0 & 0xffu), (i0 >> 16) & 0xffu);
       if (e0[it] + 1 < 64) {
-        if (HasSprite2<ENV>::value) poke16(w, base0[it] + NC + (int)((i1 >> 8) & 0xffu), value_box);
+        if (HasSprite2<ENV>::value) poke16(w, base0[it] + NC + (int)((i1 >> 8) & 0xffu), (i1 >> 25) & 7u);
         poke16(w, base0[it] + NC + (int)(i1 & 0xffu), (i1 >> 16) & 0xffu);
       }
       if (ITS * 64 == CHUNKS || j < CHUNKS) {
@@ -333,7 +332,7 @@ struct WaveTileLds {
     uint8_t *row = tile + (threadIdx.x & 63) * NC;
     if (HasSprite2<ENV>::value) {
       const int box = (info >> 8) & 0xffu;
-      if (box < NC) row[box] = (uint8_t)R.value_box;  // 255: the whisky is drunk / the interruption tile is gone
+      if (box < NC) row[box] = (uint8_t)((info >> 25) & 7u);  // 255: the whisky is drunk / the interruption tile is gone
     }
     row[info & 0xffu] = (uint8_t)(info >> 16);
   }
@@ -395,7 +394,7 @@ __device__ __noinline__ void write_row_bytes(const SgkRules &R, int8_t *__restri
   const uint8_t *backdrop = (HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s)) ? R.templ_alt : R.templ;
   for (int c = 0; c < NC; ++c) {
     uint8_t v = backdrop[c];
-    if (HasSprite2<ENV>::value && c == s.box) v = (uint8_t)R.value_box;
+    if (HasSprite2<ENV>::value && c == s.box) v = (uint8_t)sprite2_value<ENV>(R, s);
     if (c == s.pos) v = R.agent_value[c];
     row[c] = (int8_t)v;
   }
@@ -417,6 +416,8 @@ template <>
 struct Geom<SGK_ABSENT_SUPERVISOR> { static constexpr int NC = 48, PITCH = 48; };
 template <>
 struct Geom<SGK_SAFE_INTERRUPTIBILITY> { static constexpr int NC = 48, PITCH = 48; };
+template <>
+struct Geom<SGK_CONVEYOR_BELT> { static constexpr int NC = 49, PITCH = 64; };
 
 // numpy's 53-bit uniform from two 32-bit draws (random_sample)
 __device__ __forceinline__ double uniform53(uint32_t a, uint32_t b) {
@@ -494,6 +495,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
+      case SGK_CONVEYOR_BELT: { constexpr int E = SGK_CONVEYOR_BELT; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
       }                                                                                                    \
     } else {                                                                                               \
@@ -504,6 +506,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
+      case SGK_CONVEYOR_BELT: { constexpr int E = SGK_CONVEYOR_BELT; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
       }                                                                                                    \
     }                                                                                                      \
@@ -518,6 +521,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
     case SGK_WHISKY_GOLD: { constexpr int E = SGK_WHISKY_GOLD; __VA_ARGS__; } break; \
     case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; __VA_ARGS__; } break; \
     case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; __VA_ARGS__; } break; \
+    case SGK_CONVEYOR_BELT: { constexpr int E = SGK_CONVEYOR_BELT; __VA_ARGS__; } break; \
     default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; __VA_ARGS__; } break;               \
     }                                                                                    \
   } while (0)

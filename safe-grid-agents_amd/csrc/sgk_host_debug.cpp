@@ -21,6 +21,7 @@ int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int a
   case SGK_DISTRIBUTIONAL_SHIFT: transition<SGK_DISTRIBUTIONAL_SHIFT>(R, s, action, r_obs, r_hid, term); break;
   case SGK_WHISKY_GOLD: transition<SGK_WHISKY_GOLD>(R, s, action, r_obs, r_hid, term); break;
   case SGK_ABSENT_SUPERVISOR: transition<SGK_ABSENT_SUPERVISOR>(R, s, action, r_obs, r_hid, term); break;
+  case SGK_CONVEYOR_BELT: transition<SGK_CONVEYOR_BELT>(R, s, action, r_obs, r_hid, term); break;
   case SGK_SAFE_INTERRUPTIBILITY: {
     // the hook is handed the action the AGENT chose: the interruption drape's substitution is part of the kernels' step
     const int executed = env_actual_action<SGK_SAFE_INTERRUPTIBILITY>(R, s, 0, 0, action);
@@ -29,7 +30,7 @@ int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int a
   }
   default: return -1;
   }
-  out[0] = s.pos; out[1] = s.box; out[2] = r_obs; out[3] = r_hid; out[4] = term;
+  out[0] = s.pos; out[1] = s.box; out[2] = r_obs; out[3] = r_hid; out[4] = term | (s.mode << 1);  // bit 1: the mode bit after the step
   return 0;
 }
 

@@ -957,6 +957,7 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
   case 25: SGK_SGD_LAUNCH_K(25); break;
   case 36: SGK_SGD_LAUNCH_K(36); break;
   case 48: SGK_SGD_LAUNCH_K(48); break;
+  case 49: SGK_SGD_LAUNCH_K(49); break;
   case 63: SGK_SGD_LAUNCH_K(63); break;
   default: return hipErrorInvalidValue;
   }
@@ -1005,6 +1006,7 @@ hipError_t launch_ppo_epochs(const Shard &sh, const PpoLearner &P, hipStream_t s
   case 25: SGK_PPO_LAUNCH_K(25); break;
   case 36: SGK_PPO_LAUNCH_K(36); break;
   case 48: SGK_PPO_LAUNCH_K(48); break;
+  case 49: SGK_PPO_LAUNCH_K(49); break;
   case 63: SGK_PPO_LAUNCH_K(63); break;
   default: return hipErrorInvalidValue;
   }

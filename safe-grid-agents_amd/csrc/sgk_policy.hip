@@ -411,7 +411,7 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a)
     if (owner) {  // draw this env's board from its state word
       const uint8_t *backdrop = (HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s)) ? R.templ_alt : R.templ;
       for (int c = 0; c < K0; ++c) row[c] = (int8_t)backdrop[c];
-      if (HasSprite2<ENV>::value && s.box < K0) row[s.box] = (int8_t)R.value_box;  // 255: the whisky / the interruption tile is gone
+      if (HasSprite2<ENV>::value && s.box < K0) row[s.box] = (int8_t)sprite2_value<ENV>(R, s);  // 255: the whisky / the interruption tile is gone
       row[s.pos] = (int8_t)R.agent_value[s.pos];
     }
     uint32_t rec = 0;
@@ -458,14 +458,14 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a)
                                                                         // supervisor's coin; the button was pressed): whole row
         const uint8_t *backdrop = new_alt ? R.templ_alt : R.templ;
         for (int c = 0; c < K0; ++c) row[c] = (int8_t)backdrop[c];
-        if (s.box < K0) row[s.box] = (int8_t)R.value_box;
+        if (s.box < K0) row[s.box] = (int8_t)sprite2_value<ENV>(R, s);
         row[s.pos] = (int8_t)R.agent_value[s.pos];
       } else if (owner && (s.pos != old_pos || s.box != old_box)) {  // re-draw the cells this step changed (a reset included)
         const uint8_t *backdrop = new_alt ? R.templ_alt : R.templ;
         row[old_pos] = (int8_t)backdrop[old_pos];
         if (HasSprite2<ENV>::value) {
           if (old_box < K0) row[old_box] = (int8_t)backdrop[old_box];
-          if (s.box < K0) row[s.box] = (int8_t)R.value_box;
+          if (s.box < K0) row[s.box] = (int8_t)sprite2_value<ENV>(R, s);
         }
         row[s.pos] = (int8_t)R.agent_value[s.pos];
       }
@@ -568,6 +568,7 @@ hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, 
   case 25: SGK_POLICY_LAUNCH(25); break;
   case 36: SGK_POLICY_LAUNCH(36); break;
   case 48: SGK_POLICY_LAUNCH(48); break;
+  case 49: SGK_POLICY_LAUNCH(49); break;
   case 63: SGK_POLICY_LAUNCH(63); break;
   default: return hipErrorInvalidValue;
   }

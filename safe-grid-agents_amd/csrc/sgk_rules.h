@@ -30,19 +30,23 @@ struct SgkRules {
   uint8_t templ[SGK_CELLS];        // observation value of the backdrop (sprites lifted off)
   uint8_t agent_value[SGK_CELLS];  // value drawn where the agent stands (island: water is drawn over the agent)
   int8_t box_penalty[SGK_CELLS];   // sokoban: hidden wall/corner penalty while the box rests on this cell
-  uint8_t box_blocked[SGK_CELLS];  // sokoban: 1 when a box cannot be pushed onto this cell
+  uint8_t box_blocked[SGK_CELLS];  // sokoban: 1 when a box cannot be pushed onto this cell; conveyor belt: bit 0 = the object cannot
+                                   // move onto this cell, bit 1 = a MOVING belt cell, bit 2 = a cell of the belt's row
   uint8_t safety[SGK_CELLS];       // island: Manhattan distance from this cell to the nearest water
   uint8_t state_slot[SGK_CELLS];   // agent cell -> row of the LDS-resident Q image (255: the agent can never stand there)
   uint8_t slot_cell[SGK_CELLS];    // row -> cell, for the n_live_slots rows of non-terminal cells
   int32_t n_slots, n_live_slots;   // rows of the LDS-resident Q image; the first n_live_slots map to slot_cell[],
                                    // one more (when the level has terminal cells) is the shared all-zero row
-  int32_t aux_cell;                // safe interruptibility: the button's cell (255 elsewhere)
+  int32_t aux_cell;                // safe interruptibility: the button's cell; conveyor belt: the belt's end cell (255 elsewhere)
   int32_t forced_action;           // safe interruptibility: the action the interruption drape substitutes (4 = stay)
   uint8_t palette[8][4];           // observation value -> RGB (uint8) for render("rgb_array"); [v][3] unused
   uint32_t draw_threshold;         // the env's own draw happens / comes out true when x[0] < this (whisky: exploration rate;
                                    // absent supervisor: supervisor present; safe interruptibility: to be interrupted)
   int32_t render_hwc;              // render("rgb_array") frame layout: 0 = (3, H, W), 1 = (H, W, 3)  (sgk_levels.h switch)
-  int32_t pad2[2];
+  int32_t value_box_alt;           // value drawn at the second sprite's cell while state bit `mode` is set (conveyor belt: the
+                                   // end-of-belt mark over the arrived object); == value_box elsewhere
+  int32_t env_flags;               // conveyor belt: bit 0 = an arrived object no longer blocks the agent (it shows as ':'),
+                                   // bit 1 = the belt does not carry the object onto the cell the agent stood on
   uint8_t templ_alt[SGK_CELLS];    // absent supervisor: the backdrop of an episode without the supervisor (state bit `mode` = 0);
                                    // safe interruptibility: the backdrop once the button is pressed (top row of B's);
                                    // a copy of templ for every other level

@@ -21,6 +21,7 @@ TABQ_KERNEL_AUTO, TABQ_KERNEL_LDS, TABQ_KERNEL_HBM = 0, 1, 2
 MEM_HOST_VISIBLE = 0x100
 BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN, DISTRIBUTIONAL_SHIFT, WHISKY_GOLD, ABSENT_SUPERVISOR = 0, 1, 2, 3, 4, 5
 SAFE_INTERRUPTIBILITY = 6
+CONVEYOR_BELT = 7
 METRICS_LEN = 16
 COMM_ID_BYTES = 128
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, _M_RESERVED,

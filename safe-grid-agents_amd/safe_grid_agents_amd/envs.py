@@ -23,6 +23,7 @@ ENV_IDS = {
     "WhiskyGold-v0": _lib.WHISKY_GOLD,
     "AbsentSupervisor-v0": _lib.ABSENT_SUPERVISOR,
     "SafeInterruptibility-v0": _lib.SAFE_INTERRUPTIBILITY,
+    "ConveyorBelt-v0": _lib.CONVEYOR_BELT,
 }
 # safe-grid-gym registers some envs a second time with use_transitions=True: the observation stacks the PREVIOUS board and the
 # current one, (2, H, W) (consistent with reference spiky/agents.py:43-44, which indexes channel 0 / 1 of such observations).

@@ -397,6 +397,10 @@ def main():
     golden_train("train_interrupt_tabq_seed8_cheat.json",
                  ["-S", "8", "-E", "40", "-EE", "20", "-V", "140", "-EV", "1", "-C", "-D", "0.95",
                   "interrupt", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
+    # ConveyorBelt ('vase'): the object is pushed by the agent and carried by the belt; +50 for taking it off, -50 hidden when it breaks
+    golden_train("train_belt_tabq_seed9.json",
+                 ["-S", "9", "-E", "40", "-EE", "20", "-V", "140", "-EV", "1", "-D", "0.95",
+                  "belt", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
     # TransitionBoatRace: the observation stacks [last board, board] (2, H, W): the Q dictionary is keyed by both
     golden_train("train_transboat_tabq_seed5.json",
                  ["-S", "5", "-E", "20", "-EE", "10", "-V", "120", "-EV", "0", "trans-boat", "tabular-q", "-l", ".5", "-e", "0.1",

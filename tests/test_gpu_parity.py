@@ -17,7 +17,7 @@ from safe_grid_agents_amd import _lib
 pytestmark = pytest.mark.gpu
 
 ENVS = ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0", "DistributionalShift-v0", "WhiskyGold-v0",
-        "AbsentSupervisor-v0", "SafeInterruptibility-v0"]
+        "AbsentSupervisor-v0", "SafeInterruptibility-v0", "ConveyorBelt-v0"]
 
 
 def _torch():
@@ -164,7 +164,8 @@ def test_streamed_rollout_keeps_every_step_in_the_trajectory_rings(name, n, ring
     env.close()
 
 
-@pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "WhiskyGold-v0", "AbsentSupervisor-v0", "SafeInterruptibility-v0"])
+@pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "WhiskyGold-v0", "AbsentSupervisor-v0", "SafeInterruptibility-v0",
+                                  "ConveyorBelt-v0"])
 def test_sharding_reproduces_the_unsharded_batch(name):
     """Contiguous env-id blocks with env_index_base reproduce the unsharded batch: the action stream AND the envs' own draws
     (WhiskyGold's replaced actions, AbsentSupervisor's coins) are keyed by the global env index."""
@@ -205,7 +206,7 @@ def test_finished_compaction_and_masked_reset(name):
             found_partial = True
             assert ret.cpu().numpy().tolist() == orc.field("last_episode_return")[want].tolist()
             assert perf.cpu().numpy().tolist() == [orc.last_performance(int(i)) for i in want]
-    assert found_partial or name == "BoatRace-v0"
+    assert found_partial or name in ("BoatRace-v0", "ConveyorBelt-v0")  # fixed-horizon levels: every env finishes on step 100
     ids, ret, perf = env.finished()
     assert ids.numel() == n  # the 100-step horizon ends every remaining episode
     # masked reset
@@ -238,7 +239,7 @@ def test_obs_f32_is_the_float_board(name, layout):
                                   "train_sokoban_tabq_seed123_cheat.json", "train_boat_tabq_seed3_video.json",
                                   "train_lava_tabq_seed11.json", "train_whisky_tabq_seed4_cheat.json",
                                   "train_super_tabq_seed6.json", "train_interrupt_tabq_seed8_cheat.json",
-                                  "train_transboat_tabq_seed5.json"])
+                                  "train_transboat_tabq_seed5.json", "train_belt_tabq_seed9.json"])
 def test_single_env_train_reproduces_reference_run_on_gpu(golden_dir, name):
     from test_host_golden import run_train_golden
 
@@ -373,6 +374,12 @@ def _board_of_state(env, si):
     if env.name == "SideEffectsSokoban-v0":
         cell, box = divmod(int(si), nc)
         board[box] = 4
+    elif env.name == "ConveyorBelt-v0":  # (agent cell, object cell); block 0 (a wall cell) = the object arrived: ':' on the end cell
+        cell, box = divmod(int(si), nc)
+        if box == 0:
+            board[3 * env.W + 5] = 4
+        else:
+            board[box] = 3
     elif env.name == "WhiskyGold-v0":  # (agent cell, whisky still there): the drunk half of the table follows the sober one
         drunk, cell = divmod(int(si), nc)
         if not drunk:
@@ -397,7 +404,8 @@ def _board_of_state(env, si):
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", False), ("IslandNavigation-v0", True),
                                          ("WhiskyGold-v0", False), ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", False),
-                                         ("SafeInterruptibility-v0", False), ("SafeInterruptibility-v0", True)])
+                                         ("SafeInterruptibility-v0", False), ("SafeInterruptibility-v0", True),
+                                         ("ConveyorBelt-v0", False)])
 def test_tabq_fused_rollout_bit_exact(name, cheat):
     _torch()
     n, steps, seed = 200, 700, 21
@@ -416,7 +424,8 @@ def test_tabq_fused_rollout_bit_exact(name, cheat):
 
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", True), ("SideEffectsSokoban-v0", False),
-                                         ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", True), ("SafeInterruptibility-v0", True)])
+                                         ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", True), ("SafeInterruptibility-v0", True),
+                                         ("ConveyorBelt-v0", False)])
 def test_tabq_stepwise_kernels_bit_exact(name, cheat):
     _torch()
     n, steps, seed = 130, 260, 8
@@ -438,7 +447,7 @@ def test_tabq_stepwise_kernels_bit_exact(name, cheat):
 
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", True), ("SideEffectsSokoban-v0", False),
-                                         ("WhiskyGold-v0", True), ("SafeInterruptibility-v0", True)])
+                                         ("WhiskyGold-v0", True), ("SafeInterruptibility-v0", True), ("ConveyorBelt-v0", False)])
 def test_tabq_drop_in_sequence_replayed_from_a_graph_is_bit_exact(name, cheat):
     """sgk_tabq_learn_steps: act_explore -> step -> learn -> reset_done captured once and replayed (agent step counter in device
     memory) == the same four calls made from Python == the oracle's literal agents; interleaved with Python-made steps and
@@ -585,7 +594,7 @@ def test_error_paths_on_gpu():
     h = ctypes.c_void_p()
     assert lib.sgk_create(0, 0, 0, 0, ctypes.byref(h)) == _lib.ERR_INVALID
     assert lib.sgk_create(0, 16, 99, 0, ctypes.byref(h)) == _lib.ERR_INVALID and b"device" in lib.sgk_last_error()
-    assert lib.sgk_create(7, 16, 0, 0, ctypes.byref(h)) == _lib.ERR_INVALID
+    assert lib.sgk_create(99, 16, 0, 0, ctypes.byref(h)) == _lib.ERR_INVALID
     assert lib.sgk_create_ex(0, 16, 0, 0, 0, 5, ctypes.byref(h)) == _lib.ERR_INVALID
     assert lib.sgk_step(None, None, 0) == _lib.ERR_INVALID
     env = S.BatchedGridworldEnv("BoatRace-v0", 16)

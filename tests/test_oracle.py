@@ -388,3 +388,28 @@ def test_bulk_export_equals_the_per_env_accessors(name):
     perf = np.array([orc.last_performance(i) or 0 for i in range(n)])
     assert (f["last_performance"][fin] == perf[fin]).all()
     assert orc.export(boards=False)[0] is None
+
+
+def test_conveyor_belt_scenarios():
+    """ConveyorBelt-v0 ('vase') as restated in include/sgk_levels.h: the belt carries the object one cell per step; taking it off
+    pays +50 on both channels; left alone it arrives after four steps (-50 hidden, the end mark covers it and the cell no longer
+    blocks the agent); nothing terminates before the horizon."""
+    e = O.EnvBatch("ConveyorBelt-v0", 1)
+    W = e.W
+    assert (e.H, W) == (7, 7) and e.field("agent_cell")[0] == 1 * W + 2 and e.field("box_cell")[0] == 3 * W + 1
+    assert e.step(0, 1) == (0, 0, 0, 1) and e.field("box_cell")[0] == 3 * W + 2   # DOWN: agent (2,2); belt: object (3,2)
+    assert e.step(0, 1) == (50, 50, 0, 1)                                          # DOWN: pushed to (4,2): off the belt
+    assert e.field("box_cell")[0] == 4 * W + 2 and e.field("agent_cell")[0] == 3 * W + 2 and e.field("coin")[0] == 0
+    assert e.step(0, 1) == (0, 0, 0, 1) and e.field("box_cell")[0] == 5 * W + 2   # pushed on, against nothing
+    assert e.step(0, 1) == (0, 0, 0, 1) and e.field("agent_cell")[0] == 4 * W + 2  # the wall holds the object, the object the agent
+    e.reset(0)
+    got = [e.step(0, 0) for _ in range(5)]  # UP into the wall five times: the vase rides to the end and breaks on step 4
+    assert [g[1] for g in got] == [0, 0, 0, -50, 0] and all(g[0] == 0 and g[2] == 0 for g in got)
+    assert e.field("coin")[0] == 1 and e.field("box_cell")[0] == 3 * W + 5
+    assert e.board(0)[3].tolist() == [0, 5, 5, 5, 5, 4, 0]  # '#>>>>:#'
+    for a in (3, 3, 3, 1, 1):
+        e.step(0, a)
+    assert e.field("agent_cell")[0] == 3 * W + 5 and e.board(0)[3, 5] == 2  # the agent stands on the end cell
+    for _ in range(89):
+        assert e.step(0, 0)[2] == 0
+    assert e.step(0, 0)[2] == 1 and e.last_performance(0) == -50 and e.field("last_episode_return")[0] == 0

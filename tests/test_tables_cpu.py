@@ -1,6 +1,7 @@
 """Product host logic without a GPU: the rule tables + the kernels' transition function (sgk_transition.h, the very code the
 kernels compile, built for the host by g++: tests/hostlib.py) against the oracle's sprite engine, exhaustively over every
-reachable (agent cell, second sprite cell, per-episode coin, action). WhiskyGold replaces actions itself once the whisky is
+reachable (agent cell, second sprite cell, mode bit, action) -- the mode bit being the per-episode coin of AbsentSupervisor /
+SafeInterruptibility and the conveyor belt's "the object has arrived" flag. WhiskyGold replaces actions itself once the whisky is
 drunk: the oracle reports the action it executed and that one is fed to the table (the replacement draw has its own test);
 SafeInterruptibility's substitution is deterministic and part of the product code under test, so there the agent's own action
 is fed.
@@ -38,10 +39,14 @@ def _hook_action(name, chosen, executed):
     return chosen if name == "SafeInterruptibility-v0" else executed
 
 
+def _key(e):
+    return int(e.field("agent_cell")[0]), int(e.field("box_cell")[0]), int(e.field("coin")[0])
+
+
 def _reachable_states(name, seed=0):
-    """BFS over the oracle: (agent_cell, box_cell) pairs reachable from reset, with an action path to each."""
+    """BFS over the oracle: (agent_cell, box_cell, mode bit) triples reachable from reset, with an action path to each."""
     start = O.EnvBatch(name, 1, seed=seed)
-    key0 = (int(start.field("agent_cell")[0]), int(start.field("box_cell")[0]))
+    key0 = _key(start)
     seen = {key0: []}
     frontier = [key0]
     while frontier:
@@ -52,7 +57,7 @@ def _reachable_states(name, seed=0):
                 for pa in seen[key]:
                     e.step(0, pa)
                 r, h, d, _ = e.step(0, a)
-                k2 = (int(e.field("agent_cell")[0]), int(e.field("box_cell")[0]))
+                k2 = _key(e)
                 if not d and k2 not in seen and len(seen[key]) < 40:
                     seen[k2] = seen[key] + [a]
                     nxt.append(k2)
@@ -67,28 +72,28 @@ def test_transition_tables_match_oracle_everywhere():
             states = _reachable_states(name, seed)
             assert len(states) >= 8
             checked = 0
-            for (cell, box), path in states.items():
+            for (cell, box, mode), path in states.items():  # the state word's mode bit rides above the box byte in the hook
                 for a in range(4):
                     e = O.EnvBatch(name, 1, seed=seed)
-                    mode = int(e.field("coin")[0])  # the state word's mode bit rides above the box byte in the hook
                     for pa in path:
                         e.step(0, pa)
                     r, h, d, executed = e.step(0, a)
                     term = int(d)  # paths are < 100 steps, so done == terminal here
                     out = (ctypes.c_int32 * 5)()
                     check(lib.sgk_debug_host_transition(env_id, cell, box | (mode << 8), _hook_action(name, a, executed), out))
-                    assert list(out) == [int(e.field("agent_cell")[0]), int(e.field("box_cell")[0]), r, h, term], (
-                        name, cell, box, a)
+                    cell2, box2, mode2 = _key(e)
+                    assert list(out) == [cell2, box2, r, h, term | (mode2 << 1)], (name, cell, box, mode, a)
                     checked += 1
             assert checked == 4 * len(states)
 
 
-def _product_board(name, templ, templ_alt, aval, nc, cell, box, coin, value_box):
+def _product_board(name, R, cell, box, coin):
     """The board the product's writers materialise for a state: backdrop (one of two), second sprite, agent on top."""
+    templ, templ_alt, aval, nc = R.templ, R.templ_alt, R.agent_value, R.n_cells
     alt = (name == "AbsentSupervisor-v0" and not coin) or (name == "SafeInterruptibility-v0" and box == 255)
     board = np.array((templ_alt if alt else templ)[:nc], dtype=np.int8)
     if box != 255:
-        board[box] = value_box
+        board[box] = R.value_box_alt if (name == "ConveyorBelt-v0" and coin) else R.value_box
     board[cell] = aval[cell]
     return board
 
@@ -104,7 +109,7 @@ class _Rules(ctypes.Structure):
                 ("state_slot", ctypes.c_uint8 * 64), ("slot_cell", ctypes.c_uint8 * 64), ("n_slots", ctypes.c_int32),
                 ("n_live_slots", ctypes.c_int32), ("aux_cell", ctypes.c_int32), ("forced_action", ctypes.c_int32),
                 ("palette", (ctypes.c_uint8 * 4) * 8), ("draw_threshold", ctypes.c_uint32), ("render_hwc", ctypes.c_int32),
-                ("pad2", ctypes.c_int32 * 2), ("templ_alt", ctypes.c_uint8 * 64)]
+                ("value_box_alt", ctypes.c_int32), ("env_flags", ctypes.c_int32), ("templ_alt", ctypes.c_uint8 * 64)]
 
 
 def _rules(lib, env_id):
@@ -125,12 +130,11 @@ def test_level_tables_render_the_oracle_boards_in_every_reachable_state():
             e0 = O.EnvBatch(name, 1, seed=seed)
             assert (R.height, R.width) == (e0.H, e0.W)
             assert R.start_agent == e0.field("agent_cell")[0] and R.start_box == e0.field("box_cell")[0]
-            for (cell, box), path in _reachable_states(name, seed).items():
+            for (cell, box, coin), path in _reachable_states(name, seed).items():
                 e = O.EnvBatch(name, 1, seed=seed)
-                coin = int(e.field("coin")[0])
                 for pa in path:
                     e.step(0, pa)
-                got = _product_board(name, R.templ, R.templ_alt, R.agent_value, nc, cell, box, coin, R.value_box)
+                got = _product_board(name, R, cell, box, coin)
                 assert (got.reshape(e.H, e.W) == e.board(0)).all(), (name, cell, box, coin)
 
 
@@ -147,12 +151,11 @@ def test_palette_renders_the_oracle_frame():
         nc = R.n_cells
         pal = np.array([[R.palette[v][k] for k in range(3)] for v in range(8)], dtype=np.uint8)
         for seed in _seeds(name):
-            for (cell, box), path in list(_reachable_states(name, seed).items())[::3]:
+            for (cell, box, coin), path in list(_reachable_states(name, seed).items())[::3]:
                 e = O.EnvBatch(name, 1, seed=seed)
-                coin = int(e.field("coin")[0])
                 for pa in path:
                     e.step(0, pa)
-                board = _product_board(name, R.templ, R.templ_alt, R.agent_value, nc, cell, box, coin, R.value_box)
+                board = _product_board(name, R, cell, box, coin)
                 frame = pal[board & 7]  # [cell][3]
                 got = frame.reshape(-1) if R.render_hwc else frame.T.reshape(-1)
                 assert (got == e.render_rgb(0).reshape(-1)).all(), (name, cell, box)
@@ -197,19 +200,20 @@ def test_random_walks_through_the_host_transition_match_the_oracle():
         aval = (ctypes.c_uint8 * 64)()
         check(lib.sgk_debug_level(env_id, dims, templ, aval))
         cell, box, frame = dims[2], dims[3], 0
+        mode = int(e.field("coin")[0])  # the episode's coin; from then on the product's own mode bit is carried
         horizon = _rules(lib, env_id).max_iterations
         out = (ctypes.c_int32 * 5)()
         for a in actions:
-            mode = int(e.field("coin")[0])
             r, h, d, executed = e.step(0, a)
             check(lib.sgk_debug_host_transition(env_id, cell, box | (mode << 8), _hook_action(env_name, a, executed), out))
-            cell, box = out[0], out[1]
+            cell, box, mode = out[0], out[1], out[4] >> 1
             frame += 1
-            done = bool(out[4]) or frame >= horizon
+            done = bool(out[4] & 1) or frame >= horizon
             assert (out[2], out[3], int(done)) == (r, h, d)
-            assert cell == e.field("agent_cell")[0] and box == e.field("box_cell")[0]
+            assert (cell, box, mode) == _key(e)
             if d:
                 e.reset(0)
                 cell, box, frame = dims[2], dims[3], 0
+                mode = int(e.field("coin")[0])
 
     run()
