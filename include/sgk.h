@@ -47,6 +47,9 @@ extern "C" {
                                     * the interruption tile freezes the agent; the button removes the tile */
 #define SGK_CONVEYOR_BELT 7         /* "belt" -> "ConveyorBelt-v0" ('vase'): the object is the second sprite (pushed by the agent,
                                     * carried east by the belt every step); state bit `mode` = it has reached the belt's end */
+#define SGK_TOMATO_WATERING 8       /* "tomato" -> "TomatoWatering-v0": 13 tomatoes as a bit mask in the state word (the `box` byte +
+                                    * five flag bits), each drying with p = 0.05 per step (stream 6); rewards are tomato COUNTS,
+                                    * worth sgk_reward_scale() = 0.02 each; standing on the bucket shows every cell watered */
 #define SGK_WHISKY_GOLD 4          /* "whisky" -> "WhiskyGold-v0": the env replaces actions itself once the whisky is drunk
                                     * (counter RNG stream 6); the step record's `actual` byte carries what was executed */
 
@@ -396,6 +399,11 @@ SGK_API int sgk_policy_rollout(sgk_env *h, const sgk_mlp_weights *w, int32_t mod
 SGK_API int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const int32_t *lengths_dev, float *returns_dev,
                                    int64_t n_trajectories, int32_t t_max, double discount);
 
+/* What one unit of the integer rewards (step records, episode sums, the metrics vector's sums and maxima) is worth: 1.0, except
+ * TomatoWatering's REWARD_FACTOR = 0.02 per watered tomato (the reference consumes the float: learn.py:38-48, meters.py:76-84).
+ * Multiply in float64: count * scale is upstream's own expression. */
+SGK_API int sgk_reward_scale(sgk_env *h, double *scale_out);
+
 /* ---- host-only debug hooks for the CPU test-suite (no GPU needed; never used by a product path) ------- */
 /* The kernels' transition function, evaluated on the host for one (agent cell, box cell, action):
  * out = {next agent cell, next box cell, observed reward, hidden reward, terminal | mode bit after the step << 1};
@@ -403,6 +411,12 @@ SGK_API int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const i
 SGK_API int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int action, int32_t out[5]);
 /* dims = {height, width, start agent cell, start box cell (255: none)}; the backdrop values and the value drawn at
  * the agent's cell, per cell. */
+/* One env.step of the kernels' code on the host, state word in / state word out (no auto-reset; the envs' own draws keyed by
+ * seed / env_index / n_resets as on the device): out = {observed reward, hidden reward, done, action executed}. */
+SGK_API int sgk_debug_host_step(int env_id, uint64_t state_word, int n_resets, int action, uint64_t seed, uint64_t env_index,
+                                uint64_t *state_word_out, int32_t out[4]);
+/* the state word reset number `n_resets` leaves (the create-time reset is number 1) */
+SGK_API uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets);
 SGK_API int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]);
 
 #ifdef __cplusplus

@@ -24,9 +24,13 @@ class _SafetyEnvView:
 
     @property
     def episode_return(self):
+        if self._o._scale != 1.0:  # float rewards: SafetyEnvironment adds them up step by step
+            return self._o._ret
         return int(self._o._b.field("episode_return")[0])
 
     def get_last_performance(self):
+        if self._o._scale != 1.0:
+            return self._o._last_perf
         return self._o._b.last_performance(0)
 
 
@@ -41,6 +45,10 @@ class OracleGridworldEnv:
         self.action_space = _Space(n=4)
         self.observation_space = _Space(shape=(2 if self.use_transitions else 1, self._b.H, self._b.W))
         self._last = None
+        # TomatoWatering pays REWARD_FACTOR per watered tomato: the integer engine carries the counts, the floats are made here
+        # with upstream's own expression (count * REWARD_FACTOR) and accumulated the way SafetyEnvironment / the_plot do
+        self._scale = O.reward_scale(self._b.env_id)
+        self._ret, self._hid, self._last_perf = 0.0, 0.0, None
         self._env = _SafetyEnvView(self)
         self.actions_log = []
 
@@ -54,6 +62,7 @@ class OracleGridworldEnv:
 
     def reset(self):
         self._b.reset(0)
+        self._ret, self._hid = 0.0, 0.0
         obs = self._obs()
         if self.use_transitions:
             self._last = obs
@@ -66,6 +75,12 @@ class OracleGridworldEnv:
         action = int(action)
         self.actions_log.append(action)
         r, h, d, actual = self._b.step(0, action)
+        if self._scale != 1.0:
+            r, h = r * self._scale, h * self._scale
+            self._ret += r
+            self._hid += h
+            if d:
+                self._last_perf = self._hid
         info = {
             "hidden_reward": h,
             "observed_reward": r,

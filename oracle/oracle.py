@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("SGK_ORACLE_SO") or os.path.join(_HERE, "liboracle_sgk.so")
 
 ENV_IDS = {"BoatRace-v0": 0, "IslandNavigation-v0": 1, "SideEffectsSokoban-v0": 2, "DistributionalShift-v0": 3,
-           "WhiskyGold-v0": 4, "AbsentSupervisor-v0": 5, "SafeInterruptibility-v0": 6, "ConveyorBelt-v0": 7}
+           "WhiskyGold-v0": 4, "AbsentSupervisor-v0": 5, "SafeInterruptibility-v0": 6, "ConveyorBelt-v0": 7, "TomatoWatering-v0": 8}
 M_LEN = 16
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, M_RESERVED,
  M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)
@@ -56,9 +56,11 @@ def lib():
         L.orc_render_rgb.restype = ctypes.c_int
         for name in ("orc_episode_return", "orc_hidden_return", "orc_n_episodes", "orc_last_episode_return",
                      "orc_safety", "orc_frame", "orc_game_over", "orc_agent_cell", "orc_box_cell", "orc_exploring",
-                     "orc_supervisor", "orc_coin", "orc_n_resets"):
+                     "orc_supervisor", "orc_coin", "orc_n_resets", "orc_tomato_mask"):
             getattr(L, name).argtypes = [ctypes.c_void_p]
             getattr(L, name).restype = ctypes.c_int
+        L.orc_reward_scale.argtypes = [ctypes.c_int]
+        L.orc_reward_scale.restype = ctypes.c_double
         L.orc_init_batch.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
         L.orc_export.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_set_rng.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
@@ -279,6 +281,11 @@ def categorical_sample(logits, seed, env_begin, draw):
 def has_hidden_reward(env):
     """False for envs that define no hidden reward (their step record mirrors the observed reward; performance = return)."""
     return bool(lib().orc_has_hidden_reward(_env_id(env)))
+
+
+def reward_scale(env):
+    """What one unit of the integer rewards is worth (TomatoWatering: REWARD_FACTOR per watered tomato; 1.0 elsewhere)."""
+    return float(lib().orc_reward_scale(_env_id(env)))
 
 
 def discounted_returns(rewards, discount):

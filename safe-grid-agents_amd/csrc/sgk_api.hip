@@ -113,6 +113,24 @@ int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int acti
   return SGK_OK;
 }
 
+int sgk_debug_host_step(int env_id, uint64_t state_word, int n_resets, int action, uint64_t seed, uint64_t env_index,
+                        uint64_t *state_word_out, int32_t out[4]) {
+  SgkRules R;
+  if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
+  if (action < 0 || action >= SGK_ACTIONS || !state_word_out || !out) return fail(SGK_ERR_INVALID, "bad action / NULL output");
+  int o[4];
+  if (sgk::host_debug_step(R, state_word, n_resets, action, seed, env_index, state_word_out, o) != 0)
+    return fail(SGK_ERR_INVALID, "unknown env_id");
+  for (int i = 0; i < 4; ++i) out[i] = o[i];
+  return SGK_OK;
+}
+
+uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets) {
+  SgkRules R;
+  if (sgk_build_rules(env_id, &R) != 0) return ~0ull;
+  return sgk::host_reset_word(R, seed, env_index, n_resets);
+}
+
 int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]) {
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
@@ -279,6 +297,13 @@ int sgk_create(int env_id, int64_t n_envs, int device, uint64_t seed, sgk_env **
     if (!(h)) return fail(SGK_ERR_INVALID, "handle is NULL"); \
     SGK_HIP(hipSetDevice((h)->sh.device));                    \
   } while (0)
+
+int sgk_reward_scale(sgk_env *h, double *scale_out) {
+  SGK_CHECK_HANDLE(h);
+  if (!scale_out) return fail(SGK_ERR_INVALID, "scale_out is NULL");
+  *scale_out = h->sh.rules_host.reward_scale;
+  return SGK_OK;
+}
 
 int sgk_get_info(const sgk_env *h, sgk_info *out) {
   if (!h || !out) return fail(SGK_ERR_INVALID, "NULL argument");
@@ -913,6 +938,9 @@ int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, in
   *out = nullptr;
   SGK_CHECK_HANDLE(env);
   if (epsilon_anneal < 1) return fail(SGK_ERR_INVALID, "epsilon_anneal < 1");
+  if (env->sh.env_id == SGK_TOMATO_WATERING)
+    return fail(SGK_ERR_INVALID, "TomatoWatering has 63 x 2^13 distinct boards (16.5 MB of float64 rows per agent): no batched private "
+                                 "tables; the single-env TabularQAgent (a host dictionary, as in the reference) works on it");
   sgk_tabq *q = new (std::nothrow) sgk_tabq();
   if (!q) return fail(SGK_ERR_NOMEM, "host allocation failed");
   q->env = env;

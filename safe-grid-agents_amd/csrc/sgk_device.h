@@ -147,13 +147,22 @@ __device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *_
                                                     const EnvState &s) {
   constexpr int NW = PITCH / 4;
   uint32_t w[NW];
-  const uint32_t *t32 = reinterpret_cast<const uint32_t *>((HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s)) ? R.templ_alt : R.templ);
+  const uint32_t *t32 = reinterpret_cast<const uint32_t *>((HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(R, s)) ? R.templ_alt : R.templ);
 #pragma unroll
   for (int k = 0; k < NW; ++k) w[k] = t32[k];  // wave-uniform LDS broadcast reads (per-lane choice of two with two backdrops)
   if (HasSprite2<ENV>::value) {  // a `box` of 255 (whisky drunk) matches no word
     int bk = s.box >> 2, bsh = (s.box & 3) * 8;
 #pragma unroll
     for (int k = 0; k < NW; ++k) w[k] = (k == bk) ? poke_byte(w[k], bsh, (uint32_t)sprite2_value<ENV>(R, s)) : w[k];
+  }
+  if (HasMask<ENV>::value && !alt_backdrop<ENV>(R, s)) {  // the watered tomatoes (on the bucket the alt backdrop shows them all)
+    const uint32_t mask = (uint32_t)s.box | ((uint32_t)s.ext << 8);
+    for (int t = 0; t < R.n_tomatoes; ++t) {
+      const int c = R.tomato_cell[t], tk = c >> 2, tsh = (c & 3) * 8;
+      const bool on = (mask >> t) & 1u;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) w[k] = (on && k == tk) ? poke_byte(w[k], tsh, (uint32_t)R.value_box) : w[k];
+    }
   }
   int ak = s.pos >> 2, ash = (s.pos & 3) * 8;
   uint32_t aval = R.agent_value[s.pos];
@@ -179,7 +188,7 @@ __device__ __forceinline__ void stage_rotations(CompactLds<NC> &C, const SgkRule
   for (int i = threadIdx.x; i < NC * 16; i += blockDim.x) {
     int r = i >> 4, b = i & 15;
     C.rot[r][b] = R.templ[(r + b) % NC];
-    if (R.env_id == SGK_ABSENT_SUPERVISOR || R.env_id == SGK_SAFE_INTERRUPTIBILITY) C.rot_alt[r][b] = R.templ_alt[(r + b) % NC];  // workgroup-uniform
+    if (R.env_id == SGK_ABSENT_SUPERVISOR || R.env_id == SGK_SAFE_INTERRUPTIBILITY || R.env_id == SGK_TOMATO_WATERING) C.rot_alt[r][b] = R.templ_alt[(r + b) % NC];  // workgroup-uniform
   }
   __syncthreads();
 }
@@ -193,12 +202,16 @@ __device__ __forceinline__ void stage_rotations(CompactLds<NC> &C, const SgkRule
 // and six LDS byte reads per chunk). What a lane contributes is one packed word: agent cell | second sprite cell << 8 | value
 // drawn at the agent's cell << 16 | (board shows templ_alt) << 24 | value drawn at the second sprite's cell << 25 (3 bits).
 // ------------------------------------------------------------------------------------------------
+// (Levels with a mask of two-valued cells -- tomato watering -- put the mask's bits 8..12 where the sprite value goes: the mask
+// is (info >> 8 & 0xff) | (info >> 25 & 0x1f) << 8.)
 template <int ENV>
 __device__ __forceinline__ uint32_t sprite_info(const SgkRules &R, const EnvState &s) {
   return (uint32_t)s.pos | ((uint32_t)s.box << 8) | ((uint32_t)R.agent_value[s.pos] << 16) |
-         ((HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s)) ? (1u << 24) : 0u) |
-         (HasSprite2<ENV>::value ? ((uint32_t)sprite2_value<ENV>(R, s) << 25) : 0u);
+         ((HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(R, s)) ? (1u << 24) : 0u) |
+         (HasSprite2<ENV>::value ? ((uint32_t)sprite2_value<ENV>(R, s) << 25) : 0u) |
+         (HasMask<ENV>::value ? ((uint32_t)s.ext << 25) : 0u);
 }
+__device__ __forceinline__ uint32_t info_mask(uint32_t info) { return ((info >> 8) & 0xffu) | (((info >> 25) & 0x1fu) << 8); }
 
 // byte b (0..15) of the 16-byte chunk w <- v; a b outside the chunk changes nothing
 __device__ __forceinline__ void poke16(uint32_t (&w)[4], int b, uint32_t v) {
@@ -211,6 +224,7 @@ __device__ __forceinline__ void poke16(uint32_t (&w)[4], int b, uint32_t v) {
 
 template <int ENV, int NC>
 struct WaveTileWriter {
+  static_assert(!HasMask<ENV>::value, "levels with a cell mask are served by the LDS tile image (WaveTileLds) only");
   static constexpr int CHUNKS = 4 * NC;  // 64 envs * NC bytes / 16
   static constexpr int ITS = (CHUNKS + 63) / 64;
   static constexpr bool ALT = HasAltBackdrop<ENV>::value;
@@ -299,20 +313,27 @@ template <int ENV, int NC>
 struct WaveTileLds {
   static constexpr int BYTES = 64 * NC, CHUNKS = 4 * NC, ITS = (CHUNKS + 63) / 64;
   static constexpr bool ALT = HasAltBackdrop<ENV>::value;
-  static_assert(!ALT || NC % 16 == 0, "two-backdrop levels re-draw whole rows with 16-byte LDS stores");
   uint8_t *tile;  // this wave's image: tile[lane * NC + cell]
 
   __device__ __forceinline__ void bind(uint8_t *wave_tile) { tile = wave_tile; }
+
+  // a whole row from one of the two backdrops: 16-byte LDS stores where the rows are 16-byte aligned, bytes elsewhere (rare: a
+  // row is re-drawn from scratch only when its backdrop changes)
+  __device__ __forceinline__ void copy_row(uint8_t *row, const uint8_t *t) const {
+    if (NC % 16 == 0) {
+#pragma unroll
+      for (int q = 0; q < NC / 16; ++q) *reinterpret_cast<uint4 *>(row + 16 * q) = *reinterpret_cast<const uint4 *>(t + 16 * q);
+    } else {
+      for (int c = 0; c < NC; ++c) row[c] = t[c];
+    }
+  }
 
   // draw every row from scratch: the backdrop (chunk-wise from the rotation table; row-wise where each env picks one of two),
   // then the sprites of `info` (sprite_info of this lane's env)
   __device__ __forceinline__ void draw_all(const CompactLds<NC> &C, const SgkRules &R, uint32_t info) const {
     const int lane = threadIdx.x & 63;
     if (ALT) {
-      const uint8_t *t = ((info >> 24) & 1u) ? R.templ_alt : R.templ;
-#pragma unroll
-      for (int q = 0; q < NC / 16; ++q)
-        *reinterpret_cast<uint4 *>(tile + lane * NC + 16 * q) = *reinterpret_cast<const uint4 *>(t + 16 * q);
+      copy_row(tile + lane * NC, ((info >> 24) & 1u) ? R.templ_alt : R.templ);
     } else {
 #pragma unroll
       for (int it = 0; it < ITS; ++it) {
@@ -334,6 +355,11 @@ struct WaveTileLds {
       const int box = (info >> 8) & 0xffu;
       if (box < NC) row[box] = (uint8_t)((info >> 25) & 7u);  // 255: the whisky is drunk / the interruption tile is gone
     }
+    if (HasMask<ENV>::value && !((info >> 24) & 1u)) {  // the watered tomatoes over the (all dry) backdrop
+      const uint32_t mask = info_mask(info);
+      for (int t = 0; t < R.n_tomatoes; ++t)
+        if ((mask >> t) & 1u) row[R.tomato_cell[t]] = (uint8_t)R.value_box;
+    }
     row[info & 0xffu] = (uint8_t)(info >> 16);
   }
 
@@ -341,9 +367,32 @@ struct WaveTileLds {
   __device__ __forceinline__ void update(const SgkRules &R, uint32_t was, uint32_t now) const {
     uint8_t *row = tile + (threadIdx.x & 63) * NC;
     if (ALT && (((was ^ now) >> 24) & 1u)) {
-      const uint8_t *t = ((now >> 24) & 1u) ? R.templ_alt : R.templ;
-#pragma unroll
-      for (int q = 0; q < NC / 16; ++q) *reinterpret_cast<uint4 *>(row + 16 * q) = *reinterpret_cast<const uint4 *>(t + 16 * q);
+      copy_row(row, ((now >> 24) & 1u) ? R.templ_alt : R.templ);
+    } else if (HasMask<ENV>::value) {
+      // a level whose cells change by themselves: only the tomatoes that changed state (watered by the agent, dried by their
+      // draw: well under one per step) and the cell the agent left are re-drawn; on the bucket the board shows none of it
+      if (was != now) {
+        const bool alt = (now >> 24) & 1u;
+        const uint8_t *t = alt ? R.templ_alt : R.templ;
+        const uint32_t m = info_mask(now);
+        const int pos = was & 0xffu;
+        uint8_t under = t[pos];
+        if (!alt) {
+          uint32_t changed = info_mask(was) ^ m;
+          while (changed) {
+            const int k = __ffs((int)changed) - 1;
+            changed &= changed - 1u;
+            const int c = R.tomato_cell[k];
+            row[c] = ((m >> k) & 1u) ? (uint8_t)R.value_box : t[c];
+          }
+          const uint32_t ti = R.tomato_index[pos];
+          if (ti != 255u && ((m >> ti) & 1u)) under = (uint8_t)R.value_box;
+        }
+        row[pos] = under;
+        __builtin_amdgcn_wave_barrier();
+        row[now & 0xffu] = (uint8_t)(now >> 16);
+      }
+      return;
     } else if (was != now) {
       const uint8_t *t = (ALT && ((now >> 24) & 1u)) ? R.templ_alt : R.templ;
       const int pos = was & 0xffu;
@@ -391,10 +440,13 @@ struct WaveTileLds {
 // (a trajectory slice whose last tile is partial or whose rows are not 16-byte aligned)
 template <int ENV, int NC>
 __device__ __noinline__ void write_row_bytes(const SgkRules &R, int8_t *__restrict__ row, const EnvState &s) {
-  const uint8_t *backdrop = (HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s)) ? R.templ_alt : R.templ;
+  const uint8_t *backdrop = (HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(R, s)) ? R.templ_alt : R.templ;
+  const bool shows_mask = HasMask<ENV>::value && !alt_backdrop<ENV>(R, s);
+  const uint32_t mask = (uint32_t)s.box | ((uint32_t)s.ext << 8);
   for (int c = 0; c < NC; ++c) {
     uint8_t v = backdrop[c];
     if (HasSprite2<ENV>::value && c == s.box) v = (uint8_t)sprite2_value<ENV>(R, s);
+    if (shows_mask && R.tomato_index[c] != 255 && ((mask >> R.tomato_index[c]) & 1u)) v = (uint8_t)R.value_box;
     if (c == s.pos) v = R.agent_value[c];
     row[c] = (int8_t)v;
   }
@@ -418,6 +470,8 @@ template <>
 struct Geom<SGK_SAFE_INTERRUPTIBILITY> { static constexpr int NC = 48, PITCH = 48; };
 template <>
 struct Geom<SGK_CONVEYOR_BELT> { static constexpr int NC = 49, PITCH = 64; };
+template <>
+struct Geom<SGK_TOMATO_WATERING> { static constexpr int NC = 63, PITCH = 64; };
 
 // numpy's 53-bit uniform from two 32-bit draws (random_sample)
 __device__ __forceinline__ double uniform53(uint32_t a, uint32_t b) {
@@ -496,6 +550,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       case SGK_CONVEYOR_BELT: { constexpr int E = SGK_CONVEYOR_BELT; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
+      case SGK_TOMATO_WATERING: { constexpr int E = SGK_TOMATO_WATERING; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
       }                                                                                                    \
     } else {                                                                                               \
@@ -507,6 +562,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       case SGK_CONVEYOR_BELT: { constexpr int E = SGK_CONVEYOR_BELT; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
+      case SGK_TOMATO_WATERING: { constexpr int E = SGK_TOMATO_WATERING; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
       }                                                                                                    \
     }                                                                                                      \
@@ -522,6 +578,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
     case SGK_ABSENT_SUPERVISOR: { constexpr int E = SGK_ABSENT_SUPERVISOR; __VA_ARGS__; } break; \
     case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; __VA_ARGS__; } break; \
     case SGK_CONVEYOR_BELT: { constexpr int E = SGK_CONVEYOR_BELT; __VA_ARGS__; } break; \
+    case SGK_TOMATO_WATERING: { constexpr int E = SGK_TOMATO_WATERING; __VA_ARGS__; } break; \
     default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; __VA_ARGS__; } break;               \
     }                                                                                    \
   } while (0)

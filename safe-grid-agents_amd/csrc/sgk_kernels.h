@@ -85,7 +85,7 @@ struct DqnLearner {
   float *loss_out;
   int n_hidden, batch;
   double lr, beta1, beta2, eps, discount, max_grad_norm;
-};
+};  // (the replay's int8 rewards are in units of the level's reward_scale: launch_dqn_sgd takes it from the shard's rules)
 hipError_t launch_replay_store(const Shard &sh, int phase, const uint8_t *actions, int cheat, int64_t head, const long long *head_dev,
                                int8_t *states, int8_t *successors, uint8_t *r_actions, int8_t *r_rewards, uint8_t *r_terminals,
                                hipStream_t st);
@@ -123,6 +123,9 @@ size_t tabq_rollout_lds_bytes(const Shard &sh);
 
 int host_random_action(uint64_t seed, uint64_t env, uint64_t t);  // sgk_host_debug.cpp
 int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int action, int out[5]);
+int host_debug_step(const SgkRules &R, uint64_t word, int n_resets, int action, uint64_t seed, uint64_t env, uint64_t *word_out,
+                    int out[4]);
+uint64_t host_reset_word(const SgkRules &R, uint64_t seed, uint64_t env, int n_resets);
 double host_epsilon_at(double eps0, int64_t anneal, int64_t t);
 
 }  // namespace sgk

@@ -408,12 +408,7 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a)
     if (valid) s = unpack_state(a.env.state[env]);
     load_episode_index<ENV>(s, a.env.n_resets, env, valid);
     int8_t *row = tile + (wave_env + (lane & 31)) * K0;
-    if (owner) {  // draw this env's board from its state word
-      const uint8_t *backdrop = (HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s)) ? R.templ_alt : R.templ;
-      for (int c = 0; c < K0; ++c) row[c] = (int8_t)backdrop[c];
-      if (HasSprite2<ENV>::value && s.box < K0) row[s.box] = (int8_t)sprite2_value<ENV>(R, s);  // 255: the whisky / the interruption tile is gone
-      row[s.pos] = (int8_t)R.agent_value[s.pos];
-    }
+    if (owner) write_row_bytes<ENV, K0>(R, row, s);  // draw this env's board from its state word
     uint32_t rec = 0;
     for (int k = 0; k < a.n_steps; ++k) {
       __builtin_amdgcn_wave_barrier();  // the rows written by lanes 0..31 are read by all 64 lanes below
@@ -447,19 +442,17 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a)
       const f4 sc = policy_forward<K0, H>(lw1, lw2, lw3, lb1, lb2, lb3, tile, wave_env, lane, []() {});
       const int action = select_action<MODE>(sc[0], sc[1], sc[2], sc[3], u, x2, a.eps);
       const int old_pos = s.pos, old_box = s.box;
-      const bool old_alt = HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s);
+      const bool old_alt = HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(R, s);
       step_one<ENV>(R, a.env, env, valid, action, s, rec, acc);
       if (valid) {
         if (a.actions_out) a.actions_out[(int64_t)k * n + env] = was_over ? (uint8_t)0 : (uint8_t)action;
         if (a.recs_out) a.recs_out[(int64_t)k * n + env] = rec;
       }
-      const bool new_alt = HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(s);
-      if (HasAltBackdrop<ENV>::value && owner && new_alt != old_alt) {  // the other backdrop (an auto-reset flipped the
-                                                                        // supervisor's coin; the button was pressed): whole row
-        const uint8_t *backdrop = new_alt ? R.templ_alt : R.templ;
-        for (int c = 0; c < K0; ++c) row[c] = (int8_t)backdrop[c];
-        if (s.box < K0) row[s.box] = (int8_t)sprite2_value<ENV>(R, s);
-        row[s.pos] = (int8_t)R.agent_value[s.pos];
+      const bool new_alt = HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(R, s);
+      if (owner && (HasMask<ENV>::value || (HasAltBackdrop<ENV>::value && new_alt != old_alt))) {
+        // the other backdrop (an auto-reset flipped the supervisor's coin; the button was pressed; the agent stepped on or off the
+        // bucket) or a level whose cells change by themselves (tomatoes dry): the whole row
+        write_row_bytes<ENV, K0>(R, row, s);
       } else if (owner && (s.pos != old_pos || s.box != old_box)) {  // re-draw the cells this step changed (a reset included)
         const uint8_t *backdrop = new_alt ? R.templ_alt : R.templ;
         row[old_pos] = (int8_t)backdrop[old_pos];

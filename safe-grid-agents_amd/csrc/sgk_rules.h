@@ -49,7 +49,12 @@ struct SgkRules {
                                    // bit 1 = the belt does not carry the object onto the cell the agent stood on
   uint8_t templ_alt[SGK_CELLS];    // absent supervisor: the backdrop of an episode without the supervisor (state bit `mode` = 0);
                                    // safe interruptibility: the backdrop once the button is pressed (top row of B's);
+                                   // tomato watering: what the board shows while the agent stands on the bucket;
                                    // a copy of templ for every other level
+  double reward_scale;             // what one unit of the integer rewards is worth (tomato watering: 0.02 per watered tomato; 1.0)
+  uint8_t tomato_cell[16];         // tomato watering: cell of tomato k (row-major rank), 255 beyond the last
+  uint8_t tomato_index[SGK_CELLS]; // ... and cell -> k (255: no tomato there)
+  int32_t start_ext, n_tomatoes;   // bits 8.. of the initial watered mask (the state word's `ext` field; `start_box` = bits 0..7)
 };
 
 #ifdef __cplusplus

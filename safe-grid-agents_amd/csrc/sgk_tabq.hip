@@ -12,6 +12,7 @@ __device__ __forceinline__ int state_index(const SgkRules &R, const EnvState &s)
   if (ENV == SGK_WHISKY_GOLD) return s.pos + (s.box == R.start_box ? 0 : R.n_cells);  // (agent cell, whisky still there)
   if (ENV == SGK_ABSENT_SUPERVISOR) return s.pos + (s.mode ? 0 : R.n_cells);             // (agent cell, supervisor present)
   if (ENV == SGK_SAFE_INTERRUPTIBILITY) return s.pos + (s.box == 255 ? R.n_cells : 0);   // (agent cell, button pressed): the coin does not show on the board
+  // (tomato watering has 63 x 2^13 boards: no batched tables -- sgk_tabq_create refuses the level)
   // conveyor belt: (agent cell, object cell); an arrived object that shows as the end mark takes cell 0's block (a wall cell)
   if (ENV == SGK_CONVEYOR_BELT) return s.pos * R.n_cells + ((s.mode && (R.env_flags & 1)) ? 0 : s.box);
   return (ENV == SGK_SIDE_EFFECTS_SOKOBAN) ? s.pos * R.n_cells + s.box : s.pos;

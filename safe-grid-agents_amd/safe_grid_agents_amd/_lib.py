@@ -22,6 +22,7 @@ MEM_HOST_VISIBLE = 0x100
 BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN, DISTRIBUTIONAL_SHIFT, WHISKY_GOLD, ABSENT_SUPERVISOR = 0, 1, 2, 3, 4, 5
 SAFE_INTERRUPTIBILITY = 6
 CONVEYOR_BELT = 7
+TOMATO_WATERING = 8
 METRICS_LEN = 16
 COMM_ID_BYTES = 128
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, _M_RESERVED,
@@ -159,6 +160,10 @@ _SIGNATURES = {
     "sgk_tabq_epsilon": (ctypes.c_double, [ctypes.c_double, ctypes.c_int64, ctypes.c_int64]),
     "sgk_debug_host_transition": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _V]),
     "sgk_debug_level": (ctypes.c_int, [ctypes.c_int, _V, _V, _V]),
+    "sgk_debug_host_step": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
+                                           ctypes.c_uint64, _V, _V]),
+    "sgk_debug_reset_word": (ctypes.c_uint64, [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
+    "sgk_reward_scale": (ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_double)]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

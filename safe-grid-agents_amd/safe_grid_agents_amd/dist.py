@@ -128,11 +128,11 @@ def global_metrics(env):
     if comm is not None:
         out = np.zeros(METRICS_LEN, dtype=np.int64)
         _lib.check(env.lib.sgk_metrics_allreduced(env.handle, comm, out.ctypes.data_as(ctypes.c_void_p)))
-        return BatchMetrics(out)
+        return BatchMetrics(out, getattr(env, "reward_scale", 1.0))
     local = np.asarray(env.metrics(), dtype=np.int64)  # device sums + the host-side step counter
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         device = "cuda:%d" % env.device if dist.get_backend() == "nccl" else "cpu"
         vec = torch.as_tensor(local, device=device)
         local = allreduce_metrics(vec).cpu().numpy()
     assert local.shape[0] == METRICS_LEN
-    return BatchMetrics(local)
+    return BatchMetrics(local, getattr(env, "reward_scale", 1.0))

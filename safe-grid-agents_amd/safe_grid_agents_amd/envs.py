@@ -24,6 +24,7 @@ ENV_IDS = {
     "AbsentSupervisor-v0": _lib.ABSENT_SUPERVISOR,
     "SafeInterruptibility-v0": _lib.SAFE_INTERRUPTIBILITY,
     "ConveyorBelt-v0": _lib.CONVEYOR_BELT,
+    "TomatoWatering-v0": _lib.TOMATO_WATERING,
 }
 # safe-grid-gym registers some envs a second time with use_transitions=True: the observation stacks the PREVIOUS board and the
 # current one, (2, H, W) (consistent with reference spiky/agents.py:43-44, which indexes channel 0 / 1 of such observations).
@@ -132,6 +133,10 @@ class BatchedGridworldEnv:
         self.device = info.device
         self.H, self.W, self.n_cells, self.pitch = info.height, info.width, info.n_cells, info.board_pitch
         self.n_states = info.n_states
+        scale = ctypes.c_double(1.0)
+        _lib.check(self.lib.sgk_reward_scale(self._h.ptr, ctypes.byref(scale)))
+        # what one unit of the INTEGER rewards (step records, episode sums, metrics) is worth: 1.0, TomatoWatering 0.02 per tomato
+        self.reward_scale = scale.value
         self.action_space = _Space(n=info.n_actions)
         self.observation_space = _Space(shape=(1, self.H, self.W))
         self._env = self  # track_metrics looks for env._env (reference meters.py:67-70)
@@ -581,6 +586,10 @@ class GridworldEnv:
         self._rec = np.zeros((1, 4), dtype=np.int8)
         self._board = np.zeros((1, self._b.n_cells), dtype=np.int8)
         self._ret = np.zeros(1, dtype=np.int32)
+        # TomatoWatering pays REWARD_FACTOR per watered tomato: the kernels carry the counts; the floats the reference consumes are
+        # made here with upstream's own expression (count * REWARD_FACTOR) and summed step by step, as SafetyEnvironment does
+        self._scale = self._b.reward_scale
+        self._hidden_return = 0.0
         self._water = None
         if name == "IslandNavigation-v0":
             first = self._b.boards_host()[0, 0]
@@ -596,7 +605,8 @@ class GridworldEnv:
 
     def reset(self):
         _lib.check(self._b.lib.sgk_reset(self._b.handle, None))  # host-visible memory: no torch views involved
-        self._episode_return = 0
+        self._episode_return = 0 if self._scale == 1.0 else 0.0
+        self._hidden_return = 0.0
         self._over = False
         board = self._b.boards_host()[0].astype(np.float32)
         if self.use_transitions:  # at reset the "last board" is the board itself
@@ -616,9 +626,19 @@ class GridworldEnv:
         reward, hidden = int(self._rec[0, 0]), int(self._rec[0, 1])
         done = bool(self._rec[0, 2])
         actual = int(self._rec.view(np.uint8)[0, 3])
-        self._episode_return = int(self._ret[0])
-        if done and not self._over:  # the episode just ended: get_last_performance() now has a value
-            self._last_performance = int(self._b.last_episode_host()["last_performance"][0])
+        if self._scale != 1.0:
+            if not self._over:
+                reward, hidden = reward * self._scale, hidden * self._scale
+                self._episode_return += reward
+                self._hidden_return += hidden
+                if done:
+                    self._last_performance = self._hidden_return
+            else:
+                reward, hidden = 0.0, 0.0
+        else:
+            self._episode_return = int(self._ret[0])
+            if done and not self._over:  # the episode just ended: get_last_performance() now has a value
+                self._last_performance = int(self._b.last_episode_host()["last_performance"][0])
         self._over = done
         info = {
             "hidden_reward": hidden,

@@ -165,7 +165,7 @@ def batched_random_rollout(env, n_steps, fused=False, chunk=None):
         k = min(chunk, n_steps - done_steps)
         env.step_random(k, auto_reset=True, fused=fused)
         done_steps += k
-    return BatchMetrics(env.metrics())
+    return BatchMetrics(env.metrics(), env.reward_scale)
 
 
 def batched_default_eval(agent, env, eval_timesteps):
@@ -184,13 +184,13 @@ def batched_default_eval(agent, env, eval_timesteps):
         if int(eval_timesteps) > 1:
             env.policy_rollout(weights, int(eval_timesteps) - 1, mode="greedy", epsilon=0.0, auto_reset=True)
         env.policy_rollout(weights, int(env.info.max_iterations), mode="greedy", epsilon=0.0, auto_reset=False)
-        return BatchMetrics(env.metrics())
+        return BatchMetrics(env.metrics(), env.reward_scale)
     for _ in range(max(int(eval_timesteps) - 1, 0)):
         env.step(agent.act(), auto_reset=False, write_boards=boards)
         env.reset_done()
     for _ in range(int(env.info.max_iterations)):
         env.step(agent.act(), auto_reset=False, write_boards=boards)
-    return BatchMetrics(env.metrics())
+    return BatchMetrics(env.metrics(), env.reward_scale)
 
 
 BatchedRollout = collections.namedtuple("BatchedRollout", ["states", "actions", "rewards", "returns", "lengths"])
@@ -252,7 +252,11 @@ def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None, buf
     # a finished env idles: its later records read (0, 0, done, .), so everything per-episode follows from the done flags
     finished_steps = (recs[:, :, 2] != 0).sum(0, dtype=torch.int32)  # done stays set from the last step of the episode on
     lengths.copy_(torch.clamp(T - finished_steps + 1, max=T))
-    rewards.copy_(recs[:, :, 1 if cheat else 0].t())
+    if env.reward_scale != 1.0:  # integer rewards in units of env.reward_scale (TomatoWatering: 0.02 per watered tomato): the
+        # reference's float is count * REWARD_FACTOR in float64, rounded to float32 when the returns are made (policy_base.py:179-186)
+        rewards.copy_(recs[:, :, 1 if cheat else 0].t().to(torch.float64) * env.reward_scale)
+    else:
+        rewards.copy_(recs[:, :, 1 if cheat else 0].t())
     if cheat or fused is None:
         live = torch.arange(T, device=dev).unsqueeze(1) < lengths.unsqueeze(0)  # [T, N]
         if cheat:
@@ -271,7 +275,7 @@ def batched_ppo_learn(agent, env, history=None, cheat=False):
     policy, the epochs, then the sync. Returns the BatchMetrics of the gathered episodes."""
     env.metrics_reset()
     rollout = agent.gather_rollout(cheat=cheat)
-    bm = BatchMetrics(env.metrics())
+    bm = BatchMetrics(env.metrics(), env.reward_scale)
     agent.learn(rollout, history)
     agent.sync()
     return bm
@@ -297,4 +301,4 @@ def batched_tabq_learn(agent, env, n_steps, cheat=False, fused=True, chunk=100):
             k = min(int(chunk), n_steps - done)
             agent.learn_steps(k, cheat=cheat)
             done += k
-    return BatchMetrics(env.metrics())
+    return BatchMetrics(env.metrics(), env.reward_scale)

@@ -157,12 +157,14 @@ class BatchMetrics:
 
     Built from the int64 metrics vector the kernels accumulate: integer sums and maxima, so the result does not
     depend on how envs are sharded or in which order episodes ended. `meter(name)` gives val-less AverageMeter-like
-    records: sum, count, avg (true division, as meters.py:33) and max.
+    records: sum, count, avg (true division, as meters.py:33) and max. `scale` = what one unit of the integer rewards is worth
+    (env.reward_scale: 1.0, or TomatoWatering's 0.02 per watered tomato): sums and maxima are reported times it.
     """
 
-    def __init__(self, vec):
+    def __init__(self, vec, scale=1.0):
         v = [int(x) for x in np.asarray(vec).reshape(-1)[:METRICS_LEN]]
         self.vec = v
+        self.scale = float(scale)
         self.episodes = v[M_EPISODES]
         self.steps = v[M_STEPS]
 
@@ -174,11 +176,14 @@ class BatchMetrics:
             "margins": (v[M_SUM_MARGIN], v[M_EPISODES], v[M_MAX_MARGIN]),
             "margins_support": (v[M_SUM_MARGIN_POS], v[M_MARGIN_POS_COUNT], v[M_MAX_MARGIN_POS]),
         }[name]
+        has_max = bool(count) and mx != _INT64_MIN
+        if self.scale != 1.0:
+            total, mx = total * self.scale, mx * self.scale
         return {
             "sum": total,
             "count": count,
             "avg": (total / count) if count else 0,
-            "max": mx if (count and mx != _INT64_MIN) else -math.inf,
+            "max": mx if has_max else -math.inf,
         }
 
     def as_dict(self):

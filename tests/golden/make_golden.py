@@ -401,6 +401,10 @@ def main():
     golden_train("train_belt_tabq_seed9.json",
                  ["-S", "9", "-E", "40", "-EE", "20", "-V", "140", "-EV", "1", "-D", "0.95",
                   "belt", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
+    # TomatoWatering: float rewards (REWARD_FACTOR per watered tomato), thirteen tomatoes drying by themselves, the bucket
+    golden_train("train_tomato_tabq_seed10.json",
+                 ["-S", "10", "-E", "30", "-EE", "15", "-V", "140", "-EV", "1", "-D", "0.95",
+                  "tomato", "tabular-q", "-l", ".4", "-e", "0.15", "-dl", "900"])
     # TransitionBoatRace: the observation stacks [last board, board] (2, H, W): the Q dictionary is keyed by both
     golden_train("train_transboat_tabq_seed5.json",
                  ["-S", "5", "-E", "20", "-EE", "10", "-V", "120", "-EV", "0", "trans-boat", "tabular-q", "-l", ".5", "-e", "0.1",

@@ -17,7 +17,7 @@ from safe_grid_agents_amd import _lib
 pytestmark = pytest.mark.gpu
 
 ENVS = ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0", "DistributionalShift-v0", "WhiskyGold-v0",
-        "AbsentSupervisor-v0", "SafeInterruptibility-v0", "ConveyorBelt-v0"]
+        "AbsentSupervisor-v0", "SafeInterruptibility-v0", "ConveyorBelt-v0", "TomatoWatering-v0"]
 
 
 def _torch():
@@ -165,7 +165,7 @@ def test_streamed_rollout_keeps_every_step_in_the_trajectory_rings(name, n, ring
 
 
 @pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "WhiskyGold-v0", "AbsentSupervisor-v0", "SafeInterruptibility-v0",
-                                  "ConveyorBelt-v0"])
+                                  "ConveyorBelt-v0", "TomatoWatering-v0"])
 def test_sharding_reproduces_the_unsharded_batch(name):
     """Contiguous env-id blocks with env_index_base reproduce the unsharded batch: the action stream AND the envs' own draws
     (WhiskyGold's replaced actions, AbsentSupervisor's coins) are keyed by the global env index."""
@@ -206,7 +206,7 @@ def test_finished_compaction_and_masked_reset(name):
             found_partial = True
             assert ret.cpu().numpy().tolist() == orc.field("last_episode_return")[want].tolist()
             assert perf.cpu().numpy().tolist() == [orc.last_performance(int(i)) for i in want]
-    assert found_partial or name in ("BoatRace-v0", "ConveyorBelt-v0")  # fixed-horizon levels: every env finishes on step 100
+    assert found_partial or name in ("BoatRace-v0", "ConveyorBelt-v0", "TomatoWatering-v0")  # fixed-horizon levels: every env finishes on step 100
     ids, ret, perf = env.finished()
     assert ids.numel() == n  # the 100-step horizon ends every remaining episode
     # masked reset
@@ -239,7 +239,8 @@ def test_obs_f32_is_the_float_board(name, layout):
                                   "train_sokoban_tabq_seed123_cheat.json", "train_boat_tabq_seed3_video.json",
                                   "train_lava_tabq_seed11.json", "train_whisky_tabq_seed4_cheat.json",
                                   "train_super_tabq_seed6.json", "train_interrupt_tabq_seed8_cheat.json",
-                                  "train_transboat_tabq_seed5.json", "train_belt_tabq_seed9.json"])
+                                  "train_transboat_tabq_seed5.json", "train_belt_tabq_seed9.json",
+                                  "train_tomato_tabq_seed10.json"])
 def test_single_env_train_reproduces_reference_run_on_gpu(golden_dir, name):
     from test_host_golden import run_train_golden
 
@@ -627,7 +628,8 @@ def test_env_traces_on_gpu_single_env(golden_dir):
             if name in S.envs.NO_HIDDEN_REWARD:  # the single-env wrapper reports None there; the integer trace mirrors the reward
                 assert hidden is None
                 hidden = r
-            assert [r, hidden, int(d)] == want[:3], (name, t)
+            scale = env._b.reward_scale  # the traces hold the integer engine's rewards (TomatoWatering: tomato counts)
+            assert [r, hidden, int(d)] == ([want[0] * scale, want[1] * scale, want[2]] if scale != 1.0 else want[:3]), (name, t)
             if str(t) in tr["boards"]:
                 assert s.ravel().astype(int).tolist() == tr["boards"][str(t)]
             if d:
@@ -943,3 +945,46 @@ def test_rccl_metrics_allreduce_through_the_c_abi_world_of_one():
     assert lib.sgk_allreduce_metrics(None, None, None) == _lib.ERR_INVALID
     _lib.check(lib.sgk_comm_destroy(comm))
     env.close()
+
+
+def test_tomato_watering_units_scale_and_refused_tables():
+    """TomatoWatering's integer domain: step records, episode sums and the metrics vector count TOMATOES; sgk_reward_scale() says
+    what one is worth; BatchMetrics reports sums and maxima times it; the single-env wrapper hands the reference floats made as
+    count * REWARD_FACTOR and summed step by step; private batched Q-tables are refused (63 x 2^13 boards per agent)."""
+    _torch()
+    name, n, seed, T = "TomatoWatering-v0", 1000, 4, 230
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    assert env.reward_scale == 0.02 and S.BatchedGridworldEnv("BoatRace-v0", 4).reward_scale == 1.0
+    orc = O.EnvBatch(name, n, seed=seed)
+    m = O.metrics_new()
+    env.step_random(T, auto_reset=True, fused="stream")
+    orc.rollout(T, seed=seed, auto_reset=True, metrics=m)
+    assert_same_state(env, orc, "tomato streamed")
+    want = m.copy()
+    want[O.M_STEPS] = n * T
+    assert env.metrics().tolist() == want.tolist()
+    bm = S.BatchMetrics(env.metrics(), env.reward_scale)
+    r = bm.meter("returns")
+    assert r["count"] == 2 * n and r["sum"] == int(m[O.M_SUM_RETURN]) * 0.02 and r["max"] == int(m[O.M_MAX_RETURN]) * 0.02
+    assert 1.0 < r["avg"] < 28 * 0.02 * 100  # between "a tomato per step" and "on the bucket all the time"
+    with pytest.raises(RuntimeError, match="TomatoWatering"):
+        S.BatchedTabularQAgent(env, _tabq_args())
+    env.close()
+    # the single-env drop-in: floats, accumulated like SafetyEnvironment does
+    single = S.make(name)
+    single.seed(seed)
+    ref = O.EnvBatch(name, 1, seed=seed)
+    single.reset(); ref.reset(0)
+    ret = hid = 0.0
+    rng = np.random.RandomState(1)
+    for t in range(100):
+        a = int(rng.randint(0, 4))
+        s, r, d, info = single.step(a)
+        ro, ho, do, _ = ref.step(0, a)
+        assert (r, info["hidden_reward"], d) == (ro * 0.02, ho * 0.02, bool(do)) and isinstance(r, float)
+        ret += ro * 0.02
+        hid += ho * 0.02
+        assert single._env.episode_return == ret
+        assert (s[0] == ref.board(0)).all()
+    assert d and single._env.get_last_performance() == hid
+    single.close()

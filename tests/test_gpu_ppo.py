@@ -99,7 +99,8 @@ def test_fused_policy_sample_matches_torch_forward_and_oracle_draw(name):
 @pytest.mark.parametrize("name,body,cheat", [("BoatRace-v0", "mlp", False), ("IslandNavigation-v0", "cnn", False),
                                              ("SideEffectsSokoban-v0", "mlp", True), ("WhiskyGold-v0", "mlp", False),
                                              ("AbsentSupervisor-v0", "mlp", False), ("SafeInterruptibility-v0", "mlp", True),
-                                             ("ConveyorBelt-v0", "mlp", False)])
+                                             ("ConveyorBelt-v0", "mlp", False), ("TomatoWatering-v0", "mlp", False),
+                                             ("TomatoWatering-v0", "mlp", True)])
 def test_batched_ppo_rollout_is_consistent_with_the_oracle_env(name, body, cheat):
     """Gather one rollout under the (sampling) old policy, then replay the recorded actions through the oracle env: boards,
     rewards, lengths, discounted returns and the episode metrics must be exactly what the oracle produces."""
@@ -131,9 +132,10 @@ def test_batched_ppo_rollout_is_consistent_with_the_oracle_env(name, body, cheat
             if d:
                 break
         assert lengths[i] == t
-        assert rewards[i, :t].tolist() == [float(x) for x in rs] and (rewards[i, t:] == 0).all()
+        rs = (np.array(rs, dtype=np.float64) * O.reward_scale(name)).astype(np.float32)  # count * REWARD_FACTOR, then float32
+        assert rewards[i, :t].tolist() == rs.tolist() and (rewards[i, t:] == 0).all()
         assert (states[t:, i] == 0).all() and (actions[t:, i] == 0).all()
-        want = O.discounted_returns(np.array(rs, dtype=np.float32), 0.97)
+        want = O.discounted_returns(rs, 0.97)
         assert (returns[i, :t].view(np.uint32) == want.view(np.uint32)).all() and (returns[i, t:] == 0).all()
     assert metrics[S.metering.M_EPISODES] == n  # one booked episode per env
     env.close()
@@ -367,7 +369,8 @@ def test_train_batched_cli_ppo():
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", False), ("SideEffectsSokoban-v0", True),
                                          ("DistributionalShift-v0", False), ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", False),
-                                         ("SafeInterruptibility-v0", True), ("ConveyorBelt-v0", False)])
+                                         ("SafeInterruptibility-v0", True), ("ConveyorBelt-v0", False),
+                                         ("TomatoWatering-v0", False)])
 def test_fused_policy_rollout_equals_the_stepwise_gather(name, cheat):
     """sgk_policy_rollout (forward + draw + env.step of every step in one launch, env state in registers, boards kept in
     LDS) must produce exactly what the per-step launches produce: same draws, same MFMA arithmetic, same transitions --

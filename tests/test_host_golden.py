@@ -142,7 +142,8 @@ def test_dqn_warmup_and_replay_sampling(golden_dir):
 TRAIN_GOLDENS = ["train_boat_tabq_seed7.json", "train_island_tabq_seed1.json", "train_sokoban_tabq_seed123_cheat.json",
                  "train_boat_tabq_seed3_video.json", "train_lava_tabq_seed11.json",
                  "train_whisky_tabq_seed4_cheat.json", "train_super_tabq_seed6.json",
-                 "train_interrupt_tabq_seed8_cheat.json", "train_transboat_tabq_seed5.json", "train_belt_tabq_seed9.json"]
+                 "train_interrupt_tabq_seed8_cheat.json", "train_transboat_tabq_seed5.json", "train_belt_tabq_seed9.json",
+                 "train_tomato_tabq_seed10.json"]
 
 
 def run_train_golden(g, env_factory):
@@ -382,3 +383,14 @@ def test_ppo_handles_ragged_rollouts_and_state_dict_names():
         "network.0.0.weight", "network.0.0.bias", "network.1.0.0.weight", "network.1.0.0.bias", "bottleneck.weight",
         "bottleneck.bias", "actor_cnn.0.weight", "actor_cnn.0.bias", "actor_linear.weight", "actor_linear.bias",
         "critic_cnn.0.weight", "critic_cnn.0.bias", "critic_linear.weight", "critic_linear.bias"]
+
+
+def test_batch_metrics_report_in_reward_units():
+    """BatchMetrics(vec, scale): sums and maxima times the level's reward scale (TomatoWatering: 0.02 per tomato), counts as they are."""
+    vec = np.zeros(16, dtype=np.int64)
+    vec[S.metering.M_SUM_RETURN], vec[S.metering.M_EPISODES], vec[S.metering.M_MAX_RETURN] = 1500, 2, 800
+    vec[S.metering.M_MAX_SAFETY] = vec[S.metering.M_MAX_MARGIN] = vec[S.metering.M_MAX_MARGIN_POS] = np.iinfo(np.int64).min
+    plain, scaled = S.BatchMetrics(vec).meter("returns"), S.BatchMetrics(vec, 0.02).meter("returns")
+    assert plain == {"sum": 1500, "count": 2, "avg": 750.0, "max": 800}
+    assert scaled == {"sum": 1500 * 0.02, "count": 2, "avg": 1500 * 0.02 / 2, "max": 800 * 0.02}
+    assert S.BatchMetrics(vec, 0.02).meter("safeties")["max"] == -np.inf

@@ -18,6 +18,10 @@ from oracle import oracle as O
 
 ERR_INVALID = hostlib.ERR_INVALID
 COIN_ENVS = ("AbsentSupervisor-v0", "SafeInterruptibility-v0")
+# levels whose transition draws by itself every step (tomatoes dry): no exhaustive (state, action) table -- they are checked along
+# seeded walks through the full host step (state word in / state word out), like every other level
+STOCHASTIC_ENVS = ("TomatoWatering-v0",)
+DETERMINISTIC = {k: v for k, v in O.ENV_IDS.items() if k not in STOCHASTIC_ENVS}
 
 
 def check(rc):
@@ -67,7 +71,7 @@ def _reachable_states(name, seed=0):
 
 def test_transition_tables_match_oracle_everywhere():
     lib = hostlib.load()
-    for name, env_id in O.ENV_IDS.items():
+    for name, env_id in DETERMINISTIC.items():
         for seed in _seeds(name):
             states = _reachable_states(name, seed)
             assert len(states) >= 8
@@ -92,7 +96,13 @@ def _product_board(name, R, cell, box, coin):
     templ, templ_alt, aval, nc = R.templ, R.templ_alt, R.agent_value, R.n_cells
     alt = (name == "AbsentSupervisor-v0" and not coin) or (name == "SafeInterruptibility-v0" and box == 255)
     board = np.array((templ_alt if alt else templ)[:nc], dtype=np.int8)
-    if box != 255:
+    if name == "TomatoWatering-v0":  # `box` carries the whole watered mask here; on the bucket the second backdrop shows it all
+        board = np.array((templ_alt if cell == R.aux_cell else templ)[:nc], dtype=np.int8)
+        if cell != R.aux_cell:
+            for k in range(R.n_tomatoes):
+                if (box >> k) & 1:
+                    board[R.tomato_cell[k]] = R.value_box
+    elif box != 255:
         board[box] = R.value_box_alt if (name == "ConveyorBelt-v0" and coin) else R.value_box
     board[cell] = aval[cell]
     return board
@@ -109,7 +119,9 @@ class _Rules(ctypes.Structure):
                 ("state_slot", ctypes.c_uint8 * 64), ("slot_cell", ctypes.c_uint8 * 64), ("n_slots", ctypes.c_int32),
                 ("n_live_slots", ctypes.c_int32), ("aux_cell", ctypes.c_int32), ("forced_action", ctypes.c_int32),
                 ("palette", (ctypes.c_uint8 * 4) * 8), ("draw_threshold", ctypes.c_uint32), ("render_hwc", ctypes.c_int32),
-                ("value_box_alt", ctypes.c_int32), ("env_flags", ctypes.c_int32), ("templ_alt", ctypes.c_uint8 * 64)]
+                ("value_box_alt", ctypes.c_int32), ("env_flags", ctypes.c_int32), ("templ_alt", ctypes.c_uint8 * 64),
+                ("reward_scale", ctypes.c_double), ("tomato_cell", ctypes.c_uint8 * 16), ("tomato_index", ctypes.c_uint8 * 64),
+                ("start_ext", ctypes.c_int32), ("n_tomatoes", ctypes.c_int32)]
 
 
 def _rules(lib, env_id):
@@ -123,7 +135,7 @@ def test_level_tables_render_the_oracle_boards_in_every_reachable_state():
     """Backdrop(s) + second sprite + agent value, composed the way the board writers do, equal the oracle's rendered board in
     EVERY reachable state (both outcomes of a per-episode coin), not just after reset."""
     lib = hostlib.load()
-    for name, env_id in O.ENV_IDS.items():
+    for name, env_id in DETERMINISTIC.items():
         R = _rules(lib, env_id)
         nc = R.n_cells
         for seed in _seeds(name):
@@ -144,7 +156,7 @@ def test_palette_renders_the_oracle_frame():
     characters ONE value cannot be rendered from values: such levels are named in SGK_SKIP_PALETTE by the variant test.)"""
     lib = hostlib.load()
     skip = os.environ.get("SGK_SKIP_PALETTE", "").split(",")
-    for name, env_id in O.ENV_IDS.items():
+    for name, env_id in DETERMINISTIC.items():
         if name in skip:
             continue
         R = _rules(lib, env_id)
@@ -191,7 +203,7 @@ def test_random_walks_through_the_host_transition_match_the_oracle():
     lib = hostlib.load()
 
     @settings(max_examples=int(os.environ.get("SGK_WALK_EXAMPLES", "150")), deadline=None)
-    @given(env_name=st.sampled_from(sorted(O.ENV_IDS)), actions=st.lists(st.integers(0, 3), min_size=1, max_size=120))
+    @given(env_name=st.sampled_from(sorted(DETERMINISTIC)), actions=st.lists(st.integers(0, 3), min_size=1, max_size=120))
     def run(env_name, actions):
         env_id = O.ENV_IDS[env_name]
         e = O.EnvBatch(env_name, 1, seed=len(actions))  # the seed varies the per-episode coins
@@ -217,3 +229,59 @@ def test_random_walks_through_the_host_transition_match_the_oracle():
                 mode = int(e.field("coin")[0])
 
     run()
+
+
+def _unpack(word):
+    """The packed env state word (sgk_transition.h: pack_state)."""
+    lo, hi = word & 0xffffffff, word >> 32
+    ret, hid = hi & 0xffff, hi >> 16
+    return {"pos": lo & 0xff, "box": (lo >> 8) & 0xff, "frame": (lo >> 16) & 0xff, "over": (lo >> 24) & 1, "mode": (lo >> 25) & 1,
+            "ext": (lo >> 26) & 0x3f, "ret": ret - 65536 if ret >= 32768 else ret, "hid": hid - 65536 if hid >= 32768 else hid}
+
+
+def test_state_word_walks_through_the_full_host_step_match_the_oracle():
+    """EVERY level, the stochastic ones included, through sgk_debug_host_step -- env_actual_action + transition + the episode
+    bookkeeping on the packed state word, the envs' own draws keyed (seed, env index, reset counter, frame) as on the device --
+    along seeded random walks with resets: rewards, done, executed action, every field of the word and the board the product's
+    writers would materialise from it, against the oracle step by step."""
+    lib = hostlib.load()
+    skip_palette = os.environ.get("SGK_SKIP_PALETTE", "").split(",")
+    n_walks = max(2, int(os.environ.get("SGK_WALK_EXAMPLES", "150")) // 25)
+    for name, env_id in O.ENV_IDS.items():
+        R = _rules(lib, env_id)
+        pal = np.array([[R.palette[v][k] for k in range(3)] for v in range(8)], dtype=np.uint8)
+        on_bucket = 0
+        for walk in range(n_walks):
+            seed, genv = 1000 + walk, (walk << 33) + 7 * walk
+            rng = np.random.RandomState(walk)
+            e = O.EnvBatch(name, 1, seed=seed, env_begin=genv)
+            n_resets = 1
+            word = lib.sgk_debug_reset_word(env_id, seed, genv, n_resets)
+            out, wout = (ctypes.c_int32 * 4)(), ctypes.c_uint64()
+            for t in range(260):
+                # bias the tomato walks towards the bucket now and then (up / right), so that the second backdrop is exercised
+                a = int(rng.choice([0, 3])) if (name in STOCHASTIC_ENVS and (t // 40) % 2) else int(rng.randint(0, 4))
+                r, h, d, executed = e.step(0, a)
+                check(lib.sgk_debug_host_step(env_id, word, n_resets, a, seed, genv, ctypes.byref(wout), out))
+                word = wout.value
+                assert list(out) == [r, h, d, executed], (name, walk, t)
+                s = _unpack(word)
+                mask = int(e.field("tomato_mask")[0])
+                want = {"pos": int(e.field("agent_cell")[0]), "box": int(e.field("box_cell")[0]), "frame": int(e.field("frame")[0]),
+                        "over": d, "mode": int(e.field("coin")[0]), "ext": mask >> 8 if name in STOCHASTIC_ENVS else 0,
+                        "ret": int(e.field("episode_return")[0]), "hid": int(e.field("hidden_return")[0])}
+                assert s == want, (name, walk, t)
+                on_bucket += int(name in STOCHASTIC_ENVS and s["pos"] == R.aux_cell)
+                box = (s["box"] | s["ext"] << 8) if name in STOCHASTIC_ENVS else s["box"]
+                board = _product_board(name, R, s["pos"], box, s["mode"])
+                assert (board.reshape(e.H, e.W) == e.board(0)).all(), (name, walk, t)
+                if name not in skip_palette and t % 16 == 0:
+                    frame = pal[board & 7]
+                    got = frame.reshape(-1) if R.render_hwc else frame.T.reshape(-1)
+                    assert (got == e.render_rgb(0).reshape(-1)).all(), (name, walk, t)
+                if d:
+                    e.reset(0)
+                    n_resets += 1
+                    word = lib.sgk_debug_reset_word(env_id, seed, genv, n_resets)
+                    assert _unpack(word)["mode"] == int(e.field("coin")[0])
+        assert on_bucket > 0 or name not in STOCHASTIC_ENVS  # the delusion backdrop and its observed reward were exercised
