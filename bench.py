@@ -150,6 +150,7 @@ def timed_steps(env, steps, warmup, barrier, global_metrics, path="stream", ring
         for c in sorted(set(chunk_schedule(warmup) + chunk_schedule(steps))):
             env.prepare_step_random(c, auto_reset=True)
     run(warmup)
+    env.metrics_reset()  # the line's episode figures (episodes_finished, mean_return, mean_safety) are the timed region's
     env.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     # ---- timed region ---------------------------------------------------------------------------------------------------

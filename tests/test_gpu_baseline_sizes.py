@@ -5,7 +5,7 @@ config 2  BoatRace random-action rollout, 65 536 envs: the WHOLE batch vs the or
 config 5  (the metric's own batch) BoatRace random-action rollout, 1 048 576 envs: the WHOLE batch -- every board, state word field,
           last-episode array and the metrics vector -- vs the oracle (threaded) after 230 steps, through each of the three
           paths (one launch per step, streamed into the env's own buffers, streamed into a trajectory ring: the last 30
-          slices slice by slice), and as two 524 288-env shards; the same for SideEffectsSokoban and WhiskyGold.
+          slices slice by slice), and as two 524 288-env shards; the same (streamed) for SideEffectsSokoban, WhiskyGold, ConveyorBelt and TomatoWatering.
 config 3  IslandNavigation + tabular-Q, 262 144 private agents, the LDS-resident kernel FORCED (it runs ~5 rounds of 64-agent
           groups per workgroup there: the grid-stride path) -- and again at 65 536 agents forced onto the same kernel: env
           state and the f64 tables of 4 096 sampled agents (first / middle / last groups, every round of the grid-stride
@@ -96,7 +96,8 @@ def _whole_batch_equal(env, orc, where):
 
 
 @pytest.mark.parametrize("name,path", [("BoatRace-v0", "launch"), ("BoatRace-v0", "stream"), ("BoatRace-v0", "ring"),
-                                       ("SideEffectsSokoban-v0", "stream"), ("WhiskyGold-v0", "stream")])
+                                       ("SideEffectsSokoban-v0", "stream"), ("WhiskyGold-v0", "stream"),
+                                       ("ConveyorBelt-v0", "stream"), ("TomatoWatering-v0", "stream")])
 def test_one_million_envs_whole_batch_vs_oracle(name, path):
     torch = _torch()
     n, seed, T = 1 << 20, 0x5AFE, 230
