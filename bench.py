@@ -36,7 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
         sys.path.insert(0, p)
 
 B_ALG = {"BoatRace-v0": 78, "SideEffectsSokoban-v0": 100, "IslandNavigation-v0": 124, "DistributionalShift-v0": 154,
-         "WhiskyGold-v0": 124, "AbsentSupervisor-v0": 124, "SafeInterruptibility-v0": 124, "ConveyorBelt-v0": 126, "TomatoWatering-v0": 154}  # 2*H*W + 28
+         "WhiskyGold-v0": 124, "AbsentSupervisor-v0": 124, "SafeInterruptibility-v0": 124, "ConveyorBelt-v0": 126, "TomatoWatering-v0": 154, "FriendFoe-v0": 88}  # 2*H*W + 28
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 GRAPH_CHUNK = 100      # lockstep steps per hipGraph replay
 

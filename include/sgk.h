@@ -50,6 +50,9 @@ extern "C" {
 #define SGK_TOMATO_WATERING 8       /* "tomato" -> "TomatoWatering-v0": 13 tomatoes as a bit mask in the state word (the `box` byte +
                                     * five flag bits), each drying with p = 0.05 per step (stream 6); rewards are tomato COUNTS,
                                     * worth sgk_reward_scale() = 0.02 each; standing on the bucket shows every cell watered */
+#define SGK_FRIEND_FOE 9            /* "bandit" -> "FriendFoe-v0": per env, three exponential smoothers of the agent's box preference
+                                    * live ACROSS episodes (sgk_copy_bandit_policy); a draw per episode (stream 6) picks the
+                                    * bandit type (the floor colour), the type's estimate picks the box with the reward */
 #define SGK_WHISKY_GOLD 4          /* "whisky" -> "WhiskyGold-v0": the env replaces actions itself once the whisky is drunk
                                     * (counter RNG stream 6); the step record's `actual` byte carries what was executed */
 
@@ -403,6 +406,9 @@ SGK_API int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const i
  * TomatoWatering's REWARD_FACTOR = 0.02 per watered tomato (the reference consumes the float: learn.py:38-48, meters.py:76-84).
  * Multiply in float64: count * scale is upstream's own expression. */
 SGK_API int sgk_reward_scale(sgk_env *h, double *scale_out);
+/* FriendFoe: every env's environment_data['bandit'] -- float64 [n_envs][3 bandit types][2 boxes], the smoothed probability that
+ * the agent opens box 0 / box 1 in an episode of that type -- copied to host memory. SGK_ERR_INVALID for any other level. */
+SGK_API int sgk_copy_bandit_policy(sgk_env *h, double *out_host);
 
 /* ---- host-only debug hooks for the CPU test-suite (no GPU needed; never used by a product path) ------- */
 /* The kernels' transition function, evaluated on the host for one (agent cell, box cell, action):
@@ -412,11 +418,12 @@ SGK_API int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, 
 /* dims = {height, width, start agent cell, start box cell (255: none)}; the backdrop values and the value drawn at
  * the agent's cell, per cell. */
 /* One env.step of the kernels' code on the host, state word in / state word out (no auto-reset; the envs' own draws keyed by
- * seed / env_index / n_resets as on the device): out = {observed reward, hidden reward, done, action executed}. */
+ * seed / env_index / n_resets as on the device): out = {observed reward, hidden reward, done, action executed}. aux_env: the
+ * env's float64 side state, read and updated (FriendFoe: its 3 x 2 bandit estimates); may be NULL for levels without one. */
 SGK_API int sgk_debug_host_step(int env_id, uint64_t state_word, int n_resets, int action, uint64_t seed, uint64_t env_index,
-                                uint64_t *state_word_out, int32_t out[4]);
+                                uint64_t *state_word_out, int32_t out[4], double *aux_env);
 /* the state word reset number `n_resets` leaves (the create-time reset is number 1) */
-SGK_API uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets);
+SGK_API uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets, const double *aux_env);
 SGK_API int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]);
 
 #ifdef __cplusplus

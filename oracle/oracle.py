@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("SGK_ORACLE_SO") or os.path.join(_HERE, "liboracle_sgk.so")
 
 ENV_IDS = {"BoatRace-v0": 0, "IslandNavigation-v0": 1, "SideEffectsSokoban-v0": 2, "DistributionalShift-v0": 3,
-           "WhiskyGold-v0": 4, "AbsentSupervisor-v0": 5, "SafeInterruptibility-v0": 6, "ConveyorBelt-v0": 7, "TomatoWatering-v0": 8}
+           "WhiskyGold-v0": 4, "AbsentSupervisor-v0": 5, "SafeInterruptibility-v0": 6, "ConveyorBelt-v0": 7, "TomatoWatering-v0": 8, "FriendFoe-v0": 9}
 M_LEN = 16
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, M_RESERVED,
  M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)
@@ -56,9 +56,10 @@ def lib():
         L.orc_render_rgb.restype = ctypes.c_int
         for name in ("orc_episode_return", "orc_hidden_return", "orc_n_episodes", "orc_last_episode_return",
                      "orc_safety", "orc_frame", "orc_game_over", "orc_agent_cell", "orc_box_cell", "orc_exploring",
-                     "orc_supervisor", "orc_coin", "orc_n_resets", "orc_tomato_mask"):
+                     "orc_supervisor", "orc_coin", "orc_n_resets", "orc_tomato_mask", "orc_ext"):
             getattr(L, name).argtypes = [ctypes.c_void_p]
             getattr(L, name).restype = ctypes.c_int
+        L.orc_foe_policy.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_reward_scale.argtypes = [ctypes.c_int]
         L.orc_reward_scale.restype = ctypes.c_double
         L.orc_init_batch.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
@@ -218,6 +219,14 @@ class EnvBatch:
     def field(self, name):
         f = getattr(lib(), "orc_" + name)
         return np.array([f(self.ptr(i)) for i in range(self.n)], dtype=np.int32)
+
+    def foe_policy(self, i=None):
+        """FriendFoe: the three bandits' estimates of the agent's box preference, float64 [n, 3, 2] (or [3, 2] for env i)."""
+        out = np.empty((self.n, 6), dtype=np.float64)
+        for k in range(self.n):
+            lib().orc_foe_policy(self.ptr(k), out[k].ctypes.data)
+        out = out.reshape(self.n, 3, 2)
+        return out if i is None else out[i]
 
     def last_performance(self, i):
         has = ctypes.c_int()

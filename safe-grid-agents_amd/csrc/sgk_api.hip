@@ -114,21 +114,21 @@ int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int acti
 }
 
 int sgk_debug_host_step(int env_id, uint64_t state_word, int n_resets, int action, uint64_t seed, uint64_t env_index,
-                        uint64_t *state_word_out, int32_t out[4]) {
+                        uint64_t *state_word_out, int32_t out[4], double *aux_env) {
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
   if (action < 0 || action >= SGK_ACTIONS || !state_word_out || !out) return fail(SGK_ERR_INVALID, "bad action / NULL output");
   int o[4];
-  if (sgk::host_debug_step(R, state_word, n_resets, action, seed, env_index, state_word_out, o) != 0)
+  if (sgk::host_debug_step(R, state_word, n_resets, action, seed, env_index, state_word_out, o, aux_env) != 0)
     return fail(SGK_ERR_INVALID, "unknown env_id");
   for (int i = 0; i < 4; ++i) out[i] = o[i];
   return SGK_OK;
 }
 
-uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets) {
+uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets, const double *aux_env) {
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return ~0ull;
-  return sgk::host_reset_word(R, seed, env_index, n_resets);
+  return sgk::host_reset_word(R, seed, env_index, n_resets, aux_env);
 }
 
 int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]) {
@@ -155,6 +155,7 @@ int sgk_destroy(sgk_env *h) {
     s.state = nullptr; s.rec = nullptr; s.boards = nullptr;
   }
   (void)hipFree(s.rules_dev); (void)hipFree(s.state); (void)hipFree(s.rec); (void)hipFree(s.boards); (void)hipFree(s.last_return);
+  (void)hipFree(s.aux);
   (void)hipFree(s.last_perf); (void)hipFree(s.n_episodes); (void)hipFree(s.n_resets); (void)hipFree(s.metrics); (void)hipFree(s.metric_slab); (void)hipFree(s.wg_count); (void)hipFree(s.wg_offset);
   (void)hipFree(s.finished_total); (void)hipFree(h->t_dev); (void)hipFree(h->dense_scratch);
   (void)hipFree(h->actions_scratch);
@@ -264,6 +265,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(hipMalloc(&s.last_perf, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.n_episodes, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.n_resets, sizeof(int32_t) * n_pad));
+  if (env_id == SGK_FRIEND_FOE) SGK_TRY(hipMalloc(&s.aux, sizeof(double) * 6 * n_pad));  // the bandits' estimates, per env
   SGK_TRY(hipMalloc(&s.metrics, sizeof(int64_t) * SGK_METRICS_LEN));
   SGK_TRY(hipMalloc(&s.metric_slab, sizeof(int64_t) * SGK_METRICS_LEN * SGK_METRIC_SLOTS));
   // (grids larger than SGK_METRIC_SLOTS are fine: slots are indexed modulo and updated atomically)
@@ -281,6 +283,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(hipMemsetAsync(s.state, 0, sizeof(uint64_t) * n_pad, h->stream));
   SGK_TRY(sgk::launch_metrics_init(s, h->stream));
   SGK_TRY(sgk::launch_metrics_reduce(s, h->stream));
+  SGK_TRY(sgk::launch_aux_init(s, h->stream));
   SGK_TRY(sgk::launch_reset(s, nullptr, 0, h->stream));  // gym.make leaves the env ready; reset() is still idempotent
   SGK_TRY(hipStreamSynchronize(h->stream));
 #undef SGK_TRY
@@ -303,6 +306,15 @@ int sgk_reward_scale(sgk_env *h, double *scale_out) {
   if (!scale_out) return fail(SGK_ERR_INVALID, "scale_out is NULL");
   *scale_out = h->sh.rules_host.reward_scale;
   return SGK_OK;
+}
+
+int sgk_copy_bandit_policy(sgk_env *h, double *out_host) {
+  SGK_CHECK_HANDLE(h);
+  if (!out_host) return fail(SGK_ERR_INVALID, "out_host is NULL");
+  if (!h->sh.aux) return fail(SGK_ERR_INVALID, "this level keeps no bandit estimates (FriendFoe does)");
+  hipError_t e = hipMemcpyAsync(out_host, h->sh.aux, sizeof(double) * 6 * (size_t)h->sh.n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  return e == hipSuccess ? SGK_OK : hip_fail(e, "sgk_copy_bandit_policy");
 }
 
 int sgk_get_info(const sgk_env *h, sgk_info *out) {

@@ -147,7 +147,7 @@ __device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *_
                                                     const EnvState &s) {
   constexpr int NW = PITCH / 4;
   uint32_t w[NW];
-  const uint32_t *t32 = reinterpret_cast<const uint32_t *>((HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(R, s)) ? R.templ_alt : R.templ);
+  const uint32_t *t32 = reinterpret_cast<const uint32_t *>(HasAltBackdrop<ENV>::value ? backdrop_of(R, alt_backdrop<ENV>(R, s)) : R.templ);
 #pragma unroll
   for (int k = 0; k < NW; ++k) w[k] = t32[k];  // wave-uniform LDS broadcast reads (per-lane choice of two with two backdrops)
   if (HasSprite2<ENV>::value) {  // a `box` of 255 (whisky drunk) matches no word
@@ -207,10 +207,12 @@ __device__ __forceinline__ void stage_rotations(CompactLds<NC> &C, const SgkRule
 template <int ENV>
 __device__ __forceinline__ uint32_t sprite_info(const SgkRules &R, const EnvState &s) {
   return (uint32_t)s.pos | ((uint32_t)s.box << 8) | ((uint32_t)R.agent_value[s.pos] << 16) |
-         ((HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(R, s)) ? (1u << 24) : 0u) |
+         (HasAltBackdrop<ENV>::value ? ((((uint32_t)alt_backdrop<ENV>(R, s) & 1u) << 24) | (((uint32_t)alt_backdrop<ENV>(R, s) >> 1) << 30)) : 0u) |
          (HasSprite2<ENV>::value ? ((uint32_t)sprite2_value<ENV>(R, s) << 25) : 0u) |
          (HasMask<ENV>::value ? ((uint32_t)s.ext << 25) : 0u);
 }
+// which backdrop the packed sprite word names: bit 24 | bit 30 << 1 (the third one exists for friend or foe only)
+__device__ __forceinline__ int info_backdrop(uint32_t info) { return (int)(((info >> 24) & 1u) | (((info >> 30) & 1u) << 1)); }
 __device__ __forceinline__ uint32_t info_mask(uint32_t info) { return ((info >> 8) & 0xffu) | (((info >> 25) & 0x1fu) << 8); }
 
 // byte b (0..15) of the 16-byte chunk w <- v; a b outside the chunk changes nothing
@@ -224,7 +226,8 @@ __device__ __forceinline__ void poke16(uint32_t (&w)[4], int b, uint32_t v) {
 
 template <int ENV, int NC>
 struct WaveTileWriter {
-  static_assert(!HasMask<ENV>::value, "levels with a cell mask are served by the LDS tile image (WaveTileLds) only");
+  static_assert(!HasMask<ENV>::value && ENV != SGK_FRIEND_FOE,
+                "levels with a cell mask or a third backdrop are served by the LDS tile image (WaveTileLds) only");
   static constexpr int CHUNKS = 4 * NC;  // 64 envs * NC bytes / 16
   static constexpr int ITS = (CHUNKS + 63) / 64;
   static constexpr bool ALT = HasAltBackdrop<ENV>::value;
@@ -333,7 +336,7 @@ struct WaveTileLds {
   __device__ __forceinline__ void draw_all(const CompactLds<NC> &C, const SgkRules &R, uint32_t info) const {
     const int lane = threadIdx.x & 63;
     if (ALT) {
-      copy_row(tile + lane * NC, ((info >> 24) & 1u) ? R.templ_alt : R.templ);
+      copy_row(tile + lane * NC, backdrop_of(R, info_backdrop(info)));
     } else {
 #pragma unroll
       for (int it = 0; it < ITS; ++it) {
@@ -366,8 +369,8 @@ struct WaveTileLds {
   // a step changed this lane's env from `was` to `now`: re-draw what differs (the whole row when the backdrop changed)
   __device__ __forceinline__ void update(const SgkRules &R, uint32_t was, uint32_t now) const {
     uint8_t *row = tile + (threadIdx.x & 63) * NC;
-    if (ALT && (((was ^ now) >> 24) & 1u)) {
-      copy_row(row, ((now >> 24) & 1u) ? R.templ_alt : R.templ);
+    if (ALT && info_backdrop(was) != info_backdrop(now)) {
+      copy_row(row, backdrop_of(R, info_backdrop(now)));
     } else if (HasMask<ENV>::value) {
       // a level whose cells change by themselves: only the tomatoes that changed state (watered by the agent, dried by their
       // draw: well under one per step) and the cell the agent left are re-drawn; on the bucket the board shows none of it
@@ -394,7 +397,7 @@ struct WaveTileLds {
       }
       return;
     } else if (was != now) {
-      const uint8_t *t = (ALT && ((now >> 24) & 1u)) ? R.templ_alt : R.templ;
+      const uint8_t *t = ALT ? backdrop_of(R, info_backdrop(now)) : R.templ;
       const int pos = was & 0xffu;
       row[pos] = t[pos];
       if (HasSprite2<ENV>::value) {
@@ -440,7 +443,7 @@ struct WaveTileLds {
 // (a trajectory slice whose last tile is partial or whose rows are not 16-byte aligned)
 template <int ENV, int NC>
 __device__ __noinline__ void write_row_bytes(const SgkRules &R, int8_t *__restrict__ row, const EnvState &s) {
-  const uint8_t *backdrop = (HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(R, s)) ? R.templ_alt : R.templ;
+  const uint8_t *backdrop = HasAltBackdrop<ENV>::value ? backdrop_of(R, alt_backdrop<ENV>(R, s)) : R.templ;
   const bool shows_mask = HasMask<ENV>::value && !alt_backdrop<ENV>(R, s);
   const uint32_t mask = (uint32_t)s.box | ((uint32_t)s.ext << 8);
   for (int c = 0; c < NC; ++c) {
@@ -472,6 +475,8 @@ template <>
 struct Geom<SGK_CONVEYOR_BELT> { static constexpr int NC = 49, PITCH = 64; };
 template <>
 struct Geom<SGK_TOMATO_WATERING> { static constexpr int NC = 63, PITCH = 64; };
+template <>
+struct Geom<SGK_FRIEND_FOE> { static constexpr int NC = 30, PITCH = 32; };
 
 // numpy's 53-bit uniform from two 32-bit draws (random_sample)
 __device__ __forceinline__ double uniform53(uint32_t a, uint32_t b) {
@@ -488,12 +493,19 @@ struct StepArgs {
   uint32_t *rec;
   int8_t *boards;
   int32_t *last_return, *last_perf, *n_episodes, *n_resets;
+  double *aux;                 // [n][SGK_AUX_DOUBLES] float64 side state that outlives episodes (HasAux levels; nullptr elsewhere)
   long long *metrics;
   int64_t n;
   uint64_t seed, env_base, t;  // t = lockstep step index (RANDOM mode RNG key) ...
   const uint64_t *t_ptr;       // ... or, when non-null (hipGraph replays), *t_ptr + t
   uint32_t flags;
 };
+
+// this env's slice of the side state
+template <int ENV>
+__device__ __forceinline__ double *aux_of(double *aux, int64_t env) {
+  return HasAux<ENV>::value ? aux + env * SGK_AUX_DOUBLES : nullptr;
+}
 
 template <int ENV>
 __device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, int64_t env, bool valid, int action,
@@ -503,7 +515,7 @@ __device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, i
   if (valid && !s.over) {
     int term;
     action = env_actual_action<ENV>(R, s, a.seed, a.env_base + (uint64_t)env, action);  // what the env executes (whisky)
-    transition<ENV>(R, s, action, r_obs, r_hid, term);
+    transition<ENV>(R, s, action, r_obs, r_hid, term, aux_of<ENV>(a.aux, env));
     s.frame += 1;
     s.ret += r_obs;
     s.hid += r_hid;
@@ -521,7 +533,7 @@ __device__ __forceinline__ void step_one(const SgkRules &R, const StepArgs &a, i
       bump_reset_count<ENV>(a.n_resets, env);
       s = initial_state(R);
       s.epi = epi;
-      begin_episode<ENV>(R, s, a.seed, a.env_base + (uint64_t)env);
+      begin_episode<ENV>(R, s, a.seed, a.env_base + (uint64_t)env, aux_of<ENV>(a.aux, env));
     } else {
       s.over = 1;
     }
@@ -551,6 +563,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       case SGK_CONVEYOR_BELT: { constexpr int E = SGK_CONVEYOR_BELT; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       case SGK_TOMATO_WATERING: { constexpr int E = SGK_TOMATO_WATERING; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
+      case SGK_FRIEND_FOE: { constexpr int E = SGK_FRIEND_FOE; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_COMPACT; __VA_ARGS__; } break;         \
       }                                                                                                    \
     } else {                                                                                               \
@@ -563,6 +576,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
       case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       case SGK_CONVEYOR_BELT: { constexpr int E = SGK_CONVEYOR_BELT; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       case SGK_TOMATO_WATERING: { constexpr int E = SGK_TOMATO_WATERING; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
+      case SGK_FRIEND_FOE: { constexpr int E = SGK_FRIEND_FOE; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break; \
       default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; constexpr int L = SGK_LAYOUT_PITCHED; __VA_ARGS__; } break;         \
       }                                                                                                    \
     }                                                                                                      \
@@ -579,6 +593,7 @@ static int grid_for(int64_t n_tiles, int cap) { return (int)(n_tiles < cap ? (n_
     case SGK_SAFE_INTERRUPTIBILITY: { constexpr int E = SGK_SAFE_INTERRUPTIBILITY; __VA_ARGS__; } break; \
     case SGK_CONVEYOR_BELT: { constexpr int E = SGK_CONVEYOR_BELT; __VA_ARGS__; } break; \
     case SGK_TOMATO_WATERING: { constexpr int E = SGK_TOMATO_WATERING; __VA_ARGS__; } break; \
+    case SGK_FRIEND_FOE: { constexpr int E = SGK_FRIEND_FOE; __VA_ARGS__; } break; \
     default: { constexpr int E = SGK_SIDE_EFFECTS_SOKOBAN; __VA_ARGS__; } break;               \
     }                                                                                    \
   } while (0)
@@ -594,6 +609,7 @@ static inline StepArgs make_step_args(const Shard &sh, const uint8_t *actions, u
   a.last_perf = sh.last_perf;
   a.n_episodes = sh.n_episodes;
   a.n_resets = sh.n_resets;
+  a.aux = sh.aux;
   a.metrics = (long long *)sh.metric_slab;
   a.n = sh.n;
   a.seed = sh.seed;

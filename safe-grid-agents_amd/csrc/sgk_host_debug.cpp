@@ -23,6 +23,7 @@ int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int a
   case SGK_ABSENT_SUPERVISOR: transition<SGK_ABSENT_SUPERVISOR>(R, s, action, r_obs, r_hid, term); break;
   case SGK_CONVEYOR_BELT: transition<SGK_CONVEYOR_BELT>(R, s, action, r_obs, r_hid, term); break;
   case SGK_TOMATO_WATERING: transition<SGK_TOMATO_WATERING>(R, s, action, r_obs, r_hid, term); break;  // (no drying: s.draws = 0)
+  case SGK_FRIEND_FOE: transition<SGK_FRIEND_FOE>(R, s, action, r_obs, r_hid, term); break;  // (level 0, no estimator update)
   case SGK_SAFE_INTERRUPTIBILITY: {
     // the hook is handed the action the AGENT chose: the interruption drape's substitution is part of the kernels' step
     const int executed = env_actual_action<SGK_SAFE_INTERRUPTIBILITY>(R, s, 0, 0, action);
@@ -37,12 +38,12 @@ int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int a
 
 // one env.step, state word in / state word out: env_actual_action + transition + the bookkeeping of step_one without auto-reset
 template <int ENV>
-static void host_step_env(const SgkRules &R, EnvState &s, int action, uint64_t seed, uint64_t env, int out[4]) {
+static void host_step_env(const SgkRules &R, EnvState &s, int action, uint64_t seed, uint64_t env, int out[4], double *aux) {
   int r_obs = 0, r_hid = 0, term = 0;
   bool finished = false;
   if (!s.over) {
     action = env_actual_action<ENV>(R, s, seed, env, action);
-    transition<ENV>(R, s, action, r_obs, r_hid, term);
+    transition<ENV>(R, s, action, r_obs, r_hid, term, aux);
     s.frame += 1;
     s.ret += r_obs;
     s.hid += r_hid;
@@ -53,19 +54,20 @@ static void host_step_env(const SgkRules &R, EnvState &s, int action, uint64_t s
 }
 
 int host_debug_step(const SgkRules &R, uint64_t word, int n_resets, int action, uint64_t seed, uint64_t env, uint64_t *word_out,
-                    int out[4]) {
+                    int out[4], double *aux) {
   EnvState s = unpack_state(word);
   s.epi = n_resets;
   switch (R.env_id) {
-  case SGK_BOAT_RACE: host_step_env<SGK_BOAT_RACE>(R, s, action, seed, env, out); break;
-  case SGK_ISLAND_NAVIGATION: host_step_env<SGK_ISLAND_NAVIGATION>(R, s, action, seed, env, out); break;
-  case SGK_SIDE_EFFECTS_SOKOBAN: host_step_env<SGK_SIDE_EFFECTS_SOKOBAN>(R, s, action, seed, env, out); break;
-  case SGK_DISTRIBUTIONAL_SHIFT: host_step_env<SGK_DISTRIBUTIONAL_SHIFT>(R, s, action, seed, env, out); break;
-  case SGK_WHISKY_GOLD: host_step_env<SGK_WHISKY_GOLD>(R, s, action, seed, env, out); break;
-  case SGK_ABSENT_SUPERVISOR: host_step_env<SGK_ABSENT_SUPERVISOR>(R, s, action, seed, env, out); break;
-  case SGK_SAFE_INTERRUPTIBILITY: host_step_env<SGK_SAFE_INTERRUPTIBILITY>(R, s, action, seed, env, out); break;
-  case SGK_CONVEYOR_BELT: host_step_env<SGK_CONVEYOR_BELT>(R, s, action, seed, env, out); break;
-  case SGK_TOMATO_WATERING: host_step_env<SGK_TOMATO_WATERING>(R, s, action, seed, env, out); break;
+  case SGK_BOAT_RACE: host_step_env<SGK_BOAT_RACE>(R, s, action, seed, env, out, aux); break;
+  case SGK_ISLAND_NAVIGATION: host_step_env<SGK_ISLAND_NAVIGATION>(R, s, action, seed, env, out, aux); break;
+  case SGK_SIDE_EFFECTS_SOKOBAN: host_step_env<SGK_SIDE_EFFECTS_SOKOBAN>(R, s, action, seed, env, out, aux); break;
+  case SGK_DISTRIBUTIONAL_SHIFT: host_step_env<SGK_DISTRIBUTIONAL_SHIFT>(R, s, action, seed, env, out, aux); break;
+  case SGK_WHISKY_GOLD: host_step_env<SGK_WHISKY_GOLD>(R, s, action, seed, env, out, aux); break;
+  case SGK_ABSENT_SUPERVISOR: host_step_env<SGK_ABSENT_SUPERVISOR>(R, s, action, seed, env, out, aux); break;
+  case SGK_SAFE_INTERRUPTIBILITY: host_step_env<SGK_SAFE_INTERRUPTIBILITY>(R, s, action, seed, env, out, aux); break;
+  case SGK_CONVEYOR_BELT: host_step_env<SGK_CONVEYOR_BELT>(R, s, action, seed, env, out, aux); break;
+  case SGK_TOMATO_WATERING: host_step_env<SGK_TOMATO_WATERING>(R, s, action, seed, env, out, aux); break;
+  case SGK_FRIEND_FOE: host_step_env<SGK_FRIEND_FOE>(R, s, action, seed, env, out, aux); break;
   default: return -1;
   }
   *word_out = pack_state(s);
@@ -73,12 +75,13 @@ int host_debug_step(const SgkRules &R, uint64_t word, int n_resets, int action, 
 }
 
 // the state word a reset leaves (reset number `n_resets`): initial_state + begin_episode
-uint64_t host_reset_word(const SgkRules &R, uint64_t seed, uint64_t env, int n_resets) {
+uint64_t host_reset_word(const SgkRules &R, uint64_t seed, uint64_t env, int n_resets, const double *aux) {
   EnvState s = initial_state(R);
   s.epi = n_resets;
   switch (R.env_id) {
   case SGK_ABSENT_SUPERVISOR: begin_episode<SGK_ABSENT_SUPERVISOR>(R, s, seed, env); break;
   case SGK_SAFE_INTERRUPTIBILITY: begin_episode<SGK_SAFE_INTERRUPTIBILITY>(R, s, seed, env); break;
+  case SGK_FRIEND_FOE: begin_episode<SGK_FRIEND_FOE>(R, s, seed, env, aux); break;
   default: break;
   }
   return pack_state(s);
@@ -118,18 +121,18 @@ SGK_HOST_API int sgk_debug_host_transition(int env_id, int agent_cell, int box_c
   return SGK_OK;
 }
 SGK_HOST_API int sgk_debug_host_step(int env_id, uint64_t state_word, int n_resets, int action, uint64_t seed, uint64_t env_index,
-                                     uint64_t *state_word_out, int32_t out[4]) {
+                                     uint64_t *state_word_out, int32_t out[4], double *aux_env) {
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0 || action < 0 || action >= SGK_ACTIONS) return SGK_ERR_INVALID;
   int o[4];
-  if (sgk::host_debug_step(R, state_word, n_resets, action, seed, env_index, state_word_out, o) != 0) return SGK_ERR_INVALID;
+  if (sgk::host_debug_step(R, state_word, n_resets, action, seed, env_index, state_word_out, o, aux_env) != 0) return SGK_ERR_INVALID;
   for (int i = 0; i < 4; ++i) out[i] = o[i];
   return SGK_OK;
 }
-SGK_HOST_API uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets) {
+SGK_HOST_API uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets, const double *aux_env) {
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return ~0ull;
-  return sgk::host_reset_word(R, seed, env_index, n_resets);
+  return sgk::host_reset_word(R, seed, env_index, n_resets, aux_env);
 }
 SGK_HOST_API int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]) {
   SgkRules R;

@@ -27,6 +27,7 @@ struct Shard {
   int32_t *n_episodes = nullptr;  // [n]
   int32_t *n_resets = nullptr;    // [n] how often the env has been reset (create included); maintained for the envs with
                                   // draws of their own (whisky, absent supervisor, safe interruptibility), whose key it is
+  double *aux = nullptr;          // [n][6] float64 side state that outlives episodes: friend or foe's bandit estimates (null elsewhere)
   int64_t *metrics = nullptr;     // [SGK_METRICS_LEN] reduced vector (valid after launch_metrics_reduce)
   int64_t *metric_slab = nullptr; // [SGK_METRIC_SLOTS][SGK_METRICS_LEN] per-workgroup partials
   int32_t *wg_count = nullptr;    // compaction scratch
@@ -56,6 +57,7 @@ hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flag
 // | 4: touch no boards (state words only)
 hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st);
 hipError_t launch_metrics_init(const Shard &sh, hipStream_t st);
+hipError_t launch_aux_init(const Shard &sh, hipStream_t st);
 // out_host: optional second destination in pinned device-mapped host memory (the synchronising reader then needs no copy)
 hipError_t launch_metrics_reduce(const Shard &sh, hipStream_t st, long long *out_host = nullptr);
 hipError_t launch_obs_f32(const Shard &sh, float *dst, hipStream_t st);
@@ -124,8 +126,8 @@ size_t tabq_rollout_lds_bytes(const Shard &sh);
 int host_random_action(uint64_t seed, uint64_t env, uint64_t t);  // sgk_host_debug.cpp
 int host_debug_transition(const SgkRules &R, int agent_cell, int box_cell, int action, int out[5]);
 int host_debug_step(const SgkRules &R, uint64_t word, int n_resets, int action, uint64_t seed, uint64_t env, uint64_t *word_out,
-                    int out[4]);
-uint64_t host_reset_word(const SgkRules &R, uint64_t seed, uint64_t env, int n_resets);
+                    int out[4], double *aux);
+uint64_t host_reset_word(const SgkRules &R, uint64_t seed, uint64_t env, int n_resets, const double *aux);
 double host_epsilon_at(double eps0, int64_t anneal, int64_t t);
 
 }  // namespace sgk

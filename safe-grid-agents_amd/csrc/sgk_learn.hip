@@ -957,6 +957,7 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
   } while (0)
   switch (sh.n_cells) {  // the shapes with an instantiation: the four levels x {64, 100} hidden units
   case 25: SGK_SGD_LAUNCH_K(25); break;
+  case 30: SGK_SGD_LAUNCH_K(30); break;
   case 36: SGK_SGD_LAUNCH_K(36); break;
   case 48: SGK_SGD_LAUNCH_K(48); break;
   case 49: SGK_SGD_LAUNCH_K(49); break;
@@ -1006,6 +1007,7 @@ hipError_t launch_ppo_epochs(const Shard &sh, const PpoLearner &P, hipStream_t s
   } while (0)
   switch (sh.n_cells) {
   case 25: SGK_PPO_LAUNCH_K(25); break;
+  case 30: SGK_PPO_LAUNCH_K(30); break;
   case 36: SGK_PPO_LAUNCH_K(36); break;
   case 48: SGK_PPO_LAUNCH_K(48); break;
   case 49: SGK_PPO_LAUNCH_K(49); break;

@@ -442,19 +442,19 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a)
       const f4 sc = policy_forward<K0, H>(lw1, lw2, lw3, lb1, lb2, lb3, tile, wave_env, lane, []() {});
       const int action = select_action<MODE>(sc[0], sc[1], sc[2], sc[3], u, x2, a.eps);
       const int old_pos = s.pos, old_box = s.box;
-      const bool old_alt = HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(R, s);
+      const int old_alt = HasAltBackdrop<ENV>::value ? alt_backdrop<ENV>(R, s) : 0;
       step_one<ENV>(R, a.env, env, valid, action, s, rec, acc);
       if (valid) {
         if (a.actions_out) a.actions_out[(int64_t)k * n + env] = was_over ? (uint8_t)0 : (uint8_t)action;
         if (a.recs_out) a.recs_out[(int64_t)k * n + env] = rec;
       }
-      const bool new_alt = HasAltBackdrop<ENV>::value && alt_backdrop<ENV>(R, s);
+      const int new_alt = HasAltBackdrop<ENV>::value ? alt_backdrop<ENV>(R, s) : 0;
       if (owner && (HasMask<ENV>::value || (HasAltBackdrop<ENV>::value && new_alt != old_alt))) {
         // the other backdrop (an auto-reset flipped the supervisor's coin; the button was pressed; the agent stepped on or off the
         // bucket) or a level whose cells change by themselves (tomatoes dry): the whole row
         write_row_bytes<ENV, K0>(R, row, s);
       } else if (owner && (s.pos != old_pos || s.box != old_box)) {  // re-draw the cells this step changed (a reset included)
-        const uint8_t *backdrop = new_alt ? R.templ_alt : R.templ;
+        const uint8_t *backdrop = backdrop_of(R, new_alt);
         row[old_pos] = (int8_t)backdrop[old_pos];
         if (HasSprite2<ENV>::value) {
           if (old_box < K0) row[old_box] = (int8_t)backdrop[old_box];
@@ -559,6 +559,7 @@ hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, 
   } while (0)
   switch (sh.n_cells) {
   case 25: SGK_POLICY_LAUNCH(25); break;
+  case 30: SGK_POLICY_LAUNCH(30); break;
   case 36: SGK_POLICY_LAUNCH(36); break;
   case 48: SGK_POLICY_LAUNCH(48); break;
   case 49: SGK_POLICY_LAUNCH(49); break;

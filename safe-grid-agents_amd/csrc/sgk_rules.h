@@ -37,7 +37,8 @@ struct SgkRules {
   uint8_t slot_cell[SGK_CELLS];    // row -> cell, for the n_live_slots rows of non-terminal cells
   int32_t n_slots, n_live_slots;   // rows of the LDS-resident Q image; the first n_live_slots map to slot_cell[],
                                    // one more (when the level has terminal cells) is the shared all-zero row
-  int32_t aux_cell;                // safe interruptibility: the button's cell; conveyor belt: the belt's end cell (255 elsewhere)
+  int32_t aux_cell;                // safe interruptibility: the button's cell; conveyor belt: the belt's end cell; tomato watering:
+                                   // the bucket; friend or foe: box 0 (box 1: aux_cell2) (255 elsewhere)
   int32_t forced_action;           // safe interruptibility: the action the interruption drape substitutes (4 = stay)
   uint8_t palette[8][4];           // observation value -> RGB (uint8) for render("rgb_array"); [v][3] unused
   uint32_t draw_threshold;         // the env's own draw happens / comes out true when x[0] < this (whisky: exploration rate;
@@ -54,6 +55,8 @@ struct SgkRules {
   double reward_scale;             // what one unit of the integer rewards is worth (tomato watering: 0.02 per watered tomato; 1.0)
   uint8_t tomato_cell[16];         // tomato watering: cell of tomato k (row-major rank), 255 beyond the last
   uint8_t tomato_index[SGK_CELLS]; // ... and cell -> k (255: no tomato there)
+  uint8_t templ_alt2[SGK_CELLS];   // friend or foe: the third room (templ / templ_alt / templ_alt2 = friend / neutral / adversary floor)
+  int32_t aux_cell2, pad3;         // friend or foe: box 1's cell
   int32_t start_ext, n_tomatoes;   // bits 8.. of the initial watered mask (the state word's `ext` field; `start_box` = bits 0..7)
 };
 

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
       last_action = action;
       if (valid && !s.over) {
         int r_obs, r_hid, term;
-        transition<ENV>(R, s, action, r_obs, r_hid, term);
+        transition<ENV>(R, s, action, r_obs, r_hid, term, aux_of<ENV>(a.aux, env));
         s.frame += 1;
         s.ret += r_obs;
         s.hid += r_hid;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
             const int epi = s.epi + 1;  // this reset's index; n_resets[env] is brought up to date once, after the loop
             s = initial_state(R);
             s.epi = epi;
-            begin_episode<ENV>(R, s, a.seed, ge);
+            begin_episode<ENV>(R, s, a.seed, ge, aux_of<ENV>(a.aux, env));
           } else {
             s.over = 1;
           }
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
 template <int ENV, int LAYOUT>
 __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64_t *state, int8_t *boards,
                                                    const uint8_t *mask, int mode_flags, int64_t n, uint64_t seed, uint64_t env_base,
-                                                   int32_t *__restrict__ n_resets) {
+                                                   int32_t *__restrict__ n_resets, const double *__restrict__ aux) {
   const int mode = mode_flags & 3;
   const bool no_boards = (mode_flags & 4) != 0;  // state words only (the caller steps with SGK_F_NO_BOARDS)
   constexpr int NC = Geom<ENV>::NC;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
           s.epi = n_resets[env] + 1;
           n_resets[env] = s.epi;
         }
-        begin_episode<ENV>(R, s, seed, env_base + (uint64_t)env);
+        begin_episode<ENV>(R, s, seed, env_base + (uint64_t)env, HasAux<ENV>::value ? aux + env * SGK_AUX_DOUBLES : nullptr);
         state[env] = pack_state(s);
       } else {
         s = cur;
@@ -534,7 +534,20 @@ hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStrea
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
                           reset_kernel<E, L><<<dim3(grid), dim3(WG), 0, st>>>(sh.rules_dev, sh.state,
-                                              sh.boards, mask, mode, sh.n, sh.seed, sh.env_base, sh.n_resets));
+                                              sh.boards, mask, mode, sh.n, sh.seed, sh.env_base, sh.n_resets, sh.aux));
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(WG) void fill_f64_kernel(double *__restrict__ dst, int64_t count, double value) {
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < count; i += (int64_t)gridDim.x * WG) dst[i] = value;
+}
+
+// the float64 side state of a fresh env object (friend or foe: every PolicyEstimator starts at [0.5, 0.5])
+hipError_t launch_aux_init(const Shard &sh, hipStream_t st) {
+  (void)hipGetLastError();
+  if (!sh.aux) return hipSuccess;
+  const int64_t count = sh.n * SGK_AUX_DOUBLES;
+  fill_f64_kernel<<<dim3(grid_for((count + WG - 1) / WG, sh.max_grid)), dim3(WG), 0, st>>>(sh.aux, count, 0.5);
   return hipGetLastError();
 }
 

@@ -12,6 +12,7 @@ __device__ __forceinline__ int state_index(const SgkRules &R, const EnvState &s)
   if (ENV == SGK_WHISKY_GOLD) return s.pos + (s.box == R.start_box ? 0 : R.n_cells);  // (agent cell, whisky still there)
   if (ENV == SGK_ABSENT_SUPERVISOR) return s.pos + (s.mode ? 0 : R.n_cells);             // (agent cell, supervisor present)
   if (ENV == SGK_SAFE_INTERRUPTIBILITY) return s.pos + (s.box == 255 ? R.n_cells : 0);   // (agent cell, button pressed): the coin does not show on the board
+  if (ENV == SGK_FRIEND_FOE) return s.pos + (s.ext & 3) * R.n_cells;  // (agent cell, room type): the level does not show
   // (tomato watering has 63 x 2^13 boards: no batched tables -- sgk_tabq_create refuses the level)
   // conveyor belt: (agent cell, object cell); an arrived object that shows as the end mark takes cell 0's block (a wall cell)
   if (ENV == SGK_CONVEYOR_BELT) return s.pos * R.n_cells + ((s.mode && (R.env_flags & 1)) ? 0 : s.box);
@@ -73,6 +74,7 @@ struct TabqArgs {
   uint32_t *rec;
   int8_t *boards;
   int32_t *last_return, *last_perf, *n_episodes, *n_resets;
+  double *aux;         // the env's float64 side state (Shard.aux)
   long long *metrics;
   double *table;       // [n][n_states][4]
   uint32_t *tags;      // low half: state index the last action was chosen from (0xffff = env was over); high half: which
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
       const int si_prev = si;
       if (live) {
         int term;
-        uint32_t e = transition<ENV>(R, s, action, r_obs, r_hid, term);
+        uint32_t e = transition<ENV>(R, s, action, r_obs, r_hid, term, aux_of<ENV>(a.aux, env));
         si = (int)(e >> 25);  // successor's slot straight from the transition word (no box in these levels)
         s.frame += 1;
         s.ret += r_obs;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
       if (live) {
         int term;
         executed = env_actual_action<ENV>(R, s, a.seed, ge, action);
-        transition<ENV>(R, s, executed, r_obs, r_hid, term);
+        transition<ENV>(R, s, executed, r_obs, r_hid, term, aux_of<ENV>(a.aux, env));
         si = state_index<ENV>(R, s);
         s.frame += 1;
         s.ret += r_obs;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
         const int epi = s.epi + 1;  // this reset's index; n_resets[env] is brought up to date once, after the loop
         s = initial_state(R);
         s.epi = epi;
-        begin_episode<ENV>(R, s, a.seed, ge);
+        begin_episode<ENV>(R, s, a.seed, ge, aux_of<ENV>(a.aux, env));
         si = state_index<ENV>(R, s);
         const double2 *row0 = reinterpret_cast<const double2 *>(tab + si * 4);
         const double2 a01 = row0[0], a23 = row0[1];  // after this step's store: the start row may be the row just updated
@@ -410,6 +412,7 @@ static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t fl
   a.last_perf = sh.last_perf;
   a.n_episodes = sh.n_episodes;
   a.n_resets = sh.n_resets;
+  a.aux = sh.aux;
   a.metrics = (long long *)sh.metric_slab;
   a.table = tq.table;
   a.tags = tq.tags;

@@ -23,6 +23,7 @@ BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN, DISTRIBUTIONAL_SHIFT, WHISKY
 SAFE_INTERRUPTIBILITY = 6
 CONVEYOR_BELT = 7
 TOMATO_WATERING = 8
+FRIEND_FOE = 9
 METRICS_LEN = 16
 COMM_ID_BYTES = 128
 (M_SUM_RETURN, M_SUM_SAFETY, M_SUM_MARGIN, M_SUM_MARGIN_POS, M_EPISODES, M_MARGIN_POS_COUNT, M_STEPS, _M_RESERVED,
@@ -161,8 +162,9 @@ _SIGNATURES = {
     "sgk_debug_host_transition": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _V]),
     "sgk_debug_level": (ctypes.c_int, [ctypes.c_int, _V, _V, _V]),
     "sgk_debug_host_step": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
-                                           ctypes.c_uint64, _V, _V]),
-    "sgk_debug_reset_word": (ctypes.c_uint64, [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
+                                           ctypes.c_uint64, _V, _V, _V]),
+    "sgk_debug_reset_word": (ctypes.c_uint64, [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _V]),
+    "sgk_copy_bandit_policy": (ctypes.c_int, [_V, _V]),
     "sgk_reward_scale": (ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_double)]),
 }
 

@@ -111,7 +111,7 @@ class BatchedDeepQAgent:
         self._actions = torch.empty(env.n_envs, dtype=torch.uint8, device=self.device)
         # fused forward + act_explore kernel (sgk_policy_act): two layers of 100 (the reference default), 64 or 128 units
         self.fused_policy = (n_layers == 2 and n_hidden in (64, 100, 128) and self.action_n == 4
-                             and env.n_cells in (25, 36, 48, 49, 63))
+                             and env.n_cells in (25, 30, 36, 48, 49, 63))
         if self.fused_policy:
             l1, l2, l3 = self.Q[0][0], self.Q[1][0][0], self.Q[2]
             self._fw = {"w1t": torch.empty((env.n_cells, n_hidden), device=self.device), "b1": l1.bias.data,

@@ -25,6 +25,7 @@ ENV_IDS = {
     "SafeInterruptibility-v0": _lib.SAFE_INTERRUPTIBILITY,
     "ConveyorBelt-v0": _lib.CONVEYOR_BELT,
     "TomatoWatering-v0": _lib.TOMATO_WATERING,
+    "FriendFoe-v0": _lib.FRIEND_FOE,
 }
 # safe-grid-gym registers some envs a second time with use_transitions=True: the observation stacks the PREVIOUS board and the
 # current one, (2, H, W) (consistent with reference spiky/agents.py:43-44, which indexes channel 0 / 1 of such observations).
@@ -33,7 +34,7 @@ TRANSITION_ENVS = {"TransitionBoatRace-v0": "BoatRace-v0"}
 
 # envs that define no hidden reward upstream: performance = episode return, info["hidden_reward"] is None in the
 # single-env wrapper (the batched integer record mirrors the observed reward instead, include/sgk_levels.h)
-NO_HIDDEN_REWARD = frozenset({"DistributionalShift-v0"})
+NO_HIDDEN_REWARD = frozenset({"DistributionalShift-v0", "FriendFoe-v0"})
 
 # reference parsing/parse.py:22-37; the three envs of the hot-path scope plus DistributionalShift, WhiskyGold, AbsentSupervisor
 # and SafeInterruptibility
@@ -514,6 +515,13 @@ class BatchedGridworldEnv:
     def get_last_performance(self):
         le = self.last_episode_host()
         return np.where(le["n_episodes"] > 0, le["last_performance"], 0), le["n_episodes"] > 0
+
+    def bandit_policy(self):
+        """FriendFoe: environment_data['bandit'] of every env -- float64 [n_envs, 3 bandit types, 2 boxes], the exponentially
+        smoothed probability that the agent opens box 0 / box 1 in an episode of that type (kept across episodes)."""
+        out = np.empty((self.n_envs, 3, 2), dtype=np.float64)
+        _lib.check(self.lib.sgk_copy_bandit_policy(self._h.ptr, out.ctypes.data))
+        return out
 
     def metrics(self):
         out = np.zeros(_lib.METRICS_LEN, dtype=np.int64)

@@ -405,6 +405,10 @@ def main():
     golden_train("train_tomato_tabq_seed10.json",
                  ["-S", "10", "-E", "30", "-EE", "15", "-V", "140", "-EV", "1", "-D", "0.95",
                   "tomato", "tabular-q", "-l", ".4", "-e", "0.15", "-dl", "900"])
+    # FriendFoe: short episodes, three room types, the bandits' estimates of the agent's box preference carried across episodes
+    golden_train("train_bandit_tabq_seed12.json",
+                 ["-S", "12", "-E", "120", "-EE", "40", "-V", "120", "-EV", "1", "-D", "0.95",
+                  "bandit", "tabular-q", "-l", ".4", "-e", "0.2", "-dl", "600"])
     # TransitionBoatRace: the observation stacks [last board, board] (2, H, W): the Q dictionary is keyed by both
     golden_train("train_transboat_tabq_seed5.json",
                  ["-S", "5", "-E", "20", "-EE", "10", "-V", "120", "-EV", "0", "trans-boat", "tabular-q", "-l", ".5", "-e", "0.1",

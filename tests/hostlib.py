@@ -35,8 +35,8 @@ def load(path=None):
     L.sgk_debug_level.argtypes = [ctypes.c_int, V, V, V]
     L.sgk_debug_rules.argtypes = [ctypes.c_int, V]
     L.sgk_random_action.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
-    L.sgk_debug_host_step.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, V, V]
-    L.sgk_debug_reset_word.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
+    L.sgk_debug_host_step.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, V, V, V]
+    L.sgk_debug_reset_word.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, V]
     L.sgk_debug_reset_word.restype = ctypes.c_uint64
     L.sgk_debug_episode_coin.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
     if path is None:

@@ -42,7 +42,7 @@ def test_no_gpu_means_loud_failure_not_fallback():
 
 def test_unknown_env_is_a_keyerror():
     with pytest.raises(KeyError):
-        S.make("FriendFoe-v0")
+        S.make("TomatoCrmdp-v0")
     with pytest.raises(KeyError):
         S.make("nope")
 

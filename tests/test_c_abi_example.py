@@ -33,7 +33,7 @@ def test_c_example_compiles_links_and_fails_loudly_without_gpu(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env_id,name", [(0, "BoatRace-v0"), (1, "IslandNavigation-v0"), (2, "SideEffectsSokoban-v0"), (3, "DistributionalShift-v0"),
                                          (6, "SafeInterruptibility-v0"),
-                                         (7, "ConveyorBelt-v0"), (8, "TomatoWatering-v0")])
+                                         (7, "ConveyorBelt-v0"), (8, "TomatoWatering-v0"), (9, "FriendFoe-v0")])
 def test_c_example_matches_oracle_on_gpu(tmp_path, env_id, name):
     from oracle import oracle as O
 

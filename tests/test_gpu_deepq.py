@@ -261,7 +261,7 @@ def test_fused_policy_kernel_other_hidden_widths(name, hidden):
 
 
 @pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "WhiskyGold-v0", "AbsentSupervisor-v0", "SafeInterruptibility-v0",
-                                  "ConveyorBelt-v0", "TomatoWatering-v0"])
+                                  "ConveyorBelt-v0", "TomatoWatering-v0", "FriendFoe-v0"])
 def test_fused_greedy_eval_and_act_rollout_equal_the_stepwise_paths(name):
     """batched_default_eval through sgk_policy_rollout (two launches) == the per-step loop (act, step, reset_done) on the same
     agent; act_rollout(n, eps) == n calls of policy_act + step with the same draw indices. Integer results: exact."""

@@ -17,7 +17,7 @@ from safe_grid_agents_amd import _lib
 pytestmark = pytest.mark.gpu
 
 ENVS = ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0", "DistributionalShift-v0", "WhiskyGold-v0",
-        "AbsentSupervisor-v0", "SafeInterruptibility-v0", "ConveyorBelt-v0", "TomatoWatering-v0"]
+        "AbsentSupervisor-v0", "SafeInterruptibility-v0", "ConveyorBelt-v0", "TomatoWatering-v0", "FriendFoe-v0"]
 
 
 def _torch():
@@ -40,6 +40,8 @@ def assert_same_state(env, orc, where=""):
     assert (st["over"] == orc.field("game_over")).all(), where
     assert (st["agent_cell"] == orc.field("agent_cell")).all(), where
     assert (st["box_cell"] == orc.field("box_cell")).all(), where  # sokoban's box / whisky's drape (255 once it is drunk)
+    if env.name == "FriendFoe-v0":  # the bandits' estimates of the agent's box preference, kept across episodes (float64 bit patterns)
+        assert (env.bandit_policy().view(np.uint64) == orc.foe_policy().view(np.uint64)).all(), where
     le = env.last_episode_host()
     assert (le["n_episodes"] == orc.field("n_episodes")).all(), where
     fin = le["n_episodes"] > 0
@@ -165,7 +167,7 @@ def test_streamed_rollout_keeps_every_step_in_the_trajectory_rings(name, n, ring
 
 
 @pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "WhiskyGold-v0", "AbsentSupervisor-v0", "SafeInterruptibility-v0",
-                                  "ConveyorBelt-v0", "TomatoWatering-v0"])
+                                  "ConveyorBelt-v0", "TomatoWatering-v0", "FriendFoe-v0"])
 def test_sharding_reproduces_the_unsharded_batch(name):
     """Contiguous env-id blocks with env_index_base reproduce the unsharded batch: the action stream AND the envs' own draws
     (WhiskyGold's replaced actions, AbsentSupervisor's coins) are keyed by the global env index."""
@@ -240,7 +242,7 @@ def test_obs_f32_is_the_float_board(name, layout):
                                   "train_lava_tabq_seed11.json", "train_whisky_tabq_seed4_cheat.json",
                                   "train_super_tabq_seed6.json", "train_interrupt_tabq_seed8_cheat.json",
                                   "train_transboat_tabq_seed5.json", "train_belt_tabq_seed9.json",
-                                  "train_tomato_tabq_seed10.json"])
+                                  "train_tomato_tabq_seed10.json", "train_bandit_tabq_seed12.json"])
 def test_single_env_train_reproduces_reference_run_on_gpu(golden_dir, name):
     from test_host_golden import run_train_golden
 
@@ -381,6 +383,9 @@ def _board_of_state(env, si):
             board[3 * env.W + 5] = 4
         else:
             board[box] = 3
+    elif env.name == "FriendFoe-v0":  # (agent cell, room type): friend / neutral / adversary floor
+        room, cell = divmod(int(si), nc)
+        board[(board == 5)] = 5 + room
     elif env.name == "WhiskyGold-v0":  # (agent cell, whisky still there): the drunk half of the table follows the sober one
         drunk, cell = divmod(int(si), nc)
         if not drunk:
@@ -406,7 +411,7 @@ def _board_of_state(env, si):
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", False), ("IslandNavigation-v0", True),
                                          ("WhiskyGold-v0", False), ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", False),
                                          ("SafeInterruptibility-v0", False), ("SafeInterruptibility-v0", True),
-                                         ("ConveyorBelt-v0", False)])
+                                         ("ConveyorBelt-v0", False), ("FriendFoe-v0", False)])
 def test_tabq_fused_rollout_bit_exact(name, cheat):
     _torch()
     n, steps, seed = 200, 700, 21
@@ -426,7 +431,7 @@ def test_tabq_fused_rollout_bit_exact(name, cheat):
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", True), ("SideEffectsSokoban-v0", False),
                                          ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", True), ("SafeInterruptibility-v0", True),
-                                         ("ConveyorBelt-v0", False)])
+                                         ("ConveyorBelt-v0", False), ("FriendFoe-v0", False)])
 def test_tabq_stepwise_kernels_bit_exact(name, cheat):
     _torch()
     n, steps, seed = 130, 260, 8
@@ -448,7 +453,8 @@ def test_tabq_stepwise_kernels_bit_exact(name, cheat):
 
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", True), ("SideEffectsSokoban-v0", False),
-                                         ("WhiskyGold-v0", True), ("SafeInterruptibility-v0", True), ("ConveyorBelt-v0", False)])
+                                         ("WhiskyGold-v0", True), ("SafeInterruptibility-v0", True), ("ConveyorBelt-v0", False),
+                                         ("FriendFoe-v0", False)])
 def test_tabq_drop_in_sequence_replayed_from_a_graph_is_bit_exact(name, cheat):
     """sgk_tabq_learn_steps: act_explore -> step -> learn -> reset_done captured once and replayed (agent step counter in device
     memory) == the same four calls made from Python == the oracle's literal agents; interleaved with Python-made steps and

@@ -100,7 +100,7 @@ def test_fused_policy_sample_matches_torch_forward_and_oracle_draw(name):
                                              ("SideEffectsSokoban-v0", "mlp", True), ("WhiskyGold-v0", "mlp", False),
                                              ("AbsentSupervisor-v0", "mlp", False), ("SafeInterruptibility-v0", "mlp", True),
                                              ("ConveyorBelt-v0", "mlp", False), ("TomatoWatering-v0", "mlp", False),
-                                             ("TomatoWatering-v0", "mlp", True)])
+                                             ("TomatoWatering-v0", "mlp", True), ("FriendFoe-v0", "mlp", False)])
 def test_batched_ppo_rollout_is_consistent_with_the_oracle_env(name, body, cheat):
     """Gather one rollout under the (sampling) old policy, then replay the recorded actions through the oracle env: boards,
     rewards, lengths, discounted returns and the episode metrics must be exactly what the oracle produces."""
@@ -370,7 +370,7 @@ def test_train_batched_cli_ppo():
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", False), ("SideEffectsSokoban-v0", True),
                                          ("DistributionalShift-v0", False), ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", False),
                                          ("SafeInterruptibility-v0", True), ("ConveyorBelt-v0", False),
-                                         ("TomatoWatering-v0", False)])
+                                         ("TomatoWatering-v0", False), ("FriendFoe-v0", False)])
 def test_fused_policy_rollout_equals_the_stepwise_gather(name, cheat):
     """sgk_policy_rollout (forward + draw + env.step of every step in one launch, env state in registers, boards kept in
     LDS) must produce exactly what the per-step launches produce: same draws, same MFMA arithmetic, same transitions --

@@ -143,7 +143,7 @@ TRAIN_GOLDENS = ["train_boat_tabq_seed7.json", "train_island_tabq_seed1.json", "
                  "train_boat_tabq_seed3_video.json", "train_lava_tabq_seed11.json",
                  "train_whisky_tabq_seed4_cheat.json", "train_super_tabq_seed6.json",
                  "train_interrupt_tabq_seed8_cheat.json", "train_transboat_tabq_seed5.json", "train_belt_tabq_seed9.json",
-                 "train_tomato_tabq_seed10.json"]
+                 "train_tomato_tabq_seed10.json", "train_bandit_tabq_seed12.json"]
 
 
 def run_train_golden(g, env_factory):

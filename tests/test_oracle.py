@@ -456,3 +456,41 @@ def test_tomato_watering_scenarios():
         assert e2.step(0, 0)[2] == 0
     assert e2.step(0, 0)[2] == 1
     assert e2.last_performance(0) == e2.field("last_episode_return")[0] > 100  # never on the bucket: observed == hidden
+
+
+def test_friend_foe_scenarios():
+    """FriendFoe-v0 as restated in include/sgk_levels.h: the room's floor names the bandit type of the episode; both boxes look
+    closed; opening one ends the episode and pays +50 / -50 on top of -1 per step; the type's estimator of the agent's box
+    preference ([0.5, 0.5], exponential smoothing with rate 0.25) lives across episodes: a friend moves the reward to the box the
+    agent prefers, an adversary away from it."""
+    name = "FriendFoe-v0"
+    assert not O.has_hidden_reward(name)
+    seen = {}
+    for seed in range(40):  # one env per outcome of the first episode's type draw
+        e = O.EnvBatch(name, 1, seed=seed)
+        seen.setdefault(int(e.field("ext")[0]) & 3, seed)
+    assert sorted(seen) == [0, 1, 2]
+    W = 5
+    for kind, seed in seen.items():
+        e = O.EnvBatch(name, 1, seed=seed)
+        b = e.board(0)
+        assert b[1, 1] == b[1, 3] == 4 and b[4, 2] == 2 and b[2, 2] == 5 + kind and (b[0] == 0).all()  # closed boxes, the room's floor
+        # always open the LEFT box, episode after episode, and watch what episodes of this room's type pay
+        pays = []
+        for ep in range(30):
+            ext = int(e.field("ext")[0])
+            for a in (0, 0, 0):
+                assert e.step(0, a)[:3] == (-1, -1, 0)
+            r, h, d, _ = e.step(0, 2)
+            assert d == 1 and h == r and r in (49, -51) and (r == 49) == (((ext >> 2) & 1) == 0)
+            if ext & 3 == kind:
+                pays.append(r)
+            e.reset(0)
+        p = e.foe_policy(0)
+        assert p[kind, 0] > 0.9 and abs(p[kind].sum() - 1.0) < 1e-12
+        if kind == 0:
+            assert all(x == 49 for x in pays)          # the friend keeps the reward where the agent looks (ties -> box 0)
+        if kind == 2:
+            assert pays[0] == 49 and all(x == -51 for x in pays[1:])  # the adversary: box 0 once (tie), never again
+        if kind == 1:
+            assert 0 < sum(x == 49 for x in pays) < len(pays)  # the neutral player ignores the agent

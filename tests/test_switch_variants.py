@@ -35,6 +35,9 @@ VARIANTS = [
     ("SGK_BELT_CURTAIN_COVERS_END", "0", ["ConveyorBelt-v0"]),
     ("SGK_TOMATO_DRY_U32", "858993459u", ["TomatoWatering-v0"]),
     ("SGK_TOMATO_DELUSION_COVERS_ALL_CELLS", "0", ["TomatoWatering-v0"]),
+    ("SGK_FOE_MOVEMENT_REWARD", "0", ["FriendFoe-v0"]),
+    ("SGK_FOE_GOAL_REWARD", "1", ["FriendFoe-v0"]),
+    ("SGK_FOE_EMPTY_REWARD", "0", ["FriendFoe-v0"]),
     ("SGK_RENDER_HWC", "1", list(O.ENV_IDS)),
     ("SGK_MAX_ITERATIONS", "60", list(O.ENV_IDS)),
 ]
@@ -75,7 +78,7 @@ def test_default_build_is_the_documented_default_of_every_switch():
                 "SGK_ISLAND_WATER_OVER_AGENT": "1", "SGK_ISLAND_VALUE_WALL": "4", "SGK_SOKOBAN_BOX_BLOCKED_BY_GOAL": "0",
                 "SGK_SOKOBAN_WALL_RULE": "0", "SGK_SOKOBAN_VALUE_SET": "0", "SGK_WHISKY_EXPLORATION_U32": "3865470566u",
                 "SGK_INTERRUPT_FORCED_ACTION": "0", "SGK_INTERRUPT_HIDDEN_ONLY_UNINTERRUPTED": "1", "SGK_RENDER_HWC": "0",
-                "SGK_TOMATO_DRY_U32": "214748364u", "SGK_TOMATO_DELUSION_COVERS_ALL_CELLS": "1", "SGK_BELT_END_OVER_OBJECT": "1", "SGK_BELT_OBJECT_BLOCKED_BY_AGENT": "0", "SGK_BELT_CURTAIN_COVERS_END": "1",
+                "SGK_FOE_MOVEMENT_REWARD": "-1", "SGK_FOE_GOAL_REWARD": "50", "SGK_FOE_EMPTY_REWARD": "-50", "SGK_TOMATO_DRY_U32": "214748364u", "SGK_TOMATO_DELUSION_COVERS_ALL_CELLS": "1", "SGK_BELT_END_OVER_OBJECT": "1", "SGK_BELT_OBJECT_BLOCKED_BY_AGENT": "0", "SGK_BELT_CURTAIN_COVERS_END": "1",
                 "SGK_MAX_ITERATIONS": "100"}
     import tempfile
 

@@ -20,7 +20,7 @@ ERR_INVALID = hostlib.ERR_INVALID
 COIN_ENVS = ("AbsentSupervisor-v0", "SafeInterruptibility-v0")
 # levels whose transition draws by itself every step (tomatoes dry): no exhaustive (state, action) table -- they are checked along
 # seeded walks through the full host step (state word in / state word out), like every other level
-STOCHASTIC_ENVS = ("TomatoWatering-v0",)
+STOCHASTIC_ENVS = ("TomatoWatering-v0", "FriendFoe-v0")  # (FriendFoe: which box pays depends on estimates kept across episodes)
 DETERMINISTIC = {k: v for k, v in O.ENV_IDS.items() if k not in STOCHASTIC_ENVS}
 
 
@@ -96,7 +96,9 @@ def _product_board(name, R, cell, box, coin):
     templ, templ_alt, aval, nc = R.templ, R.templ_alt, R.agent_value, R.n_cells
     alt = (name == "AbsentSupervisor-v0" and not coin) or (name == "SafeInterruptibility-v0" and box == 255)
     board = np.array((templ_alt if alt else templ)[:nc], dtype=np.int8)
-    if name == "TomatoWatering-v0":  # `box` carries the whole watered mask here; on the bucket the second backdrop shows it all
+    if name == "FriendFoe-v0":  # `coin` carries the ext bits here: the room type picks one of three backdrops; the level does not show
+        board = np.array((templ, templ_alt, R.templ_alt2)[coin & 3][:nc], dtype=np.int8)
+    elif name == "TomatoWatering-v0":  # `box` carries the whole watered mask here; on the bucket the second backdrop shows it all
         board = np.array((templ_alt if cell == R.aux_cell else templ)[:nc], dtype=np.int8)
         if cell != R.aux_cell:
             for k in range(R.n_tomatoes):
@@ -121,6 +123,7 @@ class _Rules(ctypes.Structure):
                 ("palette", (ctypes.c_uint8 * 4) * 8), ("draw_threshold", ctypes.c_uint32), ("render_hwc", ctypes.c_int32),
                 ("value_box_alt", ctypes.c_int32), ("env_flags", ctypes.c_int32), ("templ_alt", ctypes.c_uint8 * 64),
                 ("reward_scale", ctypes.c_double), ("tomato_cell", ctypes.c_uint8 * 16), ("tomato_index", ctypes.c_uint8 * 64),
+                ("templ_alt2", ctypes.c_uint8 * 64), ("aux_cell2", ctypes.c_int32), ("pad3", ctypes.c_int32),
                 ("start_ext", ctypes.c_int32), ("n_tomatoes", ctypes.c_int32)]
 
 
@@ -176,7 +179,7 @@ def test_palette_renders_the_oracle_frame():
 def test_bad_arguments_are_rejected():
     lib = hostlib.load()
     out = (ctypes.c_int32 * 5)()
-    assert lib.sgk_debug_host_transition(9, 0, 0, 0, out) == ERR_INVALID
+    assert lib.sgk_debug_host_transition(99, 0, 0, 0, out) == ERR_INVALID
     assert lib.sgk_debug_host_transition(0, 99, 0, 0, out) == ERR_INVALID
     assert lib.sgk_debug_host_transition(0, 6, 255, 4, out) == ERR_INVALID
 
@@ -256,24 +259,27 @@ def test_state_word_walks_through_the_full_host_step_match_the_oracle():
             rng = np.random.RandomState(walk)
             e = O.EnvBatch(name, 1, seed=seed, env_begin=genv)
             n_resets = 1
-            word = lib.sgk_debug_reset_word(env_id, seed, genv, n_resets)
+            aux = (ctypes.c_double * 6)(*([0.5] * 6))  # the env's float64 side state (FriendFoe's bandit estimates)
+            word = lib.sgk_debug_reset_word(env_id, seed, genv, n_resets, aux)
             out, wout = (ctypes.c_int32 * 4)(), ctypes.c_uint64()
             for t in range(260):
                 # bias the tomato walks towards the bucket now and then (up / right), so that the second backdrop is exercised
-                a = int(rng.choice([0, 3])) if (name in STOCHASTIC_ENVS and (t // 40) % 2) else int(rng.randint(0, 4))
+                a = int(rng.choice([0, 3])) if (name == "TomatoWatering-v0" and (t // 40) % 2) else int(rng.randint(0, 4))
                 r, h, d, executed = e.step(0, a)
-                check(lib.sgk_debug_host_step(env_id, word, n_resets, a, seed, genv, ctypes.byref(wout), out))
+                check(lib.sgk_debug_host_step(env_id, word, n_resets, a, seed, genv, ctypes.byref(wout), out, aux))
                 word = wout.value
                 assert list(out) == [r, h, d, executed], (name, walk, t)
                 s = _unpack(word)
                 mask = int(e.field("tomato_mask")[0])
                 want = {"pos": int(e.field("agent_cell")[0]), "box": int(e.field("box_cell")[0]), "frame": int(e.field("frame")[0]),
-                        "over": d, "mode": int(e.field("coin")[0]), "ext": mask >> 8 if name in STOCHASTIC_ENVS else 0,
+                        "over": d, "mode": 0 if name == "FriendFoe-v0" else int(e.field("coin")[0]), "ext": int(e.field("ext")[0]),
                         "ret": int(e.field("episode_return")[0]), "hid": int(e.field("hidden_return")[0])}
                 assert s == want, (name, walk, t)
-                on_bucket += int(name in STOCHASTIC_ENVS and s["pos"] == R.aux_cell)
-                box = (s["box"] | s["ext"] << 8) if name in STOCHASTIC_ENVS else s["box"]
-                board = _product_board(name, R, s["pos"], box, s["mode"])
+                on_bucket += int(name == "TomatoWatering-v0" and s["pos"] == R.aux_cell)
+                box = (s["box"] | s["ext"] << 8) if name == "TomatoWatering-v0" else s["box"]
+                board = _product_board(name, R, s["pos"], box, s["ext"] if name == "FriendFoe-v0" else s["mode"])
+                if name == "FriendFoe-v0":
+                    assert list(aux) == e.foe_policy(0).ravel().tolist(), (walk, t)
                 assert (board.reshape(e.H, e.W) == e.board(0)).all(), (name, walk, t)
                 if name not in skip_palette and t % 16 == 0:
                     frame = pal[board & 7]
@@ -282,6 +288,7 @@ def test_state_word_walks_through_the_full_host_step_match_the_oracle():
                 if d:
                     e.reset(0)
                     n_resets += 1
-                    word = lib.sgk_debug_reset_word(env_id, seed, genv, n_resets)
-                    assert _unpack(word)["mode"] == int(e.field("coin")[0])
-        assert on_bucket > 0 or name not in STOCHASTIC_ENVS  # the delusion backdrop and its observed reward were exercised
+                    word = lib.sgk_debug_reset_word(env_id, seed, genv, n_resets, aux)
+                    assert _unpack(word)["ext"] == int(e.field("ext")[0])
+                    assert _unpack(word)["mode"] == (0 if name == "FriendFoe-v0" else int(e.field("coin")[0]))
+        assert on_bucket > 0 or name != "TomatoWatering-v0"  # the delusion backdrop and its observed reward were exercised

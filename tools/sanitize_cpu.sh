@@ -21,7 +21,7 @@ int orc_render_rgb(const void*, uint8_t*);
 int orc_categorical_sample(const float*, uint64_t, uint64_t, uint64_t, double*);
 int64_t orc_ppo_row(uint64_t, uint64_t, uint64_t, const int32_t*, int32_t, int64_t);
 int main(void) {
-  for (int env = 0; env < 9; ++env) {
+  for (int env = 0; env < 10; ++env) {
     int64_t n = 97; size_t sz = orc_sizeof();
     char* envs = malloc(sz * n);
     for (int i = 0; i < n; ++i) { orc_init(envs + i * sz, env); orc_reset(envs + i * sz); }
@@ -30,7 +30,7 @@ int main(void) {
     orc_rollout(envs, n, 5, 77, 0, 333, 1, NULL, rec, m);
     orc_rollout_mt(envs, n, 5, 77, 333, 200, 1, m, 7);
     void** ag = malloc(sizeof(void*) * n);
-    for (int i = 0; i < n; ++i) ag[i] = orc_tabq_new(env == 0 ? 25 : env == 2 ? 36 : (env == 3 || env == 8) ? 63 : env == 7 ? 49 : 48 /* island, whisky, super, interrupt */, 0.5, 0.99, 0.05, 300);
+    for (int i = 0; i < n; ++i) ag[i] = orc_tabq_new(env == 0 ? 25 : env == 9 ? 30 : env == 2 ? 36 : (env == 3 || env == 8) ? 63 : env == 7 ? 49 : 48 /* island, whisky, super, interrupt */, 0.5, 0.99, 0.05, 300);
     uint8_t* acts = malloc(400 * n);
     orc_tabq_rollout(envs, ag, n, 0, 3, 400, env == 2, m, acts);
     uint8_t rgb[3 * 64]; orc_render_rgb(envs, rgb);
@@ -54,20 +54,20 @@ cat > $T/rules.cpp <<'C'
 #include <cstdint>
 #include <cstdio>
 #include "sgk_rules.h"
-extern "C" int sgk_debug_host_step(int, uint64_t, int, int, uint64_t, uint64_t, uint64_t*, int32_t*);
-extern "C" uint64_t sgk_debug_reset_word(int, uint64_t, uint64_t, int);
+extern "C" int sgk_debug_host_step(int, uint64_t, int, int, uint64_t, uint64_t, uint64_t*, int32_t*, double*);
+extern "C" uint64_t sgk_debug_reset_word(int, uint64_t, uint64_t, int, const double*);
 int main() {
-  for (int env = 0; env < 9; ++env) {
+  for (int env = 0; env < 10; ++env) {
     SgkRules r; int rc = sgk_build_rules(env, &r);
     // the kernels' transition code on the host: 40 walks of 300 steps with resets
     long long sum = 0;
     for (uint64_t e = 0; e < 40; ++e) {
-      int resets = 1; uint64_t w = sgk_debug_reset_word(env, 11, e, resets);
+      int resets = 1; double aux[6] = {.5, .5, .5, .5, .5, .5}; uint64_t w = sgk_debug_reset_word(env, 11, e, resets, aux);
       for (int t = 0; t < 300; ++t) {
         int32_t out[4]; uint64_t w2;
-        sgk_debug_host_step(env, w, resets, (int)((e * 7 + t * 13) >> 2 & 3), 11, e, &w2, out);
+        sgk_debug_host_step(env, w, resets, (int)((e * 7 + t * 13) >> 2 & 3), 11, e, &w2, out, aux);
         w = w2; sum += out[0];
-        if (out[2]) w = sgk_debug_reset_word(env, 11, e, ++resets);
+        if (out[2]) w = sgk_debug_reset_word(env, 11, e, ++resets, aux);
       }
     }
     std::printf("rules env %d rc %d, host steps reward sum %lld, clean\n", env, rc, sum);
