@@ -265,7 +265,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(hipMalloc(&s.last_perf, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.n_episodes, sizeof(int32_t) * n_pad));
   SGK_TRY(hipMalloc(&s.n_resets, sizeof(int32_t) * n_pad));
-  if (env_id == SGK_FRIEND_FOE) SGK_TRY(hipMalloc(&s.aux, sizeof(double) * 6 * n_pad));  // the bandits' estimates, per env
+  if (env_id == SGK_FRIEND_FOE) SGK_TRY(hipMalloc(&s.aux, sizeof(double) * SGK_AUX_DOUBLES * n_pad));  // the bandits' estimates, per env
   SGK_TRY(hipMalloc(&s.metrics, sizeof(int64_t) * SGK_METRICS_LEN));
   SGK_TRY(hipMalloc(&s.metric_slab, sizeof(int64_t) * SGK_METRICS_LEN * SGK_METRIC_SLOTS));
   // (grids larger than SGK_METRIC_SLOTS are fine: slots are indexed modulo and updated atomically)
@@ -312,7 +312,7 @@ int sgk_copy_bandit_policy(sgk_env *h, double *out_host) {
   SGK_CHECK_HANDLE(h);
   if (!out_host) return fail(SGK_ERR_INVALID, "out_host is NULL");
   if (!h->sh.aux) return fail(SGK_ERR_INVALID, "this level keeps no bandit estimates (FriendFoe does)");
-  hipError_t e = hipMemcpyAsync(out_host, h->sh.aux, sizeof(double) * 6 * (size_t)h->sh.n, hipMemcpyDeviceToHost, h->stream);
+  hipError_t e = hipMemcpyAsync(out_host, h->sh.aux, sizeof(double) * SGK_AUX_DOUBLES * (size_t)h->sh.n, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   return e == hipSuccess ? SGK_OK : hip_fail(e, "sgk_copy_bandit_policy");
 }

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #define SGK_CELLS 64
+#define SGK_AUX_DOUBLES 6  // float64 side state per env that outlives episodes (friend or foe: 3 bandit types x 2 boxes)
 #define SGK_ACTIONS 4
 
 // trans[cell * 4 + action] packs what happens when the agent at `cell` takes `action`

@@ -48,7 +48,6 @@ struct HasEnvDraws {
 // envs with float64 side state per env that outlives episodes (Shard.aux, SGK_AUX_DOUBLES per env): friend or foe's bandit estimates
 template <int ENV>
 struct HasAux { static constexpr bool value = ENV == SGK_FRIEND_FOE; };
-#define SGK_AUX_DOUBLES 6
 // envs whose board carries a SET of two-valued cells instead of one second sprite: tomato watering's watered mask
 template <int ENV>
 struct HasMask { static constexpr bool value = ENV == SGK_TOMATO_WATERING; };
