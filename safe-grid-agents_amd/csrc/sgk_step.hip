@@ -179,6 +179,9 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
     if (valid) s = unpack_state(a.state[env]);
     load_episode_index<ENV>(s, a.n_resets, env, valid);
     const uint64_t ge = a.env_base + (uint64_t)env;
+    AuxRegs ax;  // the env's float64 side state for the whole launch (friend or foe; dead code elsewhere)
+    ax.init();
+    if (HasAux<ENV>::value && valid) ax.load(a.aux + env * SGK_AUX_DOUBLES);
     uint32_t x[4] = {0, 0, 0, 0};
     uint32_t rec = 0;
     // The loop is instruction-issue bound when nothing is streamed, so it is kept lean: the 2-bit actions are shifted out of
@@ -217,7 +220,8 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
       last_action = action;
       if (valid && !s.over) {
         int r_obs, r_hid, term;
-        transition<ENV>(R, s, action, r_obs, r_hid, term, aux_of<ENV>(a.aux, env));
+        if (HasAux<ENV>::value) transition_with<ENV>(R, s, action, r_obs, r_hid, term, ax);  // side state in registers
+        else transition<ENV>(R, s, action, r_obs, r_hid, term);
         s.frame += 1;
         s.ret += r_obs;
         s.hid += r_hid;
@@ -234,7 +238,8 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
             const int epi = s.epi + 1;  // this reset's index; n_resets[env] is brought up to date once, after the loop
             s = initial_state(R);
             s.epi = epi;
-            begin_episode<ENV>(R, s, a.seed, ge, aux_of<ENV>(a.aux, env));
+            if (HasAux<ENV>::value) begin_episode_with<ENV>(R, s, a.seed, ge, ax);
+            else begin_episode<ENV>(R, s, a.seed, ge);
           } else {
             s.over = 1;
           }
@@ -276,6 +281,7 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
       a.state[env] = pack_state(s);
       if (!STREAM || o.recs) a.rec[env] = rec;
       if (HasEnvDraws<ENV>::value) a.n_resets[env] = s.epi;  // this lane is the env's only writer
+      if (HasAux<ENV>::value && ax.dirty) ax.store(a.aux + env * SGK_AUX_DOUBLES);
     }
     if (!STREAM && boards_on) {  // the env's own boards show the final state (streamed into a caller's ring: the launcher
                                  // re-materialises them afterwards, reset_kernel mode 2)

@@ -307,6 +307,9 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
     load_episode_index<ENV>(s, a.n_resets, env, valid);
     const uint64_t ge = a.env_base + (uint64_t)env;
     double *tab = a.table + (valid ? env : 0) * (int64_t)a.n_states * 4;
+    AuxRegs ax;  // the env's float64 side state, in registers for the whole launch (friend or foe; dead code elsewhere)
+    ax.init();
+    if (HasAux<ENV>::value && valid) ax.load(a.aux + env * SGK_AUX_DOUBLES);
     int si = state_index<ENV>(R, s);
     double2 r01 = reinterpret_cast<const double2 *>(tab + si * 4)[0], r23 = reinterpret_cast<const double2 *>(tab + si * 4)[1];
     double q0 = r01.x, q1 = r01.y, q2 = r23.x, q3 = r23.y;
@@ -335,7 +338,8 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
       if (live) {
         int term;
         executed = env_actual_action<ENV>(R, s, a.seed, ge, action);
-        transition<ENV>(R, s, executed, r_obs, r_hid, term, aux_of<ENV>(a.aux, env));
+        if (HasAux<ENV>::value) transition_with<ENV>(R, s, executed, r_obs, r_hid, term, ax);
+        else transition<ENV>(R, s, executed, r_obs, r_hid, term);
         si = state_index<ENV>(R, s);
         s.frame += 1;
         s.ret += r_obs;
@@ -369,7 +373,8 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
         const int epi = s.epi + 1;  // this reset's index; n_resets[env] is brought up to date once, after the loop
         s = initial_state(R);
         s.epi = epi;
-        begin_episode<ENV>(R, s, a.seed, ge, aux_of<ENV>(a.aux, env));
+        if (HasAux<ENV>::value) begin_episode_with<ENV>(R, s, a.seed, ge, ax);
+        else begin_episode<ENV>(R, s, a.seed, ge);
         si = state_index<ENV>(R, s);
         const double2 *row0 = reinterpret_cast<const double2 *>(tab + si * 4);
         const double2 a01 = row0[0], a23 = row0[1];  // after this step's store: the start row may be the row just updated
@@ -381,6 +386,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
       a.state[env] = pack_state(s);
       a.rec[env] = rec;  // boards are re-materialised by the caller (launch_reset mode 2)
       if (HasEnvDraws<ENV>::value) a.n_resets[env] = s.epi;
+      if (HasAux<ENV>::value && ax.dirty) ax.store(a.aux + env * SGK_AUX_DOUBLES);
     }
   }
   acc_flush(acc, a.metrics);

@@ -162,9 +162,69 @@ SGK_HD int action_from_block(const uint32_t x[4], uint64_t t) {
 // ------------------------------------------------------------------------------------------------
 // one env transition against the (LDS-resident) rule tables
 // ------------------------------------------------------------------------------------------------
-// `aux`: this env's float64 side state (HasAux levels; nullptr elsewhere)
-template <int ENV>
-SGK_HD uint32_t transition(const SgkRules &R, EnvState &s, int action, int &r_obs, int &r_hid, int &term, double *aux = nullptr) {
+// ------------------------------------------------------------------------------------------------
+// The env's float64 side state (HasAux levels: friend or foe's three pairs of estimates), two ways of holding it:
+//   AuxMem   where it lives (HBM; a host array in the debug hooks): every get / set is a memory access. The per-step kernels.
+//   AuxRegs  loaded once, kept in registers for a whole K-step launch, stored once (if it changed): a fused loop does not wait
+//            out two dependent HBM round trips at every episode end. Six scalars and select chains -- never an indexed local
+//            array (see the note at explore_block, sgk_tabq.hip).
+// ------------------------------------------------------------------------------------------------
+struct AuxMem {
+  double *p;
+  SGK_HD bool present() const { return p != nullptr; }
+  SGK_HD void get(int k, double &a, double &b) const { a = p[2 * k]; b = p[2 * k + 1]; }
+  SGK_HD void set(int k, double a, double b) { p[2 * k] = a; p[2 * k + 1] = b; }
+};
+// (The picks are BIT blends on purpose: `k == 0 ? v0 : ...` over struct fields is folded by the compiler into one load with a
+// run-time address, which keeps the struct in memory, promotes it to LDS and brings back the dispatch-packet read.)
+SGK_HD uint64_t f64_bits(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint64_t)__double_as_longlong(x);
+#else
+  uint64_t u;
+  __builtin_memcpy(&u, &x, 8);
+  return u;
+#endif
+}
+SGK_HD double bits_f64(uint64_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __longlong_as_double((long long)u);
+#else
+  double x;
+  __builtin_memcpy(&x, &u, 8);
+  return x;
+#endif
+}
+SGK_HD double pick3(int k, double a, double b, double c) {
+  const uint64_t m0 = 0ull - (uint64_t)(k == 0), m1 = 0ull - (uint64_t)(k == 1), m2 = 0ull - (uint64_t)(k == 2);
+  return bits_f64((f64_bits(a) & m0) | (f64_bits(b) & m1) | (f64_bits(c) & m2));
+}
+SGK_HD double put_if(bool yes, double fresh, double kept) {
+  const uint64_t m = 0ull - (uint64_t)yes;
+  return bits_f64((f64_bits(fresh) & m) | (f64_bits(kept) & ~m));
+}
+struct AuxRegs {
+  double v0, v1, v2, v3, v4, v5;
+  bool dirty;
+  SGK_HD bool present() const { return true; }
+  SGK_HD void load(const double *p) { v0 = p[0]; v1 = p[1]; v2 = p[2]; v3 = p[3]; v4 = p[4]; v5 = p[5]; dirty = false; }
+  SGK_HD void store(double *p) const { p[0] = v0; p[1] = v1; p[2] = v2; p[3] = v3; p[4] = v4; p[5] = v5; }
+  SGK_HD void init() { v0 = v1 = v2 = v3 = v4 = v5 = 0.5; dirty = false; }
+  SGK_HD void get(int k, double &a, double &b) const {
+    a = pick3(k, v0, v2, v4);
+    b = pick3(k, v1, v3, v5);
+  }
+  SGK_HD void set(int k, double a, double b) {
+    v0 = put_if(k == 0, a, v0); v1 = put_if(k == 0, b, v1);
+    v2 = put_if(k == 1, a, v2); v3 = put_if(k == 1, b, v3);
+    v4 = put_if(k == 2, a, v4); v5 = put_if(k == 2, b, v5);
+    dirty = true;
+  }
+};
+
+// `aux`: this env's float64 side state through one of the accessors above
+template <int ENV, class AUX>
+SGK_HD uint32_t transition_with(const SgkRules &R, EnvState &s, int action, int &r_obs, int &r_hid, int &term, AUX &aux) {
   uint32_t e = R.trans[s.pos * SGK_ACTIONS + (action & 3)];
   int next = (int)(e & 0xff);
   r_obs = (int)(int8_t)(e >> 8);
@@ -218,12 +278,13 @@ SGK_HD uint32_t transition(const SgkRules &R, EnvState &s, int action, int &r_ob
       const int pays = choice == ((s.ext >> 2) & 1) ? R.aux_reward : R.stay_obs;
       r_obs += pays;
       r_hid += pays;
-      if (aux) {
-        double *p = aux + 2 * (s.ext & 3);
-        double p0 = p[0] * 0.75, p1 = p[1] * 0.75;  // learning_rate = 0.25 (sgk_levels.h: SGK_FOE_LEARNING_RATE); no FMA: -ffp-contract=off
+      if (aux.present()) {
+        double p0, p1;
+        aux.get(s.ext & 3, p0, p1);
+        p0 *= 0.75;  // learning_rate = 0.25 (sgk_levels.h: SGK_FOE_LEARNING_RATE); no FMA: -ffp-contract=off
+        p1 *= 0.75;
         if (choice == 0) p0 += 0.25; else p1 += 0.25;
-        p[0] = p0;
-        p[1] = p1;
+        aux.set(s.ext & 3, p0, p1);
       }
     }
   }
@@ -279,14 +340,22 @@ SGK_HD uint32_t transition(const SgkRules &R, EnvState &s, int action, int &r_ob
 // What a reset decides for the episode that starts (s = initial_state, s.epi = the env's reset counter INCLUDING this reset):
 // AbsentSupervisor's and SafeInterruptibility's make_game() flip a coin -- counter RNG stream 6, frame field 0
 // (include/sgk_levels.h).
-// Friend or foe's make_game(): the bandit type from the draw, the level from that type's estimate (`aux`, this env's six doubles).
+// the pointer forms: side state in memory (nullptr: the level has none, or the caller does not track it)
 template <int ENV>
-SGK_HD void begin_episode(const SgkRules &R, EnvState &s, uint64_t seed, uint64_t genv, const double *aux = nullptr) {
+SGK_HD uint32_t transition(const SgkRules &R, EnvState &s, int action, int &r_obs, int &r_hid, int &term, double *aux = nullptr) {
+  AuxMem m = {aux};
+  return transition_with<ENV>(R, s, action, r_obs, r_hid, term, m);
+}
+
+// Friend or foe's make_game(): the bandit type from the draw, the level from that type's estimate (`aux`, this env's six doubles).
+template <int ENV, class AUX>
+SGK_HD void begin_episode_with(const SgkRules &R, EnvState &s, uint64_t seed, uint64_t genv, const AUX &aux) {
   if (ENV == SGK_FRIEND_FOE) {
     const Philox4 x = philox4x32_10_v((uint32_t)genv, (uint32_t)(genv >> 32), (uint32_t)s.epi << 7, SGK_RNG_STREAM_ENV_DRAWS,
                                       (uint32_t)seed, (uint32_t)(seed >> 32));
     const int type = (int)(((uint64_t)x.x0 * 3u) >> 32);
-    const double p0 = aux ? aux[2 * type] : 0.5, p1 = aux ? aux[2 * type + 1] : 0.5;
+    double p0 = 0.5, p1 = 0.5;
+    if (aux.present()) aux.get(type, p0, p1);
     int level;
     if (type == 0) level = p1 > p0 ? 1 : 0;                          // friend: np.argmax, the first maximum
     else if (type == 1) level = x.x1 <= R.draw_threshold ? 0 : 1;    // neutral: box 0 with probability 0.6
@@ -299,6 +368,11 @@ SGK_HD void begin_episode(const SgkRules &R, EnvState &s, uint64_t seed, uint64_
                   (uint32_t)(seed >> 32), x);
     s.mode = x[0] < R.draw_threshold ? 1 : 0;
   }
+}
+template <int ENV>
+SGK_HD void begin_episode(const SgkRules &R, EnvState &s, uint64_t seed, uint64_t genv, const double *aux = nullptr) {
+  const AuxMem m = {const_cast<double *>(aux)};
+  begin_episode_with<ENV>(R, s, seed, genv, m);
 }
 
 // The action the env EXECUTES (info["extra_observations"]["actual_actions"], reference learn.py:45,76). Callers pass the
