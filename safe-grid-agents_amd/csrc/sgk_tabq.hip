@@ -215,13 +215,12 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
     ExploreBlock x = {0, 0, 0, 0};
     for (int64_t k = 0; k < n_steps; ++k) {
       const int64_t t = a.t_agent + k;
-      double eps;
-      if (a.eps_table) {
-        const int64_t tc = t < a.anneal ? t : a.anneal - 1;
-        eps = a.eps_table[tc];  // wave-uniform address: one scalar load
-      } else {
-        eps = epsilon_at(a.eps0, a.anneal, t);
-      }
+      // epsilon(t) heads the step's dependency chain (epsilon -> action -> transition -> rows), and in this kernel a SIMD holds a
+      // single wave (LDS-bound occupancy): nothing hides a memory round trip. Reading the tabulated schedule cost one per step --
+      // 1.2 of 5.1 us at the config-3 shape; removing the load: 3.9 -- and neither fetching it a step ahead nor 64 steps at a time
+      // (one value per lane, v_readlane per step) got that back (5.9 / 5.7 us: profiles/r02/exp_tabq_lds_parts.log). The closed
+      // form -- the very expression the table is built from, an IEEE-correct float64 divide -- is register-only: 4.7 us.
+      const double eps = epsilon_at(a.eps0, a.anneal, t);
       if (k == 0 || (t & 1) == 0) x = explore_block(a.seed, ge, t);
       double u;
       int ea;
