@@ -938,7 +938,6 @@ int sgk_tabq_destroy(sgk_tabq *q) {
   (void)hipFree(q->tq.table);
   (void)hipFree(q->tq.tags);
   (void)hipFree(q->tq.row_cache);
-  (void)hipFree(q->tq.eps_table);
   (void)hipFree(q->actions);
   (void)hipFree(q->t_dev);
   delete q;
@@ -970,14 +969,6 @@ int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, in
 
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.table, 0, tbytes, env->stream);  // defaultdict(zeros) (value.py:31)
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.tags, 0xff, sizeof(uint32_t) * (size_t)env->sh.n, env->stream);
-  if (e == hipSuccess && epsilon_anneal <= (int64_t)(4 << 20)) {
-    // the schedule the reference keeps as a Python list (value.py:23-26), tabulated once: the fused kernel reads
-    // eps(t) with one scalar load instead of a float64 divide per step
-    std::vector<double> tab((size_t)epsilon_anneal);
-    for (int64_t t = 0; t < epsilon_anneal; ++t) tab[(size_t)t] = sgk::host_epsilon_at(epsilon, epsilon_anneal, t);
-    e = hipMalloc(&q->tq.eps_table, sizeof(double) * tab.size());
-    if (e == hipSuccess) e = hipMemcpy(q->tq.eps_table, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice);
-  }
   if (e != hipSuccess) {
     int rc = hip_fail(e, "tabular-Q allocation");
     std::string keep = g_last_error;

@@ -40,7 +40,6 @@ struct TabqShard {
   uint32_t *tags = nullptr;     // [n] low half: state index the last action was chosen from (0xffff = env was over);
                                 //     high half: state index of the row in row_cache (0xffff = none)
   double *row_cache = nullptr;  // [n][4] the Q row of the state named by the tag: what the per-step kernels hand each other
-  double *eps_table = nullptr;  // [anneal] epsilon schedule (null when anneal is too long to tabulate)
   double lr = 0, discount = 0, eps0 = 0;
   int64_t anneal = 0;
   int64_t t_agent = 0;

@@ -86,7 +86,6 @@ struct TabqArgs {
   const long long *t_ptr;  // ... or, when non-null (hipGraph replays), *t_ptr + t_agent
   double lr, discount, eps0;
   int64_t anneal;
-  const double *eps_table;  // eps_table[t] for t < anneal (host-computed, bit-identical to the formula); may be null
   int32_t n_states;
   int32_t cheat;
   uint32_t flags;
@@ -316,13 +315,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
     ExploreBlock x = {0, 0, 0, 0};
     for (int64_t k = 0; k < n_steps; ++k) {
       const int64_t t = a.t_agent + k;
-      double eps;
-      if (a.eps_table) {
-        const int64_t tc = t < a.anneal ? t : a.anneal - 1;
-        eps = a.eps_table[tc];
-      } else {
-        eps = epsilon_at(a.eps0, a.anneal, t);
-      }
+      const double eps = epsilon_at(a.eps0, a.anneal, t);  // in registers (a tabulated schedule cost a load per step: see above)
       if (k == 0 || (t & 1) == 0) x = explore_block(a.seed, ge, t);
       double u;
       int ea;
@@ -431,7 +424,6 @@ static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t fl
   a.discount = tq.discount;
   a.eps0 = tq.eps0;
   a.anneal = tq.anneal;
-  a.eps_table = tq.eps_table;
   a.n_states = sh.n_states;
   a.cheat = 0;
   a.flags = flags;
