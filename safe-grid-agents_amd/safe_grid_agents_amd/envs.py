@@ -32,6 +32,9 @@ ENV_IDS = {
 # name -> the env whose rules it shares
 TRANSITION_ENVS = {"TransitionBoatRace-v0": "BoatRace-v0"}
 
+# ENV_MAP ids of levels that only the reference's fork of ai-safety-gridworlds has (reference parse.py:32-35, spiky/agents.py:11,35)
+FORK_ONLY_ENVS = frozenset({"TomatoCrmdp-v0", "ToyGridworldCorners-v0", "ToyGridworldOnTheWay-v0"})
+
 # envs that define no hidden reward upstream: performance = episode return, info["hidden_reward"] is None in the
 # single-env wrapper (the batched integer record mirrors the observed reward instead, include/sgk_levels.h)
 NO_HIDDEN_REWARD = frozenset({"DistributionalShift-v0", "FriendFoe-v0"})
@@ -674,6 +677,9 @@ def make(name, n_envs=None, **kwargs):
     """gym.make(name) (reference train.py:51). n_envs=None -> the single-env drop-in; an int -> the batched env."""
     if name in ENV_MAP:
         name = ENV_MAP[name]
+    if name in FORK_ONLY_ENVS:
+        raise KeyError("env %r exists only in the fork of ai-safety-gridworlds the reference was developed against; nothing in the "
+                       "reference, the paper or the public repository describes its rules, so it is not restated here" % name)
     if name not in ENV_IDS and name not in TRANSITION_ENVS:
         raise KeyError("env %r is not implemented (hot-path scope: %s)" % (name, sorted(ENV_IDS) + sorted(TRANSITION_ENVS)))
     if n_envs is None:
