@@ -26,4 +26,10 @@ for mode in stream ring launch; do for ctr in FETCH_SIZE WRITE_SIZE; do
   python tools/pmc_summary.py $O/pmc_${mode}_$ctr > $O/pmc_${mode}_${ctr}_summary.json
   find $O/pmc_${mode}_$ctr -name "*.csv" -size +1M -delete
 done; done
-python tools/make_traffic_json.py $O 1048576
+# the per-GPU shares of the 1 M batch at 2 / 4 / 8 GPUs, so that roofline.traffic is filled at every N
+for n in 524288 262144 131072; do for mode in stream launch; do for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_${mode}_n${n}_$ctr -- python3 tools/pmc_run.py BoatRace-v0 compact $n $mode > $O/pmc_${mode}_n${n}_$ctr.log 2>&1
+  python tools/pmc_summary.py $O/pmc_${mode}_n${n}_$ctr > $O/pmc_${mode}_n${n}_${ctr}_summary.json
+  find $O/pmc_${mode}_n${n}_$ctr -name "*.csv" -size +1M -delete
+done; done; done
+python tools/make_traffic_json.py $O 1048576 524288 262144 131072
