@@ -180,7 +180,8 @@ def test_epsilon_greedy_kernel_bit_exact_vs_oracle_and_eager_equals_graphed_stre
     env.close()
 
 
-@pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "BoatRace-v0", "IslandNavigation-v0", "DistributionalShift-v0"])
+@pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "BoatRace-v0", "IslandNavigation-v0", "DistributionalShift-v0",
+                                  "ConveyorBelt-v0", "FriendFoe-v0"])
 @pytest.mark.parametrize("layout", ["compact", "pitched"])
 def test_fused_policy_kernel_matches_torch_forward(name, layout):
     """sgk_policy_act (boards -> MLP -> argmax / eps-greedy in one launch) vs the same network evaluated by torch on the CPU
@@ -302,7 +303,8 @@ def test_fused_greedy_eval_and_act_rollout_equal_the_stepwise_paths(name):
     assert (f[3] == s[3]).all() and (f[4] == s[4]).all() and (f[5] == s[5]).all()
 
 
-@pytest.mark.parametrize("name,hidden,batch", [("SideEffectsSokoban-v0", 100, 64), ("BoatRace-v0", 64, 32), ("DistributionalShift-v0", 100, 48)])
+@pytest.mark.parametrize("name,hidden,batch", [("SideEffectsSokoban-v0", 100, 64), ("BoatRace-v0", 64, 32), ("DistributionalShift-v0", 100, 48),
+                                               ("TomatoWatering-v0", 100, 64), ("ConveyorBelt-v0", 64, 48), ("FriendFoe-v0", 100, 32)])
 def test_fused_dqn_sgd_step_equals_torch_autograd_adam(name, hidden, batch):
     """sgk_dqn_sgd_step (sampling, both forwards, TD target, MSE, backward, clip_grad_norm_(10), Adam amsgrad in ONE kernel)
     vs the same update by torch on the CPU in fp32 with the minibatch the kernel's counter RNG selects (indices restated by
@@ -341,7 +343,7 @@ def test_fused_dqn_sgd_step_equals_torch_autograd_adam(name, hidden, batch):
         with torch.no_grad():
             nq = cpu_t(su[ix].float()).max(1)[0]
             nq = torch.where(te[ix], torch.zeros_like(nq), nq)
-            expected = 0.9 * nq + rw[ix].float()
+            expected = 0.9 * nq + rw[ix].float() * float(env.reward_scale)  # the replay holds integer rewards (tomato: counts)
         loss = torch.nn.functional.mse_loss(q_sa, expected)
         opt.zero_grad()
         loss.backward()

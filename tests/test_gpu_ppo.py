@@ -57,7 +57,7 @@ def test_categorical_sample_kernel_vs_oracle_and_law():
 
 
 @pytest.mark.parametrize("name", ["BoatRace-v0", "SideEffectsSokoban-v0", "IslandNavigation-v0", "DistributionalShift-v0",
-                                  "WhiskyGold-v0"])
+                                  "WhiskyGold-v0", "ConveyorBelt-v0", "FriendFoe-v0"])
 def test_fused_policy_sample_matches_torch_forward_and_oracle_draw(name):
     import torch
 
@@ -181,7 +181,8 @@ def test_batched_ppo_update_equals_the_single_env_agents_update():
 
 
 @pytest.mark.parametrize("name,hidden,batch", [("IslandNavigation-v0", 100, 64), ("BoatRace-v0", 64, 48),
-                                               ("SideEffectsSokoban-v0", 100, 33), ("DistributionalShift-v0", 100, 64)])
+                                               ("SideEffectsSokoban-v0", 100, 33), ("DistributionalShift-v0", 100, 64),
+                                               ("ConveyorBelt-v0", 100, 48), ("FriendFoe-v0", 64, 64), ("TomatoWatering-v0", 100, 64)])
 def test_fused_ppo_epochs_kernel_equals_the_single_env_agents_update(name, hidden, batch):
     """sgk_ppo_epochs (every epoch of learn() in one kernel: both forwards, clipped surrogate with minibatch-normalised
     advantages, critic MSE, entropy bonus, backward incl. the advantage's path into the critic, Adam) == PPOBaseAgent's
