@@ -38,7 +38,8 @@ struct LearnArgs {
   int32_t n_hidden, batch;
   uint64_t seed;  // minibatch indices: Philox stream 4, ctr = {sample, 0, Adam step before this update, 4}
   float lr, beta1, beta2, eps, discount, max_norm;
-  float reward_scale;  // what one unit of the int8 rewards is worth (SgkRules.reward_scale; 1 except tomato watering)
+  double reward_scale;  // what one unit of the int8 rewards is worth (SgkRules.reward_scale; 1 except tomato watering): the
+                        // reference's reward is the float64 product, rounded to float32 when the batch tensor is made (value.py:170-171)
 };
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
     }
     L.idx[t] = id;
     L.act[t] = a.actions[id] & 3;
-    L.rew[t] = (float)a.rewards[id] * a.reward_scale;
+    L.rew[t] = (float)((double)a.rewards[id] * a.reward_scale);
     L.term[t] = a.terminals[id] ? 1 : 0;
   }
   // the small tensors and the first weight matrix travel meanwhile
@@ -934,7 +935,7 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
   for (int i = 0; i < 6; ++i) { a.m[i] = L.m[i]; a.v[i] = L.v[i]; a.vmax[i] = L.vmax[i]; }
   a.tw1t = L.tw1t; a.tb1 = L.tb1; a.tw2t = L.tw2t; a.tb2 = L.tb2; a.tw3 = L.tw3; a.tb3 = L.tb3;
   a.step = L.step; a.loss_out = L.loss_out; a.n_hidden = L.n_hidden; a.batch = L.batch;
-  a.reward_scale = (float)sh.rules_host.reward_scale;
+  a.reward_scale = sh.rules_host.reward_scale;
   a.seed = sh.seed;
   a.lr = (float)L.lr; a.beta1 = (float)L.beta1; a.beta2 = (float)L.beta2; a.eps = (float)L.eps; a.discount = (float)L.discount;
   a.max_norm = (float)L.max_grad_norm;

@@ -254,7 +254,7 @@ class BatchedDeepQAgent:
         with torch.no_grad():
             next_q = self.target_Q(successors.float()).max(1)[0]
             next_q = torch.where(terminals, torch.zeros_like(next_q), next_q)
-            expected = self.discount * next_q + rewards.float() * float(self.env.reward_scale)
+            expected = self.discount * next_q + (rewards.double() * float(self.env.reward_scale)).float()  # f64 product, then f32
         loss = torch.nn.functional.mse_loss(q_sa, expected)
         self.optim.zero_grad(set_to_none=True)
         loss.backward()

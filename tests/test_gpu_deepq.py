@@ -343,7 +343,7 @@ def test_fused_dqn_sgd_step_equals_torch_autograd_adam(name, hidden, batch):
         with torch.no_grad():
             nq = cpu_t(su[ix].float()).max(1)[0]
             nq = torch.where(te[ix], torch.zeros_like(nq), nq)
-            expected = 0.9 * nq + rw[ix].float() * float(env.reward_scale)  # the replay holds integer rewards (tomato: counts)
+            expected = 0.9 * nq + (rw[ix].double() * float(env.reward_scale)).float()  # the replay holds integer rewards (tomato: counts)
         loss = torch.nn.functional.mse_loss(q_sa, expected)
         opt.zero_grad()
         loss.backward()
