@@ -125,7 +125,7 @@ def chunk_schedule(k):
     return out
 
 
-def timed_steps(env, steps, warmup, barrier, global_metrics, path="stream", ring=None):
+def timed_steps(env, steps, warmup, barrier, global_metrics, path="stream", ring=None, ring_layout="slice"):
     """W untimed warm-up steps, then EXACTLY `steps` lockstep steps + the metrics flush between barrier + synchronize pairs.
     Every hipGraph the timed region replays is captured and instantiated BEFORE the region (sgk_step_random_prepare for each
     chunk size of the schedule), and the first HIP event is recorded immediately before the first replay, so neither the
@@ -139,8 +139,8 @@ def timed_steps(env, steps, warmup, barrier, global_metrics, path="stream", ring
     def run(k):
         for c in chunk_schedule(k):
             if ring is not None:  # every step's boards + records kept in the caller's trajectory ring
-                env.rollout_random_stream(c, boards=ring[0], recs=ring[1], first_slice=slice_next[0])
-                slice_next[0] = (slice_next[0] + c) % ring[0].shape[0]
+                env.rollout_random_stream(c, boards=ring[0], recs=ring[1], first_slice=slice_next[0], layout=ring_layout)
+                slice_next[0] = (slice_next[0] + c) % ring[0].shape[1 if ring_layout == "tile" else 0]
             elif path == "stream":
                 env.step_random(c, auto_reset=True, fused="stream")
             else:
@@ -291,6 +291,18 @@ def main():
             "note": "sgk_rollout_random_stream into boards [%d][n][cells] + records [%d][n]: every step's outputs KEPT "
                     "(the batched dqn_warmup, reference warmup.py:14-21); nothing is overwritten within a launch" % (slices, slices)}
         del ring
+        # the same with the rings laid out TILE-major ([n_tiles][ring][64][...]: one contiguous run per wave and launch)
+        n_tiles = (n_local + 63) // 64
+        tring = (torch.empty((n_tiles, slices, 64, env.n_cells), dtype=torch.int8, device="cuda:%d" % local_rank),
+                 torch.empty((n_tiles, slices, 64, 4), dtype=torch.int8, device="cuda:%d" % local_rank))
+        t_el, t_ms, _ = timed_steps(env, k2, w2, barrier, sdist.global_metrics, ring=tring, ring_layout="tile")
+        t_el, t_ms = max_over_ranks(t_el, t_ms)
+        total_steps += k2 + w2
+        secondary["streamed_into_tile_major_trajectory_ring"] = {
+            "value": n_total * k2 / t_el, "unit": "env-steps/s", "lockstep_steps": k2,
+            "us_per_lockstep_step": t_el * 1e6 / k2, "device_us_per_lockstep_step": t_ms * 1e3 / k2, "ring_slices": slices,
+            "note": "SGK_F_RING_TILE_MAJOR: boards [n_tiles][%d][64][cells] + records [n_tiles][%d][64]" % (slices, slices)}
+        del tring
     fused = None
     if not args.no_fused:
         # same workload through the fused rollout kernel (state in registers, boards materialised once per launch)

@@ -59,6 +59,7 @@ extern "C" {
 /* flags for sgk_step / sgk_step_random / sgk_rollout_random */
 #define SGK_F_AUTO_RESET 1u /* an env whose episode ends is reset in the same step (after its episode is recorded) */
 #define SGK_F_NO_BOARDS 2u  /* do not materialise observation boards this call (they go stale until the next writing call) */
+#define SGK_F_RING_TILE_MAJOR 8u /* sgk_rollout_random_stream: the trajectory rings are laid out tile-major (see there) */
 #define SGK_F_MASK_FINISHED 4u /* sgk_policy_rollout: rows of states_out / actions_out of an env whose episode is over are zeros */
 
 /* board layouts (sgk_create_ex) */
@@ -178,6 +179,11 @@ SGK_API int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags);
  *   otherwise trajectory rings the caller owns: boards int8 [ring_slices][n_envs][n_cells] (dense rows, 16-byte aligned),
  *       records sgk_step_rec [ring_slices][n_envs] (either may be NULL); step k of this call goes to slice
  *       (first_slice + k) % ring_slices. The env's own buffers then show the final state, as after sgk_rollout_random.
+ *       With SGK_F_RING_TILE_MAJOR in `flags` the rings are TILE-major instead: boards int8 [n_tiles][ring_slices][64][n_cells],
+ *       records sgk_step_rec [n_tiles][ring_slices][64], n_tiles = ceil(n_envs / 64) (env e = row e % 64 of tile e / 64; rows
+ *       past n_envs in the last tile are padding the caller allocates): the K steps of one 64-env tile are adjacent in
+ *       memory, so a wave streams one contiguous run per launch instead of pieces a whole slice apart -- the slice-major
+ *       layout is bound by DRAM write locality, this one writes at the rate of the env's own buffers.
  * What a per-step launch pays and this does not: the launch boundary and the state word's round trip through HBM. Results
  * (state, records, boards, episode arrays, metrics) equal n_steps calls of sgk_step_random(1), bit for bit. */
 SGK_API int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flags, int8_t *boards_ring_dev,

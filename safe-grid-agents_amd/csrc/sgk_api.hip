@@ -602,6 +602,8 @@ int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flags, int8_
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
   if ((boards_ring_dev || recs_ring_dev) && (ring_slices < 1 || first_slice < 0 || first_slice >= ring_slices))
     return fail(SGK_ERR_INVALID, "a trajectory ring needs ring_slices >= 1 and 0 <= first_slice < ring_slices");
+  if ((flags & SGK_F_RING_TILE_MAJOR) && boards_ring_dev && ((uintptr_t)boards_ring_dev % 16) != 0)
+    return fail(SGK_ERR_INVALID, "a tile-major boards ring must be 16-byte aligned");
   if (n_steps == 0) return SGK_OK;
   const bool rings = boards_ring_dev || recs_ring_dev;
   SGK_HIP(sgk::launch_rollout_stream(h->sh, n_steps, flags, boards_ring_dev, reinterpret_cast<uint32_t *>(recs_ring_dev),

@@ -157,6 +157,7 @@ struct StreamOut {
   uint32_t *recs;   // trajectory ring [ring][n], or nullptr = the env's own record buffer
   int32_t ring, slice0;
   int32_t tiles_ok;  // ring slices are 16-byte aligned (n * NC % 16 == 0): whole tiles go through the tile writer
+  int32_t tile_major;  // rings laid out [n_tiles][ring][64][...] (SGK_F_RING_TILE_MAJOR): padded tiles, always whole
 };
 
 template <int ENV, int LAYOUT, bool STREAM>
@@ -252,16 +253,21 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
       if (STREAM) {
         // this step's outputs, as env.step returns them: the record (reward, hidden reward, done, executed action) ...
         const uint32_t rk = pack_rec(last_obs, last_hid, last_done, last_action);
-        uint32_t *recs = o.recs ? o.recs + (int64_t)slice * a.n : a.rec;
+        // (tile-major rings: this tile's K steps are adjacent; the record of env e sits at row e % 64 = its lane)
+        uint32_t *recs = !o.recs ? a.rec + env
+                                 : (o.tile_major ? o.recs + (wt * (int64_t)o.ring + slice) * 64 + lane : o.recs + (int64_t)slice * a.n + env);
 #if SGK_STREAM_REC_SC1
-        if (valid) __hip_atomic_store(&recs[env], rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
+        if (valid) __hip_atomic_store(recs, rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
 #else
-        if (valid) recs[env] = rk;
+        if (valid) *recs = rk;
 #endif
         // ... and the successor board: one tile store per wave wherever the destination takes whole tiles
         if (boards_on) {
-          int8_t *dense = o.boards ? o.boards + (int64_t)slice * a.n * NC : a.boards;  // wave-uniform; rows of NC bytes
-          const bool tiles = o.boards ? (o.tiles_ok && whole_tile) : COMPACT;          // the env's own buffer is padded
+          const bool tm = o.boards && o.tile_major;
+          // wave-uniform; rows of NC bytes. Tile-major: `dense + wt * 64 * NC` below is this tile's slot of this slice
+          int8_t *dense = !o.boards ? a.boards
+                                    : (tm ? o.boards + ((wt * (int64_t)o.ring + slice) - wt) * 64 * NC : o.boards + (int64_t)slice * a.n * NC);
+          const bool tiles = o.boards ? (tm || (o.tiles_ok && whole_tile)) : COMPACT;  // the env's own buffer is padded; so are tile-major rings
 #if SGK_TILE_IN_LDS
           const uint32_t now = sprite_info<ENV>(R, s);
           W.update(R, drawn, now);
@@ -526,7 +532,8 @@ hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flag
   // every wave keeps its tile for all n_steps: more workgroups than the per-step kernel's cap (they stay resident longer,
   // and the stream of stores needs every CU busy), up to one 256-env workgroup per tile
   int grid = grid_for((sh.n + WG - 1) / WG, sh.stream_grid);
-  StreamOut o{boards_ring, recs_ring, ring < 1 ? 1 : ring, slice0, (int32_t)(((sh.n * sh.n_cells) % 16) == 0 && ((uintptr_t)boards_ring % 16) == 0)};
+  StreamOut o{boards_ring, recs_ring, ring < 1 ? 1 : ring, slice0, (int32_t)(((sh.n * sh.n_cells) % 16) == 0 && ((uintptr_t)boards_ring % 16) == 0),
+              (int32_t)((flags & SGK_F_RING_TILE_MAJOR) != 0)};
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
                           rollout_random_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a, n_steps, o));
   hipError_t e = hipGetLastError();

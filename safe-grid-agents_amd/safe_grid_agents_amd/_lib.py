@@ -15,7 +15,7 @@ INCLUDE = os.path.join(os.path.dirname(_DIST), "include")
 
 SGK_OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE = -1, -2, -3, -4
-F_AUTO_RESET, F_NO_BOARDS, F_MASK_FINISHED = 1, 2, 4
+F_AUTO_RESET, F_NO_BOARDS, F_MASK_FINISHED, F_RING_TILE_MAJOR = 1, 2, 4, 8
 LAYOUT_PITCHED, LAYOUT_COMPACT = 0, 1
 TABQ_KERNEL_AUTO, TABQ_KERNEL_LDS, TABQ_KERNEL_HBM = 0, 1, 2
 MEM_HOST_VISIBLE = 0x100

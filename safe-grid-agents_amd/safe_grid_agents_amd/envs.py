@@ -297,24 +297,34 @@ class BatchedGridworldEnv:
         _lib.check(fn(self._h.ptr, int(n_steps), flags))
         return self._step_outputs()
 
-    def rollout_random_stream(self, n_steps, boards=None, recs=None, first_slice=0, auto_reset=True):
+    def rollout_random_stream(self, n_steps, boards=None, recs=None, first_slice=0, auto_reset=True, layout="slice"):
         """n_steps random-action lockstep steps in ONE launch, every step's successor boards / step records kept: into the
         trajectory rings `boards` int8 [ring, N, n_cells] and / or `recs` int8 [ring, N, 4] (device tensors; step k goes to
         slice (first_slice + k) % ring) -- the batched dqn_warmup (reference warmup.py:14-21) --, or, with neither, into the
-        env's own buffers."""
+        env's own buffers. layout="tile": the rings are tile-major, boards [n_tiles, ring, 64, n_cells] / recs
+        [n_tiles, ring, 64, 4] with n_tiles = ceil(N / 64) (`ring_slices` re-orders one to [ring, N, ...]): one contiguous
+        run per wave and launch -- the HBM write rate of the env's own buffers instead of the slice-major layout's."""
+        assert layout in ("slice", "tile")
         ring = 1
-        for t, shape_tail in ((boards, (self.n_envs, self.n_cells)), (recs, (self.n_envs, 4))):
+        n_tiles = (self.n_envs + 63) // 64
+        for t, tail in ((boards, self.n_cells), (recs, 4)):
             if t is not None:
-                assert t.is_cuda and t.is_contiguous() and tuple(t.shape[1:]) == shape_tail, "ring must be [ring, N, ...] contiguous"
-                ring = int(t.shape[0])
+                want = (n_tiles, int(t.shape[1]), 64, tail) if layout == "tile" else (int(t.shape[0]), self.n_envs, tail)
+                assert t.is_cuda and t.is_contiguous() and tuple(t.shape) == want, "ring must be %s contiguous" % (want,)
+                ring = int(t.shape[1] if layout == "tile" else t.shape[0])
         if boards is not None and recs is not None:
-            assert boards.shape[0] == recs.shape[0]
+            assert boards.shape[1 if layout == "tile" else 0] == recs.shape[1 if layout == "tile" else 0]
         ptr = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())  # noqa: E731
+        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_RING_TILE_MAJOR if layout == "tile" else 0)
         self._sync_torch_to_lib()
-        _lib.check(self.lib.sgk_rollout_random_stream(self._h.ptr, int(n_steps), _lib.F_AUTO_RESET if auto_reset else 0,
-                                                      ptr(boards), ptr(recs), ring, int(first_slice)))
+        _lib.check(self.lib.sgk_rollout_random_stream(self._h.ptr, int(n_steps), flags, ptr(boards), ptr(recs), ring, int(first_slice)))
         self._sync_lib_to_torch()
         return self._step_outputs()
+
+    def ring_slices(self, ring_tensor):
+        """A tile-major trajectory ring [n_tiles, ring, 64, X] re-ordered to the slice-major form [ring, N, X] (a copy)."""
+        n_tiles, ring, _, x = ring_tensor.shape
+        return ring_tensor.permute(1, 0, 2, 3).reshape(ring, n_tiles * 64, x)[:, : self.n_envs]
 
     def prepare_step_random(self, n_steps, auto_reset=True, write_boards=True):
         """Build the hipGraph step_random(n_steps, ...) replays without stepping (sgk_step_random_prepare): callers that time

@@ -68,7 +68,7 @@ def test_bench_line_one_rank():
     assert d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 8192 and d["roofline"]["steps_per_launch"] == 100
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "env-steps/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
-    for k in ("per_step_launches", "streamed_into_trajectory_ring", "fused_rollout"):
+    for k in ("per_step_launches", "streamed_into_trajectory_ring", "streamed_into_tile_major_trajectory_ring", "fused_rollout"):
         assert d[k]["value"] > 0
     # the other path as the primary one, and round 1's step definition
     d2 = _line(["--steps", "40", "--warmup", "10", "--total-envs", "8192", "--path", "launch", "--lockstep-per-step", "1",

@@ -166,6 +166,45 @@ def test_streamed_rollout_keeps_every_step_in_the_trajectory_rings(name, n, ring
     env.close()
 
 
+@pytest.mark.parametrize("name,n,ring", [("BoatRace-v0", 1600, 7), ("BoatRace-v0", 1616, 4), ("IslandNavigation-v0", 37, 3),
+                                         ("TomatoWatering-v0", 1000, 5), ("FriendFoe-v0", 130, 2), ("SideEffectsSokoban-v0", 64, 1)])
+def test_tile_major_trajectory_rings_hold_the_same_steps(name, n, ring):
+    """SGK_F_RING_TILE_MAJOR: boards [n_tiles][ring][64][cells] / records [n_tiles][ring][64] -- one contiguous run per wave and
+    launch -- hold, re-ordered, exactly what the slice-major rings hold: slice (first + k) % ring = step k, bit for bit what the
+    oracle produces; the padding rows of a partial last tile are the caller's and nothing is written behind the rings."""
+    torch = _torch()
+    seed, T, first = 13, 23, 1 % ring
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    orc = O.EnvBatch(name, n, seed=seed)
+    n_tiles = (n + 63) // 64
+    boards = torch.full((n_tiles, ring, 64, env.n_cells), -7, dtype=torch.int8, device="cuda")
+    recs = torch.full((n_tiles, ring, 64, 4), -7, dtype=torch.int8, device="cuda")
+    guard = torch.full((64,), -7, dtype=torch.int8, device="cuda")
+    env.rollout_random_stream(T, boards=boards, recs=recs, first_slice=first, layout="tile")
+    want_b, want_r = {}, {}
+    m = O.metrics_new()
+    for k in range(T):
+        rec = orc.rollout(1, seed=seed, t_begin=k, auto_reset=True, metrics=m)
+        want_b[(first + k) % ring] = orc.boards()
+        want_r[(first + k) % ring] = rec
+    got_b, got_r = env.ring_slices(boards).cpu().numpy(), env.ring_slices(recs).cpu().numpy()
+    for sl in range(min(ring, T)):
+        assert (got_b[sl] == want_b[sl]).all(), (name, n, sl)
+        assert (got_r[sl] == want_r[sl]).all(), (name, n, sl)
+    if n % 64:  # records of the padding rows stay the caller's
+        assert bool((recs[-1, :, n % 64:] == -7).all())
+    assert bool((guard == -7).all())
+    assert_same_state(env, orc, "after the tile-major streamed rollout")
+    # records only, boards only
+    r2 = torch.zeros((n_tiles, 2, 64, 4), dtype=torch.int8, device="cuda")
+    env.rollout_random_stream(2, recs=r2, layout="tile")
+    for k in range(2):
+        rec = orc.rollout(1, seed=seed, t_begin=T + k, auto_reset=True)
+        assert (env.ring_slices(r2)[k].cpu().numpy() == rec).all()
+    assert_same_state(env, orc, "after the second tile-major rollout")
+    env.close()
+
+
 @pytest.mark.parametrize("name", ["SideEffectsSokoban-v0", "WhiskyGold-v0", "AbsentSupervisor-v0", "SafeInterruptibility-v0",
                                   "ConveyorBelt-v0", "TomatoWatering-v0", "FriendFoe-v0"])
 def test_sharding_reproduces_the_unsharded_batch(name):

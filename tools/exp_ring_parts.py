@@ -23,6 +23,11 @@ for name in ("BoatRace-v0", "IslandNavigation-v0"):
         bo = timed(env, lambda: env.rollout_random_stream(K, boards=boards), 10) / K
         ro = timed(env, lambda: env.rollout_random_stream(K, recs=recs), 10) / K
         own = timed(env, lambda: env.step_random(K, fused="stream"), 10) / K
+        nt = (n + 63) // 64
+        tb = torch.empty((nt, K, 64, env.n_cells), dtype=torch.int8, device="cuda")
+        tr = torch.empty((nt, K, 64, 4), dtype=torch.int8, device="cuda")
+        tile = timed(env, lambda: env.rollout_random_stream(K, boards=tb, recs=tr, layout="tile"), 10) / K
+        del tb, tr
         nb = env.n_cells * n / 1e6
-        print("%s ring both %.2f us (%.2f TB/s) | boards only %.2f us (%.2f TB/s) | recs only %.2f us | own %.2f us" % (name, both, (nb + 4.19) / both, bo, nb / bo, ro, own), flush=True)
+        print("%s ring both %.2f us (%.2f TB/s) | boards only %.2f us (%.2f TB/s) | recs only %.2f us | own %.2f us | TILE-MAJOR ring both %.2f us (%.2f TB/s)" % (name, both, (nb + 4.19) / both, bo, nb / bo, ro, own, tile, (nb + 4.19) / tile), flush=True)
     env.close()
