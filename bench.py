@@ -6,21 +6,28 @@
         bench.py --gpus N --steps K --warmup W
 
 A bench "step" is one pass of the hot path over the whole env batch = one EPISODE for every env: `--lockstep-per-step`
-(default 100 = BoatRace's fixed horizon, SURVEY.md 8(d) states the measurement in whole 100-step episodes) lockstep
+(default 100 = BoatRace's fixed horizon; SURVEY.md 8(d) states the measurement in whole 100-step episodes) lockstep
 steps, in each of which every env of every rank takes one RandomAgent action (counter RNG, in-kernel) -- transition,
-observed reward, hidden safety reward, episode bookkeeping, auto-reset -- and its outputs are MATERIALISED in HBM every
-lockstep step: the successor board (int8 cells, streaming tile stores) and the step record. `value` is env-steps/s
-(envs x lockstep steps / wall seconds); `ms_per_step` is per bench step, `us_per_lockstep_step` is beside it. (Round 1
-counted ONE lockstep step per bench step: `--lockstep-per-step 1` is that definition; at the driver's `--steps 20` its
-timed region is 80 us of device work behind ~70 us of launch + synchronise latency.) Default path ("stream"): the streaming rollout kernel, 100 lockstep steps per launch with
-the env state words in registers between them (sgk_rollout_random_stream into the env's own buffers: each step
-overwrites the previous one's outputs, exactly what 100 per-step launches leave). `--path launch`: one step-kernel
-launch per step replayed from a hipGraph (the state word makes a round trip through HBM per step); reported as a
-secondary object by the default run, as is the streamed rollout into a TRAJECTORY RING (every step's boards and records
-kept: the batched dqn_warmup). Workload = BASELINE.json's metric config: BoatRace, 1 048 576 concurrent
-envs in the whole job at every GPU count (the batch shards by env id, one contiguous block per rank, no data-path
-collective; the only exchange is one int64 metrics all-reduce at the end of the timed region). At N > 1 a secondary
-object reports the weak-scaling form (1 048 576 envs on every GPU) measured in the same run.
+observed reward, hidden safety reward, episode bookkeeping, auto-reset. `value` is env-steps/s (envs x lockstep steps /
+host wall seconds); `ms_per_step` is per bench step, `us_per_lockstep_step` beside it.
+
+What is timed -- `--path`:
+  ring    (default, `value`)  sgk_rollout_random_stream, 100 lockstep steps per launch, env state words in registers between
+          steps, EVERY step's successor board (int8 tile, write-through stores) and step record KEPT in a caller-owned
+          trajectory ring of 100 slices (boards [100][n][cells] + records [100][n]: 3.04 GB at 1 M BoatRace envs, twelve
+          times the 256 MiB Infinity Cache): the batched dqn_warmup (reference warmup.py:14-21 keeps every random-action
+          transition) and the only streamed form whose per-step outputs a consumer can read afterwards.
+  own     the same kernel into the env's own board / record buffers: step k overwrites step k-1's outputs inside the launch
+          (what 100 per-step launches leave). The 30 MB working set is rewritten in place inside the Infinity Cache, the 4-byte
+          records coalesce in L2: its rate is a fabric / Infinity-Cache write rate, not an HBM rate. Round 2's `value`.
+  launch  one step-kernel launch per lockstep step, replayed from a hipGraph (state words through memory every step). Round
+          1's `value` was this with one lockstep step per bench step.
+The default run reports the other two as secondary objects (`rewritten_in_place`, `per_step_launches`) and the outputs-once
+kernel (`fused_rollout`: no per-step output exists), each with its own counter-based traffic figures.
+
+Workload = BASELINE.json's metric config: BoatRace, 1 048 576 concurrent envs in the whole job at every GPU count (the batch
+shards by env id, one contiguous block per rank, no data-path collective; the only exchange is one int64 metrics all-reduce
+at the end of the timed region). At N > 1 a secondary object reports the weak-scaling form (1 048 576 envs on every GPU).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects added.
 """
@@ -35,10 +42,25 @@ for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# SURVEY.md 8(d)'s per-step-launch contract, 2 H W + 28 bytes per env-step (board read + written, action, counters, returns,
+# rewards, done): what ONE LAUNCH PER STEP would have to move. Kept for the `survey_8d` figures of the line.
 B_ALG = {"BoatRace-v0": 78, "SideEffectsSokoban-v0": 100, "IslandNavigation-v0": 124, "DistributionalShift-v0": 154,
-         "WhiskyGold-v0": 124, "AbsentSupervisor-v0": 124, "SafeInterruptibility-v0": 124, "ConveyorBelt-v0": 126, "TomatoWatering-v0": 154, "FriendFoe-v0": 88}  # 2*H*W + 28
+         "WhiskyGold-v0": 124, "AbsentSupervisor-v0": 124, "SafeInterruptibility-v0": 124, "ConveyorBelt-v0": 126, "TomatoWatering-v0": 154, "FriendFoe-v0": 88}
+CELLS = {k: (v - 28) // 2 for k, v in B_ALG.items()}
+REC_BYTES = 4  # sgk_step_rec: reward i8, hidden reward i8, done u8, executed action u8 (8(d)'s reward / hidden / done, packed)
+STATE_BYTES = 8  # the packed env state word
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-GRAPH_CHUNK = 100      # lockstep steps per hipGraph replay
+GRAPH_CHUNK = 100      # lockstep steps per launch (ring / own) or per hipGraph replay (launch)
+RING_SLICES = 100      # trajectory ring of the primary path: one 100-step episode of every env
+
+
+def algorithmic_bytes_per_env_step(env_name, path):
+    """Bytes per env-step a kernel of this FORM cannot avoid moving (DESIGN.md 3.2 / 5 state them):
+    ring / own: the outputs of 8(d)'s step contract that a consumer receives -- successor board H W + packed step record 4 --;
+    the state word, the counters and the returns stay in registers for the whole launch (their one round trip per launch is
+    16 B / 100 steps); launch: the same + the state word's read and write every step."""
+    out = CELLS[env_name] + REC_BYTES
+    return out + (2 * STATE_BYTES if path == "launch" else 0)
 
 
 def cpu_baseline(env_name, seed, target_seconds=10.0):
@@ -117,36 +139,58 @@ def parity_sample(env, env_name, seed, base, total_steps, block=2048):
     return True, checked
 
 
+def ring_parity_sample(env_name, seed, base, ring, first_step, n_slices, block=512):
+    """The trajectory ring's CONTENTS against the oracle: slice (first_step + k) % slices must hold the board and the step record
+    of lockstep step first_step + k for the first `block` envs of the shard (the last `n_slices` steps of the run)."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    boards, recs = ring
+    slices, n = int(boards.shape[0]), int(boards.shape[1])
+    m = min(block, n)
+    orc = O.EnvBatch(env_name, m, seed=seed, env_begin=base)
+    if first_step:
+        orc.rollout(first_step, seed=seed, env_begin=base, t_begin=0, auto_reset=True)
+    for k in range(n_slices):
+        rec = orc.rollout(1, seed=seed, env_begin=base, t_begin=first_step + k, auto_reset=True)
+        sl = (first_step + k) % slices
+        if not ((boards[sl, :m].cpu().numpy() == orc.boards()).all() and (recs[sl, :m].cpu().numpy() == np.asarray(rec)).all()):
+            return False
+    return True
+
+
 def chunk_schedule(k):
-    """Chunk sizes `run(k)` issues, in order: GRAPH_CHUNK-step launches (stream) / hipGraph replays (launch) and one tail."""
+    """Chunk sizes `run(k)` issues, in order: GRAPH_CHUNK-step launches (ring / own) / hipGraph replays (launch) and one tail."""
     out = [GRAPH_CHUNK] * (k // GRAPH_CHUNK)
     if k % GRAPH_CHUNK:
         out.append(k % GRAPH_CHUNK)
     return out
 
 
-def timed_steps(env, steps, warmup, barrier, global_metrics, path="stream", ring=None, ring_layout="slice"):
+def timed_steps(env, steps, warmup, barrier, global_metrics, path="ring", ring=None, slice_next=None):
     """W untimed warm-up steps, then EXACTLY `steps` lockstep steps + the metrics flush between barrier + synchronize pairs.
     Every hipGraph the timed region replays is captured and instantiated BEFORE the region (sgk_step_random_prepare for each
-    chunk size of the schedule), and the first HIP event is recorded immediately before the first replay, so neither the
-    host clock nor the device clock sees a capture. Returns (elapsed_s, kernel_ms, BatchMetrics)."""
+    chunk size of the schedule), and the first HIP event is recorded immediately before the first launch, so neither the
+    host clock nor the device clock sees a capture. Returns (elapsed_s, kernel_ms, BatchMetrics): the host clock stops when
+    this rank holds the all-reduced metrics and its stream is idle -- the all-reduce is the synchronisation; the barrier that
+    follows is outside the clock."""
     import torch
 
     stream = env.torch_stream()
-
-    slice_next = [0]
+    slice_next = slice_next if slice_next is not None else [0]
 
     def run(k):
         for c in chunk_schedule(k):
-            if ring is not None:  # every step's boards + records kept in the caller's trajectory ring
-                env.rollout_random_stream(c, boards=ring[0], recs=ring[1], first_slice=slice_next[0], layout=ring_layout)
-                slice_next[0] = (slice_next[0] + c) % ring[0].shape[1 if ring_layout == "tile" else 0]
-            elif path == "stream":
+            if path == "ring":  # every step's boards + records kept in the caller's trajectory ring
+                env.rollout_random_stream(c, boards=ring[0], recs=ring[1], first_slice=slice_next[0])
+                slice_next[0] = (slice_next[0] + c) % ring[0].shape[0]
+            elif path == "own":
                 env.step_random(c, auto_reset=True, fused="stream")
             else:
                 env.step_random(c, auto_reset=True)
 
-    if path == "launch" and ring is None:
+    if path == "launch":
         for c in sorted(set(chunk_schedule(warmup) + chunk_schedule(steps))):
             env.prepare_step_random(c, auto_reset=True)
     run(warmup)
@@ -166,8 +210,8 @@ def timed_steps(env, steps, warmup, barrier, global_metrics, path="stream", ring
     t_met = time.perf_counter()
     env.synchronize()
     torch.cuda.synchronize()
-    barrier()
     elapsed = time.perf_counter() - t0
+    barrier()
     if os.environ.get("SGK_BENCH_TRACE") == "1":  # where the host clock goes (stderr; stdout stays ONE JSON line)
         sys.stderr.write("bench trace: enqueue %.1f us, +metrics %.1f us, +syncs %.1f us, device %.1f us\n" % (
             (t_enq - t0) * 1e6, (t_met - t_enq) * 1e6, (t0 + elapsed - t_met) * 1e6, ev0.elapsed_time(ev1) * 1e3))
@@ -189,6 +233,81 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd)
 
 
+def traffic_bytes(env_name, layout, n_local, path, steps_per_launch):
+    """HBM-side bytes one launch of the path's kernel moves, from the committed rocprofv3 PMC passes (profiles/traffic.json:
+    FETCH_SIZE x the calibration the guide prescribes + WRITE_SIZE), scaled to this run's steps per launch; None if that size
+    was not measured."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    with open(tpath) as f:
+        tj = json.load(f)
+    key = "%s/%s/%d" % (env_name, layout, n_local)
+    if path == "launch":
+        return tj.get(key)
+    per100 = tj.get("%s/%s%d" % (key, {"ring": "ring", "own": "stream"}[path], GRAPH_CHUNK))
+    return None if per100 is None else per100 * steps_per_launch / GRAPH_CHUNK
+
+
+PATH_KERNEL = {"ring": "sgk::rollout_random_kernel<%s, stream> -> trajectory ring", "own": "sgk::rollout_random_kernel<%s, stream> -> own buffers",
+               "launch": "sgk::step_kernel<%s>"}
+PATH_BOUND = {
+    # where the bytes land decides what the rate can be held against
+    "ring": "hbm",  # 3 GB of fresh addresses per pass: every byte reaches DRAM (profiles/r03/ring_size_sweep.log)
+    "own": "fabric / infinity-cache write",   # 30 MB rewritten in place inside the 256 MiB Infinity Cache
+    "launch": "fabric / infinity-cache write",  # the same buffers, rewritten by every launch
+}
+
+
+def path_figures(env_name, layout, n_local, path, lockstep_steps, kernel_ms):
+    """The roofline-style figures of one measured path: algorithmic rate, counter-based traffic rate, what bounds it."""
+    launches = len(chunk_schedule(lockstep_steps)) if path != "launch" else lockstep_steps
+    steps_per_launch = lockstep_steps / launches
+    launch_s = kernel_ms / 1e3 / launches  # average duration of one launch of the dominant kernel incl. its launch gap
+    b_alg = algorithmic_bytes_per_env_step(env_name, path)
+    achieved = b_alg * n_local * steps_per_launch / launch_s / 1e9
+    traffic = traffic_bytes(env_name, layout, n_local, path, steps_per_launch)
+    b8d = B_ALG[env_name]
+    return {
+        "bound": PATH_BOUND[path], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        # what the fabric really moved (rocprofv3 FETCH_SIZE x calibration + WRITE_SIZE per launch, profiles/traffic.json) over the
+        # same launch time
+        "traffic": traffic,
+        "traffic_gbs": None if traffic is None else traffic / launch_s / 1e9,
+        "traffic_frac": None if traffic is None else traffic / launch_s / 1e9 / HBM_PEAK_GBS,
+        "kernel": PATH_KERNEL[path] % env_name,
+        "algorithmic_bytes_per_env_step": b_alg, "steps_per_launch": steps_per_launch,
+        "algorithmic_bytes_per_launch": b_alg * n_local * steps_per_launch,
+        "avg_launch_us": launch_s * 1e6, "device_us_per_step": launch_s * 1e6 / steps_per_launch,
+        "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+        # SURVEY 8(d)'s figure for a one-launch-per-step design (2 H W + 28: it charges a board read and a state / counter round
+        # trip per step that a K-step kernel does not make): quoted for continuity with rounds 1-2, NOT a utilisation
+        "survey_8d_bytes_per_env_step": b8d, "survey_8d_gbs": b8d * n_local * steps_per_launch / launch_s / 1e9,
+    }
+
+
+def issue_roofline(env_name, n_local, steps, seconds):
+    """`fused_rollout`'s bound is instruction issue, not memory: instructions per env-step from the committed SQ counter pass
+    (profiles/issue.json, tools/make_issue_json.py) x this run's rate, against the chip's measured issue peaks
+    (tools/exp_issue_peak.hip). None when no counter pass for this env is committed."""
+    ipath = os.path.join(ROOT, "profiles", "issue.json")
+    if not os.path.exists(ipath):
+        return None
+    with open(ipath) as f:
+        ij = json.load(f)
+    k = ij.get("%s/outputs_once" % env_name)
+    if not k:
+        return None
+    wave_steps = (n_local / 64.0) * steps / seconds  # wave-level steps per second
+    valu, salu = k["valu_per_wave_step"] * wave_steps, k["salu_per_wave_step"] * wave_steps
+    pv, ps = ij["peak"]["valu_wave_instr_per_s"], ij["peak"]["salu_wave_instr_per_s"]
+    bound = "salu-issue" if salu / ps >= valu / pv else "valu-issue"
+    return {"bound": bound, "achieved": (salu if bound == "salu-issue" else valu) / 1e9, "peak": (ps if bound == "salu-issue" else pv) / 1e9,
+            "unit": "G wave-instructions/s", "frac": max(salu / ps, valu / pv), "valu_frac": valu / pv, "salu_frac": salu / ps,
+            "valu_per_wave_step": k["valu_per_wave_step"], "salu_per_wave_step": k["salu_per_wave_step"],
+            "lds_per_wave_step": k.get("lds_per_wave_step"), "source": k.get("source")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,10 +324,10 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5AFE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true")
-    ap.add_argument("--path", default="stream", choices=["stream", "launch"],
-                    help="stream: 100 lockstep steps per launch, every step's outputs materialised (default); launch: one "
-                         "step-kernel launch per step (hipGraph)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the per-step-launch and trajectory-ring measurements")
+    ap.add_argument("--path", default="ring", choices=["ring", "own", "launch"],
+                    help="ring: streamed rollout, every step's board + record KEPT in a 100-slice trajectory ring (default); own: "
+                         "the same kernel into the env's own buffers (rewritten in place); launch: one step-kernel launch per step")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the measurements of the other two paths")
     ap.add_argument("--no-weak-line", action="store_true", help="skip the secondary 1M-envs-per-GPU measurement at N > 1")
     args = ap.parse_args()
 
@@ -233,6 +352,7 @@ def main():
     import torch.distributed as tdist
 
     torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
     weak = args.envs_per_gpu > 0
     if weak:
         n_total = args.envs_per_gpu * world
@@ -253,59 +373,76 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         return tuple(float(x) for x in t)
 
+    def gather_over_ranks(val):
+        if world == 1:
+            return [val]
+        t = torch.tensor([val], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        out = [torch.zeros_like(t) for _ in range(world)]
+        tdist.all_gather(out, t)
+        return [float(x[0]) for x in out]
+
+    def make_ring(n):
+        return (torch.empty((RING_SLICES, n, CELLS[args.env]), dtype=torch.int8, device=dev),
+                torch.empty((RING_SLICES, n, 4), dtype=torch.int8, device=dev))
+
     env = S.BatchedGridworldEnv(args.env, n_local, device=local_rank, seed=args.seed, env_index_base=base,
                                 layout=args.layout)
     stream = env.torch_stream()
-    sdist.library_comm(env)  # the RCCL communicator of the metrics all-reduce is made HERE (N > 1), not inside a timed region
+    comm = sdist.library_comm(env)  # the RCCL communicator of the metrics all-reduce is made HERE (N > 1), not inside a timed region
+    rccl_ranks = sdist.library_comm_ranks(env) if comm is not None else None
     L = max(1, args.lockstep_per_step)
     k_lock, w_lock = args.steps * L, args.warmup * L  # the timed region / the warm-up in lockstep steps
-    elapsed, kernel_ms, gm = timed_steps(env, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path)
+    gpu_leg_ms = 0.0
+    ring = make_ring(n_local) if args.path == "ring" else None
+    slice_next = [0]
+    elapsed, kernel_ms, gm = timed_steps(env, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path, ring=ring,
+                                         slice_next=slice_next)
+    per_rank_device_us = [x * 1e3 for x in gather_over_ranks(kernel_ms)]
     elapsed, kernel_ms = max_over_ranks(elapsed, kernel_ms)
-
+    gpu_leg_ms += kernel_ms
     total_steps = w_lock + k_lock
+    ring_ok = None
+    if ring is not None:  # the ring really holds the last steps' outputs (checked outside every clock)
+        ring_ok = ring_parity_sample(args.env, args.seed, base, ring, total_steps - min(3, total_steps), min(3, total_steps))
+
     secondary = {}
     if not args.no_secondary:
-        # the other path and the trajectory-ring form, same bracket, a bounded number of steps (device time per step is what
-        # these report; the host-clock figure of the primary path is `value`)
+        # the other two paths, same bracket, a bounded number of steps (device time per step is what these report; the host-clock
+        # figure of the primary path is `value`)
         k2 = min(k_lock, 400)
         w2 = min(w_lock, 100)
-        other = "launch" if args.path == "stream" else "stream"
-        o_el, o_ms, _ = timed_steps(env, k2, w2, barrier, sdist.global_metrics, path=other)
-        o_el, o_ms = max_over_ranks(o_el, o_ms)
-        total_steps += k2 + w2
-        secondary["per_step_launches" if other == "launch" else "streamed"] = {
-            "value": n_total * k2 / o_el, "unit": "env-steps/s", "lockstep_steps": k2,
-            "us_per_lockstep_step": o_el * 1e6 / k2, "device_us_per_lockstep_step": o_ms * 1e3 / k2,
-            "note": ("sgk_step_random: one step-kernel launch per lockstep step (hipGraph x%d), state words through HBM every step"
-                     % GRAPH_CHUNK) if other == "launch" else "sgk_rollout_random_stream: %d steps per launch" % GRAPH_CHUNK}
-        slices = GRAPH_CHUNK
-        ring = (torch.empty((slices, n_local, env.n_cells), dtype=torch.int8, device="cuda:%d" % local_rank),
-                torch.empty((slices, n_local, 4), dtype=torch.int8, device="cuda:%d" % local_rank))
-        r_el, r_ms, _ = timed_steps(env, k2, w2, barrier, sdist.global_metrics, ring=ring)
-        r_el, r_ms = max_over_ranks(r_el, r_ms)
-        total_steps += k2 + w2
-        secondary["streamed_into_trajectory_ring"] = {
-            "value": n_total * k2 / r_el, "unit": "env-steps/s", "lockstep_steps": k2,
-            "us_per_lockstep_step": r_el * 1e6 / k2, "device_us_per_lockstep_step": r_ms * 1e3 / k2, "ring_slices": slices,
-            "ring_bytes": int(ring[0].numel() + ring[1].numel()),
-            "note": "sgk_rollout_random_stream into boards [%d][n][cells] + records [%d][n]: every step's outputs KEPT "
-                    "(the batched dqn_warmup, reference warmup.py:14-21); nothing is overwritten within a launch" % (slices, slices)}
-        del ring
-        # the same with the rings laid out TILE-major ([n_tiles][ring][64][...]: one contiguous run per wave and launch)
-        n_tiles = (n_local + 63) // 64
-        tring = (torch.empty((n_tiles, slices, 64, env.n_cells), dtype=torch.int8, device="cuda:%d" % local_rank),
-                 torch.empty((n_tiles, slices, 64, 4), dtype=torch.int8, device="cuda:%d" % local_rank))
-        t_el, t_ms, _ = timed_steps(env, k2, w2, barrier, sdist.global_metrics, ring=tring, ring_layout="tile")
-        t_el, t_ms = max_over_ranks(t_el, t_ms)
-        total_steps += k2 + w2
-        secondary["streamed_into_tile_major_trajectory_ring"] = {
-            "value": n_total * k2 / t_el, "unit": "env-steps/s", "lockstep_steps": k2,
-            "us_per_lockstep_step": t_el * 1e6 / k2, "device_us_per_lockstep_step": t_ms * 1e3 / k2, "ring_slices": slices,
-            "note": "SGK_F_RING_TILE_MAJOR: boards [n_tiles][%d][64][cells] + records [n_tiles][%d][64]" % (slices, slices)}
-        del tring
+        names = {"ring": "kept_in_trajectory_ring", "own": "rewritten_in_place", "launch": "per_step_launches"}
+        notes = {
+            "ring": "sgk_rollout_random_stream into boards [%d][n][cells] + records [%d][n]: every step's outputs KEPT (the batched "
+                    "dqn_warmup, reference warmup.py:14-21); nothing is overwritten within a launch" % (RING_SLICES, RING_SLICES),
+            "own": "sgk_rollout_random_stream into the env's own buffers: %d steps per launch, step k overwrites step k-1's board and "
+                   "record (boards write-through, records coalesce in L2); the working set sits in the Infinity Cache" % GRAPH_CHUNK,
+            "launch": "sgk_step_random: one step-kernel launch per lockstep step (hipGraph x%d), state words through memory every step"
+                      % GRAPH_CHUNK,
+        }
+        for other in ("ring", "own", "launch"):
+            if other == args.path:
+                continue
+            r2 = make_ring(n_local) if other == "ring" else None
+            o_el, o_ms, _ = timed_steps(env, k2, w2, barrier, sdist.global_metrics, path=other, ring=r2)
+            o_el, o_ms = max_over_ranks(o_el, o_ms)
+            del r2
+            total_steps += k2 + w2
+            gpu_leg_ms += o_ms
+            fig = path_figures(args.env, args.layout, n_local, other, k2, o_ms)
+            secondary[names[other]] = {
+                "value": n_total * k2 / o_el, "unit": "env-steps/s", "lockstep_steps": k2,
+                "us_per_lockstep_step": o_el * 1e6 / k2, "device_us_per_lockstep_step": o_ms * 1e3 / k2,
+                "device_value": n_total * k2 / (o_ms / 1e3),
+                "bound": fig["bound"], "algorithmic_bytes_per_env_step": fig["algorithmic_bytes_per_env_step"],
+                # a fraction of the HBM peak only where HBM is what bounds the path; the in-place forms are held against nothing
+                # here: their traffic figures say what the fabric moved
+                "achieved_gbs": fig["achieved"], "frac": fig["frac"] if fig["bound"] == "hbm" else None,
+                "traffic": fig["traffic"], "traffic_gbs": fig["traffic_gbs"], "traffic_frac": fig["traffic_frac"],
+                "note": notes[other]}
     fused = None
     if not args.no_fused:
-        # same workload through the fused rollout kernel (state in registers, boards materialised once per launch)
+        # same workload through the outputs-once rollout kernel (state in registers, boards materialised once per launch)
         env.synchronize()
         f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         env.step_random(100, auto_reset=True, fused=True)
@@ -316,24 +453,31 @@ def main():
         env.synchronize()
         fms = f0.elapsed_time(f1)
         total_steps += 100 + fused_steps
+        gpu_leg_ms += fms
         fused = {"value": n_total * fused_steps / (fms / 1e3), "unit": "env-steps/s",
                  "ms_per_launch": fms, "steps_per_launch": fused_steps,
-                 "note": "sgk_rollout_random: %d lockstep steps in ONE launch; rank 0's device time" % fused_steps}
+                 "roofline": issue_roofline(args.env, n_local, fused_steps, fms / 1e3),
+                 "note": "sgk_rollout_random: %d lockstep steps in ONE launch, outputs once at the end (no per-step observation "
+                         "exists); rank 0's device time" % fused_steps}
     ok, n_checked = parity_sample(env, args.env, args.seed, base, total_steps)
 
     weak_line = None
     if world > 1 and not weak and not args.no_weak_line:
         # secondary: the weak-scaling form (1 048 576 envs on EVERY GPU), same K / W, same bracket
         env.close()
+        del ring
         per = 1 << 20
         wenv = S.BatchedGridworldEnv(args.env, per, device=local_rank, seed=args.seed, env_index_base=rank * per,
                                      layout=args.layout)
-        w_el, w_ms, _ = timed_steps(wenv, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path)
+        wring = make_ring(per) if args.path == "ring" else None
+        w_el, w_ms, _ = timed_steps(wenv, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path, ring=wring)
         w_el, w_ms = max_over_ranks(w_el, w_ms)
+        gpu_leg_ms += w_ms
         weak_line = {"value": per * world * k_lock / w_el, "unit": "env-steps/s", "envs_per_gpu": per,
                      "total_envs": per * world, "ms_per_step": w_el * 1e3 / args.steps,
                      "us_per_lockstep_step": w_el * 1e6 / k_lock, "device_us_per_lockstep_step": w_ms * 1e3 / k_lock,
-                     "scaling": "weak"}
+                     "device_value": per * world * k_lock / (w_ms / 1e3), "scaling": "weak"}
+        del wring
         wenv.close()
 
     if world > 1:
@@ -342,35 +486,17 @@ def main():
     if rank != 0:
         return
     value = n_total * k_lock / elapsed
-    launches = len(chunk_schedule(k_lock)) if args.path == "stream" else k_lock
-    steps_per_launch = k_lock / launches
-    launch_s = kernel_ms / 1e3 / launches  # average duration of one launch of the dominant kernel incl. its launch gap
-    b_alg = B_ALG[args.env]
-    achieved = b_alg * n_local * steps_per_launch / launch_s / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
-        if args.path == "stream":  # measured per 100-step launch; scaled to this run's steps per launch
-            per100 = tj.get("%s/%s/%d/stream%d" % (args.env, args.layout, n_local, GRAPH_CHUNK))
-            traffic = None if per100 is None else per100 * steps_per_launch / GRAPH_CHUNK
-        else:
-            traffic = tj.get("%s/%s/%d" % (args.env, args.layout, n_local))
-    roofline = {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic,
-        # what the fabric really moved (rocprofv3 FETCH_SIZE x calibration + WRITE_SIZE per launch, profiles/traffic.json)
-        # over the same launch time: the UTILISATION figure. `frac` is algorithmic (2 H W + 28 bytes per env-step,
-        # which charges a board read this design never makes) and can exceed 1.
-        "traffic_gbs": None if traffic is None else traffic / launch_s / 1e9,
-        "traffic_frac": None if traffic is None else traffic / launch_s / 1e9 / HBM_PEAK_GBS,
-        "kernel": ("sgk::rollout_random_kernel<%s, stream>" if args.path == "stream" else "sgk::step_kernel<%s>") % args.env,
-        "algorithmic_bytes_per_env_step": b_alg, "steps_per_launch": steps_per_launch,
-        "algorithmic_bytes_per_launch": b_alg * n_local * steps_per_launch,
-        "avg_launch_us": launch_s * 1e6, "device_us_per_step": launch_s * 1e6 / steps_per_launch,
-        "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-    }
+    roofline = path_figures(args.env, args.layout, n_local, args.path, k_lock, kernel_ms)
+    what = {
+        "ring": "streaming rollout kernel (%d steps per launch, env state in registers between steps), auto-reset, every step's "
+                "successor board (write-through tile stores) and step record KEPT in a %d-slice trajectory ring in HBM (%.2f GB per "
+                "GPU: the batched dqn_warmup)" % (GRAPH_CHUNK, RING_SLICES, RING_SLICES * n_local * (CELLS[args.env] + 4) / 1e9),
+        "own": "streaming rollout kernel (%d steps per launch, env state in registers between steps), auto-reset, every step's board "
+               "written through into the env's own buffer (rewritten in place: step k overwrites step k-1; the %.0f MB working set "
+               "sits in the Infinity Cache), step records coalesced in L2" % (GRAPH_CHUNK, n_local * (CELLS[args.env] + 4) / 1e6),
+        "launch": "step kernel (one launch per step, hipGraph x%d), auto-reset, state words / step records / boards of the env's own "
+                  "buffers rewritten by every launch" % GRAPH_CHUNK,
+    }[args.path]
     out = {
         "metric": "env-steps/sec at 1M concurrent BoatRace envs" if args.env == "BoatRace-v0" else "env-steps/sec",
         "value": value,
@@ -386,10 +512,7 @@ def main():
         "dtype": "int8",
         "data": "synthetic",
         "config": {
-            "workload": ("%s random-action rollout, %d concurrent envs in lockstep (%d per GPU), " % (args.env, n_total, n_local))
-                        + ("streaming rollout kernel (%d steps per launch, env state in registers between steps)" % GRAPH_CHUNK
-                           if args.path == "stream" else "step kernel (one launch per step, hipGraph x%d)" % GRAPH_CHUNK)
-                        + ", auto-reset, every step's board and step record materialised in HBM",
+            "workload": "%s random-action rollout, %d concurrent envs in lockstep (%d per GPU), %s" % (args.env, n_total, n_local, what),
             "path": args.path,
             "step": "one pass over the batch = %d lockstep steps for every env (%s)" % (
                 L, "one full BoatRace episode each" if (L == 100 and args.env == "BoatRace-v0") else "--lockstep-per-step"),
@@ -397,9 +520,20 @@ def main():
             "parallelism": "env-sharded x%d, int64 metrics all-reduce" % world,
         },
         "roofline": roofline,
+        # the same throughput from the max-over-ranks HIP-event time of the timed launches (no host latency in it), each rank's
+        # device time, and how many ranks the library's RCCL communicator spans (None: one rank, or gloo in the CPU / one-GPU tests)
+        "device_value": n_total * k_lock / (kernel_ms / 1e3),
+        "per_rank_device_us": per_rank_device_us,
+        "rccl_ranks": rccl_ranks,
+        "metrics_collective": ("sgk_metrics_allreduced (RCCL)" if comm is not None else
+                               ("torch.distributed (%s)" % backend if world > 1 else "none (one rank)")),
+        # device milliseconds of ALL timed GPU work of this run (primary + secondaries + fused + weak line): why a coarse busy
+        # sampler may see an idle GPU -- the rest of the wall clock is imports, allocation, parity checks and the CPU baseline
+        "gpu_leg_device_ms": gpu_leg_ms,
         "episodes_finished": gm.episodes,
         "mean_return": gm.meter("returns")["avg"], "mean_safety": gm.meter("safeties")["avg"],
-        "parity_sample_bit_exact": ok, "parity_sample_envs": n_checked,
+        "parity_sample_bit_exact": ok and (ring_ok is not False), "parity_sample_envs": n_checked,
+        "ring_slices_checked_bit_exact": ring_ok,
     }
     out.update(secondary)
     if fused:
@@ -409,7 +543,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line only
         out["cpu_baseline"] = cpu_baseline(args.env, args.seed)
     print(json.dumps(out))
-    if not ok:
+    if not out["parity_sample_bit_exact"]:
         sys.exit(3)
 
 

@@ -233,6 +233,8 @@ typedef struct sgk_comm sgk_comm;
 SGK_API int sgk_comm_unique_id(uint8_t id_out[SGK_COMM_ID_BYTES]);
 SGK_API int sgk_comm_create(const uint8_t id[SGK_COMM_ID_BYTES], int rank, int world_size, int device, sgk_comm **out);
 SGK_API int sgk_comm_destroy(sgk_comm *comm);
+/* rank / number of ranks (RCCL's own ncclCommUserRank / ncclCommCount) / device of a communicator; any pointer may be NULL */
+SGK_API int sgk_comm_info(const sgk_comm *comm, int32_t *rank_out, int32_t *world_out, int32_t *device_out);
 /* in place on a DEVICE vector of SGK_METRICS_LEN int64 (e.g. sgk_metrics_dev's), ordered on hip_stream */
 SGK_API int sgk_allreduce_metrics(sgk_comm *comm, int64_t *inout_dev, void *hip_stream);
 /* sgk_metrics of this shard, all-reduced over the communicator's ranks (SGK_M_STEPS included); synchronises */
@@ -266,9 +268,13 @@ SGK_API int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat);
 #define SGK_TABQ_KERNEL_LDS 1
 #define SGK_TABQ_KERNEL_HBM 2
 SGK_API int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel);
-/* [n_envs][n_states][n_actions]. A caller that WRITES through the pointer calls this again afterwards, before the next
- * sgk_tabq_act / _learn / _learn_steps: those keep a per-env copy of one row, which this call invalidates. */
+/* [n_envs][n_states][n_actions]. The per-step kernels (sgk_tabq_act / _learn / _learn_steps) keep a per-env copy of ONE table
+ * row; this call invalidates those copies once. A caller that KEEPS the pointer (the zero-copy use) and writes the table through
+ * it later calls sgk_tabq_invalidate_rows() after every such write, before the next per-step call. */
 SGK_API int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64_t *n_actions);
+/* The table was written from outside the library (through sgk_tabq_table_dev's pointer): forget the kept rows. Cheap: a flag;
+ * the re-tagging launch runs with the next per-step call. */
+SGK_API int sgk_tabq_invalidate_rows(sgk_tabq *q);
 SGK_API int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, double *table_host);
 SGK_API int sgk_tabq_global_step(const sgk_tabq *q, int64_t *t_out);
 SGK_API double sgk_tabq_epsilon(double epsilon, int64_t epsilon_anneal, int64_t t); /* epsilon in force at global step t */
@@ -431,6 +437,9 @@ SGK_API int sgk_debug_host_step(int env_id, uint64_t state_word, int n_resets, i
 /* the state word reset number `n_resets` leaves (the create-time reset is number 1) */
 SGK_API uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets, const double *aux_env);
 SGK_API int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]);
+/* how many instantiated hipGraphs the handles hold (sgk_step_random / sgk_tabq_learn_steps keep at most 16 each, least
+ * recently used dropped first); either handle and either output may be NULL */
+SGK_API int sgk_debug_graph_count(const sgk_env *h, const sgk_tabq *q, int32_t *env_graphs_out, int32_t *tabq_graphs_out);
 
 #ifdef __cplusplus
 }

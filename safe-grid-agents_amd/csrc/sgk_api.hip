@@ -7,7 +7,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
 #include <new>
 #include <string>
 #include <utility>
@@ -34,6 +33,45 @@ int hip_fail(hipError_t e, const char *what) {
     if (e__ != hipSuccess) return hip_fail(e__, #call);  \
   } while (0)
 
+// Instantiated hipGraphs of a handle, keyed by (n_steps, flags): a small LRU. A caller that varies n_steps call by call would
+// otherwise pile up instantiated graphs (each holds its kernel nodes' argument blocks) until the handle is destroyed. The
+// least recently used one is destroyed when the cap is reached -- after its stream has drained, because a replay of it may
+// still be in flight.
+struct GraphCache {
+  static constexpr size_t CAP = 16;
+  struct Item {
+    std::pair<int32_t, uint32_t> key;
+    hipGraphExec_t exec;
+    uint64_t used;
+  };
+  std::vector<Item> items;
+  uint64_t tick = 0;
+  hipGraphExec_t find(const std::pair<int32_t, uint32_t> &key) {
+    for (Item &it : items)
+      if (it.key == key) {
+        it.used = ++tick;
+        return it.exec;
+      }
+    return nullptr;
+  }
+  void insert(const std::pair<int32_t, uint32_t> &key, hipGraphExec_t exec, hipStream_t replays_on) {
+    if (items.size() >= CAP) {
+      size_t lru = 0;
+      for (size_t i = 1; i < items.size(); ++i)
+        if (items[i].used < items[lru].used) lru = i;
+      (void)hipStreamSynchronize(replays_on);
+      (void)hipGraphExecDestroy(items[lru].exec);
+      items.erase(items.begin() + (long)lru);
+    }
+    items.push_back(Item{key, exec, ++tick});
+  }
+  void clear() {
+    for (Item &it : items) (void)hipGraphExecDestroy(it.exec);
+    items.clear();
+  }
+  size_t size() const { return items.size(); }
+};
+
 __global__ void set_counter_kernel(uint64_t *ctr, uint64_t v) { *ctr = v; }
 __global__ void add_counter_kernel(uint64_t *ctr, uint64_t v) { *ctr += v; }
 
@@ -55,7 +93,7 @@ struct sgk_env {
   double gamma_discount = -1.0;
   bool host_visible = false;         // SGK_MEM_HOST_VISIBLE: state/rec/boards/actions live in pinned device-mapped host memory
   uint8_t *hv_actions = nullptr;     // host-visible action buffer (host_visible mode)
-  std::map<std::pair<int32_t, uint32_t>, hipGraphExec_t> graphs;
+  GraphCache graphs;                  // (n_steps, flags) -> captured step launches
   bool use_graph = true;
   int partitions = 1;                 // independent env partitions stepped on concurrent graph branches
   hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
@@ -70,7 +108,7 @@ struct sgk_tabq {
   long long *t_dev = nullptr;  // device copy of tq.t_agent for graph replays
   bool t_dev_stale = true;
   bool rows_stale = false;     // the table was written outside the per-step kernels: their row slots must be re-tagged invalid
-  std::map<std::pair<int32_t, uint32_t>, hipGraphExec_t> graphs;  // (n_steps, cheat | flags << 1) -> captured sequence
+  GraphCache graphs;           // (n_steps, cheat | flags << 1) -> captured sequence
   uint64_t graphs_seed = 0;    // the env seed the captured launches carry (sgk_set_seed after a capture drops the graphs)
 };
 
@@ -145,7 +183,7 @@ int sgk_destroy(sgk_env *h) {
   (void)hipSetDevice(h->sh.device);
   (void)hipStreamSynchronize(h->stream);  // nullptr = the NULL stream
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-  for (auto &kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+  h->graphs.clear();
   sgk::Shard &s = h->sh;
   if (h->host_visible) {
     if (s.state) (void)hipHostFree(s.state);
@@ -242,6 +280,12 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   if (const char *sg = getenv("SGK_STREAM_GRID")) {
     int v = atoi(sg);
     if (v >= 64) s.stream_grid = v;
+  }
+  // the outputs-once rollout is issue-bound and register-light (64 VGPRs: 8 waves per SIMD fit)
+  s.rollout_grid = s.n_cus * 12;  // measured at 1 M envs: 6 / 8 / 12 / 16 per CU = 0.428 / 0.450 / 0.408 / 0.411 us per step (BoatRace)
+  if (const char *rg = getenv("SGK_ROLLOUT_GRID")) {
+    int v = atoi(rg);
+    if (v >= 64) s.rollout_grid = v;
   }
   SGK_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
@@ -348,7 +392,7 @@ int sgk_set_stream(sgk_env *h, void *hip_stream) {
 int sgk_set_seed(sgk_env *h, uint64_t seed) {
   if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
   h->sh.seed = seed;  // kernel argument of every later launch; captured step graphs carry the old seed and are dropped
-  for (auto &kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+  (void)hipStreamSynchronize(h->stream);  // a replay of a graph about to be destroyed may still be in flight
   h->graphs.clear();
   return SGK_OK;
 }
@@ -477,10 +521,9 @@ int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_s
 static int ensure_step_graph(sgk_env *h, int32_t n_steps, uint32_t flags, hipGraphExec_t *out) {
   sgk::Shard &s = h->sh;
   auto key = std::make_pair(n_steps, flags);
-  auto it = h->graphs.find(key);
-  if (it == h->graphs.end()) {
+  hipGraphExec_t exec = h->graphs.find(key);
+  if (!exec) {
     hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
     // partitions: the env batch is cut into P independent ranges (multiples of 256 envs); each range's chain of
     // n_steps dependent launches is a separate branch of the graph, so one range's launch/ramp/drain latency
     // overlaps another range's bandwidth phase (the envs are independent: reference train.py:51-54).
@@ -521,9 +564,9 @@ static int ensure_step_graph(sgk_env *h, int32_t n_steps, uint32_t flags, hipGra
     hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate");
-    it = h->graphs.emplace(key, exec).first;
+    h->graphs.insert(key, exec, h->stream);
   }
-  *out = it->second;
+  *out = exec;
   return SGK_OK;
 }
 
@@ -936,7 +979,7 @@ int sgk_tabq_destroy(sgk_tabq *q) {
     (void)hipSetDevice(q->env->sh.device);
     (void)hipStreamSynchronize(q->env->stream);
   }
-  for (auto &kv : q->graphs) (void)hipGraphExecDestroy(kv.second);
+  q->graphs.clear();
   (void)hipFree(q->tq.table);
   (void)hipFree(q->tq.tags);
   (void)hipFree(q->tq.row_cache);
@@ -1021,15 +1064,14 @@ int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags
   // act_explore, env.step, learn (+ update_epsilon), reset of the finished envs -- captured ONCE per (n_steps, cheat, flags) and
   // replayed: the agent step counter lives in device memory, so a replay needs no new arguments.
   if (q->graphs_seed != s.seed) {  // env.seed() re-keyed the exploration draws: the recorded kernel arguments are stale
-    for (auto &kv : q->graphs) (void)hipGraphExecDestroy(kv.second);
+    (void)hipStreamSynchronize(h->stream);
     q->graphs.clear();
     q->graphs_seed = s.seed;
   }
   auto key = std::make_pair(n_steps, (uint32_t)(cheat ? 1u : 0u) | (flags << 1));
-  auto it = q->graphs.find(key);
-  if (it == q->graphs.end()) {
+  hipGraphExec_t exec = q->graphs.find(key);
+  if (!exec) {
     hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
     hipStream_t cap = h->own_stream;
     sgk::TabqShard tq = q->tq;
     tq.t_ptr = q->t_dev;
@@ -1053,7 +1095,7 @@ int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags
     hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate");
-    it = q->graphs.emplace(key, exec).first;
+    q->graphs.insert(key, exec, h->stream);
   }
   SGK_HIP(refresh_row_tags(q));
   if (q->t_dev_stale) {
@@ -1062,7 +1104,7 @@ int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags
     SGK_HIP(hipGetLastError());
     q->t_dev_stale = false;
   }
-  SGK_HIP(hipGraphLaunch(it->second, h->stream));
+  SGK_HIP(hipGraphLaunch(exec, h->stream));
   q->tq.t_agent += n_steps;
   s.lockstep_t += (uint64_t)n_steps;
   h->t_dev_stale = true;
@@ -1126,6 +1168,18 @@ int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64
   if (table_dev) *table_dev = q->tq.table;
   if (n_states) *n_states = q->env->sh.n_states;
   if (n_actions) *n_actions = SGK_ACTIONS;
+  return SGK_OK;
+}
+
+int sgk_tabq_invalidate_rows(sgk_tabq *q) {
+  if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
+  q->rows_stale = true;  // the next sgk_tabq_act / _learn / _learn_steps re-tags every row slot invalid first
+  return SGK_OK;
+}
+
+int sgk_debug_graph_count(const sgk_env *h, const sgk_tabq *q, int32_t *env_graphs_out, int32_t *tabq_graphs_out) {
+  if (env_graphs_out) *env_graphs_out = h ? (int32_t)h->graphs.size() : 0;
+  if (tabq_graphs_out) *tabq_graphs_out = q ? (int32_t)q->graphs.size() : 0;
   return SGK_OK;
 }
 

@@ -30,6 +30,8 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;     // optional: what RCCL itself says the communicator spans
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;  // optional
   std::string error;
 };
 
@@ -44,7 +46,8 @@ Rccl &rccl() {
     if (r.dl) break;
   }
   if (!r.dl) {
-    r.error = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?");
+    const char *de = dlerror();  // one call: a second one returns NULL (the first clears the error)
+    r.error = std::string("librccl.so.1 could not be loaded: ") + (de ? de : "?");
     return r;
   }
 #define SGK_SYM(field, name)                                                             \
@@ -60,6 +63,8 @@ Rccl &rccl() {
   SGK_SYM(GroupEnd, "ncclGroupEnd");
   SGK_SYM(GetErrorString, "ncclGetErrorString");
 #undef SGK_SYM
+  *reinterpret_cast<void **>(&r.CommCount) = dlsym(r.dl, "ncclCommCount");
+  *reinterpret_cast<void **>(&r.CommUserRank) = dlsym(r.dl, "ncclCommUserRank");
   return r;
 }
 
@@ -123,6 +128,19 @@ int sgk_comm_destroy(sgk_comm *c) {
   Rccl &r = rccl();
   if (c->comm && r.CommDestroy) (void)r.CommDestroy(c->comm);
   delete c;
+  return SGK_OK;
+}
+
+int sgk_comm_info(const sgk_comm *c, int32_t *rank_out, int32_t *world_out, int32_t *device_out) {
+  if (!c) return sgk_set_error(SGK_ERR_INVALID, "comm is NULL");
+  int rank = c->rank, world = c->world;
+  Rccl &r = rccl();
+  // RCCL's own view where the library offers it (a check that the communicator spans what the caller meant it to)
+  if (c->comm && r.CommCount && r.CommCount(c->comm, &world) != NCCL_SUCCESS) world = c->world;
+  if (c->comm && r.CommUserRank && r.CommUserRank(c->comm, &rank) != NCCL_SUCCESS) rank = c->rank;
+  if (rank_out) *rank_out = rank;
+  if (world_out) *world_out = world;
+  if (device_out) *device_out = c->device;
   return SGK_OK;
 }
 

@@ -14,7 +14,7 @@ namespace sgk {
 struct Shard {
   int env_id = 0, layout = 0, device = 0;
   int n_cells = 0, pitch = 0, n_states = 0;
-  int n_cus = 256, max_grid = 2048, stream_grid = 2048;
+  int n_cus = 256, max_grid = 2048, stream_grid = 2048, rollout_grid = 2048;
   int64_t n = 0;
   uint64_t seed = 0, env_base = 0, lockstep_t = 0;
   SgkRules rules_host;

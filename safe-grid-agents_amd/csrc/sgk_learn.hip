@@ -899,7 +899,9 @@ __global__ __launch_bounds__(WG) void replay_store_kernel(const int8_t *__restri
   if (phase == 1) {
     for (int64_t env = gtid; env < n; env += gsz) {
       const uint32_t r = rec[env];  // reward | hidden << 8 | done << 16 | actual action << 24
-      r_actions[slice * n + env] = cheat ? (uint8_t)(r >> 24) : actions[env];
+      // (& 3: an executed "stay", action 4 under a non-default SGK_INTERRUPT_FORCED_ACTION, has no Q column; it is stored as UP,
+      // the default reading of that switch -- same trajectory in the level's corridor)
+      r_actions[slice * n + env] = cheat ? (uint8_t)((r >> 24) & 3u) : actions[env];
       r_rewards[slice * n + env] = cheat ? (int8_t)(r >> 8) : (int8_t)r;
       r_terminals[slice * n + env] = (uint8_t)((r >> 16) & 1u);
     }

@@ -2,6 +2,8 @@
 // once (reference learn.py:38,69; train.py:64; warmup.py:17-20), RandomAgent.act fused into the step (dummy.py:15-16), the
 // K-step fused random rollout, the episode bookkeeping track_metrics reads (meters.py:66-84), the float32 observation
 // cast, render("rgb_array") and the done-mask compaction. HBM-bound integer work: no MFMA here.
+#include <type_traits>
+
 #include "sgk_device.h"
 
 namespace sgk {
@@ -10,6 +12,10 @@ namespace sgk {
 // (SGK_TILE_IN_LDS=0; kept for the A/B in profiles/r02). Both produce the same bytes.
 #ifndef SGK_TILE_IN_LDS
 #define SGK_TILE_IN_LDS 1
+#endif
+#ifndef SGK_STREAM_MIN_WAVES
+#define SGK_STREAM_MIN_WAVES 4  // __launch_bounds__ of the streamed rollout (resident waves per SIMD the register budget must allow):
+                                // 6 and 8 spill and lose (profiles/r03/stream_grid_x_occupancy.log)
 #endif
 #ifndef SGK_STREAM_REC_SC1
 #define SGK_STREAM_REC_SC1 0  // the streamed rollout's per-step records: plain stores (A/B: write-through dwords)
@@ -161,7 +167,7 @@ struct StreamOut {
 };
 
 template <int ENV, int LAYOUT, bool STREAM>
-__global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(StepArgs a, int32_t n_steps, StreamOut o) {
+__global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout_random_kernel(StepArgs a, int32_t n_steps, StreamOut o) {
   constexpr int NC = Geom<ENV>::NC;
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
   __shared__ SgkRules R;
@@ -198,6 +204,7 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
     uint32_t drawn = sprite_info<ENV>(R, s);
     if (STREAM && boards_on) W.draw_all(C, R, drawn);
 #endif
+    if (STREAM) {
     // which Philox block (64 steps) and which of its words (16 steps) are in hand: compared against the step index, so the
     // first step needs no special case (a peeled first iteration doubled the loop body, Philox and tile writer included)
     uint64_t have_block = ~0ull, have_word = ~0ull;
@@ -280,6 +287,82 @@ __global__ __launch_bounds__(WG, STREAM ? 4 : 1) void rollout_random_kernel(Step
           else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
         }
         if (++slice == o.ring) slice = 0;
+      }
+    }
+    } else {
+      // Outputs once: nothing is stored per step, so the loop is bound by instruction ISSUE -- and it was the SCALAR port that
+      // was full (profiles/r03/pmc_sq_rollout_boatrace_fused.json: 15.7 SALU + 5.3 branch instructions per wave-step against
+      // 20.5 VALU, the scalar issue slot of a SIMD busy ~90 % of the launch): 64-bit step-index arithmetic and word / block
+      // comparisons on every step, and three exec-mask instructions per `if`. Here the loop nest follows the action stream's own
+      // structure -- a Philox block of 64 steps, its four words of 16 steps, the steps of a word -- so that the step loop carries
+      // one 32-bit counter, and a wave in which every lane steps on every step (whole tile, nobody's episode over, auto-reset)
+      // runs the LEAN body: no liveness test per step.
+      auto one_step = [&](int action, auto check) {
+        constexpr bool CHECK = decltype(check)::value;
+        const bool live = CHECK ? (valid && !s.over) : true;
+        if (live) action = env_actual_action<ENV>(R, s, a.seed, ge, action);
+        last_action = action;
+        if (live) {
+          int r_obs, r_hid, term;
+          if (HasAux<ENV>::value) transition_with<ENV>(R, s, action, r_obs, r_hid, term, ax);  // side state in registers
+          else transition<ENV>(R, s, action, r_obs, r_hid, term);
+          s.frame += 1;
+          s.ret += r_obs;
+          s.hid += r_hid;
+          last_obs = r_obs;
+          last_hid = r_hid;
+          last_done = 0;
+          if (term || s.frame >= R.max_iterations) {
+            last_done = 1;
+            acc_add(acc, true, s.ret, s.hid);
+            a.last_return[env] = s.ret;
+            a.last_perf[env] = s.hid;
+            bump_episode_count(a.n_episodes, env);
+            if (auto_reset) {
+              const int epi = s.epi + 1;  // this reset's index; n_resets[env] is brought up to date once, after the loop
+              s = initial_state(R);
+              s.epi = epi;
+              if (HasAux<ENV>::value) begin_episode_with<ENV>(R, s, a.seed, ge, ax);
+              else begin_episode<ENV>(R, s, a.seed, ge);
+            } else {
+              s.over = 1;
+            }
+          }
+        } else {
+          last_obs = 0;
+          last_hid = 0;
+          last_done = valid ? 1 : 0;
+        }
+      };
+      const bool lean = auto_reset && whole_tile && (__ballot(s.over != 0) == 0ull);  // wave-uniform
+      uint64_t t = a.t;
+      int32_t k = 0;
+      bool have_block = false;
+#pragma nounroll
+      while (k < n_steps) {
+        const uint32_t tl = (uint32_t)t;
+        if (!have_block || (tl & 63u) == 0u) {
+          philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
+          have_block = true;
+        }
+        const uint32_t j = (tl >> 4) & 3u;
+        w = (j == 0 ? x[0] : (j == 1 ? x[1] : (j == 2 ? x[2] : x[3]))) >> (2 * (tl & 15u));
+        const int32_t m = min((int32_t)(16u - (tl & 15u)), n_steps - k);  // steps this word serves
+        if (lean) {
+#pragma nounroll
+          for (int32_t i = 0; i < m; ++i) {
+            one_step((int)(w & 3u), std::false_type{});
+            w >>= 2;
+          }
+        } else {
+#pragma nounroll
+          for (int32_t i = 0; i < m; ++i) {
+            one_step((int)(w & 3u), std::true_type{});
+            w >>= 2;
+          }
+        }
+        k += m;
+        t += (uint64_t)m;
       }
     }
     rec = pack_rec(last_obs, last_hid, last_done, last_action);
@@ -488,6 +571,7 @@ static Shard shard_view(const Shard &sh, int64_t env_off, int64_t count) {
   v.last_perf = sh.last_perf + env_off;
   v.n_episodes = sh.n_episodes + env_off;
   v.n_resets = sh.n_resets + env_off;
+  if (sh.aux) v.aux = sh.aux + env_off * SGK_AUX_DOUBLES;  // friend or foe: the partition's own estimator rows
   return v;
 }
 
@@ -518,7 +602,7 @@ hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, 
 hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flags, hipStream_t st) {
   (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   StepArgs a = make_step_args(sh, nullptr, flags);
-  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.rollout_grid);
   StreamOut o{nullptr, nullptr, 1, 0, 0};
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
                           rollout_random_kernel<E, L, false><<<dim3(grid), dim3(WG), 0, st>>>(a, n_steps, o));

@@ -162,10 +162,15 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
     }
     int an = argmax4(n0, n1, n2, n3);
     double v_next = pick4(an, n0, n1, n2, n3);  // from the row BEFORE this update (value.py:47-50)
-    const double q_new = q_update(pick4(action, p0, p1, p2, p3), reward, v_next, a.lr, a.discount);
-    a.table[((int64_t)env * a.n_states + sp) * 4 + action] = q_new;
-    if (sn == sp) {  // the agent did not move: its next row is the row just updated
-      if (action == 0) n0 = q_new; else if (action == 1) n1 = q_new; else if (action == 2) n2 = q_new; else n3 = q_new;
+    // (under --cheat the learnt action is the EXECUTED one; a build that reads the interruption as "stay", action 4 --
+    // SGK_INTERRUPT_FORCED_ACTION -- executes an action with no Q column: the reference's Q[state][4] raises there, here the
+    // update is skipped)
+    if (action < SGK_ACTIONS) {
+      const double q_new = q_update(pick4(action, p0, p1, p2, p3), reward, v_next, a.lr, a.discount);
+      a.table[((int64_t)env * a.n_states + sp) * 4 + action] = q_new;
+      if (sn == sp) {  // the agent did not move: its next row is the row just updated
+        if (action == 0) n0 = q_new; else if (action == 1) n1 = q_new; else if (action == 2) n2 = q_new; else n3 = q_new;
+      }
     }
     keep_row(a, env, n0, n1, n2, n3);  // the next act() is in s'
     a.tags[env] = (uint32_t)sp | ((uint32_t)sn << 16);
@@ -341,12 +346,12 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
       rec = pack_rec(r_obs, r_hid, (valid && (s.over || finished)) ? 1 : 0, executed);
       if (a.cheat) action = executed;  // learn.py:73-79
       double n0 = q0, n1 = q1, n2 = q2, n3 = q3;
-      if (live) {
-        if (si != si_prev) {
-          const double2 *rown = reinterpret_cast<const double2 *>(tab + si * 4);
-          const double2 a01 = rown[0], a23 = rown[1];
-          n0 = a01.x; n1 = a01.y; n2 = a23.x; n3 = a23.y;
-        }
+      if (live && si != si_prev) {
+        const double2 *rown = reinterpret_cast<const double2 *>(tab + si * 4);
+        const double2 a01 = rown[0], a23 = rown[1];
+        n0 = a01.x; n1 = a01.y; n2 = a23.x; n3 = a23.y;
+      }
+      if (live && action < SGK_ACTIONS) {  // an executed "stay" (action 4 under --cheat, a non-default reading) has no Q column
         const int an = argmax4(n0, n1, n2, n3);
         const double v_next = pick4(an, n0, n1, n2, n3);
         const double reward = a.cheat ? (double)r_hid : (double)r_obs;

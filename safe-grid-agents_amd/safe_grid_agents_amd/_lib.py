@@ -143,6 +143,7 @@ _SIGNATURES = {
     "sgk_comm_unique_id": (ctypes.c_int, [_V]),
     "sgk_comm_create": (ctypes.c_int, [_V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_V)]),
     "sgk_comm_destroy": (ctypes.c_int, [_V]),
+    "sgk_comm_info": (ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "sgk_allreduce_metrics": (ctypes.c_int, [_V, _V, _V]),
     "sgk_metrics_allreduced": (ctypes.c_int, [_V, _V, _V]),
     "sgk_finished": (ctypes.c_int, [_V, _V, _V, _V, ctypes.POINTER(ctypes.c_int64)]),
@@ -156,6 +157,8 @@ _SIGNATURES = {
     "sgk_tabq_rollout_ex": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "sgk_tabq_table_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V), ctypes.POINTER(ctypes.c_int64),
                                           ctypes.POINTER(ctypes.c_int64)]),
+    "sgk_tabq_invalidate_rows": (ctypes.c_int, [_V]),
+    "sgk_debug_graph_count": (ctypes.c_int, [_V, _V, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "sgk_tabq_copy_table": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int64, _V]),
     "sgk_tabq_global_step": (ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_int64)]),
     "sgk_tabq_epsilon": (ctypes.c_double, [ctypes.c_double, ctypes.c_int64, ctypes.c_int64]),

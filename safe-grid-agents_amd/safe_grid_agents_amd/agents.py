@@ -303,6 +303,19 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         k = {"auto": _lib.TABQ_KERNEL_AUTO, "lds": _lib.TABQ_KERNEL_LDS, "hbm": _lib.TABQ_KERNEL_HBM}[kernel]
         _lib.check(self.lib.sgk_tabq_rollout_ex(self._h, int(n_steps), int(cheat), k))
 
+    def table(self):
+        """The Q tables where they live: a float64 torch view [N, n_states, 4] over HBM (zero copy, sgk_tabq_table_dev). After
+        WRITING through a view that was obtained earlier, call invalidate_rows() before the next act / learn / learn_steps."""
+        from .envs import _view
+
+        p, ns, na = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self.lib.sgk_tabq_table_dev(self._h, ctypes.byref(p), ctypes.byref(ns), ctypes.byref(na)))
+        return _view(self, self.env.device, p.value, (self.env.n_envs, ns.value, na.value), "float64")
+
+    def invalidate_rows(self):
+        """The table was written from outside (through table()): the per-step kernels forget the one row per env they keep."""
+        _lib.check(self.lib.sgk_tabq_invalidate_rows(self._h))
+
     def table_host(self, env_begin=0, env_count=None):
         env_count = self.env.n_envs - env_begin if env_count is None else env_count
         out = np.empty((env_count, self.env.n_states, self.action_n), dtype=np.float64)

@@ -88,17 +88,18 @@ def library_comm(env):
         return _COMMS[env.device]
     lib = _lib.load()
     rank, world = dist.get_rank(), dist.get_world_size()
+    # EVERY rank draws an id first (only rank 0's is used): it is the cheapest call that needs librccl loaded and working. All
+    # ranks agree on that before anyone enters ncclCommInitRank -- a rank that cannot load RCCL would return at once and leave
+    # the others waiting in the rendezvous for ever.
     ident = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)()
-    ok = 1
-    if rank == 0:
-        ok = int(lib.sgk_comm_unique_id(ident) == _lib.SGK_OK)
-    t = torch.tensor([ok] + list(ident), dtype=torch.uint8, device="cuda:%d" % env.device)
+    ok = torch.tensor([int(lib.sgk_comm_unique_id(ident) == _lib.SGK_OK)], dtype=torch.int32, device="cuda:%d" % env.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    t = torch.tensor(list(ident), dtype=torch.uint8, device="cuda:%d" % env.device)
     dist.broadcast(t, src=0)
-    vals = t.cpu().tolist()
     comm = ctypes.c_void_p()
     made = 0
-    if vals[0]:
-        ident = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)(*vals[1:])
+    if int(ok.item()) == 1:
+        ident = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)(*t.cpu().tolist())
         made = int(lib.sgk_comm_create(ident, rank, world, env.device, ctypes.byref(comm)) == _lib.SGK_OK)
     agree = torch.tensor([made], dtype=torch.int32, device="cuda:%d" % env.device)
     dist.all_reduce(agree, op=dist.ReduceOp.MIN)  # all ranks take the same path
@@ -112,6 +113,21 @@ def library_comm(env):
         return None
     _COMMS[env.device] = comm
     return comm
+
+
+def library_comm_ranks(env):
+    """How many ranks the library's RCCL communicator of this process spans (RCCL's own ncclCommCount through sgk_comm_info),
+    or None when the metrics go through torch.distributed / there is one rank."""
+    import ctypes
+
+    from . import _lib
+
+    comm = library_comm(env)
+    if comm is None:
+        return None
+    world = ctypes.c_int32(0)
+    _lib.check(env.lib.sgk_comm_info(comm, None, ctypes.byref(world), None))
+    return int(world.value)
 
 
 def global_metrics(env):

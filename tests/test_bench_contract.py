@@ -31,6 +31,10 @@ def test_chunk_schedule_covers_exactly_the_requested_steps():
     for name in O.ENV_IDS:
         H, W = O.shape(O.ENV_IDS[name])
         assert b.B_ALG[name] == 2 * H * W + 28, name
+        # what a kernel of each form cannot avoid moving: the kept outputs (board + packed record); + the state word's round trip
+        # when every step is a launch
+        assert b.algorithmic_bytes_per_env_step(name, "ring") == b.algorithmic_bytes_per_env_step(name, "own") == H * W + 4
+        assert b.algorithmic_bytes_per_env_step(name, "launch") == H * W + 4 + 16
 
 
 def _line(args, env=None, timeout=600):
@@ -52,8 +56,14 @@ def _check_contract(d, n_gpus, steps, warmup):
     # value = units all ranks processed / the timed region
     assert abs(d["value"] - total_envs * steps * L / (d["ms_per_step"] * steps / 1e3)) <= 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    path = d["config"]["path"]
+    assert r["bound"] == ("hbm" if path == "ring" else "fabric / infinity-cache write") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert ("KEPT in a 100-slice trajectory ring" in d["config"]["workload"]) == (path == "ring")
+    # the device-clock form of `value`, per rank, and the GPU leg's total
+    assert len(d["per_rank_device_us"]) == n_gpus and all(x > 0 for x in d["per_rank_device_us"])
+    assert abs(d["device_value"] - total_envs * steps * L / (max(d["per_rank_device_us"]) * 1e-6)) <= 1e-6 * d["device_value"]
+    assert d["device_value"] >= d["value"] and d["gpu_leg_device_ms"] >= max(d["per_rank_device_us"]) / 1e3
     per_launch = r["algorithmic_bytes_per_env_step"] * d["config"]["envs_per_gpu"] * r["steps_per_launch"]
     assert r["algorithmic_bytes_per_launch"] == per_launch
     assert abs(r["achieved"] - per_launch / (r["avg_launch_us"] * 1e-6) / 1e9) <= 1e-6 * r["achieved"]
@@ -68,13 +78,20 @@ def test_bench_line_one_rank():
     assert d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 8192 and d["roofline"]["steps_per_launch"] == 100
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "env-steps/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
-    for k in ("per_step_launches", "streamed_into_trajectory_ring", "streamed_into_tile_major_trajectory_ring", "fused_rollout"):
-        assert d[k]["value"] > 0
-    # the other path as the primary one, and round 1's step definition
+    assert d["config"]["path"] == "ring" and d["ring_slices_checked_bit_exact"] is True and d["rccl_ranks"] is None
+    for k in ("per_step_launches", "rewritten_in_place"):  # every secondary object carries its own counter-based figures
+        assert d[k]["value"] > 0 and d[k]["device_value"] > 0 and d[k]["bound"] == "fabric / infinity-cache write"
+        assert {"traffic", "traffic_gbs", "traffic_frac", "frac", "algorithmic_bytes_per_env_step"} <= set(d[k]) and d[k]["frac"] is None
+    assert d["fused_rollout"]["value"] > 0 and "roofline" in d["fused_rollout"]
+    # another path as the primary one, and round 1's step definition
     d2 = _line(["--steps", "40", "--warmup", "10", "--total-envs", "8192", "--path", "launch", "--lockstep-per-step", "1",
                 "--no-cpu-baseline", "--no-fused"])
     _check_contract(d2, 1, 40, 10)
-    assert d2["roofline"]["steps_per_launch"] == 1 and "streamed" in d2 and "cpu_baseline" not in d2
+    assert d2["roofline"]["steps_per_launch"] == 1 and "cpu_baseline" not in d2
+    assert d2["kept_in_trajectory_ring"]["bound"] == "hbm" and d2["rewritten_in_place"]["value"] > 0
+    d3 = _line(["--steps", "3", "--warmup", "1", "--total-envs", "8192", "--path", "own", "--no-cpu-baseline", "--no-fused",
+                "--no-secondary"])
+    _check_contract(d3, 1, 3, 1)
 
 
 @pytest.mark.gpu
@@ -87,3 +104,14 @@ def test_bench_line_two_ranks_on_one_gpu_shards_the_batch():
     assert d["scaling"] == "strong" and d["config"]["envs_per_gpu"] == 4096 and d["config"]["total_envs"] == 8192
     assert d["weak_1m_per_gpu"]["total_envs"] == 2 << 20 and "cpu_baseline" not in d
     assert d["episodes_finished"] == 8192 * 3  # every env of both shards finished one episode per bench step
+    assert d["metrics_collective"] == "torch.distributed (gloo)" and d["rccl_ranks"] is None
+
+
+@pytest.mark.gpu
+def test_bench_line_eight_ranks_dry_run_on_one_gpu():
+    """The driver's 8-GPU launch, rehearsed on the one GPU of a test box (gloo collectives): eight ranks, eight contiguous env-id
+    shards, one line with eight device times (what an 8-GPU node adds is RCCL and seven more devices, not control flow)."""
+    d = _line(["--gpus", "8", "--steps", "2", "--warmup", "1", "--total-envs", "16384", "--no-fused", "--no-weak-line"],
+              env={"SGK_BENCH_BACKEND": "gloo", "SGK_BENCH_ONE_DEVICE": "1"}, timeout=900)
+    _check_contract(d, 8, 2, 1)
+    assert d["config"]["envs_per_gpu"] == 2048 and d["scaling"] == "strong" and d["episodes_finished"] == 16384 * 2

@@ -5,6 +5,7 @@ Run on the GPU box:  python -m pytest tests -m gpu -x -q
 """
 import json
 import os
+import sys
 import types
 
 import numpy as np
@@ -13,6 +14,8 @@ import pytest
 import safe_grid_agents_amd as S
 from oracle import oracle as O
 from safe_grid_agents_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -990,6 +993,99 @@ def test_rccl_metrics_allreduce_through_the_c_abi_world_of_one():
     assert lib.sgk_allreduce_metrics(None, None, None) == _lib.ERR_INVALID
     _lib.check(lib.sgk_comm_destroy(comm))
     env.close()
+
+
+def test_comm_info_reports_what_rccl_says_the_communicator_spans():
+    import ctypes
+
+    _torch()
+    lib = _lib.load()
+    ident = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)()
+    _lib.check(lib.sgk_comm_unique_id(ident))
+    comm = ctypes.c_void_p()
+    _lib.check(lib.sgk_comm_create(ident, 0, 1, 0, ctypes.byref(comm)))
+    rank, world, device = ctypes.c_int32(-1), ctypes.c_int32(-1), ctypes.c_int32(-1)
+    _lib.check(lib.sgk_comm_info(comm, ctypes.byref(rank), ctypes.byref(world), ctypes.byref(device)))
+    assert (rank.value, world.value, device.value) == (0, 1, 0)
+    assert lib.sgk_comm_info(None, None, None, None) == _lib.ERR_INVALID
+    _lib.check(lib.sgk_comm_destroy(comm))
+
+
+def test_graph_caches_are_bounded_lru():
+    """sgk_step_random / sgk_tabq_learn_steps keep at most 16 instantiated hipGraphs per handle: a caller that varies n_steps
+    call by call does not pile them up, and an evicted chunk size is simply captured again (results unchanged)."""
+    import ctypes
+
+    _torch()
+    n, seed = 700, 11
+    env = S.BatchedGridworldEnv("IslandNavigation-v0", n, seed=seed)
+    agent = S.BatchedTabularQAgent(env, _tabq_args())
+    orc = O.EnvBatch("IslandNavigation-v0", n, seed=seed)
+    ge, gq = ctypes.c_int32(-1), ctypes.c_int32(-1)
+    t = 0
+    for k in list(range(4, 44)) + [4, 5, 43]:  # 40 distinct chunk sizes (all >= 4: graph replays), then old and recent ones again
+        env.step_random(k, auto_reset=True)
+        orc.rollout(k, seed=seed, t_begin=t, auto_reset=True)
+        t += k
+        _lib.check(env.lib.sgk_debug_graph_count(env.handle, agent._h, ctypes.byref(ge), ctypes.byref(gq)))
+        assert 1 <= ge.value <= 16, ge.value
+    assert ge.value == 16
+    assert_same_state(env, orc, "after 43 graph-replayed chunks of 40 sizes")
+    for k in range(1, 41):
+        agent.learn_steps(k)
+        _lib.check(env.lib.sgk_debug_graph_count(env.handle, agent._h, ctypes.byref(ge), ctypes.byref(gq)))
+        assert gq.value <= 16
+    assert gq.value == 16 and agent.t == sum(range(1, 41))
+    agent.close(); env.close()
+
+
+def test_friend_foe_partitions_step_their_own_estimator_rows():
+    """SGK_PARTITIONS > 1 runs sgk_step_random's launches on concurrent graph branches over env sub-ranges: each branch must see
+    ITS envs' float64 bandit estimates (the shard view offsets the side array like every other per-env array)."""
+    import subprocess
+
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import safe_grid_agents_amd as S\n"
+        "from oracle import oracle as O\n"
+        "n, seed = 4096, 5\n"
+        "env = S.BatchedGridworldEnv('FriendFoe-v0', n, seed=seed)\n"
+        "orc = O.EnvBatch('FriendFoe-v0', n, seed=seed)\n"
+        "t = 0\n"
+        "for k in (64, 150, 37):\n"
+        "    env.step_random(k, auto_reset=True)\n"
+        "    orc.rollout(k, seed=seed, t_begin=t, auto_reset=True)\n"
+        "    t += k\n"
+        "assert (env.boards_host().reshape(n, -1) == orc.boards()).all()\n"
+        "st = env.episode_state_host()\n"
+        "assert (st['episode_return'] == orc.field('episode_return')).all()\n"
+        "assert (env.bandit_policy() == orc.foe_policy()).all()\n"
+        "print('ok')\n" % (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")))
+    for parts in ("2", "4"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SGK_PARTITIONS=parts), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (parts, r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_tabq_invalidate_rows_after_writing_the_table_through_a_kept_pointer():
+    """A caller that keeps sgk_tabq_table_dev's pointer and writes the table later must call sgk_tabq_invalidate_rows: the per-step
+    kernels then re-read their rows from the table instead of the per-env row slots."""
+    _torch()
+    import torch
+
+    n = 512
+    env = S.BatchedGridworldEnv("BoatRace-v0", n, seed=2)
+    agent = S.BatchedTabularQAgent(env, _tabq_args())
+    table = agent.table()                      # zero-copy view, kept
+    a0 = agent.act().cpu().numpy()             # rows of the start state now sit in the row slots (all zero: action 0)
+    assert (a0 == 0).all()
+    si = int(env.episode_state_host()["agent_cell"][0])
+    table[:, si, 3] = 1.0                      # written through the kept pointer, behind the library's back
+    torch.cuda.synchronize()
+    agent.invalidate_rows()
+    assert (agent.act().cpu().numpy() == 3).all()
+    agent.close(); env.close()
 
 
 def test_tomato_watering_units_scale_and_refused_tables():

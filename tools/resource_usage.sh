@@ -1,7 +1,8 @@
 #!/bin/bash
-# VGPR / SGPR / occupancy of every kernel of one source file (default sgk_step.hip), optionally filtered by a substring
+# VGPR / SGPR / occupancy of every kernel of one source file (default sgk_step.hip), optionally filtered by a substring;
+# extra compiler flags through EXTRA (e.g. EXTRA=-DSGK_STREAM_MIN_WAVES=5)
 cd "$(dirname "$0")/../safe-grid-agents_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Rpass-analysis=kernel-resource-usage -c "${1:-sgk_step.hip}" -o /dev/null 2>&1 | python3 -c "
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $EXTRA -Rpass-analysis=kernel-resource-usage -c "${1:-sgk_step.hip}" -o /dev/null 2>&1 | python3 -c "
 import sys,re,subprocess
 flt=sys.argv[1] if len(sys.argv)>1 else ''
 cur=None;rows={}
