@@ -247,6 +247,19 @@ SGK_API int sgk_finished(sgk_env *h, int32_t *ids_dev, int32_t *return_dev, int3
 
 /* ---- TabularQAgent, one private agent per env (reference common/agents/value.py:15-58) ---------- */
 SGK_API int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, int64_t epsilon_anneal, sgk_tabq **out);
+/* The same with the table size named for levels whose boards have NO perfect hash (SGK_TOMATO_WATERING: 63 cells x 2^13 watered
+ * sets): every agent's table is then an open-addressing hash table in HBM keyed by the board (agent cell + the watered set the
+ * board shows), `hash_capacity` slots per agent (a power of two, 64 .. 2^24; 0 = 4096), a slot claimed by the first lookup of its
+ * board and zero until learnt -- the reference's defaultdict (value.py:31-36). 36 bytes per slot and agent. hash_capacity must be 0
+ * for every other level. A table that fills up sets a flag (sgk_tabq_hash_info); results are undefined from then on. */
+SGK_API int sgk_tabq_create_ex(sgk_env *env, double lr, double discount, double epsilon, int64_t epsilon_anneal,
+                               int32_t hash_capacity, sgk_tabq **out);
+/* capacity (0: perfect-hash level), slots in use in the fullest agent's table, and whether any table overflowed; synchronises and
+ * (for max_used) copies the keys to the host: a diagnostic. Any output may be NULL. */
+SGK_API int sgk_tabq_hash_info(sgk_tabq *q, int32_t *capacity_out, int32_t *max_used_out, int32_t *overflowed_out);
+/* hashed levels: uint32 [env_count][hash_capacity], the board each slot holds (0xffffffff = empty; tomato watering: agent cell |
+ * shown watered set << 8, 0x2000 = the bucket's delusion board), row-aligned with sgk_tabq_copy_table's [env][slot][action] */
+SGK_API int sgk_tabq_copy_keys(sgk_tabq *q, int64_t env_begin, int64_t env_count, uint32_t *keys_host);
 SGK_API int sgk_tabq_destroy(sgk_tabq *q);
 /* act (explore == 0, value.py:33-35) / act_explore (value.py:37-42) for every env's current state */
 SGK_API int sgk_tabq_act(sgk_tabq *q, int explore, uint8_t *actions_out_dev);

@@ -982,6 +982,8 @@ int sgk_tabq_destroy(sgk_tabq *q) {
   q->graphs.clear();
   (void)hipFree(q->tq.table);
   (void)hipFree(q->tq.tags);
+  (void)hipFree(q->tq.keys);
+  (void)hipFree(q->tq.hash_overflow);
   (void)hipFree(q->tq.row_cache);
   (void)hipFree(q->actions);
   (void)hipFree(q->t_dev);
@@ -989,14 +991,20 @@ int sgk_tabq_destroy(sgk_tabq *q) {
   return SGK_OK;
 }
 
-int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, int64_t epsilon_anneal, sgk_tabq **out) {
+int sgk_tabq_create_ex(sgk_env *env, double lr, double discount, double epsilon, int64_t epsilon_anneal, int32_t hash_capacity,
+                       sgk_tabq **out) {
   if (!out) return fail(SGK_ERR_INVALID, "out is NULL");
   *out = nullptr;
   SGK_CHECK_HANDLE(env);
   if (epsilon_anneal < 1) return fail(SGK_ERR_INVALID, "epsilon_anneal < 1");
-  if (env->sh.env_id == SGK_TOMATO_WATERING)
-    return fail(SGK_ERR_INVALID, "TomatoWatering has 63 x 2^13 distinct boards (16.5 MB of float64 rows per agent): no batched private "
-                                 "tables; the single-env TabularQAgent (a host dictionary, as in the reference) works on it");
+  const bool hashed = env->sh.env_id == SGK_TOMATO_WATERING;  // 63 x 2^13 distinct boards: no perfect hash
+  if (hashed) {
+    if (hash_capacity == 0) hash_capacity = 4096;
+    if (hash_capacity < 64 || hash_capacity > (1 << 24) || (hash_capacity & (hash_capacity - 1)))
+      return fail(SGK_ERR_INVALID, "hash_capacity must be a power of two in 64 .. 2^24 (slots per agent; 0 = 4096)");
+  } else if (hash_capacity != 0) {
+    return fail(SGK_ERR_INVALID, "this level's boards have a perfect hash: hash_capacity must be 0");
+  }
   sgk_tabq *q = new (std::nothrow) sgk_tabq();
   if (!q) return fail(SGK_ERR_NOMEM, "host allocation failed");
   q->env = env;
@@ -1005,15 +1013,22 @@ int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, in
   q->tq.eps0 = epsilon;
   q->tq.anneal = epsilon_anneal;
   q->tq.t_agent = 0;
-  const size_t tbytes = sizeof(double) * (size_t)env->sh.n * env->sh.n_states * SGK_ACTIONS;
+  q->tq.hash_cap = hashed ? hash_capacity : 0;
+  q->tq.n_states = hashed ? hash_capacity : env->sh.n_states;
+  const size_t n = (size_t)env->sh.n;
+  const size_t tbytes = sizeof(double) * n * (size_t)q->tq.n_states * SGK_ACTIONS;
   hipError_t e = hipMalloc(&q->tq.table, tbytes);
-  if (e == hipSuccess) e = hipMalloc(&q->tq.tags, sizeof(uint32_t) * (size_t)env->sh.n);
-  if (e == hipSuccess) e = hipMalloc(&q->actions, (size_t)env->sh.n);
+  if (e == hipSuccess) e = hipMalloc(&q->tq.tags, sizeof(uint64_t) * n);
+  if (e == hipSuccess) e = hipMalloc(&q->actions, n);
   if (e == hipSuccess) e = hipMalloc(&q->t_dev, sizeof(long long));
-  if (e == hipSuccess) e = hipMalloc(&q->tq.row_cache, sizeof(double) * 4 * (size_t)env->sh.n);
+  if (e == hipSuccess) e = hipMalloc(&q->tq.row_cache, sizeof(double) * 4 * n);
+  if (e == hipSuccess) e = hipMalloc(&q->tq.hash_overflow, sizeof(int32_t));
+  if (e == hipSuccess && hashed) e = hipMalloc(&q->tq.keys, sizeof(uint32_t) * n * (size_t)hash_capacity);
 
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.table, 0, tbytes, env->stream);  // defaultdict(zeros) (value.py:31)
-  if (e == hipSuccess) e = hipMemsetAsync(q->tq.tags, 0xff, sizeof(uint32_t) * (size_t)env->sh.n, env->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(q->tq.tags, 0xff, sizeof(uint64_t) * n, env->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(q->tq.hash_overflow, 0, sizeof(int32_t), env->stream);
+  if (e == hipSuccess && hashed) e = hipMemsetAsync(q->tq.keys, 0xff, sizeof(uint32_t) * n * (size_t)hash_capacity, env->stream);
   if (e != hipSuccess) {
     int rc = hip_fail(e, "tabular-Q allocation");
     std::string keep = g_last_error;
@@ -1022,6 +1037,46 @@ int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, in
     return rc;
   }
   *out = q;
+  return SGK_OK;
+}
+
+int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, int64_t epsilon_anneal, sgk_tabq **out) {
+  return sgk_tabq_create_ex(env, lr, discount, epsilon, epsilon_anneal, 0, out);
+}
+
+int sgk_tabq_hash_info(sgk_tabq *q, int32_t *capacity_out, int32_t *max_used_out, int32_t *overflowed_out) {
+  if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_CHECK_HANDLE(q->env);
+  if (capacity_out) *capacity_out = q->tq.hash_cap;
+  int32_t ov = 0;
+  SGK_HIP(hipMemcpyAsync(&ov, q->tq.hash_overflow, sizeof(ov), hipMemcpyDeviceToHost, q->env->stream));
+  SGK_HIP(hipStreamSynchronize(q->env->stream));
+  if (overflowed_out) *overflowed_out = ov;
+  if (max_used_out) {
+    *max_used_out = 0;
+    if (q->tq.hash_cap) {  // the fullest agent's slot count (a host pass over the keys: a diagnostic, not a hot path)
+      const size_t n = (size_t)q->env->sh.n, cap = (size_t)q->tq.hash_cap;
+      std::vector<uint32_t> keys(n * cap);
+      SGK_HIP(hipMemcpy(keys.data(), q->tq.keys, sizeof(uint32_t) * n * cap, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n; ++i) {
+        int32_t used = 0;
+        for (size_t k = 0; k < cap; ++k) used += keys[i * cap + k] != 0xffffffffu;
+        if (used > *max_used_out) *max_used_out = used;
+      }
+    }
+  }
+  return SGK_OK;
+}
+
+int sgk_tabq_copy_keys(sgk_tabq *q, int64_t env_begin, int64_t env_count, uint32_t *keys_host) {
+  if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_CHECK_HANDLE(q->env);
+  if (!q->tq.hash_cap) return fail(SGK_ERR_INVALID, "this level's tables are indexed by a perfect hash: there are no keys");
+  if (!keys_host || env_begin < 0 || env_count < 0 || env_begin + env_count > q->env->sh.n) return fail(SGK_ERR_INVALID, "bad range");
+  const size_t cap = (size_t)q->tq.hash_cap;
+  SGK_HIP(hipMemcpyAsync(keys_host, q->tq.keys + (size_t)env_begin * cap, sizeof(uint32_t) * cap * (size_t)env_count,
+                         hipMemcpyDeviceToHost, q->env->stream));
+  SGK_HIP(hipStreamSynchronize(q->env->stream));
   return SGK_OK;
 }
 
@@ -1137,7 +1192,7 @@ int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel) {
     // 1.79; profiles/r01/bench_tabq.log), behind everywhere else.
     const int per_cu = (int)((160u * 1024u) / lds_need);
     const int64_t groups = (s.n + 63) / 64, slots = (int64_t)s.n_cus * per_cu;
-    const int64_t table_bytes = s.n * (int64_t)s.n_states * 4 * (int64_t)sizeof(double);
+    const int64_t table_bytes = s.n * (int64_t)q->tq.n_states * 4 * (int64_t)sizeof(double);
     const int64_t fits = per_cu <= 2 ? (270ll << 20) : (140ll << 20);  // two resident waves per CU lose earlier (lava: 1.9-2.7 vs
                                                                        // 2.6-3.5 us up to 131 072 agents)
     if (per_cu <= 3 && groups > slots && table_bytes <= fits) use_lds = false;
@@ -1166,7 +1221,7 @@ int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   q->rows_stale = true;  // the caller may write through the pointer: the per-step kernels re-read the table afterwards
   if (table_dev) *table_dev = q->tq.table;
-  if (n_states) *n_states = q->env->sh.n_states;
+  if (n_states) *n_states = q->tq.n_states;
   if (n_actions) *n_actions = SGK_ACTIONS;
   return SGK_OK;
 }
@@ -1188,7 +1243,7 @@ int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, doubl
   SGK_CHECK_HANDLE(q->env);
   if (!table_host || env_begin < 0 || env_count < 0 || env_begin + env_count > q->env->sh.n)
     return fail(SGK_ERR_INVALID, "bad range");
-  const size_t row = (size_t)q->env->sh.n_states * SGK_ACTIONS;
+  const size_t row = (size_t)q->tq.n_states * SGK_ACTIONS;
   SGK_HIP(hipMemcpyAsync(table_host, q->tq.table + (size_t)env_begin * row, sizeof(double) * row * (size_t)env_count,
                          hipMemcpyDeviceToHost, q->env->stream));
   SGK_HIP(hipStreamSynchronize(q->env->stream));

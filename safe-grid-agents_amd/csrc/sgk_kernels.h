@@ -37,9 +37,16 @@ struct Shard {
 
 struct TabqShard {
   double *table = nullptr;   // [n][n_states][4] float64
-  uint32_t *tags = nullptr;     // [n] low half: state index the last action was chosen from (0xffff = env was over);
-                                //     high half: state index of the row in row_cache (0xffff = none)
+  uint64_t *tags = nullptr;     // [n] low word: state index the last action was chosen from (0xffffffff = env was over);
+                                //     high word: state index of the row in row_cache (0xffffffff = none)
   double *row_cache = nullptr;  // [n][4] the Q row of the state named by the tag: what the per-step kernels hand each other
+  // Levels whose boards have no perfect hash (tomato watering: 63 cells x 2^13 watered sets): every agent's table is an
+  // open-addressing hash table of `hash_cap` slots (a power of two <= 32768), keys[n][hash_cap] (0xffffffff = empty) beside the
+  // rows table[n][hash_cap][4]; a slot is claimed the first time a board is looked up -- the defaultdict of value.py:31-36.
+  uint32_t *keys = nullptr;
+  int32_t hash_cap = 0;          // 0: perfect-hash level
+  int32_t *hash_overflow = nullptr;  // [1] set when some agent's table was full (results are then undefined: re-create larger)
+  int32_t n_states = 0;          // rows per agent: the level's n_states, or hash_cap
   double lr = 0, discount = 0, eps0 = 0;
   int64_t anneal = 0;
   int64_t t_agent = 0;

@@ -7,13 +7,18 @@ namespace sgk {
 // ------------------------------------------------------------------------------------------------
 // Tabular Q-learning, one private float64 table per env: Q[env][state][action] (reference value.py:15-58)
 // ------------------------------------------------------------------------------------------------
+struct TabqArgs;
 template <int ENV>
-__device__ __forceinline__ int state_index(const SgkRules &R, const EnvState &s) {
+__device__ __forceinline__ int state_index(const SgkRules &R, const EnvState &s, const TabqArgs &a, int64_t env);
+
+// perfect-hash levels: the dictionary key (the flattened board, value.py:34) is a function of a few state fields
+template <int ENV>
+__device__ __forceinline__ int perfect_state_index(const SgkRules &R, const EnvState &s) {
   if (ENV == SGK_WHISKY_GOLD) return s.pos + (s.box == R.start_box ? 0 : R.n_cells);  // (agent cell, whisky still there)
   if (ENV == SGK_ABSENT_SUPERVISOR) return s.pos + (s.mode ? 0 : R.n_cells);             // (agent cell, supervisor present)
   if (ENV == SGK_SAFE_INTERRUPTIBILITY) return s.pos + (s.box == 255 ? R.n_cells : 0);   // (agent cell, button pressed): the coin does not show on the board
   if (ENV == SGK_FRIEND_FOE) return s.pos + (s.ext & 3) * R.n_cells;  // (agent cell, room type): the level does not show
-  // (tomato watering has 63 x 2^13 boards: no batched tables -- sgk_tabq_create refuses the level)
+  // (tomato watering has 63 x 2^13 boards: a per-agent hash table, state_index below)
   // conveyor belt: (agent cell, object cell); an arrived object that shows as the end mark takes cell 0's block (a wall cell)
   if (ENV == SGK_CONVEYOR_BELT) return s.pos * R.n_cells + ((s.mode && (R.env_flags & 1)) ? 0 : s.box);
   return (ENV == SGK_SIDE_EFFECTS_SOKOBAN) ? s.pos * R.n_cells + s.box : s.pos;
@@ -70,6 +75,8 @@ __device__ __forceinline__ double q_update(double q_sa, double reward, double v_
 
 struct TabqArgs {
   const SgkRules *rules;
+  uint32_t *keys;           // [n][n_states] hashed levels: the key held by each slot (0xffffffff = empty); nullptr elsewhere
+  int32_t *hash_overflow;   // [1]
   uint64_t *state;
   uint32_t *rec;
   int8_t *boards;
@@ -77,8 +84,8 @@ struct TabqArgs {
   double *aux;         // the env's float64 side state (Shard.aux)
   long long *metrics;
   double *table;       // [n][n_states][4]
-  uint32_t *tags;      // low half: state index the last action was chosen from (0xffff = env was over); high half: which
-                       // state's row row_cache holds (0xffff: none)
+  uint64_t *tags;      // low word: state index the last action was chosen from (0xffffffff = env was over); high word: which
+                       // state's row row_cache holds (0xffffffff: none)
   double *row_cache;   // [n][4] per-env copy of ONE table row, coalesced (32 B per env)
   int64_t n;
   uint64_t seed, env_base;
@@ -91,6 +98,39 @@ struct TabqArgs {
   uint32_t flags;
 };
 
+// Tomato watering: the board (the reference's dictionary key) shows the agent's cell and which tomatoes are watered -- or, while
+// the agent stands on the bucket, the delusion board (every cell watered), whatever the true set is. key = cell | shown set << 8
+// (the tomato under the agent is hidden by it: its bit is cleared),
+// 0x2000 standing for the delusion. The agent's table is an open-addressing hash table in HBM (linear probing from a
+// multiplicative hash; n_states slots, a power of two): a slot is claimed by the first lookup of its board and never released,
+// like a defaultdict row (value.py:31,34-36: act() and learn() both insert on a miss; a claimed row is zeros until learnt).
+// One lane owns one agent, so nothing races inside a table.
+__device__ __forceinline__ int hash_slot(uint32_t *__restrict__ keys, int cap, uint32_t key, int32_t *overflow) {
+  int i = (int)((key * 0x9E3779B1u) >> 8) & (cap - 1);
+  for (int probes = 0; probes < cap; ++probes) {
+    const uint32_t k = keys[i];
+    if (k == key) return i;
+    if (k == 0xffffffffu) {
+      keys[i] = key;
+      return i;
+    }
+    i = (i + 1) & (cap - 1);
+  }
+  *overflow = 1;  // table full: the caller reads the flag (sgk_tabq_hash_info) and re-creates the agents with more slots
+  return 0;
+}
+
+template <int ENV>
+__device__ __forceinline__ int state_index(const SgkRules &R, const EnvState &s, const TabqArgs &a, int64_t env) {
+  if (ENV == SGK_TOMATO_WATERING) {
+    // (the agent is drawn OVER the tomato it stands on: whether that one is watered does not show, so its bit is not part of the key)
+    const uint32_t under = R.tomato_index[s.pos] != 255 ? (1u << R.tomato_index[s.pos]) : 0u;
+    const uint32_t shown = alt_backdrop<ENV>(R, s) ? 0x2000u : (((uint32_t)s.box | ((uint32_t)s.ext << 8)) & ~under);
+    return hash_slot(a.keys + env * a.n_states, a.n_states, (uint32_t)s.pos | (shown << 8), a.hash_overflow);
+  }
+  return perfect_state_index<ENV>(R, s);
+}
+
 // The per-step kernels' row hand-off. A table row is 32 B inside a 0.8-41 KB private table: every agent's access is a separate
 // DRAM line, and at 262 144 IslandNavigation agents the two gathers of a step (act: the row of s; learn: the row of s') ran at
 // 1.7 TB/s of line traffic (learn: 13.4 us of a step; profiles/r02/tabq_learn_steps_kernel_stats_before_row_cache.csv).
@@ -99,9 +139,9 @@ struct TabqArgs {
 // the next kernel uses the slot when the tag matches the state it needs and gathers from the table otherwise (after a reset,
 // or after the table was written by another kernel: the API invalidates the tags then). The table itself is always written
 // through: it stays the state of record.
-__device__ __forceinline__ void load_row(const TabqArgs &a, int64_t env, uint32_t tag, int si, double &q0, double &q1, double &q2,
+__device__ __forceinline__ void load_row(const TabqArgs &a, int64_t env, uint64_t tag, int si, double &q0, double &q1, double &q2,
                                          double &q3) {
-  const double2 *row = ((tag >> 16) == (uint32_t)si)
+  const double2 *row = ((uint32_t)(tag >> 32) == (uint32_t)si)
                            ? reinterpret_cast<const double2 *>(a.row_cache + env * 4)
                            : reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + si) * 4);
   const double2 q01 = row[0], q23 = row[1];
@@ -121,7 +161,7 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
   const double eps = explore ? epsilon_at(a.eps0, a.anneal, t_agent) : 0.0;
   for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
     EnvState s = unpack_state(a.state[env]);
-    const int si = state_index<ENV>(R, s);
+    const int si = state_index<ENV>(R, s, a, env);
     double q0, q1, q2, q3;
     load_row(a, env, a.tags[env], si, q0, q1, q2, q3);
     int action = argmax4(q0, q1, q2, q3);
@@ -134,7 +174,7 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
       if (u < eps) action = ea;
     }
     actions_out[env] = (uint8_t)action;
-    a.tags[env] = (s.over ? 0xffffu : (uint32_t)si) | ((uint32_t)si << 16);
+    a.tags[env] = (uint64_t)(s.over ? 0xffffffffu : (uint32_t)si) | ((uint64_t)(uint32_t)si << 32);
     keep_row(a, env, q0, q1, q2, q3);  // learn() reads Q[s][.] from here
   }
 }
@@ -144,14 +184,17 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
   __shared__ SgkRules R;
   stage_rules(R, a.rules);
   for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
-    const uint32_t tag = a.tags[env];
-    const int sp = (int)(tag & 0xffffu);
-    if (sp == 0xffff) continue;
+    const uint64_t tag = a.tags[env];
+    const uint32_t sp_tag = (uint32_t)tag;
+    if (sp_tag == 0xffffffffu) continue;
+    const int sp = (int)sp_tag;
     EnvState s = unpack_state(a.state[env]);
     uint32_t rec = a.rec[env];
     int action = a.cheat ? (int)(rec >> 24) : (int)(actions[env] & 3);
-    double reward = a.cheat ? (double)(int8_t)(rec >> 8) : (double)(int8_t)rec;
-    int sn = state_index<ENV>(R, s);
+    // (the reward as the reference's agent receives it: the integer record times what one unit is worth -- 1.0, or tomato
+    // watering's REWARD_FACTOR per watered tomato, upstream's own float64 product)
+    double reward = __dmul_rn(a.cheat ? (double)(int8_t)(rec >> 8) : (double)(int8_t)rec, R.reward_scale);
+    int sn = state_index<ENV>(R, s, a, env);
     double p0, p1, p2, p3, n0, n1, n2, n3;
     load_row(a, env, tag, sp, p0, p1, p2, p3);  // the row act() chose from (its slot, unless something intervened)
     if (sn == sp) { n0 = p0; n1 = p1; n2 = p2; n3 = p3; }
@@ -173,7 +216,7 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
       }
     }
     keep_row(a, env, n0, n1, n2, n3);  // the next act() is in s'
-    a.tags[env] = (uint32_t)sp | ((uint32_t)sn << 16);
+    a.tags[env] = (uint64_t)(uint32_t)sp | ((uint64_t)(uint32_t)sn << 32);
   }
 }
 
@@ -252,7 +295,7 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_
       if (live) {
         int an = argmax4(n0, n1, n2, n3);
         double v_next = pick4(an, n0, n1, n2, n3);
-        double reward = a.cheat ? (double)r_hid : (double)r_obs;
+        double reward = __dmul_rn(a.cheat ? (double)r_hid : (double)r_obs, R.reward_scale);
         double q_sa = pick4(action, q0, q1, q2, q3);
         double q_new = q_update(q_sa, reward, v_next, a.lr, a.discount);
         Q[(si_prev * 4 + action) * 64 + lane] = q_new;
@@ -313,7 +356,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
     AuxRegs ax;  // the env's float64 side state, in registers for the whole launch (friend or foe; dead code elsewhere)
     ax.init();
     if (HasAux<ENV>::value && valid) ax.load(a.aux + env * SGK_AUX_DOUBLES);
-    int si = state_index<ENV>(R, s);
+    int si = valid ? state_index<ENV>(R, s, a, env) : 0;
     double2 r01 = reinterpret_cast<const double2 *>(tab + si * 4)[0], r23 = reinterpret_cast<const double2 *>(tab + si * 4)[1];
     double q0 = r01.x, q1 = r01.y, q2 = r23.x, q3 = r23.y;
     uint32_t rec = 0;
@@ -337,7 +380,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
         executed = env_actual_action<ENV>(R, s, a.seed, ge, action);
         if (HasAux<ENV>::value) transition_with<ENV>(R, s, executed, r_obs, r_hid, term, ax);
         else transition<ENV>(R, s, executed, r_obs, r_hid, term);
-        si = state_index<ENV>(R, s);
+        si = state_index<ENV>(R, s, a, env);
         s.frame += 1;
         s.ret += r_obs;
         s.hid += r_hid;
@@ -354,7 +397,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
       if (live && action < SGK_ACTIONS) {  // an executed "stay" (action 4 under --cheat, a non-default reading) has no Q column
         const int an = argmax4(n0, n1, n2, n3);
         const double v_next = pick4(an, n0, n1, n2, n3);
-        const double reward = a.cheat ? (double)r_hid : (double)r_obs;
+        const double reward = __dmul_rn(a.cheat ? (double)r_hid : (double)r_obs, R.reward_scale);
         const double q_sa = pick4(action, q0, q1, q2, q3);
         const double q_new = q_update(q_sa, reward, v_next, a.lr, a.discount);
         tab[si_prev * 4 + action] = q_new;
@@ -372,7 +415,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
         s.epi = epi;
         if (HasAux<ENV>::value) begin_episode_with<ENV>(R, s, a.seed, ge, ax);
         else begin_episode<ENV>(R, s, a.seed, ge);
-        si = state_index<ENV>(R, s);
+        si = state_index<ENV>(R, s, a, env);
         const double2 *row0 = reinterpret_cast<const double2 *>(tab + si * 4);
         const double2 a01 = row0[0], a23 = row0[1];  // after this step's store: the start row may be the row just updated
         n0 = a01.x; n1 = a01.y; n2 = a23.x; n3 = a23.y;
@@ -391,8 +434,8 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
 
 // "no row kept" for every env (the high half of the tag); the pending-action half stays: an act() made before the table was
 // written elsewhere is still learnt from
-__global__ __launch_bounds__(WG) void tabq_forget_rows_kernel(uint32_t *__restrict__ tags, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) tags[i] |= 0xffff0000u;
+__global__ __launch_bounds__(WG) void tabq_forget_rows_kernel(uint64_t *__restrict__ tags, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) tags[i] |= 0xffffffff00000000ull;
 }
 
 hipError_t launch_tabq_forget_rows(const Shard &sh, const TabqShard &tq, hipStream_t st) {
@@ -418,6 +461,8 @@ static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t fl
   a.aux = sh.aux;
   a.metrics = (long long *)sh.metric_slab;
   a.table = tq.table;
+  a.keys = tq.keys;
+  a.hash_overflow = tq.hash_overflow;
   a.tags = tq.tags;
   a.row_cache = tq.row_cache;
   a.n = sh.n;
@@ -429,7 +474,7 @@ static TabqArgs make_tabq_args(const Shard &sh, const TabqShard &tq, uint32_t fl
   a.discount = tq.discount;
   a.eps0 = tq.eps0;
   a.anneal = tq.anneal;
-  a.n_states = sh.n_states;
+  a.n_states = tq.n_states;
   a.cheat = 0;
   a.flags = flags;
   return a;
@@ -454,7 +499,7 @@ hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t
 
 // Sokoban's state is (agent cell, box cell): n_cells^2 rows do not fit LDS -> 0 = "use the per-step kernels"
 size_t tabq_rollout_lds_bytes(const Shard &sh) {
-  if (sh.n_states != sh.n_cells) return 0;
+  if (sh.n_states != sh.n_cells || sh.env_id == SGK_TOMATO_WATERING) return 0;  // (tomato: hashed tables live in HBM)
   return ((sizeof(SgkRules) + 15) / 16) * 16 + (size_t)sh.rules_host.n_slots * 4 * 64 * sizeof(double);
 }
 

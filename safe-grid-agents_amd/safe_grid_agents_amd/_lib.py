@@ -149,6 +149,11 @@ _SIGNATURES = {
     "sgk_finished": (ctypes.c_int, [_V, _V, _V, _V, ctypes.POINTER(ctypes.c_int64)]),
     "sgk_tabq_create": (ctypes.c_int, [_V, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
                                        ctypes.POINTER(_V)]),
+    "sgk_tabq_create_ex": (ctypes.c_int, [_V, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int32,
+                                          ctypes.POINTER(_V)]),
+    "sgk_tabq_hash_info": (ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                          ctypes.POINTER(ctypes.c_int32)]),
+    "sgk_tabq_copy_keys": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int64, _V]),
     "sgk_tabq_destroy": (ctypes.c_int, [_V]),
     "sgk_tabq_act": (ctypes.c_int, [_V, ctypes.c_int, _V]),
     "sgk_tabq_learn": (ctypes.c_int, [_V, _V, ctypes.c_int]),

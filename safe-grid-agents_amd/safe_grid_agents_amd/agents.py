@@ -244,9 +244,14 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         self.lr, self.discount = float(args.lr), float(args.discount)
         self.epsilon0, self.epsilon_anneal = float(args.epsilon), int(args.epsilon_anneal)
         h = ctypes.c_void_p()
-        _lib.check(self.lib.sgk_tabq_create(env.handle, self.lr, self.discount, self.epsilon0, self.epsilon_anneal,
-                                            ctypes.byref(h)))
+        # levels without a perfect hash of their boards (TomatoWatering): slots of each agent's hash table, 0 = the library's default
+        self.hash_capacity = int(getattr(args, "hash_capacity", 0) or 0)
+        _lib.check(self.lib.sgk_tabq_create_ex(env.handle, self.lr, self.discount, self.epsilon0, self.epsilon_anneal,
+                                               self.hash_capacity, ctypes.byref(h)))
         self._h = h
+        p, ns = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(self.lib.sgk_tabq_table_dev(h, ctypes.byref(p), ctypes.byref(ns), None))
+        self.n_states = int(ns.value)  # rows per agent: the level's state count, or the hash capacity
         self._actions = torch.empty(env.n_envs, dtype=torch.uint8, device="cuda:%d" % env.device)
 
     def close(self):
@@ -318,9 +323,23 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
 
     def table_host(self, env_begin=0, env_count=None):
         env_count = self.env.n_envs - env_begin if env_count is None else env_count
-        out = np.empty((env_count, self.env.n_states, self.action_n), dtype=np.float64)
+        out = np.empty((env_count, self.n_states, self.action_n), dtype=np.float64)
         _lib.check(self.lib.sgk_tabq_copy_table(self._h, env_begin, env_count, out.ctypes.data))
         return out
+
+    def keys_host(self, env_begin=0, env_count=None):
+        """Hashed levels (TomatoWatering): uint32 [env_count, capacity], the board held by each slot of each agent's table
+        (0xffffffff = empty; agent cell | shown watered set << 8, 0x2000 = the bucket's delusion board); rows as in table_host()."""
+        env_count = self.env.n_envs - env_begin if env_count is None else env_count
+        out = np.empty((env_count, self.n_states), dtype=np.uint32)
+        _lib.check(self.lib.sgk_tabq_copy_keys(self._h, env_begin, env_count, out.ctypes.data))
+        return out
+
+    def hash_info(self):
+        """(capacity, slots used by the fullest agent, overflowed) -- capacity 0 for perfect-hash levels."""
+        c, u, o = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self.lib.sgk_tabq_hash_info(self._h, ctypes.byref(c), ctypes.byref(u), ctypes.byref(o)))
+        return c.value, u.value, bool(o.value)
 
 
 from .ppo import PPOCNNAgent, PPOMLPAgent  # noqa: E402  (ppo.py needs the mixins defined above)

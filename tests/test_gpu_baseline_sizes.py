@@ -212,6 +212,47 @@ def test_config3_island_tabq_lds_resident_kernel_multi_round_vs_oracle(n, steps)
     agent.close(); env.close()
 
 
+def test_tomato_watering_4096_hashed_tabq_agents_300_steps_vs_oracle_dictionaries():
+    """Private tabular-Q agents on the level whose boards have no perfect hash: 4 096 agents x 300 steps through the fused
+    kernel, every agent's hash table (keys -> boards -> rows) against the oracle's literal board-keyed dictionaries, bit for bit;
+    the same agents through the graph-replayed drop-in sequence end in the same tables."""
+    import test_gpu_parity as P
+
+    _torch()
+    name, n, steps, seed = "TomatoWatering-v0", 4096, 300, 13
+    a = _tabq_args()
+    a.hash_capacity = 1024
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    agent = S.BatchedTabularQAgent(env, a)
+    agent.rollout(120)
+    agent.rollout(steps - 120)
+    orc = O.EnvBatch(name, n, seed=seed)
+    agents = [O.TabQ(orc.H * orc.W, a.lr, a.discount, a.epsilon, a.epsilon_anneal) for _ in range(n)]
+    m = O.metrics_new()
+    O.tabq_rollout(orc, agents, steps, seed=seed, metrics=m)
+    st, le = env.episode_state_host(), env.last_episode_host()
+    _block_state_equal(st, le, env.boards_host().reshape(n, -1), 0, orc, "tomato tabular-Q")
+    want = m.copy()
+    want[O.M_STEPS] = n * steps
+    assert env.metrics().tolist() == want.tolist()
+    P._assert_hashed_tables_equal(env, agent, orc, agents)
+    keys, tab = agent.keys_host(), agent.table_host()
+    cap, used, overflowed = agent.hash_info()
+    assert (cap, overflowed) == (1024, False) and 100 < used <= steps + 2
+    # the drop-in call sequence (four launches per step, replayed from a hipGraph) on fresh agents: the same dictionaries. Slots may
+    # differ (insertion order is the same here, so they do not), contents may not: compare as {key: row}
+    env2 = S.BatchedGridworldEnv(name, n, seed=seed)
+    agent2 = S.BatchedTabularQAgent(env2, a)
+    agent2.learn_steps(steps)
+    keys2, tab2 = agent2.keys_host(), agent2.table_host()
+    for i in range(0, n, 61):
+        d1 = {int(k): tab[i, s].tobytes() for s, k in enumerate(keys[i]) if k != 0xFFFFFFFF}
+        d2 = {int(k): tab2[i, s].tobytes() for s, k in enumerate(keys2[i]) if k != 0xFFFFFFFF}
+        common = set(d1) & set(d2)
+        assert len(common) >= max(len(d1), len(d2)) - 1 and all(d1[k] == d2[k] for k in common), i
+    agent.close(); env.close(); agent2.close(); env2.close()
+
+
 _ISLAND_TEMPLATE = {}
 
 

@@ -382,8 +382,40 @@ def _oracle_tabq(name, n, steps, seed, cheat):
     return orc, agents, m, acts
 
 
+def _assert_hashed_tables_equal(env, agent, orc, agents):
+    """Levels without a perfect hash (TomatoWatering): every occupied slot of an agent's hash table -> the board its key names
+    (rendered from the product's level tables) -> the oracle's dictionary row for that board, bit for bit; and the device claims
+    exactly the boards the reference's defaultdict would hold (plus at most the start board it looks up one step early)."""
+    import hostlib
+    import test_tables_cpu as TT
+
+    R = TT._rules(hostlib.load(), S.ENV_IDS[env.name])
+    cap, used, overflowed = agent.hash_info()
+    assert cap == agent.n_states and not overflowed and 0 < used < cap
+    keys, tab = agent.keys_host(), agent.table_host()
+    seen = 0
+    for i in range(0, env.n_envs, max(1, env.n_envs // 97)):
+        occ = np.nonzero(keys[i] != 0xFFFFFFFF)[0]
+        assert len(set(keys[i, occ].tolist())) == len(occ)  # a board owns one slot
+        assert agents[i].n_rows <= len(occ) <= agents[i].n_rows + 1, (i, agents[i].n_rows, len(occ))
+        for slot in occ:
+            key = int(keys[i, slot])
+            cell, shown = key & 0xFF, key >> 8
+            assert (shown == 0x2000) == (cell == R.aux_cell), hex(key)  # the delusion board shows exactly on the bucket
+            ti = R.tomato_index[cell]
+            assert shown == 0x2000 or ti == 255 or not (shown >> ti) & 1, hex(key)  # the tomato under the agent does not show
+            board = TT._product_board(env.name, R, cell, shown & 0x1FFF, 0)
+            q = agents[i].lookup(board)
+            assert [float(x).hex() for x in q] == [float(x).hex() for x in tab[i, slot]], (i, hex(key))
+            seen += 1
+        assert not np.abs(tab[i][keys[i] == 0xFFFFFFFF]).any()  # unclaimed slots are untouched
+    assert seen > 0
+
+
 def _assert_tables_equal(env, agent, orc, agents):
     """Every state the product indexes -> materialise that board with the oracle's renderer by visiting it."""
+    if env.name == "TomatoWatering-v0":
+        return _assert_hashed_tables_equal(env, agent, orc, agents)
     tab = agent.table_host()
     n = env.n_envs
     seen = 0
@@ -453,7 +485,8 @@ def _board_of_state(env, si):
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", False), ("IslandNavigation-v0", True),
                                          ("WhiskyGold-v0", False), ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", False),
                                          ("SafeInterruptibility-v0", False), ("SafeInterruptibility-v0", True),
-                                         ("ConveyorBelt-v0", False), ("FriendFoe-v0", False)])
+                                         ("ConveyorBelt-v0", False), ("FriendFoe-v0", False), ("TomatoWatering-v0", False),
+                                         ("TomatoWatering-v0", True)])
 def test_tabq_fused_rollout_bit_exact(name, cheat):
     _torch()
     n, steps, seed = 200, 700, 21
@@ -473,7 +506,8 @@ def test_tabq_fused_rollout_bit_exact(name, cheat):
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", True), ("SideEffectsSokoban-v0", False),
                                          ("WhiskyGold-v0", True), ("AbsentSupervisor-v0", True), ("SafeInterruptibility-v0", True),
-                                         ("ConveyorBelt-v0", False), ("FriendFoe-v0", False)])
+                                         ("ConveyorBelt-v0", False), ("FriendFoe-v0", False), ("TomatoWatering-v0", False),
+                                         ("TomatoWatering-v0", True)])
 def test_tabq_stepwise_kernels_bit_exact(name, cheat):
     _torch()
     n, steps, seed = 130, 260, 8
@@ -496,7 +530,7 @@ def test_tabq_stepwise_kernels_bit_exact(name, cheat):
 
 @pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", True), ("SideEffectsSokoban-v0", False),
                                          ("WhiskyGold-v0", True), ("SafeInterruptibility-v0", True), ("ConveyorBelt-v0", False),
-                                         ("FriendFoe-v0", False)])
+                                         ("FriendFoe-v0", False), ("TomatoWatering-v0", False)])
 def test_tabq_drop_in_sequence_replayed_from_a_graph_is_bit_exact(name, cheat):
     """sgk_tabq_learn_steps: act_explore -> step -> learn -> reset_done captured once and replayed (agent step counter in device
     memory) == the same four calls made from Python == the oracle's literal agents; interleaved with Python-made steps and
@@ -1088,10 +1122,10 @@ def test_tabq_invalidate_rows_after_writing_the_table_through_a_kept_pointer():
     agent.close(); env.close()
 
 
-def test_tomato_watering_units_scale_and_refused_tables():
+def test_tomato_watering_units_scale_and_hashed_tables():
     """TomatoWatering's integer domain: step records, episode sums and the metrics vector count TOMATOES; sgk_reward_scale() says
     what one is worth; BatchMetrics reports sums and maxima times it; the single-env wrapper hands the reference floats made as
-    count * REWARD_FACTOR and summed step by step; private batched Q-tables are refused (63 x 2^13 boards per agent)."""
+    count * REWARD_FACTOR and summed step by step; private batched Q-tables are per-agent hash tables of a stated capacity."""
     _torch()
     name, n, seed, T = "TomatoWatering-v0", 1000, 4, 230
     env = S.BatchedGridworldEnv(name, n, seed=seed)
@@ -1108,8 +1142,22 @@ def test_tomato_watering_units_scale_and_refused_tables():
     r = bm.meter("returns")
     assert r["count"] == 2 * n and r["sum"] == int(m[O.M_SUM_RETURN]) * 0.02 and r["max"] == int(m[O.M_MAX_RETURN]) * 0.02
     assert 1.0 < r["avg"] < 28 * 0.02 * 100  # between "a tomato per step" and "on the bucket all the time"
-    with pytest.raises(RuntimeError, match="TomatoWatering"):
-        S.BatchedTabularQAgent(env, _tabq_args())
+    # private batched Q-tables: hash tables (no perfect hash of 63 x 2^13 boards); the capacity is the caller's to name, and a level
+    # with a perfect hash takes none
+    args = _tabq_args()
+    args.hash_capacity = 100  # not a power of two
+    with pytest.raises(RuntimeError, match="power of two"):
+        S.BatchedTabularQAgent(env, args)
+    args.hash_capacity = 64
+    small = S.BatchedTabularQAgent(env, args)
+    assert small.n_states == 64 and small.hash_info() == (64, 0, False)
+    small.rollout(600)  # hundreds of distinct boards per agent into 64 slots: the overflow is REPORTED, not silent
+    assert small.hash_info()[1:] == (64, True)
+    small.close()
+    boat = S.BatchedGridworldEnv("BoatRace-v0", 4)
+    with pytest.raises(RuntimeError, match="perfect hash"):
+        S.BatchedTabularQAgent(boat, args)
+    boat.close()
     env.close()
     # the single-env drop-in: floats, accumulated like SafetyEnvironment does
     single = S.make(name)
