@@ -200,6 +200,9 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
     if (sn == sp) { n0 = p0; n1 = p1; n2 = p2; n3 = p3; }
     else {
       const double2 *rown = reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + sn) * 4);
+      // (this scattered 32-byte read costs a whole 128-byte line: the fabric's read requests are ALL 128 bytes here --
+      // TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ, none of 32 -- and a non-temporal load changes neither that nor the time for the
+      // better: 15.6 -> 17.8 us per launch at 262 144 agents, profiles/r03/exp_tabq_learn_gather.log)
       const double2 n01 = rown[0], n23 = rown[1];
       n0 = n01.x; n1 = n01.y; n2 = n23.x; n3 = n23.y;
     }

@@ -11,6 +11,7 @@ Two families:
 """
 import collections
 import ctypes
+import os
 from typing import NamedTuple
 
 import numpy as np
@@ -245,7 +246,8 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         self.epsilon0, self.epsilon_anneal = float(args.epsilon), int(args.epsilon_anneal)
         h = ctypes.c_void_p()
         # levels without a perfect hash of their boards (TomatoWatering): slots of each agent's hash table, 0 = the library's default
-        self.hash_capacity = int(getattr(args, "hash_capacity", 0) or 0)
+        # (args.hash_capacity, else SGK_TABQ_HASH_CAPACITY: the reference's flag grammar has no such option to extend)
+        self.hash_capacity = int(getattr(args, "hash_capacity", 0) or os.environ.get("SGK_TABQ_HASH_CAPACITY", 0) or 0)
         _lib.check(self.lib.sgk_tabq_create_ex(env.handle, self.lr, self.discount, self.epsilon0, self.epsilon_anneal,
                                                self.hash_capacity, ctypes.byref(h)))
         self._h = h
@@ -334,6 +336,15 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         out = np.empty((env_count, self.n_states), dtype=np.uint32)
         _lib.check(self.lib.sgk_tabq_copy_keys(self._h, env_begin, env_count, out.ctypes.data))
         return out
+
+    def check_hash_tables(self):
+        """Raise when some agent's hash table filled up (hashed levels): its Q-values are undefined from then on."""
+        cap, used, overflowed = self.hash_info()
+        if overflowed:
+            raise RuntimeError("a tabular-Q hash table of %d slots per agent overflowed on %s: re-run with a larger table "
+                               "(args.hash_capacity / SGK_TABQ_HASH_CAPACITY, a power of two; 36 bytes per slot and agent)"
+                               % (cap, self.env.name))
+        return cap, used
 
     def hash_info(self):
         """(capacity, slots used by the fullest agent, overflowed) -- capacity 0 for perfect-hash levels."""

@@ -254,6 +254,8 @@ def _batched_eval(agent, env, args, writer, period, rank, sdist):
 
     if rank == 0:
         print("#### EVAL ####")
+    if hasattr(agent, "check_hash_tables"):
+        agent.check_hash_tables()  # levels without a perfect hash of their boards: a full table is an error, not a silent state
     batched_default_eval(agent, env, args.eval_timesteps)
     sdist.global_metrics(env).write(writer, period, prefix="Evaluation/")
     env.reset()
