@@ -91,6 +91,10 @@ struct sgk_env {
   long long *metrics_pinned = nullptr;  // [SGK_METRICS_LEN] pinned device-mapped host words the reduce kernel also writes
   float *gamma_dev = nullptr;        // [1024] float32(discount ** t) for sgk_discounted_returns
   double gamma_discount = -1.0;
+  // the single-env step server (sgk_step.hip, env_server_kernel): a resident wave that serves sgk_step_host through a mailbox
+  sgk::SgkMailbox *mailbox = nullptr;  // pinned device-mapped host memory (host_visible handles of <= 64 envs)
+  bool server_running = false;
+  uint32_t server_seq = 0;             // number of the last step requested
   bool host_visible = false;         // SGK_MEM_HOST_VISIBLE: state/rec/boards/actions live in pinned device-mapped host memory
   uint8_t *hv_actions = nullptr;     // host-visible action buffer (host_visible mode)
   GraphCache graphs;                  // (n_steps, flags) -> captured step launches
@@ -117,6 +121,21 @@ namespace sgk {
 hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st,
                                int64_t env_off, int64_t count);
 }  // namespace sgk
+
+// Ask the step server to leave and wait until it has: afterwards the handle's arrays in memory are current (state words, metric
+// partials) and its stream is free for the next kernel.
+static int stop_server(sgk_env *h) {
+  if (!h->server_running) return SGK_OK;
+  h->mailbox->request = (uint64_t)SGK_SERVER_STOP;
+  __sync_synchronize();
+  hipError_t e = hipStreamSynchronize(h->stream);
+  h->server_running = false;
+  h->mailbox->request = (uint64_t)h->server_seq;
+  h->mailbox->exited = 0;
+  __sync_synchronize();
+  if (e != hipSuccess) return hip_fail(e, "stopping the step server");
+  return SGK_OK;
+}
 
 extern "C" {
 
@@ -181,6 +200,7 @@ int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agen
 int sgk_destroy(sgk_env *h) {
   if (!h) return SGK_OK;
   (void)hipSetDevice(h->sh.device);
+  (void)stop_server(h);
   (void)hipStreamSynchronize(h->stream);  // nullptr = the NULL stream
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   h->graphs.clear();
@@ -190,6 +210,7 @@ int sgk_destroy(sgk_env *h) {
     if (s.rec) (void)hipHostFree(s.rec);
     if (s.boards) (void)hipHostFree(s.boards);
     if (h->hv_actions) (void)hipHostFree(h->hv_actions);
+    if (h->mailbox) (void)hipHostFree(h->mailbox);
     s.state = nullptr; s.rec = nullptr; s.boards = nullptr;
   }
   (void)hipFree(s.rules_dev); (void)hipFree(s.state); (void)hipFree(s.rec); (void)hipFree(s.boards); (void)hipFree(s.last_return);
@@ -300,6 +321,11 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
     SGK_TRY(hipHostMalloc((void **)&s.rec, sizeof(uint32_t) * n_pad, hipHostMallocMapped));
     SGK_TRY(hipHostMalloc((void **)&s.boards, (size_t)s.pitch * n_pad, hipHostMallocMapped));
     SGK_TRY(hipHostMalloc((void **)&h->hv_actions, (size_t)n_pad, hipHostMallocMapped));
+    const char *srv = getenv("SGK_STEP_SERVER");  // A/B knob: 0 = one launch per sgk_step_host call, as before
+    if (n_envs <= 64 && !(srv && srv[0] == '0')) {
+      SGK_TRY(hipHostMalloc((void **)&h->mailbox, sizeof(sgk::SgkMailbox), hipHostMallocMapped));
+      memset((void *)h->mailbox, 0, sizeof(sgk::SgkMailbox));
+    }
   } else {
     SGK_TRY(hipMalloc(&s.state, sizeof(uint64_t) * n_pad));
     SGK_TRY(hipMalloc(&s.rec, sizeof(uint32_t) * n_pad));
@@ -343,6 +369,10 @@ int sgk_create(int env_id, int64_t n_envs, int device, uint64_t seed, sgk_env **
   do {                                                        \
     if (!(h)) return fail(SGK_ERR_INVALID, "handle is NULL"); \
     SGK_HIP(hipSetDevice((h)->sh.device));                    \
+    if ((h)->server_running) {                                \
+      int rc__ = stop_server(h);                              \
+      if (rc__ != SGK_OK) return rc__;                        \
+    }                                                         \
   } while (0)
 
 int sgk_reward_scale(sgk_env *h, double *scale_out) {
@@ -384,13 +414,13 @@ int sgk_get_info(const sgk_env *h, sgk_info *out) {
 }
 
 int sgk_set_stream(sgk_env *h, void *hip_stream) {
-  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_CHECK_HANDLE(h);  // (also stops the step server: it runs on the stream that is about to change)
   h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;  // graphs are captured on own_stream and stay valid
   return SGK_OK;
 }
 
 int sgk_set_seed(sgk_env *h, uint64_t seed) {
-  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_CHECK_HANDLE(h);
   h->sh.seed = seed;  // kernel argument of every later launch; captured step graphs carry the old seed and are dropped
   (void)hipStreamSynchronize(h->stream);  // a replay of a graph about to be destroyed may still be in flight
   h->graphs.clear();
@@ -398,7 +428,7 @@ int sgk_set_seed(sgk_env *h, uint64_t seed) {
 }
 
 int sgk_use_default_stream(sgk_env *h) {
-  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_CHECK_HANDLE(h);
   h->stream = nullptr;  // the device's NULL (legacy default) stream: where PyTorch queues work unless told otherwise
   return SGK_OK;
 }
@@ -454,7 +484,7 @@ int sgk_step(sgk_env *h, const uint8_t *actions_dev, uint32_t flags) {
 }
 
 int sgk_account_steps(sgk_env *h, int64_t n_steps) {
-  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_CHECK_HANDLE(h);
   if (n_steps < 0 && (uint64_t)(-n_steps) > h->sh.lockstep_t) return fail(SGK_ERR_INVALID, "would make the step counter negative");
   h->sh.lockstep_t += (uint64_t)n_steps;  // two's complement: also un-counts a launch that was only recorded
   h->t_dev_stale = true;
@@ -464,10 +494,53 @@ int sgk_account_steps(sgk_env *h, int64_t n_steps) {
 
 int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_step_rec *rec_host, int8_t *boards_host,
                   int32_t *episode_return_host) {
-  SGK_CHECK_HANDLE(h);
+  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_HIP(hipSetDevice(h->sh.device));  // (not SGK_CHECK_HANDLE: this is the one entry point the step server keeps running for)
   if (!actions_host) return fail(SGK_ERR_INVALID, "actions_host is NULL");
   sgk::Shard &s = h->sh;
   const size_t n = (size_t)s.n, bbytes = n * (size_t)s.n_cells;
+  if (h->host_visible && h->mailbox) {
+    // the step server: no launch at all in the steady state -- the action goes into host-visible memory, a request number into
+    // the mailbox, and the resident wave publishes the number back once the outputs are in the host-visible buffers
+    memcpy(h->hv_actions, actions_host, n);
+    sgk::SgkMailbox *mb = h->mailbox;
+    if (!h->server_running) {
+      mb->request = (uint64_t)h->server_seq;
+      mb->done = h->server_seq;
+      mb->exited = 0;
+      __sync_synchronize();
+      SGK_HIP(sgk::launch_env_server(s, h->hv_actions, mb, h->server_seq, h->stream));
+      h->server_running = true;
+    }
+    const uint32_t prev = h->server_seq;
+    uint32_t seq = prev + 1u;
+    if (seq == SGK_SERVER_STOP) seq = 0u;
+    __sync_synchronize();  // the other envs' actions before the request word
+    mb->request = (uint64_t)seq | ((uint64_t)(flags & 0xffu) << 32) | ((uint64_t)(actions_host[0] & 3u) << 40);
+    h->server_seq = seq;
+    uint64_t spins = 0;
+    while (mb->done != seq) {
+      if (mb->exited != 0) {
+        // the server left (idle) without having seen this request: start another one that has served up to seq - 1
+        SGK_HIP(hipStreamSynchronize(h->stream));
+        mb->exited = 0;
+        __sync_synchronize();
+        SGK_HIP(sgk::launch_env_server(s, h->hv_actions, mb, prev, h->stream));
+      }
+      if (++spins > (1ull << 33)) return fail(SGK_ERR_HIP, "the step server did not answer");
+      __builtin_ia32_pause();
+    }
+    __sync_synchronize();
+    s.lockstep_t += 1;
+    h->t_dev_stale = true;
+    h->steps_issued += s.n;
+    if (rec_host) memcpy(rec_host, s.rec, 4 * n);
+    if (boards_host)
+      for (size_t i = 0; i < n; ++i) memcpy(boards_host + i * s.n_cells, s.boards + i * s.pitch, (size_t)s.n_cells);
+    if (episode_return_host)
+      for (size_t i = 0; i < n; ++i) episode_return_host[i] = (int32_t)(int16_t)((uint32_t)(s.state[i] >> 32) & 0xffff);
+    return SGK_OK;
+  }
   if (h->host_visible) {
     // zero-copy: the action vector, the state words, the records and the boards are host-visible; one launch, one sync
     memcpy(h->hv_actions, actions_host, n);
@@ -658,7 +731,7 @@ int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flags, int8_
 }
 
 int sgk_boards_dev(sgk_env *h, int8_t **boards_dev, int64_t *pitch) {
-  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_CHECK_HANDLE(h);
   if (boards_dev) *boards_dev = h->sh.boards;
   if (pitch) *pitch = h->sh.pitch;
   return SGK_OK;
@@ -666,20 +739,21 @@ int sgk_boards_dev(sgk_env *h, int8_t **boards_dev, int64_t *pitch) {
 
 int sgk_step_records_dev(sgk_env *h, sgk_step_rec **rec_dev) {
   if (!h || !rec_dev) return fail(SGK_ERR_INVALID, "NULL argument");
+  SGK_CHECK_HANDLE(h);
   *rec_dev = reinterpret_cast<sgk_step_rec *>(h->sh.rec);
   return SGK_OK;
 }
 
 int sgk_metrics_dev(sgk_env *h, int64_t **metrics_dev) {
   if (!h || !metrics_dev) return fail(SGK_ERR_INVALID, "NULL argument");
-  SGK_HIP(hipSetDevice(h->sh.device));
+  SGK_CHECK_HANDLE(h);
   SGK_HIP(sgk::launch_metrics_reduce(h->sh, h->stream));  // folds the per-workgroup partials; stream-ordered
   *metrics_dev = h->sh.metrics;
   return SGK_OK;
 }
 
 int sgk_episode_arrays_dev(sgk_env *h, int32_t **last_return_dev, int32_t **last_performance_dev, int32_t **n_episodes_dev) {
-  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  SGK_CHECK_HANDLE(h);
   if (last_return_dev) *last_return_dev = h->sh.last_return;
   if (last_performance_dev) *last_performance_dev = h->sh.last_perf;
   if (n_episodes_dev) *n_episodes_dev = h->sh.n_episodes;

@@ -133,6 +133,9 @@ typedef uint32_t sgk_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SGK_BOARD_STORE_AUX
 #define SGK_BOARD_STORE_AUX 16
 #endif
+#ifndef SGK_RING_STORE_AUX
+#define SGK_RING_STORE_AUX 18  // trajectory rings: sc1 | nt
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // observation materialisation
@@ -409,7 +412,10 @@ struct WaveTileLds {
     if (was != now) poke(R, now);
   }
 
-  // image -> HBM: all 64 * NC bytes, `dst` wave-uniform and 16-byte aligned
+  // image -> HBM: all 64 * NC bytes, `dst` wave-uniform and 16-byte aligned. AUX = the stores' cache policy: write-through
+  // (sc1) for buffers that are rewritten in place; write-through + non-temporal for a trajectory ring, whose bytes nothing
+  // on the chip reads again (the pure store probe gains 2.6-3.6 % with it on every box: profiles/r03/write_patterns_*.log)
+  template <int AUX = SGK_BOARD_STORE_AUX>
   __device__ __forceinline__ void flush(int8_t *dst) const {
     const int lane = threadIdx.x & 63;
     __builtin_amdgcn_wave_barrier();
@@ -423,13 +429,25 @@ struct WaveTileLds {
         const uint4 v = *reinterpret_cast<const uint4 *>(tile + 16 * j);
 #if SGK_STREAM_STORES
         sgk_u32x4 v4 = {v.x, v.y, v.z, v.w};
-        __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, j * 16, 0, SGK_BOARD_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, j * 16, 0, AUX);
 #else
         reinterpret_cast<uint4 *>(dst)[j] = v;
 #endif
       }
     }
     __builtin_amdgcn_wave_barrier();  // the next re-draw comes after these reads in the instruction stream
+  }
+
+  // the first n_bytes of the image only (a batch smaller than a tile whose destination is not padded HBM but host memory)
+  __device__ __forceinline__ void flush_prefix(int8_t *dst, int n_bytes) const {
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      const int j = lane + 64 * it;
+      if (j * 16 < n_bytes) reinterpret_cast<uint4 *>(dst)[j] = *reinterpret_cast<const uint4 *>(tile + 16 * j);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 
   // one-shot form (per-launch kernels): draw, store

@@ -54,6 +54,21 @@ struct TabqShard {
 };
 
 hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, hipStream_t st);
+// The single-env step server's mailbox (pinned, device-mapped host memory; each word on a cache line of its own) and launcher
+struct SgkMailbox {
+  // host -> device, ONE 8-byte word so that one PCIe read carries the whole request of a single env: bits 0..31 the number of
+  // the step asked for (never SGK_SERVER_STOP; SGK_SERVER_STOP = leave), bits 32..39 the SGK_F_* flags of that step, bits 40..47
+  // env 0's action (the other envs' actions, if any, are read from the host-visible action buffer)
+  volatile uint64_t request;
+  uint32_t pad0[14];
+  volatile uint32_t done;     // device -> host: number of the last step whose outputs are in the host-visible buffers
+  uint32_t pad2[15];
+  volatile uint32_t exited;   // device -> host: 0 while the server runs; (last step served + 1) once it has left
+  uint32_t pad3[15];
+};
+#define SGK_SERVER_STOP 0xffffffffu
+#define SGK_SERVER_IDLE_POLLS 4000u  // ~a few milliseconds of PCIe polls
+hipError_t launch_env_server(const Shard &sh, const uint8_t *actions, SgkMailbox *mb, uint32_t last, hipStream_t st);
 hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flags, hipStream_t st);
 // the same loop with every step's board tile and step record materialised: into the env's own buffers (rings == nullptr) or
 // into trajectory rings boards [ring][n][n_cells] / recs [ring][n], step k -> slice (slice0 + k) % ring

@@ -148,6 +148,87 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The single-env drop-in's step server (host-in-the-loop: reference learn.py:38,69 calls env.step once per agent decision).
+// A launch per step costs the host ~22 us (launch + completion); here ONE wave stays resident and serves steps through a
+// mailbox in pinned, device-mapped HOST memory: the host writes the action(s) and a request number, the wave polls the number
+// over PCIe, steps its envs (state words in registers between steps, rule tables staged once), writes state word / step record /
+// board tile to the host-visible buffers, fences to system scope and publishes the number. The server leaves by itself after
+// SGK_SERVER_IDLE_POLLS polls without work (a host that went away cannot strand it) and whenever the host asks (request ==
+// SGK_SERVER_STOP): every other entry point stops it first, so the arrays in memory are always current outside sgk_step_host.
+// ------------------------------------------------------------------------------------------------
+template <int ENV, int LAYOUT>
+__global__ __launch_bounds__(64) void env_server_kernel(StepArgs a, SgkMailbox *mb, uint32_t last) {
+  constexpr int NC = Geom<ENV>::NC;
+  constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
+  __shared__ SgkRules R;
+  __shared__ CompactLds<NC> C;
+  stage_rules(R, a.rules);
+  __shared__ __attribute__((aligned(16))) uint8_t tile_image[64 * NC];
+  WaveTileLds<ENV, NC> W;
+  W.bind(tile_image);
+  if (COMPACT) stage_rotations(C, R);
+  const int lane = threadIdx.x;
+  const int64_t env = lane;
+  const bool valid = env < a.n;
+  EnvState s = initial_state(R);
+  if (valid) s = unpack_state(a.state[env]);
+  load_episode_index<ENV>(s, a.n_resets, env, valid);
+  EpisodeAcc acc;
+  acc_init(acc);
+  uint32_t idle = 0;
+  for (;;) {
+    // lane 0's system-scope load is the poll (one PCIe read); the word is made wave-uniform before it steers control flow
+    uint64_t word = 0;
+    if (lane == 0) word = __hip_atomic_load(&mb->request, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t req = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(word >> 32));
+    if (req == last) {
+      if (++idle > SGK_SERVER_IDLE_POLLS) break;
+      continue;
+    }
+    if (req == SGK_SERVER_STOP) break;
+    idle = 0;
+    const uint32_t flags = hi & 0xffu;
+    int action = (int)((hi >> 8) & 3u);  // env 0's action rides in the request word
+    if (a.n > 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the other actions were written before the request word
+      if (valid) action = (int)(__hip_atomic_load(&a.actions[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & 3u);
+    }
+    StepArgs b = a;
+    b.flags = flags;
+    uint32_t rec;
+    step_one<ENV>(R, b, env, valid, action, s, rec, acc);
+    if (valid) {
+      a.state[env] = pack_state(s);
+      a.rec[env] = rec;
+    }
+    if (!(flags & SGK_F_NO_BOARDS)) {
+      if (COMPACT) {  // only the rows of the envs there are: the destination is host memory, every byte crosses PCIe
+        W.draw_all(C, R, sprite_info<ENV>(R, s));
+        W.flush_prefix(a.boards, (int)a.n * NC);
+      } else if (valid) {
+        write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the outputs are visible to the host before the number is
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&mb->done, req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    last = req;
+  }
+  acc_flush(acc, a.metrics);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(&mb->exited, last + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // "served up to `last`"
+}
+
+hipError_t launch_env_server(const Shard &sh, const uint8_t *actions, SgkMailbox *mb, uint32_t last, hipStream_t st) {
+  (void)hipGetLastError();
+  StepArgs a = make_step_args(sh, actions, 0);
+  SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, env_server_kernel<E, L><<<dim3(1), dim3(64), 0, st>>>(a, mb, last));
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused random rollout: n_steps lockstep steps in one launch, the env state in registers for all of them.
 //   STREAM = false  boards and the step record are materialised ONCE, after the last step (no per-step output exists);
 //   STREAM = true   every step's outputs are MATERIALISED in HBM like a per-step launch's -- the board tile (wave-private
@@ -164,6 +245,7 @@ struct StreamOut {
   int32_t ring, slice0;
   int32_t tiles_ok;  // ring slices are 16-byte aligned (n * NC % 16 == 0): whole tiles go through the tile writer
   int32_t tile_major;  // rings laid out [n_tiles][ring][64][...] (SGK_F_RING_TILE_MAJOR): padded tiles, always whole
+  int32_t ring_nt;     // board tiles into the ring as non-temporal write-through stores (rings far larger than the caches)
 };
 
 template <int ENV, int LAYOUT, bool STREAM>
@@ -279,7 +361,12 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
           const uint32_t now = sprite_info<ENV>(R, s);
           W.update(R, drawn, now);
           drawn = now;
-          if (tiles) W.flush(dense + wt * 64 * NC);
+          if (tiles) {
+            if (o.boards && o.ring_nt) W.template flush<SGK_RING_STORE_AUX>(dense + wt * 64 * NC);
+            else W.flush(dense + wt * 64 * NC);
+            // the last step's board also into the env's own buffer: it shows the final state without a re-render launch
+            if (o.boards && k == n_steps - 1 && COMPACT) W.flush(a.boards + wt * 64 * NC);
+          }
 #else
           if (tiles) W.write(sprite_info<ENV>(R, s), dense + wt * 64 * NC);
 #endif
@@ -603,7 +690,7 @@ hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flag
   (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   StepArgs a = make_step_args(sh, nullptr, flags);
   int grid = grid_for((sh.n + WG - 1) / WG, sh.rollout_grid);
-  StreamOut o{nullptr, nullptr, 1, 0, 0};
+  StreamOut o{nullptr, nullptr, 1, 0, 0, 0, 0};
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
                           rollout_random_kernel<E, L, false><<<dim3(grid), dim3(WG), 0, st>>>(a, n_steps, o));
   return hipGetLastError();
@@ -617,12 +704,18 @@ hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flag
   // and the stream of stores needs every CU busy), up to one 256-env workgroup per tile
   int grid = grid_for((sh.n + WG - 1) / WG, sh.stream_grid);
   StreamOut o{boards_ring, recs_ring, ring < 1 ? 1 : ring, slice0, (int32_t)(((sh.n * sh.n_cells) % 16) == 0 && ((uintptr_t)boards_ring % 16) == 0),
-              (int32_t)((flags & SGK_F_RING_TILE_MAJOR) != 0)};
+              (int32_t)((flags & SGK_F_RING_TILE_MAJOR) != 0),
+              // non-temporal only where the ring dwarfs the caches. Measured at 1 M BoatRace envs, same box, three repeats: a
+              // 100-slice ring (3 GB) 6.32 vs 6.52 us per step with / without, a 32-slice ring (1 GB) 5.34 vs 4.90
+              (int32_t)((int64_t)(ring < 1 ? 1 : ring) * sh.n * (sh.n_cells + 4) > (3ll << 29))};
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
                           rollout_random_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a, n_steps, o));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (boards_ring && !(flags & SGK_F_NO_BOARDS)) return launch_reset(sh, nullptr, 2, st);  // the env's own boards: the final state
+  // the env's own boards show the final state: whole compact tiles were written by the kernel's last step; the other cases
+  // (pitched rows, a partial last tile, unaligned slices, the register tile writer) are re-rendered from the state words
+  const bool in_kernel = SGK_TILE_IN_LDS && sh.layout == SGK_LAYOUT_COMPACT && (o.tile_major || (o.tiles_ok && sh.n % 64 == 0));
+  if (boards_ring && !(flags & SGK_F_NO_BOARDS) && !in_kernel) return launch_reset(sh, nullptr, 2, st);
   return hipSuccess;
 }
 

@@ -1029,6 +1029,42 @@ def test_rccl_metrics_allreduce_through_the_c_abi_world_of_one():
     env.close()
 
 
+@pytest.mark.parametrize("name,n", [("BoatRace-v0", 1), ("WhiskyGold-v0", 37), ("FriendFoe-v0", 64), ("TomatoWatering-v0", 5)])
+def test_step_server_serves_host_steps_bit_exactly(name, n):
+    """sgk_step_host on a host-visible handle of <= 64 envs is served by a resident wave (no launch per step): results equal the
+    oracle's step by step, other entry points in between stop it and see current arrays, an idle server leaves by itself and the
+    next step starts another, and with SGK_STEP_SERVER=0 semantics (one launch per call) the outputs are the same."""
+    import ctypes
+    import time
+
+    _torch()
+    seed = 6
+    env = S.BatchedGridworldEnv(name, n, seed=seed, host_visible=True)
+    orc = O.EnvBatch(name, n, seed=seed)
+    m = O.metrics_new()
+    rng = np.random.RandomState(3)
+    rec = np.zeros((n, 4), dtype=np.int8)
+    boards = np.zeros((n, env.n_cells), dtype=np.int8)
+    ret = np.zeros(n, dtype=np.int32)
+    for t in range(330):
+        acts = rng.randint(0, 4, size=n).astype(np.uint8)
+        _lib.check(env.lib.sgk_step_host(env.handle, acts.ctypes.data, _lib.F_AUTO_RESET, rec.ctypes.data, boards.ctypes.data,
+                                         ret.ctypes.data))
+        want = orc.rollout(1, seed=seed, actions=acts[None], auto_reset=True, metrics=m)
+        assert (rec == want).all(), t
+        assert (boards == orc.boards()).all(), t
+        assert (ret == orc.field("episode_return")).all(), t
+        if t in (40, 171):   # another entry point: the server is stopped, the arrays in memory are current
+            assert_same_state(env, orc, "t=%d" % t)
+        if t == 250:         # longer than the server's idle budget: it has left; the next step starts another one
+            time.sleep(0.3)
+    got = env.metrics()
+    want_m = m.copy()
+    want_m[O.M_STEPS] = n * 330
+    assert got.tolist() == want_m.tolist()
+    env.close()
+
+
 def test_comm_info_reports_what_rccl_says_the_communicator_spans():
     import ctypes
 

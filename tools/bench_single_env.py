@@ -1,0 +1,49 @@
+"""Where a single-env `env.step()` of the drop-in goes (BASELINE config 1: one env, a host-side agent in the loop): the C entry
+point alone (sgk_step_host through ctypes), the GridworldEnv wrapper around it, and the reference-shaped train() loop on it
+(long enough that creating the env does not show). The CPU side of the comparison is bench.py's cpu_baseline leg
+(`reference_shaped_python_loop_1core`): only tests/, smoke() and that leg touch oracle/."""
+import contextlib
+import io
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+
+import safe_grid_agents_amd as S  # noqa: E402
+from safe_grid_agents_amd import _lib  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "BoatRace-v0"
+N = 20000
+env = S.make(name)
+env.reset()
+b = env._b
+act = np.zeros(1, dtype=np.uint8)
+rec = np.zeros((1, 4), dtype=np.int8)
+board = np.zeros((1, b.n_cells), dtype=np.int8)
+ret = np.zeros(1, dtype=np.int32)
+lib = b.lib
+for _ in range(200):
+    lib.sgk_step_host(b.handle, act.ctypes.data, 0, rec.ctypes.data, board.ctypes.data, ret.ctypes.data)
+t0 = time.perf_counter()
+for i in range(N):
+    act[0] = i & 3
+    lib.sgk_step_host(b.handle, act.ctypes.data, 1, rec.ctypes.data, board.ctypes.data, ret.ctypes.data)
+t_c = (time.perf_counter() - t0) / N * 1e6
+env.reset()
+t0 = time.perf_counter()
+for i in range(N):
+    s, r, d, info = env.step(i & 3)
+    if d:
+        env.reset()
+t_w = (time.perf_counter() - t0) / N * 1e6
+print("%s: sgk_step_host (ctypes) %.1f us | GridworldEnv.step %.1f us" % (name, t_c, t_w), flush=True)
+a = S.prepare_parser().parse_args(["-S", "7", "-E", "400", "-EE", "1000", "-V", "100", "-EV", "0", "boat", "tabular-q", "-l", ".5"])
+with contextlib.redirect_stdout(io.StringIO()):
+    t0 = time.perf_counter()
+    _, hist, _ = S.train(a, env_factory=lambda nm: env if env.reset() is not None else env, writer_factory=lambda d: S.NullWriter(d))
+    dt = time.perf_counter() - t0
+print("train() boat tabular-q, 400 episodes on the HIP single env: %.0f steps/s (%.1f us per step)" % ((hist["t"] + 100) / dt, dt / (hist["t"] + 100) * 1e6), flush=True)
