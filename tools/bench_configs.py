@@ -40,7 +40,7 @@ out = []
 # config 1: BoatRace + tabular-q, single env, the reference-shaped Python loop (`main.py boat tabular-q --lr .5`)
 # (the CPU leg of this config lives in bench.py's cpu_baseline: only tests/, smoke() and that leg may touch oracle/)
 
-def single_env_rate(env_factory, episodes=30):
+def single_env_rate(env_factory, episodes=400):  # long enough that creating the env (~0.3 s) does not show
     args = S.prepare_parser().parse_args(["-S", "7", "-E", str(episodes), "-EE", "1000", "-V", "100", "-EV", "0",
                                           "boat", "tabular-q", "-l", ".5"])
     args.log_dir = None
@@ -51,7 +51,7 @@ def single_env_rate(env_factory, episodes=30):
 
 
 r_gpu = single_env_rate(lambda name: S.make(name))
-out.append({"config": 1, "what": "same loop on the HIP single env (sgk_step_host: H2D action + launch + D2H record/board per step; PCIe-inclusive)",
+out.append({"config": 1, "what": "reference-shaped train() loop (boat tabular-q, 400 episodes) on the HIP single env (sgk_step_host served by the step server; PCIe-inclusive)",
             "env_steps_per_s": r_gpu})
 
 # config 2: BoatRace random-action rollout, 65 536 envs lockstep on 1 MI355X (step kernel only)
