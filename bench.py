@@ -91,7 +91,8 @@ def cpu_baseline(env_name, seed, target_seconds=10.0):
     import safe_grid_agents_amd as S
     from oracle.gym_shim import OracleGridworldEnv
 
-    a = S.prepare_parser().parse_args(["-S", "7", "-E", "40", "-EE", "1000", "-V", "100", "-EV", "0", "boat", "tabular-q",
+    # (400 episodes: long enough that creating the env and the first calls do not show -- 40 episodes read 3 x lower)
+    a = S.prepare_parser().parse_args(["-S", "7", "-E", "400", "-EE", "1000", "-V", "100", "-EV", "0", "boat", "tabular-q",
                                        "-l", ".5"])
     import contextlib
     import io

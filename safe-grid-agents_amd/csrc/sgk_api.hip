@@ -528,7 +528,9 @@ int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_s
         SGK_HIP(sgk::launch_env_server(s, h->hv_actions, mb, prev, h->stream));
       }
       if (++spins > (1ull << 33)) return fail(SGK_ERR_HIP, "the step server did not answer");
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#endif
     }
     __sync_synchronize();
     s.lockstep_t += 1;

@@ -26,6 +26,12 @@ namespace sgk {
 
 constexpr int WG = 256;
 
+// The wave's index inside its workgroup as a value the compiler KNOWS to be wave-uniform. `threadIdx.x >> 6` is uniform but not
+// provably so: everything derived from it (tile index, tile pointer, the buffer descriptor of the tile stores) then lives in
+// VGPRs, and hipcc wraps every buffer store in a "waterfall" loop (v_readfirstlane x 4, compare, s_and_saveexec, the store,
+// loop; cdna_hip_programming.md T20) -- ten extra instructions per store and no overlap between consecutive stores.
+__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // workgroup-cooperative copy of the rule tables HBM/L2 -> LDS
 __device__ __forceinline__ void stage_rules(SgkRules &dst, const SgkRules *__restrict__ src) {
   constexpr int NW = sizeof(SgkRules) / 4;
@@ -422,19 +428,29 @@ struct WaveTileLds {
 #if SGK_STREAM_STORES
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, BYTES, 0x00020000);
 #endif
+#if SGK_STREAM_STORES
+    // All the LDS reads first, then the stores: one LDS round trip per flush, not one per 16-byte chunk. No lane is predicated:
+    // a lane past the image's last chunk reads the last chunk again and its store is dropped by the buffer's range check
+    // (num_records = BYTES) -- a predicated second chunk made the compiler merge the stores behind a waterfall loop.
+    uint4 v[ITS];
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
       const int j = lane + 64 * it;
-      if (ITS * 64 == CHUNKS || j < CHUNKS) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(tile + 16 * j);
-#if SGK_STREAM_STORES
-        sgk_u32x4 v4 = {v.x, v.y, v.z, v.w};
-        __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, j * 16, 0, AUX);
-#else
-        reinterpret_cast<uint4 *>(dst)[j] = v;
-#endif
-      }
+      const int jr = (ITS * 64 == CHUNKS || j < CHUNKS) ? j : CHUNKS - 1;
+      v[it] = *reinterpret_cast<const uint4 *>(tile + 16 * jr);
     }
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      sgk_u32x4 v4 = {v[it].x, v[it].y, v[it].z, v[it].w};
+      __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, (lane + 64 * it) * 16, 0, AUX);
+    }
+#else
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      const int j = lane + 64 * it;
+      if (ITS * 64 == CHUNKS || j < CHUNKS) reinterpret_cast<uint4 *>(dst)[j] = *reinterpret_cast<const uint4 *>(tile + 16 * j);
+    }
+#endif
     __builtin_amdgcn_wave_barrier();  // the next re-draw comes after these reads in the instruction stream
   }
 

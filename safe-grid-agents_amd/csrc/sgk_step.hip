@@ -24,7 +24,7 @@ namespace sgk {
 #define SGK_TILE_DECLARE(ENV, NC, ON)                                                 \
   __shared__ __attribute__((aligned(16))) uint8_t tile_images[WG / 64][64 * (NC)];    \
   WaveTileLds<ENV, NC> W;                                                             \
-  W.bind(tile_images[threadIdx.x >> 6]);                                              \
+  W.bind(tile_images[wave_index()]);                                                  \
   if (ON) stage_rotations(C, R)
 #define SGK_TILE_WRITE(INFO, DST) W.write(C, R, (INFO), (DST))
 #else
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
   __shared__ SgkRules R;
   __shared__ CompactLds<NC> C;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int64_t n_wt = (a.n + 63) / 64;
   const int64_t wt0 = (int64_t)blockIdx.x * (WG / 64) + wave, wstride = (int64_t)gridDim.x * (WG / 64);
   // issue the first tile's state (and action) loads before the rule tables are staged: one memory round trip less
@@ -256,7 +256,8 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
   __shared__ CompactLds<NC> C;
   stage_rules(R, a.rules);
   SGK_TILE_DECLARE(ENV, NC, (COMPACT || STREAM));
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the outputs-once form stores nothing per step: a scalar tile index buys it nothing and costs it registers -- 64 -> 79 VGPRs)
+  const int lane = threadIdx.x & 63, wave = STREAM ? wave_index() : (int)(threadIdx.x >> 6);
   const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
   const int64_t n_wt = (a.n + 63) / 64;
   EpisodeAcc acc;
@@ -287,28 +288,46 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
     if (STREAM && boards_on) W.draw_all(C, R, drawn);
 #endif
     if (STREAM) {
-    // which Philox block (64 steps) and which of its words (16 steps) are in hand: compared against the step index, so the
-    // first step needs no special case (a peeled first iteration doubled the loop body, Philox and tile writer included)
-    uint64_t have_block = ~0ull, have_word = ~0ull;
+    // Streamed: at 1 M envs the loop hides behind its stores, but a small batch (65 536 envs = ONE wave per SIMD, the per-GPU
+    // share of an 8-GPU run two) is bound by the wave's own instruction latency, so the step carries as little as it can: every
+    // destination is a pointer set up here and advanced by a wave-uniform stride (the slice / layout / ring arithmetic and its
+    // branches used to run on every step), the action word is counted down instead of compared against the 64-bit step index.
+    const bool tm = o.boards && o.tile_major;
+    // the env's own buffer is padded; so are tile-major rings; slice-major rings take whole tiles where slices are 16-byte aligned
+    const bool tiles = o.boards ? (tm || (o.tiles_ok && whole_tile)) : COMPACT;
+    const bool flush_nt = o.boards && o.ring_nt;
+    // this lane's record of the current slice (tile-major: the record of env e sits at row e % 64 = its lane) ...
+    uint32_t *recs_p = !o.recs ? a.rec + env
+                               : (o.tile_major ? o.recs + (wt * (int64_t)o.ring + slice) * 64 + lane : o.recs + (int64_t)slice * a.n + env);
+    const int64_t rec_stride = !o.recs ? 0 : (o.tile_major ? 64 : a.n);  // elements per slice
+    // ... and the board base of the current slice, wave-uniform, rows of NC bytes (tile-major: `dense + wt * 64 * NC` is this
+    // tile's slot of the slice)
+    int8_t *dense = !o.boards ? a.boards
+                              : (tm ? o.boards + ((wt * (int64_t)o.ring + slice) - wt) * 64 * NC : o.boards + (int64_t)slice * a.n * NC);
+    const int64_t brd_stride = !o.boards ? 0 : (tm ? (int64_t)64 * NC : a.n * (int64_t)NC);  // bytes per slice
+    const int64_t rec_wrap = rec_stride * (o.ring - 1), brd_wrap = brd_stride * (o.ring - 1);
+    uint32_t left = 0;  // steps left in the action word in hand
 #pragma nounroll
     for (int32_t k = 0; k < n_steps; ++k) {
-      const uint64_t t = a.t + (uint64_t)k;
-      const uint32_t tl = (uint32_t)t;
-      if ((t >> 4) != have_word) {
-        if ((t >> 6) != have_block) {
-          philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)a.seed,
-                        (uint32_t)(a.seed >> 32), x);
-          have_block = t >> 6;
-        }
+      if (left == 0) {  // a new 16-step word; a new Philox block every 64 steps (and on the launch's first step)
+        const uint64_t t = a.t + (uint64_t)k;
+        const uint32_t tl = (uint32_t)t;
+        if (k == 0 || (tl & 63u) == 0)
+          philox4x32_10((uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(t >> 6), 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
         const uint32_t j = (tl >> 4) & 3u;
         w = (j == 0 ? x[0] : (j == 1 ? x[1] : (j == 2 ? x[2] : x[3]))) >> (2 * (tl & 15u));
-        have_word = t >> 4;
+        left = 16 - (tl & 15u);
       }
+      --left;
       int action = (int)(w & 3u);
       w >>= 2;
-      if (valid && !s.over) action = env_actual_action<ENV>(R, s, a.seed, ge, action);
+      const bool live = valid && !s.over;
+      if (live) action = env_actual_action<ENV>(R, s, a.seed, ge, action);
       last_action = action;
-      if (valid && !s.over) {
+      last_obs = 0;
+      last_hid = 0;
+      last_done = valid ? 1 : 0;
+      if (live) {
         int r_obs, r_hid, term;
         if (HasAux<ENV>::value) transition_with<ENV>(R, s, action, r_obs, r_hid, term, ax);  // side state in registers
         else transition<ENV>(R, s, action, r_obs, r_hid, term);
@@ -334,48 +353,43 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
             s.over = 1;
           }
         }
-      } else {
-        last_obs = 0;
-        last_hid = 0;
-        last_done = valid ? 1 : 0;
       }
-      if (STREAM) {
-        // this step's outputs, as env.step returns them: the record (reward, hidden reward, done, executed action) ...
-        const uint32_t rk = pack_rec(last_obs, last_hid, last_done, last_action);
-        // (tile-major rings: this tile's K steps are adjacent; the record of env e sits at row e % 64 = its lane)
-        uint32_t *recs = !o.recs ? a.rec + env
-                                 : (o.tile_major ? o.recs + (wt * (int64_t)o.ring + slice) * 64 + lane : o.recs + (int64_t)slice * a.n + env);
+      // this step's outputs, as env.step returns them: the record (reward, hidden reward, done, executed action) ...
+      const uint32_t rk = pack_rec(last_obs, last_hid, last_done, last_action);
 #if SGK_STREAM_REC_SC1
-        if (valid) __hip_atomic_store(recs, rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
+      if (valid) __hip_atomic_store(recs_p, rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
 #else
-        if (valid) *recs = rk;
+      if (valid) *recs_p = rk;
 #endif
-        // ... and the successor board: one tile store per wave wherever the destination takes whole tiles
-        if (boards_on) {
-          const bool tm = o.boards && o.tile_major;
-          // wave-uniform; rows of NC bytes. Tile-major: `dense + wt * 64 * NC` below is this tile's slot of this slice
-          int8_t *dense = !o.boards ? a.boards
-                                    : (tm ? o.boards + ((wt * (int64_t)o.ring + slice) - wt) * 64 * NC : o.boards + (int64_t)slice * a.n * NC);
-          const bool tiles = o.boards ? (tm || (o.tiles_ok && whole_tile)) : COMPACT;  // the env's own buffer is padded; so are tile-major rings
+      // ... and the successor board: one tile store per wave wherever the destination takes whole tiles
+      if (boards_on) {
 #if SGK_TILE_IN_LDS
-          const uint32_t now = sprite_info<ENV>(R, s);
-          W.update(R, drawn, now);
-          drawn = now;
-          if (tiles) {
-            if (o.boards && o.ring_nt) W.template flush<SGK_RING_STORE_AUX>(dense + wt * 64 * NC);
-            else W.flush(dense + wt * 64 * NC);
-            // the last step's board also into the env's own buffer: it shows the final state without a re-render launch
-            if (o.boards && k == n_steps - 1 && COMPACT) W.flush(a.boards + wt * 64 * NC);
-          }
-#else
-          if (tiles) W.write(sprite_info<ENV>(R, s), dense + wt * 64 * NC);
-#endif
-          else if (o.boards) { if (valid) write_row_bytes<ENV, NC>(R, dense + env * NC, s); }
-          else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+        const uint32_t now = sprite_info<ENV>(R, s);
+        W.update(R, drawn, now);
+        drawn = now;
+        if (tiles) {
+          if (flush_nt) W.template flush<SGK_RING_STORE_AUX>(dense + wt * 64 * NC);
+          else W.flush(dense + wt * 64 * NC);
         }
-        if (++slice == o.ring) slice = 0;
+#else
+        if (tiles) W.write(sprite_info<ENV>(R, s), dense + wt * 64 * NC);
+#endif
+        else if (o.boards) { if (valid) write_row_bytes<ENV, NC>(R, dense + env * NC, s); }
+        else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+      }
+      if (++slice == o.ring) {
+        slice = 0;
+        recs_p -= rec_wrap;
+        dense -= brd_wrap;
+      } else {
+        recs_p += rec_stride;
+        dense += brd_stride;
       }
     }
+#if SGK_TILE_IN_LDS
+    // the last step's board also into the env's own buffer: it shows the final state without a re-render launch
+    if (boards_on && o.boards && tiles && COMPACT && n_steps > 0) W.flush(a.boards + wt * 64 * NC);
+#endif
     } else {
       // Outputs once: nothing is stored per step, so the loop is bound by instruction ISSUE -- and it was the SCALAR port that
       // was full (profiles/r03/pmc_sq_rollout_boatrace_fused.json: 15.7 SALU + 5.3 branch instructions per wave-step against
@@ -484,7 +498,7 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
   __shared__ CompactLds<NC> C;
   stage_rules(R, rules);
   SGK_TILE_DECLARE(ENV, NC, COMPACT);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int64_t n_wt = (n + 63) / 64;
   for (int64_t wt = (int64_t)blockIdx.x * (WG / 64) + wave; wt < n_wt; wt += (int64_t)gridDim.x * (WG / 64)) {
     const int64_t env = wt * 64 + lane;

@@ -169,6 +169,33 @@ def test_streamed_rollout_keeps_every_step_in_the_trajectory_rings(name, n, ring
     env.close()
 
 
+@pytest.mark.parametrize("name", ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0", "TomatoWatering-v0"])
+@pytest.mark.parametrize("layout", ["slice", "tile"])
+def test_tile_stores_end_at_the_tile(name, layout):
+    """The tile writer's stores are not predicated: a lane past the image's last 16-byte chunk relies on the buffer descriptor's
+    range check to drop its store. Rings that are the head of a larger, sentinel-filled allocation: the bytes right behind the
+    last tile of the last slice -- where such a store would land -- stay the caller's, and so do the env's neighbours."""
+    torch = _torch()
+    n, ring, T, seed = 128, 3, 6, 21
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    orc = O.EnvBatch(name, n, seed=seed)
+    shape_b = (n // 64, ring, 64, env.n_cells) if layout == "tile" else (ring, n, env.n_cells)
+    shape_r = (n // 64, ring, 64, 4) if layout == "tile" else (ring, n, 4)
+    big_b = torch.full((shape_b[0] + 1,) + shape_b[1:], -7, dtype=torch.int8, device="cuda")
+    big_r = torch.full((shape_r[0] + 1,) + shape_r[1:], -7, dtype=torch.int8, device="cuda")
+    boards, recs = big_b[:shape_b[0]], big_r[:shape_r[0]]
+    env.rollout_random_stream(T, boards=boards, recs=recs, layout=layout)  # the last step lands in the last slice
+    assert bool((big_b[-1] == -7).all()) and bool((big_r[-1] == -7).all())
+    for k in range(T):
+        rec = orc.rollout(1, seed=seed, t_begin=k, auto_reset=True)
+        if k >= T - ring:
+            got_b = (env.ring_slices(boards) if layout == "tile" else boards)[k % ring].cpu().numpy()
+            got_r = (env.ring_slices(recs) if layout == "tile" else recs)[k % ring].cpu().numpy()
+            assert (got_b == orc.boards()).all() and (got_r == rec).all(), (name, layout, k)
+    assert_same_state(env, orc, "after the rollout into the head of a larger allocation")
+    env.close()
+
+
 @pytest.mark.parametrize("name,n,ring", [("BoatRace-v0", 1600, 7), ("BoatRace-v0", 1616, 4), ("IslandNavigation-v0", 37, 3),
                                          ("TomatoWatering-v0", 1000, 5), ("FriendFoe-v0", 130, 2), ("SideEffectsSokoban-v0", 64, 1)])
 def test_tile_major_trajectory_rings_hold_the_same_steps(name, n, ring):

@@ -163,6 +163,7 @@ int main(int argc, char **argv) {
   int n_tiles = 16384, steps = 100, piece = 1600, rpiece = 256;  // BoatRace at 1 M envs
   const char *only = argc > 1 ? argv[1] : "";
   if (argc > 2) piece = atoi(argv[2]);  // 3072 = IslandNavigation
+  if (argc > 3) n_tiles = atoi(argv[3]);  // 2048 = the per-GPU share of the 1 M batch at 8 GPUs
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   n_cus = prop.multiProcessorCount;
