@@ -343,6 +343,72 @@ def golden_deepq_forward():
     print("wrote deepq_forward.npz; state_dict keys:", list(agent.Q.state_dict().keys()))
 
 
+def golden_deepq_learn():
+    """DeepQAgent.learn (value.py:113-136) step by step: replay add + sample (np.random.choice, contain.py:21), the
+    [B,1]-vs-[B] mse_loss broadcast (value.py:119-123), the undetached target network, clip_grad_norm_ 10, Adam(amsgrad),
+    sync_target_Q in the middle. As written the method stops at `next_Qs[terminals] = 0` under torch >= 2 ("masked_fill_ only
+    supports boolean masks"): terminals are lifted as uint8 (value.py:179), which the torch of the reference's day read as
+    the boolean mask. The ONE shim here: a subclass whose _lift turns a requested uint8 into bool; every other line that
+    runs is the reference's own. Recorded: the transitions fed in, both networks' initial weights, every step's loss and the
+    weights after the last step."""
+    import warnings
+
+    from safe_grid_agents.common.agents.value import DeepQAgent
+
+    class MaskAsBool(DeepQAgent):
+        def _lift(self, x, dtype=torch.float32, grad=False):
+            return super()._lift(x, dtype=torch.bool if dtype == torch.uint8 else dtype, grad=grad)
+
+    H, W, B, STEPS, SYNC_AT = 6, 6, 8, 14, 7
+    env = types.SimpleNamespace(action_space=types.SimpleNamespace(n=4),
+                                observation_space=types.SimpleNamespace(shape=(H, W)))
+    args = types.SimpleNamespace(device="cpu", log_gradients=False, epsilon=0.01, epsilon_anneal=1000,
+                                 discount=0.99, lr=1e-3, batch_size=B, n_layers=2, n_hidden=32, replay_capacity=10)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        torch.manual_seed(23)
+        agent = MaskAsBool(env, args)
+        init_q = {k: v.clone() for k, v in agent.Q.state_dict().items()}
+        init_t = {k: v.clone() for k, v in agent.target_Q.state_dict().items()}
+        rng = np.random.RandomState(17)
+        writer = RecordingWriter()
+        hist = {"writer": writer, "t": 0}
+        fed = {"states": [], "actions": [], "rewards": [], "successors": [], "terminals": []}
+        np.random.seed(31)  # ReplayBuffer.sample draws from the global numpy stream
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # the broadcast warning of mse_loss
+            for k in range(STEPS):
+                s0 = rng.randint(0, 6, size=(H, W)).astype(np.float32)
+                s1 = rng.randint(0, 6, size=(H, W)).astype(np.float32)
+                a, r, term = int(rng.randint(4)), float(rng.choice([-1.0, 2.0, 49.0, -51.0])), bool(rng.rand() < 0.3)
+                for key, v in zip(("states", "actions", "rewards", "successors", "terminals"), (s0, a, r, s1, term)):
+                    fed[key].append(v)
+                hist["t"] = k
+                agent.learn(s0, a, r, s1, term, hist)
+                if k + 1 == SYNC_AT:
+                    agent.sync_target_Q()
+    finally:
+        torch.set_num_threads(threads)
+
+    def hexes(sd):  # float32 arrays: an .npz keeps the bits
+        return {k.replace(".", "_"): v.detach().numpy().copy() for k, v in sd.items()}
+
+    np.savez_compressed(
+        os.path.join(HERE, "deepq_learn.npz"),
+        states=np.stack(fed["states"]), successors=np.stack(fed["successors"]), actions=np.array(fed["actions"]),
+        rewards=np.array(fed["rewards"]), terminals=np.array(fed["terminals"]),
+        losses=np.array([float.fromhex(c[2]) for c in writer.calls if c[1] == "Train/value_loss"], dtype=np.float64),
+        meta=np.array(json.dumps({"H": H, "W": W, "batch_size": B, "steps": STEPS, "sync_after_step": SYNC_AT, "n_hidden": 32,
+                                  "n_layers": 2, "replay_capacity": 10, "lr": 1e-3, "discount": 0.99, "torch_seed": 23,
+                                  "numpy_seed": 31, "torch": torch.__version__,
+                                  "shim": "terminals lifted as bool instead of uint8 (value.py:179)"})),
+        **{"init_Q_" + k: v for k, v in hexes(init_q).items()}, **{"init_T_" + k: v for k, v in hexes(init_t).items()},
+        **{"final_Q_" + k: v for k, v in hexes(agent.Q.state_dict()).items()},
+        **{"final_T_" + k: v for k, v in hexes(agent.target_Q.state_dict()).items()})
+    print("wrote deepq_learn.npz; losses:", [float.fromhex(c[2]) for c in writer.calls][:4], "...")
+
+
 def golden_discounted_returns():
     """PPOBaseAgent.get_discounted_returns (policy_base.py:179-186): float32, gamma**t in Python floats, suffix sums
     accumulated left to right by Python's sum()."""
@@ -369,6 +435,7 @@ def main():
     golden_rng()
     golden_warmup()
     golden_deepq_forward()
+    golden_deepq_learn()
     golden_train("train_boat_tabq_seed7.json",
                  ["-S", "7", "-E", "30", "-EE", "10", "-V", "250", "-EV", "0", "boat", "tabular-q", "-l", ".5"])
     golden_train("train_island_tabq_seed1.json",

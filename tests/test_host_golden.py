@@ -236,6 +236,63 @@ def test_deepq_forward_matches_reference_weights(golden_dir):
     assert agent3.n_input == 36 and agent3.act(z["boards"][0][None]).shape == (1,)
 
 
+def test_deepq_learn_matches_the_reference_step_by_step(golden_dir):
+    """DeepQAgent.learn against the reference's own learn() (value.py:113-136; tests/golden/make_golden.py:golden_deepq_learn
+    -- run with its uint8 terminal mask lifted as bool, the one line torch >= 2 rejects): the same transitions, the same
+    numpy stream for the replay samples, a target sync in the middle -> every step's loss and the final weights of both
+    networks. The quirks this pins: the [B,1]-vs-[B] loss broadcast, gradients flowing through the undetached target
+    network, zeroed terminal targets, clip_grad_norm_ 10, Adam(amsgrad)."""
+    import json
+    import warnings
+
+    import torch
+
+    z = np.load(os.path.join(golden_dir, "deepq_learn.npz"))
+    meta = json.loads(str(z["meta"]))
+    env = _fake_env(shape=(meta["H"], meta["W"]))
+    args = types.SimpleNamespace(device="cpu", log_gradients=False, epsilon=0.01, epsilon_anneal=1000, discount=meta["discount"],
+                                 lr=meta["lr"], batch_size=meta["batch_size"], n_layers=meta["n_layers"],
+                                 n_hidden=meta["n_hidden"], replay_capacity=meta["replay_capacity"])
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        agent = S.DeepQAgent(env, args)
+        for net, tag in ((agent.Q, "init_Q_"), (agent.target_Q, "init_T_")):
+            net.load_state_dict({k: torch.as_tensor(z[tag + k.replace(".", "_")]) for k in net.state_dict().keys()})
+        writer = S.RecordingWriter()
+        hist = {"writer": writer, "t": 0}
+        np.random.seed(meta["numpy_seed"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for k in range(meta["steps"]):
+                hist["t"] = k
+                agent.learn(z["states"][k], int(z["actions"][k]), float(z["rewards"][k]), z["successors"][k],
+                            bool(z["terminals"][k]), hist)
+                if k + 1 == meta["sync_after_step"]:
+                    agent.sync_target_Q()
+    finally:
+        torch.set_num_threads(threads)
+    losses = np.array([float.fromhex(c[2]) if isinstance(c[2], str) else float(c[2]) for c in writer.calls
+                       if c[1] == "Train/value_loss"])
+    assert len(losses) == meta["steps"]
+    # same torch, same ops, one thread: in practice bit-equal; the tolerance is for another torch build's GEMM order
+    np.testing.assert_allclose(losses, z["losses"], rtol=1e-5)
+    for net, tag in ((agent.Q, "final_Q_"), (agent.target_Q, "final_T_")):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), z[tag + k.replace(".", "_")], rtol=1e-4, atol=1e-6, err_msg=tag + k)
+    # the broadcast really is part of it: the squeezed loss gives other numbers from the second step on
+    agent2 = S.DeepQAgent(env, args, reference_loss_broadcast=False)
+    agent2.Q.load_state_dict({k: torch.as_tensor(z["init_Q_" + k.replace(".", "_")]) for k in agent2.Q.state_dict().keys()})
+    agent2.target_Q.load_state_dict({k: torch.as_tensor(z["init_T_" + k.replace(".", "_")]) for k in agent2.Q.state_dict().keys()})
+    w2 = S.RecordingWriter()
+    np.random.seed(meta["numpy_seed"])
+    for k in range(4):
+        agent2.learn(z["states"][k], int(z["actions"][k]), float(z["rewards"][k]), z["successors"][k], bool(z["terminals"][k]),
+                     {"writer": w2, "t": k})
+    l2 = [float.fromhex(c[2]) if isinstance(c[2], str) else float(c[2]) for c in w2.calls if c[1] == "Train/value_loss"]
+    assert not np.allclose(l2[1:], z["losses"][1:4], rtol=1e-3)
+
+
 def test_deepq_learn_step_runs_and_changes_weights():
     import torch
 
