@@ -41,6 +41,7 @@ struct P {
   int s0;  // first slice of this launch (chunked launches: a launch covers `steps` consecutive slices from here)
   int rec_dword;  // 1: the record ring is written as one plain dword per lane (256 B per wave-instruction), like the product's step records
   int xcd;  // 1: workgroup b (dealt to XCD b % 8) owns tiles of the b % 8-th CONTIGUOUS eighth of the batch
+  int wait;  // >= 0: after every step the wave waits until at most this many of its stores are outstanding (s_waitcnt vmcnt)
 };
 
 template <int AUX>
@@ -81,6 +82,16 @@ __global__ __launch_bounds__(256) void wr(P p) {
       }
     }
     v += 7;
+    // bound how far a wave's ISSUED stores run ahead of the memory system (3 store instructions per step here)
+    switch (p.wait) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+      default: break;
+    }
   }
 }
 
@@ -97,12 +108,58 @@ __global__ __launch_bounds__(256) void fill16_plain(u32x4 *dst, size_t n16) {
 struct Cfg {
   int M, B, layout, aux, wgs_per_cu, delay, ring, boards_on, recs_on, merged;
   int xcd = 0, rec_dword = 0;
+  int wait = -1;  // >= 0: s_waitcnt vmcnt(wait) after every step
+  int oneshot = 0;  // 1: a workgroup per (step, four tiles), step-major; 2: + flag chain; 3: + 24-byte hand-off per lane
   int chunk = 0;  // > 0: the `steps` steps are issued as steps / chunk launches of `chunk` steps each (bounds the waves' drift)
 };
 
 static char *g_boards, *g_recs;
 static size_t g_cap_b, g_cap_r;
 static int n_cus;
+
+// ONE-SHOT shape: a workgroup per (step, four tiles), dispatched step-major -- the order a launch per step would write in, inside
+// one launch. chain = 1: workgroup (s, j) first waits for a flag that workgroup (s - 1, j) sets when it is done (what a K-step
+// env kernel of this shape would need: the state is handed from step to step through memory); chain = 2 additionally reads and
+// rewrites 24 bytes per lane as that hand-off.
+template <int AUX>
+__global__ __launch_bounds__(256) void wr_oneshot(P p, int groups, int chain, uint32_t *flags, uint32_t epoch, u32x4 *handoff) {
+  const int s_idx = blockIdx.x / groups, j = blockIdx.x % groups;
+  const int w = j * 4 + (threadIdx.x >> 6);
+  uint32_t v = (uint32_t)w + 7u * s_idx;
+  if (chain) {
+    if (s_idx > 0) {
+      if (threadIdx.x == 0)
+        for (int spin = 0; spin < 2000000 && __hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch + (uint32_t)s_idx; ++spin)
+          __builtin_amdgcn_s_sleep(1);  // (bounded: a probe must not be able to hang the box)
+      __syncthreads();
+    }
+    if (chain == 2 && w < p.n_waves) {
+      const u32x4 h = handoff[(size_t)w * 64 + (threadIdx.x & 63)];
+      v += h.x & 1u;
+    }
+  }
+  for (int i = 0; i < p.delay; ++i) __builtin_amdgcn_s_sleep(1);
+  if (w < p.n_waves) {
+    const int s = (p.s0 + s_idx) % p.ring;
+    put<AUX>(p.boards + ((size_t)s * p.n_waves + w) * p.piece, p.piece, v);
+    if (p.rpiece) put<AUX>(p.recs + ((size_t)s * p.n_waves + w) * p.rpiece, p.rpiece, v);
+    if (chain == 2) {
+      u32x4 h = {v, v, v, v};
+      handoff[(size_t)w * 64 + (threadIdx.x & 63)] = h;
+    }
+  }
+  if (chain) {
+    __syncthreads();  // (the hand-off stores of all four waves are issued; same-XCD successor: groups % 8 == 0)
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_store(&flags[j], epoch + (uint32_t)s_idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+static uint32_t *g_flags;
+static u32x4 *g_handoff;
+static uint32_t g_epoch = 0;
 
 static double run(const Cfg &c, int n_tiles, int steps, int piece1, int rpiece1) {
   P p;
@@ -124,10 +181,27 @@ static double run(const Cfg &c, int n_tiles, int steps, int piece1, int rpiece1)
   p.delay = c.delay;
   p.xcd = c.xcd;
   p.rec_dword = c.rec_dword;
+  p.wait = c.wait;
   if ((size_t)p.n_waves * p.ring * p.piece > g_cap_b || (size_t)p.n_waves * p.ring * (size_t)p.rpiece > g_cap_r) return -1;
   const int lds = c.wgs_per_cu >= 8 ? 0 : (160 * 1024 / c.wgs_per_cu) - 512;
   const int grid = (p.n_waves + 3) / 4;
   auto launch = [&]() {
+   if (c.oneshot) {
+     const int groups = (p.n_waves + 3) / 4;
+     if (!g_flags) {
+       CK(hipMalloc(&g_flags, sizeof(uint32_t) * 65536));
+       CK(hipMemset(g_flags, 0, sizeof(uint32_t) * 65536));
+       CK(hipMalloc(&g_handoff, sizeof(u32x4) * 64 * 65536 * 4));
+       CK(hipMemset(g_handoff, 0, sizeof(u32x4) * 64 * 65536 * 4));
+     }
+     p.s0 = 0;
+     const int chain = c.oneshot - 1;
+     if (c.aux == 18) hipLaunchKernelGGL(wr_oneshot<18>, dim3(groups * steps), dim3(256), lds, 0, p, groups, chain, g_flags, g_epoch, g_handoff);
+     else if (c.aux == 0) hipLaunchKernelGGL(wr_oneshot<0>, dim3(groups * steps), dim3(256), lds, 0, p, groups, chain, g_flags, g_epoch, g_handoff);
+     else hipLaunchKernelGGL(wr_oneshot<16>, dim3(groups * steps), dim3(256), lds, 0, p, groups, chain, g_flags, g_epoch, g_handoff);
+     g_epoch += (uint32_t)steps;
+     return;
+   }
    for (int l = 0; l < n_launch; ++l) {
     p.s0 = l * p.steps;
     switch (c.aux) {
@@ -301,6 +375,27 @@ int main(int argc, char **argv) {
     T.push_back({"tile-major chunked launches", c});
   }
   for (int r : {36, 40, 48, 56, 64, 72, 80, 90}) T.push_back({"slice ring size fine", {1, 1, 0, 16, 8, 0, r, 1, 1, 0}});
+  for (int os : {1, 2, 3})
+    for (int ring : {100, 32})
+      for (int aux : {16, 0, 18})
+        for (int dly : {0, 4, 16}) {
+          if ((aux != 16 || ring != 100) && dly) continue;
+          Cfg c{1, 1, 0, aux, 8, dly, ring, 1, 1, 0};
+          c.oneshot = os;
+          T.push_back({os == 1 ? "ONE-SHOT per (step, 4 tiles)" : (os == 2 ? "ONE-SHOT + flag chain" : "ONE-SHOT + chain + hand-off"), c});
+        }
+  for (int ring : {100, 32})
+    for (int wg : {8, 5})
+      for (int wt : {0, 3, 6, 9, 12, 24}) {
+        Cfg c{1, 1, 0, 16, wg, 0, ring, 1, 1, 0};
+        c.wait = wt;
+        T.push_back({"slice sc1, stores in flight capped", c});
+      }
+  for (int wt : {3, 6, 12}) {
+    Cfg c{1, 1, 1, 16, 8, 0, 100, 1, 1, 0};
+    c.wait = wt;
+    T.push_back({"tile-major sc1, stores in flight capped", c});
+  }
   printf("%-30s %2s %3s %3s %3s %3s %4s %4s | %9s %8s %7s\n", "variant", "M", "B", "lay", "aux", "wg", "dly", "ring", "us/100st.", "us/step",
          "TB/s");
   const char *ring_only = getenv("WP_RING"), *index_only = getenv("WP_INDEX");
@@ -314,6 +409,7 @@ int main(int argc, char **argv) {
     if (getenv("WP_LIST")) {
       printf("[%3d] %s M=%d B=%d lay=%d aux=%d wg=%d dly=%d ring=%d xcd=%d chunk=%d recdw=%d\n", index, t.first, c.M, c.B, c.layout, c.aux,
              c.wgs_per_cu, c.delay, c.ring, c.xcd, c.chunk, c.rec_dword);
+      if (c.wait >= 0) printf("      (vmcnt cap %d)\n", c.wait);
       continue;
     }
     printf("[%3d] ", index);
@@ -322,6 +418,7 @@ int main(int argc, char **argv) {
       const double bytes = (double)n_tiles * steps * ((c.boards_on ? piece : 0) + (c.recs_on ? rpiece : 0));
       printf("%s%-30s %2d %3d %3d %3d %3d %4d %4d | %9.1f %8.3f %7.2f\n", rep ? "      " : "", t.first, c.M, c.B, c.layout, c.aux, c.wgs_per_cu, c.delay, c.ring,
              us, us / steps, bytes / (us * 1e-6) / 1e12);
+      if (c.wait >= 0 && !rep) printf("      (at most %d store instructions of a wave outstanding after each step)\n", c.wait);
     }
     fflush(stdout);
   }
