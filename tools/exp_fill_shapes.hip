@@ -39,6 +39,18 @@ __global__ __launch_bounds__(256) void fill_stride_capped(u32x4 *dst, size_t n16
   }
 }
 
+// persistent, but the waves of a workgroup issue each iteration's stores TOGETHER (a barrier per iteration): T * 16 contiguous bytes at a time
+template <int T>
+__global__ __launch_bounds__(T) void fill_stride_sync(u32x4 *dst, size_t n16) {
+  u32x4 x = {1, 2, 3, 4};
+  const size_t iters = (n16 + (size_t)gridDim.x * T - 1) / ((size_t)gridDim.x * T);
+  for (size_t it = 0; it < iters; ++it) {
+    const size_t i = (it * gridDim.x + blockIdx.x) * T + threadIdx.x;
+    __syncthreads();
+    if (i < n16) dst[i] = x;
+  }
+}
+
 // one workgroup per PER * 4 KB: PER stores per lane, the workgroup's region contiguous
 template <int PER>
 __global__ __launch_bounds__(256) void fill_oneshot(u32x4 *dst, size_t n16) {
@@ -93,7 +105,7 @@ int main() {
   printf("%-44s %8s | %10s %8s\n", "shape", "MB", "us/launch", "TB/s");
   for (size_t mb : {256, 1000, 3000}) {
     const size_t n16 = mb * 1000 * 1000 / 16;
-    for (int shape = 0; shape < 20; ++shape) {
+    for (int shape = 0; shape < 26; ++shape) {
       if (shape == 9 || shape == 10) continue;  // 16 KB tickets: 1.2-1.35 TB/s (same-address atomics serialise), measured once
       float best = 1e9;
       const char *name = "";
@@ -113,6 +125,12 @@ int main() {
             case 9: name = "16 KB tickets, 8 workgroups per CU"; CK(hipMemsetAsync(ticket, 0, 8, 0)); hipLaunchKernelGGL(fill_ticket, dim3(cus * 8), dim3(256), 0, 0, (u32x4 *)buf, n16, ticket); break;
             case 10: name = "16 KB tickets, 4 workgroups per CU"; CK(hipMemsetAsync(ticket, 0, 8, 0)); hipLaunchKernelGGL(fill_ticket, dim3(cus * 4), dim3(256), 0, 0, (u32x4 *)buf, n16, ticket); break;
             case 11: name = "hipMemsetAsync"; CK(hipMemsetAsync(buf, 3, n16 * 16, 0)); break;
+            case 20: name = "grid-stride + barrier per iteration, 8/CU"; hipLaunchKernelGGL(fill_stride_sync<256>, dim3(cus * 8), dim3(256), 0, 0, (u32x4 *)buf, n16); break;
+            case 21: name = "grid-stride + barrier per iteration, 2/CU"; hipLaunchKernelGGL(fill_stride_sync<256>, dim3(cus * 2), dim3(256), 0, 0, (u32x4 *)buf, n16); break;
+            case 22: name = "grid-stride + barrier, 1024-lane groups, 2/CU"; hipLaunchKernelGGL(fill_stride_sync<1024>, dim3(cus * 2), dim3(1024), 0, 0, (u32x4 *)buf, n16); break;
+            case 23: name = "grid-stride + barrier, 1024-lane groups, 1/CU"; hipLaunchKernelGGL(fill_stride_sync<1024>, dim3(cus), dim3(1024), 0, 0, (u32x4 *)buf, n16); break;
+            case 24: name = "grid-stride + barrier, 64-lane groups, 8/CU"; hipLaunchKernelGGL(fill_stride_sync<64>, dim3(cus * 8), dim3(64), 0, 0, (u32x4 *)buf, n16); break;
+            case 25: name = "grid-stride + barrier, 64-lane groups, 32/CU"; hipLaunchKernelGGL(fill_stride_sync<64>, dim3(cus * 32), dim3(64), 0, 0, (u32x4 *)buf, n16); break;
             case 12: name = "grid-stride 8/CU, <= 0 stores outstanding"; hipLaunchKernelGGL(fill_stride_capped<0>, dim3(cus * 8), dim3(256), 0, 0, (u32x4 *)buf, n16); break;
             case 13: name = "grid-stride 8/CU, <= 1 outstanding"; hipLaunchKernelGGL(fill_stride_capped<1>, dim3(cus * 8), dim3(256), 0, 0, (u32x4 *)buf, n16); break;
             case 14: name = "grid-stride 8/CU, <= 2 outstanding"; hipLaunchKernelGGL(fill_stride_capped<2>, dim3(cus * 8), dim3(256), 0, 0, (u32x4 *)buf, n16); break;

@@ -41,6 +41,7 @@ struct P {
   int s0;  // first slice of this launch (chunked launches: a launch covers `steps` consecutive slices from here)
   int rec_dword;  // 1: the record ring is written as one plain dword per lane (256 B per wave-instruction), like the product's step records
   int xcd;  // 1: workgroup b (dealt to XCD b % 8) owns tiles of the b % 8-th CONTIGUOUS eighth of the batch
+  int sync;  // 1: the four waves of a workgroup meet at a barrier before every step's stores (6.4 KB contiguous issued together)
   int wait;  // >= 0: after every step the wave waits until at most this many of its stores are outstanding (s_waitcnt vmcnt)
 };
 
@@ -52,19 +53,20 @@ __device__ __forceinline__ void put(char *dst, int len, uint32_t v) {  // dst wa
   for (int j = lane; j < len / 16; j += 64) __builtin_amdgcn_raw_buffer_store_b128(x, rsrc, j * 16, 0, AUX);
 }
 
-template <int AUX>
-__global__ __launch_bounds__(256) void wr(P p) {
+template <int AUX, int WGT = 256>
+__global__ __launch_bounds__(WGT) void wr(P p) {
   extern __shared__ char lds_pad[];
-  int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int w = blockIdx.x * (WGT / 64) + (threadIdx.x >> 6);
   if (p.xcd) {  // n_waves % 32 == 0 here
     const int per = p.n_waves / 8;
     w = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
   }
-  if (w >= p.n_waves) return;
+  if (w >= p.n_waves && !p.sync) return;  // (sync: n_waves % 4 == 0, nobody leaves)
   if (p.delay < 0) lds_pad[threadIdx.x] = 1;  // keeps the dynamic LDS allocation alive
   uint32_t v = (uint32_t)w;
   for (int k0 = 0; k0 < p.steps; k0 += p.burst) {
     for (int i = 0; i < p.delay * p.burst; ++i) __builtin_amdgcn_s_sleep(1);
+    if (p.sync) __syncthreads();
     const int nb = min(p.burst, p.steps - k0);
     if (p.layout == 1) {
       // the wave's steps are adjacent: one run of nb * piece bytes (rings wrap at whole bursts: ring % burst == 0)
@@ -109,6 +111,8 @@ struct Cfg {
   int M, B, layout, aux, wgs_per_cu, delay, ring, boards_on, recs_on, merged;
   int xcd = 0, rec_dword = 0;
   int wait = -1;  // >= 0: s_waitcnt vmcnt(wait) after every step
+  int sync = 0;  // 1: barrier before every step's stores
+  int big = 0;   // 1: 1024-lane workgroups (16 tiles = 25.6 KB contiguous per step), with sync
   int oneshot = 0;  // 1: a workgroup per (step, four tiles), step-major; 2: + flag chain; 3: + 24-byte hand-off per lane
   int chunk = 0;  // > 0: the `steps` steps are issued as steps / chunk launches of `chunk` steps each (bounds the waves' drift)
 };
@@ -182,6 +186,7 @@ static double run(const Cfg &c, int n_tiles, int steps, int piece1, int rpiece1)
   p.xcd = c.xcd;
   p.rec_dword = c.rec_dword;
   p.wait = c.wait;
+  p.sync = c.sync;
   if ((size_t)p.n_waves * p.ring * p.piece > g_cap_b || (size_t)p.n_waves * p.ring * (size_t)p.rpiece > g_cap_r) return -1;
   const int lds = c.wgs_per_cu >= 8 ? 0 : (160 * 1024 / c.wgs_per_cu) - 512;
   const int grid = (p.n_waves + 3) / 4;
@@ -200,6 +205,13 @@ static double run(const Cfg &c, int n_tiles, int steps, int piece1, int rpiece1)
      else if (c.aux == 0) hipLaunchKernelGGL(wr_oneshot<0>, dim3(groups * steps), dim3(256), lds, 0, p, groups, chain, g_flags, g_epoch, g_handoff);
      else hipLaunchKernelGGL(wr_oneshot<16>, dim3(groups * steps), dim3(256), lds, 0, p, groups, chain, g_flags, g_epoch, g_handoff);
      g_epoch += (uint32_t)steps;
+     return;
+   }
+   if (c.big) {
+     p.s0 = 0;
+     const int g16 = (p.n_waves + 15) / 16;
+     if (c.aux == 18) hipLaunchKernelGGL((wr<18, 1024>), dim3(g16), dim3(1024), lds, 0, p);
+     else hipLaunchKernelGGL((wr<16, 1024>), dim3(g16), dim3(1024), lds, 0, p);
      return;
    }
    for (int l = 0; l < n_launch; ++l) {
@@ -375,6 +387,22 @@ int main(int argc, char **argv) {
     T.push_back({"tile-major chunked launches", c});
   }
   for (int r : {36, 40, 48, 56, 64, 72, 80, 90}) T.push_back({"slice ring size fine", {1, 1, 0, 16, 8, 0, r, 1, 1, 0}});
+  for (int ring : {100, 32})
+    for (int wg : {8, 5, 2})
+      for (int aux : {16, 18}) {
+        Cfg c{1, 1, 0, aux, wg, 0, ring, 1, 1, 0};
+        c.sync = 1;
+        T.push_back({"slice, workgroup barrier per step", c});
+      }
+  for (int ring : {100, 32})
+    for (int wg : {1, 2})
+      for (int sync : {1, 0})
+        for (int aux : {16, 18}) {
+          Cfg c{1, 1, 0, aux, wg, 0, ring, 1, 1, 0};
+          c.sync = sync;
+          c.big = 1;
+          T.push_back({sync ? "slice, 1024-lane groups + barrier" : "slice, 1024-lane groups", c});
+        }
   for (int os : {1, 2, 3})
     for (int ring : {100, 32})
       for (int aux : {16, 0, 18})
