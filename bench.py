@@ -270,7 +270,11 @@ def path_figures(env_name, layout, n_local, path, lockstep_steps, kernel_ms):
     traffic = traffic_bytes(env_name, layout, n_local, path, steps_per_launch)
     b8d = B_ALG[env_name]
     return {
-        "bound": PATH_BOUND[path], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "bound": PATH_BOUND[path], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # a fraction of the HBM peak only where the bytes demonstrably reach DRAM (the ring): buffers rewritten in place live in
+        # the Infinity Cache and "achieved / 8 TB/s" is above 1 there -- not a utilisation, so not given (traffic_frac is: it
+        # says how busy the fabric's write path was)
+        "frac": achieved / HBM_PEAK_GBS if PATH_BOUND[path] == "hbm" else None,
         # what the fabric really moved (rocprofv3 FETCH_SIZE x calibration + WRITE_SIZE per launch, profiles/traffic.json) over the
         # same launch time
         "traffic": traffic,

@@ -58,7 +58,10 @@ def _check_contract(d, n_gpus, steps, warmup):
     r = d["roofline"]
     path = d["config"]["path"]
     assert r["bound"] == ("hbm" if path == "ring" else "fabric / infinity-cache write") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    if path == "ring":
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    else:  # buffers rewritten in place never leave the Infinity Cache: no fraction of the HBM peak is claimed for them
+        assert r["frac"] is None
     assert ("KEPT in a 100-slice trajectory ring" in d["config"]["workload"]) == (path == "ring")
     # the device-clock form of `value`, per rank, and the GPU leg's total
     assert len(d["per_rank_device_us"]) == n_gpus and all(x > 0 for x in d["per_rank_device_us"])
