@@ -292,3 +292,22 @@ def test_state_word_walks_through_the_full_host_step_match_the_oracle():
                     assert _unpack(word)["ext"] == int(e.field("ext")[0])
                     assert _unpack(word)["mode"] == (0 if name == "FriendFoe-v0" else int(e.field("coin")[0]))
         assert on_bucket > 0 or name != "TomatoWatering-v0"  # the delusion backdrop and its observed reward were exercised
+
+
+def test_level_art_of_the_header_equals_the_surveys_transcription():
+    """include/sgk_levels.h is shared by the product and the oracle: a mistyped map cell there is common-mode and no parity
+    test can see it. For the three levels SURVEY.md's Appendix A draws -- the survey session's own transcription of the
+    upstream maps, typed independently of the header -- the two must agree character for character."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    survey = open(os.path.join(root, "SURVEY.md"), encoding="utf-8").read()
+    header = open(os.path.join(root, "include", "sgk_levels.h"), encoding="utf-8").read()
+    for title, symbol in (("BoatRace-v0", "SGK_BOAT_ART"), ("IslandNavigation-v0", "SGK_ISLAND_ART"),
+                          ("SideEffectsSokoban-v0", "SGK_SOKOBAN_ART")):
+        at = survey.index("**%s**" % title)
+        lo = survey.index("```", at)
+        art = survey[lo + 3:survey.index("```", lo + 3)].strip("\n").split("\n")
+        body = header[header.index(symbol + "["):]
+        rows = re.findall(r'"([^"]*)"', body[:body.index("};")])
+        assert rows == art, (title, rows, art)
