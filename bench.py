@@ -24,6 +24,8 @@ What is timed -- `--path`:
           1's `value` was this with one lockstep step per bench step.
 The default run reports the other two as secondary objects (`rewritten_in_place`, `per_step_launches`) and the outputs-once
 kernel (`fused_rollout`: no per-step output exists), each with its own counter-based traffic figures.
+The ring's rate differs from allocation to allocation of the 3 GB; `other_ring_allocations` times three more
+fresh rings in the same process so that the line shows the spread `value` is drawn from.
 
 Workload = BASELINE.json's metric config: BoatRace, 1 048 576 concurrent envs in the whole job at every GPU count (the batch
 shards by env id, one contiguous block per rank, no data-path collective; the only exchange is one int64 metrics all-reduce
@@ -445,6 +447,25 @@ def main():
                 "achieved_gbs": fig["achieved"], "frac": fig["frac"] if fig["bound"] == "hbm" else None,
                 "traffic": fig["traffic"], "traffic_gbs": fig["traffic_gbs"], "traffic_frac": fig["traffic_frac"],
                 "note": notes[other]}
+    ring_spread = None
+    if args.path == "ring" and not args.no_secondary:
+        # The ring's write rate differs from ALLOCATION to allocation of the 3 GB (5.3-6.6 us per step over the
+        # round's boxes, the same spread in a kernel that only stores): `value` is whatever the ONE ring above got, so the line
+        # also says what a few more fresh rings get in this very process -- nothing is picked. The earlier rings stay allocated
+        # while the next is timed (a freed block would simply be handed out again).
+        held, spread_us = [ring], []
+        for _ in range(3):
+            r3 = make_ring(n_local)
+            held.append(r3)
+            _, s_ms, _ = timed_steps(env, 3 * GRAPH_CHUNK, GRAPH_CHUNK, barrier, sdist.global_metrics, path="ring", ring=r3)
+            _, s_ms = max_over_ranks(0.0, s_ms)
+            total_steps += 4 * GRAPH_CHUNK
+            gpu_leg_ms += s_ms
+            spread_us.append(s_ms * 1e3 / (3 * GRAPH_CHUNK))
+        del held, r3
+        ring_spread = {"device_us_per_lockstep_step": spread_us, "rings": len(spread_us), "lockstep_steps_each": 3 * GRAPH_CHUNK,
+                       "note": "fresh %d-slice rings allocated and timed one after another in this process (device clock, max over "
+                               "ranks); the primary measurement's own figure is roofline.device_us_per_step" % RING_SLICES}
     fused = None
     if not args.no_fused:
         # same workload through the outputs-once rollout kernel (state in registers, boards materialised once per launch)
@@ -543,6 +564,8 @@ def main():
     out.update(secondary)
     if fused:
         out["fused_rollout"] = fused
+    if ring_spread:
+        out["other_ring_allocations"] = ring_spread
     if weak_line:
         out["weak_1m_per_gpu"] = weak_line
     if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line only

@@ -41,6 +41,7 @@ struct P {
   int s0;  // first slice of this launch (chunked launches: a launch covers `steps` consecutive slices from here)
   int rec_dword;  // 1: the record ring is written as one plain dword per lane (256 B per wave-instruction), like the product's step records
   int xcd;  // 1: workgroup b (dealt to XCD b % 8) owns tiles of the b % 8-th CONTIGUOUS eighth of the batch
+  long long pad_b, pad_r;  // bytes added to the slice stride of the board / record ring (slice-major layout): WP_SLICE_PAD
   int sync;  // 1: the four waves of a workgroup meet at a barrier before every step's stores (6.4 KB contiguous issued together)
   int wait;  // >= 0: after every step the wave waits until at most this many of its stores are outstanding (s_waitcnt vmcnt)
 };
@@ -76,11 +77,12 @@ __global__ __launch_bounds__(WGT) void wr(P p) {
     } else {
       for (int b = 0; b < nb; ++b) {
         const int s = (p.s0 + k0 + b) % p.ring;
-        put<AUX>(p.boards + ((size_t)s * p.n_waves + w) * p.piece, p.piece, v);
+        put<AUX>(p.boards + (size_t)s * ((size_t)p.n_waves * p.piece + p.pad_b) + (size_t)w * p.piece, p.piece, v);
+        char *rbase = p.recs + (size_t)s * ((size_t)p.n_waves * p.rpiece + p.pad_r) + (size_t)w * p.rpiece;
         if (p.rpiece && p.rec_dword) {
-          uint32_t *r = reinterpret_cast<uint32_t *>(p.recs + ((size_t)s * p.n_waves + w) * p.rpiece);
+          uint32_t *r = reinterpret_cast<uint32_t *>(rbase);
           for (int j = threadIdx.x & 63; j < p.rpiece / 4; j += 64) r[j] = v;
-        } else if (p.rpiece) put<AUX>(p.recs + ((size_t)s * p.n_waves + w) * p.rpiece, p.rpiece, v);
+        } else if (p.rpiece) put<AUX>(rbase, p.rpiece, v);
       }
     }
     v += 7;
@@ -186,8 +188,13 @@ static double run(const Cfg &c, int n_tiles, int steps, int piece1, int rpiece1)
   p.xcd = c.xcd;
   p.rec_dword = c.rec_dword;
   p.wait = c.wait;
+  {  // WP_SLICE_PAD="<board bytes>,<record bytes>": slices of 25 MiB / 4 MiB put every slice's tile w on the same channel and bank
+    const char *sp = getenv("WP_SLICE_PAD");
+    p.pad_b = p.pad_r = 0;
+    if (sp) sscanf(sp, "%lld,%lld", &p.pad_b, &p.pad_r);
+  }
   p.sync = c.sync;
-  if ((size_t)p.n_waves * p.ring * p.piece > g_cap_b || (size_t)p.n_waves * p.ring * (size_t)p.rpiece > g_cap_r) return -1;
+  if (((size_t)p.n_waves * p.piece + p.pad_b) * p.ring > g_cap_b || ((size_t)p.n_waves * (size_t)p.rpiece + p.pad_r) * p.ring > g_cap_r) return -1;
   const int lds = c.wgs_per_cu >= 8 ? 0 : (160 * 1024 / c.wgs_per_cu) - 512;
   const int grid = (p.n_waves + 3) / 4;
   auto launch = [&]() {
@@ -253,8 +260,8 @@ int main(int argc, char **argv) {
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   n_cus = prop.multiProcessorCount;
-  g_cap_b = (size_t)n_tiles * 100 * (piece + rpiece) + (1 << 20);
-  g_cap_r = (size_t)n_tiles * 100 * rpiece + (1 << 20);
+  g_cap_b = (size_t)n_tiles * 100 * (piece + rpiece) + (256 << 20);
+  g_cap_r = (size_t)n_tiles * 100 * rpiece + (256 << 20);
   // WP_ALLOC=vmm: the two rings through HIP's virtual memory management API -- one physical allocation each, mapped at a
   // 1-GiB-aligned virtual address -- instead of hipMalloc: does the driver then cover them with larger page-table fragments?
   const char *alloc = getenv("WP_ALLOC");
