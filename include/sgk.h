@@ -188,6 +188,16 @@ SGK_API int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags);
  * (state, records, boards, episode arrays, metrics) equal n_steps calls of sgk_step_random(1), bit for bit. */
 SGK_API int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flags, int8_t *boards_ring_dev,
                                       sgk_step_rec *recs_ring_dev, int32_t ring_slices, int32_t first_slice);
+/* How fast can THIS trajectory ring be written? Runs the streamed rollout's stores and nothing else over every slice of the ring
+ * (layout and cache policy as sgk_rollout_random_stream would use for it; the contents are zeros afterwards) and returns the
+ * median device time of three passes, in microseconds per slice (= per lockstep step of a streamed rollout that is bound by its
+ * stores). The write rate of a multi-GB ring is a property of the allocation it lives in -- 4.6-4.9 us against 5.6-6.1 at 1 M
+ * BoatRace envs between hipMalloc blocks of one process, for the block's lifetime -- so a caller that keeps a
+ * ring for a whole run can allocate a few candidates, probe each and keep the best. The batched dqn_warmup's storage (reference
+ * warmup.py:14-21, contain.py:11-17) has no counterpart of this in the reference: a deque does not care where it lives.
+ * Either ring may be NULL. Slice-major boards need 16-byte-aligned slices (n_envs * n_cells % 16 == 0). */
+SGK_API int sgk_ring_probe(sgk_env *h, int8_t *boards_ring_dev, sgk_step_rec *recs_ring_dev, int32_t ring_slices, uint32_t flags,
+                           double *us_per_slice);
 /* Book n_steps lockstep steps that were issued OUTSIDE the library's sight: a caller that captured sgk_step() into its
  * own hipGraph (e.g. torch.cuda.CUDAGraph around policy + env.step) replays it without re-entering sgk_step, so the
  * host-side lockstep counter and SGK_M_STEPS must be advanced by hand after each replay (n_steps < 0 un-counts the

@@ -3,6 +3,7 @@
 // needs a GPU and says so when there is none.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -729,6 +730,38 @@ int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flags, int8_
   h->sh.lockstep_t += (uint64_t)n_steps;
   h->t_dev_stale = true;
   h->steps_issued += h->sh.n * (int64_t)n_steps;
+  return SGK_OK;
+}
+
+int sgk_ring_probe(sgk_env *h, int8_t *boards_ring_dev, sgk_step_rec *recs_ring_dev, int32_t ring_slices, uint32_t flags,
+                   double *us_per_slice) {
+  SGK_CHECK_HANDLE(h);
+  if (!us_per_slice) return fail(SGK_ERR_INVALID, "us_per_slice is NULL");
+  if (!boards_ring_dev && !recs_ring_dev) return fail(SGK_ERR_INVALID, "no ring to probe");
+  if (ring_slices < 1) return fail(SGK_ERR_INVALID, "ring_slices < 1");
+  if (flags & ~(uint32_t)SGK_F_RING_TILE_MAJOR) return fail(SGK_ERR_INVALID, "only SGK_F_RING_TILE_MAJOR is meaningful here");
+  sgk::Shard &s = h->sh;
+  if (boards_ring_dev && (((uintptr_t)boards_ring_dev % 16) != 0 || (!(flags & SGK_F_RING_TILE_MAJOR) && (s.n * s.n_cells) % 16 != 0)))
+    return fail(SGK_ERR_INVALID, "the probe writes whole 16-byte-aligned tiles: boards ring and slices must be 16-byte aligned");
+  if (s.n < 64) return fail(SGK_ERR_INVALID, "the probe needs at least one whole 64-env tile");
+  // one launch to touch every page, then three timed ones: the median, per slice
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  SGK_HIP(hipEventCreate(&e0));
+  hipError_t err = hipEventCreate(&e1);
+  float ms[3] = {0, 0, 0};
+  if (err == hipSuccess) err = sgk::launch_ring_probe(s, boards_ring_dev, reinterpret_cast<uint32_t *>(recs_ring_dev), ring_slices, flags, h->stream);
+  for (int r = 0; r < 3 && err == hipSuccess; ++r) {
+    err = hipEventRecord(e0, h->stream);
+    if (err == hipSuccess) err = sgk::launch_ring_probe(s, boards_ring_dev, reinterpret_cast<uint32_t *>(recs_ring_dev), ring_slices, flags, h->stream);
+    if (err == hipSuccess) err = hipEventRecord(e1, h->stream);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms[r], e0, e1);
+  }
+  (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (err != hipSuccess) return hip_fail(err, "sgk_ring_probe");
+  std::sort(ms, ms + 3);
+  *us_per_slice = (double)ms[1] * 1e3 / ring_slices;
   return SGK_OK;
 }
 

@@ -77,6 +77,7 @@ hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flag
 // mode 0: reset all (mask == nullptr) or masked envs; 1: reset envs whose episode is over; 2: re-materialise boards only;
 // | 4: touch no boards (state words only)
 hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st);
+hipError_t launch_ring_probe(const Shard &sh, int8_t *boards_ring, uint32_t *recs_ring, int32_t ring, uint32_t flags, hipStream_t st);
 hipError_t launch_metrics_init(const Shard &sh, hipStream_t st);
 hipError_t launch_aux_init(const Shard &sh, hipStream_t st);
 // out_host: optional second destination in pinned device-mapped host memory (the synchronising reader then needs no copy)

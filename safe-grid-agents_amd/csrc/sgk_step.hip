@@ -340,9 +340,13 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
         if (term || s.frame >= R.max_iterations) {
           last_done = 1;
           acc_add(acc, true, s.ret, s.hid);
-          a.last_return[env] = s.ret;
-          a.last_perf[env] = s.hid;
-          bump_episode_count(a.n_episodes, env);
+          // (the index goes through an opaque copy: otherwise the three element addresses are hoisted out of the step loop and
+          // live in six VGPRs for all of it -- episode ends are rare, the registers decide the occupancy)
+          int64_t env_here = env;
+          asm volatile("" : "+v"(env_here));
+          a.last_return[env_here] = s.ret;
+          a.last_perf[env_here] = s.hid;
+          bump_episode_count(a.n_episodes, env_here);
           if (auto_reset) {
             const int epi = s.epi + 1;  // this reset's index; n_resets[env] is brought up to date once, after the loop
             s = initial_state(R);
@@ -722,6 +726,9 @@ hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flag
               // non-temporal only where the ring dwarfs the caches. Measured at 1 M BoatRace envs, same box, three repeats: a
               // 100-slice ring (3 GB) 6.32 vs 6.52 us per step with / without, a 32-slice ring (1 GB) 5.34 vs 4.90
               (int32_t)((int64_t)(ring < 1 ? 1 : ring) * sh.n * (sh.n_cells + 4) > (3ll << 29))};
+  // (Lowering the residency to whole rounds -- 16 workgroups per CU at 4 resident instead of 3 rounds of 5 and a last one of 1 --
+  // by padding the dynamic LDS was measured on a fast ring: 5.17-5.31 us per step at 2, 3, 4 and 5 per CU alike,
+  // profiles/r03/stream_residency_ab.log. Not kept.)
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
                           rollout_random_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a, n_steps, o));
   hipError_t e = hipGetLastError();
@@ -731,6 +738,50 @@ hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flag
   const bool in_kernel = SGK_TILE_IN_LDS && sh.layout == SGK_LAYOUT_COMPACT && (o.tile_major || (o.tiles_ok && sh.n % 64 == 0));
   if (boards_ring && !(flags & SGK_F_NO_BOARDS) && !in_kernel) return launch_reset(sh, nullptr, 2, st);
   return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------
+// How fast can THIS ring be written? The streamed rollout's stores and nothing else -- a wave per 64-env tile, every slice of
+// the ring once per launch, 16-byte write-through buffer stores for the board tile and a dword per env for the record (zeros:
+// the ring's contents are undefined afterwards). The rate a persistent kernel writes a multi-GB ring at is a property of the
+// ALLOCATION: 4.6-4.9 us per step at 1 M BoatRace envs for some 3 GB hipMalloc blocks and 5.6-6.1 for others on one GPU in one
+// process, stable for the block's lifetime, the same with a 16-fold spread of its slices, blind to every L2-side counter
+// (profiles/r03/ring_alloc_*.log). A caller that keeps a trajectory ring for a whole run can therefore afford to allocate a few
+// candidates, time each with this probe and keep the best (BatchedGridworldEnv.alloc_trajectory_ring).
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(WG) void ring_probe_kernel(int8_t *boards, uint32_t *recs, int64_t n, int32_t ring, int32_t tile_major,
+                                                       int32_t nt) {
+  constexpr int BYTES = 64 * NC, CHUNKS = 4 * NC, ITS = (CHUNKS + 63) / 64;
+  const int lane = threadIdx.x & 63, wave = wave_index();
+  const int64_t n_wt = n / 64;  // whole tiles: a partial last tile goes row by row in the real kernel, a rounding error here
+  const sgk_u32x4 zero = {0u, 0u, 0u, 0u};
+  for (int64_t wt = (int64_t)blockIdx.x * (WG / 64) + wave; wt < n_wt; wt += (int64_t)gridDim.x * (WG / 64)) {
+    for (int32_t s = 0; s < ring; ++s) {
+      if (boards) {
+        int8_t *dst = tile_major ? boards + (wt * (int64_t)ring + s) * BYTES : boards + ((int64_t)s * n + wt * 64) * NC;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, BYTES, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {  // (a lane past the last chunk: dropped by the descriptor's range check)
+          if (nt) __builtin_amdgcn_raw_buffer_store_b128(zero, rsrc, (lane + 64 * it) * 16, 0, SGK_RING_STORE_AUX);
+          else __builtin_amdgcn_raw_buffer_store_b128(zero, rsrc, (lane + 64 * it) * 16, 0, SGK_BOARD_STORE_AUX);
+        }
+      }
+      if (recs) {
+        uint32_t *r = tile_major ? recs + (wt * (int64_t)ring + s) * 64 + lane : recs + (int64_t)s * n + wt * 64 + lane;
+        *r = 0u;
+      }
+    }
+  }
+}
+
+hipError_t launch_ring_probe(const Shard &sh, int8_t *boards_ring, uint32_t *recs_ring, int32_t ring, uint32_t flags, hipStream_t st) {
+  (void)hipGetLastError();
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.stream_grid);
+  const int32_t tm = (flags & SGK_F_RING_TILE_MAJOR) != 0;
+  const int32_t nt = (int64_t)ring * sh.n * (sh.n_cells + 4) > (3ll << 29);  // as launch_rollout_stream decides it
+  SGK_DISPATCH_ENV(sh.env_id, (ring_probe_kernel<Geom<E>::NC><<<dim3(grid), dim3(WG), 0, st>>>(boards_ring, recs_ring, sh.n, ring, tm, nt)));
+  return hipGetLastError();
 }
 
 hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStream_t st) {

@@ -321,6 +321,64 @@ class BatchedGridworldEnv:
         self._sync_lib_to_torch()
         return self._step_outputs()
 
+    def probe_trajectory_ring(self, boards=None, recs=None, layout="slice"):
+        """Microseconds per slice a store-bound streamed rollout needs into THESE rings (sgk_ring_probe: the streamed kernel's
+        stores and nothing else over every slice; the rings hold zeros afterwards)."""
+        assert layout in ("slice", "tile") and (boards is not None or recs is not None)
+        ring = int((boards if boards is not None else recs).shape[1 if layout == "tile" else 0])
+        ptr = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())  # noqa: E731
+        us = ctypes.c_double(0.0)
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_ring_probe(self._h.ptr, ptr(boards), ptr(recs), ring, _lib.F_RING_TILE_MAJOR if layout == "tile" else 0,
+                                           ctypes.byref(us)))
+        return float(us.value)
+
+    def alloc_trajectory_ring(self, slices, candidates=8, layout="slice", with_boards=True, with_recs=True, min_bytes=1 << 30,
+                              spread_gib=16):
+        """Trajectory rings for rollout_random_stream -- boards int8 [slices, N, n_cells], recs int8 [slices, N, 4] (tile-major:
+        [n_tiles, slices, 64, ...]) -- placed where they can be written fast. The rate at which a persistent kernel writes a
+        multi-GB ring is a property of the ALLOCATION the ring lives in (at 1 M BoatRace envs, 3 GB: 4.6-4.9 us per step in some
+        hipMalloc blocks, 5.6-6.1 in others of the same process, for the block's lifetime), so `candidates` pairs
+        are allocated side by side, each is timed with the store-only probe, the fastest is kept and the others are returned to
+        the driver. Rings below `min_bytes` (1 GiB: a few Infinity Caches) do not show the effect: one candidate, no probe needed.
+        `spread_gib`: a spacer allocation of that size between consecutive candidates (fast and slow placements come in runs).
+        Returns (boards, recs, info); info["candidates_us"] lists every candidate's probe time in allocation order."""
+        import torch
+
+        assert layout in ("slice", "tile") and (with_boards or with_recs) and slices >= 1
+        n_tiles = (self.n_envs + 63) // 64
+        dev = "cuda:%d" % self.device
+        total = slices * self.n_envs * ((self.n_cells if with_boards else 0) + (4 if with_recs else 0))
+        probe_ok = self.n_envs >= 64 and (layout == "tile" or (self.n_envs * self.n_cells) % 16 == 0 or not with_boards)
+        if total < min_bytes or not probe_ok:
+            candidates = 1
+
+        def make():
+            shape = (lambda tail: (n_tiles, slices, 64, tail)) if layout == "tile" else (lambda tail: (slices, self.n_envs, tail))
+            b = torch.empty(shape(self.n_cells), dtype=torch.int8, device=dev) if with_boards else None
+            r = torch.empty(shape(4), dtype=torch.int8, device=dev) if with_recs else None
+            return b, r
+
+        # fast and slow placements come in runs of 10-20 GB of consecutively allocated memory (profiles/r03/ring_alloc_map.log):
+        # candidates allocated back to back would share their fate, so a spacer block is allocated between them -- held until
+        # the choice is made -- while the device has the room
+        held, times, spacers = [], [], []
+        for i in range(max(1, int(candidates))):
+            if i and spread_gib > 0:
+                free_b, _ = torch.cuda.mem_get_info(self.device)
+                if free_b > (int(spread_gib) << 30) + 2 * total + (8 << 30):
+                    spacers.append(torch.empty(int(spread_gib) << 30, dtype=torch.int8, device=dev))
+            b, r = make()
+            held.append((b, r))
+            times.append(self.probe_trajectory_ring(b, r, layout) if probe_ok else float("nan"))
+        del spacers
+        best = min(range(len(held)), key=lambda i: times[i]) if probe_ok else 0
+        boards, recs = held[best]
+        del held, b, r
+        if len(times) > 1:
+            torch.cuda.empty_cache()  # the losing candidates go back to the driver, not into torch's cache
+        return boards, recs, {"candidates_us": times, "chosen": best, "layout": layout, "bytes": total}
+
     def ring_slices(self, ring_tensor):
         """A tile-major trajectory ring [n_tiles, ring, 64, X] re-ordered to the slice-major form [ring, N, X] (a copy)."""
         n_tiles, ring, _, x = ring_tensor.shape

@@ -169,6 +169,55 @@ def test_streamed_rollout_keeps_every_step_in_the_trajectory_rings(name, n, ring
     env.close()
 
 
+@pytest.mark.parametrize("name,n,layout", [("BoatRace-v0", 4096, "slice"), ("IslandNavigation-v0", 1024, "tile"),
+                                           ("SideEffectsSokoban-v0", 1000, "slice")])
+def test_probed_trajectory_ring_allocation(name, n, layout):
+    """alloc_trajectory_ring: candidates allocated side by side, each timed by the store-only probe (sgk_ring_probe), the fastest
+    kept. The probe writes zeros into exactly the ring's bytes; the chosen rings then take a streamed rollout bit for bit."""
+    torch = _torch()
+    seed, ring, T = 17, 6, 9
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    orc = O.EnvBatch(name, n, seed=seed)
+    probe_ok = layout == "tile" or (n * env.n_cells) % 16 == 0
+    # a small ring takes one candidate unless told otherwise
+    b1, r1, info1 = env.alloc_trajectory_ring(ring, layout=layout)
+    assert len(info1["candidates_us"]) == 1 and info1["chosen"] == 0
+    boards, recs, info = env.alloc_trajectory_ring(ring, candidates=3, layout=layout, min_bytes=0)
+    assert len(info["candidates_us"]) == (3 if probe_ok else 1)
+    if probe_ok:
+        assert all(u > 0 for u in info["candidates_us"]) and info["candidates_us"][info["chosen"]] == min(info["candidates_us"])
+        # the probe touches the rings and nothing behind them
+        big_b = torch.full((boards.shape[0] + 1,) + tuple(boards.shape[1:]), -7, dtype=torch.int8, device="cuda")
+        big_r = torch.full((recs.shape[0] + 1,) + tuple(recs.shape[1:]), -7, dtype=torch.int8, device="cuda")
+        us = env.probe_trajectory_ring(big_b[:-1], big_r[:-1], layout)
+        assert us > 0 and bool((big_b[-1] == -7).all()) and bool((big_r[-1] == -7).all())
+        whole = (n // 64) * 64  # whole tiles are written (zeros); the rows of a partial last tile are left alone
+        if layout == "slice":
+            assert bool((big_b[:-1, :whole] == 0).all()) and bool((big_r[:-1, :whole] == 0).all())
+            assert bool((big_b[:-1, whole:] == -7).all())
+        with pytest.raises(RuntimeError):
+            _raise_on_bad_probe(env)
+    env.rollout_random_stream(T, boards=boards, recs=recs, layout=layout)
+    for k in range(T):
+        rec = orc.rollout(1, seed=seed, t_begin=k, auto_reset=True)
+        if k >= T - ring:
+            got_b = (env.ring_slices(boards) if layout == "tile" else boards)[k % ring].cpu().numpy()
+            got_r = (env.ring_slices(recs) if layout == "tile" else recs)[k % ring].cpu().numpy()
+            assert (got_b == orc.boards()).all() and (got_r == rec).all(), (name, layout, k)
+    assert_same_state(env, orc, "after a rollout into probed rings")
+    env.close()
+
+
+def _raise_on_bad_probe(env):
+    """sgk_ring_probe refuses what it cannot measure: no ring at all."""
+    import ctypes
+
+    from safe_grid_agents_amd import _lib
+
+    us = ctypes.c_double(0.0)
+    _lib.check(env.lib.sgk_ring_probe(env._h.ptr, None, None, 4, 0, ctypes.byref(us)))
+
+
 @pytest.mark.parametrize("name", ["BoatRace-v0", "IslandNavigation-v0", "SideEffectsSokoban-v0", "TomatoWatering-v0"])
 @pytest.mark.parametrize("layout", ["slice", "tile"])
 def test_tile_stores_end_at_the_tile(name, layout):
