@@ -25,9 +25,9 @@ What is timed -- `--path`:
 The default run reports the other two as secondary objects (`rewritten_in_place`, `per_step_launches`) and the outputs-once
 kernel (`fused_rollout`: no per-step output exists), each with its own counter-based traffic figures.
 The ring's rate differs from allocation to allocation of the 3 GB; `other_ring_allocations` times three more
-PLAIN rings (torch.empty) in the same process, and `probed_ring_allocation` the same kernel on the ring the library's
-placement-aware allocator returns (the fastest of 8 candidates by the store-only probe). `value` itself is measured on a plain
-allocation; `--ring-candidates N` makes the allocator's ring the primary one.
+PLAIN rings (torch.empty) in the same process. The primary ring's memory comes from the library's ring allocator
+(`sgk_ring_alloc`: one virtual range mapped from 256 MiB physical chunks, on the fast level every time -- a recipe, nothing is
+timed or picked; `--ring-backing torch` for a plain block).
 
 Workload = BASELINE.json's metric config: BoatRace, 1 048 576 concurrent envs in the whole job at every GPU count (the batch
 shards by env id, one contiguous block per rank, no data-path collective; the only exchange is one int64 metrics all-reduce
@@ -337,9 +337,9 @@ def main():
                     help="ring: streamed rollout, every step's board + record KEPT in a 100-slice trajectory ring (default); own: "
                          "the same kernel into the env's own buffers (rewritten in place); launch: one step-kernel launch per step")
     ap.add_argument("--no-secondary", action="store_true", help="skip the measurements of the other two paths")
-    ap.add_argument("--ring-candidates", type=int, default=1,
-                    help="> 1: the PRIMARY trajectory ring is the fastest of this many probed allocations (alloc_trajectory_ring); the "
-                         "default is a plain allocation, and the allocator's ring is measured as a secondary object")
+    ap.add_argument("--ring-backing", choices=("ring", "torch"), default="ring",
+                    help="memory of the PRIMARY trajectory ring: the library's ring allocator (sgk_ring_alloc: HIP virtual memory "
+                         "management, 256 MiB physical chunks) or a plain torch.empty block")
     ap.add_argument("--no-weak-line", action="store_true", help="skip the secondary 1M-envs-per-GPU measurement at N > 1")
     args = ap.parse_args()
 
@@ -405,13 +405,14 @@ def main():
     L = max(1, args.lockstep_per_step)
     k_lock, w_lock = args.steps * L, args.warmup * L  # the timed region / the warm-up in lockstep steps
     gpu_leg_ms = 0.0
-    # The rate a persistent kernel writes a multi-GB ring at is a property of the allocation. `value` is measured
-    # on a PLAIN allocation (one candidate = torch.empty, nothing probed, nothing picked); the library's placement-aware
-    # allocator (alloc_trajectory_ring: several candidates, each timed by the store-only probe sgk_ring_probe, the fastest
-    # kept) is measured as the secondary object `probed_ring_allocation`. --ring-candidates N > 1 makes it the primary ring.
+    # The rate a persistent kernel writes a multi-GB ring at depends on how the ring's physical memory is made up:
+    # hipMalloc blocks measure 4.6-4.9 or 5.6-6.1 us per step, block by block; memory mapped from 256 MiB physical chunks
+    # (sgk_ring_alloc, what BatchedGridworldEnv.alloc_trajectory_ring hands out) 4.5-4.8 every time. The primary ring comes from
+    # the library's allocator -- a deterministic recipe, nothing is timed or picked --; what plain torch.empty rings get in this
+    # same process is in `other_ring_allocations`. --ring-backing torch makes the primary ring a plain block too.
     ring, ring_alloc = None, None
     if args.path == "ring":
-        rb, rr, ring_alloc = env.alloc_trajectory_ring(RING_SLICES, candidates=max(1, args.ring_candidates))
+        rb, rr, ring_alloc = env.alloc_trajectory_ring(RING_SLICES, backing=args.ring_backing)
         ring = (rb, rr)
     slice_next = [0]
     elapsed, kernel_ms, gm = timed_steps(env, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path, ring=ring,
@@ -479,20 +480,6 @@ def main():
                        "note": "PLAIN %d-slice rings (torch.empty, no probing) allocated and timed one after another in this process "
                                "with the same kernel (device clock, max over ranks); the primary measurement's own figure is "
                                "roofline.device_us_per_step" % RING_SLICES}
-    probed = None
-    if args.path == "ring" and not args.no_secondary and args.ring_candidates <= 1:
-        pb, pr, pinfo = env.alloc_trajectory_ring(RING_SLICES, candidates=8)
-        _, p_ms, _ = timed_steps(env, 3 * GRAPH_CHUNK, GRAPH_CHUNK, barrier, sdist.global_metrics, path="ring", ring=(pb, pr))
-        _, p_ms = max_over_ranks(0.0, p_ms)
-        total_steps += 4 * GRAPH_CHUNK
-        gpu_leg_ms += p_ms
-        del pb, pr
-        probed = {"device_us_per_lockstep_step": p_ms * 1e3 / (3 * GRAPH_CHUNK),
-                  "device_value": n_total * 3 * GRAPH_CHUNK / (p_ms / 1e3), "unit": "env-steps/s",
-                  "candidates_probe_us_per_slice": pinfo["candidates_us"], "chosen": pinfo["chosen"],
-                  "note": "the same kernel into the ring BatchedGridworldEnv.alloc_trajectory_ring returns: the fastest of %d candidate "
-                          "allocations by the store-only probe (sgk_ring_probe); rank 0's candidates, device clock max over ranks"
-                          % len(pinfo["candidates_us"])}
     fused = None
     if not args.no_fused:
         # same workload through the outputs-once rollout kernel (state in registers, boards materialised once per launch)
@@ -593,12 +580,9 @@ def main():
         out["fused_rollout"] = fused
     if ring_alloc is not None:
         out["ring_allocation"] = {
-            "allocator": ("plain: one allocation, nothing probed" if len(ring_alloc["candidates_us"]) == 1 else
-                          "BatchedGridworldEnv.alloc_trajectory_ring: fastest of %d candidate allocations by the store-only probe "
-                          "(sgk_ring_probe), chosen before the warm-up" % len(ring_alloc["candidates_us"])),
-            "candidates_probe_us_per_slice": ring_alloc["candidates_us"], "chosen": ring_alloc["chosen"], "bytes": ring_alloc["bytes"]}
-    if probed:
-        out["probed_ring_allocation"] = probed
+            "backing": ("sgk_ring_alloc: one virtual range mapped from 256 MiB physical chunks (HIP virtual memory management); nothing "
+                        "timed, nothing picked" if ring_alloc["backing"] == "ring" else "torch.empty: one hipMalloc block per ring"),
+            "bytes": ring_alloc["bytes"]}
     if ring_spread:
         out["other_ring_allocations"] = ring_spread
     if weak_line:

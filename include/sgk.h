@@ -188,6 +188,14 @@ SGK_API int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags);
  * (state, records, boards, episode arrays, metrics) equal n_steps calls of sgk_step_random(1), bit for bit. */
 SGK_API int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flags, int8_t *boards_ring_dev,
                                       sgk_step_rec *recs_ring_dev, int32_t ring_slices, int32_t first_slice);
+/* Device memory for trajectory rings (and any other multi-GB buffer a long-running kernel streams into): one contiguous range
+ * of `bytes` (rounded up to 2 MiB) mapped through HIP's virtual-memory management from physical chunks of 256 MiB. The streamed
+ * rollout writes such a ring at 4.5-4.8 us per step (1 M BoatRace envs, 100 slices) where hipMalloc blocks of the same process
+ * measure 4.6-4.9 or 5.6-6.1 depending on the block, for its lifetime. The reference keeps its transitions in a
+ * Python deque (contain.py:11-13); this is where the batched form keeps them. sgk_ring_free synchronises the device first.
+ * SGK_RING_CHUNK_MIB (2 ... 512) overrides the chunk size. */
+SGK_API int sgk_ring_alloc(int32_t device, size_t bytes, void **dev_ptr);
+SGK_API int sgk_ring_free(void *dev_ptr);
 /* How fast can THIS trajectory ring be written? Runs the streamed rollout's stores and nothing else over every slice of the ring
  * (layout and cache policy as sgk_rollout_random_stream would use for it; the contents are zeros afterwards) and returns the
  * median device time of three passes, in microseconds per slice (= per lockstep step of a streamed rollout that is bound by its

@@ -116,6 +116,8 @@ _SIGNATURES = {
     "sgk_rollout_random": (ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_uint32]),
     "sgk_rollout_random_stream": (ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_uint32, _V, _V, ctypes.c_int32, ctypes.c_int32]),
     "sgk_ring_probe": (ctypes.c_int, [_V, _V, _V, ctypes.c_int32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]),
+    "sgk_ring_alloc": (ctypes.c_int, [ctypes.c_int32, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    "sgk_ring_free": (ctypes.c_int, [_V]),
     "sgk_step_repeat": (ctypes.c_int, [_V, _V, ctypes.c_int32, ctypes.c_uint32]),
     "sgk_random_action": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]),
     "sgk_boards_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V), ctypes.POINTER(ctypes.c_int64)]),

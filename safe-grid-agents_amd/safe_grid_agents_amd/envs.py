@@ -114,6 +114,23 @@ class _Handle:
             pass
 
 
+class _RingMemory:
+    """Device memory from sgk_ring_alloc as a __cuda_array_interface__ object: torch.as_tensor(this) is a zero-copy int8 view that
+    keeps this object alive; the memory goes back to the library when the last such tensor is gone."""
+
+    def __init__(self, lib, ptr, shape):
+        self._lib, self._ptr = lib, ptr
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": "|i1", "data": (ptr, False), "version": 2, "strides": None}
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                self._lib.sgk_ring_free(ctypes.c_void_p(self._ptr))
+                self._ptr = None
+        except Exception:  # interpreter shutdown: the process's memory goes with it
+            pass
+
+
 class BatchedGridworldEnv:
     """N independent grid instances stepped in lockstep by hand-written HIP kernels on one MI355X.
 
@@ -333,19 +350,40 @@ class BatchedGridworldEnv:
                                            ctypes.byref(us)))
         return float(us.value)
 
-    def alloc_trajectory_ring(self, slices, candidates=8, layout="slice", with_boards=True, with_recs=True, min_bytes=1 << 30,
-                              spread_gib=16):
-        """Trajectory rings for rollout_random_stream -- boards int8 [slices, N, n_cells], recs int8 [slices, N, 4] (tile-major:
-        [n_tiles, slices, 64, ...]) -- placed where they can be written fast. The rate at which a persistent kernel writes a
-        multi-GB ring is a property of the ALLOCATION the ring lives in (at 1 M BoatRace envs, 3 GB: 4.6-4.9 us per step in some
-        hipMalloc blocks, 5.6-6.1 in others of the same process, for the block's lifetime), so `candidates` pairs
-        are allocated side by side, each is timed with the store-only probe, the fastest is kept and the others are returned to
-        the driver. Rings below `min_bytes` (1 GiB: a few Infinity Caches) do not show the effect: one candidate, no probe needed.
-        `spread_gib`: a spacer allocation of that size between consecutive candidates (fast and slow placements come in runs).
-        Returns (boards, recs, info); info["candidates_us"] lists every candidate's probe time in allocation order."""
+    def _ring_tensor(self, shape, backing):
+        """An int8 device tensor of `shape`: backing="ring" -> memory from sgk_ring_alloc (HIP virtual memory management, 256 MiB
+        physical chunks), handed to torch through __cuda_array_interface__ and returned to the library when the tensor dies;
+        backing="torch" -> torch.empty."""
         import torch
 
-        assert layout in ("slice", "tile") and (with_boards or with_recs) and slices >= 1
+        dev = "cuda:%d" % self.device
+        nbytes = 1
+        for d in shape:
+            nbytes *= int(d)
+        if backing == "torch" or nbytes == 0:
+            return torch.empty(shape, dtype=torch.int8, device=dev)
+        ptr = ctypes.c_void_p()
+        _lib.check(self.lib.sgk_ring_alloc(self.device, nbytes, ctypes.byref(ptr)))
+        t = torch.as_tensor(_RingMemory(self.lib, ptr.value, tuple(int(d) for d in shape)), device=dev)
+        assert t.data_ptr() == ptr.value and t.dtype == torch.int8
+        return t
+
+    def alloc_trajectory_ring(self, slices, candidates=1, layout="slice", with_boards=True, with_recs=True, min_bytes=1 << 30,
+                              spread_gib=16, backing="ring"):
+        """Trajectory rings for rollout_random_stream -- boards int8 [slices, N, n_cells], recs int8 [slices, N, 4] (tile-major:
+        [n_tiles, slices, 64, ...]) -- placed where they can be written fast. The rate at which a persistent kernel writes a
+        multi-GB ring depends on how the ring's physical memory is made up: hipMalloc blocks (torch.empty) of one
+        process measure 4.6-4.9 us per step at 1 M BoatRace envs / 3 GB or 5.6-6.1, for the block's lifetime; memory mapped from
+        256 MiB physical chunks through HIP's virtual-memory management (sgk_ring_alloc) 4.5-4.8 every time. backing="ring"
+        (default) uses the latter, backing="torch" plain torch.empty.
+        `candidates` > 1 additionally allocates that many pairs side by side (a `spread_gib` spacer between them while the device has
+        room), times each with the store-only probe (sgk_ring_probe) and keeps the fastest -- what one can do about torch.empty
+        blocks; rings below `min_bytes` take one candidate.
+        Returns (boards, recs, info); info["candidates_us"] lists every candidate's probe time in allocation order (one entry,
+        not probed = nan, when nothing had to be chosen)."""
+        import torch
+
+        assert layout in ("slice", "tile") and (with_boards or with_recs) and slices >= 1 and backing in ("ring", "torch")
         n_tiles = (self.n_envs + 63) // 64
         dev = "cuda:%d" % self.device
         total = slices * self.n_envs * ((self.n_cells if with_boards else 0) + (4 if with_recs else 0))
@@ -355,29 +393,31 @@ class BatchedGridworldEnv:
 
         def make():
             shape = (lambda tail: (n_tiles, slices, 64, tail)) if layout == "tile" else (lambda tail: (slices, self.n_envs, tail))
-            b = torch.empty(shape(self.n_cells), dtype=torch.int8, device=dev) if with_boards else None
-            r = torch.empty(shape(4), dtype=torch.int8, device=dev) if with_recs else None
+            b = self._ring_tensor(shape(self.n_cells), backing) if with_boards else None
+            r = self._ring_tensor(shape(4), backing) if with_recs else None
             return b, r
 
+        if candidates <= 1:
+            b, r = make()
+            return b, r, {"candidates_us": [float("nan")], "chosen": 0, "layout": layout, "bytes": total, "backing": backing}
         # fast and slow placements come in runs of 10-20 GB of consecutively allocated memory (profiles/r03/ring_alloc_map.log):
         # candidates allocated back to back would share their fate, so a spacer block is allocated between them -- held until
         # the choice is made -- while the device has the room
         held, times, spacers = [], [], []
-        for i in range(max(1, int(candidates))):
+        for i in range(int(candidates)):
             if i and spread_gib > 0:
                 free_b, _ = torch.cuda.mem_get_info(self.device)
                 if free_b > (int(spread_gib) << 30) + 2 * total + (8 << 30):
                     spacers.append(torch.empty(int(spread_gib) << 30, dtype=torch.int8, device=dev))
             b, r = make()
             held.append((b, r))
-            times.append(self.probe_trajectory_ring(b, r, layout) if probe_ok else float("nan"))
+            times.append(self.probe_trajectory_ring(b, r, layout))
         del spacers
-        best = min(range(len(held)), key=lambda i: times[i]) if probe_ok else 0
+        best = min(range(len(held)), key=lambda i: times[i])
         boards, recs = held[best]
         del held, b, r
-        if len(times) > 1:
-            torch.cuda.empty_cache()  # the losing candidates go back to the driver, not into torch's cache
-        return boards, recs, {"candidates_us": times, "chosen": best, "layout": layout, "bytes": total}
+        torch.cuda.empty_cache()  # the losing candidates go back to the driver, not into torch's cache
+        return boards, recs, {"candidates_us": times, "chosen": best, "layout": layout, "bytes": total, "backing": backing}
 
     def ring_slices(self, ring_tensor):
         """A tile-major trajectory ring [n_tiles, ring, 64, X] re-ordered to the slice-major form [ring, N, X] (a copy)."""

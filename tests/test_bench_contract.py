@@ -86,9 +86,7 @@ def test_bench_line_one_rank():
         assert d[k]["value"] > 0 and d[k]["device_value"] > 0 and d[k]["bound"] == "fabric / infinity-cache write"
         assert {"traffic", "traffic_gbs", "traffic_frac", "frac", "algorithmic_bytes_per_env_step"} <= set(d[k]) and d[k]["frac"] is None
     assert d["fused_rollout"]["value"] > 0 and "roofline" in d["fused_rollout"]
-    ra = d["ring_allocation"]  # `value` is measured on a plain allocation: one candidate, nothing chosen
-    assert ra["chosen"] == 0 and len(ra["candidates_probe_us_per_slice"]) == 1 and ra["allocator"].startswith("plain")
-    assert d["probed_ring_allocation"]["device_us_per_lockstep_step"] > 0  # (8192 envs: below the size where placement shows)
+    assert d["ring_allocation"]["backing"].startswith("sgk_ring_alloc") and d["ring_allocation"]["bytes"] == 100 * 8192 * 29
     spread = d["other_ring_allocations"]  # what other fresh rings get in the same process: the allocation lottery, shown
     assert spread["rings"] == 3 and len(spread["device_us_per_lockstep_step"]) == 3 and min(spread["device_us_per_lockstep_step"]) > 0
     # another path as the primary one, and round 1's step definition

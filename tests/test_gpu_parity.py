@@ -179,9 +179,15 @@ def test_probed_trajectory_ring_allocation(name, n, layout):
     env = S.BatchedGridworldEnv(name, n, seed=seed)
     orc = O.EnvBatch(name, n, seed=seed)
     probe_ok = layout == "tile" or (n * env.n_cells) % 16 == 0
-    # a small ring takes one candidate unless told otherwise
+    # the default: memory from the library's ring allocator, nothing probed; torch ops work on it like on any device tensor
     b1, r1, info1 = env.alloc_trajectory_ring(ring, layout=layout)
-    assert len(info1["candidates_us"]) == 1 and info1["chosen"] == 0
+    assert info1["backing"] == "ring" and len(info1["candidates_us"]) == 1 and info1["chosen"] == 0
+    b1.fill_(5)
+    assert int(b1.to(torch.int32).sum().item()) == 5 * b1.numel() and bool((b1[-1].cpu() == 5).all())
+    shape1 = tuple(b1.shape)
+    del b1, r1  # (returns the memory to the library: sgk_ring_free)
+    bt, rt, info_t = env.alloc_trajectory_ring(ring, layout=layout, backing="torch")
+    assert info_t["backing"] == "torch" and tuple(bt.shape) == shape1
     boards, recs, info = env.alloc_trajectory_ring(ring, candidates=3, layout=layout, min_bytes=0)
     assert len(info["candidates_us"]) == (3 if probe_ok else 1)
     if probe_ok:
@@ -206,6 +212,43 @@ def test_probed_trajectory_ring_allocation(name, n, layout):
             assert (got_b == orc.boards()).all() and (got_r == rec).all(), (name, layout, k)
     assert_same_state(env, orc, "after a rollout into probed rings")
     env.close()
+
+
+class _Borrowed:
+    """A raw device range as a __cuda_array_interface__ object (no ownership)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|i1", "data": (ptr, False), "version": 2, "strides": None}
+
+
+def test_ring_alloc_and_free_through_the_c_abi():
+    """sgk_ring_alloc / sgk_ring_free: sizes below and above one 256 MiB chunk, the memory is ordinary device memory (hipMemcpy
+    at its first and last bytes), a pointer the allocator did not return is refused, NULL is a no-op."""
+    import ctypes
+
+    from safe_grid_agents_amd import _lib
+
+    torch = _torch()
+    lib = _lib.load()
+    for nbytes in (1, 5 * 1000 * 1000, (256 << 20) + 12345, 600 << 20):
+        ptr = ctypes.c_void_p()
+        _lib.check(lib.sgk_ring_alloc(0, nbytes, ctypes.byref(ptr)))
+        assert ptr.value and ptr.value % (2 << 20) == 0
+        view = torch.as_tensor(_Borrowed(ptr.value, nbytes), device="cuda")  # a non-owning int8 view of the whole range
+        src = torch.arange(min(nbytes, 4096), dtype=torch.int32, device="cuda").to(torch.int8)
+        view[: src.numel()] = src
+        view[-src.numel():] = src  # (the last chunk is mapped too)
+        assert bool((view[: src.numel()].cpu() == src.cpu()).all()) and bool((view[-src.numel():].cpu() == src.cpu()).all())
+        del view
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.SgkError):
+            _lib.check(lib.sgk_ring_free(ctypes.c_void_p(ptr.value + 4096)))
+        _lib.check(lib.sgk_ring_free(ptr))
+        with pytest.raises(_lib.SgkError):
+            _lib.check(lib.sgk_ring_free(ptr))  # twice
+    _lib.check(lib.sgk_ring_free(None))
+    with pytest.raises(_lib.SgkError):
+        _lib.check(lib.sgk_ring_alloc(0, 0, ctypes.byref(ctypes.c_void_p())))
 
 
 def _raise_on_bad_probe(env):

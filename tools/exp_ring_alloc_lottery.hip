@@ -101,6 +101,72 @@ static double us_per_step(char *b, char *r, int mul = 1, size_t pad = 0, int tmu
 
 int main(int argc, char **argv) {
   const size_t bb = (size_t)TILES * STEPS * PIECE, rb = (size_t)TILES * STEPS * RPIECE, slack = (size_t)1 << 30;
+  if (argc > 1 && !strcmp(argv[1], "vmm")) {
+    // A contiguous VIRTUAL ring over scattered PHYSICAL memory (HIP virtual memory management): physical chunks of `chunk` bytes
+    // created one after another, mapped into the ring's address range in order, in a shuffled order, or with every other created
+    // chunk given back first (the kept ones lie 2 x chunk apart). Does the ring's rate follow the physical arrangement?
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    size_t gran = 0;
+    CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+    printf("# granularity %zu bytes; columns: in order | shuffled | every other chunk kept (in order) | every other kept + shuffled\n", gran);
+    for (size_t chunk : {(size_t)64 << 10, (size_t)2 << 20, (size_t)32 << 20, (size_t)256 << 20, (size_t)512 << 20, (size_t)1 << 30, (size_t)2 << 30, (size_t)4 << 30}) {
+      if (argc > 2 && (size_t)atoll(argv[2]) != (chunk >> 10)) continue;  // one chunk size, in KiB
+      for (int trial = 0; trial < 3; ++trial) {
+        printf("chunk %7zu KiB, trial %d:", chunk >> 10, trial);
+        for (int mode = 0; mode < 4; ++mode) {
+          const bool shuffle = mode & 1, sparse = mode & 2;
+          if (chunk < ((size_t)1 << 20) && mode) continue;  // (47 000 handles: once)
+          if (sparse && chunk > ((size_t)256 << 20)) continue;
+          char *base[2];
+          std::vector<hipMemGenericAllocationHandle_t> hs[2], dropped;
+          size_t sizes[2] = {(bb + chunk - 1) / chunk * chunk, (rb + chunk - 1) / chunk * chunk};
+          for (int w = 0; w < 2; ++w) {
+            const size_t nch = sizes[w] / chunk;
+            for (size_t i = 0; i < nch; ++i) {
+              hipMemGenericAllocationHandle_t h;
+              CK(hipMemCreate(&h, chunk, &prop, 0));
+              hs[w].push_back(h);
+              if (sparse) {  // a second chunk right behind it, given back below: the kept ones are 2 x chunk apart
+                hipMemGenericAllocationHandle_t d;
+                CK(hipMemCreate(&d, chunk, &prop, 0));
+                dropped.push_back(d);
+              }
+            }
+            void *ptr = nullptr;
+            CK(hipMemAddressReserve(&ptr, sizes[w], 0, nullptr, 0));
+            base[w] = (char *)ptr;
+            std::vector<size_t> order(nch);
+            for (size_t i = 0; i < nch; ++i) order[i] = i;
+            if (shuffle) {
+              uint64_t x = 88172645463325252ull + trial;
+              for (size_t i = nch - 1; i > 0; --i) {
+                x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                std::swap(order[i], order[x % (i + 1)]);
+              }
+            }
+            for (size_t i = 0; i < nch; ++i) CK(hipMemMap(base[w] + i * chunk, chunk, 0, hs[w][order[i]], 0));
+            hipMemAccessDesc acc = {};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            CK(hipMemSetAccess(ptr, sizes[w], &acc, 1));
+          }
+          for (auto d : dropped) CK(hipMemRelease(d));
+          printf(" %.2f", us_per_step(base[0], base[1]));
+          fflush(stdout);
+          for (int w = 0; w < 2; ++w) {
+            CK(hipMemUnmap(base[w], sizes[w]));
+            CK(hipMemAddressFree(base[w], sizes[w]));
+            for (auto h : hs[w]) CK(hipMemRelease(h));
+          }
+        }
+        printf("\n");
+      }
+    }
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "spread")) {
     // Is it WHERE in physical memory the slices lie relative to each other? The ring as NCH chunks, allocated back to back or
     // with spacer allocations of `gap` GiB between them (kept while measuring), several trials each.

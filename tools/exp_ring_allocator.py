@@ -26,6 +26,10 @@ def kernel_us(env, b, r, launches=3):
 
 n = 1 << 20
 env = S.BatchedGridworldEnv("BoatRace-v0", n, seed=1)
+for trial in range(4):  # the library's ring allocator (HIP VMM, 256 MiB chunks): probe and kernel
+    vb, vr, _ = env.alloc_trajectory_ring(100)
+    print("sgk_ring_alloc ring %d: probe %.2f, kernel %.2f us per step" % (trial, env.probe_trajectory_ring(vb, vr), kernel_us(env, vb, vr, 5)), flush=True)
+    del vb, vr
 if os.environ.get("ONLY_AB"):
     sys.argv.append("ab")
 pb = torch.empty((100, n, env.n_cells), dtype=torch.int8, device="cuda")
@@ -33,7 +37,7 @@ pr = torch.empty((100, n, 4), dtype=torch.int8, device="cuda")
 print("plain ring: probe %.2f, kernel %.2f us per step" % (env.probe_trajectory_ring(pb, pr), kernel_us(env, pb, pr)), flush=True)
 for spread in (() if "ab" in sys.argv else (0, 16, 24)):
     for cand in (8, 12):
-        b, r, info = env.alloc_trajectory_ring(100, candidates=cand, spread_gib=spread)
+        b, r, info = env.alloc_trajectory_ring(100, candidates=cand, spread_gib=spread, backing="torch")
         print("candidates %2d, spacers %2d GiB: probes %s -> chosen %d: kernel %.2f us per step" % (
             cand, spread, " ".join("%.2f" % u for u in info["candidates_us"]), info["chosen"], kernel_us(env, b, r)), flush=True)
         del b, r
@@ -42,7 +46,7 @@ env.close()
 
 # ---- on ONE fast ring: does the residency of the streamed kernel matter? (SGK_STREAM_RESIDENT is read per launch)
 env = S.BatchedGridworldEnv("BoatRace-v0", n, seed=1)
-b, r, info = env.alloc_trajectory_ring(100, candidates=8, spread_gib=16)
+b, r, info = env.alloc_trajectory_ring(100, candidates=8, spread_gib=16, backing="torch")
 print("ring for the residency A/B: probe %.2f us per step (candidates %s)" % (
     info["candidates_us"][info["chosen"]], " ".join("%.2f" % u for u in info["candidates_us"])), flush=True)
 for rep in range(2):
