@@ -248,9 +248,19 @@ struct StreamOut {
   int32_t ring_nt;     // board tiles into the ring as non-temporal write-through stores (rings far larger than the caches)
 };
 
+#if SGK_DBG_TIMELINE  // investigation build only (tools/exp_stream_timeline.py): when does each workgroup start, store first, end?
+__device__ unsigned long long sgk_dbg_tl[3 * 16384];
+extern "C" __attribute__((visibility("default"))) int sgk_debug_timeline(unsigned long long *host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sgk_dbg_tl), sizeof(unsigned long long) * (size_t)n_words);
+}
+#endif
+
 template <int ENV, int LAYOUT, bool STREAM>
 __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout_random_kernel(StepArgs a, int32_t n_steps, StreamOut o) {
   constexpr int NC = Geom<ENV>::NC;
+#if SGK_DBG_TIMELINE
+  if (STREAM && threadIdx.x == 0 && blockIdx.x < 16384) sgk_dbg_tl[blockIdx.x * 3] = wall_clock64();
+#endif
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
   __shared__ SgkRules R;
   __shared__ CompactLds<NC> C;
@@ -262,6 +272,10 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
   const int64_t n_wt = (a.n + 63) / 64;
   EpisodeAcc acc;
   acc_init(acc);
+  // (Handing the tile groups out by ticket to a resident-sized grid of persistent workgroups -- the XCDs do not write at the same
+  // rate: at 1 M envs the workgroups of the even XCDs live 190-215 us per 100 steps, those of the odd ones 150-165, and the odd
+  // XCDs sit idle for the last 15 % of a launch, profiles/r03/stream_timeline.log -- was built and measured: BoatRace 6.25 vs 6.18
+  // us per step, IslandNavigation 9.03 vs 9.5, Sokoban 8.1-8.25 vs 8.3, at 97 instead of 80 VGPRs; stream_tickets_ab.log. Not kept.)
   for (int64_t wt = (int64_t)blockIdx.x * (WG / 64) + wave; wt < n_wt; wt += (int64_t)gridDim.x * (WG / 64)) {
     const int64_t env = wt * 64 + lane;
     const bool valid = env < a.n;
@@ -307,6 +321,9 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
     const int64_t brd_stride = !o.boards ? 0 : (tm ? (int64_t)64 * NC : a.n * (int64_t)NC);  // bytes per slice
     const int64_t rec_wrap = rec_stride * (o.ring - 1), brd_wrap = brd_stride * (o.ring - 1);
     uint32_t left = 0;  // steps left in the action word in hand
+#if SGK_DBG_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x < 16384) sgk_dbg_tl[blockIdx.x * 3 + 1] = wall_clock64();
+#endif
 #pragma nounroll
     for (int32_t k = 0; k < n_steps; ++k) {
       if (left == 0) {  // a new 16-step word; a new Philox block every 64 steps (and on the launch's first step)
@@ -483,6 +500,9 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
       else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
     }
   }
+#if SGK_DBG_TIMELINE
+  if (STREAM && threadIdx.x == 0 && blockIdx.x < 16384) sgk_dbg_tl[blockIdx.x * 3 + 2] = wall_clock64();
+#endif
   acc_flush(acc, a.metrics);
 }
 
@@ -726,6 +746,7 @@ hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flag
               // non-temporal only where the ring dwarfs the caches. Measured at 1 M BoatRace envs, same box, three repeats: a
               // 100-slice ring (3 GB) 6.32 vs 6.52 us per step with / without, a 32-slice ring (1 GB) 5.34 vs 4.90
               (int32_t)((int64_t)(ring < 1 ? 1 : ring) * sh.n * (sh.n_cells + 4) > (3ll << 29))};
+  if (const char *nt = getenv("SGK_RING_NT")) o.ring_nt = atoi(nt);  // A/B switch of the tools (read per launch)
   // (Lowering the residency to whole rounds -- 16 workgroups per CU at 4 resident instead of 3 rounds of 5 and a last one of 1 --
   // by padding the dynamic LDS was measured on a fast ring: 5.17-5.31 us per step at 2, 3, 4 and 5 per CU alike,
   // profiles/r03/stream_residency_ab.log. Not kept.)

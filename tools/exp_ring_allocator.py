@@ -26,6 +26,39 @@ def kernel_us(env, b, r, launches=3):
 
 n = 1 << 20
 env = S.BatchedGridworldEnv("BoatRace-v0", n, seed=1)
+if "k" in sys.argv:  # launch length: fixed costs per launch (workgroup start-up, final flush) against per-step costs
+    st = env.torch_stream()
+    vb, vr, _ = env.alloc_trajectory_ring(100)
+    print("sgk_ring_alloc ring: probe %.2f" % env.probe_trajectory_ring(vb, vr), flush=True)
+    for rep in range(3):
+        if rep == 2:
+            env.bind_torch_stream()  # the library's kernels on torch's current stream: no cross-stream events around each call
+            st = torch.cuda.current_stream()
+            print("  -- bound to torch's current stream", flush=True)
+        for K in (100, 200, 400, 1000):
+            env.rollout_random_stream(K, boards=vb, recs=vr)
+            env.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            launches = max(2, 600 // K)
+            for _ in range(launches):
+                env.rollout_random_stream(K, boards=vb, recs=vr)
+            e1.record(st)
+            env.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / launches
+            print("  K = %4d steps per launch: %.1f us per launch = %.3f us per step" % (K, us, us / K), flush=True)
+    sys.exit(0)
+if "nt" in sys.argv:  # on rings from the library's allocator: board stores non-temporal write-through (default above 1.5 GB) or write-through
+    for trial in range(3):
+        vb, vr, _ = env.alloc_trajectory_ring(100)
+        line = "sgk_ring_alloc ring %d: probe %.2f |" % (trial, env.probe_trajectory_ring(vb, vr))
+        for nt in ("1", "0", "1", "0"):
+            os.environ["SGK_RING_NT"] = nt
+            line += " nt=%s kernel %.2f" % (nt, kernel_us(env, vb, vr, 5))
+        print(line, flush=True)
+        del vb, vr
+    os.environ.pop("SGK_RING_NT")
+    sys.exit(0)
 for trial in range(4):  # the library's ring allocator (HIP VMM, 256 MiB chunks): probe and kernel
     vb, vr, _ = env.alloc_trajectory_ring(100)
     print("sgk_ring_alloc ring %d: probe %.2f, kernel %.2f us per step" % (trial, env.probe_trajectory_ring(vb, vr), kernel_us(env, vb, vr, 5)), flush=True)
