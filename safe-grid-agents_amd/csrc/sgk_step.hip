@@ -264,6 +264,14 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
   __shared__ SgkRules R;
   __shared__ CompactLds<NC> C;
+  // the first tile's state words are asked for BEFORE the rules are staged: behind a saturated write path each of these is a
+  // multi-microsecond round trip, and a workgroup's start-up (11 us median at 1 M envs, profiles/r03/stream_timeline.log) was a
+  // chain of them
+  uint64_t first_word = 0;
+  {
+    const int64_t env0 = ((int64_t)blockIdx.x * (WG / 64) + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63);
+    if (STREAM && env0 < a.n) first_word = a.state[env0];
+  }
   stage_rules(R, a.rules);
   SGK_TILE_DECLARE(ENV, NC, (COMPACT || STREAM));
   // (the outputs-once form stores nothing per step: a scalar tile index buys it nothing and costs it registers -- 64 -> 79 VGPRs)
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
     const int64_t env = wt * 64 + lane;
     const bool valid = env < a.n;
     EnvState s = initial_state(R);
-    if (valid) s = unpack_state(a.state[env]);
+    if (valid) s = unpack_state((STREAM && wt < (int64_t)gridDim.x * (WG / 64)) ? first_word : a.state[env]);
     load_episode_index<ENV>(s, a.n_resets, env, valid);
     const uint64_t ge = a.env_base + (uint64_t)env;
     AuxRegs ax;  // the env's float64 side state for the whole launch (friend or foe; dead code elsewhere)
