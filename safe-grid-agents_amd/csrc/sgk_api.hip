@@ -743,6 +743,7 @@ int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flags, int8_
 // 4.52-4.78 / 5.34-5.53 (64 KiB: 23; profiles/r03/ring_alloc_vmm*.log): chunks of 256 MiB are on the fast level every time.
 namespace {
 struct RingBlock {
+  int device = 0;
   size_t va_bytes = 0;
   std::vector<hipMemGenericAllocationHandle_t> chunks;
   std::vector<size_t> chunk_bytes;
@@ -778,6 +779,7 @@ int sgk_ring_alloc(int32_t device, size_t bytes, void **dev_ptr) {
   prop.location.id = device;
   const size_t two_mib = (size_t)2 << 20;
   RingBlock b;
+  b.device = device;
   // whole chunks, and a last one rounded up to 2 MiB (a ring smaller than a chunk is one allocation of its own size)
   for (size_t left = bytes; left > 0;) {
     const size_t take = left >= chunk ? chunk : (left + two_mib - 1) / two_mib * two_mib;
@@ -824,6 +826,7 @@ int sgk_ring_free(void *dev_ptr) {
     b = std::move(it->second);
     g_rings.erase(it);
   }
+  SGK_HIP(hipSetDevice(b.device));
   (void)hipDeviceSynchronize();  // nothing may still be writing into it
   release_ring(dev_ptr, b, b.chunks.size());
   return SGK_OK;
