@@ -198,25 +198,30 @@ def timed_steps(env, steps, warmup, barrier, global_metrics, path="ring", ring=N
     if path == "launch":
         for c in sorted(set(chunk_schedule(warmup) + chunk_schedule(steps))):
             env.prepare_step_random(c, auto_reset=True)
-    run(warmup)
-    env.metrics_reset()  # the line's episode figures (episodes_finished, mean_return, mean_safety) are the timed region's
-    env.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    # ---- timed region ---------------------------------------------------------------------------------------------------
-    barrier()
-    torch.cuda.synchronize()
-    env.synchronize()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    run(steps)
-    t_enq = time.perf_counter()
-    ev1.record(stream)
-    gm = global_metrics(env)  # syncs the stream; one int64 all-reduce (RCCL over xGMI) when world > 1
-    t_met = time.perf_counter()
-    env.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
+    # The env's stream is torch's CURRENT stream for the whole region. Otherwise every call of the Python wrapper orders the
+    # library's stream against torch's current stream with a pair of events (so that torch ops before / after see the right
+    # data), and two such hops between back-to-back launches cost 25 us of idle GPU each time (rocprofv3 kernel trace of this
+    # file, profiles/r03/bench_launch_gaps.log) -- with nothing of torch's in between to order against.
+    with torch.cuda.stream(stream):
+        run(warmup)
+        env.metrics_reset()  # the line's episode figures (episodes_finished, mean_return, mean_safety) are the timed region's
+        env.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # ---- timed region -----------------------------------------------------------------------------------------------
+        barrier()
+        torch.cuda.synchronize()
+        env.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        run(steps)
+        t_enq = time.perf_counter()
+        ev1.record(stream)
+        gm = global_metrics(env)  # syncs the stream; one int64 all-reduce (RCCL over xGMI) when world > 1
+        t_met = time.perf_counter()
+        env.synchronize()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
     if os.environ.get("SGK_BENCH_TRACE") == "1":  # where the host clock goes (stderr; stdout stays ONE JSON line)
         sys.stderr.write("bench trace: enqueue %.1f us, +metrics %.1f us, +syncs %.1f us, device %.1f us\n" % (
             (t_enq - t0) * 1e6, (t_met - t_enq) * 1e6, (t0 + elapsed - t_met) * 1e6, ev0.elapsed_time(ev1) * 1e3))
