@@ -18,11 +18,12 @@ def ev_time(env, fn, reps=1):
     s = env.torch_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     env.synchronize(); torch.cuda.synchronize()
-    e0.record(s)
-    for _ in range(reps):
-        fn()
-    e1.record(s)
-    env.synchronize(); torch.cuda.synchronize()
+    with torch.cuda.stream(s):  # (no cross-stream event hops between back-to-back library launches)
+        e0.record(s)
+        for _ in range(reps):
+            fn()
+        e1.record(s)
+        env.synchronize(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 1e3 / reps
 
 
