@@ -45,6 +45,23 @@ __global__ __launch_bounds__(256) void ring_writer(char *boards, char *recs, int
   }
 }
 
+// XCD skew: workgroup b runs on XCD b % 8; the even XCDs get `even` tile groups each, the odd ones (1024 - even): does giving the
+// XCDs that write faster more tiles shorten the launch?
+__global__ __launch_bounds__(256) void ring_writer_skew(char *boards, char *recs, int even) {
+  const int x = blockIdx.x & 7, i = blockIdx.x >> 3, odd = 1024 - even;
+  const int quota = (x & 1) ? odd : even;
+  if (i >= quota) return;
+  int off = 0;
+  for (int y = 0; y < x; ++y) off += (y & 1) ? odd : even;
+  const int w = (off + i) * 4 + (threadIdx.x >> 6);
+  uint32_t v = (uint32_t)w;
+  for (int s = 0; s < STEPS; ++s) {
+    put(boards + ((size_t)s * TILES + w) * PIECE, PIECE, v);
+    put(recs + ((size_t)s * TILES + w) * RPIECE, RPIECE, v);
+    v += 7;
+  }
+}
+
 // the ring as NCH separately allocated chunks of STEPS / NCH slices each (boards and records of a chunk in one allocation)
 struct Chunks { char *b[20]; char *r[20]; int per; };
 __global__ __launch_bounds__(256) void ring_writer_chunks(Chunks c) {
@@ -101,6 +118,35 @@ static double us_per_step(char *b, char *r, int mul = 1, size_t pad = 0, int tmu
 
 int main(int argc, char **argv) {
   const size_t bb = (size_t)TILES * STEPS * PIECE, rb = (size_t)TILES * STEPS * RPIECE, slack = (size_t)1 << 30;
+  if (argc > 1 && !strcmp(argv[1], "skew")) {
+    for (int a = 0; a < 3; ++a) {
+      char *b, *r;
+      CK(hipMalloc(&b, bb));
+      CK(hipMalloc(&r, rb));
+      printf("pair %d: uniform %.2f |", a, us_per_step(b, r));
+      for (int even : {512, 480, 544, 560, 576, 592, 608, 640, 704}) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        const int grid = 8 * (even > 512 ? even : 1024 - even);  // every XCD gets enough workgroup ids for the larger quota
+        std::vector<float> ms;
+        for (int rep = 0; rep < 4; ++rep) {
+          CK(hipEventRecord(e0, 0));
+          hipLaunchKernelGGL(ring_writer_skew, dim3(grid), dim3(256), 0, 0, b, r, even);
+          CK(hipEventRecord(e1, 0));
+          CK(hipEventSynchronize(e1));
+          float t;
+          CK(hipEventElapsedTime(&t, e0, e1));
+          if (rep) ms.push_back(t);
+        }
+        std::sort(ms.begin(), ms.end());
+        printf(" even=%d %.2f", even, ms[1] * 1e3 / STEPS);
+      }
+      printf("\n");
+      fflush(stdout);
+    }
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "vmm")) {
     // A contiguous VIRTUAL ring over scattered PHYSICAL memory (HIP virtual memory management): physical chunks of `chunk` bytes
     // created one after another, mapped into the ring's address range in order, in a shuffled order, or with every other created
