@@ -98,6 +98,10 @@ def test_bench_line_one_rank():
     d3 = _line(["--steps", "3", "--warmup", "1", "--total-envs", "8192", "--path", "own", "--no-cpu-baseline", "--no-fused",
                 "--no-secondary"])
     _check_contract(d3, 1, 3, 1)
+    d4 = _line(["--steps", "3", "--warmup", "1", "--total-envs", "8192", "--ring-backing", "torch", "--no-cpu-baseline", "--no-fused",
+                "--no-secondary"])
+    _check_contract(d4, 1, 3, 1)
+    assert d4["ring_allocation"]["backing"].startswith("torch.empty")
 
 
 @pytest.mark.gpu
