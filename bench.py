@@ -417,7 +417,11 @@ def main():
     # same process is in `other_ring_allocations`. --ring-backing torch makes the primary ring a plain block too.
     ring, ring_alloc = None, None
     if args.path == "ring":
-        rb, rr, ring_alloc = env.alloc_trajectory_ring(RING_SLICES, backing=args.ring_backing)
+        try:
+            rb, rr, ring_alloc = env.alloc_trajectory_ring(RING_SLICES, backing=args.ring_backing)
+        except S._lib.SgkError as e:  # (a driver without HIP virtual memory management: say so, measure on a plain block)
+            sys.stderr.write("bench: sgk_ring_alloc failed (%s); the primary ring is a torch.empty block\n" % e)
+            rb, rr, ring_alloc = env.alloc_trajectory_ring(RING_SLICES, backing="torch")
         ring = (rb, rr)
     slice_next = [0]
     elapsed, kernel_ms, gm = timed_steps(env, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path, ring=ring,
