@@ -118,6 +118,28 @@ static double us_per_step(char *b, char *r, int mul = 1, size_t pad = 0, int tmu
 
 int main(int argc, char **argv) {
   const size_t bb = (size_t)TILES * STEPS * PIECE, rb = (size_t)TILES * STEPS * RPIECE, slack = (size_t)1 << 30;
+  if (argc > 1 && !strcmp(argv[1], "flags")) {
+    // other kinds of device memory: fine-grained (coherent) and uncached allocations, next to plain hipMalloc
+    for (int trial = 0; trial < 3; ++trial) {
+      printf("trial %d:", trial);
+      for (int kind = 0; kind < 4; ++kind) {
+        char *b = nullptr, *r = nullptr;
+        hipError_t e1, e2;
+        if (kind == 0) { e1 = hipMalloc(&b, bb); e2 = hipMalloc(&r, rb); }
+        else {
+          const unsigned flag = kind == 1 ? hipDeviceMallocFinegrained : (kind == 2 ? hipDeviceMallocUncached : hipDeviceMallocContiguous);
+          e1 = hipExtMallocWithFlags((void **)&b, bb, flag);
+          e2 = hipExtMallocWithFlags((void **)&r, rb, flag);
+        }
+        const char *name = kind == 0 ? "hipMalloc" : (kind == 1 ? "fine-grained" : (kind == 2 ? "uncached" : "contiguous"));
+        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); printf(" %s (failed)", name); continue; }
+        printf(" %s %.2f", name, us_per_step(b, r));
+        fflush(stdout);
+      }
+      printf("\n");
+    }
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "skew")) {
     for (int a = 0; a < 3; ++a) {
       char *b, *r;
