@@ -788,7 +788,8 @@ int sgk_ring_alloc(int32_t device, size_t bytes, void **dev_ptr) {
     left -= left >= chunk ? chunk : left;
   }
   void *va = nullptr;
-  hipError_t err = hipMemAddressReserve(&va, b.va_bytes, chunk, nullptr, 0);
+  // (the range is aligned to the chunk size where that is a power of two, to 2 MiB otherwise)
+  hipError_t err = hipMemAddressReserve(&va, b.va_bytes, (chunk & (chunk - 1)) ? two_mib : chunk, nullptr, 0);
   if (err != hipSuccess) return hip_fail(err, "hipMemAddressReserve (trajectory ring)");
   size_t mapped = 0, off = 0;
   for (size_t i = 0; i < b.chunk_bytes.size() && err == hipSuccess; ++i) {
