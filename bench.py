@@ -24,10 +24,13 @@ What is timed -- `--path`:
           1's `value` was this with one lockstep step per bench step.
 The default run reports the other two as secondary objects (`rewritten_in_place`, `per_step_launches`) and the outputs-once
 kernel (`fused_rollout`: no per-step output exists), each with its own counter-based traffic figures.
-The ring's rate differs from allocation to allocation of the 3 GB; `other_ring_allocations` times three more
-PLAIN rings (torch.empty) in the same process. The primary ring's memory comes from the library's ring allocator
-(`sgk_ring_alloc`: one virtual range mapped from 256 MiB physical chunks, on the fast level every time -- a recipe, nothing is
-timed or picked; `--ring-backing torch` for a plain block).
+The ring's rate differs from allocation to allocation of the 3 GB, so the primary measurement is made
+`--rings` times (default 3), each on a FRESH ring of the same backing (the library's ring allocator `sgk_ring_alloc`: one virtual
+range mapped from 256 MiB physical chunks; `--ring-backing torch` for plain blocks), earlier rings held while the next is timed:
+`value` is the MEDIAN ring's whole-job rate, `value_min` / `value_max` and `primary_rings` give the spread, and every ring
+is also timed with the library's store-only probe (`sgk_ring_probe`: the kernel's stores and nothing else) so that
+`roofline.kernel_over_probe` says how far the kernel is from what THIS memory can take. `other_ring_allocations` times three
+PLAIN rings (torch.empty) in the same process. Nothing is picked anywhere.
 
 Workload = BASELINE.json's metric config: BoatRace, 1 048 576 concurrent envs in the whole job at every GPU count (the batch
 shards by env id, one contiguous block per rank, no data-path collective; the only exchange is one int64 metrics all-reduce
@@ -144,9 +147,10 @@ def parity_sample(env, env_name, seed, base, total_steps, block=2048):
     return True, checked
 
 
-def ring_parity_sample(env_name, seed, base, ring, first_step, n_slices, block=512):
-    """The trajectory ring's CONTENTS against the oracle: slice (first_step + k) % slices must hold the board and the step record
-    of lockstep step first_step + k for the first `block` envs of the shard (the last `n_slices` steps of the run)."""
+def ring_parity_sample(env_name, seed, base, ring, first_step, n_slices, block=512, ring_start=0):
+    """The trajectory ring's CONTENTS against the oracle: slice (first_step + k - ring_start) % slices must hold the board and the
+    step record of lockstep step first_step + k for the first `block` envs of the shard (the last `n_slices` steps written;
+    `ring_start` = the lockstep step whose outputs went into slice 0 first)."""
     import numpy as np
 
     from oracle import oracle as O
@@ -159,7 +163,7 @@ def ring_parity_sample(env_name, seed, base, ring, first_step, n_slices, block=5
         orc.rollout(first_step, seed=seed, env_begin=base, t_begin=0, auto_reset=True)
     for k in range(n_slices):
         rec = orc.rollout(1, seed=seed, env_begin=base, t_begin=first_step + k, auto_reset=True)
-        sl = (first_step + k) % slices
+        sl = (first_step + k - ring_start) % slices
         if not ((boards[sl, :m].cpu().numpy() == orc.boards()).all() and (recs[sl, :m].cpu().numpy() == np.asarray(rec)).all()):
             return False
     return True
@@ -300,10 +304,11 @@ def path_figures(env_name, layout, n_local, path, lockstep_steps, kernel_ms):
     }
 
 
-def issue_roofline(env_name, n_local, steps, seconds):
+def issue_roofline(env_name, n_local, steps, seconds, peak_now=None):
     """`fused_rollout`'s bound is instruction issue, not memory: instructions per env-step from the committed SQ counter pass
-    (profiles/issue.json, tools/make_issue_json.py) x this run's rate, against the chip's measured issue peaks
-    (tools/exp_issue_peak.hip). None when no counter pass for this env is committed."""
+    (profiles/issue.json, tools/make_issue_json.py: a property of the code) x this run's rate, against the chip's issue peaks
+    MEASURED IN THIS PROCESS (sgk_issue_peak: the peaks move with the clock the box runs at); the committed peaks of another box
+    are kept beside them as `peak_committed`. None when no counter pass for this env is committed."""
     ipath = os.path.join(ROOT, "profiles", "issue.json")
     if not os.path.exists(ipath):
         return None
@@ -314,12 +319,22 @@ def issue_roofline(env_name, n_local, steps, seconds):
         return None
     wave_steps = (n_local / 64.0) * steps / seconds  # wave-level steps per second
     valu, salu = k["valu_per_wave_step"] * wave_steps, k["salu_per_wave_step"] * wave_steps
-    pv, ps = ij["peak"]["valu_wave_instr_per_s"], ij["peak"]["salu_wave_instr_per_s"]
+    cv, cs = ij["peak"]["valu_wave_instr_per_s"], ij["peak"]["salu_wave_instr_per_s"]
+    pv, ps = peak_now if peak_now else (cv, cs)
     bound = "salu-issue" if salu / ps >= valu / pv else "valu-issue"
     return {"bound": bound, "achieved": (salu if bound == "salu-issue" else valu) / 1e9, "peak": (ps if bound == "salu-issue" else pv) / 1e9,
             "unit": "G wave-instructions/s", "frac": max(salu / ps, valu / pv), "valu_frac": valu / pv, "salu_frac": salu / ps,
+            "peak_source": "sgk_issue_peak, this process" if peak_now else "profiles/issue.json (committed)",
+            "peak_in_run": None if not peak_now else {"valu": pv / 1e9, "salu": ps / 1e9},
+            "peak_committed": {"valu": cv / 1e9, "salu": cs / 1e9, "frac": max(salu / cs, valu / cv)},
             "valu_per_wave_step": k["valu_per_wave_step"], "salu_per_wave_step": k["salu_per_wave_step"],
             "lds_per_wave_step": k.get("lds_per_wave_step"), "source": k.get("source")}
+
+
+def median_index(vals):
+    """Index of the median element (the lower one for an even count)."""
+    order = sorted(range(len(vals)), key=lambda i: vals[i])
+    return order[(len(vals) - 1) // 2]
 
 
 def main():
@@ -345,6 +360,8 @@ def main():
     ap.add_argument("--ring-backing", choices=("ring", "torch"), default="ring",
                     help="memory of the PRIMARY trajectory ring: the library's ring allocator (sgk_ring_alloc: HIP virtual memory "
                          "management, 256 MiB physical chunks) or a plain torch.empty block")
+    ap.add_argument("--rings", type=int, default=3,
+                    help="how many fresh primary rings the timed region is repeated on (value = the median ring; path ring only)")
     ap.add_argument("--no-weak-line", action="store_true", help="skip the secondary 1M-envs-per-GPU measurement at N > 1")
     args = ap.parse_args()
 
@@ -398,9 +415,15 @@ def main():
         tdist.all_gather(out, t)
         return [float(x[0]) for x in out]
 
-    def make_ring(n):
-        return (torch.empty((RING_SLICES, n, CELLS[args.env]), dtype=torch.int8, device=dev),
-                torch.empty((RING_SLICES, n, 4), dtype=torch.int8, device=dev))
+    def alloc_ring(e, backing):
+        """A trajectory ring for env `e` from `backing` ("ring": sgk_ring_alloc; "torch": torch.empty) -> ((boards, recs), info);
+        a driver without HIP virtual memory management says so and gets a plain block."""
+        try:
+            rb, rr, info = e.alloc_trajectory_ring(RING_SLICES, backing=backing)
+        except S._lib.SgkError as err:
+            sys.stderr.write("bench: sgk_ring_alloc failed (%s); this ring is a torch.empty block\n" % err)
+            rb, rr, info = e.alloc_trajectory_ring(RING_SLICES, backing="torch")
+        return (rb, rr), info
 
     env = S.BatchedGridworldEnv(args.env, n_local, device=local_rank, seed=args.seed, env_index_base=base,
                                 layout=args.layout)
@@ -411,28 +434,38 @@ def main():
     k_lock, w_lock = args.steps * L, args.warmup * L  # the timed region / the warm-up in lockstep steps
     gpu_leg_ms = 0.0
     # The rate a persistent kernel writes a multi-GB ring at depends on how the ring's physical memory is made up:
-    # hipMalloc blocks measure 4.6-4.9 or 5.6-6.1 us per step, block by block; memory mapped from 256 MiB physical chunks
-    # (sgk_ring_alloc, what BatchedGridworldEnv.alloc_trajectory_ring hands out) 4.5-4.8 every time. The primary ring comes from
-    # the library's allocator -- a deterministic recipe, nothing is timed or picked --; what plain torch.empty rings get in this
-    # same process is in `other_ring_allocations`. --ring-backing torch makes the primary ring a plain block too.
-    ring, ring_alloc = None, None
-    if args.path == "ring":
-        try:
-            rb, rr, ring_alloc = env.alloc_trajectory_ring(RING_SLICES, backing=args.ring_backing)
-        except S._lib.SgkError as e:  # (a driver without HIP virtual memory management: say so, measure on a plain block)
-            sys.stderr.write("bench: sgk_ring_alloc failed (%s); the primary ring is a torch.empty block\n" % e)
-            rb, rr, ring_alloc = env.alloc_trajectory_ring(RING_SLICES, backing="torch")
-        ring = (rb, rr)
+    # the same kernel measures 4.5-6.1 us per step from ring to ring. So the timed region (W warm-up + K timed steps, same bracket)
+    # is repeated on --rings fresh rings of the same backing, the earlier ones held (a freed block would be handed out again);
+    # `value` is the median ring. Each ring is then timed with the store-only probe: the kernel's stores and nothing else.
+    ring, ring_alloc, primary = None, None, []
+    held = []
+    total_steps = 0
     slice_next = [0]
-    elapsed, kernel_ms, gm = timed_steps(env, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path, ring=ring,
-                                         slice_next=slice_next)
-    per_rank_device_us = [x * 1e3 for x in gather_over_ranks(kernel_ms)]
-    elapsed, kernel_ms = max_over_ranks(elapsed, kernel_ms)
-    gpu_leg_ms += kernel_ms
-    total_steps = w_lock + k_lock
-    ring_ok = None
-    if ring is not None:  # the ring really holds the last steps' outputs (checked outside every clock)
-        ring_ok = ring_parity_sample(args.env, args.seed, base, ring, total_steps - min(3, total_steps), min(3, total_steps))
+    n_primary = max(1, args.rings) if args.path == "ring" else 1
+    for r_i in range(n_primary):
+        if args.path == "ring":
+            ring, ring_alloc = alloc_ring(env, args.ring_backing)
+            held.append(ring)
+        slice_next, ring_start = [0], total_steps
+        el, kms, gm_r = timed_steps(env, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path, ring=ring, slice_next=slice_next)
+        per_rank = [x * 1e3 for x in gather_over_ranks(kms)]
+        el, kms = max_over_ranks(el, kms)
+        gpu_leg_ms += kms
+        total_steps += w_lock + k_lock
+        ok_r, probe_us = None, None
+        if ring is not None:  # the ring really holds the last steps' outputs (checked outside every clock) ...
+            ok_r = ring_parity_sample(args.env, args.seed, base, ring, total_steps - min(3, total_steps), min(3, total_steps),
+                                      ring_start=ring_start)
+            try:  # ... and what its memory takes from a kernel that only stores (zeros the ring: after the check)
+                probe_us = max_over_ranks(env.probe_trajectory_ring(ring[0], ring[1]))[0]
+            except S._lib.SgkError:
+                probe_us = None
+        primary.append({"elapsed": el, "kernel_ms": kms, "gm": gm_r, "per_rank_device_us": per_rank, "ring_ok": ok_r,
+                        "probe_us": probe_us, "backing": None if ring_alloc is None else ring_alloc["backing"]})
+    mi = median_index([p["elapsed"] for p in primary])
+    elapsed, kernel_ms, gm = primary[mi]["elapsed"], primary[mi]["kernel_ms"], primary[mi]["gm"]
+    per_rank_device_us = primary[mi]["per_rank_device_us"]
+    ring_ok = None if args.path != "ring" else all(p["ring_ok"] for p in primary)
 
     secondary = {}
     if not args.no_secondary:
@@ -452,7 +485,7 @@ def main():
         for other in ("ring", "own", "launch"):
             if other == args.path:
                 continue
-            r2 = make_ring(n_local) if other == "ring" else None
+            r2 = alloc_ring(env, args.ring_backing)[0] if other == "ring" else None
             o_el, o_ms, _ = timed_steps(env, k2, w2, barrier, sdist.global_metrics, path=other, ring=r2)
             o_el, o_ms = max_over_ranks(o_el, o_ms)
             del r2
@@ -471,24 +504,23 @@ def main():
                 "note": notes[other]}
     ring_spread = None
     if args.path == "ring" and not args.no_secondary:
-        # The ring's write rate differs from ALLOCATION to allocation of the 3 GB (5.3-6.6 us per step over the
-        # round's boxes, the same spread in a kernel that only stores): `value` is whatever the ONE ring above got, so the line
-        # also says what a few more fresh rings get in this very process -- nothing is picked. The earlier rings stay allocated
-        # while the next is timed (a freed block would simply be handed out again).
-        held, spread_us = [ring], []
+        # what PLAIN rings (torch.empty: one hipMalloc block each) get in this very process, next to the primary rings' figures;
+        # the earlier rings stay allocated while the next is timed
+        spread_us = []
         for _ in range(3):
-            r3 = make_ring(n_local)
+            r3, _info = alloc_ring(env, "torch")
             held.append(r3)
             _, s_ms, _ = timed_steps(env, 3 * GRAPH_CHUNK, GRAPH_CHUNK, barrier, sdist.global_metrics, path="ring", ring=r3)
             _, s_ms = max_over_ranks(0.0, s_ms)
             total_steps += 4 * GRAPH_CHUNK
             gpu_leg_ms += s_ms
             spread_us.append(s_ms * 1e3 / (3 * GRAPH_CHUNK))
-        del held, r3
+        del r3
         ring_spread = {"device_us_per_lockstep_step": spread_us, "rings": len(spread_us), "lockstep_steps_each": 3 * GRAPH_CHUNK,
-                       "note": "PLAIN %d-slice rings (torch.empty, no probing) allocated and timed one after another in this process "
-                               "with the same kernel (device clock, max over ranks); the primary measurement's own figure is "
-                               "roofline.device_us_per_step" % RING_SLICES}
+                       "backing": "torch.empty",
+                       "note": "PLAIN %d-slice rings (torch.empty) allocated and timed one after another in this process with the "
+                               "same kernel (device clock, max over ranks); the primary rings' own figures are in primary_rings"
+                               % RING_SLICES}
     fused = None
     if not args.no_fused:
         # same workload through the outputs-once rollout kernel (state in registers, boards materialised once per launch)
@@ -501,11 +533,15 @@ def main():
         f1.record(stream)
         env.synchronize()
         fms = f0.elapsed_time(f1)
+        try:  # the issue ceilings of THIS box at THIS moment, right after the kernel they are held against
+            peak_now = S._lib.issue_peak(local_rank)
+        except S._lib.SgkError:
+            peak_now = None
         total_steps += 100 + fused_steps
         gpu_leg_ms += fms
         fused = {"value": n_total * fused_steps / (fms / 1e3), "unit": "env-steps/s",
                  "ms_per_launch": fms, "steps_per_launch": fused_steps,
-                 "roofline": issue_roofline(args.env, n_local, fused_steps, fms / 1e3),
+                 "roofline": issue_roofline(args.env, n_local, fused_steps, fms / 1e3, peak_now),
                  "note": "sgk_rollout_random: %d lockstep steps in ONE launch, outputs once at the end (no per-step observation "
                          "exists); rank 0's device time" % fused_steps}
     ok, n_checked = parity_sample(env, args.env, args.seed, base, total_steps)
@@ -514,18 +550,19 @@ def main():
     if world > 1 and not weak and not args.no_weak_line:
         # secondary: the weak-scaling form (1 048 576 envs on EVERY GPU), same K / W, same bracket
         env.close()
-        del ring
+        del ring, held
         per = 1 << 20
         wenv = S.BatchedGridworldEnv(args.env, per, device=local_rank, seed=args.seed, env_index_base=rank * per,
                                      layout=args.layout)
-        wring = make_ring(per) if args.path == "ring" else None
+        wring, winfo = alloc_ring(wenv, args.ring_backing) if args.path == "ring" else (None, None)
         w_el, w_ms, _ = timed_steps(wenv, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path, ring=wring)
         w_el, w_ms = max_over_ranks(w_el, w_ms)
         gpu_leg_ms += w_ms
         weak_line = {"value": per * world * k_lock / w_el, "unit": "env-steps/s", "envs_per_gpu": per,
                      "total_envs": per * world, "ms_per_step": w_el * 1e3 / args.steps,
                      "us_per_lockstep_step": w_el * 1e6 / k_lock, "device_us_per_lockstep_step": w_ms * 1e3 / k_lock,
-                     "device_value": per * world * k_lock / (w_ms / 1e3), "scaling": "weak"}
+                     "device_value": per * world * k_lock / (w_ms / 1e3), "scaling": "weak",
+                     "ring_backing": None if winfo is None else winfo["backing"], "rings_timed": 1}
         del wring
         wenv.close()
 
@@ -534,8 +571,15 @@ def main():
         tdist.destroy_process_group()
     if rank != 0:
         return
-    value = n_total * k_lock / elapsed
+    value = n_total * k_lock / elapsed  # the median ring's
     roofline = path_figures(args.env, args.layout, n_local, args.path, k_lock, kernel_ms)
+    if args.path == "ring":
+        # the same ring under a kernel that only stores (sgk_ring_probe: the streamed kernel's store instructions over every slice,
+        # no env work): what THIS allocation takes, measured in this process right after the timed region
+        pr = primary[mi]["probe_us"]
+        roofline["store_only_probe_us_per_step"] = pr
+        roofline["kernel_over_probe"] = None if not pr else roofline["device_us_per_step"] / pr
+        roofline["store_only_probe_frac"] = None if not pr else roofline["algorithmic_bytes_per_env_step"] * n_local / (pr * 1e-6) / 1e9 / HBM_PEAK_GBS
     what = {
         "ring": "streaming rollout kernel (%d steps per launch, env state in registers between steps), auto-reset, every step's "
                 "successor board (write-through tile stores) and step record KEPT in a %d-slice trajectory ring in HBM (%.2f GB per "
@@ -569,6 +613,18 @@ def main():
             "parallelism": "env-sharded x%d, int64 metrics all-reduce" % world,
         },
         "roofline": roofline,
+        # every primary ring of this run (allocation order): host-clock rate, device time per lockstep step, the store-only probe
+        # on the same ring; `value` is the median of these, nothing is picked
+        "value_min": min(n_total * k_lock / p["elapsed"] for p in primary),
+        "value_max": max(n_total * k_lock / p["elapsed"] for p in primary),
+        "value_is": "median of %d fresh primary ring%s" % (len(primary), "" if len(primary) == 1 else "s") if args.path == "ring" else "one measurement",
+        "primary_rings": [{"value": n_total * k_lock / p["elapsed"], "us_per_lockstep_step": p["elapsed"] * 1e6 / k_lock,
+                           "device_us_per_lockstep_step": p["kernel_ms"] * 1e3 / k_lock,
+                           "frac": None if args.path != "ring" else algorithmic_bytes_per_env_step(args.env, args.path) * n_local
+                           / (p["kernel_ms"] * 1e-3 / k_lock) / 1e9 / HBM_PEAK_GBS,
+                           "store_only_probe_us_per_step": p["probe_us"],
+                           "kernel_over_probe": None if not p["probe_us"] else p["kernel_ms"] * 1e3 / k_lock / p["probe_us"],
+                           "backing": p["backing"], "median": i == mi} for i, p in enumerate(primary)],
         # the same throughput from the max-over-ranks HIP-event time of the timed launches (no host latency in it), each rank's
         # device time, and how many ranks the library's RCCL communicator spans (None: one rank, or gloo in the CPU / one-GPU tests)
         "device_value": n_total * k_lock / (kernel_ms / 1e3),

@@ -206,6 +206,13 @@ SGK_API int sgk_ring_free(void *dev_ptr);
  * Either ring may be NULL. Slice-major boards need 16-byte-aligned slices (n_envs * n_cells % 16 == 0). */
 SGK_API int sgk_ring_probe(sgk_env *h, int8_t *boards_ring_dev, sgk_step_rec *recs_ring_dev, int32_t ring_slices, uint32_t flags,
                            double *us_per_slice);
+/* The chip's instruction-issue ceilings, measured NOW on `device`: wave-instructions per second through the vector-ALU port and
+ * through the scalar-ALU port with 8 waves resident per SIMD (register-only loops of independent instructions, best of three
+ * passes, ~30 ms of device time on a stream of its own; synchronising). What the outputs-once rollout (sgk_rollout_random:
+ * RandomAgent.act + env.step fused, reference dummy.py:15-16 / warmup.py:14-21, no per-step output) is held against: its bound
+ * is instruction issue, which moves with the clock the box runs at, so bench.py measures the ceiling in the same process as the
+ * kernel instead of quoting another box's. */
+SGK_API int sgk_issue_peak(int32_t device, double *valu_wave_instr_per_s, double *salu_wave_instr_per_s);
 /* Book n_steps lockstep steps that were issued OUTSIDE the library's sight: a caller that captured sgk_step() into its
  * own hipGraph (e.g. torch.cuda.CUDAGraph around policy + env.step) replays it without re-entering sgk_step, so the
  * host-side lockstep counter and SGK_M_STEPS must be advanced by hand after each replay (n_steps < 0 un-counts the

@@ -102,10 +102,6 @@ struct sgk_env {
   uint8_t *hv_actions = nullptr;     // host-visible action buffer (host_visible mode)
   GraphCache graphs;                  // (n_steps, flags) -> captured step launches
   bool use_graph = true;
-  int partitions = 1;                 // independent env partitions stepped on concurrent graph branches
-  hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t fork_event = nullptr;
-  hipEvent_t join_events[3] = {nullptr, nullptr, nullptr};
 };
 
 struct sgk_tabq {
@@ -121,8 +117,7 @@ struct sgk_tabq {
 
 namespace sgk {
 // step kernel variant that reads the lockstep counter from device memory (graph replays)
-hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st,
-                               int64_t env_off, int64_t count);
+hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st);
 }  // namespace sgk
 
 // Ask the step server to leave and wait until it has: afterwards the handle's arrays in memory are current (state words, metric
@@ -224,11 +219,6 @@ int sgk_destroy(sgk_env *h) {
   (void)hipFree(h->gamma_dev);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->metrics_pinned) (void)hipHostFree(h->metrics_pinned);
-  for (int i = 0; i < 3; ++i) {
-    if (h->side_streams[i]) (void)hipStreamDestroy(h->side_streams[i]);
-    if (h->join_events[i]) (void)hipEventDestroy(h->join_events[i]);
-  }
-  if (h->fork_event) (void)hipEventDestroy(h->fork_event);
   for (int i = 0; i < 2; ++i)
     if (h->order_events[i]) (void)hipEventDestroy(h->order_events[i]);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -268,12 +258,8 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   const int pitched = ((s.n_cells + 15) / 16) * 16;
   s.layout = layout;  // for 16-byte-multiple rows (IslandNavigation) both layouts have pitch == n_cells; they differ in who writes which bytes
   s.pitch = (s.layout == SGK_LAYOUT_COMPACT) ? s.n_cells : pitched;
-  const char *ng = getenv("SGK_NO_GRAPH");
+  const char *ng = getenv("SGK_NO_GRAPH");  // (the environment knobs of this file: the table in include/sgk.h)
   h->use_graph = !(ng && ng[0] == '1');
-  const char *np = getenv("SGK_PARTITIONS");
-  h->partitions = np ? atoi(np) : 1;
-  if (h->partitions < 1) h->partitions = 1;
-  if (h->partitions > 4) h->partitions = 4;
 
 #define SGK_TRY(call)                                   \
   do {                                                  \
@@ -307,10 +293,6 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   }
   // the outputs-once rollout is issue-bound and register-light (64 VGPRs: 8 waves per SIMD fit)
   s.rollout_grid = s.n_cus * 12;  // measured at 1 M envs: 6 / 8 / 12 / 16 per CU = 0.428 / 0.450 / 0.408 / 0.411 us per step (BoatRace)
-  if (const char *rg = getenv("SGK_ROLLOUT_GRID")) {
-    int v = atoi(rg);
-    if (v >= 64) s.rollout_grid = v;
-  }
   SGK_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   const int64_t n_pad = ((s.n + 255) / 256) * 256;
@@ -602,35 +584,10 @@ static int ensure_step_graph(sgk_env *h, int32_t n_steps, uint32_t flags, hipGra
   hipGraphExec_t exec = h->graphs.find(key);
   if (!exec) {
     hipGraph_t graph = nullptr;
-    // partitions: the env batch is cut into P independent ranges (multiples of 256 envs); each range's chain of
-    // n_steps dependent launches is a separate branch of the graph, so one range's launch/ramp/drain latency
-    // overlaps another range's bandwidth phase (the envs are independent: reference train.py:51-54).
-    int P = h->partitions;
-    const int64_t n_tiles = (s.n + 255) / 256;
-    if (n_tiles < 4 * P) P = 1;
-    if (P > 1) {
-      if (!h->fork_event) SGK_HIP(hipEventCreateWithFlags(&h->fork_event, hipEventDisableTiming));
-      for (int i = 0; i < P - 1; ++i) {
-        if (!h->side_streams[i]) SGK_HIP(hipStreamCreateWithFlags(&h->side_streams[i], hipStreamNonBlocking));
-        if (!h->join_events[i]) SGK_HIP(hipEventCreateWithFlags(&h->join_events[i], hipEventDisableTiming));
-      }
-    }
     hipStream_t cap = h->own_stream;  // never the caller's stream: it may be the NULL stream, which cannot be captured
     SGK_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
     hipError_t le = hipSuccess;
-    if (P > 1) {
-      le = hipEventRecord(h->fork_event, cap);
-      for (int i = 0; i < P - 1 && le == hipSuccess; ++i) le = hipStreamWaitEvent(h->side_streams[i], h->fork_event, 0);
-    }
-    for (int p = 0; p < P && le == hipSuccess; ++p) {
-      const int64_t t0 = n_tiles * p / P, t1 = n_tiles * (p + 1) / P;
-      const int64_t off = t0 * 256, cnt = (p == P - 1 ? s.n : t1 * 256) - off;
-      hipStream_t st = (p == 0) ? cap : h->side_streams[p - 1];
-      for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k)
-        le = sgk::launch_step_counter(s, h->t_dev, (uint64_t)k, flags, st, off, cnt);
-      if (p > 0 && le == hipSuccess) le = hipEventRecord(h->join_events[p - 1], st);
-    }
-    for (int i = 0; i < P - 1 && le == hipSuccess; ++i) le = hipStreamWaitEvent(cap, h->join_events[i], 0);
+    for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k) le = sgk::launch_step_counter(s, h->t_dev, (uint64_t)k, flags, cap);
     if (le == hipSuccess) {
       (void)hipGetLastError();
       hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, cap, h->t_dev, (uint64_t)n_steps);
@@ -1388,24 +1345,11 @@ int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel) {
   const bool lds_possible = lds_need != 0 && lds_need <= 160u * 1024u;
   if (kernel == SGK_TABQ_KERNEL_LDS && !lds_possible)
     return fail(SGK_ERR_INVALID, "this env's tables do not fit LDS: the LDS-resident kernel cannot run");
-  if (kernel == SGK_TABQ_KERNEL_AUTO) {  // A/B switches of the tools: one kernel for every env that allows it
-    if (getenv("SGK_TABQ_HBM")) kernel = SGK_TABQ_KERNEL_HBM;
-    else if (getenv("SGK_TABQ_LDS") && lds_possible) kernel = SGK_TABQ_KERNEL_LDS;
-  }
+  // AUTO = the LDS-resident kernel wherever the tables fit: since round 4 (Q image only in LDS, transition table in registers) it is
+  // ahead of the HBM-resident one at every size measured -- IslandNavigation 0.40 / 0.44 / 1.70 / 6.6 us per step at 16 K / 64 K /
+  // 256 K / 1 M agents against 1.24 / 1.38 / 9.65 / 40.6, DistributionalShift 0.40 / 0.91 / 3.54 / 13.8 against 1.22 / 1.42 / 9.44 /
+  // 39.6 (profiles/r04/bench_tabq_sizes_{lds,hbm}.log); the mid-size exception of rounds 1-3 is gone.
   bool use_lds = lds_possible;
-  if (kernel == SGK_TABQ_KERNEL_AUTO && use_lds) {
-    // The LDS-resident kernel runs in rounds of n_cus * per_cu workgroups of 64 agents. With big tables (<= 3 workgroups per
-    // CU) a second round costs a whole ~0.9 us, while the HBM-resident kernel serves every agent in one wave of workgroups
-    // and its rows stay in L2 / MALL as long as all tables together are small: measured ahead by 25-35 % exactly there
-    // (IslandNavigation 65 536 agents 1.30 vs 1.75 us per step, DistributionalShift 49 152 / 65 536: 1.26 / 1.36 vs 1.73 /
-    // 1.79; profiles/r01/bench_tabq.log), behind everywhere else.
-    const int per_cu = (int)((160u * 1024u) / lds_need);
-    const int64_t groups = (s.n + 63) / 64, slots = (int64_t)s.n_cus * per_cu;
-    const int64_t table_bytes = s.n * (int64_t)q->tq.n_states * 4 * (int64_t)sizeof(double);
-    const int64_t fits = per_cu <= 2 ? (270ll << 20) : (140ll << 20);  // two resident waves per CU lose earlier (lava: 1.9-2.7 vs
-                                                                       // 2.6-3.5 us up to 131 072 agents)
-    if (per_cu <= 3 && groups > slots && table_bytes <= fits) use_lds = false;
-  }
   if (kernel == SGK_TABQ_KERNEL_HBM) use_lds = false;
   if (use_lds) {
     SGK_HIP(sgk::launch_tabq_rollout(s, q->tq, n_steps, cheat, h->stream));

@@ -129,19 +129,11 @@ __device__ __forceinline__ void acc_flush(const EpisodeAcc &a, long long *__rest
 // launch. Measured at 1M BoatRace envs: 12.3 -> 10.8 us per step. (For the PITCHED layout -- 16-byte pieces at a 32/48-byte
 // stride -- write-through costs partial-line fabric writes: 25 -> 36 us on IslandNavigation; it keeps plain stores. Dword
 // sc1 stores cost one fabric write each, so the step records keep plain stores too.)
-// SGK_STREAM_STORES=0 builds plain stores (A/B).
 // ------------------------------------------------------------------------------------------------
-#ifndef SGK_STREAM_STORES
-#define SGK_STREAM_STORES 1
-#endif
 typedef uint32_t sgk_u32x4 __attribute__((ext_vector_type(4)));
-// cache policy of the board-tile stores (raw buffer store aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1). Default: sc1.
-#ifndef SGK_BOARD_STORE_AUX
-#define SGK_BOARD_STORE_AUX 16
-#endif
-#ifndef SGK_RING_STORE_AUX
-#define SGK_RING_STORE_AUX 18  // trajectory rings: sc1 | nt
-#endif
+// cache policy of the board-tile stores (raw buffer store aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+constexpr int BOARD_STORE_AUX = 16;  // write-through
+constexpr int RING_STORE_AUX = 18;   // trajectory rings: write-through + non-temporal
 
 // ------------------------------------------------------------------------------------------------
 // observation materialisation
@@ -185,7 +177,7 @@ __device__ __forceinline__ void write_board_pitched(const SgkRules &R, int8_t *_
 // COMPACT: rows of exactly NC bytes, written tile-wise as 16-byte chunks so that each store instruction covers up to 1 KiB of
 // contiguous memory. A chunk is the backdrop rotated to the chunk's phase (tabulated once per workgroup in LDS:
 // rot[r][b] = templ[(r + b) % NC]) with the agent / second-sprite cells of the (at most two, NC >= 16) envs it overlaps poked
-// in (WaveTileWriter below).
+// in (WaveTileLds below).
 template <int NC>
 struct alignas(16) CompactLds {  // rot rows are read with ds_read_b128
   uint8_t rot[NC][16];
@@ -204,12 +196,10 @@ __device__ __forceinline__ void stage_rotations(CompactLds<NC> &C, const SgkRule
 
 // ------------------------------------------------------------------------------------------------
 // WAVE-PRIVATE compact tiles. One wave = 64 consecutive envs = 64 * NC contiguous bytes (a multiple of 16), written as 4 * NC
-// 16-byte chunks, lane l taking chunks l, l + 64, ...: every store instruction still covers up to 1 KiB of contiguous HBM, but
-// a wave assembles its OWN chunks -- the sprite cells of the (at most two) envs a chunk overlaps come from the owning lanes by
-// ds_bpermute (the LDS crossbar, no LDS memory), the backdrop rotated to each chunk's phase sits in registers for the whole
-// kernel -- so there is no workgroup barrier and no LDS traffic per tile (the workgroup-tile writer above needs two barriers
-// and six LDS byte reads per chunk). What a lane contributes is one packed word: agent cell | second sprite cell << 8 | value
-// drawn at the agent's cell << 16 | (board shows templ_alt) << 24 | value drawn at the second sprite's cell << 25 (3 bits).
+// 16-byte chunks, lane l taking chunks l, l + 64, ...: every store instruction covers up to 1 KiB of contiguous HBM and a wave
+// assembles its OWN tile, so there is no workgroup barrier per tile. What a lane contributes is one packed word: agent cell |
+// second sprite cell << 8 | value drawn at the agent's cell << 16 | (board shows templ_alt) << 24 | value drawn at the second
+// sprite's cell << 25 (3 bits).
 // ------------------------------------------------------------------------------------------------
 // (Levels with a mask of two-valued cells -- tomato watering -- put the mask's bits 8..12 where the sprite value goes: the mask
 // is (info >> 8 & 0xff) | (info >> 25 & 0x1f) << 8.)
@@ -224,102 +214,14 @@ __device__ __forceinline__ uint32_t sprite_info(const SgkRules &R, const EnvStat
 __device__ __forceinline__ int info_backdrop(uint32_t info) { return (int)(((info >> 24) & 1u) | (((info >> 30) & 1u) << 1)); }
 __device__ __forceinline__ uint32_t info_mask(uint32_t info) { return ((info >> 8) & 0xffu) | (((info >> 25) & 0x1fu) << 8); }
 
-// byte b (0..15) of the 16-byte chunk w <- v; a b outside the chunk changes nothing
-__device__ __forceinline__ void poke16(uint32_t (&w)[4], int b, uint32_t v) {
-  const bool in = (unsigned)b < 16u;
-  const int k = b >> 2, sh = (b & 3) * 8;
-  const uint32_t keep = ~(0xffu << sh), val = v << sh;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) w[q] = (in && k == q) ? ((w[q] & keep) | val) : w[q];
-}
-
-template <int ENV, int NC>
-struct WaveTileWriter {
-  static_assert(!HasMask<ENV>::value && ENV != SGK_FRIEND_FOE,
-                "levels with a cell mask or a third backdrop are served by the LDS tile image (WaveTileLds) only");
-  static constexpr int CHUNKS = 4 * NC;  // 64 envs * NC bytes / 16
-  static constexpr int ITS = (CHUNKS + 63) / 64;
-  static constexpr bool ALT = HasAltBackdrop<ENV>::value;
-  uint32_t rot[ITS][4];                 // the backdrop rotated to this lane's chunk phases
-  uint32_t rot_alt[ALT ? ITS : 1][4];   // the same for templ_alt
-  int e0[ITS];                          // first env (lane of this wave) chunk `it` overlaps
-  int base0[ITS];                       // chunk-relative byte of cell 0 of env e0 (<= 0); env e0 + 1 starts NC later
-
-  // C: the rotation tables staged in LDS once per workgroup (stage_rotations)
-  __device__ __forceinline__ void init(const CompactLds<NC> &C, const SgkRules &R) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      int j = lane + 64 * it;
-      if (j >= CHUNKS) j = CHUNKS - 1;  // inactive lanes of the last round keep valid indices
-      const int byte0 = 16 * j;
-      e0[it] = byte0 / NC;
-      const int r = byte0 - e0[it] * NC;
-      base0[it] = -r;
-      const uint4 v = *reinterpret_cast<const uint4 *>(&C.rot[r][0]);
-      rot[it][0] = v.x; rot[it][1] = v.y; rot[it][2] = v.z; rot[it][3] = v.w;
-      if (ALT) {
-        const uint4 va = *reinterpret_cast<const uint4 *>(&C.rot_alt[r][0]);
-        rot_alt[it][0] = va.x; rot_alt[it][1] = va.y; rot_alt[it][2] = va.z; rot_alt[it][3] = va.w;
-      }
-    }
-  }
-
-  // Assemble and store this wave's tile. All 64 lanes must call (the exchange is a wave operation). `tile` is wave-uniform and
-  // 16-byte aligned; all 64 * NC bytes are written (callers point it at memory that has them).
-  __device__ __forceinline__ void write(uint32_t info, int8_t *tile) const {
-    const int lane = threadIdx.x & 63;
-#if SGK_STREAM_STORES
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tile, 0, 64 * NC, 0x00020000);
-#endif
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      const int j = lane + 64 * it;
-      const uint32_t i0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * e0[it], (int)info);
-      const uint32_t i1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * min(e0[it] + 1, 63), (int)info);
-      uint32_t w[4];
-      if (ALT) {
-        // the backdrop depends on the env: bytes below `bnd` belong to env e0, the rest to env e0 + 1 (NC >= 16: never a third)
-        const int bnd = NC + base0[it];
-        const bool a0 = (i0 >> 24) & 1u, a1 = (e0[it] + 1 < 64) ? ((i1 >> 24) & 1u) : a0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int nb = bnd - 4 * k;  // bytes of this dword that belong to env e0
-          const uint32_t low = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
-          w[k] = ((a0 ? rot_alt[it][k] : rot[it][k]) & low) | ((a1 ? rot_alt[it][k] : rot[it][k]) & ~low);
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = rot[it][k];
-      }
-      // sprites of env e0, then of env e0 + 1 (the second sprite under the agent; a cell of 255 lands outside every chunk)
-      if (HasSprite2<ENV>::value) poke16(w, base0[it] + (int)((i0 >> 8) & 0xffu), (i0 >> 25) & 7u);
-      poke16(w, base0[it] + (int)(i0 & 0xffu), (i0 >> 16) & 0xffu);
-      if (e0[it] + 1 < 64) {
-        if (HasSprite2<ENV>::value) poke16(w, base0[it] + NC + (int)((i1 >> 8) & 0xffu), (i1 >> 25) & 7u);
-        poke16(w, base0[it] + NC + (int)(i1 & 0xffu), (i1 >> 16) & 0xffu);
-      }
-      if (ITS * 64 == CHUNKS || j < CHUNKS) {
-#if SGK_STREAM_STORES
-        sgk_u32x4 v4 = {w[0], w[1], w[2], w[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, j * 16, 0, SGK_BOARD_STORE_AUX);
-#else
-        reinterpret_cast<uint4 *>(tile)[j] = make_uint4(w[0], w[1], w[2], w[3]);
-#endif
-      }
-    }
-  }
-};
-
 // ------------------------------------------------------------------------------------------------
-// The same wave-private tile kept as an IMAGE IN LDS (64 * NC bytes per wave). A lane owns row `lane` of the image and
+// The wave's tile as an IMAGE IN LDS (64 * NC bytes per wave). A lane owns row `lane` of the image and
 // (re)draws it with byte stores -- backdrop, second sprite, agent on top --; then the wave reads the image back as 16-byte chunks
 // and streams them to HBM (up to 1 KiB of contiguous memory per store instruction, as above). LDS operations of one wave execute
-// in issue order, so no barrier is needed (a compiler-only wave barrier keeps the order in the instruction stream). Against the
-// register / ds_bpermute assembly above this needs no cross-lane exchange and no byte-poking ALU chains: a kernel that keeps
-// the image across steps (the streaming rollout) re-draws only the cells a step changed -- two byte stores per sprite -- which
-// took the streamed BoatRace step from ~110 to ~15 instructions of board work per lane (the bpermute form was VALU-issue-bound:
-// profiles/r02/01_stream_v1_*).
+// in issue order, so no barrier is needed (a compiler-only wave barrier keeps the order in the instruction stream). A kernel that
+// keeps the image across steps (the streaming rollout) re-draws only the cells a step changed -- two byte stores per sprite. (Round
+// 2's register / ds_bpermute assembly of the chunks took ~110 instructions of board work per lane and step against ~15 here and
+// was VALU-issue-bound: profiles/r02/01_stream_v1_*; removed in round 4.)
 // ------------------------------------------------------------------------------------------------
 template <int ENV, int NC>
 struct WaveTileLds {
@@ -421,14 +323,11 @@ struct WaveTileLds {
   // image -> HBM: all 64 * NC bytes, `dst` wave-uniform and 16-byte aligned. AUX = the stores' cache policy: write-through
   // (sc1) for buffers that are rewritten in place; write-through + non-temporal for a trajectory ring, whose bytes nothing
   // on the chip reads again (the pure store probe gains 2.6-3.6 % with it on every box: profiles/r03/write_patterns_*.log)
-  template <int AUX = SGK_BOARD_STORE_AUX>
+  template <int AUX = BOARD_STORE_AUX>
   __device__ __forceinline__ void flush(int8_t *dst) const {
     const int lane = threadIdx.x & 63;
     __builtin_amdgcn_wave_barrier();
-#if SGK_STREAM_STORES
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, BYTES, 0x00020000);
-#endif
-#if SGK_STREAM_STORES
     // All the LDS reads first, then the stores: one LDS round trip per flush, not one per 16-byte chunk. No lane is predicated:
     // a lane past the image's last chunk reads the last chunk again and its store is dropped by the buffer's range check
     // (num_records = BYTES) -- a predicated second chunk made the compiler merge the stores behind a waterfall loop.
@@ -444,13 +343,6 @@ struct WaveTileLds {
       sgk_u32x4 v4 = {v[it].x, v[it].y, v[it].z, v[it].w};
       __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, (lane + 64 * it) * 16, 0, AUX);
     }
-#else
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      const int j = lane + 64 * it;
-      if (ITS * 64 == CHUNKS || j < CHUNKS) reinterpret_cast<uint4 *>(dst)[j] = *reinterpret_cast<const uint4 *>(tile + 16 * j);
-    }
-#endif
     __builtin_amdgcn_wave_barrier();  // the next re-draw comes after these reads in the instruction stream
   }
 

@@ -8,34 +8,15 @@
 
 namespace sgk {
 
-// Which wave-private tile writer the kernels of this file use: the LDS image (default) or the register / ds_bpermute assembly
-// (SGK_TILE_IN_LDS=0; kept for the A/B in profiles/r02). Both produce the same bytes.
-#ifndef SGK_TILE_IN_LDS
-#define SGK_TILE_IN_LDS 1
-#endif
-#ifndef SGK_STREAM_MIN_WAVES
-#define SGK_STREAM_MIN_WAVES 4  // __launch_bounds__ of the streamed rollout (resident waves per SIMD the register budget must allow):
-                                // 6 and 8 spill and lose (profiles/r03/stream_grid_x_occupancy.log)
-#endif
-#ifndef SGK_STREAM_REC_SC1
-#define SGK_STREAM_REC_SC1 0  // the streamed rollout's per-step records: plain stores (A/B: write-through dwords)
-#endif
-#if SGK_TILE_IN_LDS
+// The wave-private tile writer of this file's kernels: the tile image in LDS (WaveTileLds, sgk_device.h)
+constexpr int STREAM_MIN_WAVES = 4;  // __launch_bounds__ of the streamed rollout (resident waves per SIMD the register budget must
+                                     // allow): 6 and 8 spill and lose (profiles/r03/stream_grid_x_occupancy.log)
 #define SGK_TILE_DECLARE(ENV, NC, ON)                                                 \
   __shared__ __attribute__((aligned(16))) uint8_t tile_images[WG / 64][64 * (NC)];    \
   WaveTileLds<ENV, NC> W;                                                             \
   W.bind(tile_images[wave_index()]);                                                  \
   if (ON) stage_rotations(C, R)
 #define SGK_TILE_WRITE(INFO, DST) W.write(C, R, (INFO), (DST))
-#else
-#define SGK_TILE_DECLARE(ENV, NC, ON)  \
-  WaveTileWriter<ENV, NC> W;           \
-  if (ON) {                            \
-    stage_rotations(C, R);             \
-    W.init(C, R);                      \
-  }
-#define SGK_TILE_WRITE(INFO, DST) W.write((INFO), (DST))
-#endif
 
 // slab -> one metrics vector (sums over slots for [0..7], maxima for [8..11]); one workgroup of 1024 lanes:
 // 16 columns x 64 slot-lanes, four independent loads in flight per lane, LDS tree over the slot-lanes
@@ -76,7 +57,7 @@ __global__ __launch_bounds__(WG) void metrics_init_kernel(long long *__restrict_
 
 // ------------------------------------------------------------------------------------------------
 // the lockstep step kernel: env.step(action) for every env of the shard. One lane = one env, one wave = one 64-env tile
-// (grid-stride over tiles); the COMPACT board tile is assembled and stored by the wave itself (WaveTileWriter: no workgroup
+// (grid-stride over tiles); the COMPACT board tile is assembled and stored by the wave itself (WaveTileLds: no workgroup
 // barrier after the rule tables are staged).
 // ------------------------------------------------------------------------------------------------
 template <int ENV, int LAYOUT, bool RANDOM>
@@ -133,11 +114,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
     step_one<ENV>(R, a, env, valid, action, s, rec, acc);
     if (valid) {
       a.state[env] = pack_state(s);
-#if SGK_STREAM_STORES
       __hip_atomic_store(&a.rec[env], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
-#else
-      a.rec[env] = rec;
-#endif
     }
     if (boards_on) {
       if (COMPACT) SGK_TILE_WRITE(sprite_info<ENV>(R, s), a.boards + wt * 64 * NC);  // the buffer is padded to whole tiles
@@ -248,19 +225,9 @@ struct StreamOut {
   int32_t ring_nt;     // board tiles into the ring as non-temporal write-through stores (rings far larger than the caches)
 };
 
-#if SGK_DBG_TIMELINE  // investigation build only (tools/exp_stream_timeline.py): when does each workgroup start, store first, end?
-__device__ unsigned long long sgk_dbg_tl[3 * 16384];
-extern "C" __attribute__((visibility("default"))) int sgk_debug_timeline(unsigned long long *host, int n_words) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sgk_dbg_tl), sizeof(unsigned long long) * (size_t)n_words);
-}
-#endif
-
 template <int ENV, int LAYOUT, bool STREAM>
-__global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout_random_kernel(StepArgs a, int32_t n_steps, StreamOut o) {
+__global__ __launch_bounds__(WG, STREAM ? STREAM_MIN_WAVES : 1) void rollout_random_kernel(StepArgs a, int32_t n_steps, StreamOut o) {
   constexpr int NC = Geom<ENV>::NC;
-#if SGK_DBG_TIMELINE
-  if (STREAM && threadIdx.x == 0 && blockIdx.x < 16384) sgk_dbg_tl[blockIdx.x * 3] = wall_clock64();
-#endif
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
   __shared__ SgkRules R;
   __shared__ CompactLds<NC> C;
@@ -304,11 +271,9 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
     const bool auto_reset = (a.flags & SGK_F_AUTO_RESET) != 0;
     const bool whole_tile = wt * 64 + 64 <= a.n;  // wave-uniform
     int32_t slice = o.slice0;
-#if SGK_TILE_IN_LDS
     // the tile image lives in LDS for all n_steps: drawn once here, then only the cells a step changes are re-drawn
     uint32_t drawn = sprite_info<ENV>(R, s);
     if (STREAM && boards_on) W.draw_all(C, R, drawn);
-#endif
     if (STREAM) {
     // Streamed: at 1 M envs the loop hides behind its stores, but a small batch (65 536 envs = ONE wave per SIMD, the per-GPU
     // share of an 8-GPU run two) is bound by the wave's own instruction latency, so the step carries as little as it can: every
@@ -329,9 +294,6 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
     const int64_t brd_stride = !o.boards ? 0 : (tm ? (int64_t)64 * NC : a.n * (int64_t)NC);  // bytes per slice
     const int64_t rec_wrap = rec_stride * (o.ring - 1), brd_wrap = brd_stride * (o.ring - 1);
     uint32_t left = 0;  // steps left in the action word in hand
-#if SGK_DBG_TIMELINE
-    if (threadIdx.x == 0 && blockIdx.x < 16384) sgk_dbg_tl[blockIdx.x * 3 + 1] = wall_clock64();
-#endif
 #pragma nounroll
     for (int32_t k = 0; k < n_steps; ++k) {
       if (left == 0) {  // a new 16-step word; a new Philox block every 64 steps (and on the launch's first step)
@@ -385,24 +347,16 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
       }
       // this step's outputs, as env.step returns them: the record (reward, hidden reward, done, executed action) ...
       const uint32_t rk = pack_rec(last_obs, last_hid, last_done, last_action);
-#if SGK_STREAM_REC_SC1
-      if (valid) __hip_atomic_store(recs_p, rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
-#else
-      if (valid) *recs_p = rk;
-#endif
+      if (valid) *recs_p = rk;  // (plain stores: write-through dwords cost a fabric write each)
       // ... and the successor board: one tile store per wave wherever the destination takes whole tiles
       if (boards_on) {
-#if SGK_TILE_IN_LDS
         const uint32_t now = sprite_info<ENV>(R, s);
         W.update(R, drawn, now);
         drawn = now;
         if (tiles) {
-          if (flush_nt) W.template flush<SGK_RING_STORE_AUX>(dense + wt * 64 * NC);
+          if (flush_nt) W.template flush<RING_STORE_AUX>(dense + wt * 64 * NC);
           else W.flush(dense + wt * 64 * NC);
         }
-#else
-        if (tiles) W.write(sprite_info<ENV>(R, s), dense + wt * 64 * NC);
-#endif
         else if (o.boards) { if (valid) write_row_bytes<ENV, NC>(R, dense + env * NC, s); }
         else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
       }
@@ -415,10 +369,8 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
         dense += brd_stride;
       }
     }
-#if SGK_TILE_IN_LDS
     // the last step's board also into the env's own buffer: it shows the final state without a re-render launch
     if (boards_on && o.boards && tiles && COMPACT && n_steps > 0) W.flush(a.boards + wt * 64 * NC);
-#endif
     } else {
       // Outputs once: nothing is stored per step, so the loop is bound by instruction ISSUE -- and it was the SCALAR port that
       // was full (profiles/r03/pmc_sq_rollout_boatrace_fused.json: 15.7 SALU + 5.3 branch instructions per wave-step against
@@ -508,9 +460,6 @@ __global__ __launch_bounds__(WG, STREAM ? SGK_STREAM_MIN_WAVES : 1) void rollout
       else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
     }
   }
-#if SGK_DBG_TIMELINE
-  if (STREAM && threadIdx.x == 0 && blockIdx.x < 16384) sgk_dbg_tl[blockIdx.x * 3 + 2] = wall_clock64();
-#endif
   acc_flush(acc, a.metrics);
 }
 
@@ -693,30 +642,14 @@ __global__ __launch_bounds__(WG) void finished_scatter_kernel(const uint32_t *__
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-static Shard shard_view(const Shard &sh, int64_t env_off, int64_t count) {
-  Shard v = sh;
-  v.n = count;
-  v.env_base = sh.env_base + (uint64_t)env_off;
-  v.state = sh.state + env_off;
-  v.rec = sh.rec + env_off;
-  v.boards = sh.boards + env_off * sh.pitch;
-  v.last_return = sh.last_return + env_off;
-  v.last_perf = sh.last_perf + env_off;
-  v.n_episodes = sh.n_episodes + env_off;
-  v.n_resets = sh.n_resets + env_off;
-  if (sh.aux) v.aux = sh.aux + env_off * SGK_AUX_DOUBLES;  // friend or foe: the partition's own estimator rows
-  return v;
-}
-
-hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st,
-                               int64_t env_off, int64_t count) {
+// the step kernel reading the lockstep counter from device memory (hipGraph replays need no new arguments)
+hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st) {
   (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
-  Shard v = shard_view(sh, env_off, count);
-  StepArgs a = make_step_args(v, nullptr, flags);
+  StepArgs a = make_step_args(sh, nullptr, flags);
   a.t = t_off;
   a.t_ptr = t_dev;
-  int grid = grid_for((v.n + WG - 1) / WG, v.max_grid);
-  SGK_DISPATCH_ENV_LAYOUT(v.env_id, v.layout, step_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a));
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a));
   return hipGetLastError();
 }
 
@@ -754,7 +687,6 @@ hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flag
               // non-temporal only where the ring dwarfs the caches. Measured at 1 M BoatRace envs, same box, three repeats: a
               // 100-slice ring (3 GB) 6.32 vs 6.52 us per step with / without, a 32-slice ring (1 GB) 5.34 vs 4.90
               (int32_t)((int64_t)(ring < 1 ? 1 : ring) * sh.n * (sh.n_cells + 4) > (3ll << 29))};
-  if (const char *nt = getenv("SGK_RING_NT")) o.ring_nt = atoi(nt);  // A/B switch of the tools (read per launch)
   // (Lowering the residency to whole rounds -- 16 workgroups per CU at 4 resident instead of 3 rounds of 5 and a last one of 1 --
   // by padding the dynamic LDS was measured on a fast ring: 5.17-5.31 us per step at 2, 3, 4 and 5 per CU alike,
   // profiles/r03/stream_residency_ab.log. Not kept.)
@@ -763,8 +695,8 @@ hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flag
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // the env's own boards show the final state: whole compact tiles were written by the kernel's last step; the other cases
-  // (pitched rows, a partial last tile, unaligned slices, the register tile writer) are re-rendered from the state words
-  const bool in_kernel = SGK_TILE_IN_LDS && sh.layout == SGK_LAYOUT_COMPACT && (o.tile_major || (o.tiles_ok && sh.n % 64 == 0));
+  // (pitched rows, a partial last tile, unaligned slices) are re-rendered from the state words
+  const bool in_kernel = sh.layout == SGK_LAYOUT_COMPACT && (o.tile_major || (o.tiles_ok && sh.n % 64 == 0));
   if (boards_ring && !(flags & SGK_F_NO_BOARDS) && !in_kernel) return launch_reset(sh, nullptr, 2, st);
   return hipSuccess;
 }
@@ -792,8 +724,8 @@ __global__ __launch_bounds__(WG) void ring_probe_kernel(int8_t *boards, uint32_t
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, BYTES, 0x00020000);
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {  // (a lane past the last chunk: dropped by the descriptor's range check)
-          if (nt) __builtin_amdgcn_raw_buffer_store_b128(zero, rsrc, (lane + 64 * it) * 16, 0, SGK_RING_STORE_AUX);
-          else __builtin_amdgcn_raw_buffer_store_b128(zero, rsrc, (lane + 64 * it) * 16, 0, SGK_BOARD_STORE_AUX);
+          if (nt) __builtin_amdgcn_raw_buffer_store_b128(zero, rsrc, (lane + 64 * it) * 16, 0, RING_STORE_AUX);
+          else __builtin_amdgcn_raw_buffer_store_b128(zero, rsrc, (lane + 64 * it) * 16, 0, BOARD_STORE_AUX);
         }
       }
       if (recs) {

@@ -1,5 +1,7 @@
 // sgk_tabq.hip -- TabularQAgent.act / act_explore / learn / update_epsilon (reference value.py:33-58) for N private agents:
 // per-step kernels on HBM-resident float64 tables and the fused learning rollout with the tables resident in LDS.
+#include <algorithm>
+
 #include "sgk_device.h"
 
 namespace sgk {
@@ -223,115 +225,281 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
   }
 }
 
-// Fused learning rollout: one wave = 64 private agents whose whole Q-tables live in LDS for the launch,
-// lane-minor ([state*4+action][lane], 8-byte elements => lanes l and l+32 are served in different LDS
-// passes and every lane hits its own bank pair: conflict-free for arbitrary per-lane states).
-template <int ENV>
-__global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int64_t n_steps) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  SgkRules &R = *reinterpret_cast<SgkRules *>(smem);
-  double *Q = reinterpret_cast<double *>(smem + ((sizeof(SgkRules) + 15) / 16) * 16);
-  stage_rules(R, a.rules);
+// ------------------------------------------------------------------------------------------------
+// Fused learning rollout, tables resident in LDS: one wave = 64 private agents for the whole launch (n_steps of
+// act_explore -> env.step -> learn -> update_epsilon -> reset on done; reference learn.py:61-85 inside train.py:62-70).
+//
+// What bounds it: LDS CAPACITY and the wave's own instruction latency. A CU holds floor(160 KB / image) waves -- under one per
+// SIMD for IslandNavigation -- so nothing hides a wave's stalls and a launch lasts ceil(groups / resident waves) rounds of
+// n_steps x (one wave-step). Hence:
+//  * LDS holds the Q image and NOTHING else: [live slot * 4 + action][64 lanes] float64, lane-minor (every lane on its own bank
+//    pair whatever state it is in). 20 live cells x 2 KB = 40 960 B for IslandNavigation: FOUR waves per CU, one per SIMD (the
+//    image used to carry the rule tables and an all-zero row for terminal cells: 44.8 KB, three per CU, six rounds at 262 144
+//    agents instead of four).
+//  * the transition table lives in REGISTERS, slot-indexed: entry slot * 4 + action sits in lane (i & 63) of T[i >> 6]; a lookup
+//    is a ds_bpermute through the LDS crossbar (no LDS memory, no bank conflicts).
+//  * a terminal successor has no row: its value is 0.0 (rows of terminal cells are never written: defaultdict zeros, value.py:31).
+//  * epsilon is wave-uniform: once per 64 steps every lane evaluates the closed form for ONE of them -- as the integer threshold
+//    the 53-bit draw is compared against: u = m / 2^53 < eps  <=>  m < ceil(eps * 2^53), both scalings exact -- and a step reads
+//    its threshold with two v_readlane. (Evaluating it per step was 26 dependent float64 instructions incl. an IEEE divide.)
+//  * the exploration block (Philox, two steps per block) is computed one pair AHEAD, half of its rounds in each step of the
+//    pair, so that its ~60 integer instructions sit in the shadow of the step's two LDS round trips.
+//  * selects, not branches: the only divergent region of a step is the episode end.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t explore_threshold(double eps0, int64_t anneal, int64_t t) {
+  return (uint64_t)ceil(ldexp(epsilon_at(eps0, anneal, t), 53));
+}
+
+// Philox4x32-10 in two halves of five rounds (the same function as philox4x32_10_v: sgk_transition.h)
+struct PhiloxMid { uint32_t c0, c1, c2, c3; };
+template <int R0>
+__device__ __forceinline__ PhiloxMid philox_rounds5(PhiloxMid s, uint32_t k0, uint32_t k1) {
+  k0 += 0x9E3779B9u * (uint32_t)R0;
+  k1 += 0xBB67AE85u * (uint32_t)R0;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * s.c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * s.c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ s.c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ s.c3 ^ k1;
+    s.c1 = (uint32_t)p1;
+    s.c3 = (uint32_t)p0;
+    s.c0 = n0;
+    s.c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return s;
+}
+
+// a select the compiler keeps a select (two v_cndmask_b32): chains of `?:` on doubles come back as exec-mask branches
+__device__ __forceinline__ double sel64(bool c, double a, double b) {
+  const uint64_t ua = f64_bits(a), ub = f64_bits(b);
+  const uint32_t lo = c ? (uint32_t)ua : (uint32_t)ub, hi = c ? (uint32_t)(ua >> 32) : (uint32_t)(ub >> 32);
+  return bits_f64(((uint64_t)hi << 32) | lo);
+}
+
+// NT = registers of the transition table in use: ceil(live cells * 4 / 64) rounded up to 1, 2 or 4 (the kernel is the same for
+// every level whose state is the agent's cell: nothing else depends on the level)
+// (Tried: 32 agents per wave -- image [.][32], twice the waves per CU, two per SIMD to fill each other's stalls. Slower: 2.41 vs
+// 1.79 us per step at 262 144 IslandNavigation agents, 1.87 vs 1.33 BoatRace, 3.58 vs 3.73 DistributionalShift
+// (profiles/r04/tabq_agents_per_wave_ab.log): the loop is bound by instruction issue, not by exposed latency.)
+template <int NT>
+__global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int32_t n_steps) {
+  extern __shared__ __attribute__((aligned(16))) double Q[];  // [n_live * 4][64]
+  constexpr int AG = 64;
+  const SgkRules *__restrict__ Rg = a.rules;  // wave-uniform fields: scalar loads, once
   const int lane = threadIdx.x;
+  const int n_live = Rg->n_live_slots, max_it = Rg->max_iterations;
   const int S4 = a.n_states * 4;  // HBM row stride: tables are indexed by cell there
-  const int L4 = R.n_live_slots * 4;  // LDS image: one row per non-terminal cell the agent can stand on ...
-  const int Z4 = R.n_slots * 4;       // ... plus, when the level has terminal cells, one shared all-zero row (sgk_rules.cpp)
-  const int64_t n_groups = (a.n + 63) / 64;
+  const double rscale = Rg->reward_scale;
+  const int start_slot = Rg->state_slot[Rg->start_agent];
+  const int start_box = Rg->start_box, start_ext = Rg->start_ext;
+  const bool cheat = a.cheat != 0;
+  // this lane's entries of the slot-indexed transition table and its row -> cell entry
+  uint32_t T0 = 0, T1 = 0, T2 = 0, T3 = 0;
+  {
+    const int n_ent = n_live * 4;
+    auto entry = [&](int i) -> uint32_t { return i < n_ent ? Rg->trans[(int)Rg->slot_cell[i >> 2] * 4 + (i & 3)] : 0u; };
+    T0 = entry(lane);
+    if (NT > 1) T1 = entry(lane + 64);
+    if (NT > 2) T2 = entry(lane + 128);
+    if (NT > 2) T3 = entry(lane + 192);
+  }
+  const int my_cell = Rg->slot_cell[lane];   // lane r < n_live: the cell of row r
+  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+  const int64_t t0 = a.t_agent;
+  const uint32_t par = (uint32_t)t0 & 1u;                   // parity of the launch's first agent step
+  const uint32_t pair0 = (uint32_t)((uint64_t)t0 >> 1);     // its pair (the Philox counter word, mod 2^32)
+  const int64_t n_groups = (a.n + AG - 1) / AG;
   EpisodeAcc acc;
   acc_init(acc);
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const int64_t env0 = g * 64;
+    const int64_t env0 = g * AG;
     const int64_t env = env0 + lane;
     const bool valid = env < a.n;
-    const int n_here = (int)min((int64_t)64, a.n - env0);
-    // load the 64 tables' reachable rows into the lane-minor LDS image
+    // the tables' live rows -> the lane-minor LDS image: lane = agent, one 32-byte row per load pair
     {
-      const double *src = a.table + env0 * S4;
-      const int total = n_here * L4;
-      for (int i = lane; i < total; i += 64) {
-        int e = i / L4, idx = i - e * L4;
-        Q[idx * 64 + e] = src[(int64_t)e * S4 + (int)R.slot_cell[idx >> 2] * 4 + (idx & 3)];
+      const double *src = a.table + (valid ? env : env0) * (int64_t)S4;
+      for (int r = 0; r < n_live; ++r) {
+        const int cell = __builtin_amdgcn_readlane(my_cell, r);
+        const double2 v01 = reinterpret_cast<const double2 *>(src + cell * 4)[0], v23 = reinterpret_cast<const double2 *>(src + cell * 4)[1];
+        Q[(r * 4 + 0) * AG + lane] = v01.x;
+        Q[(r * 4 + 1) * AG + lane] = v01.y;
+        Q[(r * 4 + 2) * AG + lane] = v23.x;
+        Q[(r * 4 + 3) * AG + lane] = v23.y;
       }
-      for (int i = L4 * 64 + lane; i < Z4 * 64; i += 64) Q[i] = 0.0;  // rows of terminal cells are never written: zeros
     }
-    __syncthreads();
-    EnvState s = initial_state(R);
+    EnvState s = initial_state(*Rg);
     if (valid) s = unpack_state(a.state[env]);
-    const uint64_t ge = a.env_base + (uint64_t)env;
-    int si = R.state_slot[s.pos];
-    double q0 = Q[(si * 4 + 0) * 64 + lane], q1 = Q[(si * 4 + 1) * 64 + lane];
-    double q2 = Q[(si * 4 + 2) * 64 + lane], q3 = Q[(si * 4 + 3) * 64 + lane];
-    uint32_t rec = 0;
-    ExploreBlock x = {0, 0, 0, 0};
-    for (int64_t k = 0; k < n_steps; ++k) {
-      const int64_t t = a.t_agent + k;
-      // epsilon(t) heads the step's dependency chain (epsilon -> action -> transition -> rows), and in this kernel a SIMD holds a
-      // single wave (LDS-bound occupancy): nothing hides a memory round trip. Reading the tabulated schedule cost one per step --
-      // 1.2 of 5.1 us at the config-3 shape; removing the load: 3.9 -- and neither fetching it a step ahead nor 64 steps at a time
-      // (one value per lane, v_readlane per step) got that back (5.9 / 5.7 us: profiles/r02/exp_tabq_lds_parts.log). The closed
-      // form -- the very expression the table is built from, an IEEE-correct float64 divide -- is register-only: 4.7 us.
-      const double eps = epsilon_at(a.eps0, a.anneal, t);
-      if (k == 0 || (t & 1) == 0) x = explore_block(a.seed, ge, t);
-      double u;
-      int ea;
-      explore_draw(x, t, u, ea);
-      int action = argmax4(q0, q1, q2, q3);
-      if (u < eps) action = ea;
-      // env.step
-      bool finished = false;
-      int r_obs = 0, r_hid = 0;
-      const bool live = valid && !s.over;
-      const int si_prev = si;
-      if (live) {
-        int term;
-        uint32_t e = transition<ENV>(R, s, action, r_obs, r_hid, term, aux_of<ENV>(a.aux, env));
-        si = (int)(e >> 25);  // successor's slot straight from the transition word (no box in these levels)
-        s.frame += 1;
-        s.ret += r_obs;
-        s.hid += r_hid;
-        finished = term || s.frame >= R.max_iterations;
+    const bool live = valid && !s.over;
+    const uint32_t ge_lo = (uint32_t)(a.env_base + (uint64_t)env), ge_hi = (uint32_t)((a.env_base + (uint64_t)env) >> 32);
+    int si = live ? (int)Rg->state_slot[s.pos] : 0;
+    if (si >= n_live) si = 0;  // (cannot happen for a live env: it stands on a non-terminal cell)
+    int frame = s.frame, ret = s.ret, hid = s.hid;
+    bool reset_seen = false;
+    const double *qrow = Q + lane;
+    double q0 = qrow[(si * 4 + 0) * AG], q1 = qrow[(si * 4 + 1) * AG], q2 = qrow[(si * 4 + 2) * AG], q3 = qrow[(si * 4 + 3) * AG];
+    uint32_t e_last = 0;
+    int action_last = 0;
+    bool fin_last = false;
+
+    // One agent step: draw words (wa, wb), exploration threshold thr. EVERY lane of the wave runs it -- ds_bpermute returns 0 for
+    // a source lane that is masked off, and any lane may hold the table entry another lane needs --; a lane without a live env
+    // (past the batch's end, or its episode is over) walks a phantom agent through its own LDS column: it never finishes an
+    // episode (no global store) and its column is not written back.
+    auto step = [&](uint32_t wa, uint32_t wb, uint64_t thr, auto &&in_the_shadow) {
+      // act_explore (value.py:37-42): argmax with its value; explore iff the 53-bit draw is under epsilon
+      const uint64_t m = ((uint64_t)(wa >> 5) << 26) | (uint64_t)(wb >> 6);
+      const bool explore = m < thr;
+      const int ea = (int)(wa & 3u);
+      const bool c1 = q1 > q0;
+      double bv = sel64(c1, q1, q0);
+      int best = c1 ? 1 : 0;
+      const bool c2 = q2 > bv;
+      bv = sel64(c2, q2, bv);
+      best = c2 ? 2 : best;
+      const bool c3 = q3 > bv;
+      bv = sel64(c3, q3, bv);
+      best = c3 ? 3 : best;
+      const double q_lo = sel64((ea & 1) != 0, q1, q0), q_hi = sel64((ea & 1) != 0, q3, q2);
+      const double q_ea = sel64((ea & 2) != 0, q_hi, q_lo);
+      const int action = explore ? ea : best;
+      const double q_sa = sel64(explore, q_ea, bv);
+      // env.step: the slot-indexed table entry through the crossbar
+      const int idx = si * 4 + action;
+      uint32_t e = (uint32_t)__builtin_amdgcn_ds_bpermute(idx << 2, (int)T0);
+      if (NT > 1) {
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx << 2, (int)T1);
+        e = (idx & 64) ? e1 : e;
       }
-      rec = pack_rec(r_obs, r_hid, (valid && (s.over || finished)) ? 1 : 0, action);
-      // learn (no terminal masking: value.py:48-50 bootstraps from Q[s'] even when the episode ended)
-      double n0 = Q[(si * 4 + 0) * 64 + lane], n1 = Q[(si * 4 + 1) * 64 + lane];
-      double n2 = Q[(si * 4 + 2) * 64 + lane], n3 = Q[(si * 4 + 3) * 64 + lane];
-      if (live) {
-        int an = argmax4(n0, n1, n2, n3);
-        double v_next = pick4(an, n0, n1, n2, n3);
-        double reward = __dmul_rn(a.cheat ? (double)r_hid : (double)r_obs, R.reward_scale);
-        double q_sa = pick4(action, q0, q1, q2, q3);
-        double q_new = q_update(q_sa, reward, v_next, a.lr, a.discount);
-        Q[(si_prev * 4 + action) * 64 + lane] = q_new;
-        if (si == si_prev) {  // refused move: the successor row is the row just updated
-          if (action == 0) n0 = q_new; else if (action == 1) n1 = q_new; else if (action == 2) n2 = q_new; else n3 = q_new;
-        }
+      if (NT > 2) {
+        const uint32_t e2 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx << 2, (int)T2), e3 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx << 2, (int)T3);
+        e = (idx & 128) ? ((idx & 64) ? e3 : e2) : e;
       }
-      acc_add(acc, finished, s.ret, s.hid);
-      if (finished) {  // train.py:62-70: the next episode starts from env.reset()
-        a.last_return[env] = s.ret;
-        a.last_perf[env] = s.hid;
+      const int sn = (int)(e >> 25);
+      const bool term = (e & 0x1000000u) != 0;
+      const int r_obs = (int)(int8_t)(e >> 8), r_hid = (int)(int8_t)(e >> 16);
+      frame += 1;
+      ret += r_obs;
+      hid += r_hid;
+      const bool finished = live && (term || frame >= max_it);
+      // learn (value.py:44-52; no terminal masking: a terminal successor's row is the defaultdict's zeros)
+      const int sr = term ? 0 : sn;  // terminal cells have no row in the image
+      const double n0 = qrow[(sr * 4 + 0) * AG], n1 = qrow[(sr * 4 + 1) * AG], n2 = qrow[(sr * 4 + 2) * AG], n3 = qrow[(sr * 4 + 3) * AG];
+      double vmax = sel64(n1 > n0, n1, n0);
+      vmax = sel64(n2 > vmax, n2, vmax);
+      vmax = sel64(n3 > vmax, n3, vmax);
+      const double v_next = sel64(term, 0.0, vmax);  // the FIRST maximum's value == the maximum's value
+      const double reward = __dmul_rn((double)(cheat ? r_hid : r_obs), rscale);
+      const double q_new = q_update(q_sa, reward, v_next, a.lr, a.discount);
+      Q[(si * 4 + action) * AG + lane] = q_new;
+      e_last = e;
+      action_last = action;
+      fin_last = finished;
+      // The row the NEXT step chooses from, read AFTER the store (LDS operations of a wave run in issue order): the successor's --
+      // which is the row just updated when the move was refused --, or the start cell's when the episode ended (train.py:62-70:
+      // the next episode starts from env.reset()). No patching of registers, no second read in the episode-end branch.
+      si = finished ? start_slot : sr;
+      q0 = qrow[(si * 4 + 0) * AG];
+      q1 = qrow[(si * 4 + 1) * AG];
+      q2 = qrow[(si * 4 + 2) * AG];
+      q3 = qrow[(si * 4 + 3) * AG];
+      in_the_shadow();  // work that does not depend on this step, pinned behind the reads
+      if (finished) {
+        acc_add(acc, true, ret, hid);
+        a.last_return[env] = ret;
+        a.last_perf[env] = hid;
         bump_episode_count(a.n_episodes, env);
-        s = initial_state(R);
-        si = R.state_slot[s.pos];
-        n0 = Q[(si * 4 + 0) * 64 + lane]; n1 = Q[(si * 4 + 1) * 64 + lane];
-        n2 = Q[(si * 4 + 2) * 64 + lane]; n3 = Q[(si * 4 + 3) * 64 + lane];
+        frame = 0;
+        ret = 0;
+        hid = 0;
+        reset_seen = true;
       }
-      q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+    };
+
+    PhiloxMid xn = {0, 0, 0, 0};  // the NEXT pair's block, under way
+    Philox4 x = {0, 0, 0, 0};     // the pair in hand
+    // (the empty asm keeps each half where it is written: its results feed the NEXT iteration only, and the compiler otherwise
+    // sinks all ten rounds behind the pair's second step, where nothing is in flight)
+    auto begin_block = [&](uint32_t pair) {
+      xn = philox_rounds5<0>(PhiloxMid{ge_lo, ge_hi, pair, 1u}, k0, k1);
+      asm volatile("" : "+v"(xn.c0), "+v"(xn.c1), "+v"(xn.c2), "+v"(xn.c3));
+    };
+    auto end_block = [&]() {
+      const PhiloxMid f = philox_rounds5<5>(xn, k0, k1);
+      x = Philox4{f.c0, f.c1, f.c2, f.c3};
+      asm volatile("" : "+v"(x.x0), "+v"(x.x1), "+v"(x.x2), "+v"(x.x3));
+    };
+    auto nothing = [] {};
+    for (int32_t kw = 0; kw < n_steps; kw += 64) {
+      // this window's thresholds, one step per lane
+      const uint64_t thr_l = explore_threshold(a.eps0, a.anneal, t0 + kw + lane);
+      const uint32_t thr_lo = (uint32_t)thr_l, thr_hi = (uint32_t)(thr_l >> 32);
+      const int32_t m = min((int32_t)64, n_steps - kw);
+      auto thr_at = [&](int32_t i) -> uint64_t {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)thr_hi, i) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)thr_lo, i);
+      };
+      int32_t i = 0;
+      if (kw == 0) {  // the launch's first pair
+        begin_block(pair0);
+        end_block();
+      }
+      if (par) {  // an odd first step: the second half of a block that is already in hand (the previous window's tail)
+        const Philox4 cur = x;
+        const uint32_t next_pair = pair0 + ((par + (uint32_t)kw + 1u) >> 1);
+        step(cur.x2, cur.x3, thr_at(0), [&] { begin_block(next_pair); end_block(); });
+        i = 1;
+      }
+      // x = the block of the pair that starts at step i
+      for (; i + 1 < m; i += 2) {
+        const Philox4 cur = x;
+        const uint32_t next_pair = pair0 + ((par + (uint32_t)(kw + i) + 2u) >> 1);  // the pair after this one
+        step(cur.x0, cur.x1, thr_at(i), [&] { begin_block(next_pair); });
+        step(cur.x2, cur.x3, thr_at(i + 1), [&] { end_block(); });
+      }
+      if (i < m) step(x.x0, x.x1, thr_at(i), nothing);  // an even last step; x stays: the next window's odd first step is its other half
     }
-    if (valid) {
+    const int pos_end = __builtin_amdgcn_ds_bpermute(si << 2, my_cell);
+    if (live) {
+      s.pos = pos_end;
+      s.frame = frame;
+      s.ret = ret;
+      s.hid = hid;
+      if (reset_seen) {
+        s.box = start_box;
+        s.mode = 0;
+        s.ext = start_ext;
+      }
       a.state[env] = pack_state(s);
-      a.rec[env] = rec;  // boards are re-materialised by the caller (launch_reset mode 2)
+      const bool fin = fin_last;
+      a.rec[env] = pack_rec((int)(int8_t)(e_last >> 8), (int)(int8_t)(e_last >> 16), fin ? 1 : 0, action_last);
     }
-    __syncthreads();
-    {
-      double *dst = a.table + env0 * S4;
-      const int total = n_here * L4;
-      for (int i = lane; i < total; i += 64) {
-        int e = i / L4, idx = i - e * L4;
-        dst[(int64_t)e * S4 + (int)R.slot_cell[idx >> 2] * 4 + (idx & 3)] = Q[idx * 64 + e];
+    if (__ballot(valid && !live) != 0ull) {
+      // an env whose episode is over takes no step; its record still names the action its agent would have chosen at the last
+      // step (row of the cell it stands on: the table in HBM -- this lane wrote nothing)
+      if (valid && !live && n_steps > 0) {
+        const int64_t t = t0 + n_steps - 1;
+        const double2 r01 = reinterpret_cast<const double2 *>(a.table + env * (int64_t)S4 + s.pos * 4)[0];
+        const double2 r23 = reinterpret_cast<const double2 *>(a.table + env * (int64_t)S4 + s.pos * 4)[1];
+        int action = argmax4(r01.x, r01.y, r23.x, r23.y);
+        const ExploreBlock xb = explore_block(a.seed, a.env_base + (uint64_t)env, t);
+        double u;
+        int ea;
+        explore_draw(xb, t, u, ea);
+        if (u < epsilon_at(a.eps0, a.anneal, t)) action = ea;
+        a.rec[env] = pack_rec(0, 0, 1, action);
       }
     }
-    __syncthreads();
+    // the image back into the tables (a lane reads and writes its own column only: no barrier anywhere)
+    if (live) {
+      double *dst = a.table + env * (int64_t)S4;
+      for (int r = 0; r < n_live; ++r) {
+        const int cell = __builtin_amdgcn_readlane(my_cell, r);
+        reinterpret_cast<double2 *>(dst + cell * 4)[0] = make_double2(Q[(r * 4 + 0) * AG + lane], Q[(r * 4 + 1) * AG + lane]);
+        reinterpret_cast<double2 *>(dst + cell * 4)[1] = make_double2(Q[(r * 4 + 2) * AG + lane], Q[(r * 4 + 3) * AG + lane]);
+      }
+    }
   }
   acc_flush(acc, a.metrics);
 }
@@ -500,10 +668,10 @@ hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t
   return hipGetLastError();
 }
 
-// Sokoban's state is (agent cell, box cell): n_cells^2 rows do not fit LDS -> 0 = "use the per-step kernels"
+// Sokoban's state is (agent cell, box cell): n_cells^2 rows do not fit LDS -> 0 = "use the HBM-resident kernel"
 size_t tabq_rollout_lds_bytes(const Shard &sh) {
   if (sh.n_states != sh.n_cells || sh.env_id == SGK_TOMATO_WATERING) return 0;  // (tomato: hashed tables live in HBM)
-  return ((sizeof(SgkRules) + 15) / 16) * 16 + (size_t)sh.rules_host.n_slots * 4 * 64 * sizeof(double);
+  return (size_t)sh.rules_host.n_live_slots * 4 * 64 * sizeof(double);  // the Q image and nothing else
 }
 
 hipError_t launch_tabq_rollout_hbm(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st) {
@@ -519,21 +687,29 @@ hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_s
   (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   TabqArgs a = make_tabq_args(sh, tq, 0);
   a.cheat = cheat;
-  size_t lds = tabq_rollout_lds_bytes(sh);
+  const size_t lds = tabq_rollout_lds_bytes(sh);
   int64_t n_groups = (sh.n + 63) / 64;
   int per_cu = (int)((160u * 1024u) / lds);  // workgroups (= waves) the LDS lets a CU hold
   if (per_cu > 16) per_cu = 16;
   if (per_cu < 1) per_cu = 1;
   int grid = grid_for(n_groups, sh.n_cus * per_cu);
   hipError_t err = hipSuccess;
-  SGK_DISPATCH_ENV(sh.env_id, {
-    err = hipFuncSetAttribute(reinterpret_cast<const void *>(&tabq_rollout_kernel<E>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (err == hipSuccess)
-      hipLaunchKernelGGL((tabq_rollout_kernel<E>), dim3(grid), dim3(64), lds, st, a, n_steps);
-  });
-  if (err != hipSuccess) return err;
-  return hipGetLastError();
+  // (the kernel counts its steps in 32 bits: a longer request goes out as several launches, which is the same computation)
+  for (int64_t done = 0; done < n_steps && err == hipSuccess;) {
+    const int32_t chunk = (int32_t)std::min<int64_t>(n_steps - done, (int64_t)1 << 30);
+    const int n_ent = sh.rules_host.n_live_slots * 4;
+    auto go = [&](auto kernel) {
+      err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err == hipSuccess) hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, st, a, chunk);
+    };
+    if (n_ent <= 64) go(&tabq_rollout_kernel<1>);
+    else if (n_ent <= 128) go(&tabq_rollout_kernel<2>);
+    else go(&tabq_rollout_kernel<4>);
+    if (err == hipSuccess) err = hipGetLastError();
+    done += chunk;
+    a.t_agent += chunk;
+  }
+  return err;
 }
 
 }  // namespace sgk

@@ -72,6 +72,17 @@ def _check_contract(d, n_gpus, steps, warmup):
     assert abs(r["achieved"] - per_launch / (r["avg_launch_us"] * 1e-6) / 1e9) <= 1e-6 * r["achieved"]
     assert "traffic" in r and (r["traffic"] is None) == (r["traffic_frac"] is None)
     assert d["parity_sample_bit_exact"] is True and d["parity_sample_envs"] > 0
+    # `value` is the median of the primary rings of THIS run; every fraction of the line follows from numbers inside the line
+    pr = d["primary_rings"]
+    assert d["value_min"] <= d["value"] <= d["value_max"] and sum(1 for p in pr if p["median"]) == 1
+    assert len(pr) == (3 if path == "ring" else 1) and [p for p in pr if p["median"]][0]["value"] == d["value"]
+    assert sorted(p["value"] for p in pr)[(len(pr) - 1) // 2] == d["value"]
+    if path == "ring":
+        assert all(p["store_only_probe_us_per_step"] > 0 and p["kernel_over_probe"] > 0 and 0 < p["frac"] for p in pr)
+        assert r["store_only_probe_us_per_step"] > 0
+        assert abs(r["kernel_over_probe"] - r["device_us_per_step"] / r["store_only_probe_us_per_step"]) < 1e-9
+        mp = [p for p in pr if p["median"]][0]
+        assert abs(mp["frac"] - r["frac"]) < 1e-9 and mp["store_only_probe_us_per_step"] == r["store_only_probe_us_per_step"]
 
 
 @pytest.mark.gpu
@@ -86,6 +97,10 @@ def test_bench_line_one_rank():
         assert d[k]["value"] > 0 and d[k]["device_value"] > 0 and d[k]["bound"] == "fabric / infinity-cache write"
         assert {"traffic", "traffic_gbs", "traffic_frac", "frac", "algorithmic_bytes_per_env_step"} <= set(d[k]) and d[k]["frac"] is None
     assert d["fused_rollout"]["value"] > 0 and "roofline" in d["fused_rollout"]
+    fr = d["fused_rollout"]["roofline"]  # issue-bound: the peak is measured in the same process (sgk_issue_peak), the committed one kept beside it
+    assert fr["peak_source"].startswith("sgk_issue_peak") and fr["peak_in_run"]["valu"] > 0 and fr["peak_in_run"]["salu"] > 0
+    assert abs(fr["frac"] - max(fr["valu_frac"], fr["salu_frac"])) < 1e-12 and fr["peak_committed"]["frac"] > 0
+    assert fr["peak"] in (fr["peak_in_run"]["valu"], fr["peak_in_run"]["salu"])
     assert d["ring_allocation"]["backing"].startswith("sgk_ring_alloc") and d["ring_allocation"]["bytes"] == 100 * 8192 * 29
     spread = d["other_ring_allocations"]  # what other fresh rings get in the same process: the allocation lottery, shown
     assert spread["rings"] == 3 and len(spread["device_us_per_lockstep_step"]) == 3 and min(spread["device_us_per_lockstep_step"]) > 0
