@@ -52,7 +52,7 @@ for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
 # SURVEY.md 8(d)'s per-step-launch contract, 2 H W + 28 bytes per env-step (board read + written, action, counters, returns,
 # rewards, done): what ONE LAUNCH PER STEP would have to move. Kept for the `survey_8d` figures of the line.
 B_ALG = {"BoatRace-v0": 78, "SideEffectsSokoban-v0": 100, "IslandNavigation-v0": 124, "DistributionalShift-v0": 154,
-         "WhiskyGold-v0": 124, "AbsentSupervisor-v0": 124, "SafeInterruptibility-v0": 124, "ConveyorBelt-v0": 126, "TomatoWatering-v0": 154, "FriendFoe-v0": 88}
+         "WhiskyGold-v0": 124, "AbsentSupervisor-v0": 124, "SafeInterruptibility-v0": 140, "ConveyorBelt-v0": 126, "TomatoWatering-v0": 154, "FriendFoe-v0": 88}
 CELLS = {k: (v - 28) // 2 for k, v in B_ALG.items()}
 REC_BYTES = 4  # sgk_step_rec: reward i8, hidden reward i8, done u8, executed action u8 (8(d)'s reward / hidden / done, packed)
 STATE_BYTES = 8  # the packed env state word
@@ -366,8 +366,18 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))  # nothing here has initialised the GPU yet
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))  # nothing here has initialised the GPU yet; the child's code is ours
 
+    from safe_grid_agents_amd import dist as sdist
+
+    # One rank's body under fail_fast: an exception on ANY rank is printed and that process leaves at once with a non-zero code --
+    # torch.distributed.run then ends the job, and a rank nobody watches fails in its next collective after the process group's
+    # 120 s timeout instead of parking there until the launcher's limit. No JSON line is printed unless every rank got to the end.
+    code = sdist.fail_fast(lambda: run_rank(args))
+    sys.exit(code or 0)
+
+
+def run_rank(args):
     import torch
 
     import safe_grid_agents_amd as S
@@ -375,8 +385,8 @@ def main():
 
     rank, local_rank, world = sdist.env_from_torchrun()
     if world != args.gpus:
-        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node == --gpus"
-                 % (args.gpus, world))
+        raise RuntimeError("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node == --gpus"
+                           % (args.gpus, world))
     # test-only knobs for exercising the multi-rank control flow on a 1-GPU box: every rank on GPU 0, gloo collectives
     backend = os.environ.get("SGK_BENCH_BACKEND", "nccl")
     if os.environ.get("SGK_BENCH_ONE_DEVICE") == "1":
@@ -566,11 +576,14 @@ def main():
         del wring
         wenv.close()
 
+    # every rank's parity sample counts: MIN over the ranks (also the last collective: every rank got here)
+    mine = bool(ok) and ring_ok is not False
+    ok_all = mine if world == 1 else max_over_ranks(0.0 if mine else 1.0)[0] == 0.0  # (max of "failed" over the ranks)
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()
     if rank != 0:
-        return
+        return 0 if ok_all else 3
     value = n_total * k_lock / elapsed  # the median ring's
     roofline = path_figures(args.env, args.layout, n_local, args.path, k_lock, kernel_ms)
     if args.path == "ring":
@@ -637,7 +650,7 @@ def main():
         "gpu_leg_device_ms": gpu_leg_ms,
         "episodes_finished": gm.episodes,
         "mean_return": gm.meter("returns")["avg"], "mean_safety": gm.meter("safeties")["avg"],
-        "parity_sample_bit_exact": ok and (ring_ok is not False), "parity_sample_envs": n_checked,
+        "parity_sample_bit_exact": ok_all, "parity_sample_envs": n_checked, "parity_sample_ranks": world,
         "ring_slices_checked_bit_exact": ring_ok,
     }
     out.update(secondary)
@@ -655,8 +668,8 @@ def main():
     if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line only
         out["cpu_baseline"] = cpu_baseline(args.env, args.seed)
     print(json.dumps(out))
-    if not out["parity_sample_bit_exact"]:
-        sys.exit(3)
+    sys.stdout.flush()
+    return 0 if out["parity_sample_bit_exact"] else 3
 
 
 if __name__ == "__main__":

@@ -255,6 +255,9 @@ SGK_API int sgk_metrics_reset(sgk_env *h);
  * bytes to the other ranks over any channel (MPI, a file, torch.distributed's store), then every rank creates its end. */
 #define SGK_COMM_ID_BYTES 128
 typedef struct sgk_comm sgk_comm;
+/* Can this process use RCCL? Loads librccl and resolves the entry points (no socket, no thread: ncclGetUniqueId opens a bootstrap
+ * listener per call, so only the rank whose id is used should draw one); *version_out = ncclGetVersion()'s code or 0. */
+SGK_API int sgk_comm_available(int32_t *version_out);
 SGK_API int sgk_comm_unique_id(uint8_t id_out[SGK_COMM_ID_BYTES]);
 SGK_API int sgk_comm_create(const uint8_t id[SGK_COMM_ID_BYTES], int rank, int world_size, int device, sgk_comm **out);
 SGK_API int sgk_comm_destroy(sgk_comm *comm);
@@ -276,11 +279,12 @@ SGK_API int sgk_tabq_create(sgk_env *env, double lr, double discount, double eps
  * sets): every agent's table is then an open-addressing hash table in HBM keyed by the board (agent cell + the watered set the
  * board shows), `hash_capacity` slots per agent (a power of two, 64 .. 2^24; 0 = 4096), a slot claimed by the first lookup of its
  * board and zero until learnt -- the reference's defaultdict (value.py:31-36). 36 bytes per slot and agent. hash_capacity must be 0
- * for every other level. A table that fills up sets a flag (sgk_tabq_hash_info); results are undefined from then on. */
+ * for every other level. A board that finds its agent's table full gets no row: it reads zeros (what a fresh defaultdict row
+ * holds), learns nothing, and raises a flag (sgk_tabq_hash_info) -- re-create the agents with more slots. */
 SGK_API int sgk_tabq_create_ex(sgk_env *env, double lr, double discount, double epsilon, int64_t epsilon_anneal,
                                int32_t hash_capacity, sgk_tabq **out);
-/* capacity (0: perfect-hash level), slots in use in the fullest agent's table, and whether any table overflowed; synchronises and
- * (for max_used) copies the keys to the host: a diagnostic. Any output may be NULL. */
+/* capacity (0: perfect-hash level), slots in use in the fullest agent's table (counted by a kernel: a diagnostic), and whether
+ * any board found its table full. Synchronises. Any output may be NULL; with max_used_out NULL the call is a 4-byte copy. */
 SGK_API int sgk_tabq_hash_info(sgk_tabq *q, int32_t *capacity_out, int32_t *max_used_out, int32_t *overflowed_out);
 /* hashed levels: uint32 [env_count][hash_capacity], the board each slot holds (0xffffffff = empty; tomato watering: agent cell |
  * shown watered set << 8, 0x2000 = the bucket's delusion board), row-aligned with sgk_tabq_copy_table's [env][slot][action] */

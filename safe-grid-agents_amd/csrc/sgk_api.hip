@@ -503,19 +503,46 @@ int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_s
     __sync_synchronize();  // the other envs' actions before the request word
     mb->request = (uint64_t)seq | ((uint64_t)(flags & 0xffu) << 32) | ((uint64_t)(actions_host[0] & 3u) << 40);
     h->server_seq = seq;
+    // Wait for the answer. The loop watches the mailbox, and every 2^20 spins (~a millisecond) it also asks the STREAM: a server
+    // kernel that died, or never started, leaves the stream idle (or in error) with no answer and no exit word -- the caller then
+    // gets an error instead of spinning for minutes. On every failure the request is taken back (the host counters have not moved)
+    // and the server is marked gone, so the next call starts from the arrays in memory.
     uint64_t spins = 0;
+    int failed = 0;
     while (mb->done != seq) {
       if (mb->exited != 0) {
         // the server left (idle) without having seen this request: start another one that has served up to seq - 1
-        SGK_HIP(hipStreamSynchronize(h->stream));
+        hipError_t e = hipStreamSynchronize(h->stream);
         mb->exited = 0;
         __sync_synchronize();
-        SGK_HIP(sgk::launch_env_server(s, h->hv_actions, mb, prev, h->stream));
+        if (e == hipSuccess) e = sgk::launch_env_server(s, h->hv_actions, mb, prev, h->stream);
+        if (e != hipSuccess) {
+          failed = hip_fail(e, "restarting the step server");
+          break;
+        }
       }
-      if (++spins > (1ull << 33)) return fail(SGK_ERR_HIP, "the step server did not answer");
+      if ((++spins & ((1ull << 20) - 1)) == 0) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q != hipErrorNotReady && mb->done != seq && mb->exited == 0) {  // nothing is running and nothing was answered
+          failed = q == hipSuccess ? fail(SGK_ERR_HIP, "the step server is gone (its stream is idle) without an answer")
+                                   : hip_fail(q, "the step server's stream");
+          break;
+        }
+        if (spins > (1ull << 33)) {
+          failed = fail(SGK_ERR_HIP, "the step server did not answer");
+          break;
+        }
+      }
 #if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
 #endif
+    }
+    if (failed) {
+      const std::string keep = g_last_error;
+      h->server_seq = prev;  // the step was not taken: lockstep_t / steps_issued are untouched, so is the request number
+      (void)stop_server(h);  // asks a server that may still be there to leave, waits for the stream, clears the mailbox
+      g_last_error = keep;
+      return failed;
     }
     __sync_synchronize();
     s.lockstep_t += 1;
@@ -708,6 +735,17 @@ struct RingBlock {
 std::mutex g_ring_mutex;
 std::map<void *, RingBlock> g_rings;
 
+// The ring entry points take no handle and run at arbitrary points of the caller's program (sgk_ring_free: from destructors);
+// whatever device they work on, the thread's current device is what it was when they return.
+struct DeviceGuard {
+  int before = -1;
+  DeviceGuard() { (void)hipGetDevice(&before); }
+  ~DeviceGuard() {
+    if (before >= 0) (void)hipSetDevice(before);
+    (void)hipGetLastError();
+  }
+};
+
 void release_ring(void *va, RingBlock &b, size_t mapped_chunks) {
   size_t off = 0;
   for (size_t i = 0; i < b.chunks.size(); ++i) {
@@ -724,29 +762,29 @@ int sgk_ring_alloc(int32_t device, size_t bytes, void **dev_ptr) {
   if (!dev_ptr) return fail(SGK_ERR_INVALID, "dev_ptr is NULL");
   *dev_ptr = nullptr;
   if (bytes == 0) return fail(SGK_ERR_INVALID, "bytes == 0");
+  DeviceGuard keep_current_device;
   SGK_HIP(hipSetDevice(device));
-  size_t chunk = (size_t)256 << 20;
-  if (const char *e = getenv("SGK_RING_CHUNK_MIB")) {
-    const long v = atol(e);
-    if (v >= 2 && v <= 512) chunk = (size_t)v << 20;
-  }
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
   prop.location.id = device;
-  const size_t two_mib = (size_t)2 << 20;
+  // 256 MiB physical chunks (profiles/r03/ring_alloc_vmm*.log: 2 MiB / 32 MiB / 256-512 MiB / 1 GiB chunks measure 5.25 / 5.05 /
+  // 4.52-4.78 / 5.34-5.53 us per step), every size a multiple of what the driver maps in (its recommended granularity)
+  size_t gran = 0;
+  SGK_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+  if (gran < ((size_t)2 << 20) || (gran & (gran - 1))) gran = (size_t)2 << 20;  // never below 2 MiB (a power of two: a multiple of the driver's)
+  const size_t chunk = (((size_t)256 << 20) + gran - 1) / gran * gran;
   RingBlock b;
   b.device = device;
-  // whole chunks, and a last one rounded up to 2 MiB (a ring smaller than a chunk is one allocation of its own size)
+  // whole chunks, and a last one rounded up to the granularity (a ring smaller than a chunk is one allocation of its own size)
   for (size_t left = bytes; left > 0;) {
-    const size_t take = left >= chunk ? chunk : (left + two_mib - 1) / two_mib * two_mib;
+    const size_t take = left >= chunk ? chunk : (left + gran - 1) / gran * gran;
     b.chunk_bytes.push_back(take);
     b.va_bytes += take;
     left -= left >= chunk ? chunk : left;
   }
   void *va = nullptr;
-  // (the range is aligned to the chunk size where that is a power of two, to 2 MiB otherwise)
-  hipError_t err = hipMemAddressReserve(&va, b.va_bytes, (chunk & (chunk - 1)) ? two_mib : chunk, nullptr, 0);
+  hipError_t err = hipMemAddressReserve(&va, b.va_bytes, (chunk & (chunk - 1)) ? gran : chunk, nullptr, 0);  // aligned to the chunk size
   if (err != hipSuccess) return hip_fail(err, "hipMemAddressReserve (trajectory ring)");
   size_t mapped = 0, off = 0;
   for (size_t i = 0; i < b.chunk_bytes.size() && err == hipSuccess; ++i) {
@@ -784,6 +822,7 @@ int sgk_ring_free(void *dev_ptr) {
     b = std::move(it->second);
     g_rings.erase(it);
   }
+  DeviceGuard keep_current_device;
   SGK_HIP(hipSetDevice(b.device));
   (void)hipDeviceSynchronize();  // nothing may still be writing into it
   release_ring(dev_ptr, b, b.chunks.size());
@@ -1188,12 +1227,12 @@ int sgk_tabq_create_ex(sgk_env *env, double lr, double discount, double epsilon,
   if (e == hipSuccess) e = hipMalloc(&q->actions, n);
   if (e == hipSuccess) e = hipMalloc(&q->t_dev, sizeof(long long));
   if (e == hipSuccess) e = hipMalloc(&q->tq.row_cache, sizeof(double) * 4 * n);
-  if (e == hipSuccess) e = hipMalloc(&q->tq.hash_overflow, sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&q->tq.hash_overflow, 2 * sizeof(int32_t));
   if (e == hipSuccess && hashed) e = hipMalloc(&q->tq.keys, sizeof(uint32_t) * n * (size_t)hash_capacity);
 
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.table, 0, tbytes, env->stream);  // defaultdict(zeros) (value.py:31)
   if (e == hipSuccess) e = hipMemsetAsync(q->tq.tags, 0xff, sizeof(uint64_t) * n, env->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(q->tq.hash_overflow, 0, sizeof(int32_t), env->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(q->tq.hash_overflow, 0, 2 * sizeof(int32_t), env->stream);
   if (e == hipSuccess && hashed) e = hipMemsetAsync(q->tq.keys, 0xff, sizeof(uint32_t) * n * (size_t)hash_capacity, env->stream);
   if (e != hipSuccess) {
     int rc = hip_fail(e, "tabular-Q allocation");
@@ -1220,15 +1259,12 @@ int sgk_tabq_hash_info(sgk_tabq *q, int32_t *capacity_out, int32_t *max_used_out
   if (overflowed_out) *overflowed_out = ov;
   if (max_used_out) {
     *max_used_out = 0;
-    if (q->tq.hash_cap) {  // the fullest agent's slot count (a host pass over the keys: a diagnostic, not a hot path)
-      const size_t n = (size_t)q->env->sh.n, cap = (size_t)q->tq.hash_cap;
-      std::vector<uint32_t> keys(n * cap);
-      SGK_HIP(hipMemcpy(keys.data(), q->tq.keys, sizeof(uint32_t) * n * cap, hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < n; ++i) {
-        int32_t used = 0;
-        for (size_t k = 0; k < cap; ++k) used += keys[i * cap + k] != 0xffffffffu;
-        if (used > *max_used_out) *max_used_out = used;
-      }
+    if (q->tq.hash_cap) {  // the fullest agent's slot count, counted on the device (a diagnostic, not a hot path)
+      int32_t *scratch = q->tq.hash_overflow + 1;
+      SGK_HIP(hipMemsetAsync(scratch, 0, sizeof(int32_t), q->env->stream));
+      SGK_HIP(sgk::launch_tabq_hash_used(q->env->sh, q->tq, scratch, q->env->stream));
+      SGK_HIP(hipMemcpyAsync(max_used_out, scratch, sizeof(int32_t), hipMemcpyDeviceToHost, q->env->stream));
+      SGK_HIP(hipStreamSynchronize(q->env->stream));
     }
   }
   return SGK_OK;

@@ -32,6 +32,7 @@ struct Rccl {
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;     // optional: what RCCL itself says the communicator spans
   ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;  // optional
+  ncclResult_t (*GetVersion)(int *) = nullptr;                      // optional
   std::string error;
 };
 
@@ -65,6 +66,7 @@ Rccl &rccl() {
 #undef SGK_SYM
   *reinterpret_cast<void **>(&r.CommCount) = dlsym(r.dl, "ncclCommCount");
   *reinterpret_cast<void **>(&r.CommUserRank) = dlsym(r.dl, "ncclCommUserRank");
+  *reinterpret_cast<void **>(&r.GetVersion) = dlsym(r.dl, "ncclGetVersion");
   return r;
 }
 
@@ -85,6 +87,15 @@ static int rccl_fail(const char *what, ncclResult_t e) {
   Rccl &r = rccl();
   std::string m = std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(e) : "RCCL error");
   return sgk_set_error(SGK_ERR_HIP, m.c_str());
+}
+
+int sgk_comm_available(int32_t *version_out) {
+  Rccl &r = rccl();  // dlopen + dlsym of every entry point the path needs: no socket, no thread, nothing to clean up
+  if (!r.error.empty()) return sgk_set_error(SGK_ERR_NODEVICE, r.error.c_str());
+  int v = 0;
+  if (r.GetVersion && r.GetVersion(&v) != NCCL_SUCCESS) v = 0;
+  if (version_out) *version_out = v;
+  return SGK_OK;
 }
 
 int sgk_comm_unique_id(uint8_t id_out[SGK_COMM_ID_BYTES]) {

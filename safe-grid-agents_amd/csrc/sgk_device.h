@@ -396,7 +396,7 @@ struct Geom<SGK_WHISKY_GOLD> { static constexpr int NC = 48, PITCH = 48; };
 template <>
 struct Geom<SGK_ABSENT_SUPERVISOR> { static constexpr int NC = 48, PITCH = 48; };
 template <>
-struct Geom<SGK_SAFE_INTERRUPTIBILITY> { static constexpr int NC = 48, PITCH = 48; };
+struct Geom<SGK_SAFE_INTERRUPTIBILITY> { static constexpr int NC = 56, PITCH = 64; };
 template <>
 struct Geom<SGK_CONVEYOR_BELT> { static constexpr int NC = 49, PITCH = 64; };
 template <>

@@ -41,11 +41,12 @@ struct TabqShard {
                                 //     high word: state index of the row in row_cache (0xffffffff = none)
   double *row_cache = nullptr;  // [n][4] the Q row of the state named by the tag: what the per-step kernels hand each other
   // Levels whose boards have no perfect hash (tomato watering: 63 cells x 2^13 watered sets): every agent's table is an
-  // open-addressing hash table of `hash_cap` slots (a power of two <= 32768), keys[n][hash_cap] (0xffffffff = empty) beside the
+  // open-addressing hash table of `hash_cap` slots (a power of two, 64 .. 2^24), keys[n][hash_cap] (0xffffffff = empty) beside the
   // rows table[n][hash_cap][4]; a slot is claimed the first time a board is looked up -- the defaultdict of value.py:31-36.
   uint32_t *keys = nullptr;
   int32_t hash_cap = 0;          // 0: perfect-hash level
-  int32_t *hash_overflow = nullptr;  // [1] set when some agent's table was full (results are then undefined: re-create larger)
+  int32_t *hash_overflow = nullptr;  // [2]: [0] set when some agent's table was full and a board found no row (it then reads zeros
+                                     // and learns nothing: re-create larger); [1] scratch of sgk_tabq_hash_info's slot count
   int32_t n_states = 0;          // rows per agent: the level's n_states, or hash_cap
   double lr = 0, discount = 0, eps0 = 0;
   int64_t anneal = 0;
@@ -140,6 +141,7 @@ hipError_t launch_dense_boards(const Shard &sh, int8_t *dst, hipStream_t st);
 hipError_t launch_finished(const Shard &sh, int32_t *ids, int32_t *ret, int32_t *perf, hipStream_t st);
 hipError_t launch_tabq_act(const Shard &sh, const TabqShard &tq, int explore, uint8_t *actions_out, hipStream_t st);
 hipError_t launch_tabq_forget_rows(const Shard &sh, const TabqShard &tq, hipStream_t st);
+hipError_t launch_tabq_hash_used(const Shard &sh, const TabqShard &tq, int32_t *max_used_dev, hipStream_t st);
 hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t *actions, int cheat, hipStream_t st);
 hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st);
 hipError_t launch_tabq_rollout_hbm(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st);

@@ -118,8 +118,11 @@ __device__ __forceinline__ int hash_slot(uint32_t *__restrict__ keys, int cap, u
     }
     i = (i + 1) & (cap - 1);
   }
-  *overflow = 1;  // table full: the caller reads the flag (sgk_tabq_hash_info) and re-creates the agents with more slots
-  return 0;
+  // Table full and the board is not in it: the flag is raised (sgk_tabq_hash_info; the trainer reads it at every period's sync
+  // point and stops) and the lookup answers "no row" (-1): the callers read zeros for it -- what a fresh defaultdict row holds --
+  // and skip the update, so no other board's row is touched.
+  *overflow = 1;
+  return -1;
 }
 
 template <int ENV>
@@ -164,8 +167,8 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
   for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
     EnvState s = unpack_state(a.state[env]);
     const int si = state_index<ENV>(R, s, a, env);
-    double q0, q1, q2, q3;
-    load_row(a, env, a.tags[env], si, q0, q1, q2, q3);
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    if (si >= 0) load_row(a, env, a.tags[env], si, q0, q1, q2, q3);  // (si < 0: a full hash table has no row for this board)
     int action = argmax4(q0, q1, q2, q3);
     if (explore) {
       uint64_t ge = a.env_base + (uint64_t)env;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
       if (u < eps) action = ea;
     }
     actions_out[env] = (uint8_t)action;
-    a.tags[env] = (uint64_t)(s.over ? 0xffffffffu : (uint32_t)si) | ((uint64_t)(uint32_t)si << 32);
+    a.tags[env] = (uint64_t)((s.over || si < 0) ? 0xffffffffu : (uint32_t)si) | ((uint64_t)(uint32_t)si << 32);  // si = -1: "no row kept"
     keep_row(a, env, q0, q1, q2, q3);  // learn() reads Q[s][.] from here
   }
 }
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
     double p0, p1, p2, p3, n0, n1, n2, n3;
     load_row(a, env, tag, sp, p0, p1, p2, p3);  // the row act() chose from (its slot, unless something intervened)
     if (sn == sp) { n0 = p0; n1 = p1; n2 = p2; n3 = p3; }
+    else if (sn < 0) { n0 = n1 = n2 = n3 = 0.0; }  // no row for the successor's board (full hash table): a fresh row's zeros
     else {
       const double2 *rown = reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + sn) * 4);
       // (this scattered 32-byte read costs a whole 128-byte line: the fabric's read requests are ALL 128 bytes here --
@@ -527,9 +531,17 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
     AuxRegs ax;  // the env's float64 side state, in registers for the whole launch (friend or foe; dead code elsewhere)
     ax.init();
     if (HasAux<ENV>::value && valid) ax.load(a.aux + env * SGK_AUX_DOUBLES);
+    // (a row index of -1 = "a full hash table has no row for this board": it reads as zeros and is never written)
+    auto read_row = [&](int row, double &r0, double &r1, double &r2, double &r3) {
+      r0 = r1 = r2 = r3 = 0.0;
+      if (row >= 0) {
+        const double2 a01 = reinterpret_cast<const double2 *>(tab + row * 4)[0], a23 = reinterpret_cast<const double2 *>(tab + row * 4)[1];
+        r0 = a01.x; r1 = a01.y; r2 = a23.x; r3 = a23.y;
+      }
+    };
     int si = valid ? state_index<ENV>(R, s, a, env) : 0;
-    double2 r01 = reinterpret_cast<const double2 *>(tab + si * 4)[0], r23 = reinterpret_cast<const double2 *>(tab + si * 4)[1];
-    double q0 = r01.x, q1 = r01.y, q2 = r23.x, q3 = r23.y;
+    double q0, q1, q2, q3;
+    read_row(si, q0, q1, q2, q3);
     uint32_t rec = 0;
     ExploreBlock x = {0, 0, 0, 0};
     for (int64_t k = 0; k < n_steps; ++k) {
@@ -560,12 +572,8 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
       rec = pack_rec(r_obs, r_hid, (valid && (s.over || finished)) ? 1 : 0, executed);
       if (a.cheat) action = executed;  // learn.py:73-79
       double n0 = q0, n1 = q1, n2 = q2, n3 = q3;
-      if (live && si != si_prev) {
-        const double2 *rown = reinterpret_cast<const double2 *>(tab + si * 4);
-        const double2 a01 = rown[0], a23 = rown[1];
-        n0 = a01.x; n1 = a01.y; n2 = a23.x; n3 = a23.y;
-      }
-      if (live && action < SGK_ACTIONS) {  // an executed "stay" (action 4 under --cheat, a non-default reading) has no Q column
+      if (live && si != si_prev) read_row(si, n0, n1, n2, n3);
+      if (live && action < SGK_ACTIONS && si_prev >= 0) {  // an executed "stay" (action 4 under --cheat, a non-default reading) has no Q column
         const int an = argmax4(n0, n1, n2, n3);
         const double v_next = pick4(an, n0, n1, n2, n3);
         const double reward = __dmul_rn(a.cheat ? (double)r_hid : (double)r_obs, R.reward_scale);
@@ -587,9 +595,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
         if (HasAux<ENV>::value) begin_episode_with<ENV>(R, s, a.seed, ge, ax);
         else begin_episode<ENV>(R, s, a.seed, ge);
         si = state_index<ENV>(R, s, a, env);
-        const double2 *row0 = reinterpret_cast<const double2 *>(tab + si * 4);
-        const double2 a01 = row0[0], a23 = row0[1];  // after this step's store: the start row may be the row just updated
-        n0 = a01.x; n1 = a01.y; n2 = a23.x; n3 = a23.y;
+        read_row(si, n0, n1, n2, n3);  // after this step's store: the start row may be the row just updated
       }
       q0 = n0; q1 = n1; q2 = n2; q3 = n3;
     }
@@ -601,6 +607,22 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
     }
   }
   acc_flush(acc, a.metrics);
+}
+
+// hashed levels: slots in use in the fullest agent's table (one lane per agent; a diagnostic, not a hot path)
+__global__ __launch_bounds__(WG) void tabq_hash_used_kernel(const uint32_t *__restrict__ keys, int64_t n, int cap, int32_t *__restrict__ max_used) {
+  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < n; env += (int64_t)gridDim.x * WG) {
+    int used = 0;
+    for (int k = 0; k < cap; ++k) used += keys[env * cap + k] != 0xffffffffu;
+    atomicMax(max_used, used);
+  }
+}
+
+hipError_t launch_tabq_hash_used(const Shard &sh, const TabqShard &tq, int32_t *max_used_dev, hipStream_t st) {
+  (void)hipGetLastError();
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  tabq_hash_used_kernel<<<dim3(grid), dim3(WG), 0, st>>>(tq.keys, sh.n, tq.hash_cap, max_used_dev);
+  return hipGetLastError();
 }
 
 // "no row kept" for every env (the high half of the tag); the pending-action half stays: an act() made before the table was

@@ -144,6 +144,7 @@ _SIGNATURES = {
     "sgk_copy_last_episode": (ctypes.c_int, [_V, _V, _V, _V]),
     "sgk_metrics": (ctypes.c_int, [_V, _V]),
     "sgk_metrics_reset": (ctypes.c_int, [_V]),
+    "sgk_comm_available": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int32)]),
     "sgk_comm_unique_id": (ctypes.c_int, [_V]),
     "sgk_comm_create": (ctypes.c_int, [_V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_V)]),
     "sgk_comm_destroy": (ctypes.c_int, [_V]),

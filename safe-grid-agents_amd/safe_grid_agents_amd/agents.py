@@ -352,6 +352,14 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         _lib.check(self.lib.sgk_tabq_hash_info(self._h, ctypes.byref(c), ctypes.byref(u), ctypes.byref(o)))
         return c.value, u.value, bool(o.value)
 
+    def check_hash_overflow(self):
+        """The cheap form of check_hash_tables (a 4-byte copy, no slot count): raise when some board found its agent's table full.
+        The batched trainer calls it at every period's synchronisation point."""
+        c, o = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self.lib.sgk_tabq_hash_info(self._h, ctypes.byref(c), None, ctypes.byref(o)))
+        if o.value:
+            self.check_hash_tables()
+
 
 from .ppo import PPOCNNAgent, PPOMLPAgent  # noqa: E402  (ppo.py needs the mixins defined above)
 

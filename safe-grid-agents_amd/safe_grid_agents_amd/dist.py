@@ -28,8 +28,12 @@ def env_from_torchrun():
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
 
 
-def init_process_group(backend=None):
-    """One process per GPU. backend 'nccl' IS RCCL on ROCm; 'gloo' for the CPU tests."""
+def init_process_group(backend=None, timeout_s=None):
+    """One process per GPU. backend 'nccl' IS RCCL on ROCm; 'gloo' for the CPU tests. Collectives time out after `timeout_s`
+    seconds (default 120, SGK_DIST_TIMEOUT_S overrides): the path's only exchange is a 96-byte all-reduce, so a rank that waits
+    longer than that is waiting for a rank that died -- it fails instead of parking the job until a launcher's limit."""
+    import datetime
+
     import torch
     import torch.distributed as dist
 
@@ -41,8 +45,30 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl" and os.environ.get("SGK_BENCH_ONE_DEVICE") != "1":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("SGK_DIST_TIMEOUT_S", "120"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     return rank, local_rank, world
+
+
+def fail_fast(body):
+    """Run one rank's `body()`; on ANY exception print it to stderr and leave the process at once with a non-zero code -- no
+    interpreter shutdown, no process-group destructor that would wait for the other ranks. A launcher that watches its children
+    (torch.distributed.run does) then ends the job; ranks it does not watch run into the collective timeout of
+    init_process_group. Returns body()'s value otherwise."""
+    import sys
+    import traceback
+
+    try:
+        return body()
+    except SystemExit:
+        raise
+    except BaseException:  # noqa: BLE001  (a rank must not outlive its failure, whatever it was)
+        rank = os.environ.get("RANK", "0")
+        sys.stderr.write("rank %s failed:\n%s" % (rank, traceback.format_exc()))
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(1)
 
 
 def allreduce_metrics(vec):
@@ -88,11 +114,13 @@ def library_comm(env):
         return _COMMS[env.device]
     lib = _lib.load()
     rank, world = dist.get_rank(), dist.get_world_size()
-    # EVERY rank draws an id first (only rank 0's is used): it is the cheapest call that needs librccl loaded and working. All
-    # ranks agree on that before anyone enters ncclCommInitRank -- a rank that cannot load RCCL would return at once and leave
-    # the others waiting in the rendezvous for ever.
+    # Every rank first checks that librccl loads and resolves (sgk_comm_available: side-effect free), rank 0 also draws the id
+    # (ncclGetUniqueId opens a bootstrap listener and a thread per call: only the rank whose id is used makes one). All ranks
+    # agree on the outcome before anyone enters ncclCommInitRank -- a rank that cannot load RCCL would return at once and leave the
+    # others waiting in the rendezvous.
     ident = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)()
-    ok = torch.tensor([int(lib.sgk_comm_unique_id(ident) == _lib.SGK_OK)], dtype=torch.int32, device="cuda:%d" % env.device)
+    mine = lib.sgk_comm_unique_id(ident) if rank == 0 else lib.sgk_comm_available(None)
+    ok = torch.tensor([int(mine == _lib.SGK_OK)], dtype=torch.int32, device="cuda:%d" % env.device)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     t = torch.tensor(list(ident), dtype=torch.uint8, device="cuda:%d" % env.device)
     dist.broadcast(t, src=0)

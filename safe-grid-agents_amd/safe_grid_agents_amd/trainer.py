@@ -228,6 +228,8 @@ def train_batched(args, writer_factory=None, reporter=_noop):
                     agent.step(learn=True, cheat=args.cheat)
             else:
                 agent.rollout(horizon, cheat=args.cheat)
+                if hasattr(agent, "check_hash_overflow"):
+                    agent.check_hash_overflow()  # hashed tables (tomato watering): a full table stops the run at THIS period
             bm = sdist.global_metrics(env)  # this shard's metrics, all-reduced over the ranks when there are several
         bm.write(writer, episode, prefix="Train/")
         if agent is not None and not ppo:

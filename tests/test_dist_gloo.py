@@ -70,3 +70,49 @@ def test_two_rank_allreduce_equals_unsharded(tmp_path):
 def test_allreduce_is_identity_without_process_group():
     v = torch.arange(16, dtype=torch.int64)
     assert sdist.allreduce_metrics(v).tolist() == v.tolist()
+
+
+_FAIL_SCRIPT = """
+import os, sys, time
+sys.path[:0] = [%r, %r]
+import torch, torch.distributed as dist
+from safe_grid_agents_amd import dist as sdist
+
+def body():
+    rank, _, world = sdist.init_process_group("gloo", timeout_s=20)
+    dist.barrier()  # the rendezvous worked: every rank is here
+    if rank == 1:
+        raise RuntimeError("rank 1 breaks after the rendezvous")
+    t = torch.ones(1)
+    dist.all_reduce(t)  # rank 0 waits for a rank that is gone: the timeout (or the launcher) ends it
+    return 0
+
+sys.exit(sdist.fail_fast(body) or 0)
+"""
+
+
+def test_a_rank_that_dies_after_the_rendezvous_ends_the_job_quickly(tmp_path):
+    """A rank that raises after the rendezvous leaves at once with a non-zero code (dist.fail_fast); the launcher ends the job --
+    and even an unwatched survivor fails in its next collective after the process group's timeout: the job is over in well under
+    150 s with a non-zero code, instead of parking in a collective until the launcher's limit."""
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fail_rank.py"
+    script.write_text(_FAIL_SCRIPT % (root, os.path.join(root, "safe-grid-agents_amd")))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, timeout=300)
+    took = time.time() - t0
+    assert p.returncode != 0 and took < 150, (p.returncode, took, p.stderr[-2000:])
+    assert "rank 1 failed" in p.stderr and "rank 1 breaks after the rendezvous" in p.stderr
+    # without a launcher that watches: rank 0 alone must come back by itself (collective timeout), non-zero
+    env0 = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env0, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [q.communicate(timeout=200) for q in procs]
+    took = time.time() - t0
+    assert procs[1].returncode == 1 and procs[0].returncode != 0 and took < 150, ([q.returncode for q in procs], took, outs[0][1][-1500:])

@@ -1280,6 +1280,11 @@ def test_tomato_watering_units_scale_and_hashed_tables():
     assert small.n_states == 64 and small.hash_info() == (64, 0, False)
     small.rollout(600)  # hundreds of distinct boards per agent into 64 slots: the overflow is REPORTED, not silent
     assert small.hash_info()[1:] == (64, True)
+    with pytest.raises(RuntimeError, match="overflowed"):  # what the batched trainer calls after every period's rollout
+        small.check_hash_overflow()
+    small.learn_steps(20)  # the per-step kernels with full tables: a board without a row reads zeros and learns nothing
+    a = small.act_explore()
+    assert int(a.max()) < 4 and small.hash_info()[1:] == (64, True)
     small.close()
     boat = S.BatchedGridworldEnv("BoatRace-v0", 4)
     with pytest.raises(RuntimeError, match="perfect hash"):
