@@ -337,6 +337,202 @@ def median_index(vals):
     return order[(len(vals) - 1) // 2]
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def _threads_timed(make_worker, n_threads):
+    """Run make_worker(i)() on n_threads Python threads (the oracle's C calls release the GIL); returns wall seconds."""
+    import threading
+
+    workers = [make_worker(i) for i in range(n_threads)]
+    ts = [threading.Thread(target=w) for w in workers]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_tabq(env_name, seed, target_seconds=10.0):
+    """Config 3's CPU side: the oracle's tabular-Q rollout (scalar C: act_explore -> env.step -> learn per agent-step, dictionary
+    Q-tables like the reference's defaultdict), one agent block per host thread."""
+    from oracle import oracle as O
+
+    args = dict(lr=0.5, discount=0.99, eps0=0.01, anneal=100000)
+
+    def block(n, steps):
+        envs = O.EnvBatch(env_name, n, seed=seed)
+        agents = [O.TabQ(envs.H * envs.W, args["lr"], args["discount"], args["eps0"], args["anneal"]) for _ in range(n)]
+        return lambda: O.tabq_rollout(envs, agents, steps, seed=seed)
+
+    n1 = 1024
+    w = block(n1, 20)
+    t0 = time.perf_counter(); w(); probe = n1 * 20 / (time.perf_counter() - t0)
+    steps1 = int(max(50, min(5000, target_seconds * 0.4 * probe / n1)))
+    w = block(n1, steps1)
+    t0 = time.perf_counter(); w(); one = n1 * steps1 / (time.perf_counter() - t0)
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    steps_all = int(max(50, min(5000, target_seconds * 0.6 * one / n1)))
+    dt = _threads_timed(lambda i: block(n1, steps_all), threads)
+    return {"value": threads * n1 * steps_all / dt, "unit": "agent-steps/s", "cores": threads, "kind": "port", "one_core_value": one,
+            "host_cpus": cores,
+            "sample": "%s + tabular-q, oracle C (gcc -O2): %d threads x %d agents x %d steps; 1 thread: %d agents x %d steps"
+                      % (env_name, threads, n1, steps_all, n1, steps1)}
+
+
+def cpu_baseline_mlp(env_name, seed, n_hidden, target_seconds=10.0):
+    """Config 4's CPU side: the same MLP forward in torch fp32 on the host cores (torch's own thread pool) + the oracle's env.step
+    on the greedy actions, for a block of envs. (No exploration draws: a baseline of the arithmetic, not of the stream.)"""
+    import numpy as np
+    import torch
+
+    from oracle import oracle as O
+
+    H, W = O.shape(env_name)
+    n = 4096
+    envs = O.EnvBatch(env_name, n, seed=seed)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(H * W, n_hidden), torch.nn.ReLU(), torch.nn.Linear(n_hidden, n_hidden), torch.nn.ReLU(),
+                              torch.nn.Linear(n_hidden, 4))
+
+    def run(steps):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for k in range(steps):
+                obs = torch.from_numpy(envs.boards().astype(np.float32))
+                a = net(obs).argmax(1).numpy().astype(np.uint8)
+                envs.rollout(1, seed=seed, t_begin=k, auto_reset=True, actions=a.reshape(1, n))
+        return time.perf_counter() - t0
+
+    probe = n * 5 / run(5)
+    steps = int(max(10, min(2000, target_seconds * probe / n)))
+    dt = run(steps)
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port", "host_cpus": os.cpu_count(),
+            "sample": "%s: torch fp32 CPU forward of the %d-%d-%d-4 MLP (%d torch threads) + oracle env.step (1 thread), %d envs x %d "
+                      "steps, greedy actions" % (env_name, H * W, n_hidden, n_hidden, torch.get_num_threads(), n, steps)}
+
+
+def run_config(args):
+    """BASELINE.json configs 2 / 3 / 4 on one GPU: one JSON object each, with the roofline of the config's dominant kernel and a CPU
+    baseline on the box's host cores. Every fraction follows from numbers inside the object."""
+    import types
+
+    import torch
+
+    import safe_grid_agents_amd as S
+
+    dev = 0
+    torch.cuda.set_device(dev)
+
+    def ev_time(env, fn, reps):
+        st = env.torch_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        env.synchronize(); torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            e0.record(st)
+            for _ in range(reps):
+                fn()
+            e1.record(st)
+            env.synchronize(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 1e3 / reps
+
+    out = {"config": args.config, "n_gpus": 1, "data": "synthetic", "higher_is_better": True}
+    if args.config == 2:
+        name, n = "BoatRace-v0", 65536
+        env = S.BatchedGridworldEnv(name, n, device=dev, seed=args.seed, layout="compact")
+        env.step_random(200, auto_reset=True)
+        per = {}
+        per["launch"] = ev_time(env, lambda: env.step_random(100, auto_reset=True), 20) / 100
+        per["own"] = ev_time(env, lambda: env.step_random(100, auto_reset=True, fused="stream"), 20) / 100
+        per["fused"] = ev_time(env, lambda: env.step_random(1000, auto_reset=True, fused=True), 5) / 1000
+        b = algorithmic_bytes_per_env_step(name, "launch")
+        gbs = b * n / per["launch"] / 1e9
+        out.update({
+            "workload": "BoatRace random-action rollout, 65 536 envs lockstep, step kernel (one launch per lockstep step, hipGraph x100)",
+            "metric": "env-steps/s", "unit": "env-steps/s", "value": n / per["launch"], "us_per_lockstep_step": per["launch"] * 1e6,
+            "dtype": "int8",
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_env_step": b, "kernel": "sgk::step_kernel<BoatRace-v0>",
+                         "note": "2.9 MB per launch: the working set lives in L2 / Infinity Cache and a launch is ~1 dependent-launch "
+                                 "boundary long -- the config is launch-latency-bound, the HBM fraction says how far from bandwidth"},
+            "other_forms": {"streamed_100_steps_per_launch_us": per["own"] * 1e6, "outputs_once_1000_steps_per_launch_us": per["fused"] * 1e6,
+                            "streamed_value": n / per["own"], "outputs_once_value": n / per["fused"]}})
+        env.close()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(name, args.seed)
+    elif args.config == 3:
+        name, n = "IslandNavigation-v0", 262144
+        targs = types.SimpleNamespace(lr=0.5, discount=0.99, epsilon=0.01, epsilon_anneal=100000)
+        env = S.BatchedGridworldEnv(name, n, device=dev, seed=args.seed)
+        agent = S.BatchedTabularQAgent(env, targs)
+        agent.rollout(200)
+        dt = ev_time(env, lambda: agent.rollout(1000), 3) / 1000
+        peak1 = S._lib.issue_peak(dev, 1)  # the kernel's residency: its Q image leaves room for ONE wave per SIMD
+        peak8 = S._lib.issue_peak(dev, 8)
+        kpath = os.path.join(ROOT, "profiles", "issue.json")
+        k = json.load(open(kpath)).get("%s/tabq_rollout" % name) if os.path.exists(kpath) else None
+        roof = None
+        if k:
+            wave_steps = (n / 64.0) / dt
+            valu = k["valu_per_wave_step"] * wave_steps
+            roof = {"bound": "valu-issue", "achieved": valu / 1e9, "peak": peak1[0] / 1e9, "unit": "G wave-instructions/s",
+                    "frac": valu / peak1[0], "peak_is": "sgk_issue_peak at 1 wave per SIMD, this process (what the LDS-resident Q image allows: "
+                    "4 waves of 64 agents per CU)", "frac_of_8_waves_per_simd_peak": valu / peak8[0], "peak_8_waves_per_simd": peak8[0] / 1e9,
+                    "valu_per_wave_step": k["valu_per_wave_step"], "salu_per_wave_step": k["salu_per_wave_step"],
+                    "lds_per_wave_step": k.get("lds_per_wave_step"), "source": k.get("source"), "kernel": "sgk::tabq_rollout_kernel<2>",
+                    "survey_8d_bytes_per_agent_step": 196, "survey_8d_gbs": 196 * n / dt / 1e9,
+                    "note": "tables resident in LDS: no HBM traffic per step (8(d)'s 196 B per agent-step would be %.1f TB/s)" % (196 * n / dt / 1e12)}
+        out.update({"workload": "IslandNavigation + tabular-q, 262 144 private agents, fused LDS-resident rollout (1000 steps per launch)",
+                    "metric": "agent-steps/s", "unit": "agent-steps/s", "value": n / dt, "us_per_lockstep_step": dt * 1e6, "dtype": "f64",
+                    "roofline": roof})
+        agent.close(); env.close()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_tabq(name, args.seed)
+    else:
+        name, n, nh = "SideEffectsSokoban-v0", 32768, 100
+        dargs = types.SimpleNamespace(discount=0.99, lr=1e-3, batch_size=64, sync_every=10000, epsilon=0.01, epsilon_anneal=100000,
+                                      n_layers=2, n_hidden=nh)
+        env = S.BatchedGridworldEnv(name, n, device=dev, seed=args.seed, layout="compact")
+        env.bind_torch_stream()
+        dq = S.BatchedDeepQAgent(env, dargs, sgd_steps=1, replay_slices=8)
+        dq.warmup(8)
+        dq.act_rollout(100, epsilon=0.01)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dq.act_rollout(1000, epsilon=0.01)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3000
+        for _ in range(20):
+            dq.step(learn=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(300):
+            dq.step(learn=True)
+        torch.cuda.synchronize()
+        dt_learn = (time.perf_counter() - t0) / 300
+        nc = env.n_cells
+        flops = 2.0 * (nc * nh + nh * nh + nh * 4)  # useful multiply-adds of one forward, x 2
+        tf = flops * n / dt / 1e12
+        out.update({"workload": "SideEffectsSokoban + deep-q (the reference's MLP %d-%d-%d-4, fp32), 32 768 envs: acting with frozen weights, "
+                                "1000 x {forward + eps-greedy + env.step + auto-reset} per launch (sgk_policy_rollout)" % (nc, nh, nh),
+                    "metric": "env-steps/s", "unit": "env-steps/s", "value": n / dt, "us_per_lockstep_step": dt * 1e6, "dtype": "f32",
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                                 "useful_flops_per_env_step": flops, "kernel": "sgk::policy_rollout_kernel",
+                                 "note": "useful multiply-adds only (the kernel pads the hidden width to MFMA tiles)"},
+                    "with_learning": {"us_per_lockstep_step": dt_learn * 1e6, "value": n / dt_learn,
+                                      "note": "one SGD step (batch 64, Adam amsgrad, fused kernel) per lockstep step of all 32 768 envs; the "
+                                              "reference's ratio is one SGD step per SINGLE env-step (value.py:113-117)"}})
+        env.close()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_mlp(name, args.seed, nh)
+    print(json.dumps(out))
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -363,7 +559,15 @@ def main():
     ap.add_argument("--rings", type=int, default=3,
                     help="how many fresh primary rings the timed region is repeated on (value = the median ring; path ring only)")
     ap.add_argument("--no-weak-line", action="store_true", help="skip the secondary 1M-envs-per-GPU measurement at N > 1")
+    ap.add_argument("--config", type=int, default=0, choices=(0, 2, 3, 4),
+                    help="instead of the headline: BASELINE.json's config 2 (BoatRace 65 536 envs, step kernel), 3 (IslandNavigation + "
+                         "tabular-q, 262 144 agents) or 4 (Sokoban + deep-q MLP, 32 768 envs) on ONE GPU, as one JSON object with its own "
+                         "roofline and cpu_baseline (tools/gpu_configs.sh collects them into profiles/rNN/configs.json)")
     args = ap.parse_args()
+    if args.config:
+        from safe_grid_agents_amd import dist as sdist
+
+        sys.exit(sdist.fail_fast(lambda: run_config(args)) or 0)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))  # nothing here has initialised the GPU yet; the child's code is ours

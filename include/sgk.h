@@ -72,6 +72,17 @@ extern "C" {
                                       single-env / small-batch case with a host-side agent in the loop (sgk_step_host then
                                       needs no staging copies: one launch + one synchronisation). n_envs <= 65536. */
 
+/* ENVIRONMENT KNOBS the library reads -- all of them (grep getenv over csrc), each once per sgk_create*, none on a hot path:
+ *   SGK_NO_GRAPH=1      sgk_step_random issues eager launches instead of replaying a hipGraph (the profiler workloads set it: one
+ *                       kernel record per launch).
+ *   SGK_MAX_GRID=<n>    workgroups per launch of the grid-stride kernels (default 6 per CU; n >= 64); tools/sweep.py.
+ *   SGK_STREAM_GRID=<n> workgroups per launch of the streamed rollout (default 16 per CU; n >= 64); likewise.
+ *   SGK_STEP_SERVER=0   host-visible handles of <= 64 envs serve sgk_step_host with one launch per call instead of the resident
+ *                       step server (the A/B of tools/bench_single_env.py).
+ * The Python host adds SGK_LIB_PATH (another build of libsgk.so), SGK_NO_BUILD=1 (never start a build: set under profilers),
+ * SGK_METRICS_COLLECTIVE=torch (metrics all-reduce through torch.distributed instead of the library's RCCL communicator),
+ * SGK_DIST_TIMEOUT_S (collective timeout, default 120), SGK_TABQ_HASH_CAPACITY (slots per agent of hashed Q-tables). */
+
 typedef struct sgk_env sgk_env;   /* one shard: N independent grid instances resident on one GPU */
 typedef struct sgk_tabq sgk_tabq; /* N private tabular-Q agents bound to an sgk_env */
 
@@ -192,8 +203,9 @@ SGK_API int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flag
  * of `bytes` (rounded up to 2 MiB) mapped through HIP's virtual-memory management from physical chunks of 256 MiB. The streamed
  * rollout writes such a ring at 4.5-4.8 us per step (1 M BoatRace envs, 100 slices) where hipMalloc blocks of the same process
  * measure 4.6-4.9 or 5.6-6.1 depending on the block, for its lifetime. The reference keeps its transitions in a
- * Python deque (contain.py:11-13); this is where the batched form keeps them. sgk_ring_free synchronises the device first.
- * SGK_RING_CHUNK_MIB (2 ... 512) overrides the chunk size. */
+ * Python deque (contain.py:11-13); this is where the batched form keeps them. sgk_ring_free synchronises the device first. Sizes
+ * are rounded to the driver's recommended allocation granularity (never below 2 MiB); both calls leave the thread's current
+ * device as they found it. */
 SGK_API int sgk_ring_alloc(int32_t device, size_t bytes, void **dev_ptr);
 SGK_API int sgk_ring_free(void *dev_ptr);
 /* How fast can THIS trajectory ring be written? Runs the streamed rollout's stores and nothing else over every slice of the ring
@@ -207,12 +219,13 @@ SGK_API int sgk_ring_free(void *dev_ptr);
 SGK_API int sgk_ring_probe(sgk_env *h, int8_t *boards_ring_dev, sgk_step_rec *recs_ring_dev, int32_t ring_slices, uint32_t flags,
                            double *us_per_slice);
 /* The chip's instruction-issue ceilings, measured NOW on `device`: wave-instructions per second through the vector-ALU port and
- * through the scalar-ALU port with 8 waves resident per SIMD (register-only loops of independent instructions, best of three
- * passes, ~30 ms of device time on a stream of its own; synchronising). What the outputs-once rollout (sgk_rollout_random:
- * RandomAgent.act + env.step fused, reference dummy.py:15-16 / warmup.py:14-21, no per-step output) is held against: its bound
- * is instruction issue, which moves with the clock the box runs at, so bench.py measures the ceiling in the same process as the
- * kernel instead of quoting another box's. */
-SGK_API int sgk_issue_peak(int32_t device, double *valu_wave_instr_per_s, double *salu_wave_instr_per_s);
+ * through the scalar-ALU port with `waves_per_simd` (1 .. 8) waves resident on every SIMD (register-only loops of independent
+ * instructions, best of three passes, ~30 ms of device time on a stream of its own; synchronising). What the kernels that store
+ * nothing per step are held against -- the outputs-once rollout (sgk_rollout_random: RandomAgent.act + env.step fused, reference
+ * dummy.py:15-16 / warmup.py:14-21; 8 waves per SIMD) and the LDS-resident tabular-Q rollout (sgk_tabq_rollout, value.py:33-58;
+ * ONE wave per SIMD, all its Q image leaves room for): their bound is instruction issue, which moves with the clock the box runs
+ * at, so bench.py measures the ceiling in the same process as the kernel instead of quoting another box's. */
+SGK_API int sgk_issue_peak(int32_t device, int32_t waves_per_simd, double *valu_wave_instr_per_s, double *salu_wave_instr_per_s);
 /* Book n_steps lockstep steps that were issued OUTSIDE the library's sight: a caller that captured sgk_step() into its
  * own hipGraph (e.g. torch.cuda.CUDAGraph around policy + env.step) replays it without re-entering sgk_step, so the
  * host-side lockstep counter and SGK_M_STEPS must be advanced by hand after each replay (n_steps < 0 un-counts the

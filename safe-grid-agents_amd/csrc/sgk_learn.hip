@@ -964,6 +964,7 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
   case 36: SGK_SGD_LAUNCH_K(36); break;
   case 48: SGK_SGD_LAUNCH_K(48); break;
   case 49: SGK_SGD_LAUNCH_K(49); break;
+  case 56: SGK_SGD_LAUNCH_K(56); break;
   case 63: SGK_SGD_LAUNCH_K(63); break;
   default: return hipErrorInvalidValue;
   }
@@ -1014,6 +1015,7 @@ hipError_t launch_ppo_epochs(const Shard &sh, const PpoLearner &P, hipStream_t s
   case 36: SGK_PPO_LAUNCH_K(36); break;
   case 48: SGK_PPO_LAUNCH_K(48); break;
   case 49: SGK_PPO_LAUNCH_K(49); break;
+  case 56: SGK_PPO_LAUNCH_K(56); break;
   case 63: SGK_PPO_LAUNCH_K(63); break;
   default: return hipErrorInvalidValue;
   }

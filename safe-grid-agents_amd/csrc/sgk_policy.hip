@@ -563,6 +563,7 @@ hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, 
   case 36: SGK_POLICY_LAUNCH(36); break;
   case 48: SGK_POLICY_LAUNCH(48); break;
   case 49: SGK_POLICY_LAUNCH(49); break;
+  case 56: SGK_POLICY_LAUNCH(56); break;
   case 63: SGK_POLICY_LAUNCH(63); break;
   default: return hipErrorInvalidValue;
   }

@@ -51,15 +51,16 @@ int hip_fail(hipError_t e, const char *what) {
 
 }  // namespace
 
-extern "C" int sgk_issue_peak(int32_t device, double *valu_wave_instr_per_s, double *salu_wave_instr_per_s) {
+extern "C" int sgk_issue_peak(int32_t device, int32_t waves_per_simd, double *valu_wave_instr_per_s, double *salu_wave_instr_per_s) {
   if (!valu_wave_instr_per_s || !salu_wave_instr_per_s) return sgk_set_error(SGK_ERR_INVALID, "NULL output");
+  if (waves_per_simd < 1 || waves_per_simd > 8) return sgk_set_error(SGK_ERR_INVALID, "waves_per_simd must be 1 .. 8");
   hipError_t err = hipSetDevice(device);
   if (err != hipSuccess) return hip_fail(err, "hipSetDevice");
   hipDeviceProp_t prop;
   err = hipGetDeviceProperties(&prop, device);
   if (err != hipSuccess) return hip_fail(err, "hipGetDeviceProperties");
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  const int grid = cus * 8, iters = 10000;  // eight 256-lane workgroups per CU = 8 waves per SIMD, the rollout kernel's residency
+  const int grid = cus * waves_per_simd, iters = 10000;  // w 256-lane workgroups per CU = w waves on every SIMD
   uint32_t *out = nullptr;
   hipStream_t st = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -116,7 +116,7 @@ _SIGNATURES = {
     "sgk_rollout_random": (ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_uint32]),
     "sgk_rollout_random_stream": (ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_uint32, _V, _V, ctypes.c_int32, ctypes.c_int32]),
     "sgk_ring_probe": (ctypes.c_int, [_V, _V, _V, ctypes.c_int32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]),
-    "sgk_issue_peak": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "sgk_issue_peak": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "sgk_ring_alloc": (ctypes.c_int, [ctypes.c_int32, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
     "sgk_ring_free": (ctypes.c_int, [_V]),
     "sgk_step_repeat": (ctypes.c_int, [_V, _V, ctypes.c_int32, ctypes.c_uint32]),
@@ -222,10 +222,11 @@ def check(rc):
     return rc
 
 
-def issue_peak(device=0):
-    """(VALU, SALU) wave-instructions per second the chip issues right now at 8 waves per SIMD (sgk_issue_peak; synchronising)."""
+def issue_peak(device=0, waves_per_simd=8):
+    """(VALU, SALU) wave-instructions per second the chip issues right now with `waves_per_simd` waves on every SIMD
+    (sgk_issue_peak; synchronising)."""
     v, s = ctypes.c_double(0.0), ctypes.c_double(0.0)
-    check(load().sgk_issue_peak(int(device), ctypes.byref(v), ctypes.byref(s)))
+    check(load().sgk_issue_peak(int(device), int(waves_per_simd), ctypes.byref(v), ctypes.byref(s)))
     return v.value, s.value
 
 

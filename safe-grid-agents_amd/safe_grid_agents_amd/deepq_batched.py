@@ -11,6 +11,12 @@ samples per SINGLE env-step of its single env; with N envs in lockstep one call 
 a parameter here: `sgd_steps` SGD steps of `batch_size` samples per LOCKSTEP step, replay of `replay_slices` x N
 transitions (a ring of whole lockstep slices). The [B,1]-vs-[B] mse_loss broadcast of value.py:119-123 is NOT kept here
 (shapes are squeezed): this is a different training schedule anyway, parity is claimed only for forward / argmax / policy.
+
+`q_body="cnn"` (NOT the reference's DeepQAgent, which is an MLP: value.py:148-158 -- offered because BASELINE.json's config 4 is
+worded "conv policy"): the Q-network is the convolutional body of the reference's PPO agent (policy_cnn.py:17-81: n_layers 3x3
+convolutions of n_channels with a 1x1 residual bottleneck, then a 3x3 head convolution and a linear layer, here onto the four
+Q-values). It runs through PyTorch-ROCm (MIOpen) on the float32 observation (sgk_obs_f32), acts through sgk_epsilon_greedy and
+learns with torch autograd + Adam: no fused kernel, no parity claim.
 """
 
 
@@ -81,14 +87,40 @@ class DeviceReplay:
                 flat(self.terminals)[ix])
 
 
+def _ConvQ(nn, height, width, channels, n_layers, n_actions):
+    """The conv body of policy_cnn.py:17-81 with a Q head: rows of n_cells cell values in, n_actions scores out."""
+
+    class ConvQ(nn.Module):
+        def __init__(self):
+            super().__init__()
+
+            def conv3(n_in):
+                return nn.Sequential(nn.Conv2d(n_in, channels, kernel_size=3, stride=1, padding=1), nn.ReLU())
+
+            self.network = nn.Sequential(conv3(1), *[conv3(channels) for _ in range(n_layers - 1)])
+            self.bottleneck = nn.Conv2d(1, channels, kernel_size=1, stride=1)
+            self.head_cnn = conv3(channels)
+            self.head_linear = nn.Linear(channels * height * width, n_actions)
+
+        def forward(self, x):
+            x = x.reshape(-1, 1, height, width)
+            trunk = self.network(x) + self.bottleneck(x)
+            return self.head_linear(self.head_cnn(trunk).flatten(1))
+
+    return ConvQ()
+
+
 class BatchedDeepQAgent:
     reads_boards = True  # acts on the materialised cells (batched_default_eval must keep writing them)
 
-    def __init__(self, env, args, sgd_steps=1, replay_slices=8, fused_learn=True):
+    def __init__(self, env, args, sgd_steps=1, replay_slices=8, fused_learn=True, q_body=None):
         import torch
 
         self.torch = torch
         self.env = env
+        self.q_body = q_body or getattr(args, "q_body", None) or "mlp"
+        assert self.q_body in ("mlp", "cnn"), "q_body must be 'mlp' (the reference's DeepQAgent) or 'cnn' (non-parity option)"
+        self.n_channels = int(getattr(args, "n_channels", None) or 5)  # policy_cnn.py's default (agent_parser_configs.yaml:107-111)
         self.device = "cuda:%d" % env.device
         self.action_n = env.action_space.n
         self.n_input = env.n_cells
@@ -110,8 +142,8 @@ class BatchedDeepQAgent:
         self.last_loss = None
         self._actions = torch.empty(env.n_envs, dtype=torch.uint8, device=self.device)
         # fused forward + act_explore kernel (sgk_policy_act): two layers of 100 (the reference default), 64 or 128 units
-        self.fused_policy = (n_layers == 2 and n_hidden in (64, 100, 128) and self.action_n == 4
-                             and env.n_cells in (25, 30, 36, 48, 49, 63))
+        self.fused_policy = (self.q_body == "mlp" and n_layers == 2 and n_hidden in (64, 100, 128) and self.action_n == 4
+                             and env.n_cells in (25, 30, 36, 48, 49, 56, 63))
         if self.fused_policy:
             l1, l2, l3 = self.Q[0][0], self.Q[1][0][0], self.Q[2]
             self._fw = {"w1t": torch.empty((env.n_cells, n_hidden), device=self.device), "b1": l1.bias.data,
@@ -141,6 +173,8 @@ class BatchedDeepQAgent:
 
     def build_Q(self, n_input, n_layers, n_hidden):
         nn = self.torch.nn
+        if self.q_body == "cnn":
+            return _ConvQ(nn, int(self.env.H), int(self.env.W), self.n_channels, n_layers, int(self.action_n))
         first = nn.Sequential(nn.Linear(n_input, n_hidden), nn.ReLU())
         hidden = nn.Sequential(*[nn.Sequential(nn.Linear(n_hidden, n_hidden), nn.ReLU()) for _ in range(n_layers - 1)])
         return nn.Sequential(first, hidden, nn.Linear(n_hidden, int(self.action_n)))

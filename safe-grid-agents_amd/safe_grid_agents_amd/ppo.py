@@ -274,7 +274,7 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         self._obs = torch.empty((env.n_envs, env.n_cells), dtype=torch.float32, device=self.device)
         hidden = int(getattr(args, "n_hidden", 0))  # ppo-cnn has no such flag
         self.fused_policy = (body == "mlp" and int(args.n_layers) == 2 and hidden in (64, 100, 128) and self.action_n == 4
-                             and env.n_cells in (25, 30, 36, 48, 49, 63))
+                             and env.n_cells in (25, 30, 36, 48, 49, 56, 63))
         # learn() as ONE launch (sgk_ppo_epochs) where that kernel applies; Adam's state then lives in self._pl
         self.fused_learn = self.fused_policy and hidden in (64, 100) and 2 <= self.batch_size <= 64
         self._pl = None

@@ -61,7 +61,12 @@ _AGENT_FLAGS = {
                ("n-hidden", "hd", dict(type=int, default=100)),
                ("batch-size", "b", dict(type=int, default=64)),
                ("device", "dv", dict(type=int, default=0)),
-               ("log-gradients", "lg", dict(action="store_true"))],
+               ("log-gradients", "lg", dict(action="store_true")),
+               # extension, batched trainer (-N) only, NOT the reference's DeepQAgent (an MLP: value.py:148-158): a convolutional
+               # Q-body built like policy_cnn.py:17-81, through PyTorch-ROCm; no parity claim (BASELINE config 4 says "conv policy")
+               ("q-body", "qb", dict(type=str, default="mlp", choices=("mlp", "cnn"),
+                                     help="mlp: the reference's network (default, pinned); cnn: non-parity conv body, -N only")),
+               ("n-channels", "ch", dict(type=int, default=5))],
     "ppo-mlp": _PPO_FLAGS + [("n-hidden", "hd", dict(type=int, default=100)), _DEVICE, _GRADLOG],
     "ppo-cnn": [("n-channels", "ch", dict(type=int, default=5))] + _PPO_FLAGS + [_DEVICE, _GRADLOG],
 }

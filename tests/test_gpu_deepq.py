@@ -376,3 +376,41 @@ def test_train_batched_cli_deepq():
     assert tags.count("Train/returns") == 2 and "Train/value_loss" in tags and "Evaluation/returns" in tags
     assert agent.t == 200 and int(agent._fl["step"].cpu()) == 200  # one SGD step per lockstep step
     env.close()
+
+
+def test_conv_q_body_option_shapes_env_parity_and_learning_on_boat_race():
+    """`q_body="cnn"`: the NON-PARITY conv Q-body (the reference's DeepQAgent is an MLP, value.py:148-158; BASELINE config 4 says
+    "conv policy") -- policy_cnn.py's trunk with a Q head, through PyTorch-ROCm. Shapes, the env under it stays bit-exact against the
+    oracle, and it learns: on BoatRace the mean TD loss falls and the greedy policy's observed return beats the random walk's."""
+    import torch
+
+    torch.manual_seed(11)
+    n = 1024
+    env = S.BatchedGridworldEnv("BoatRace-v0", n, seed=9, layout="compact")
+    env.bind_torch_stream()
+    orc = O.EnvBatch("BoatRace-v0", n)
+    agent = S.BatchedDeepQAgent(env, _args(lr=2e-3, epsilon=0.1, epsilon_anneal=150, sync_every=25, n_channels=4), sgd_steps=2,
+                                replay_slices=16, q_body="cnn")
+    assert agent.q_body == "cnn" and not agent.fused_policy and not agent.fused_learn
+    obs = env.obs_f32()
+    q = agent.scores(obs)
+    assert tuple(q.shape) == (n, 4) and q.dtype == torch.float32
+    n_params = sum(p.numel() for p in agent.Q.parameters())
+    assert n_params == (4 * 9 + 4) + (4 * 4 * 9 + 4) + (4 + 4) + (4 * 4 * 9 + 4) + (4 * 25 * 4 + 4)  # conv3, conv3, 1x1, head conv3, linear
+    agent.warmup(8)
+    for k in range(8):  # the env under the agent is the same env: replay the stored actions through the oracle
+        acts = agent.replay.actions[k].cpu().numpy()
+        orc.rollout(1, actions=acts[None], auto_reset=False)
+        assert (agent.replay.successors[k].cpu().numpy() == orc.boards()).all()
+    losses = []
+    for t in range(300):
+        agent.step(learn=True)
+        losses.append(float(agent.last_loss))
+    assert np.isfinite(losses).all() and np.mean(losses[-50:]) < np.mean(losses[:50])
+    env.reset()
+    env.metrics_reset()
+    for _ in range(100):
+        agent.step(learn=False, explore=False)
+    greedy = S.BatchMetrics(env.metrics()).meter("returns")["avg"]
+    assert greedy > -40.0, greedy  # a random walk averages about -62 observed return per 100-step episode
+    env.close()

@@ -591,9 +591,9 @@ def _board_of_state(env, si):
     elif env.name == "SafeInterruptibility-v0":  # (agent cell, button pressed): the pressed half follows the other
         pressed, cell = divmod(int(si), nc)
         if pressed:
-            board[: env.W] = 4  # the top row of B's; the interruption tile is gone
+            board[: env.W] = 5  # the top row of B's (value 5); the interruption tile is gone
         else:
-            board[dims[3]] = 5
+            board[dims[3]] = 2  # the interruption tile (value 2)
     else:
         cell = int(si)
     board[cell] = aval[cell]

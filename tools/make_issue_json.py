@@ -3,7 +3,8 @@ SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH ..., tools/pmc_run.py <env> compact <
 table: instructions per WAVE-STEP (one lockstep step of one 64-env wave) and the chip's issue peaks at 8 waves per SIMD.
 bench.py's `fused_rollout.roofline` multiplies the first by the run's own wave-steps per second and divides by the second.
 
-    python tools/make_issue_json.py profiles/r03 1048576 1000
+    python tools/make_issue_json.py profiles/r03 1048576 1000 profiles/r04
+(the last argument: where the tabular-Q rollout's SQ pass lives, pmc_sq1_tabq_rollout.json)
 """
 import json
 import os
@@ -31,6 +32,21 @@ for tag, env in names.items():
                 "valu_per_wave_step": c["SQ_INSTS_VALU"] / wave_steps, "salu_per_wave_step": (c["SQ_INSTS_SALU"]) / wave_steps,
                 "branch_per_wave_step": c.get("SQ_INSTS_BRANCH", 0) / wave_steps, "lds_per_wave_step": c["SQ_INSTS_LDS"] / wave_steps,
                 "source": os.path.join(src, os.path.basename(p)), "n_envs": n, "steps_per_launch": steps}
+# the LDS-resident tabular-Q rollout at config 3's shape (tools/gpu_pmc_tabq.sh: 262 144 agents, 500 steps per launch)
+tq_dir = sys.argv[4] if len(sys.argv) > 4 else "profiles/r04"
+tp = os.path.join(ROOT, tq_dir, "pmc_sq1_tabq_rollout.json")
+if os.path.exists(tp):
+    d = json.load(open(tp))
+    tq_n, tq_steps = 262144, 500
+    for k, v in d.items():
+        if "tabq_rollout_kernel" in k:
+            c = {name: x["avg_per_dispatch"] for name, x in v.items()}
+            ws = tq_n / 64 * tq_steps
+            out["IslandNavigation-v0/tabq_rollout"] = {
+                "valu_per_wave_step": c["SQ_INSTS_VALU"] / ws, "salu_per_wave_step": c["SQ_INSTS_SALU"] / ws,
+                "branch_per_wave_step": c.get("SQ_INSTS_BRANCH", 0) / ws, "lds_per_wave_step": c["SQ_INSTS_LDS"] / ws,
+                "wave_cycles_per_wave_step": 4 * c["SQ_WAVE_CYCLES"] / ws, "waves_per_launch": c["SQ_WAVES"],
+                "source": os.path.join(tq_dir, os.path.basename(tp)), "n_agents": tq_n, "steps_per_launch": tq_steps}
 peak = {}
 for line in open(os.path.join(ROOT, src, "issue_peak.log")):
     m = re.match(r"(VALU|SALU)\s+8 \|\s+[\d.]+\s+([\d.]+)", line)
