@@ -671,9 +671,11 @@ def run_rank(args):
             ok_r = ring_parity_sample(args.env, args.seed, base, ring, total_steps - min(3, total_steps), min(3, total_steps),
                                       ring_start=ring_start)
             try:  # ... and what its memory takes from a kernel that only stores (zeros the ring: after the check)
-                probe_us = max_over_ranks(env.probe_trajectory_ring(ring[0], ring[1]))[0]
+                mine_us = env.probe_trajectory_ring(ring[0], ring[1])
             except S._lib.SgkError:
-                probe_us = None
+                mine_us = float("inf")  # (every rank still enters the collective below)
+            probe_us = max_over_ranks(mine_us)[0]
+            probe_us = None if probe_us == float("inf") else probe_us
         primary.append({"elapsed": el, "kernel_ms": kms, "gm": gm_r, "per_rank_device_us": per_rank, "ring_ok": ok_r,
                         "probe_us": probe_us, "backing": None if ring_alloc is None else ring_alloc["backing"]})
     mi = median_index([p["elapsed"] for p in primary])

@@ -288,6 +288,14 @@ __device__ __forceinline__ double sel64(bool c, double a, double b) {
 // (Tried: 32 agents per wave -- image [.][32], twice the waves per CU, two per SIMD to fill each other's stalls. Slower: 2.41 vs
 // 1.79 us per step at 262 144 IslandNavigation agents, 1.87 vs 1.33 BoatRace, 3.58 vs 3.73 DistributionalShift
 // (profiles/r04/tabq_agents_per_wave_ab.log): the loop is bound by instruction issue, not by exposed latency.)
+// v_max_f64 as ONE instruction (fmax() is llvm.maxnum: in IEEE mode the compiler first canonicalises both operands with a v_max_f64
+// x, x each, which gives the three instructions back)
+__device__ __forceinline__ double max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <int NT>
 __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int32_t n_steps) {
   extern __shared__ __attribute__((aligned(16))) double Q[];  // [n_live * 4][64]
@@ -357,14 +365,16 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int32_t n_
       const uint64_t m = ((uint64_t)(wa >> 5) << 26) | (uint64_t)(wb >> 6);
       const bool explore = m < thr;
       const int ea = (int)(wa & 3u);
+      // (the running maximum as v_max_f64, the index from the compares: they can only disagree on which ZERO of a +0.0 / -0.0 pair
+      // is "the" maximum, and the update below gives the same bits for either -- r + discount * v with r never -0.0, q + lr * (t - q))
       const bool c1 = q1 > q0;
-      double bv = sel64(c1, q1, q0);
+      double bv = max_f64(q0, q1);
       int best = c1 ? 1 : 0;
       const bool c2 = q2 > bv;
-      bv = sel64(c2, q2, bv);
+      bv = max_f64(bv, q2);
       best = c2 ? 2 : best;
       const bool c3 = q3 > bv;
-      bv = sel64(c3, q3, bv);
+      bv = max_f64(bv, q3);
       best = c3 ? 3 : best;
       const double q_lo = sel64((ea & 1) != 0, q1, q0), q_hi = sel64((ea & 1) != 0, q3, q2);
       const double q_ea = sel64((ea & 2) != 0, q_hi, q_lo);
@@ -391,9 +401,7 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int32_t n_
       // learn (value.py:44-52; no terminal masking: a terminal successor's row is the defaultdict's zeros)
       const int sr = term ? 0 : sn;  // terminal cells have no row in the image
       const double n0 = qrow[(sr * 4 + 0) * AG], n1 = qrow[(sr * 4 + 1) * AG], n2 = qrow[(sr * 4 + 2) * AG], n3 = qrow[(sr * 4 + 3) * AG];
-      double vmax = sel64(n1 > n0, n1, n0);
-      vmax = sel64(n2 > vmax, n2, vmax);
-      vmax = sel64(n3 > vmax, n3, vmax);
+      const double vmax = max_f64(max_f64(n0, n1), max_f64(n2, n3));
       const double v_next = sel64(term, 0.0, vmax);  // the FIRST maximum's value == the maximum's value
       const double reward = __dmul_rn((double)(cheat ? r_hid : r_obs), rscale);
       const double q_new = q_update(q_sa, reward, v_next, a.lr, a.discount);

@@ -140,3 +140,31 @@ def test_bench_line_eight_ranks_dry_run_on_one_gpu():
               env={"SGK_BENCH_BACKEND": "gloo", "SGK_BENCH_ONE_DEVICE": "1"}, timeout=900)
     _check_contract(d, 8, 2, 1)
     assert d["config"]["envs_per_gpu"] == 2048 and d["scaling"] == "strong" and d["episodes_finished"] == 16384 * 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_bench_config_objects_carry_their_own_roofline_and_cpu_baseline(k):
+    """`bench.py --config k` (BASELINE.json configs 2-4 on one GPU): one JSON object with value, the dominant kernel's roofline --
+    every fraction following from numbers inside the object -- and a CPU baseline on the host cores."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(k)], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"] == k and d["value"] > 0 and d["n_gpus"] == 1 and d["data"] == "synthetic"
+    n = {2: 65536, 3: 262144, 4: 32768}[k]
+    assert abs(d["value"] - n / (d["us_per_lockstep_step"] * 1e-6)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == {2: "hbm", 3: "valu-issue", 4: "mfma"}[k] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1.5
+    if k == 2:
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_env_step"] * d["value"] / 1e9) <= 1e-6 * r["achieved"]
+    if k == 3:  # instructions per wave-step (committed SQ pass) x this run's wave-steps per second, against the in-run 1-wave peak
+        assert abs(r["achieved"] - r["valu_per_wave_step"] * (d["value"] / 64) / 1e9) <= 1e-6 * r["achieved"]
+        assert r["frac_of_8_waves_per_simd_peak"] < r["frac"]
+    if k == 4:
+        assert abs(r["achieved"] - r["useful_flops_per_env_step"] * d["value"] / 1e12) <= 1e-6 * r["achieved"] and r["peak"] == 157.3
+        assert d["with_learning"]["value"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
