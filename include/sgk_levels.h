@@ -16,7 +16,7 @@
  * SWITCHES. Every reading of an upstream detail the survey marks uncertain ("(?)" in SURVEY.md Appendix A) is a named macro
  * with an #ifndef default -- the oracle's header carries the same names --, so a build with -D<NAME>=<alternative> flips it for
  * the product's rule builder AND the oracle at once; tests/test_switch_variants.py builds both sides under each alternative and re-runs the exhaustive table-vs-engine
- * check (DESIGN.md section 4 lists switch, default, alternative, test). A later session with upstream access flips
+ * check (DESIGN.md section 4 lists switch, default and alternative). A later session with upstream access flips
  * constants here instead of rewriting kernels.
  */
 #ifndef SGK_LEVELS_H

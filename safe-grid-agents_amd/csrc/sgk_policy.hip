@@ -100,6 +100,17 @@ template <int K0, int H>
 struct PolicyMfmaGeom {
   static constexpr int MT = (H + 15) / 16;   // neuron tiles of the hidden layers
   static constexpr int KS1 = (K0 + 3) / 4;   // k-steps of the first layer
+  // Where the hidden neurons sit. A full tile t < FT holds neurons 16 t .. 16 t + 15 in row order. The last, partial tile (H = 100:
+  // four neurons) spreads its neurons over the rows 4 g + j with j < RK -- one per lane group g and k-step j -- because a k-step
+  // (tile, r) of the NEXT layer consumes rows {4 g + r : g = 0..3} of that tile: packed like this its R neurons cost R / 4 k-steps
+  // instead of four (H = 100: 25 k-steps per hidden K dimension instead of 28; 526 MFMAs per 32 envs instead of 574). The order of
+  // neurons inside a layer is free as long as the next layer's K order follows it: `neuron()` is the one place that decides it.
+  static_assert(H % 4 == 0, "hidden widths are multiples of four");
+  static constexpr int FT = H / 16, RK = (H % 16) / 4;
+  static __host__ __device__ constexpr int neuron(int t, int row) {
+    return t < FT ? 16 * t + row : ((t == FT && (row & 3) < RK) ? 16 * FT + (row >> 2) * RK + (row & 3) : -1);
+  }
+  static __host__ __device__ constexpr int ksteps(int t) { return t < FT ? 4 : RK; }  // k-steps tile t feeds the next layer with
   static constexpr int W1 = MT * KS1 * 64;   // floats: [mt][s][lane]
   static constexpr int W2 = MT * MT * 64 * 4;  // floats: [mt_out][mt_k][lane][r]
   static constexpr int W3 = MT * 64 * 4;     // floats: [mt_k][lane][r]
@@ -159,7 +170,7 @@ __device__ __forceinline__ __attribute__((ext_vector_type(4))) float policy_forw
 #pragma unroll
     for (int mo = 0; mo < MT; ++mo) a[mo] = *reinterpret_cast<const f4 *>(lw2 + ((mo * MT + mk) * 64 + lane) * 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < G::ksteps(mk); ++r)
 #pragma unroll
       for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
@@ -181,7 +192,7 @@ __device__ __forceinline__ __attribute__((ext_vector_type(4))) float policy_forw
   for (int mk = 0; mk < MT; ++mk) {
     const f4 a = *reinterpret_cast<const f4 *>(lw3 + (mk * 64 + lane) * 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < G::ksteps(mk); ++r)
 #pragma unroll
       for (int e = 0; e < NT; ++e) sc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], h2[e][mk][r], sc[e], 0, 0, 0);
   }
@@ -258,27 +269,37 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_mfma_kernel(const int8_t *__r
   for (int it = 0; it < N1; ++it) {
     const int i = it * PMFMA_WG + threadIdx.x;  // (mt, s, lane)
     const int l = i & 63, s = (i >> 6) % KS1, mt = (i >> 6) / KS1;
-    const int nrn = 16 * mt + (l & 15), k = 4 * s + (l >> 4);
-    const float v = w1t[min(k, K0 - 1) * H + min(nrn, H - 1)];
-    r1[it] = (nrn < H && k < K0) ? v : 0.0f;
+    const int nrn = G::neuron(mt, l & 15), k = 4 * s + (l >> 4);
+    const float v = w1t[min(k, K0 - 1) * H + max(nrn, 0)];
+    r1[it] = (nrn >= 0 && mt < MT && k < K0) ? v : 0.0f;
   }
-  const float rb1 = b1[min((int)threadIdx.x, H - 1)], rb2 = b2[min((int)threadIdx.x, H - 1)];
+  const int bias_nrn = G::neuron((int)threadIdx.x >> 4, (int)threadIdx.x & 15);  // the neuron at padded position threadIdx.x
+  const float rb1 = b1[max(bias_nrn, 0)], rb2 = b2[max(bias_nrn, 0)];
   const float rb3 = b3[threadIdx.x & 3];
 #pragma unroll
   for (int it = 0; it < N2; ++it) {
     const int i = it * PMFMA_WG + threadIdx.x;  // (mo, mk, lane)
     const int l = i & 63, mk = (i >> 6) % MT, mo = (i >> 6) / MT;
-    const int nrn = 16 * mo + (l & 15), k = 16 * mk + 4 * (l >> 4);
-    const f4 v = *reinterpret_cast<const f4 *>(w2 + min(nrn, H - 1) * H + min(k, H - 4));
-    r2[it] = (nrn < H && k < H) ? v : (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    const int nrn = G::neuron(mo, l & 15), g = l >> 4;
+    const float *wrow = w2 + max(nrn, 0) * H;
+    // the four features (mk, 4 g + r): consecutive in a full tile; in the partial one the r < RK first are neurons, the rest padding
+    f4 v = *reinterpret_cast<const f4 *>(wrow + min(16 * mk + 4 * g, H - 4));
+    if (G::RK > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float part = wrow[min(16 * G::FT + g * G::RK + min(r, G::RK - 1), H - 1)];
+        if (mk >= G::FT) v[r] = r < G::RK ? part : 0.0f;
+      }
+    }
+    r2[it] = (nrn >= 0 && mo < MT && mk < MT) ? v : (f4){0.0f, 0.0f, 0.0f, 0.0f};
   }
 #pragma unroll
   for (int it = 0; it < N3; ++it) {
     const int i = it * PMFMA_WG + threadIdx.x;  // (mk, lane, r)
     const int r = i & 3, l = (i >> 2) & 63, mk = i >> 8;
-    const int a = l & 15, k = 16 * mk + 4 * (l >> 4) + r;
-    const float v = w3t[min(k, H - 1) * 4 + (a & 3)];
-    r3[it] = (a < 4 && k < H) ? v : 0.0f;
+    const int a = l & 15, k = G::neuron(mk, 4 * (l >> 4) + r);
+    const float v = w3t[max(k, 0) * 4 + (a & 3)];
+    r3[it] = (a < 4 && k >= 0 && mk < MT) ? v : 0.0f;
   }
 #pragma unroll
   for (int it = 0; it < N1; ++it) {
@@ -287,8 +308,8 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_mfma_kernel(const int8_t *__r
   }
   static_assert(G::B <= PMFMA_WG, "one thread per padded bias entry");
   if (threadIdx.x < G::B) {
-    lb1[threadIdx.x] = (int)threadIdx.x < H ? rb1 : 0.0f;
-    lb2[threadIdx.x] = (int)threadIdx.x < H ? rb2 : 0.0f;
+    lb1[threadIdx.x] = bias_nrn >= 0 ? rb1 : 0.0f;
+    lb2[threadIdx.x] = bias_nrn >= 0 ? rb2 : 0.0f;
   }
   if (threadIdx.x < 16) lb3[threadIdx.x] = threadIdx.x < 4 ? rb3 : 0.0f;
   if (eps_ptr) eps = *eps_ptr;
@@ -372,24 +393,31 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_rollout_kernel(RolloutArgs a)
   // weights in operand order (same arrangement as policy_mfma_kernel; staged once per launch, so plainly)
   for (int i = threadIdx.x; i < G::W1; i += PMFMA_WG) {
     const int l = i & 63, s = (i >> 6) % KS1, mt = (i >> 6) / KS1;
-    const int nrn = 16 * mt + (l & 15), k = 4 * s + (l >> 4);
-    lw1[i] = (nrn < H && k < K0) ? w.w1t[k * H + nrn] : 0.0f;
+    const int nrn = G::neuron(mt, l & 15), k = 4 * s + (l >> 4);
+    lw1[i] = (nrn >= 0 && k < K0) ? w.w1t[k * H + nrn] : 0.0f;
   }
   for (int i = threadIdx.x; i < G::W2 / 4; i += PMFMA_WG) {
     const int l = i & 63, mk = (i >> 6) % MT, mo = (i >> 6) / MT;
-    const int nrn = 16 * mo + (l & 15), k = 16 * mk + 4 * (l >> 4);
+    const int nrn = G::neuron(mo, l & 15);
     f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (nrn < H && k < H) v = *reinterpret_cast<const f4 *>(w.w2 + nrn * H + k);
+    if (nrn >= 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = G::neuron(mk, 4 * (l >> 4) + r);
+        if (k >= 0) v[r] = w.w2[nrn * H + k];
+      }
+    }
     reinterpret_cast<f4 *>(lw2)[i] = v;
   }
   for (int i = threadIdx.x; i < G::W3; i += PMFMA_WG) {
     const int r = i & 3, l = (i >> 2) & 63, mk = i >> 8;
-    const int ac = l & 15, k = 16 * mk + 4 * (l >> 4) + r;
-    lw3[i] = (ac < 4 && k < H) ? w.w3t[k * 4 + ac] : 0.0f;
+    const int ac = l & 15, k = G::neuron(mk, 4 * (l >> 4) + r);
+    lw3[i] = (ac < 4 && k >= 0) ? w.w3t[k * 4 + ac] : 0.0f;
   }
   for (int i = threadIdx.x; i < G::B; i += PMFMA_WG) {
-    lb1[i] = i < H ? w.b1[i] : 0.0f;
-    lb2[i] = i < H ? w.b2[i] : 0.0f;
+    const int nrn = G::neuron(i >> 4, i & 15);
+    lb1[i] = nrn >= 0 ? w.b1[nrn] : 0.0f;
+    lb2[i] = nrn >= 0 ? w.b2[nrn] : 0.0f;
   }
   if (threadIdx.x < 16) lb3[threadIdx.x] = threadIdx.x < 4 ? w.b3[threadIdx.x] : 0.0f;
   stage_rules(R, a.env.rules);  // ends with a workgroup barrier: weights and rules are in place

@@ -283,8 +283,9 @@ __device__ __forceinline__ double sel64(bool c, double a, double b) {
   return bits_f64(((uint64_t)hi << 32) | lo);
 }
 
-// NT = registers of the transition table in use: ceil(live cells * 4 / 64) rounded up to 1, 2 or 4 (the kernel is the same for
-// every level whose state is the agent's cell: nothing else depends on the level)
+// NT = registers of the transition table in use: 1 or 2 = up to 16 / 32 live cells (BoatRace 8, IslandNavigation 20,
+// DistributionalShift 28); a level with more goes to the HBM-resident kernel. The kernel is the same for every level whose state
+// is the agent's cell: nothing else depends on the level.
 // (Tried: 32 agents per wave -- image [.][32], twice the waves per CU, two per SIMD to fill each other's stalls. Slower: 2.41 vs
 // 1.79 us per step at 262 144 IslandNavigation agents, 1.87 vs 1.33 BoatRace, 3.58 vs 3.73 DistributionalShift
 // (profiles/r04/tabq_agents_per_wave_ab.log): the loop is bound by instruction issue, not by exposed latency.)
@@ -309,14 +310,12 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int32_t n_
   const int start_box = Rg->start_box, start_ext = Rg->start_ext;
   const bool cheat = a.cheat != 0;
   // this lane's entries of the slot-indexed transition table and its row -> cell entry
-  uint32_t T0 = 0, T1 = 0, T2 = 0, T3 = 0;
+  uint32_t T0 = 0, T1 = 0;
   {
     const int n_ent = n_live * 4;
     auto entry = [&](int i) -> uint32_t { return i < n_ent ? Rg->trans[(int)Rg->slot_cell[i >> 2] * 4 + (i & 3)] : 0u; };
     T0 = entry(lane);
     if (NT > 1) T1 = entry(lane + 64);
-    if (NT > 2) T2 = entry(lane + 128);
-    if (NT > 2) T3 = entry(lane + 192);
   }
   const int my_cell = Rg->slot_cell[lane];   // lane r < n_live: the cell of row r
   const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
@@ -386,10 +385,6 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int32_t n_
       if (NT > 1) {
         const uint32_t e1 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx << 2, (int)T1);
         e = (idx & 64) ? e1 : e;
-      }
-      if (NT > 2) {
-        const uint32_t e2 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx << 2, (int)T2), e3 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx << 2, (int)T3);
-        e = (idx & 128) ? ((idx & 64) ? e3 : e2) : e;
       }
       const int sn = (int)(e >> 25);
       const bool term = (e & 0x1000000u) != 0;
@@ -701,6 +696,7 @@ hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t
 // Sokoban's state is (agent cell, box cell): n_cells^2 rows do not fit LDS -> 0 = "use the HBM-resident kernel"
 size_t tabq_rollout_lds_bytes(const Shard &sh) {
   if (sh.n_states != sh.n_cells || sh.env_id == SGK_TOMATO_WATERING) return 0;  // (tomato: hashed tables live in HBM)
+  if (sh.rules_host.n_live_slots > 32) return 0;  // the transition table is held in two registers per lane
   return (size_t)sh.rules_host.n_live_slots * 4 * 64 * sizeof(double);  // the Q image and nothing else
 }
 
@@ -733,8 +729,7 @@ hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_s
       if (err == hipSuccess) hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, st, a, chunk);
     };
     if (n_ent <= 64) go(&tabq_rollout_kernel<1>);
-    else if (n_ent <= 128) go(&tabq_rollout_kernel<2>);
-    else go(&tabq_rollout_kernel<4>);
+    else go(&tabq_rollout_kernel<2>);
     if (err == hipSuccess) err = hipGetLastError();
     done += chunk;
     a.t_agent += chunk;

@@ -62,3 +62,21 @@ def test_host_epsilon_helper_matches_oracle():
     for eps, anneal in [(0.01, 100000), (0.05, 7), (0.3, 1), (0.0, 50)]:
         for t in (0, 1, 2, 5, 6, 7, 49, 50, 99999, 100000, 10**7):
             assert lib.sgk_tabq_epsilon(eps, anneal, t) == O.epsilon(eps, anneal, t)
+
+
+def test_rccl_probe_is_side_effect_free_and_answers_on_any_box():
+    """sgk_comm_available: loads librccl and resolves the entry points, or says why not -- never a socket or a thread (what the
+    ranks other than 0 call before the communicator is made)."""
+    import ctypes
+    import threading
+
+    lib = _lib.load()
+    before = threading.active_count()
+    ver = ctypes.c_int32(-1)
+    rc = lib.sgk_comm_available(ctypes.byref(ver))
+    assert rc in (_lib.SGK_OK, _lib.ERR_NODEVICE)
+    if rc == _lib.SGK_OK:
+        assert ver.value >= 0
+    else:
+        assert b"rccl" in lib.sgk_last_error().lower()
+    assert threading.active_count() == before

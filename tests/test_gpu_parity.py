@@ -704,6 +704,39 @@ def test_tabq_rollout_either_kernel_at_a_mid_size_is_bit_exact(kernel):
     agent.close(); env.close()
 
 
+@pytest.mark.parametrize("name", ["IslandNavigation-v0", "BoatRace-v0", "DistributionalShift-v0"])
+def test_tabq_rollout_lds_and_hbm_kernels_agree_with_finished_envs_odd_start_and_a_partial_group(name):
+    """The two fused kernels side by side on the cases the oracle's rollout never produces: envs whose episode is OVER when the
+    rollout starts (stepped without auto-reset before: they take no step and learn nothing; their record names the action the
+    agent would have chosen), an ODD first agent step (the exploration block's second half first), a step count that is no
+    multiple of the 64-step threshold window, and a batch that ends inside a 64-agent group. State words, step records, episode
+    arrays, metrics and every table must be identical, bit for bit."""
+    _torch()
+    n, seed = 200 + 37, 13
+    out = []
+    for kernel in ("lds", "hbm"):
+        env = S.BatchedGridworldEnv(name, n, seed=seed)
+        agent = S.BatchedTabularQAgent(env, _tabq_args())
+        agent.rollout(33, kernel=kernel)           # t = 33: the next launch starts on an odd agent step
+        env.step_random(70, auto_reset=False)      # many episodes end and STAY over (BoatRace: none -- its horizon is 100)
+        over = env.episode_state_host()["over"].copy()
+        agent.rollout(131, kernel=kernel)
+        st, le = env.episode_state_host(), env.last_episode_host()
+        out.append((over, {k: v.copy() for k, v in st.items()}, {k: v.copy() for k, v in le.items()}, env.step_records_host().copy(),
+                    env.metrics().copy(), agent.table_host().copy(), env.boards_host().copy()))
+        assert agent.t == 33 + 131
+        agent.close(); env.close()
+    a, b = out
+    assert (a[0] == b[0]).all() and (name == "BoatRace-v0" or a[0].sum() > 10)
+    for k in a[1]:
+        assert (a[1][k] == b[1][k]).all(), k
+    for k in a[2]:
+        assert (a[2][k] == b[2][k]).all(), k
+    assert (a[3] == b[3]).all() and a[4].tolist() == b[4].tolist() and (a[6] == b[6]).all()
+    assert a[5].tobytes() == b[5].tobytes()  # float64 tables, bit patterns
+    assert (a[1]["over"][a[0] != 0] != 0).all()  # an env that was over stays over: the rollout does not step it
+
+
 def test_tabq_rollout_sokoban_hbm_resident_kernel_matches():
     _torch()
     name, n, steps, seed = "SideEffectsSokoban-v0", 64, 240, 3
@@ -1126,6 +1159,9 @@ def test_rccl_metrics_allreduce_through_the_c_abi_world_of_one():
 
     _torch()
     lib = _lib.load()
+    ver = ctypes.c_int32(-1)
+    _lib.check(lib.sgk_comm_available(ctypes.byref(ver)))  # what ranks other than 0 probe with: no socket, no thread
+    assert ver.value > 20000 and lib.sgk_comm_available(None) == _lib.SGK_OK  # RCCL reports its NCCL-compatible version code
     ident = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)()
     _lib.check(lib.sgk_comm_unique_id(ident))
     assert any(ident)

@@ -30,7 +30,7 @@ int main(void) {
     orc_rollout(envs, n, 5, 77, 0, 333, 1, NULL, rec, m);
     orc_rollout_mt(envs, n, 5, 77, 333, 200, 1, m, 7);
     void** ag = malloc(sizeof(void*) * n);
-    for (int i = 0; i < n; ++i) ag[i] = orc_tabq_new(env == 0 ? 25 : env == 9 ? 30 : env == 2 ? 36 : (env == 3 || env == 8) ? 63 : env == 7 ? 49 : 48 /* island, whisky, super, interrupt */, 0.5, 0.99, 0.05, 300);
+    for (int i = 0; i < n; ++i) ag[i] = orc_tabq_new(env == 0 ? 25 : env == 9 ? 30 : env == 2 ? 36 : (env == 3 || env == 8) ? 63 : env == 7 ? 49 : env == 6 ? 56 : 48 /* island, whisky, super */, 0.5, 0.99, 0.05, 300);
     uint8_t* acts = malloc(400 * n);
     orc_tabq_rollout(envs, ag, n, 0, 3, 400, env == 2, m, acts);
     uint8_t rgb[3 * 64]; orc_render_rgb(envs, rgb);
