@@ -160,7 +160,12 @@ __global__ __launch_bounds__(64) void env_server_kernel(StepArgs a, SgkMailbox *
     const uint32_t req = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(word >> 32));
     if (req == last) {
+      // Nothing asked yet. A host loop that comes back within microseconds (tabular-Q: ~10 us between calls) finds the wave
+      // polling flat out; one that is away for longer (a DeepQ agent's torch kernels: ~2 ms) should not have a wave hammering
+      // PCIe reads next to its own work -- measured 13 % slower than a launch per step, profiles/r04/single_env.log -- so the
+      // polls thin out after the first 64 (s_sleep ~1 us each) and the server leaves after SGK_SERVER_IDLE_POLLS of them.
       if (++idle > SGK_SERVER_IDLE_POLLS) break;
+      if (idle > 64) __builtin_amdgcn_s_sleep(32);  // 32 x 64 clocks ~ 1 us
       continue;
     }
     if (req == SGK_SERVER_STOP) break;
