@@ -1076,6 +1076,15 @@ int sgk_copy_boards(sgk_env *h, int8_t *boards_host) {
   if (!boards_host) return fail(SGK_ERR_INVALID, "boards_host is NULL");
   sgk::Shard &s = h->sh;
   const size_t bytes = (size_t)s.n * s.n_cells;
+  if (h->host_visible) {
+    // The boards live in pinned HOST memory: wait for the stream, then read them with the CPU. (A hipMemcpyAsync between two host
+    // pointers is carried out by the runtime on the calling thread at once -- it is not ordered behind the kernels of the stream --
+    // so env.reset() now and then returned the board of the step BEFORE the reset kernel had written: one stale observation in
+    // ~5 000 resets, caught by the reference's train() goldens on the single env.)
+    SGK_HIP(hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < s.n; ++i) memcpy(boards_host + i * s.n_cells, s.boards + i * s.pitch, (size_t)s.n_cells);
+    return SGK_OK;
+  }
   if (s.pitch == s.n_cells) {
     SGK_HIP(hipMemcpyAsync(boards_host, s.boards, bytes, hipMemcpyDeviceToHost, h->stream));
   } else {
@@ -1090,6 +1099,11 @@ int sgk_copy_boards(sgk_env *h, int8_t *boards_host) {
 int sgk_copy_step_records(sgk_env *h, sgk_step_rec *rec_host) {
   SGK_CHECK_HANDLE(h);
   if (!rec_host) return fail(SGK_ERR_INVALID, "rec_host is NULL");
+  if (h->host_visible) {  // (host memory: synchronise, then a CPU copy -- see sgk_copy_boards)
+    SGK_HIP(hipStreamSynchronize(h->stream));
+    memcpy(rec_host, h->sh.rec, sizeof(uint32_t) * (size_t)h->sh.n);
+    return SGK_OK;
+  }
   SGK_HIP(hipMemcpyAsync(rec_host, h->sh.rec, sizeof(uint32_t) * h->sh.n, hipMemcpyDeviceToHost, h->stream));
   SGK_HIP(hipStreamSynchronize(h->stream));
   return SGK_OK;
@@ -1099,8 +1113,13 @@ int sgk_copy_episode_state(sgk_env *h, int32_t *episode_return_host, int32_t *hi
                            uint8_t *over_host, uint8_t *agent_cell_host, uint8_t *box_cell_host) {
   SGK_CHECK_HANDLE(h);
   std::vector<uint64_t> w((size_t)h->sh.n);
-  SGK_HIP(hipMemcpyAsync(w.data(), h->sh.state, sizeof(uint64_t) * w.size(), hipMemcpyDeviceToHost, h->stream));
-  SGK_HIP(hipStreamSynchronize(h->stream));
+  if (h->host_visible) {  // (host memory: synchronise, then a CPU copy -- see sgk_copy_boards)
+    SGK_HIP(hipStreamSynchronize(h->stream));
+    memcpy(w.data(), h->sh.state, sizeof(uint64_t) * w.size());
+  } else {
+    SGK_HIP(hipMemcpyAsync(w.data(), h->sh.state, sizeof(uint64_t) * w.size(), hipMemcpyDeviceToHost, h->stream));
+    SGK_HIP(hipStreamSynchronize(h->stream));
+  }
   for (size_t i = 0; i < w.size(); ++i) {
     uint32_t lo = (uint32_t)w[i], hi = (uint32_t)(w[i] >> 32);
     if (agent_cell_host) agent_cell_host[i] = (uint8_t)(lo & 0xff);

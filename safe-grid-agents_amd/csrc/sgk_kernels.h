@@ -68,7 +68,7 @@ struct SgkMailbox {
   uint32_t pad3[15];
 };
 #define SGK_SERVER_STOP 0xffffffffu
-#define SGK_SERVER_IDLE_POLLS 400u  // ~64 back-to-back PCIe polls, then ~0.4 ms of polls a microsecond apart: then the server leaves
+#define SGK_SERVER_IDLE_US 100  // the step server leaves after this long without a request (wall_clock64: 100 MHz)
 hipError_t launch_env_server(const Shard &sh, const uint8_t *actions, SgkMailbox *mb, uint32_t last, hipStream_t st);
 hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flags, hipStream_t st);
 // the same loop with every step's board tile and step record materialised: into the env's own buffers (rings == nullptr) or

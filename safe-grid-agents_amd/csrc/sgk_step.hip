@@ -130,7 +130,7 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
 // mailbox in pinned, device-mapped HOST memory: the host writes the action(s) and a request number, the wave polls the number
 // over PCIe, steps its envs (state words in registers between steps, rule tables staged once), writes state word / step record /
 // board tile to the host-visible buffers, fences to system scope and publishes the number. The server leaves by itself after
-// SGK_SERVER_IDLE_POLLS polls without work (a host that went away cannot strand it) and whenever the host asks (request ==
+// SGK_SERVER_IDLE_US microseconds without work (a host that went away cannot strand it) and whenever the host asks (request ==
 // SGK_SERVER_STOP): every other entry point stops it first, so the arrays in memory are always current outside sgk_step_host.
 // ------------------------------------------------------------------------------------------------
 template <int ENV, int LAYOUT>
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void env_server_kernel(StepArgs a, SgkMailbox *
   load_episode_index<ENV>(s, a.n_resets, env, valid);
   EpisodeAcc acc;
   acc_init(acc);
-  uint32_t idle = 0;
+  unsigned long long idle_since = 0;  // wall_clock64() of the first poll without a request, 0 = busy
   for (;;) {
     // lane 0's system-scope load is the poll (one PCIe read); the word is made wave-uniform before it steers control flow
     uint64_t word = 0;
@@ -160,16 +160,16 @@ __global__ __launch_bounds__(64) void env_server_kernel(StepArgs a, SgkMailbox *
     const uint32_t req = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(word >> 32));
     if (req == last) {
-      // Nothing asked yet. A host loop that comes back within microseconds (tabular-Q: ~10 us between calls) finds the wave
-      // polling flat out; one that is away for longer (a DeepQ agent's torch kernels: ~2 ms) should not have a wave hammering
-      // PCIe reads next to its own work -- measured 13 % slower than a launch per step, profiles/r04/single_env.log -- so the
-      // polls thin out after the first 64 (s_sleep ~1 us each) and the server leaves after SGK_SERVER_IDLE_POLLS of them.
-      if (++idle > SGK_SERVER_IDLE_POLLS) break;
-      if (idle > 64) __builtin_amdgcn_s_sleep(32);  // 32 x 64 clocks ~ 1 us
+      // Nothing asked yet. The server leaves after SGK_SERVER_IDLE_US of that, by the constant 100 MHz clock: a host loop that
+      // comes back within microseconds (tabular-Q: ~13 us between an answer and the next request) keeps finding it; one that is
+      // away for longer (a DeepQ agent's torch kernels, ~2 ms) finds the device free -- a device-wide synchronisation in the
+      // caller's process waits for every resident kernel, this wave included, so the budget bounds what such a call can cost.
+      if (idle_since == 0) idle_since = wall_clock64();
+      else if (wall_clock64() - idle_since > (unsigned long long)SGK_SERVER_IDLE_US * 100ull) break;
       continue;
     }
     if (req == SGK_SERVER_STOP) break;
-    idle = 0;
+    idle_since = 0;
     const uint32_t flags = hi & 0xffu;
     int action = (int)((hi >> 8) & 3u);  // env 0's action rides in the request word
     if (a.n > 1) {

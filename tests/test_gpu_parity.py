@@ -1185,6 +1185,70 @@ def test_rccl_metrics_allreduce_through_the_c_abi_world_of_one():
     env.close()
 
 
+@pytest.mark.parametrize("name,n", [("ConveyorBelt-v0", 1), ("SideEffectsSokoban-v0", 3)])
+def test_step_server_leaving_and_returning_around_every_call_loses_and_repeats_nothing(name, n):
+    """Host pauses scattered around the server's idle budget (0 .. 120 us between calls): the resident wave leaves while a request
+    is on its way, has just left, or is still there -- 6 000 steps, each checked against the oracle (a repeated or lost step shows in
+    the frame counter, the rewards and the board)."""
+    import time
+
+    _torch()
+    seed = 11
+    env = S.BatchedGridworldEnv(name, n, seed=seed, host_visible=True)
+    orc = O.EnvBatch(name, n, seed=seed)
+    rng = np.random.RandomState(5)
+    rec = np.zeros((n, 4), dtype=np.int8)
+    boards = np.zeros((n, env.n_cells), dtype=np.int8)
+    ret = np.zeros(n, dtype=np.int32)
+    pauses = rng.randint(0, 120, size=6000) * 1e-6
+    for t in range(6000):
+        acts = rng.randint(0, 4, size=n).astype(np.uint8)
+        _lib.check(env.lib.sgk_step_host(env.handle, acts.ctypes.data, _lib.F_AUTO_RESET, rec.ctypes.data, boards.ctypes.data,
+                                         ret.ctypes.data))
+        want = orc.rollout(1, seed=seed, actions=acts[None], auto_reset=True)
+        assert (rec == want).all() and (boards == orc.boards()).all() and (ret == orc.field("episode_return")).all(), t
+        end = time.perf_counter() + pauses[t]
+        while time.perf_counter() < end:
+            pass
+    assert_same_state(env, orc, "after 6000 served steps")
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["ConveyorBelt-v0", "SideEffectsSokoban-v0", "IslandNavigation-v0"])
+def test_single_env_under_the_train_loops_call_pattern_with_pauses_equals_the_oracle_env(name):
+    """The gym-shaped single env driven the way train() drives it -- step, and at every episode end the metrics reads
+    (episode_return, get_last_performance: other entry points, which stop the step server) and reset() -- with host pauses of
+    0 .. 150 us scattered around the server's idle budget, against the oracle's gym shim on the same actions: observation, reward,
+    done, info and the metrics reads of 8 000 steps."""
+    import time
+
+    from oracle.gym_shim import OracleGridworldEnv
+
+    _torch()
+    env, ref = S.make(name), OracleGridworldEnv(name)
+    env.seed(3); ref.seed(3)
+    rng = np.random.RandomState(17)
+    a, b = env.reset(), ref.reset()
+    assert (a == b).all()
+    pauses = rng.randint(0, 150, size=8000) * 1e-6
+    episodes = 0
+    for t in range(8000):
+        act = int(rng.randint(0, 4))
+        so, ro, do, io = env.step(act)
+        sr, rr, dr, ir = ref.step(act)
+        assert (so == sr).all() and (ro, do) == (rr, dr) and io["hidden_reward"] == ir["hidden_reward"], (t, act, ro, rr, do, dr)
+        assert io["extra_observations"]["actual_actions"] == ir["extra_observations"]["actual_actions"], t
+        end = time.perf_counter() + pauses[t]
+        while time.perf_counter() < end:
+            pass
+        if do:
+            assert env._env.episode_return == ref._env.episode_return and env._env.get_last_performance() == ref._env.get_last_performance(), t
+            a, b = env.reset(), ref.reset()
+            assert (a == b).all(), t
+            episodes += 1
+    assert episodes >= 8000 // 100
+
+
 @pytest.mark.parametrize("name,n", [("BoatRace-v0", 1), ("WhiskyGold-v0", 37), ("FriendFoe-v0", 64), ("TomatoWatering-v0", 5)])
 def test_step_server_serves_host_steps_bit_exactly(name, n):
     """sgk_step_host on a host-visible handle of <= 64 envs is served by a resident wave (no launch per step): results equal the
