@@ -283,12 +283,6 @@ __device__ __forceinline__ double sel64(bool c, double a, double b) {
   return bits_f64(((uint64_t)hi << 32) | lo);
 }
 
-// NT = registers of the transition table in use: 1 or 2 = up to 16 / 32 live cells (BoatRace 8, IslandNavigation 20,
-// DistributionalShift 28); a level with more goes to the HBM-resident kernel. The kernel is the same for every level whose state
-// is the agent's cell: nothing else depends on the level.
-// (Tried: 32 agents per wave -- image [.][32], twice the waves per CU, two per SIMD to fill each other's stalls. Slower: 2.41 vs
-// 1.79 us per step at 262 144 IslandNavigation agents, 1.87 vs 1.33 BoatRace, 3.58 vs 3.73 DistributionalShift
-// (profiles/r04/tabq_agents_per_wave_ab.log): the loop is bound by instruction issue, not by exposed latency.)
 // v_max_f64 as ONE instruction (fmax() is llvm.maxnum: in IEEE mode the compiler first canonicalises both operands with a v_max_f64
 // x, x each, which gives the three instructions back)
 __device__ __forceinline__ double max_f64(double a, double b) {
@@ -297,6 +291,12 @@ __device__ __forceinline__ double max_f64(double a, double b) {
   return r;
 }
 
+// NT = registers of the transition table in use: 1 or 2 = up to 16 / 32 live cells (BoatRace 8, IslandNavigation 20,
+// DistributionalShift 28); a level with more goes to the HBM-resident kernel. The kernel is the same for every level whose state
+// is the agent's cell: nothing else depends on the level.
+// (Tried: 32 agents per wave -- image [.][32], twice the waves per CU, two per SIMD to fill each other's stalls. Slower: 2.41 vs
+// 1.79 us per step at 262 144 IslandNavigation agents, 1.87 vs 1.33 BoatRace, 3.58 vs 3.73 DistributionalShift
+// (profiles/r04/tabq_agents_per_wave_ab.log): the loop is bound by instruction issue, not by exposed latency.)
 template <int NT>
 __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int32_t n_steps) {
   extern __shared__ __attribute__((aligned(16))) double Q[];  // [n_live * 4][64]
