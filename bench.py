@@ -559,6 +559,9 @@ def main():
     ap.add_argument("--rings", type=int, default=3,
                     help="how many fresh primary rings the timed region is repeated on (value = the median ring; path ring only)")
     ap.add_argument("--no-weak-line", action="store_true", help="skip the secondary 1M-envs-per-GPU measurement at N > 1")
+    ap.add_argument("--sustain-seconds", type=float, default=3.0,
+                    help="after the timed region: the primary path's launches back to back for about this long (device time), as "
+                         "`sustained` -- long enough for a coarse busy / clock sampler to see the kernel; 0 skips it")
     ap.add_argument("--config", type=int, default=0, choices=(0, 2, 3, 4),
                     help="instead of the headline: BASELINE.json's config 2 (BoatRace 65 536 envs, step kernel), 3 (IslandNavigation + "
                          "tabular-q, 262 144 agents) or 4 (Sokoban + deep-q MLP, 32 768 envs) on ONE GPU, as one JSON object with its own "
@@ -762,6 +765,23 @@ def run_rank(args):
                          "exists); rank 0's device time" % fused_steps}
     ok, n_checked = parity_sample(env, args.env, args.seed, base, total_steps)
 
+    sustained = None
+    if args.sustain_seconds > 0:
+        # The timed region is K x 100 lockstep steps = milliseconds of device work: a one-second busy sampler sees an idle GPU. The
+        # same launches, back to back for seconds, on the last primary ring (rewritten lap after lap; after the parity sample: the
+        # oracle does not follow these steps) -- whether the rate holds when the chip is warm and the clocks have settled.
+        k_s = int(args.sustain_seconds / (kernel_ms * 1e-3 / k_lock) / GRAPH_CHUNK + 0.5) * GRAPH_CHUNK  # (kernel_ms: max over ranks)
+        k_s = max(GRAPH_CHUNK, min(k_s, 4000 * GRAPH_CHUNK))
+        s_el, s_ms, _ = timed_steps(env, k_s, 0, barrier, sdist.global_metrics, path=args.path, ring=ring)
+        s_el, s_ms = max_over_ranks(s_el, s_ms)
+        gpu_leg_ms += s_ms
+        sustained = {"value": n_total * k_s / s_el, "unit": "env-steps/s", "lockstep_steps": k_s, "seconds": s_el,
+                     "us_per_lockstep_step": s_el * 1e6 / k_s, "device_us_per_lockstep_step": s_ms * 1e3 / k_s,
+                     "frac": None if args.path != "ring" else algorithmic_bytes_per_env_step(args.env, args.path) * n_local
+                     / (s_ms * 1e-3 / k_s) / 1e9 / HBM_PEAK_GBS,
+                     "note": "the primary path's launches back to back on the last primary ring, host clock around all of them "
+                             "(not part of `value`; not followed by the oracle)"}
+
     weak_line = None
     if world > 1 and not weak and not args.no_weak_line:
         # secondary: the weak-scaling form (1 048 576 envs on EVERY GPU), same K / W, same bracket
@@ -869,6 +889,8 @@ def run_rank(args):
             "bytes": ring_alloc["bytes"]}
     if ring_spread:
         out["other_ring_allocations"] = ring_spread
+    if sustained:
+        out["sustained"] = sustained
     if weak_line:
         out["weak_1m_per_gpu"] = weak_line
     if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line only

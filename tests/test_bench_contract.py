@@ -104,15 +104,20 @@ def test_bench_line_one_rank():
     assert d["ring_allocation"]["backing"].startswith("sgk_ring_alloc") and d["ring_allocation"]["bytes"] == 100 * 8192 * 29
     spread = d["other_ring_allocations"]  # what other fresh rings get in the same process: the allocation lottery, shown
     assert spread["rings"] == 3 and len(spread["device_us_per_lockstep_step"]) == 3 and min(spread["device_us_per_lockstep_step"]) > 0
+    su = d["sustained"]  # the same launches back to back for seconds (capped at 4 000 launches: this batch is small), not `value`
+    assert su["lockstep_steps"] % 100 == 0 and 100 <= su["lockstep_steps"] <= 400000 and su["frac"] > 0
+    assert abs(su["value"] - 8192 * su["lockstep_steps"] / su["seconds"]) <= 1e-6 * su["value"]
+    assert su["device_us_per_lockstep_step"] <= su["us_per_lockstep_step"] and d["gpu_leg_device_ms"] >= su["device_us_per_lockstep_step"] * su["lockstep_steps"] / 1e3
     # another path as the primary one, and round 1's step definition
     d2 = _line(["--steps", "40", "--warmup", "10", "--total-envs", "8192", "--path", "launch", "--lockstep-per-step", "1",
-                "--no-cpu-baseline", "--no-fused"])
+                "--no-cpu-baseline", "--no-fused", "--sustain-seconds", "0.05"])
     _check_contract(d2, 1, 40, 10)
-    assert d2["roofline"]["steps_per_launch"] == 1 and "cpu_baseline" not in d2
+    assert d2["roofline"]["steps_per_launch"] == 1 and "cpu_baseline" not in d2 and d2["sustained"]["frac"] is None
     assert d2["kept_in_trajectory_ring"]["bound"] == "hbm" and d2["rewritten_in_place"]["value"] > 0
     d3 = _line(["--steps", "3", "--warmup", "1", "--total-envs", "8192", "--path", "own", "--no-cpu-baseline", "--no-fused",
-                "--no-secondary"])
+                "--no-secondary", "--sustain-seconds", "0"])
     _check_contract(d3, 1, 3, 1)
+    assert "sustained" not in d3
     d4 = _line(["--steps", "3", "--warmup", "1", "--total-envs", "8192", "--ring-backing", "torch", "--no-cpu-baseline", "--no-fused",
                 "--no-secondary"])
     _check_contract(d4, 1, 3, 1)
@@ -123,20 +128,20 @@ def test_bench_line_one_rank():
 def test_bench_line_two_ranks_on_one_gpu_shards_the_batch():
     """`python bench.py --gpus 2` starts its ranks itself (torch.distributed.run as a child, before any GPU call); the batch is
     cut into two contiguous env-id blocks; the line reports the whole job."""
-    d = _line(["--gpus", "2", "--steps", "3", "--warmup", "1", "--total-envs", "8192", "--no-fused"],
+    d = _line(["--gpus", "2", "--steps", "3", "--warmup", "1", "--total-envs", "8192", "--no-fused", "--sustain-seconds", "0.2"],
               env={"SGK_BENCH_BACKEND": "gloo", "SGK_BENCH_ONE_DEVICE": "1"})
     _check_contract(d, 2, 3, 1)
     assert d["scaling"] == "strong" and d["config"]["envs_per_gpu"] == 4096 and d["config"]["total_envs"] == 8192
     assert d["weak_1m_per_gpu"]["total_envs"] == 2 << 20 and "cpu_baseline" not in d
     assert d["episodes_finished"] == 8192 * 3  # every env of both shards finished one episode per bench step
-    assert d["metrics_collective"] == "torch.distributed (gloo)" and d["rccl_ranks"] is None
+    assert d["metrics_collective"] == "torch.distributed (gloo)" and d["rccl_ranks"] is None and d["sustained"]["value"] > 0
 
 
 @pytest.mark.gpu
 def test_bench_line_eight_ranks_dry_run_on_one_gpu():
     """The driver's 8-GPU launch, rehearsed on the one GPU of a test box (gloo collectives): eight ranks, eight contiguous env-id
     shards, one line with eight device times (what an 8-GPU node adds is RCCL and seven more devices, not control flow)."""
-    d = _line(["--gpus", "8", "--steps", "2", "--warmup", "1", "--total-envs", "16384", "--no-fused", "--no-weak-line"],
+    d = _line(["--gpus", "8", "--steps", "2", "--warmup", "1", "--total-envs", "16384", "--no-fused", "--no-weak-line", "--sustain-seconds", "0.2"],
               env={"SGK_BENCH_BACKEND": "gloo", "SGK_BENCH_ONE_DEVICE": "1"}, timeout=900)
     _check_contract(d, 8, 2, 1)
     assert d["config"]["envs_per_gpu"] == 2048 and d["scaling"] == "strong" and d["episodes_finished"] == 16384 * 2
