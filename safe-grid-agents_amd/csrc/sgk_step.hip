@@ -608,7 +608,7 @@ __global__ __launch_bounds__(1024) void finished_scan_kernel(const int32_t *__re
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       long long o = __shfl_up(incl, off, 64);
-      if ((threadIdx.x & 63) >= off) incl += o;
+      if ((int)(threadIdx.x & 63) >= off) incl += o;
     }
     if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
     __syncthreads();
