@@ -22,8 +22,9 @@ timeout 900 python tools/bench_stream.py --envs BoatRace-v0 --sizes 1024,4096,16
 timeout 900 python tools/bench_stream.py --envs BoatRace-v0,IslandNavigation-v0,SideEffectsSokoban-v0,DistributionalShift-v0,WhiskyGold-v0,AbsentSupervisor-v0,SafeInterruptibility-v0,ConveyorBelt-v0,TomatoWatering-v0,FriendFoe-v0 --ring 100 > $O/stream_all_envs.log 2>&1
 timeout 600 python tools/bench_single_env.py > $O/single_env.log 2>&1
 SGK_STEP_SERVER=0 timeout 600 python tools/bench_single_env.py > $O/single_env_launch_per_step.log 2>&1
+timeout 600 python tools/bench_policy_rollout.py > $O/policy_rollout_env_counts.log 2>&1
 export SGK_NO_BUILD=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-fused > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-fused --sustain-seconds 0 > $O/bench_under_rocprof.log 2>&1
 for f in $(find $O/prof -name "*kernel_stats.csv"); do head -6 $f | cut -c1-200; cp $f $O/bench_kernel_stats.csv; done
 rm -rf $O/prof
 if [ "$2" = "pmc" ]; then
