@@ -88,7 +88,8 @@ __global__ __launch_bounds__(WG) void eps_greedy_kernel(const float4 *__restrict
 // A wave owns NT = 2 env tiles (32 envs) per pass so that every A operand read from LDS feeds two MFMAs and 14 independent
 // accumulators cover the 40-cycle dependent latency; a workgroup of 4 waves = 128 envs, i.e. at 32 768 envs one wave per
 // SIMD on all 1 024 SIMDs. Work per 32 envs: (MT * ceil(K0 / 4) + MT * 4 MT + 4 MT) * 2 MFMAs of 32 cycles
-// = 574 MFMAs = 18.4 k cycles at H = 100, K0 = 36 (8.4 us at the ~2.2 GHz the kernel runs at). Measured in-kernel at 32 768
+// = 574 MFMAs = 18.4 k cycles at H = 100, K0 = 36 (8.4 us at the ~2.2 GHz the kernel runs at; 526 since round 4: the partial
+// tile's k-steps, PolicyMfmaGeom below). Measured in-kernel (round 1, 574 MFMAs) at 32 768
 // envs (clock64): 5.1 k cycles until the first tile and W1 are staged (one cold memory round trip), 5.7 k layer 1, 14.8 k
 // layer 2 (incl. the W2 commit), 4.0 k layer 3 + draw + stores = 14.5 us per launch; 10.0 us per 128-env pass in steady
 // state at 1 M envs (84 % of the MFMA issue bound; the useful-FLOP rate is 82 TFLOP/s f32 because of the 100 -> 112 padding).
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(PMFMA_WG) void policy_mfma_kernel(const int8_t *__r
 // for the whole rollout. A wave owns 32 envs (lanes 0..31 hold their state words); their boards live as rows of the
 // workgroup's LDS tile -- the MFMA forward reads them there -- and are kept current by re-drawing only the cells a step
 // changed. Everything a wave touches in the loop is its own (its 32 tile rows, its lanes' registers), so the step loop has
-// no workgroup barrier. Per step and wave: 574 MFMAs (H = 100), one Philox block, one table lookup, <= 4 LDS byte writes,
+// no workgroup barrier. Per step and wave: 526 MFMAs (H = 100), one Philox block, one table lookup, <= 4 LDS byte writes,
 // and the optional trajectory stores (board rows as dwords, one action byte, one 4-byte record per env).
 // ------------------------------------------------------------------------------------------------
 struct RolloutArgs {
