@@ -28,10 +28,12 @@ def env_from_torchrun():
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
 
 
-def init_process_group(backend=None, timeout_s=None):
+def init_process_group(backend=None, timeout_s=None, rendezvous_s=None):
     """One process per GPU. backend 'nccl' IS RCCL on ROCm; 'gloo' for the CPU tests. Collectives time out after `timeout_s`
     seconds (default 120, SGK_DIST_TIMEOUT_S overrides): the path's only exchange is a 96-byte all-reduce, so a rank that waits
-    longer than that is waiting for a rank that died -- it fails instead of parking the job until a launcher's limit."""
+    longer than that is waiting for a rank that died -- it fails instead of parking the job until a launcher's limit. The
+    RENDEZVOUS gets `rendezvous_s` (default 600, SGK_DIST_RENDEZVOUS_S; never less than timeout_s): ranks of a fresh box reach it
+    minutes apart while the image pages in, and nobody has died yet."""
     import datetime
 
     import torch
@@ -47,7 +49,21 @@ def init_process_group(backend=None, timeout_s=None):
             torch.cuda.set_device(local_rank)
         if timeout_s is None:
             timeout_s = float(os.environ.get("SGK_DIST_TIMEOUT_S", "120"))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+        if rendezvous_s is None:
+            rendezvous_s = float(os.environ.get("SGK_DIST_RENDEZVOUS_S", "600"))
+        rendezvous_s = max(float(rendezvous_s), float(timeout_s))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=rendezvous_s))
+        if rendezvous_s > timeout_s:
+            # every rank is here: from now on a wait is a wait for a dead rank. (A private torch call -- there is no public one that
+            # changes a live group's timeout; a torch without it keeps the rendezvous' figure and says so.)
+            try:
+                from torch.distributed.distributed_c10d import _set_pg_timeout
+
+                _set_pg_timeout(datetime.timedelta(seconds=timeout_s), dist.group.WORLD)
+            except Exception as err:  # noqa: BLE001
+                import sys
+
+                sys.stderr.write("safe_grid_agents_amd.dist: collectives keep the rendezvous timeout of %.0f s (%s)\n" % (rendezvous_s, err))
     return rank, local_rank, world
 
 

@@ -116,3 +116,42 @@ def test_a_rank_that_dies_after_the_rendezvous_ends_the_job_quickly(tmp_path):
     outs = [q.communicate(timeout=200) for q in procs]
     took = time.time() - t0
     assert procs[1].returncode == 1 and procs[0].returncode != 0 and took < 150, ([q.returncode for q in procs], took, outs[0][1][-1500:])
+
+
+_LATE_SCRIPT = """
+import os, sys, time
+sys.path[:0] = [%r, %r]
+import torch, torch.distributed as dist
+from safe_grid_agents_amd import dist as sdist
+
+rank, _, world = sdist.init_process_group("gloo", timeout_s=4)  # (rendezvous: the default 600 s)
+dist.barrier()
+t0 = time.time()
+if rank == 1:
+    time.sleep(20)  # alive, but not coming
+    os._exit(0)
+try:
+    dist.all_reduce(torch.ones(1))
+    print("returned", flush=True)
+except Exception as err:
+    print("failed after %%.1f s" %% (time.time() - t0), flush=True)
+os._exit(0)
+"""
+
+
+def test_collectives_time_out_after_timeout_s_not_after_the_rendezvous_timeout(tmp_path):
+    """init_process_group gives the rendezvous 600 s (ranks of a fresh box arrive minutes apart) and every collective after it
+    `timeout_s`: a rank waiting for a peer that is alive but never comes fails after timeout_s."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "late_rank.py"
+    script.write_text(_LATE_SCRIPT % (root, os.path.join(root, "safe-grid-agents_amd")))
+    env0 = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env0, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [q.communicate(timeout=120) for q in procs]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith(("failed", "returned"))]
+    assert line and line[0].startswith("failed after"), outs[0]
+    assert 3.0 <= float(line[0].split()[2]) <= 15.0, line
