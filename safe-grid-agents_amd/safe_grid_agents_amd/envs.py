@@ -178,6 +178,10 @@ class BatchedGridworldEnv:
         return self.lib.sgk_get_stream(self._h.ptr)
 
     def torch_stream(self):
+        """The library's own HIP stream as a torch.cuda.ExternalStream (torch does not own it: it dies with close()). Whatever
+        torch remembers the stream for must be gone by then -- in particular PINNED host tensors copied to / from on it: torch's
+        pinned-memory allocator records an event on every stream a block was used on when the block is freed, and recording on a
+        destroyed stream is a crash. Free (or `del`) such tensors before close()."""
         import torch
 
         if self._tstream is None:
