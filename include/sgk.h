@@ -145,6 +145,9 @@ SGK_API int sgk_set_seed(sgk_env *h, uint64_t seed);
 SGK_API int sgk_get_info(const sgk_env *h, sgk_info *out);
 SGK_API int sgk_set_stream(sgk_env *h, void *hip_stream); /* NULL restores the handle's own stream */
 SGK_API int sgk_use_default_stream(sgk_env *h);           /* enqueue on the device's NULL (legacy default) stream */
+/* The stream the handle enqueues on. The handle's OWN stream is never destroyed: after sgk_destroy it waits in a per-device pool
+ * for the next sgk_create on that device, so a caller-side object that still remembers it (an event to record, a wrapper) finds a
+ * valid stream. */
 SGK_API void *sgk_get_stream(const sgk_env *h);
 SGK_API int sgk_synchronize(sgk_env *h); /* waits for the handle's stream */
 /* Stream ordering against another HIP stream of the same device (e.g. torch's current stream, where the policy network

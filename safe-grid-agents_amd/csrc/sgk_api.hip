@@ -195,6 +195,33 @@ int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agen
   return SGK_OK;
 }
 
+// A handle's own stream outlives the handle: sgk_stream() hands it to the caller (the Python wrapper wraps it as a
+// torch.cuda.ExternalStream), and a caller-side object that remembers it -- torch's pinned-memory allocator records an event on
+// every stream a block was used on when the block is freed -- must never find a destroyed stream there. Streams of destroyed handles
+// wait in a per-device pool for the next sgk_create on that device; a process holds as many as it ever had handles alive at once.
+namespace {
+std::mutex g_stream_pool_mutex;
+std::map<int, std::vector<hipStream_t>> g_stream_pool;
+
+hipError_t pooled_stream(int device, hipStream_t *out) {
+  {
+    std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+    auto &free_streams = g_stream_pool[device];
+    if (!free_streams.empty()) {
+      *out = free_streams.back();
+      free_streams.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void return_stream(int device, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+  g_stream_pool[device].push_back(st);
+}
+}  // namespace
+
 int sgk_destroy(sgk_env *h) {
   if (!h) return SGK_OK;
   (void)hipSetDevice(h->sh.device);
@@ -221,7 +248,7 @@ int sgk_destroy(sgk_env *h) {
   if (h->metrics_pinned) (void)hipHostFree(h->metrics_pinned);
   for (int i = 0; i < 2; ++i)
     if (h->order_events[i]) (void)hipEventDestroy(h->order_events[i]);
-  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  if (h->own_stream) return_stream(h->sh.device, h->own_stream);  // (idle: synchronised above)
   delete h;
   return SGK_OK;
 }
@@ -293,7 +320,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   }
   // the outputs-once rollout is issue-bound and register-light (64 VGPRs: 8 waves per SIMD fit)
   s.rollout_grid = s.n_cus * 12;  // measured at 1 M envs: 6 / 8 / 12 / 16 per CU = 0.428 / 0.450 / 0.408 / 0.411 us per step (BoatRace)
-  SGK_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  SGK_TRY(pooled_stream(device, &h->own_stream));
   h->stream = h->own_stream;
   const int64_t n_pad = ((s.n + 255) / 256) * 256;
   const int64_t n_wg = n_pad / 256;

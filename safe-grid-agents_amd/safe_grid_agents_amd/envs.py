@@ -178,10 +178,9 @@ class BatchedGridworldEnv:
         return self.lib.sgk_get_stream(self._h.ptr)
 
     def torch_stream(self):
-        """The library's own HIP stream as a torch.cuda.ExternalStream (torch does not own it: it dies with close()). Whatever
-        torch remembers the stream for must be gone by then -- in particular PINNED host tensors copied to / from on it: torch's
-        pinned-memory allocator records an event on every stream a block was used on when the block is freed, and recording on a
-        destroyed stream is a crash. Free (or `del`) such tensors before close()."""
+        """The library's own HIP stream as a torch.cuda.ExternalStream. torch does not own it; the library never destroys it
+        either (streams of closed envs wait in a pool for the next env of the device), so torch-side objects that remember it --
+        pinned host tensors copied on it record an event there when they are freed -- stay valid after close()."""
         import torch
 
         if self._tstream is None:

@@ -1409,3 +1409,39 @@ def test_tomato_watering_units_scale_and_hashed_tables():
         assert (s[0] == ref.board(0)).all()
     assert d and single._env.get_last_performance() == hid
     single.close()
+
+
+@pytest.mark.gpu
+def test_the_envs_stream_outlives_the_env_for_torch_objects_that_remember_it():
+    """A closed env's stream goes to a per-device pool, not to hipStreamDestroy: a pinned host tensor that was copied on
+    env.torch_stream() records an event on that stream when it is freed -- after close() that used to be a segmentation fault --,
+    and the next env of the device takes the pooled stream. (In a child process: the failure mode is a crash.)"""
+    import subprocess
+    import sys
+
+    code = """
+import sys
+sys.path[:0] = [%r, %r]
+import torch
+import safe_grid_agents_amd as S
+env = S.BatchedGridworldEnv("BoatRace-v0", 4096, seed=3, layout="compact")
+st = env.torch_stream()
+host = torch.empty((4096, env.n_cells), dtype=torch.int8).pin_memory()
+with torch.cuda.stream(st):
+    boards, _, _, _ = env.step(torch.zeros(4096, dtype=torch.uint8, device="cuda"), auto_reset=True)
+    host.copy_(boards.reshape(4096, env.n_cells), non_blocking=True)
+    env.synchronize()
+ptr = env.stream_ptr
+want = env.boards_host().reshape(4096, -1)
+assert (host.numpy() == want).all()
+env.close()
+del host, boards          # the pinned block is freed AFTER the env: an event is recorded on the env's stream
+torch.cuda.synchronize()
+again = S.BatchedGridworldEnv("IslandNavigation-v0", 64, seed=1)
+assert again.stream_ptr == ptr, (again.stream_ptr, ptr)
+again.step_random(3)
+again.close()
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "safe-grid-agents_amd"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ok" in p.stdout, (p.returncode, p.stderr[-2000:])

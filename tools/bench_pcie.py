@@ -54,8 +54,7 @@ def main():
         print("%s n=%d: device-resident %.1f us/step (%.3g env-steps/s) | + actions from the host %.1f | + records to the host %.1f | "
               "+ boards to the host %.1f us/step = %.3g env-steps/s PCIe-inclusive (%.1f GB/s over the link)"
               % (name, n, a, n / a * 1e6, b, c, d, n / d * 1e6, n * (env.n_cells + 5) / d / 1e3))
-        del host_actions, host_boards, host_recs, loop  # pinned blocks record an event on the streams they were used on when freed:
-        env.close()                                     # before the env's stream goes (envs.torch_stream)
+        env.close()
 
 
 if __name__ == "__main__":
