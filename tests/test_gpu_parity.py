@@ -1445,3 +1445,32 @@ print("ok")
 """ % (ROOT, os.path.join(ROOT, "safe-grid-agents_amd"))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "ok" in p.stdout, (p.returncode, p.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_create_use_destroy_cycles_give_their_memory_back():
+    """60 cycles of env + private tabular agents + a trajectory ring from the library's allocator, each used and closed: the
+    device's free memory ends where it started (the runtime's own pools allowed for), the pooled stream is one and the same."""
+    torch = _torch()
+    import gc
+
+    def cycle(i):
+        env = S.BatchedGridworldEnv(("BoatRace-v0", "IslandNavigation-v0", "TomatoWatering-v0")[i % 3], 65536, seed=i)
+        agent = S.BatchedTabularQAgent(env, _tabq_args())
+        agent.rollout(20)
+        rb, rr, _ = env.alloc_trajectory_ring(8)
+        env.rollout_random_stream(8, boards=rb, recs=rr)
+        env.synchronize()
+        ptr = env.stream_ptr
+        del rb, rr
+        agent.close(); env.close()
+        return ptr
+
+    streams = {cycle(i) for i in range(3)}  # (first touches: code objects, the runtime's pools)
+    gc.collect(); torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    streams |= {cycle(i) for i in range(60)}
+    gc.collect(); torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert len(streams) == 1
+    assert free0 - free1 < 64 << 20, (free0, free1)
