@@ -1474,3 +1474,64 @@ def test_create_use_destroy_cycles_give_their_memory_back():
     free1, _ = torch.cuda.mem_get_info()
     assert len(streams) == 1
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ENVS)
+@pytest.mark.parametrize("plan_seed,n", [(1, 37), (2, 257), (3, 1000)])
+def test_random_schedules_of_every_kind_of_step_stay_exact(name, plan_seed, n):
+    """The fixed interleaving above, drawn at random: 36 operations per plan -- random-action steps as graph replays / the fused
+    rollout / the streamed rollout (into the env's own buffers and into a small trajectory ring), given-action and repeated-action
+    steps, reset_done, masked resets, auto-reset on and off -- with random step counts, on ragged batch sizes; the oracle follows
+    the same plan and is compared after every operation."""
+    torch = _torch()
+    seed = 100 + plan_seed
+    env = S.BatchedGridworldEnv(name, n, seed=seed, layout=("pitched", "compact")[plan_seed % 2])
+    orc = O.EnvBatch(name, n, seed=seed)
+    rng = np.random.RandomState(plan_seed * 7919 + len(name))
+    ring_b = torch.empty((5, n, env.n_cells), dtype=torch.int8, device="cuda")
+    ring_r = torch.empty((5, n, 4), dtype=torch.int8, device="cuda")
+    t = 0
+    for op_i in range(36):
+        op = rng.choice(["graph", "fused", "stream", "ring", "given", "repeat", "reset_done", "mask", "noreset"])
+        k = int(rng.choice([1, 1, 2, 3, 5, 17, 64, 101]))
+        what = "%s op %d: %s k=%d at t=%d" % (name, op_i, op, k, t)
+        if op in ("graph", "fused", "stream", "noreset"):
+            auto = op != "noreset"
+            env.step_random(k, auto_reset=auto, fused={"graph": False, "noreset": False, "fused": True, "stream": "stream"}[op])
+            orc.rollout(k, seed=seed, t_begin=t, auto_reset=auto)
+            t += k
+        elif op == "ring":
+            first = int(rng.randint(0, 5))
+            env.rollout_random_stream(k, boards=ring_b, recs=ring_r, first_slice=first)
+            for j in range(k):
+                rec = orc.rollout(1, seed=seed, t_begin=t + j, auto_reset=True)
+                if j >= k - 5:  # the last five steps are still in the ring
+                    sl = (first + j) % 5
+                    assert (ring_b[sl].cpu().numpy() == orc.boards()).all(), what
+                    assert (ring_r[sl].cpu().numpy() == np.asarray(rec)).all(), what
+            t += k
+        elif op == "given":
+            acts = rng.randint(0, 4, size=n).astype(np.uint8)
+            auto = bool(rng.randint(0, 2))
+            env.step(torch.as_tensor(acts, device="cuda"), auto_reset=auto)
+            orc.rollout(1, seed=seed, actions=acts[None], auto_reset=auto)
+            t += 1
+        elif op == "repeat":
+            k = min(k, 17)
+            acts = rng.randint(0, 4, size=n).astype(np.uint8)
+            env.step_repeat(torch.as_tensor(acts, device="cuda"), k, auto_reset=True)
+            orc.rollout(k, seed=seed, actions=np.repeat(acts[None], k, axis=0), auto_reset=True)
+            t += k
+        elif op == "reset_done":
+            env.reset_done()
+            for i in np.nonzero(orc.field("game_over"))[0]:
+                orc.reset(int(i))
+        else:
+            m = (rng.rand(n) < 0.2).astype(np.uint8)
+            env.reset(torch.as_tensor(m, device="cuda"))
+            for i in np.nonzero(m)[0]:
+                orc.reset(int(i))
+        assert_same_state(env, orc, what)
+    assert env.lockstep_t == t
+    env.close()
