@@ -1535,3 +1535,44 @@ def test_random_schedules_of_every_kind_of_step_stay_exact(name, plan_seed, n):
         assert_same_state(env, orc, what)
     assert env.lockstep_t == t
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cheat", [("BoatRace-v0", False), ("IslandNavigation-v0", True), ("DistributionalShift-v0", False),
+                                         ("SideEffectsSokoban-v0", False), ("TomatoWatering-v0", False), ("FriendFoe-v0", False)])
+@pytest.mark.parametrize("plan_seed,n", [(1, 130), (2, 321)])
+def test_tabq_random_plans_of_fused_graphed_and_called_steps_are_bit_exact(name, cheat, plan_seed, n):
+    """Tabular-Q learning through a random plan of its three forms -- the fused rollout (LDS-resident or HBM-resident tables as the
+    level needs), the four-launch sequence replayed from a graph, and the same four calls made from Python -- with random, mostly
+    odd step counts (the exploration draw's two-step Philox block starts at either half): agent step counter, env state, episode
+    metrics and every float64 table entry equal the oracle's literal agents after the plan."""
+    _torch()
+    seed = 40 + plan_seed
+    rng = np.random.RandomState(plan_seed * 104729 + len(name))
+    plan = [(str(rng.choice(["fused", "graph", "calls"])), int(rng.choice([1, 1, 2, 3, 7, 20, 65, 129]))) for _ in range(9)]
+    plan = [(how, min(k, 3) if how == "calls" else k) for how, k in plan]
+    steps = sum(k for _, k in plan)
+    env = S.BatchedGridworldEnv(name, n, seed=seed)
+    agent = S.BatchedTabularQAgent(env, _tabq_args())
+    orc, agents, m, _ = _oracle_tabq(name, n, steps, seed, cheat)
+    for how, k in plan:
+        if how == "graph":
+            agent.learn_steps(k, cheat=cheat)
+        elif how == "fused":
+            agent.rollout(k, cheat=cheat)
+        else:
+            for _ in range(k):
+                a = agent.act_explore()
+                env.step(a, auto_reset=False, write_boards=False)
+                agent.learn(action=a, cheat=cheat)
+                env.reset_done()
+    assert agent.t == steps and env.lockstep_t == steps, plan
+    st = env.episode_state_host()
+    assert (st["agent_cell"] == orc.field("agent_cell")).all() and (st["box_cell"] == orc.field("box_cell")).all(), plan
+    assert (st["episode_return"] == orc.field("episode_return")).all() and (st["frame"] == orc.field("frame")).all(), plan
+    assert (env.last_episode_host()["n_episodes"] == orc.field("n_episodes")).all(), plan
+    want = m.copy()
+    want[O.M_STEPS] = n * steps
+    assert env.metrics().tolist() == want.tolist(), plan
+    _assert_tables_equal(env, agent, orc, agents)
+    agent.close(); env.close()
