@@ -162,6 +162,7 @@ int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int acti
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
   if (agent_cell < 0 || agent_cell >= R.n_cells || action < 0 || action >= SGK_ACTIONS) return fail(SGK_ERR_INVALID, "bad cell/action");
+  if (!out) return fail(SGK_ERR_INVALID, "out is NULL");
   int o[5];
   if (sgk::host_debug_transition(R, agent_cell, box_cell, action, o) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
   for (int i = 0; i < 5; ++i) out[i] = o[i];
@@ -189,6 +190,7 @@ uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int
 int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]) {
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
+  if (!dims || !templ || !agent_value) return fail(SGK_ERR_INVALID, "NULL output");
   dims[0] = R.height; dims[1] = R.width; dims[2] = R.start_agent; dims[3] = R.start_box;
   memcpy(templ, R.templ, 64);
   memcpy(agent_value, R.agent_value, 64);

@@ -114,7 +114,7 @@ extern "C" {
 SGK_HOST_API int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int action, int32_t out[5]) {
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return SGK_ERR_INVALID;
-  if (agent_cell < 0 || agent_cell >= R.n_cells || action < 0 || action >= SGK_ACTIONS) return SGK_ERR_INVALID;
+  if (agent_cell < 0 || agent_cell >= R.n_cells || action < 0 || action >= SGK_ACTIONS || !out) return SGK_ERR_INVALID;
   int o[5];
   if (sgk::host_debug_transition(R, agent_cell, box_cell, action, o) != 0) return SGK_ERR_INVALID;
   for (int i = 0; i < 5; ++i) out[i] = o[i];
@@ -123,7 +123,7 @@ SGK_HOST_API int sgk_debug_host_transition(int env_id, int agent_cell, int box_c
 SGK_HOST_API int sgk_debug_host_step(int env_id, uint64_t state_word, int n_resets, int action, uint64_t seed, uint64_t env_index,
                                      uint64_t *state_word_out, int32_t out[4], double *aux_env) {
   SgkRules R;
-  if (sgk_build_rules(env_id, &R) != 0 || action < 0 || action >= SGK_ACTIONS) return SGK_ERR_INVALID;
+  if (sgk_build_rules(env_id, &R) != 0 || action < 0 || action >= SGK_ACTIONS || !state_word_out || !out) return SGK_ERR_INVALID;
   int o[4];
   if (sgk::host_debug_step(R, state_word, n_resets, action, seed, env_index, state_word_out, o, aux_env) != 0) return SGK_ERR_INVALID;
   for (int i = 0; i < 4; ++i) out[i] = o[i];
@@ -136,13 +136,13 @@ SGK_HOST_API uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t e
 }
 SGK_HOST_API int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]) {
   SgkRules R;
-  if (sgk_build_rules(env_id, &R) != 0) return SGK_ERR_INVALID;
+  if (sgk_build_rules(env_id, &R) != 0 || !dims || !templ || !agent_value) return SGK_ERR_INVALID;
   dims[0] = R.height; dims[1] = R.width; dims[2] = R.start_agent; dims[3] = R.start_box;
   std::memcpy(templ, R.templ, 64);
   std::memcpy(agent_value, R.agent_value, 64);
   return SGK_OK;
 }
-SGK_HOST_API int sgk_debug_rules(int env_id, SgkRules *out) { return sgk_build_rules(env_id, out) == 0 ? SGK_OK : SGK_ERR_INVALID; }
+SGK_HOST_API int sgk_debug_rules(int env_id, SgkRules *out) { return (out && sgk_build_rules(env_id, out) == 0) ? SGK_OK : SGK_ERR_INVALID; }
 SGK_HOST_API int sgk_debug_rules_size(void) { return (int)sizeof(SgkRules); }
 SGK_HOST_API int sgk_random_action(uint64_t seed, uint64_t env_index, uint64_t t) { return sgk::host_random_action(seed, env_index, t); }
 SGK_HOST_API int sgk_debug_episode_coin(int env_id, uint64_t seed, uint64_t env_index, int n_resets) {

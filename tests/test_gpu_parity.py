@@ -1576,3 +1576,59 @@ def test_tabq_random_plans_of_fused_graphed_and_called_steps_are_bit_exact(name,
     assert env.metrics().tolist() == want.tolist(), plan
     _assert_tables_equal(env, agent, orc, agents)
     agent.close(); env.close()
+
+
+@pytest.mark.gpu
+def test_every_entry_point_survives_null_and_zero_arguments():
+    """Every exported function called (a) with all-NULL / all-zero arguments and (b) with a VALID first handle and everything else
+    NULL / zero: no crash (a child process: the failure mode is a segmentation fault), a status that is SGK_OK only where doing
+    nothing is the documented meaning (sgk_destroy(NULL) and friends), and a non-empty sgk_last_error after every refusal."""
+    import subprocess
+    import sys
+
+    code = """
+import ctypes, sys
+sys.path[:0] = [%r, %r]
+import torch
+import safe_grid_agents_amd as S
+from safe_grid_agents_amd import _lib
+lib = _lib.load()
+V = ctypes.c_void_p
+env = S.BatchedGridworldEnv("BoatRace-v0", 256, seed=1)
+agent = S.BatchedTabularQAgent(env, type("A", (), dict(lr=0.5, discount=0.99, epsilon=0.05, epsilon_anneal=300))())
+handles = {"env": env.handle, "tabq": agent._h}
+skip = {"sgk_abi_version", "sgk_random_action", "sgk_tabq_epsilon", "sgk_debug_reset_word", "sgk_get_stream",
+        "sgk_destroy", "sgk_tabq_destroy"}  # (non-status returns; the two destructors are exercised at the end)
+ok_on_null = {"sgk_ring_free", "sgk_comm_destroy", "sgk_comm_available", "sgk_device_count", "sgk_debug_graph_count"}
+n_called = 0
+for name, (res, args) in sorted(_lib._SIGNATURES.items()):
+    if name in skip:
+        continue
+    fn = getattr(lib, name)
+    zero = [a() if a in (ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double, ctypes.c_size_t)
+            else None for a in args]
+    sys.stderr.write("null: %%s\\n" %% name); sys.stderr.flush()
+    rc = fn(*zero)
+    n_called += 1
+    if name == "sgk_device_count":
+        assert rc != _lib.SGK_OK  # n_out is NULL
+    elif name not in ok_on_null:
+        assert rc != _lib.SGK_OK, name
+        assert lib.sgk_last_error(), name
+    # a valid handle of the right kind first, the rest NULL / zero
+    if args and args[0] is V and not name.startswith(("sgk_comm", "sgk_ring", "sgk_allreduce")):
+        first = handles["tabq"] if name.startswith("sgk_tabq") and name not in ("sgk_tabq_create", "sgk_tabq_create_ex") else handles["env"]
+        sys.stderr.write("handle: %%s\\n" %% name); sys.stderr.flush()
+        rc = fn(first, *zero[1:])
+        n_called += 1
+        assert isinstance(rc, int), name
+assert lib.sgk_destroy(None) == _lib.SGK_OK and lib.sgk_tabq_destroy(None) == _lib.SGK_OK
+# the env still works after all of that
+env.step_random(5, auto_reset=True)
+assert env.metrics()[_lib.M_STEPS] >= 5 * 256
+agent.close(); env.close()
+print("ok", n_called)
+""" % (ROOT, os.path.join(ROOT, "safe-grid-agents_amd"))
+    p = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ok" in p.stdout, (p.returncode, p.stdout[-500:], [ln for ln in p.stderr.splitlines() if ln.startswith(("null:", "handle:"))][-1:], p.stderr[-1500:])
+    assert int(p.stdout.split()[-1]) > 120

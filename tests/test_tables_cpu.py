@@ -311,3 +311,18 @@ def test_level_art_of_the_header_equals_the_surveys_transcription():
         body = header[header.index(symbol + "["):]
         rows = re.findall(r'"([^"]*)"', body[:body.index("};")])
         assert rows == art, (title, rows, art)
+
+
+def test_debug_hooks_refuse_null_outputs():
+    """The host-only library's debug entry points (the same code libsgk.so links) return an error for a NULL output instead of
+    writing through it, for every level."""
+    H = hostlib
+    L = H.load()
+    for env_id in range(10):
+        assert L.sgk_debug_host_transition(env_id, 0, 0, 0, None) == H.ERR_INVALID
+        assert L.sgk_debug_level(env_id, None, None, None) == H.ERR_INVALID
+        assert L.sgk_debug_rules(env_id, None) == H.ERR_INVALID
+        assert L.sgk_debug_host_step(env_id, 0, 1, 0, 0, 0, None, None, None) == H.ERR_INVALID
+        word = L.sgk_debug_reset_word(env_id, 1, 2, 1, None)  # (friend or foe: no estimates given -> the prior's level)
+        assert word != 2**64 - 1
+    assert L.sgk_debug_level(99, None, None, None) == H.ERR_INVALID
