@@ -385,3 +385,37 @@ def test_config4_fused_sgd_step_matches_torch_on_a_32768_env_replay():
         for (k, v), (k2, v2) in zip(agent.Q.state_dict().items(), cpu_q.state_dict().items()):
             np.testing.assert_allclose(v.cpu().numpy(), v2.numpy(), rtol=2e-4, atol=2e-6, err_msg="%s step %d" % (k, step))
     env.close()
+
+
+def test_the_documented_maximum_of_two_billion_envs_on_one_gpu_is_bit_exact_at_both_ends():
+    """sgk_create's limit, 2^31 - 512 envs (BoatRace, compact boards: 94 GB of the 288): every form of the random rollout a few
+    steps each; the first, a middle and the LAST 777 envs -- boards and step records -- equal the oracle keyed by the same global
+    env ids, and the step total is 64-bit exact. 64-bit indexing at the far end of every array, in about six seconds."""
+    torch = _torch()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120e9:
+        pytest.skip("needs ~95 GB of free device memory")
+    n, name, seed = (1 << 31) - 512, "BoatRace-v0", 5
+    env = S.BatchedGridworldEnv(name, n, seed=seed, layout="compact")
+    v = env._device_views()
+    blocks = [0, n // 2 - 100, n - 777]
+    orcs = [O.EnvBatch(name, 777, seed=seed, env_begin=b) for b in blocks]
+    total = 0
+    for how, k in (("graph", 3), ("stream", 5), ("fused", 7), ("graph", 1)):
+        env.step_random(k, auto_reset=True, fused={"graph": False, "stream": "stream", "fused": True}[how])
+        env.synchronize()
+        for b, orc in zip(blocks, orcs):
+            rec = orc.rollout(k, seed=seed, env_begin=b, t_begin=total, auto_reset=True)
+            assert (v["boards"][b:b + 777].reshape(777, -1).cpu().numpy() == orc.boards()).all(), (how, b)
+            assert (v["rec"][b:b + 777].cpu().numpy() == np.asarray(rec)).all(), (how, b)
+        total += k
+    assert env.metrics()[_lib.M_STEPS] == total * n
+    # one whole episode for everyone: the episode counters and sums are 64-bit, the done-mask compaction covers the id space
+    env.step_random(100 - total, auto_reset=True, fused="stream")
+    m = env.metrics()
+    assert m[_lib.M_EPISODES] == n and m[_lib.M_STEPS] == 100 * n
+    ids, ret, perf = env.finished()
+    assert ids.numel() == n and int(ids[-1]) == n - 1 and int(ids[0]) == 0
+    assert int(ret.to(torch.int64).sum()) == m[_lib.M_SUM_RETURN]
+    del v, ids, ret, perf
+    env.close()
