@@ -419,3 +419,49 @@ def test_the_documented_maximum_of_two_billion_envs_on_one_gpu_is_bit_exact_at_b
     assert int(ret.to(torch.int64).sum()) == m[_lib.M_SUM_RETURN]
     del v, ids, ret, perf
     env.close()
+
+
+@pytest.mark.parametrize("name,n,ring,layout", [("BoatRace-v0", 1 << 20, 180, "slice"), ("IslandNavigation-v0", 1 << 20, 100, "slice"),
+                                                ("BoatRace-v0", 1 << 20, 180, "tile")])
+def test_trajectory_rings_beyond_four_gigabytes_hold_every_step(name, n, ring, layout):
+    """A boards ring larger than 2^32 bytes (1 M envs x 180 BoatRace slices = 4.7 GB, x 100 IslandNavigation slices = 5.0 GB;
+    slice-major and tile-major): one launch per 60 steps streams into it, and slices on both sides of the 4 GB line hold exactly
+    the oracle's boards and records for the first and the last 512 envs."""
+    torch = _torch()
+    seed = 77
+    env = S.BatchedGridworldEnv(name, n, seed=seed, layout="compact")
+    cells = env.n_cells
+    n_tiles = (n + 63) // 64
+    if layout == "slice":
+        boards = torch.empty((ring, n, cells), dtype=torch.int8, device="cuda")
+        recs = torch.empty((ring, n, 4), dtype=torch.int8, device="cuda")
+    else:
+        boards = torch.empty((n_tiles, ring, 64, cells), dtype=torch.int8, device="cuda")
+        recs = torch.empty((n_tiles, ring, 64, 4), dtype=torch.int8, device="cuda")
+    assert boards.numel() > 1 << 32
+    blocks = [0, n - 512]
+    orcs = [O.EnvBatch(name, 512, seed=seed, env_begin=b) for b in blocks]
+    want = {}  # (block, slice) -> (boards, recs)
+    check = sorted({0, 1, ring // 2, ring - 25, ring - 2, ring - 1})
+    for b, orc in zip(blocks, orcs):
+        for k in range(ring):
+            rec = orc.rollout(1, seed=seed, env_begin=b, t_begin=k, auto_reset=True)
+            if k in check:
+                want[(b, k)] = (orc.boards().copy(), np.asarray(rec).copy())
+    t = 0
+    while t < ring:
+        c = min(60, ring - t)
+        env.rollout_random_stream(c, boards=boards, recs=recs, first_slice=t, layout=layout)
+        t += c
+    env.synchronize()
+    for b in blocks:
+        for k in check:
+            if layout == "slice":
+                gb, gr = boards[k, b:b + 512], recs[k, b:b + 512]
+            else:
+                gb = boards[b // 64:(b + 512) // 64, k].reshape(512, cells)
+                gr = recs[b // 64:(b + 512) // 64, k].reshape(512, 4)
+            assert (gb.cpu().numpy() == want[(b, k)][0]).all(), (layout, b, k)
+            assert (gr.cpu().numpy() == want[(b, k)][1]).all(), (layout, b, k)
+    del boards, recs
+    env.close()
