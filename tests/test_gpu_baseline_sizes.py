@@ -175,15 +175,16 @@ def _sample_blocks(n, block, count):
     return starts
 
 
-@pytest.mark.parametrize("n,steps", [(262144, 130), (65536, 230)])
-def test_config3_island_tabq_lds_resident_kernel_multi_round_vs_oracle(n, steps):
+@pytest.mark.parametrize("n,steps,kernel", [(262144, 130, "lds"), (65536, 230, "lds"),
+                                            (1 << 22, 41, "lds"), (1 << 22, 21, "hbm")])  # 4 M agents: 6.4 GB of tables (> 2^32 bytes)
+def test_config3_island_tabq_lds_resident_kernel_multi_round_vs_oracle(n, steps, kernel):
     _torch()
     name, seed = "IslandNavigation-v0", 21
     env = S.BatchedGridworldEnv(name, n, seed=seed)
     agent = S.BatchedTabularQAgent(env, _tabq_args())
     first = steps // 2
-    agent.rollout(first, kernel="lds")          # two launches: tables leave LDS for HBM and come back in between
-    agent.rollout(steps - first, kernel="lds")
+    agent.rollout(first, kernel=kernel)          # two launches: tables leave LDS for HBM and come back in between
+    agent.rollout(steps - first, kernel=kernel)
     assert agent.t == steps
     st, le = env.episode_state_host(), env.last_episode_host()
     boards = env.boards_host().reshape(n, -1)
