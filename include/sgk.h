@@ -382,7 +382,7 @@ typedef struct sgk_dqn_learner {
   const uint8_t *actions;
   const int8_t *rewards;
   const uint8_t *terminals;
-  int32_t slices_filled, n_hidden, batch, pad0;
+  int32_t slices_filled, n_hidden, batch, pad0; /* slices_filled * n_envs < 2^31 (32-bit transition indices) */
   float *w1, *b1, *w2, *b2, *w3, *b3, *w1t, *w2t, *w3t;
   float *m[6], *v[6], *vmax[6];
   const float *tw1t, *tb1, *tw2t, *tb2, *tw3, *tb3;

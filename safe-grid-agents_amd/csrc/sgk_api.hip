@@ -1024,6 +1024,8 @@ int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) {
     if (!L->m[i] || !L->v[i] || !L->vmax[i]) return fail(SGK_ERR_INVALID, "NULL Adam state in sgk_dqn_learner");
   if ((L->n_hidden != 64 && L->n_hidden != 100) || L->batch < 1 || L->batch > 64 || L->slices_filled < 1)
     return fail(SGK_ERR_INVALID, "sgk_dqn_sgd_step needs n_hidden 64 or 100 (the reference default), 1 <= batch <= 64, slices_filled >= 1");
+  if ((int64_t)L->slices_filled * h->sh.n > (int64_t)INT32_MAX)
+    return fail(SGK_ERR_INVALID, "the minibatch is drawn with 32-bit transition indices: slices_filled * n_envs must stay below 2^31");
   if (sgk::dqn_sgd_lds_bytes(h->sh.n_cells, L->n_hidden) > 160u * 1024u)
     return fail(SGK_ERR_INVALID, "this n_cells / n_hidden does not fit the 160 KB of LDS the kernel works in");
   sgk::DqnLearner d;
