@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "sgk_kernels.h"
@@ -36,11 +37,16 @@ struct Rccl {
   std::string error;
 };
 
-Rccl &rccl() {
+void load_rccl(Rccl &r);
+
+Rccl &rccl() {  // loaded once, whichever thread asks first
   static Rccl r;
-  static bool tried = false;
-  if (tried) return r;
-  tried = true;
+  static std::once_flag once;
+  std::call_once(once, [] { load_rccl(r); });
+  return r;
+}
+
+void load_rccl(Rccl &r) {
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char *n : names) {
     r.dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -49,12 +55,12 @@ Rccl &rccl() {
   if (!r.dl) {
     const char *de = dlerror();  // one call: a second one returns NULL (the first clears the error)
     r.error = std::string("librccl.so.1 could not be loaded: ") + (de ? de : "?");
-    return r;
+    return;
   }
 #define SGK_SYM(field, name)                                                             \
   do {                                                                                   \
     *reinterpret_cast<void **>(&r.field) = dlsym(r.dl, name);                            \
-    if (!r.field) { r.error = std::string("librccl has no symbol ") + name; return r; } \
+    if (!r.field) { r.error = std::string("librccl has no symbol ") + name; return; } \
   } while (0)
   SGK_SYM(GetUniqueId, "ncclGetUniqueId");
   SGK_SYM(CommInitRank, "ncclCommInitRank");
@@ -67,7 +73,6 @@ Rccl &rccl() {
   *reinterpret_cast<void **>(&r.CommCount) = dlsym(r.dl, "ncclCommCount");
   *reinterpret_cast<void **>(&r.CommUserRank) = dlsym(r.dl, "ncclCommUserRank");
   *reinterpret_cast<void **>(&r.GetVersion) = dlsym(r.dl, "ncclGetVersion");
-  return r;
 }
 
 __global__ void set_word_kernel(long long *p, long long v) { *p = v; }

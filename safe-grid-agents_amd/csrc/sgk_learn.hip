@@ -10,6 +10,8 @@
 // fp32 throughout, same formulas as torch (mse_loss mean reduction, clip coefficient max_norm / (norm + 1e-6) clamped to 1,
 // Adam with bias corrections and amsgrad); the summation order inside the dot products differs from rocBLAS, so parity with
 // torch's step is to fp32 tolerance (tests: 1e-5 relative after one step), not bit for bit.
+#include <atomic>
+
 #include "sgk_device.h"
 
 extern "C" __device__ float __ockl_wfred_add_f32(float);
@@ -943,12 +945,12 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
   a.max_norm = (float)L.max_grad_norm;
 #define SGK_SGD_LAUNCH(K0V, HV)                                                                                            \
   do {                                                                                                                     \
-    static unsigned long long opted_in = 0;                                                                                \
-    if (!((opted_in >> (sh.device & 63)) & 1ull)) {                                                                        \
+    static std::atomic<unsigned long long> opted_in{0};                                                                                \
+    if (!((opted_in.load() >> (sh.device & 63)) & 1ull)) {                                                                        \
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&dqn_sgd_kernel<K0V, HV>),                        \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
       if (ae != hipSuccess) return ae;                                                                                     \
-      opted_in |= 1ull << (sh.device & 63);                                                                                \
+      opted_in.fetch_or(1ull << (sh.device & 63));                                                                         \
     }                                                                                                                      \
     dqn_sgd_kernel<K0V, HV><<<dim3(1), dim3(LWG), lds, st>>>(a);                                                           \
   } while (0)
@@ -994,12 +996,12 @@ hipError_t launch_ppo_epochs(const Shard &sh, const PpoLearner &P, hipStream_t s
   a.clipping = (float)P.clipping; a.critic_coeff = (float)P.critic_coeff; a.entropy_bonus = (float)P.entropy_bonus;
 #define SGK_PPO_LAUNCH(K0V, HV)                                                                                            \
   do {                                                                                                                     \
-    static unsigned long long opted_in = 0;                                                                                \
-    if (!((opted_in >> (sh.device & 63)) & 1ull)) {                                                                        \
+    static std::atomic<unsigned long long> opted_in{0};                                                                                \
+    if (!((opted_in.load() >> (sh.device & 63)) & 1ull)) {                                                                        \
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&ppo_epochs_kernel<K0V, HV>),                     \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
       if (ae != hipSuccess) return ae;                                                                                     \
-      opted_in |= 1ull << (sh.device & 63);                                                                                \
+      opted_in.fetch_or(1ull << (sh.device & 63));                                                                         \
     }                                                                                                                      \
     ppo_epochs_kernel<K0V, HV><<<dim3(1), dim3(LWG), lds, st>>>(a);                                                        \
   } while (0)

@@ -1,6 +1,8 @@
 // sgk_policy.hip -- the network-facing kernels: action draws on scores / logits (DeepQAgent.act_explore, reference
 // value.py:94-111; PPOBaseAgent.act_explore, policy_base.py:54-64), the fused MLP forward + draw on the matrix cores
 // (value.py:89-111,148-158; policy_mlp.py:17-43) and PPOBaseAgent.get_discounted_returns (policy_base.py:179-186).
+#include <atomic>
+
 #include "sgk_device.h"
 
 namespace sgk {
@@ -559,12 +561,12 @@ hipError_t launch_policy_act(const Shard &sh, int mode, const PolicyWeights &w, 
 #define SGK_POLICY_LAUNCH_M(K0, HID, MODE)                                                                                 \
   do {                                                                                                                     \
     constexpr size_t lds = PolicyMfmaGeom<K0, HID>::lds_bytes;                                                             \
-    static unsigned long long opted_in = 0; /* > 64 KB of dynamic LDS needs the opt-in, once per kernel and device */      \
-    if (!((opted_in >> (sh.device & 63)) & 1ull)) {                                                                        \
+    static std::atomic<unsigned long long> opted_in{0}; /* > 64 KB of dynamic LDS needs the opt-in, once per kernel and device */      \
+    if (!((opted_in.load() >> (sh.device & 63)) & 1ull)) {                                                                        \
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&policy_mfma_kernel<K0, HID, MODE>),              \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
       if (ae != hipSuccess) return ae;                                                                                     \
-      opted_in |= 1ull << (sh.device & 63);                                                                                \
+      opted_in.fetch_or(1ull << (sh.device & 63));                                                                         \
     }                                                                                                                      \
     policy_mfma_kernel<K0, HID, MODE><<<dim3(grid), dim3(PMFMA_WG), lds, st>>>(sh.boards, sh.pitch, w.w1t, w.b1, w.w2, w.b2, \
                                                                               w.w3t, w.b3, actions, scores, sh.n, eps,     \
@@ -618,12 +620,12 @@ hipError_t launch_policy_rollout(const Shard &sh, int mode, const PolicyWeights 
 #define SGK_ROLLOUT_LAUNCH_M(E, HID, MODE)                                                                                 \
   do {                                                                                                                     \
     constexpr size_t lds = policy_rollout_lds_bytes<E, HID>();                                                             \
-    static unsigned long long opted_in = 0;                                                                                \
-    if (!((opted_in >> (sh.device & 63)) & 1ull)) {                                                                        \
+    static std::atomic<unsigned long long> opted_in{0};                                                                                \
+    if (!((opted_in.load() >> (sh.device & 63)) & 1ull)) {                                                                        \
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&policy_rollout_kernel<E, HID, MODE>),            \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
       if (ae != hipSuccess) return ae;                                                                                     \
-      opted_in |= 1ull << (sh.device & 63);                                                                                \
+      opted_in.fetch_or(1ull << (sh.device & 63));                                                                         \
     }                                                                                                                      \
     policy_rollout_kernel<E, HID, MODE><<<dim3(grid), dim3(PMFMA_WG), lds, st>>>(a);                                       \
   } while (0)
