@@ -1677,3 +1677,40 @@ def test_handles_driven_from_concurrent_threads_stay_exact():
     for th in threads:
         th.join(600)
     assert not errors, errors
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ENVS + ["TransitionBoatRace-v0"])
+def test_single_env_random_call_sequences_equal_the_oracle_env(name):
+    """The gym-shaped single env under a random sequence of calls -- steps (also after the episode is over), resets in the middle of
+    an episode, re-seeding, renders, the SafetyEnvironment view's episode_return / get_last_performance -- against the oracle's env
+    of the same surface: every observation, reward, done flag, info dictionary and side value is equal, call by call."""
+    _torch()
+    from oracle.gym_shim import OracleGridworldEnv
+
+    env, orc = S.make(name), OracleGridworldEnv(name)
+    rng = np.random.RandomState(len(name) * 31 + 5)
+    for e in (env, orc):
+        e.seed(11)
+    a, b = env.reset(), orc.reset()
+    assert a.dtype == b.dtype and a.shape == b.shape and (a == b).all()
+    for i in range(600):
+        p = rng.rand()
+        what = "%s call %d" % (name, i)
+        if p < 0.86:
+            act = int(rng.randint(0, 4))
+            (o1, r1, d1, i1), (o2, r2, d2, i2) = env.step(act), orc.step(act)
+            assert o1.dtype == o2.dtype and o1.shape == o2.shape and (o1 == o2).all(), what
+            assert r1 == r2 and type(r1) is type(r2) and d1 == d2, (what, r1, r2, d1, d2)
+            assert i1 == i2, (what, i1, i2)
+        elif p < 0.93:
+            a, b = env.reset(), orc.reset()
+            assert (a == b).all(), what
+        elif p < 0.96:
+            s = int(rng.randint(0, 1 << 30))
+            env.seed(s); orc.seed(s)
+        else:
+            assert (np.asarray(env.render()) == np.asarray(orc.render())).all(), what
+        assert env._env.episode_return == orc._env.episode_return, what
+        assert env._env.get_last_performance() == orc._env.get_last_performance(), what
+    env.close()
