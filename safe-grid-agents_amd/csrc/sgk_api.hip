@@ -135,6 +135,71 @@ static int stop_server(sgk_env *h) {
   return SGK_OK;
 }
 
+// One request to the handle's step server and its answer (host-visible handles with a mailbox): `flags8` = the SGK_F_* flags of a
+// step, or SGK_SRV_RESET; `action0` rides in the request word. Starts the server when none is running. On failure the request is
+// taken back (the host counters have not moved) and the server is marked gone.
+static int server_round_trip(sgk_env *h, uint32_t flags8, uint32_t action0) {
+  sgk::Shard &s = h->sh;
+  sgk::SgkMailbox *mb = h->mailbox;
+  if (!h->server_running) {
+    mb->request = (uint64_t)h->server_seq;
+    mb->done = h->server_seq;
+    mb->exited = 0;
+    __sync_synchronize();
+    SGK_HIP(sgk::launch_env_server(s, h->hv_actions, mb, h->server_seq, h->stream));
+    h->server_running = true;
+  }
+  const uint32_t prev = h->server_seq;
+  uint32_t seq = prev + 1u;
+  if (seq == SGK_SERVER_STOP) seq = 0u;
+  __sync_synchronize();  // the other envs' actions before the request word
+  mb->request = (uint64_t)seq | ((uint64_t)(flags8 & 0xffu) << 32) | ((uint64_t)(action0 & 3u) << 40);
+  h->server_seq = seq;
+  // Wait for the answer. The loop watches the mailbox, and every 2^20 spins (~a millisecond) it also asks the STREAM: a server
+  // kernel that died, or never started, leaves the stream idle (or in error) with no answer and no exit word -- the caller then
+  // gets an error instead of spinning for minutes. On every failure the request is taken back (the host counters have not moved)
+  // and the server is marked gone, so the next call starts from the arrays in memory.
+  uint64_t spins = 0;
+  int failed = 0;
+  while (mb->done != seq) {
+    if (mb->exited != 0) {
+      // the server left (idle) without having seen this request: start another one that has served up to seq - 1
+      hipError_t e = hipStreamSynchronize(h->stream);
+      mb->exited = 0;
+      __sync_synchronize();
+      if (e == hipSuccess) e = sgk::launch_env_server(s, h->hv_actions, mb, prev, h->stream);
+      if (e != hipSuccess) {
+        failed = hip_fail(e, "restarting the step server");
+        break;
+      }
+    }
+    if ((++spins & ((1ull << 20) - 1)) == 0) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q != hipErrorNotReady && mb->done != seq && mb->exited == 0) {  // nothing is running and nothing was answered
+        failed = q == hipSuccess ? fail(SGK_ERR_HIP, "the step server is gone (its stream is idle) without an answer")
+                                 : hip_fail(q, "the step server's stream");
+        break;
+      }
+      if (spins > (1ull << 33)) {
+        failed = fail(SGK_ERR_HIP, "the step server did not answer");
+        break;
+      }
+    }
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+  }
+  if (failed) {
+    const std::string keep = g_last_error;
+    h->server_seq = prev;  // the request was not served: the host counters are untouched, so is the request number
+    (void)stop_server(h);  // asks a server that may still be there to leave, waits for the stream, clears the mailbox
+    g_last_error = keep;
+    return failed;
+  }
+  __sync_synchronize();  // the server's outputs (released before the number) are read after it
+  return SGK_OK;
+}
+
 extern "C" {
 
 const char *sgk_last_error(void) { return g_last_error.c_str(); }
@@ -238,7 +303,10 @@ int sgk_destroy(sgk_env *h) {
     if (s.boards) (void)hipHostFree(s.boards);
     if (h->hv_actions) (void)hipHostFree(h->hv_actions);
     if (h->mailbox) (void)hipHostFree(h->mailbox);
+    if (s.last_return) (void)hipHostFree(s.last_return);
+    if (s.last_perf) (void)hipHostFree(s.last_perf);
     s.state = nullptr; s.rec = nullptr; s.boards = nullptr;
+    s.last_return = nullptr; s.last_perf = nullptr;
   }
   (void)hipFree(s.rules_dev); (void)hipFree(s.state); (void)hipFree(s.rec); (void)hipFree(s.boards); (void)hipFree(s.last_return);
   (void)hipFree(s.aux);
@@ -345,9 +413,14 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
     SGK_TRY(hipMalloc(&s.rec, sizeof(uint32_t) * n_pad));
     SGK_TRY(hipMalloc(&s.boards, (size_t)s.pitch * n_pad));
   }
-  SGK_TRY(hipMalloc(&s.last_return, sizeof(int32_t) * n_pad));
-  SGK_TRY(hipMalloc(&s.last_perf, sizeof(int32_t) * n_pad));
-  SGK_TRY(hipMalloc(&s.n_episodes, sizeof(int32_t) * n_pad));
+  if (host_visible) {  // what get_last_performance() reads at an episode's end: host memory too (plain stores over PCIe)
+    SGK_TRY(hipHostMalloc((void **)&s.last_return, sizeof(int32_t) * n_pad, hipHostMallocMapped));
+    SGK_TRY(hipHostMalloc((void **)&s.last_perf, sizeof(int32_t) * n_pad, hipHostMallocMapped));
+  } else {
+    SGK_TRY(hipMalloc(&s.last_return, sizeof(int32_t) * n_pad));
+    SGK_TRY(hipMalloc(&s.last_perf, sizeof(int32_t) * n_pad));
+  }
+  SGK_TRY(hipMalloc(&s.n_episodes, sizeof(int32_t) * n_pad));  // (device memory everywhere: the kernels bump it with an atomic)
   SGK_TRY(hipMalloc(&s.n_resets, sizeof(int32_t) * n_pad));
   if (env_id == SGK_FRIEND_FOE) SGK_TRY(hipMalloc(&s.aux, sizeof(double) * SGK_AUX_DOUBLES * n_pad));  // the bandits' estimates, per env
   SGK_TRY(hipMalloc(&s.metrics, sizeof(int64_t) * SGK_METRICS_LEN));
@@ -476,6 +549,11 @@ int sgk_synchronize(sgk_env *h) {
 }
 
 int sgk_reset(sgk_env *h, const uint8_t *mask_dev) {
+  if (h && h->server_running && !mask_dev) {
+    // the single-env loop's env.reset() between episodes: the resident step server does it (no launch, and the server stays)
+    SGK_HIP(hipSetDevice(h->sh.device));
+    return server_round_trip(h, SGK_SRV_RESET, 0);
+  }
   SGK_CHECK_HANDLE(h);
   SGK_HIP(sgk::launch_reset(h->sh, mask_dev, 0, h->stream));
   return SGK_OK;
@@ -517,63 +595,8 @@ int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_s
     // the step server: no launch at all in the steady state -- the action goes into host-visible memory, a request number into
     // the mailbox, and the resident wave publishes the number back once the outputs are in the host-visible buffers
     memcpy(h->hv_actions, actions_host, n);
-    sgk::SgkMailbox *mb = h->mailbox;
-    if (!h->server_running) {
-      mb->request = (uint64_t)h->server_seq;
-      mb->done = h->server_seq;
-      mb->exited = 0;
-      __sync_synchronize();
-      SGK_HIP(sgk::launch_env_server(s, h->hv_actions, mb, h->server_seq, h->stream));
-      h->server_running = true;
-    }
-    const uint32_t prev = h->server_seq;
-    uint32_t seq = prev + 1u;
-    if (seq == SGK_SERVER_STOP) seq = 0u;
-    __sync_synchronize();  // the other envs' actions before the request word
-    mb->request = (uint64_t)seq | ((uint64_t)(flags & 0xffu) << 32) | ((uint64_t)(actions_host[0] & 3u) << 40);
-    h->server_seq = seq;
-    // Wait for the answer. The loop watches the mailbox, and every 2^20 spins (~a millisecond) it also asks the STREAM: a server
-    // kernel that died, or never started, leaves the stream idle (or in error) with no answer and no exit word -- the caller then
-    // gets an error instead of spinning for minutes. On every failure the request is taken back (the host counters have not moved)
-    // and the server is marked gone, so the next call starts from the arrays in memory.
-    uint64_t spins = 0;
-    int failed = 0;
-    while (mb->done != seq) {
-      if (mb->exited != 0) {
-        // the server left (idle) without having seen this request: start another one that has served up to seq - 1
-        hipError_t e = hipStreamSynchronize(h->stream);
-        mb->exited = 0;
-        __sync_synchronize();
-        if (e == hipSuccess) e = sgk::launch_env_server(s, h->hv_actions, mb, prev, h->stream);
-        if (e != hipSuccess) {
-          failed = hip_fail(e, "restarting the step server");
-          break;
-        }
-      }
-      if ((++spins & ((1ull << 20) - 1)) == 0) {
-        const hipError_t q = hipStreamQuery(h->stream);
-        if (q != hipErrorNotReady && mb->done != seq && mb->exited == 0) {  // nothing is running and nothing was answered
-          failed = q == hipSuccess ? fail(SGK_ERR_HIP, "the step server is gone (its stream is idle) without an answer")
-                                   : hip_fail(q, "the step server's stream");
-          break;
-        }
-        if (spins > (1ull << 33)) {
-          failed = fail(SGK_ERR_HIP, "the step server did not answer");
-          break;
-        }
-      }
-#if defined(__x86_64__) || defined(__i386__)
-      __builtin_ia32_pause();
-#endif
-    }
-    if (failed) {
-      const std::string keep = g_last_error;
-      h->server_seq = prev;  // the step was not taken: lockstep_t / steps_issued are untouched, so is the request number
-      (void)stop_server(h);  // asks a server that may still be there to leave, waits for the stream, clears the mailbox
-      g_last_error = keep;
-      return failed;
-    }
-    __sync_synchronize();
+    const int rt = server_round_trip(h, flags, actions_host[0]);
+    if (rt != SGK_OK) return rt;
     s.lockstep_t += 1;
     h->t_dev_stale = true;
     h->steps_issued += s.n;
@@ -1102,7 +1125,25 @@ int sgk_render_rgb(sgk_env *h, uint8_t *rgb_dev) {
   return SGK_OK;
 }
 
+// Host-visible handles keep what the host reads in pinned host memory. While the step server is resident that memory is current
+// whenever the host is not inside a request (the server writes, fences and only then publishes the answer): the copies below then
+// read it as it is -- stopping the server for a look would cost a launch at the next step. Otherwise: wait for the stream first.
+static int host_visible_ready(sgk_env *h) {
+  if (h->server_running) {
+    __sync_synchronize();
+    return SGK_OK;
+  }
+  SGK_HIP(hipStreamSynchronize(h->stream));
+  return SGK_OK;
+}
+
 int sgk_copy_boards(sgk_env *h, int8_t *boards_host) {
+  if (h && h->host_visible && h->server_running && boards_host) {
+    const sgk::Shard &s = h->sh;
+    __sync_synchronize();
+    for (int64_t i = 0; i < s.n; ++i) memcpy(boards_host + i * s.n_cells, s.boards + i * s.pitch, (size_t)s.n_cells);
+    return SGK_OK;
+  }
   SGK_CHECK_HANDLE(h);
   if (!boards_host) return fail(SGK_ERR_INVALID, "boards_host is NULL");
   sgk::Shard &s = h->sh;
@@ -1164,13 +1205,28 @@ int sgk_copy_episode_state(sgk_env *h, int32_t *episode_return_host, int32_t *hi
 }
 
 int sgk_copy_last_episode(sgk_env *h, int32_t *last_return_host, int32_t *last_performance_host, int32_t *n_episodes_host) {
+  if (h && h->host_visible && !n_episodes_host) {  // (the two arrays are pinned host memory there: see host_visible_ready)
+    SGK_HIP(hipSetDevice(h->sh.device));
+    const int rc = host_visible_ready(h);
+    if (rc != SGK_OK) return rc;
+    const size_t nb = sizeof(int32_t) * (size_t)h->sh.n;
+    if (last_return_host) memcpy(last_return_host, h->sh.last_return, nb);
+    if (last_performance_host) memcpy(last_performance_host, h->sh.last_perf, nb);
+    return SGK_OK;
+  }
   SGK_CHECK_HANDLE(h);
   const size_t bytes = sizeof(int32_t) * (size_t)h->sh.n;
-  if (last_return_host) SGK_HIP(hipMemcpyAsync(last_return_host, h->sh.last_return, bytes, hipMemcpyDeviceToHost, h->stream));
-  if (last_performance_host)
-    SGK_HIP(hipMemcpyAsync(last_performance_host, h->sh.last_perf, bytes, hipMemcpyDeviceToHost, h->stream));
   if (n_episodes_host) SGK_HIP(hipMemcpyAsync(n_episodes_host, h->sh.n_episodes, bytes, hipMemcpyDeviceToHost, h->stream));
+  if (!h->host_visible) {
+    if (last_return_host) SGK_HIP(hipMemcpyAsync(last_return_host, h->sh.last_return, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (last_performance_host)
+      SGK_HIP(hipMemcpyAsync(last_performance_host, h->sh.last_perf, bytes, hipMemcpyDeviceToHost, h->stream));
+  }
   SGK_HIP(hipStreamSynchronize(h->stream));
+  if (h->host_visible) {  // host memory: read with the CPU once the stream is idle (a host-to-host hipMemcpyAsync is not stream-ordered)
+    if (last_return_host) memcpy(last_return_host, h->sh.last_return, bytes);
+    if (last_performance_host) memcpy(last_performance_host, h->sh.last_perf, bytes);
+  }
   return SGK_OK;
 }
 

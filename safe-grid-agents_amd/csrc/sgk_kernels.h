@@ -68,6 +68,7 @@ struct SgkMailbox {
   uint32_t pad3[15];
 };
 #define SGK_SERVER_STOP 0xffffffffu
+#define SGK_SRV_RESET 0x80u  // in the flags byte of a step-server request: reset every env of the handle instead of stepping
 #define SGK_SERVER_IDLE_US 100  // the step server leaves after this long without a request (wall_clock64: 100 MHz)
 hipError_t launch_env_server(const Shard &sh, const uint8_t *actions, SgkMailbox *mb, uint32_t last, hipStream_t st);
 hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flags, hipStream_t st);

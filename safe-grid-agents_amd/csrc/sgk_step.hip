@@ -176,13 +176,26 @@ __global__ __launch_bounds__(64) void env_server_kernel(StepArgs a, SgkMailbox *
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the other actions were written before the request word
       if (valid) action = (int)(__hip_atomic_load(&a.actions[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & 3u);
     }
-    StepArgs b = a;
-    b.flags = flags;
-    uint32_t rec;
-    step_one<ENV>(R, b, env, valid, action, s, rec, acc);
-    if (valid) {
-      a.state[env] = pack_state(s);
-      a.rec[env] = rec;
+    if (flags & SGK_SRV_RESET) {
+      // env.reset() for every env of the handle (reset_kernel's mode 0 without a mask): a new episode index for the envs that draw,
+      // the initial state; the step record and the episode arrays stay as they are
+      if (valid) {
+        const int epi = s.epi + 1;
+        bump_reset_count<ENV>(a.n_resets, env);
+        s = initial_state(R);
+        s.epi = epi;
+        begin_episode<ENV>(R, s, a.seed, a.env_base + (uint64_t)env, aux_of<ENV>(a.aux, env));
+        a.state[env] = pack_state(s);
+      }
+    } else {
+      StepArgs b = a;
+      b.flags = flags;
+      uint32_t rec;
+      step_one<ENV>(R, b, env, valid, action, s, rec, acc);
+      if (valid) {
+        a.state[env] = pack_state(s);
+        a.rec[env] = rec;
+      }
     }
     if (!(flags & SGK_F_NO_BOARDS)) {
       if (COMPACT) {  // only the rows of the envs there are: the destination is host memory, every byte crosses PCIe

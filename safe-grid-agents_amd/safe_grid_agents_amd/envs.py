@@ -615,6 +615,13 @@ class BatchedGridworldEnv:
         return {"episode_return": ret, "hidden_return": hid, "frame": frame, "over": over, "agent_cell": cell,
                 "box_cell": box}
 
+    def last_performance_host(self):
+        """last_episode_host()["last_performance"] alone: what get_last_performance() reads (on a host-visible handle a plain read
+        of pinned host memory that leaves the resident step server where it is)."""
+        perf = np.empty(self.n_envs, dtype=np.int32)
+        _lib.check(self.lib.sgk_copy_last_episode(self._h.ptr, None, perf.ctypes.data, None))
+        return perf
+
     def last_episode_host(self):
         n = self.n_envs
         a, b, c = (np.empty(n, dtype=np.int32) for _ in range(3))
@@ -712,10 +719,21 @@ class GridworldEnv:
         # made here with upstream's own expression (count * REWARD_FACTOR) and summed step by step, as SafetyEnvironment does
         self._scale = self._b.reward_scale
         self._hidden_return = 0.0
-        self._water = None
-        if name == "IslandNavigation-v0":
+        self._water_dist = None
+        if name == "IslandNavigation-v0":  # the side information "safety": Manhattan distance from each cell to the nearest water cell
             first = self._b.boards_host()[0, 0]
-            self._water = np.argwhere(first == 0)  # value_mapping: water = 0
+            water = np.argwhere(first == 0)  # value_mapping: water = 0
+            cells = np.argwhere(np.ones_like(first, dtype=bool))
+            self._water_dist = np.abs(cells[:, None, :] - water[None, :, :]).sum(axis=2).min(axis=1).astype(np.int64)
+        # everything env.step touches on every call, looked up once (numpy's .ctypes and the property chain cost microseconds)
+        self._no_hidden = name in NO_HIDDEN_REWARD
+        self._step_fn = self._b.lib.sgk_step_host
+        self._step_args = (self._b.handle, self._act.ctypes.data, 0, self._rec.ctypes.data, self._board.ctypes.data,
+                           self._ret.ctypes.data)
+        self._rec_row, self._rec_u8 = self._rec[0], self._rec.view(np.uint8)[0]
+        self._board_hw = self._board.reshape(1, self._b.H, self._b.W)
+        self._board_flat = self._board[0]
+        self._n_actions = self.action_space.n
 
     def seed(self, seed=None):
         """env.seed(seed) (reference train.py:52): re-keys the counter RNG -- the env's own draws (WhiskyGold's replaced
@@ -740,14 +758,14 @@ class GridworldEnv:
         if hasattr(action, "item"):  # np.int64 (value.py:35) or a 1-element tensor (value.py:92 via eval.py:35-36)
             action = action.item()
         action = int(action)
-        assert 0 <= action < self.action_space.n, "Not a valid action."
+        assert 0 <= action < self._n_actions, "Not a valid action."
         self._act[0] = action
-        lib = self._b.lib
-        _lib.check(lib.sgk_step_host(self._b.handle, self._act.ctypes.data, 0, self._rec.ctypes.data,
-                                     self._board.ctypes.data, self._ret.ctypes.data))
-        reward, hidden = int(self._rec[0, 0]), int(self._rec[0, 1])
-        done = bool(self._rec[0, 2])
-        actual = int(self._rec.view(np.uint8)[0, 3])
+        rc = self._step_fn(*self._step_args)
+        if rc:
+            _lib.check(rc)
+        reward, hidden, done, _ = self._rec_row.tolist()
+        done = bool(done)
+        actual = int(self._rec_u8[3])
         if self._scale != 1.0:
             if not self._over:
                 reward, hidden = reward * self._scale, hidden * self._scale
@@ -760,23 +778,20 @@ class GridworldEnv:
         else:
             self._episode_return = int(self._ret[0])
             if done and not self._over:  # the episode just ended: get_last_performance() now has a value
-                self._last_performance = int(self._b.last_episode_host()["last_performance"][0])
+                self._last_performance = int(self._b.last_performance_host()[0])
         self._over = done
         info = {
-            "hidden_reward": hidden,
+            "hidden_reward": None if self._no_hidden else hidden,  # (None: as safe_grid_gym reports an env without a hidden reward)
             "observed_reward": reward,
             "discount": 0.0 if done else 1.0,
             "extra_observations": {"actual_actions": actual},
         }
-        state = self._board.reshape(1, self._b.H, self._b.W).astype(np.float32)
+        state = self._board_hw.astype(np.float32)
         if self.use_transitions:
             state, self._last_board = np.concatenate([self._last_board, state], axis=0), state
-        if self.name in NO_HIDDEN_REWARD:
-            info["hidden_reward"] = None  # as safe_grid_gym reports it for an env without a hidden reward
-        if self._water is not None:  # IslandNavigation's side information: Manhattan distance to the nearest water cell
-            at = np.argwhere(state[0] == 2)
-            info["extra_observations"]["safety"] = (
-                0 if at.size == 0 else int(np.abs(self._water - at[0]).sum(axis=1).min()))
+        if self._water_dist is not None:  # IslandNavigation's side information: distance of the agent (value 2) to the nearest water cell
+            at = np.flatnonzero(self._board_flat == 2)
+            info["extra_observations"]["safety"] = 0 if at.size == 0 else int(self._water_dist[at[0]])
         return state, reward, done, info
 
     def render(self, mode="rgb_array"):

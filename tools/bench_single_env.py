@@ -26,12 +26,13 @@ rec = np.zeros((1, 4), dtype=np.int8)
 board = np.zeros((1, b.n_cells), dtype=np.int8)
 ret = np.zeros(1, dtype=np.int32)
 lib = b.lib
+fn, args = lib.sgk_step_host, (b.handle, act.ctypes.data, 1, rec.ctypes.data, board.ctypes.data, ret.ctypes.data)  # (pointers looked up once)
 for _ in range(200):
-    lib.sgk_step_host(b.handle, act.ctypes.data, 0, rec.ctypes.data, board.ctypes.data, ret.ctypes.data)
+    fn(*args)
 t0 = time.perf_counter()
 for i in range(N):
     act[0] = i & 3
-    lib.sgk_step_host(b.handle, act.ctypes.data, 1, rec.ctypes.data, board.ctypes.data, ret.ctypes.data)
+    fn(*args)
 t_c = (time.perf_counter() - t0) / N * 1e6
 env.reset()
 t0 = time.perf_counter()
@@ -40,7 +41,12 @@ for i in range(N):
     if d:
         env.reset()
 t_w = (time.perf_counter() - t0) / N * 1e6
-print("%s: sgk_step_host (ctypes) %.1f us | GridworldEnv.step %.1f us" % (name, t_c, t_w), flush=True)
+t0 = time.perf_counter()
+for i in range(2000):  # an episode of one step: what env.reset() costs between episodes (the resident server does it)
+    env.reset()
+    env.step(i & 3)
+t_r = (time.perf_counter() - t0) / 2000 * 1e6 - t_w
+print("%s: sgk_step_host (ctypes) %.1f us | GridworldEnv.step %.1f us | GridworldEnv.reset %.1f us" % (name, t_c, t_w, t_r), flush=True)
 a = S.prepare_parser().parse_args(["-S", "7", "-E", "400", "-EE", "1000", "-V", "100", "-EV", "0", "boat", "tabular-q", "-l", ".5"])
 with contextlib.redirect_stdout(io.StringIO()):
     t0 = time.perf_counter()
