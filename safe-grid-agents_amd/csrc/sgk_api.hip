@@ -163,10 +163,17 @@ static int server_round_trip(sgk_env *h, uint32_t flags8, uint32_t action0) {
   int failed = 0;
   while (mb->done != seq) {
     if (mb->exited != 0) {
-      // the server left (idle) without having seen this request: start another one that has served up to seq - 1
+      // the server left (idle) without having seen this request: start another one that has served up to seq - 1. (The exit word
+      // of an EARLIER server can land late, after this thread cleared it: the stream then still holds a live server, which answers
+      // while we wait for it here -- look at the answer again before starting anything, and a server started needlessly finds the
+      // request already answered in the mailbox: env_server_kernel.)
       hipError_t e = hipStreamSynchronize(h->stream);
       mb->exited = 0;
       __sync_synchronize();
+      if (e == hipSuccess && mb->done == seq) {
+        h->server_running = false;  // (the stream is idle and the exit word is cleared: the next request starts a server afresh)
+        break;
+      }
       if (e == hipSuccess) e = sgk::launch_env_server(s, h->hv_actions, mb, prev, h->stream);
       if (e != hipSuccess) {
         failed = hip_fail(e, "restarting the step server");
@@ -798,14 +805,15 @@ struct DeviceGuard {
   }
 };
 
-void release_ring(void *va, RingBlock &b, size_t mapped_chunks) {
+void release_ring(void *va, RingBlock &b, size_t mapped_chunks, bool free_range = true) {
   size_t off = 0;
   for (size_t i = 0; i < b.chunks.size(); ++i) {
     if (i < mapped_chunks) (void)hipMemUnmap((char *)va + off, b.chunk_bytes[i]);
     (void)hipMemRelease(b.chunks[i]);
     off += b.chunk_bytes[i];
   }
-  if (va) (void)hipMemAddressFree(va, b.va_bytes);
+  b.chunks.clear();
+  if (va && free_range) (void)hipMemAddressFree(va, b.va_bytes);
   (void)hipGetLastError();
 }
 }  // namespace
@@ -835,29 +843,53 @@ int sgk_ring_alloc(int32_t device, size_t bytes, void **dev_ptr) {
     b.va_bytes += take;
     left -= left >= chunk ? chunk : left;
   }
+  // Reserve, create, map, open. On one box of this pool the driver refused to map into (or open) a range it had just handed out
+  // -- "invalid argument", one call in a few hundred, the same sizes fine a moment later --: such a range is set aside (it stays
+  // reserved until the call returns, so that the next reservation is a different one) and another is tried, three times in all.
   void *va = nullptr;
-  hipError_t err = hipMemAddressReserve(&va, b.va_bytes, (chunk & (chunk - 1)) ? gran : chunk, nullptr, 0);  // aligned to the chunk size
-  if (err != hipSuccess) return hip_fail(err, "hipMemAddressReserve (trajectory ring)");
-  size_t mapped = 0, off = 0;
-  for (size_t i = 0; i < b.chunk_bytes.size() && err == hipSuccess; ++i) {
-    hipMemGenericAllocationHandle_t h;
-    err = hipMemCreate(&h, b.chunk_bytes[i], &prop, 0);
-    if (err != hipSuccess) break;
-    b.chunks.push_back(h);
-    err = hipMemMap((char *)va + off, b.chunk_bytes[i], 0, h, 0);
-    if (err == hipSuccess) ++mapped;
-    off += b.chunk_bytes[i];
+  std::vector<void *> set_aside;
+  hipError_t err = hipSuccess;
+  std::string where;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    va = nullptr;
+    b.chunks.clear();
+    err = hipMemAddressReserve(&va, b.va_bytes, (chunk & (chunk - 1)) ? gran : chunk, nullptr, 0);  // aligned to the chunk size
+    if (err != hipSuccess) {
+      where = "hipMemAddressReserve (trajectory ring)";
+      break;
+    }
+    size_t mapped = 0, off = 0;
+    const char *what = "";
+    for (size_t i = 0; i < b.chunk_bytes.size() && err == hipSuccess; ++i) {
+      hipMemGenericAllocationHandle_t h;
+      what = "hipMemCreate";
+      err = hipMemCreate(&h, b.chunk_bytes[i], &prop, 0);
+      if (err != hipSuccess) break;
+      b.chunks.push_back(h);
+      what = "hipMemMap";
+      err = hipMemMap((char *)va + off, b.chunk_bytes[i], 0, h, 0);
+      if (err == hipSuccess) ++mapped;
+      off += b.chunk_bytes[i];
+    }
+    if (err == hipSuccess) {
+      hipMemAccessDesc acc = {};
+      acc.location = prop.location;
+      acc.flags = hipMemAccessFlagsProtReadWrite;
+      what = "hipMemSetAccess";
+      err = hipMemSetAccess(va, b.va_bytes, &acc, 1);
+    }
+    if (err == hipSuccess) break;
+    where = std::string("sgk_ring_alloc: ") + what + " (" + std::to_string(bytes) + " bytes as " + std::to_string(b.chunk_bytes.size()) +
+            " chunk(s), granularity " + std::to_string(gran) + ", chunk " + std::to_string(b.chunks.size()) + ", va " +
+            std::to_string((unsigned long long)(uintptr_t)va) + ", attempt " + std::to_string(attempt + 1) + " of 3)";
+    release_ring(va, b, mapped, false);  // the chunks go (unmapped where they were mapped); the range itself is kept aside
+    set_aside.push_back(va);
+    va = nullptr;
+    if (err == hipErrorOutOfMemory) break;  // not a range's fault
   }
-  if (err == hipSuccess) {
-    hipMemAccessDesc acc = {};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    err = hipMemSetAccess(va, b.va_bytes, &acc, 1);
-  }
-  if (err != hipSuccess) {
-    release_ring(va, b, mapped);
-    return hip_fail(err, "sgk_ring_alloc (HIP virtual memory management)");
-  }
+  for (void *r : set_aside) (void)hipMemAddressFree(r, b.va_bytes);
+  (void)hipGetLastError();
+  if (err != hipSuccess) return hip_fail(err, where.c_str());
   std::lock_guard<std::mutex> lock(g_ring_mutex);
   g_rings[va] = std::move(b);
   *dev_ptr = va;

@@ -152,6 +152,15 @@ __global__ __launch_bounds__(64) void env_server_kernel(StepArgs a, SgkMailbox *
   load_episode_index<ENV>(s, a.n_resets, env, valid);
   EpisodeAcc acc;
   acc_init(acc);
+  // What has been served is what the mailbox says, not what the launcher believes: `done` is written by the servers alone (after
+  // every request, behind a system-scope release), and a server starts only after its predecessor has ended (stream order). A
+  // server that was started for a request another one has already answered -- the host took a late-landing exit word for a fresh
+  // one -- then finds nothing to do instead of taking the step a second time.
+  {
+    uint32_t served = last;
+    if (lane == 0) served = __hip_atomic_load(&mb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    last = (uint32_t)__builtin_amdgcn_readfirstlane((int)served);
+  }
   unsigned long long idle_since = 0;  // wall_clock64() of the first poll without a request, 0 = busy
   for (;;) {
     // lane 0's system-scope load is the poll (one PCIe read); the word is made wave-uniform before it steers control flow
