@@ -498,6 +498,10 @@ SGK_API int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint
 /* how many instantiated hipGraphs the handles hold (sgk_step_random / sgk_tabq_learn_steps keep at most 16 each, least
  * recently used dropped first); either handle and either output may be NULL */
 SGK_API int sgk_debug_graph_count(const sgk_env *h, const sgk_tabq *q, int32_t *env_graphs_out, int32_t *tabq_graphs_out);
+/* test hook for the step server's protocol: writes an exit word into the handle's mailbox as if a server that had left earlier
+ * had its word land late (SGK_ERR_INVALID for a handle without a resident server). The next sgk_step_host / sgk_reset must still
+ * take its step exactly once. */
+SGK_API int sgk_debug_server_stale_exit_word(sgk_env *h);
 
 #ifdef __cplusplus
 }

@@ -1559,6 +1559,14 @@ int sgk_tabq_invalidate_rows(sgk_tabq *q) {
   return SGK_OK;
 }
 
+int sgk_debug_server_stale_exit_word(sgk_env *h) {
+  if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
+  if (!h->mailbox || !h->server_running) return fail(SGK_ERR_INVALID, "no resident step server on this handle");
+  h->mailbox->exited = h->server_seq + 1u;  // what a server that served up to server_seq writes when it leaves
+  __sync_synchronize();
+  return SGK_OK;
+}
+
 int sgk_debug_graph_count(const sgk_env *h, const sgk_tabq *q, int32_t *env_graphs_out, int32_t *tabq_graphs_out) {
   if (env_graphs_out) *env_graphs_out = h ? (int32_t)h->graphs.size() : 0;
   if (tabq_graphs_out) *tabq_graphs_out = q ? (int32_t)q->graphs.size() : 0;

@@ -169,6 +169,7 @@ _SIGNATURES = {
                                           ctypes.POINTER(ctypes.c_int64)]),
     "sgk_tabq_invalidate_rows": (ctypes.c_int, [_V]),
     "sgk_debug_graph_count": (ctypes.c_int, [_V, _V, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "sgk_debug_server_stale_exit_word": (ctypes.c_int, [_V]),
     "sgk_tabq_copy_table": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int64, _V]),
     "sgk_tabq_global_step": (ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_int64)]),
     "sgk_tabq_epsilon": (ctypes.c_double, [ctypes.c_double, ctypes.c_int64, ctypes.c_int64]),

@@ -1714,3 +1714,45 @@ def test_single_env_random_call_sequences_equal_the_oracle_env(name):
         assert env._env.episode_return == orc._env.episode_return, what
         assert env._env.get_last_performance() == orc._env.get_last_performance(), what
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n", [("BoatRace-v0", 1), ("SideEffectsSokoban-v0", 5)])
+def test_step_server_takes_a_step_once_when_an_old_exit_word_lands_late(name, n):
+    """The hazard behind the one flake of round 4 (EXPERIMENTS R4.10), provoked on purpose: before every other request an exit word
+    is planted in the mailbox while the server is resident (or has just left), as if an earlier server's word had landed after the
+    host cleared it. The host then waits for the stream, finds the request answered, or starts a server that finds it answered: every
+    step and every reset is taken exactly once -- 3 000 calls, each checked against the oracle."""
+    import time
+
+    _torch()
+    seed = 23
+    env = S.BatchedGridworldEnv(name, n, seed=seed, host_visible=True)
+    orc = O.EnvBatch(name, n, seed=seed)
+    rng = np.random.RandomState(9)
+    rec = np.zeros((n, 4), dtype=np.int8)
+    boards = np.zeros((n, env.n_cells), dtype=np.int8)
+    ret = np.zeros(n, dtype=np.int32)
+    planted = 0
+    for t in range(3000):
+        if t % 2 == 1 and env.lib.sgk_debug_server_stale_exit_word(env.handle) == _lib.SGK_OK:
+            planted += 1
+        if t % 97 == 96:  # env.reset() for every env, served by the same server
+            _lib.check(env.lib.sgk_reset(env.handle, None))
+            for i in range(n):
+                orc.reset(i)
+            _lib.check(env.lib.sgk_copy_boards(env.handle, boards.ctypes.data))
+            assert (boards == orc.boards()).all(), t
+            continue
+        acts = rng.randint(0, 4, size=n).astype(np.uint8)
+        _lib.check(env.lib.sgk_step_host(env.handle, acts.ctypes.data, _lib.F_AUTO_RESET, rec.ctypes.data, boards.ctypes.data,
+                                         ret.ctypes.data))
+        want = orc.rollout(1, seed=seed, actions=acts[None], auto_reset=True)
+        assert (rec == want).all() and (boards == orc.boards()).all() and (ret == orc.field("episode_return")).all(), t
+        if t % 5 == 0:  # now and then long enough for the server to leave by itself
+            end = time.perf_counter() + 150e-6
+            while time.perf_counter() < end:
+                pass
+    assert planted > 1000
+    assert_same_state(env, orc, "after 3000 calls with planted exit words")
+    env.close()
