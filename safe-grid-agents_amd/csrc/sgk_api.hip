@@ -127,6 +127,13 @@ static int stop_server(sgk_env *h) {
   h->mailbox->request = (uint64_t)SGK_SERVER_STOP;
   __sync_synchronize();
   hipError_t e = hipStreamSynchronize(h->stream);
+  // every server writes its exit word before it ends: see it here, so that it cannot land later -- into a mailbox that has been
+  // cleared for the next server, or freed (bounded: a stream in error has no server to wait for)
+  for (uint32_t spin = 0; e == hipSuccess && h->mailbox->exited == 0 && spin < (1u << 22); ++spin) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+  }
   h->server_running = false;
   h->mailbox->request = (uint64_t)h->server_seq;
   h->mailbox->exited = 0;
