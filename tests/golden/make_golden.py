@@ -427,6 +427,248 @@ def golden_discounted_returns():
     _dump("discounted_returns.json", cases)
 
 
+# ---- the BATCHED agent path, pinned by the reference's own classes ------------------------------------------------------
+# The batched kernels (sgk_tabq_rollout*, sgk_tabq_act / _learn, the streamed random rollout into a trajectory ring) give every
+# env index its own agent and draw from a counter RNG instead of numpy's one global Mersenne Twister. Below, the reference's
+# own train() / TabularQAgent / tabq_learn / RandomAgent / dqn_warmup run ONCE PER ENV INDEX with the numpy calls they make
+# (value.py:37-38, dummy.py:12-16) answered from that counter RNG, so that the fixtures are reference output for exactly the
+# inputs the batched path consumes. The Philox-4x32-10 below is written out here from the published algorithm (Salmon et al.,
+# SC'11) and the keying documented in include/sgk.h; it does not call the oracle or the product.
+
+_M0, _M1, _W0, _W1, _MASK = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+
+
+def _philox4x32_10(ctr, key):
+    c0, c1, c2, c3 = ctr
+    k0, k1 = key
+    for _ in range(10):
+        p0, p1 = _M0 * c0, _M1 * c2
+        c0, c1, c2, c3 = (p1 >> 32) ^ c1 ^ k0, p1 & _MASK, (p0 >> 32) ^ c3 ^ k1, p0 & _MASK
+        k0, k1 = (k0 + _W0) & _MASK, (k1 + _W1) & _MASK
+    return c0, c1, c2, c3
+
+
+def _block(seed, stream, env, j):
+    return _philox4x32_10((env & _MASK, env >> 32, j & _MASK, stream), (seed & _MASK, seed >> 32))
+
+
+def _explore_draw(seed, env, t):
+    """Stream 1: agent step t of env index `env` -> (53-bit uniform built as numpy builds random_sample(), explore action)."""
+    x = _block(seed, 1, env, t >> 1)
+    a, b = (x[2], x[3]) if t & 1 else (x[0], x[1])
+    return ((a >> 5) * 67108864 + (b >> 6)) / 9007199254740992.0, a & 3
+
+
+def _random_action(seed, env, t):
+    """Stream 0: lockstep step t of env index `env` -> 2 bits of block t >> 6."""
+    x = _block(seed, 0, env, t >> 6)
+    return (x[(t >> 4) & 3] >> (2 * (t & 15))) & 3
+
+
+class _Budget(Exception):
+    """Raised by the patched draw when the agent asks for step number `steps`: the reference loop stops there, mid-episode."""
+
+
+class _NumpyProxy:
+    """What a reference module sees as `np`: numpy, except for the np.random members named in `random_members`."""
+
+    def __init__(self, **random_members):
+        self.random = types.SimpleNamespace(**random_members)
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+
+class _IndexedEnv(OracleGridworldEnv):
+    """The oracle env of ONE env index of a batch: its own draws (WhiskyGold's exploration, ...) are keyed (seed, env index, reset
+    counter) like the batch's, and the first reset() after construction does nothing -- train.py:64 resets an env that gym.make
+    has just reset; the batched path starts its first episode from the reset that created it (reset counter 1)."""
+    env_index = 0
+
+    def __init__(self, name):
+        super().__init__(name)
+        self._fresh = True
+
+    def seed(self, seed=None):
+        from oracle import oracle as O
+
+        # the env of this index as the batch creates it: keyed (seed, env index) from its first reset on (reset counter 1)
+        self._b = O.EnvBatch(self._b.env_id, 1, seed=int(seed) & (2**64 - 1), env_begin=self.env_index)
+        self._fresh = True
+        return [seed]
+
+    def reset(self):
+        if self._fresh:
+            self._fresh = False
+            obs = self._obs()
+            self._last = obs
+            return np.concatenate([obs, obs], axis=0) if self.use_transitions else obs
+        return super().reset()
+
+    def step(self, action):
+        self._fresh = False
+        return super().step(action)
+
+
+def golden_batched_tabq(name, argv, n_agents, steps):
+    """The reference's train() (train.py:21-70: ctor, env.seed, the episode loop with its reset, whiler + tabq_learn with
+    --cheat's reward / action swap, track_metrics) once per env index 0 .. n_agents-1, `steps` agent steps each; np.random.sample /
+    np.random.choice as value.py:37-38 calls them return Philox stream 1's draw for (seed, env index, agent step)."""
+    import train as ref_train
+    from safe_grid_agents.parsing import prepare_parser
+    import safe_grid_agents.common.agents.value as value_mod
+
+    global _PARSER
+    if _PARSER is None:
+        _PARSER = prepare_parser()
+    per_agent = []
+    eps_used_all = None
+    q_agent, q_boards, q_rows = [], [], []
+    gym = sys.modules["gym"]
+    orig_make, orig_np, orig_init = gym.make, value_mod.np, value_mod.TabularQAgent.__init__
+    orig_writer = ref_train.SummaryWriter
+    try:
+        for index in range(n_agents):
+            args = _PARSER.parse_args(argv)
+            args.device, args.log_dir = "cpu", "unused"
+            args.episodes, args.eval_every = 10**9, 10**9  # the draw budget ends the run; no evaluation in between
+            seed = int(args.seed)
+            captured, writers, made = {}, [], []
+            state = {"t": 0, "pending": None}
+            eps_used = []
+
+            def sample():
+                t = state["t"]
+                if t == steps:
+                    raise _Budget()
+                eps_used.append(float(captured["agent"].epsilon).hex())
+                u, a = _explore_draw(seed, index, t)
+                state["pending"], state["t"] = a, t + 1
+                return u
+
+            def choice(n):
+                assert n == 4 and state["pending"] is not None
+                a, state["pending"] = state["pending"], None
+                return a
+
+            def spy_init(self, env, a):
+                orig_init(self, env, a)
+                captured["agent"] = self
+
+            def make(env_name):
+                env = _IndexedEnv(env_name)
+                env.env_index = index
+                made.append(env)
+                return env
+
+            class W(RecordingWriter):
+                def __init__(self, log_dir=None):
+                    super().__init__(log_dir)
+                    writers.append(self)
+
+            gym.make, ref_train.SummaryWriter = make, W
+            value_mod.np = _NumpyProxy(sample=sample, choice=choice)
+            value_mod.TabularQAgent.__init__ = spy_init
+            try:
+                ref_train.train(args)
+                raise AssertionError("the reference loop outlived its draw budget")
+            except _Budget:
+                pass
+            agent, env = captured["agent"], made[0]
+            assert len(env.actions_log) == steps and len(eps_used) == steps
+            if eps_used_all is None:
+                eps_used_all = eps_used
+            assert eps_used == eps_used_all  # a function of the agent step alone
+            episodes = {"returns": [], "safeties": [], "margins": [], "margins_support": []}
+            for c in writers[0].calls:
+                if c[0] == "scalar" and c[1].startswith("Train/") and c[1][6:] in episodes:
+                    episodes[c[1][6:]].append(c[2])
+            for key, row in agent.Q.items():
+                q_agent.append(index)
+                q_boards.append([int(x) for x in key])
+                q_rows.append(np.asarray(row, dtype=np.float64))
+            per_agent.append({"actions": "".join(str(int(a)) for a in env.actions_log), "episodes": episodes,
+                              "final_board": [int(x) for x in env._obs().ravel()],
+                              "episode_return_at_stop": RecordingWriter._num(env._env.episode_return),
+                              "epsilon_at_stop": float(agent.epsilon).hex()})
+    finally:
+        gym.make, value_mod.np, value_mod.TabularQAgent.__init__ = orig_make, orig_np, orig_init
+        ref_train.SummaryWriter = orig_writer
+    args = _PARSER.parse_args(argv)
+    # the draws themselves, so that a reader of the fixture need not trust this script's Philox: checked against the oracle's here
+    from oracle import oracle as O
+    for index in (0, 1, n_agents - 1):
+        for t in (0, 1, 2, 3, steps - 1):
+            assert _explore_draw(int(args.seed), index, t) == O.explore_draw(int(args.seed), index, t)
+    meta = {"argv": argv, "env": _made_name(args), "cheat": bool(args.cheat), "seed": int(args.seed), "n_agents": n_agents,
+            "steps": steps, "lr": args.lr, "discount": args.discount, "epsilon": args.epsilon,
+            "epsilon_anneal": args.epsilon_anneal, "epsilon_used": eps_used_all, "agents": per_agent,
+            "draw_probe": {"%d,%d" % (i, t): [float(_explore_draw(int(args.seed), i, t)[0]).hex(), _explore_draw(int(args.seed), i, t)[1]]
+                           for i in (0, 1, n_agents - 1) for t in (0, 1, 2, 3, steps - 1)}}
+    np.savez_compressed(os.path.join(HERE, name), meta=np.array(json.dumps(meta, separators=(",", ":"))),
+                        q_agent=np.asarray(q_agent, dtype=np.int32), q_boards=np.asarray(q_boards, dtype=np.int8),
+                        q_rows=np.stack(q_rows))
+    print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes;", len(q_agent), "Q rows")
+
+
+def _made_name(args):
+    from safe_grid_agents.parsing import ENV_MAP
+
+    return ENV_MAP[args.env_alias]
+
+
+def golden_batched_warmup(name, env_name, seed, n_agents, steps):
+    """The reference's dqn_warmup (warmup.py:8-23) with its RandomAgent (dummy.py:10-16) once per env index; np.random.randint as
+    dummy.py:16 calls it returns Philox stream 0's action for (seed, env index, lockstep step). Recorded: what the replay buffer
+    holds afterwards (contain.py:16-17) and the `returns` meter with its spurious first update (warmup.py:12-17)."""
+    import safe_grid_agents.common.agents.dummy as dummy_mod
+    from safe_grid_agents.common.warmup import dqn_warmup
+    from safe_grid_agents.common.utils.meters import make_meters
+    from safe_grid_agents.common.utils.contain import ReplayBuffer
+    from oracle import oracle as O
+
+    orig_np = dummy_mod.np
+    out = {k: [] for k in ("states", "successors", "actions", "rewards", "terminals")}
+    meters = []
+    try:
+        for index in range(n_agents):
+            state = {"t": 0}
+
+            def randint(lo, hi):
+                assert (lo, hi) == (0, 4)
+                t = state["t"]
+                state["t"] = t + 1
+                return _random_action(seed, index, t)
+
+            dummy_mod.np = _NumpyProxy(randint=randint, seed=lambda s: None)
+            env = _IndexedEnv(env_name)
+            env.env_index = index
+            env.seed(seed)
+            args = types.SimpleNamespace(seed=seed, replay_capacity=steps)
+            agent = types.SimpleNamespace(replay=ReplayBuffer(args.replay_capacity))
+            hist = make_meters({})
+            dqn_warmup(agent, env, hist, args)
+            buf = list(agent.replay._buffer)
+            assert len(buf) == steps and state["t"] == steps and env.actions_log == [int(e.action) for e in buf]
+            out["states"].append(np.stack([e.state.ravel() for e in buf]).astype(np.int8))
+            out["successors"].append(np.stack([e.successor.ravel() for e in buf]).astype(np.int8))
+            out["actions"].append(np.asarray([e.action for e in buf], dtype=np.uint8))
+            out["rewards"].append(np.asarray([e.reward for e in buf], dtype=np.int32))
+            out["terminals"].append(np.asarray([e.terminal for e in buf], dtype=np.uint8))
+            h = hist["returns"]
+            meters.append({"count": int(h.count), "sum": int(h.sum), "max": int(h.max), "history": [int(x) for x in h._history],
+                           "episode_return_at_stop": int(env._env.episode_return)})
+    finally:
+        dummy_mod.np = orig_np
+    for index in (0, n_agents - 1):
+        for t in (0, 1, 63, 64, steps - 1):
+            assert _random_action(seed, index, t) == O.random_action(seed, index, t)
+    meta = {"env": env_name, "seed": seed, "n_agents": n_agents, "steps": steps, "returns_meters": meters}
+    np.savez_compressed(os.path.join(HERE, name), meta=np.array(json.dumps(meta, separators=(",", ":"))),
+                        **{k: np.stack(v) for k, v in out.items()})
+    print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+
+
 def main():
     _install_stubs()
     golden_discounted_returns()
@@ -490,6 +732,18 @@ def main():
     golden_train_ppo("train_whisky_ppo_mlp_seed2_cheat.json",
                      ["-S", "2", "-E", "5", "-EE", "3", "-V", "110", "-EV", "0", "-C", "whisky", "ppo-mlp", "-l", "0.001", "-r", "1",
                       "-e", "4", "-b", "32", "-hd", "24"])  # -r 1: the reference cannot stack rollouts of different lengths
+    # the batched path's own inputs through the reference's own classes (one run of train() / dqn_warmup per env index)
+    golden_batched_tabq("batched_tabq_boat.npz",
+                        ["-S", "21", "boat", "tabular-q", "-l", ".5", "-e", "0.05", "-dl", "1200"], 64, 1600)
+    golden_batched_tabq("batched_tabq_island.npz",
+                        ["-S", "5", "-D", "0.95", "island", "tabular-q", "-l", ".5", "-e", "0.1", "-dl", "1200"], 64, 1600)
+    golden_batched_tabq("batched_tabq_sokoban_cheat.npz",
+                        ["-S", "123", "-C", "sokoban", "tabular-q", "-l", ".1", "-e", "0.1", "-dl", "1000"], 64, 1600)
+    golden_batched_tabq("batched_tabq_whisky_cheat.npz",
+                        ["-S", "4", "-C", "-D", "0.95", "whisky", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"], 64, 1500)
+    golden_batched_warmup("batched_warmup_boat.npz", "BoatRace-v0", 0x5AFE, 64, 330)
+    golden_batched_warmup("batched_warmup_island.npz", "IslandNavigation-v0", 9, 64, 330)
+    golden_batched_warmup("batched_warmup_sokoban.npz", "SideEffectsSokoban-v0", 17, 64, 330)
     # the reference tree must be left untouched
     leaked = [os.path.join(d, f) for d, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
     assert not leaked, leaked

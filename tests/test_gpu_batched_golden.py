@@ -1,0 +1,158 @@
+"""The HIP kernels of the BATCHED agent path against REFERENCE output (tests/golden/batched_*.npz): the reference's own
+train() / TabularQAgent / tabq_learn (value.py:15-58, learn.py:8-26,61-85) and RandomAgent / dqn_warmup (dummy.py:10-16,
+warmup.py:8-23), one run per env index with np.random answered from the counter RNG the kernels draw from. One link from the
+reference to the kernels -- no host restatement, no oracle in between (tests/test_batched_golden_cpu.py is the oracle's own link).
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+import batched_golden as BG
+import safe_grid_agents_amd as S
+from safe_grid_agents_amd import _lib
+from test_batched_golden_cpu import check_warmup_meters, expected_metrics
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _assert_tables_are_the_reference_dictionaries(env, agent, fx):
+    """Every row of every reference agent's Q dictionary (keyed by the flattened board, value.py:34) == the row of the state
+    index that board hashes to, as float64 bit patterns; and the device holds no other non-zero row."""
+    from test_gpu_parity import _board_of_state
+
+    tab = agent.table_host()
+    index_of = {}
+    for si in range(agent.n_states):
+        try:
+            index_of[_board_of_state(env, si).tobytes()] = si
+        except Exception:  # state indices that name no board (e.g. the agent on a wall cell)
+            pass
+    for i in range(fx.n):
+        claimed = set()
+        for board, q in fx.rows_of(i):
+            si = index_of.get(board.astype(np.int8).tobytes())
+            if si is None:  # a board without a row of its own: terminal boards are never looked up before they are left...
+                assert not np.abs(q).any(), (i, board.tolist())  # ...so the reference only ever holds zeros for them
+                continue
+            assert BG.hexes(tab[i, si]) == BG.hexes(q), (i, si, board.tolist())
+            claimed.add(si)
+        nz = set(np.nonzero(np.abs(tab[i]).sum(axis=1))[0].tolist())
+        assert nz <= claimed, (i, sorted(nz - claimed))
+
+
+def _assert_final_state(env, agent, fx):
+    assert agent.t == fx.steps
+    assert float(agent.epsilon).hex() == fx.agents[0]["epsilon_at_stop"]
+    assert (env.boards_host().reshape(fx.n, -1) == fx.final_boards).all()
+    st = env.episode_state_host()
+    assert st["episode_return"].tolist() == [int(BG._num(a["episode_return_at_stop"])) for a in fx.agents]
+    got = env.metrics()
+    for k, v in expected_metrics(fx, fx.n * fx.steps).items():
+        assert int(got[k]) == v, (k, int(got[k]), v)
+
+
+@pytest.mark.parametrize("name", BG.TABQ_FIXTURES)
+def test_device_epsilon_schedule_is_the_reference_agents(name):
+    fx = BG.TabqFixture(name)
+    lib = _lib.load()
+    assert [float(lib.sgk_tabq_epsilon(fx.eps0, fx.anneal, t)).hex() for t in range(fx.steps)] == fx.epsilon_used
+
+
+@pytest.mark.parametrize("kernel", ["auto", "lds", "hbm"])
+@pytest.mark.parametrize("name", BG.TABQ_FIXTURES)
+def test_fused_tabq_rollout_kernels_reproduce_the_reference_agents(name, kernel):
+    """tabq_rollout_kernel (tables in LDS) / tabq_rollout_hbm_kernel (rows in HBM): what bench.py --config 3 times."""
+    _torch()
+    fx = BG.TabqFixture(name)
+    env = S.BatchedGridworldEnv(fx.env, fx.n, seed=fx.seed)
+    agent = S.BatchedTabularQAgent(env, fx.args())
+    try:
+        try:
+            agent.rollout(700, cheat=fx.cheat, kernel=kernel)
+        except _lib.SgkError as exc:
+            assert kernel == "lds" and "do not fit LDS" in str(exc)
+            pytest.skip("%s: tables do not fit LDS" % fx.env)
+        agent.rollout(fx.steps - 700, cheat=fx.cheat, kernel=kernel)
+        _assert_final_state(env, agent, fx)
+        _assert_tables_are_the_reference_dictionaries(env, agent, fx)
+    finally:
+        agent.close(); env.close()
+
+
+@pytest.mark.parametrize("how", ["calls", "graph"])
+@pytest.mark.parametrize("name", BG.TABQ_FIXTURES)
+def test_drop_in_call_sequence_reproduces_the_reference_agents(name, how):
+    """act_explore -> env.step -> learn -> reset_done as four launches per lockstep step, made from Python (every step's actions
+    compared with the reference agents') and replayed from a hipGraph (sgk_tabq_learn_steps)."""
+    _torch()
+    fx = BG.TabqFixture(name)
+    env = S.BatchedGridworldEnv(fx.env, fx.n, seed=fx.seed)
+    agent = S.BatchedTabularQAgent(env, fx.args())
+    try:
+        if how == "calls":
+            for t in range(fx.steps):
+                a = agent.act_explore()
+                assert a.cpu().numpy().tolist() == fx.actions[t].tolist(), t
+                env.step(a, auto_reset=False, write_boards=(t == fx.steps - 1))
+                agent.learn(action=a, cheat=fx.cheat)
+                env.reset_done()
+        else:
+            done = 0
+            for k in (100, 100, 7, 1, 500):
+                agent.learn_steps(k, cheat=fx.cheat)
+                done += k
+            agent.learn_steps(fx.steps - done - 1, cheat=fx.cheat)
+            agent.learn_steps(1, cheat=fx.cheat, write_boards=True)
+        _assert_final_state(env, agent, fx)
+        _assert_tables_are_the_reference_dictionaries(env, agent, fx)
+    finally:
+        agent.close(); env.close()
+
+
+@pytest.mark.parametrize("path", ["stream_ring", "launches"])
+@pytest.mark.parametrize("name", BG.WARMUP_FIXTURES)
+def test_random_rollout_into_a_trajectory_ring_reproduces_the_reference_warmup(name, path):
+    """RandomAgent + dqn_warmup per env index: slice t of the trajectory ring == what the reference's replay buffer holds for
+    step t (successor board, reward, terminal, action) -- the headline kernel (rollout_random_kernel<stream>, bench.py's `value`)
+    and the per-step step_kernel launches."""
+    torch = _torch()
+    fx = BG.WarmupFixture(name)
+    env = S.BatchedGridworldEnv(fx.env, fx.n, seed=fx.seed)
+    try:
+        reset_board = env.boards_host().reshape(fx.n, -1).copy()
+        assert (fx.states == reset_board[None]).all()  # (warmup.py:17,21 never advances `state`: see the CPU test)
+        if path == "stream_ring":
+            boards = torch.full((fx.steps, fx.n, env.n_cells), -7, dtype=torch.int8, device="cuda")
+            recs = torch.full((fx.steps, fx.n, 4), -7, dtype=torch.int8, device="cuda")
+            env.rollout_random_stream(fx.steps, boards=boards, recs=recs, first_slice=0)
+            got_b, got_r = boards.cpu().numpy(), recs.cpu().numpy()
+        else:
+            got_b = np.empty((fx.steps, fx.n, env.n_cells), dtype=np.int8)
+            got_r = np.empty((fx.steps, fx.n, 4), dtype=np.int8)
+            for t in range(fx.steps):
+                env.step_random(1, auto_reset=False)
+                got_b[t] = env.boards_host().reshape(fx.n, -1)
+                got_r[t] = env.step_records_host()
+                env.reset_done()
+        want_b = fx.successors
+        if path == "stream_ring":
+            # The one convention that differs, by design: a trajectory ring keeps, at an episode's last step, the observation the
+            # agent acts on NEXT (the auto-reset board: `state` of the following row) where the reference's row keeps the terminal
+            # board as `successor` -- a board DeepQAgent.learn never uses (value.py:121 zeroes next_Q where terminal). The terminal
+            # boards themselves are compared on the per-step path of this same test (no auto-reset: the step leaves them in place).
+            want_b = np.where((fx.terminals != 0)[:, :, None], reset_board[None], fx.successors)
+        assert (got_b == want_b).all(), np.argwhere((got_b != want_b).any(axis=2))[:3]
+        assert (got_r[:, :, 0] == fx.rewards).all()
+        assert ((got_r[:, :, 2] != 0) == (fx.terminals != 0)).all()
+        assert (got_r[:, :, 3].view(np.uint8) == fx.actions).all()
+        check_warmup_meters(fx, env.metrics())
+    finally:
+        env.close()
