@@ -7,7 +7,8 @@
  * (safe-grid-agents_amd/safe_grid_agents_amd) binds these with ctypes; INTEGRATION.md shows the stub.
  *
  * Conventions: flat C, plain pointers and sizes. Every function returns SGK_OK (0) or a negative
- * SGK_ERR_* and leaves a message for sgk_last_error() (thread-local). Handles are opaque and
+ * SGK_ERR_* and leaves a message for sgk_last_error() (thread-local, a fixed buffer: reporting an error allocates nothing).
+ * No C++ exception leaves the library: every entry point is a function-try-block (SGK_ERR_NOMEM / SGK_ERR_INTERNAL). Handles are opaque and
  * thread-compatible (one thread at a time per handle). Pointers named *_dev are DEVICE pointers
  * valid on the handle's GPU (e.g. torch tensor.data_ptr()); pointers named *_host are host memory.
  * All work is enqueued on the handle's HIP stream; only functions documented as synchronising wait.
@@ -33,8 +34,9 @@ extern "C" {
 #define SGK_OK 0
 #define SGK_ERR_INVALID (-1) /* bad argument */
 #define SGK_ERR_HIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
-#define SGK_ERR_NOMEM (-3)
+#define SGK_ERR_NOMEM (-3)    /* a host allocation failed inside the library (std::bad_alloc stops at the boundary) */
 #define SGK_ERR_NODEVICE (-4) /* no usable GPU: the library has NO CPU fallback */
+#define SGK_ERR_INTERNAL (-5) /* any other C++ exception stopped at the boundary: no exception crosses the C-ABI */
 
 /* env ids (reference parsing/parse.py:22-37 ENV_MAP aliases boat / island / sokoban / lava) */
 #define SGK_BOAT_RACE 0
@@ -502,6 +504,9 @@ SGK_API int sgk_debug_graph_count(const sgk_env *h, const sgk_tabq *q, int32_t *
  * had its word land late (SGK_ERR_INVALID for a handle without a resident server). The next sgk_step_host / sgk_reset must still
  * take its step exactly once. */
 SGK_API int sgk_debug_server_stale_exit_word(sgk_env *h);
+/* test hook for the out-of-memory paths: the k-th host allocation the library makes from now on (k = 1: the next one) fails as an
+ * exhausted heap would (std::bad_alloc inside, SGK_ERR_NOMEM at the boundary); k = 0 disarms. Returns the previous countdown. */
+SGK_API int sgk_debug_fail_host_alloc(int k);
 
 #ifdef __cplusplus
 }

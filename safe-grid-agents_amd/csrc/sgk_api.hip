@@ -8,72 +8,18 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <mutex>
-#include <new>
-#include <string>
+#include <memory>
 #include <utility>
-#include <vector>
 
+#include "sgk_host_core.h"
 #include "sgk_kernels.h"
 
+using sgk::host::fail;
+using sgk::host::GraphCache;
+using sgk::host::hip_fail;
+using sgk::host::KeepError;
+
 namespace {
-
-thread_local std::string g_last_error;
-
-int fail(int code, const std::string &msg) {
-  g_last_error = msg;
-  return code;
-}
-
-int hip_fail(hipError_t e, const char *what) {
-  return fail(SGK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-
-#define SGK_HIP(call)                                    \
-  do {                                                   \
-    hipError_t e__ = (call);                             \
-    if (e__ != hipSuccess) return hip_fail(e__, #call);  \
-  } while (0)
-
-// Instantiated hipGraphs of a handle, keyed by (n_steps, flags): a small LRU. A caller that varies n_steps call by call would
-// otherwise pile up instantiated graphs (each holds its kernel nodes' argument blocks) until the handle is destroyed. The
-// least recently used one is destroyed when the cap is reached -- after its stream has drained, because a replay of it may
-// still be in flight.
-struct GraphCache {
-  static constexpr size_t CAP = 16;
-  struct Item {
-    std::pair<int32_t, uint32_t> key;
-    hipGraphExec_t exec;
-    uint64_t used;
-  };
-  std::vector<Item> items;
-  uint64_t tick = 0;
-  hipGraphExec_t find(const std::pair<int32_t, uint32_t> &key) {
-    for (Item &it : items)
-      if (it.key == key) {
-        it.used = ++tick;
-        return it.exec;
-      }
-    return nullptr;
-  }
-  void insert(const std::pair<int32_t, uint32_t> &key, hipGraphExec_t exec, hipStream_t replays_on) {
-    if (items.size() >= CAP) {
-      size_t lru = 0;
-      for (size_t i = 1; i < items.size(); ++i)
-        if (items[i].used < items[lru].used) lru = i;
-      (void)hipStreamSynchronize(replays_on);
-      (void)hipGraphExecDestroy(items[lru].exec);
-      items.erase(items.begin() + (long)lru);
-    }
-    items.push_back(Item{key, exec, ++tick});
-  }
-  void clear() {
-    for (Item &it : items) (void)hipGraphExecDestroy(it.exec);
-    items.clear();
-  }
-  size_t size() const { return items.size(); }
-};
 
 __global__ void set_counter_kernel(uint64_t *ctr, uint64_t v) { *ctr = v; }
 __global__ void add_counter_kernel(uint64_t *ctr, uint64_t v) { *ctr += v; }
@@ -90,14 +36,14 @@ struct sgk_env {
   int8_t *dense_scratch = nullptr;
   uint8_t *actions_scratch = nullptr;
   uint8_t *pinned = nullptr;         // host staging for sgk_step_host: [actions n][rec 4n][state 8n][boards n*n_cells]
+  uint64_t *copy_chunk = nullptr;    // pinned staging of sgk_copy_episode_state: 2^17 state words at a time
   hipEvent_t order_events[2] = {nullptr, nullptr};  // sgk_stream_wait / sgk_stream_signal
   long long *metrics_pinned = nullptr;  // [SGK_METRICS_LEN] pinned device-mapped host words the reduce kernel also writes
   float *gamma_dev = nullptr;        // [1024] float32(discount ** t) for sgk_discounted_returns
   double gamma_discount = -1.0;
   // the single-env step server (sgk_step.hip, env_server_kernel): a resident wave that serves sgk_step_host through a mailbox
-  sgk::SgkMailbox *mailbox = nullptr;  // pinned device-mapped host memory (host_visible handles of <= 64 envs)
-  bool server_running = false;
-  uint32_t server_seq = 0;             // number of the last step requested
+  sgk::host::ServerLink srv;           // srv.mb: pinned device-mapped host memory (host_visible handles of <= 64 envs); the protocol:
+                                       // sgk_host_core.h
   bool host_visible = false;         // SGK_MEM_HOST_VISIBLE: state/rec/boards/actions live in pinned device-mapped host memory
   uint8_t *hv_actions = nullptr;     // host-visible action buffer (host_visible mode)
   GraphCache graphs;                  // (n_steps, flags) -> captured step launches
@@ -120,124 +66,47 @@ namespace sgk {
 hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t t_off, uint32_t flags, hipStream_t st);
 }  // namespace sgk
 
-// Ask the step server to leave and wait until it has: afterwards the handle's arrays in memory are current (state words, metric
-// partials) and its stream is free for the next kernel.
-static int stop_server(sgk_env *h) {
-  if (!h->server_running) return SGK_OK;
-  h->mailbox->request = (uint64_t)SGK_SERVER_STOP;
-  __sync_synchronize();
-  hipError_t e = hipStreamSynchronize(h->stream);
-  // every server writes its exit word before it ends: see it here, so that it cannot land later -- into a mailbox that has been
-  // cleared for the next server, or freed (bounded: a stream in error has no server to wait for)
-  for (uint32_t spin = 0; e == hipSuccess && h->mailbox->exited == 0 && spin < (1u << 22); ++spin) {
-#if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
-#endif
-  }
-  h->server_running = false;
-  h->mailbox->request = (uint64_t)h->server_seq;
-  h->mailbox->exited = 0;
-  __sync_synchronize();
-  if (e != hipSuccess) return hip_fail(e, "stopping the step server");
-  return SGK_OK;
+// The step server's protocol lives in sgk_host_core.h (stop_server / server_round_trip on a ServerLink); here is the link's launcher
+// and the two calls with the handle's current stream filled in (sgk_set_stream may have changed it since the last call).
+static hipError_t launch_server_of(void *ctx, sgk::SgkMailbox *mb, uint32_t served, hipStream_t stream) {
+  sgk_env *h = static_cast<sgk_env *>(ctx);
+  return sgk::launch_env_server(h->sh, h->hv_actions, mb, served, stream);
 }
-
-// One request to the handle's step server and its answer (host-visible handles with a mailbox): `flags8` = the SGK_F_* flags of a
-// step, or SGK_SRV_RESET; `action0` rides in the request word. Starts the server when none is running. On failure the request is
-// taken back (the host counters have not moved) and the server is marked gone.
+static int stop_server(sgk_env *h) {
+  h->srv.stream = h->stream;
+  return sgk::host::stop_server(h->srv);
+}
 static int server_round_trip(sgk_env *h, uint32_t flags8, uint32_t action0) {
-  sgk::Shard &s = h->sh;
-  sgk::SgkMailbox *mb = h->mailbox;
-  if (!h->server_running) {
-    mb->request = (uint64_t)h->server_seq;
-    mb->done = h->server_seq;
-    mb->exited = 0;
-    __sync_synchronize();
-    SGK_HIP(sgk::launch_env_server(s, h->hv_actions, mb, h->server_seq, h->stream));
-    h->server_running = true;
-  }
-  const uint32_t prev = h->server_seq;
-  uint32_t seq = prev + 1u;
-  if (seq == SGK_SERVER_STOP) seq = 0u;
-  __sync_synchronize();  // the other envs' actions before the request word
-  mb->request = (uint64_t)seq | ((uint64_t)(flags8 & 0xffu) << 32) | ((uint64_t)(action0 & 3u) << 40);
-  h->server_seq = seq;
-  // Wait for the answer. The loop watches the mailbox, and every 2^20 spins (~a millisecond) it also asks the STREAM: a server
-  // kernel that died, or never started, leaves the stream idle (or in error) with no answer and no exit word -- the caller then
-  // gets an error instead of spinning for minutes. On every failure the request is taken back (the host counters have not moved)
-  // and the server is marked gone, so the next call starts from the arrays in memory.
-  uint64_t spins = 0;
-  int failed = 0;
-  while (mb->done != seq) {
-    if (mb->exited != 0) {
-      // the server left (idle) without having seen this request: start another one that has served up to seq - 1. (The exit word
-      // of an EARLIER server can land late, after this thread cleared it: the stream then still holds a live server, which answers
-      // while we wait for it here -- look at the answer again before starting anything, and a server started needlessly finds the
-      // request already answered in the mailbox: env_server_kernel.)
-      hipError_t e = hipStreamSynchronize(h->stream);
-      mb->exited = 0;
-      __sync_synchronize();
-      if (e == hipSuccess && mb->done == seq) {
-        h->server_running = false;  // (the stream is idle and the exit word is cleared: the next request starts a server afresh)
-        break;
-      }
-      if (e == hipSuccess) e = sgk::launch_env_server(s, h->hv_actions, mb, prev, h->stream);
-      if (e != hipSuccess) {
-        failed = hip_fail(e, "restarting the step server");
-        break;
-      }
-    }
-    if ((++spins & ((1ull << 20) - 1)) == 0) {
-      const hipError_t q = hipStreamQuery(h->stream);
-      if (q != hipErrorNotReady && mb->done != seq && mb->exited == 0) {  // nothing is running and nothing was answered
-        failed = q == hipSuccess ? fail(SGK_ERR_HIP, "the step server is gone (its stream is idle) without an answer")
-                                 : hip_fail(q, "the step server's stream");
-        break;
-      }
-      if (spins > (1ull << 33)) {
-        failed = fail(SGK_ERR_HIP, "the step server did not answer");
-        break;
-      }
-    }
-#if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
-#endif
-  }
-  if (failed) {
-    const std::string keep = g_last_error;
-    h->server_seq = prev;  // the request was not served: the host counters are untouched, so is the request number
-    (void)stop_server(h);  // asks a server that may still be there to leave, waits for the stream, clears the mailbox
-    g_last_error = keep;
-    return failed;
-  }
-  __sync_synchronize();  // the server's outputs (released before the number) are read after it
-  return SGK_OK;
+  h->srv.stream = h->stream;
+  h->srv.launch_ctx = h;
+  h->srv.launch = launch_server_of;
+  return sgk::host::server_round_trip(h->srv, flags8, action0);
 }
 
 extern "C" {
 
-const char *sgk_last_error(void) { return g_last_error.c_str(); }
-int sgk_set_error(int code, const char *msg) { return fail(code, msg ? msg : "?"); }  // for the other translation units
+const char *sgk_last_error(void) { return sgk::host::error_buffer(); }
+int sgk_set_error(int code, const char *msg) try { return fail(code, "%s", msg ? msg : "?"); } SGK_CATCH_STATUS  // for the other translation units
 int sgk_abi_version(void) { return SGK_ABI_VERSION; }
 
-int sgk_device_count(int *n_out) {
+int sgk_device_count(int *n_out) try {
   if (!n_out) return fail(SGK_ERR_INVALID, "n_out is NULL");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) {
     *n_out = 0;
-    return fail(SGK_ERR_NODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return fail(SGK_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
   }
   *n_out = n;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_random_action(uint64_t seed, uint64_t env_index, uint64_t t) { return sgk::host_random_action(seed, env_index, t); }
-double sgk_tabq_epsilon(double epsilon, int64_t epsilon_anneal, int64_t t) {
+int sgk_random_action(uint64_t seed, uint64_t env_index, uint64_t t) try { return sgk::host_random_action(seed, env_index, t); } SGK_CATCH_STATUS
+double sgk_tabq_epsilon(double epsilon, int64_t epsilon_anneal, int64_t t) try {
   return sgk::host_epsilon_at(epsilon, epsilon_anneal, t);
-}
+} SGK_CATCH_VALUE(0.0)
 
-int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int action, int32_t out[5]) {
+int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int action, int32_t out[5]) try {
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
   if (agent_cell < 0 || agent_cell >= R.n_cells || action < 0 || action >= SGK_ACTIONS) return fail(SGK_ERR_INVALID, "bad cell/action");
@@ -246,10 +115,10 @@ int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int acti
   if (sgk::host_debug_transition(R, agent_cell, box_cell, action, o) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
   for (int i = 0; i < 5; ++i) out[i] = o[i];
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_debug_host_step(int env_id, uint64_t state_word, int n_resets, int action, uint64_t seed, uint64_t env_index,
-                        uint64_t *state_word_out, int32_t out[4], double *aux_env) {
+                        uint64_t *state_word_out, int32_t out[4], double *aux_env) try {
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
   if (action < 0 || action >= SGK_ACTIONS || !state_word_out || !out) return fail(SGK_ERR_INVALID, "bad action / NULL output");
@@ -258,15 +127,15 @@ int sgk_debug_host_step(int env_id, uint64_t state_word, int n_resets, int actio
     return fail(SGK_ERR_INVALID, "unknown env_id");
   for (int i = 0; i < 4; ++i) out[i] = o[i];
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets, const double *aux_env) {
+uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets, const double *aux_env) try {
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return ~0ull;
   return sgk::host_reset_word(R, seed, env_index, n_resets, aux_env);
-}
+} SGK_CATCH_VALUE(~0ull)
 
-int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]) {
+int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]) try {
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
   if (!dims || !templ || !agent_value) return fail(SGK_ERR_INVALID, "NULL output");
@@ -274,36 +143,13 @@ int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agen
   memcpy(templ, R.templ, 64);
   memcpy(agent_value, R.agent_value, 64);
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-// A handle's own stream outlives the handle: sgk_stream() hands it to the caller (the Python wrapper wraps it as a
-// torch.cuda.ExternalStream), and a caller-side object that remembers it -- torch's pinned-memory allocator records an event on
-// every stream a block was used on when the block is freed -- must never find a destroyed stream there. Streams of destroyed handles
-// wait in a per-device pool for the next sgk_create on that device; a process holds as many as it ever had handles alive at once.
-namespace {
-std::mutex g_stream_pool_mutex;
-std::map<int, std::vector<hipStream_t>> g_stream_pool;
+// (A handle's own stream outlives the handle: it goes back to the per-device pool of sgk_host_core.h.)
+static hipError_t pooled_stream(int device, hipStream_t *out) { return sgk::host::stream_pool().take(device, out); }
+static void return_stream(int device, hipStream_t st) { sgk::host::stream_pool().give_back(device, st); }
 
-hipError_t pooled_stream(int device, hipStream_t *out) {
-  {
-    std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
-    auto &free_streams = g_stream_pool[device];
-    if (!free_streams.empty()) {
-      *out = free_streams.back();
-      free_streams.pop_back();
-      return hipSuccess;
-    }
-  }
-  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-}
-
-void return_stream(int device, hipStream_t st) {
-  std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
-  g_stream_pool[device].push_back(st);
-}
-}  // namespace
-
-int sgk_destroy(sgk_env *h) {
+int sgk_destroy(sgk_env *h) try {
   if (!h) return SGK_OK;
   (void)hipSetDevice(h->sh.device);
   (void)stop_server(h);
@@ -316,7 +162,8 @@ int sgk_destroy(sgk_env *h) {
     if (s.rec) (void)hipHostFree(s.rec);
     if (s.boards) (void)hipHostFree(s.boards);
     if (h->hv_actions) (void)hipHostFree(h->hv_actions);
-    if (h->mailbox) (void)hipHostFree(h->mailbox);
+    // a server whose exit word never showed up may still write it: such a mailbox is left alone (192 bytes, once) instead of freed
+    if (h->srv.mb && !h->srv.words_owed()) (void)hipHostFree(h->srv.mb);
     if (s.last_return) (void)hipHostFree(s.last_return);
     if (s.last_perf) (void)hipHostFree(s.last_perf);
     s.state = nullptr; s.rec = nullptr; s.boards = nullptr;
@@ -329,16 +176,17 @@ int sgk_destroy(sgk_env *h) {
   (void)hipFree(h->actions_scratch);
   (void)hipFree(h->gamma_dev);
   if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->copy_chunk) (void)hipHostFree(h->copy_chunk);
   if (h->metrics_pinned) (void)hipHostFree(h->metrics_pinned);
   for (int i = 0; i < 2; ++i)
     if (h->order_events[i]) (void)hipEventDestroy(h->order_events[i]);
   if (h->own_stream) return_stream(h->sh.device, h->own_stream);  // (idle: synchronised above)
   delete h;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_t env_index_base, int layout,
-                  sgk_env **out) {
+                  sgk_env **out) try {
   if (!out) return fail(SGK_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (n_envs <= 0 || n_envs > ((int64_t)1 << 31) - 512) return fail(SGK_ERR_INVALID, "n_envs out of range");
@@ -349,11 +197,10 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   int n_dev = 0;
   hipError_t e = hipGetDeviceCount(&n_dev);
   if (e != hipSuccess || n_dev <= 0)
-    return fail(SGK_ERR_NODEVICE, "libsgk has no CPU fallback and found no HIP device" +
-                                      (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string()));
+    return fail(SGK_ERR_NODEVICE, "libsgk has no CPU fallback and found no HIP device%s%s", e != hipSuccess ? ": " : "",
+                e != hipSuccess ? hipGetErrorString(e) : "");
   if (device < 0 || device >= n_dev) return fail(SGK_ERR_INVALID, "device ordinal out of range");
-  sgk_env *h = new (std::nothrow) sgk_env();
-  if (!h) return fail(SGK_ERR_NOMEM, "host allocation failed");
+  sgk_env *h = sgk::host::host_new<sgk_env>();  // (std::bad_alloc -> SGK_ERR_NOMEM at the entry point's barrier)
   sgk::Shard &s = h->sh;
   if (sgk_build_rules(env_id, &s.rules_host) != 0) {
     delete h;
@@ -377,9 +224,9 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
     hipError_t e__ = (call);                            \
     if (e__ != hipSuccess) {                            \
       int rc__ = hip_fail(e__, #call);                  \
-      std::string keep__ = g_last_error;                \
+      const KeepError keep__;                           \
       sgk_destroy(h);                                   \
-      g_last_error = keep__;                            \
+      keep__.restore();                                 \
       return rc__;                                      \
     }                                                   \
   } while (0)
@@ -408,7 +255,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   h->stream = h->own_stream;
   const int64_t n_pad = ((s.n + 255) / 256) * 256;
   const int64_t n_wg = n_pad / 256;
-  SGK_TRY(hipMalloc(&s.rules_dev, sizeof(SgkRules)));
+  SGK_TRY(hipMalloc((void **)&s.rules_dev, sgk::SGK_RULES_DEV_BYTES));  // the table, padded, + a blank board tile (sgk_device.h)
   h->host_visible = host_visible;
   if (host_visible) {
     // pinned, fine-grained, device-mapped host memory: the kernels read/write it over PCIe, the host reads it after one
@@ -419,8 +266,8 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
     SGK_TRY(hipHostMalloc((void **)&h->hv_actions, (size_t)n_pad, hipHostMallocMapped));
     const char *srv = getenv("SGK_STEP_SERVER");  // A/B knob: 0 = one launch per sgk_step_host call, as before
     if (n_envs <= 64 && !(srv && srv[0] == '0')) {
-      SGK_TRY(hipHostMalloc((void **)&h->mailbox, sizeof(sgk::SgkMailbox), hipHostMallocMapped));
-      memset((void *)h->mailbox, 0, sizeof(sgk::SgkMailbox));
+      SGK_TRY(hipHostMalloc((void **)&h->srv.mb, sizeof(sgk::SgkMailbox), hipHostMallocMapped));
+      memset((void *)h->srv.mb, 0, sizeof(sgk::SgkMailbox));
     }
   } else {
     SGK_TRY(hipMalloc(&s.state, sizeof(uint64_t) * n_pad));
@@ -445,7 +292,15 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(hipMalloc(&s.finished_total, sizeof(int64_t)));
   SGK_TRY(hipMalloc(&h->t_dev, sizeof(uint64_t)));
   SGK_TRY(hipHostMalloc((void **)&h->metrics_pinned, sizeof(long long) * SGK_METRICS_LEN, hipHostMallocMapped));
-  SGK_TRY(hipMemcpyAsync(s.rules_dev, &s.rules_host, sizeof(SgkRules), hipMemcpyHostToDevice, h->stream));
+  {
+    // [rule table | zeros up to SGK_RULES_IMAGE_BYTES | the backdrop 64 times over, n_cells bytes each: a blank COMPACT tile]
+    static_assert(sgk::SGK_RULES_DEV_BYTES <= 8192, "staged on the stack");
+    uint8_t image[sgk::SGK_RULES_DEV_BYTES];
+    memset(image, 0, sizeof(image));
+    memcpy(image, &s.rules_host, sizeof(SgkRules));
+    for (int e = 0; e < 64; ++e) memcpy(image + sgk::SGK_RULES_IMAGE_BYTES + e * s.n_cells, s.rules_host.templ, (size_t)s.n_cells);
+    SGK_TRY(hipMemcpy(s.rules_dev, image, sizeof(image), hipMemcpyHostToDevice));  // synchronous: `image` dies with this block
+  }
   SGK_TRY(hipMemsetAsync(s.rec, 0, sizeof(uint32_t) * n_pad, h->stream));
   SGK_TRY(hipMemsetAsync(s.last_return, 0, sizeof(int32_t) * n_pad, h->stream));
   SGK_TRY(hipMemsetAsync(s.last_perf, 0, sizeof(int32_t) * n_pad, h->stream));
@@ -460,39 +315,39 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
 #undef SGK_TRY
   *out = h;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_create(int env_id, int64_t n_envs, int device, uint64_t seed, sgk_env **out) {
+int sgk_create(int env_id, int64_t n_envs, int device, uint64_t seed, sgk_env **out) try {
   return sgk_create_ex(env_id, n_envs, device, seed, 0, SGK_LAYOUT_COMPACT, out);
-}
+} SGK_CATCH_STATUS
 
 #define SGK_CHECK_HANDLE(h)                                   \
   do {                                                        \
     if (!(h)) return fail(SGK_ERR_INVALID, "handle is NULL"); \
     SGK_HIP(hipSetDevice((h)->sh.device));                    \
-    if ((h)->server_running) {                                \
+    if ((h)->srv.running) {                                \
       int rc__ = stop_server(h);                              \
       if (rc__ != SGK_OK) return rc__;                        \
     }                                                         \
   } while (0)
 
-int sgk_reward_scale(sgk_env *h, double *scale_out) {
+int sgk_reward_scale(sgk_env *h, double *scale_out) try {
   SGK_CHECK_HANDLE(h);
   if (!scale_out) return fail(SGK_ERR_INVALID, "scale_out is NULL");
   *scale_out = h->sh.rules_host.reward_scale;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_copy_bandit_policy(sgk_env *h, double *out_host) {
+int sgk_copy_bandit_policy(sgk_env *h, double *out_host) try {
   SGK_CHECK_HANDLE(h);
   if (!out_host) return fail(SGK_ERR_INVALID, "out_host is NULL");
   if (!h->sh.aux) return fail(SGK_ERR_INVALID, "this level keeps no bandit estimates (FriendFoe does)");
   hipError_t e = hipMemcpyAsync(out_host, h->sh.aux, sizeof(double) * SGK_AUX_DOUBLES * (size_t)h->sh.n, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   return e == hipSuccess ? SGK_OK : hip_fail(e, "sgk_copy_bandit_policy");
-}
+} SGK_CATCH_STATUS
 
-int sgk_get_info(const sgk_env *h, sgk_info *out) {
+int sgk_get_info(const sgk_env *h, sgk_info *out) try {
   if (!h || !out) return fail(SGK_ERR_INVALID, "NULL argument");
   const sgk::Shard &s = h->sh;
   out->env_id = s.env_id;
@@ -512,58 +367,58 @@ int sgk_get_info(const sgk_env *h, sgk_info *out) {
   out->render_hwc = s.rules_host.render_hwc;
   out->reserved = 0;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_set_stream(sgk_env *h, void *hip_stream) {
+int sgk_set_stream(sgk_env *h, void *hip_stream) try {
   SGK_CHECK_HANDLE(h);  // (also stops the step server: it runs on the stream that is about to change)
   h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;  // graphs are captured on own_stream and stay valid
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_set_seed(sgk_env *h, uint64_t seed) {
+int sgk_set_seed(sgk_env *h, uint64_t seed) try {
   SGK_CHECK_HANDLE(h);
   h->sh.seed = seed;  // kernel argument of every later launch; captured step graphs carry the old seed and are dropped
   (void)hipStreamSynchronize(h->stream);  // a replay of a graph about to be destroyed may still be in flight
   h->graphs.clear();
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_use_default_stream(sgk_env *h) {
+int sgk_use_default_stream(sgk_env *h) try {
   SGK_CHECK_HANDLE(h);
   h->stream = nullptr;  // the device's NULL (legacy default) stream: where PyTorch queues work unless told otherwise
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 void *sgk_get_stream(const sgk_env *h) { return h ? (void *)h->stream : nullptr; }
 
-int sgk_stream_wait(sgk_env *h, void *other_stream) {
+int sgk_stream_wait(sgk_env *h, void *other_stream) try {
   SGK_CHECK_HANDLE(h);
   if ((hipStream_t)other_stream == h->stream) return SGK_OK;
   if (!h->order_events[0]) SGK_HIP(hipEventCreateWithFlags(&h->order_events[0], hipEventDisableTiming));
   SGK_HIP(hipEventRecord(h->order_events[0], (hipStream_t)other_stream));
   SGK_HIP(hipStreamWaitEvent(h->stream, h->order_events[0], 0));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_stream_signal(sgk_env *h, void *other_stream) {
+int sgk_stream_signal(sgk_env *h, void *other_stream) try {
   SGK_CHECK_HANDLE(h);
   if ((hipStream_t)other_stream == h->stream) return SGK_OK;
   if (!h->order_events[1]) SGK_HIP(hipEventCreateWithFlags(&h->order_events[1], hipEventDisableTiming));
   SGK_HIP(hipEventRecord(h->order_events[1], h->stream));
   SGK_HIP(hipStreamWaitEvent((hipStream_t)other_stream, h->order_events[1], 0));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 static hipError_t wait_stream_low_latency(hipStream_t st);
 
-int sgk_synchronize(sgk_env *h) {
+int sgk_synchronize(sgk_env *h) try {
   SGK_CHECK_HANDLE(h);
   SGK_HIP(wait_stream_low_latency(h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_reset(sgk_env *h, const uint8_t *mask_dev) {
-  if (h && h->server_running && !mask_dev) {
+int sgk_reset(sgk_env *h, const uint8_t *mask_dev) try {
+  if (h && h->srv.running && !mask_dev) {
     // the single-env loop's env.reset() between episodes: the resident step server does it (no launch, and the server stays)
     SGK_HIP(hipSetDevice(h->sh.device));
     return server_round_trip(h, SGK_SRV_RESET, 0);
@@ -571,15 +426,15 @@ int sgk_reset(sgk_env *h, const uint8_t *mask_dev) {
   SGK_CHECK_HANDLE(h);
   SGK_HIP(sgk::launch_reset(h->sh, mask_dev, 0, h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_reset_done(sgk_env *h) {
+int sgk_reset_done(sgk_env *h) try {
   SGK_CHECK_HANDLE(h);
   SGK_HIP(sgk::launch_reset(h->sh, nullptr, 1, h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_step(sgk_env *h, const uint8_t *actions_dev, uint32_t flags) {
+int sgk_step(sgk_env *h, const uint8_t *actions_dev, uint32_t flags) try {
   SGK_CHECK_HANDLE(h);
   if (!actions_dev) return fail(SGK_ERR_INVALID, "actions_dev is NULL (use sgk_step_random for RNG actions)");
   SGK_HIP(sgk::launch_step(h->sh, actions_dev, flags, h->stream));
@@ -587,25 +442,25 @@ int sgk_step(sgk_env *h, const uint8_t *actions_dev, uint32_t flags) {
   h->t_dev_stale = true;
   h->steps_issued += h->sh.n;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_account_steps(sgk_env *h, int64_t n_steps) {
+int sgk_account_steps(sgk_env *h, int64_t n_steps) try {
   SGK_CHECK_HANDLE(h);
   if (n_steps < 0 && (uint64_t)(-n_steps) > h->sh.lockstep_t) return fail(SGK_ERR_INVALID, "would make the step counter negative");
   h->sh.lockstep_t += (uint64_t)n_steps;  // two's complement: also un-counts a launch that was only recorded
   h->t_dev_stale = true;
   h->steps_issued += h->sh.n * n_steps;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_step_rec *rec_host, int8_t *boards_host,
-                  int32_t *episode_return_host) {
+                  int32_t *episode_return_host) try {
   if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
   SGK_HIP(hipSetDevice(h->sh.device));  // (not SGK_CHECK_HANDLE: this is the one entry point the step server keeps running for)
   if (!actions_host) return fail(SGK_ERR_INVALID, "actions_host is NULL");
   sgk::Shard &s = h->sh;
   const size_t n = (size_t)s.n, bbytes = n * (size_t)s.n_cells;
-  if (h->host_visible && h->mailbox) {
+  if (h->host_visible && h->srv.mb) {
     // the step server: no launch at all in the steady state -- the action goes into host-visible memory, a request number into
     // the mailbox, and the resident wave publishes the number back once the outputs are in the host-visible buffers
     memcpy(h->hv_actions, actions_host, n);
@@ -667,7 +522,7 @@ int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_s
     for (size_t i = 0; i < n; ++i) episode_return_host[i] = (int32_t)(int16_t)((uint32_t)(w[i] >> 32) & 0xffff);
   }
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 // Capture + instantiate the hipGraph of `n_steps` dependent step launches for (n_steps, flags), once per key. The launch-bound
 // inner loop is replayed from it; the lockstep counter lives in device memory so replays need no new arguments.
@@ -698,7 +553,7 @@ static int ensure_step_graph(sgk_env *h, int32_t n_steps, uint32_t flags, hipGra
   return SGK_OK;
 }
 
-int sgk_step_random_prepare(sgk_env *h, int32_t n_steps, uint32_t flags) {
+int sgk_step_random_prepare(sgk_env *h, int32_t n_steps, uint32_t flags) try {
   SGK_CHECK_HANDLE(h);
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
   if (!h->use_graph || n_steps < 4) return SGK_OK;  // these run as eager launches: nothing to prepare
@@ -712,9 +567,9 @@ int sgk_step_random_prepare(sgk_env *h, int32_t n_steps, uint32_t flags) {
     h->t_dev_stale = false;
   }
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
+int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) try {
   SGK_CHECK_HANDLE(h);
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
   if (n_steps == 0) return SGK_OK;
@@ -741,9 +596,9 @@ int sgk_step_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
   s.lockstep_t += (uint64_t)n_steps;
   h->steps_issued += s.n * (int64_t)n_steps;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_step_repeat(sgk_env *h, const uint8_t *actions_dev, int32_t n_steps, uint32_t flags) {
+int sgk_step_repeat(sgk_env *h, const uint8_t *actions_dev, int32_t n_steps, uint32_t flags) try {
   SGK_CHECK_HANDLE(h);
   if (!actions_dev) return fail(SGK_ERR_INVALID, "actions_dev is NULL");
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
@@ -754,9 +609,9 @@ int sgk_step_repeat(sgk_env *h, const uint8_t *actions_dev, int32_t n_steps, uin
   h->t_dev_stale = true;
   h->steps_issued += h->sh.n * (int64_t)n_steps;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
+int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags) try {
   SGK_CHECK_HANDLE(h);
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
   if (n_steps == 0) return SGK_OK;
@@ -765,10 +620,10 @@ int sgk_rollout_random(sgk_env *h, int32_t n_steps, uint32_t flags) {
   h->t_dev_stale = true;
   h->steps_issued += h->sh.n * (int64_t)n_steps;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flags, int8_t *boards_ring_dev, sgk_step_rec *recs_ring_dev,
-                              int32_t ring_slices, int32_t first_slice) {
+                              int32_t ring_slices, int32_t first_slice) try {
   SGK_CHECK_HANDLE(h);
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
   if ((boards_ring_dev || recs_ring_dev) && (ring_slices < 1 || first_slice < 0 || first_slice >= ring_slices))
@@ -783,145 +638,15 @@ int sgk_rollout_random_stream(sgk_env *h, int32_t n_steps, uint32_t flags, int8_
   h->t_dev_stale = true;
   h->steps_issued += h->sh.n * (int64_t)n_steps;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-// ---- trajectory-ring memory -----------------------------------------------------------------------------------------------------
-// Device memory for rings a persistent kernel streams into, through HIP's virtual-memory management: one contiguous virtual range
-// backed by physical chunks of 256 MiB. Why: the rate at which the streamed rollout writes a multi-GB ring depends on how the
-// ring's PHYSICAL memory is made up -- hipMalloc blocks of one process measure 4.6-4.9 us per step at 1 M BoatRace envs or
-// 5.6-6.1, for the block's lifetime, and a ring mapped from chunks of 2 MiB / 32 MiB / 256-512 MiB / 1 GiB measures 5.25 / 5.05 /
-// 4.52-4.78 / 5.34-5.53 (64 KiB: 23; profiles/r03/ring_alloc_vmm*.log): chunks of 256 MiB are on the fast level every time.
-namespace {
-struct RingBlock {
-  int device = 0;
-  size_t va_bytes = 0;
-  std::vector<hipMemGenericAllocationHandle_t> chunks;
-  std::vector<size_t> chunk_bytes;
-};
-std::mutex g_ring_mutex;
-std::map<void *, RingBlock> g_rings;
+// ---- trajectory-ring memory: sgk_host_core.h (ring_alloc / ring_free over HIP's virtual-memory management) ----------------------------
+int sgk_ring_alloc(int32_t device, size_t bytes, void **dev_ptr) try { return sgk::host::ring_alloc(device, bytes, dev_ptr); } SGK_CATCH_STATUS
 
-// The ring entry points take no handle and run at arbitrary points of the caller's program (sgk_ring_free: from destructors);
-// whatever device they work on, the thread's current device is what it was when they return.
-struct DeviceGuard {
-  int before = -1;
-  DeviceGuard() { (void)hipGetDevice(&before); }
-  ~DeviceGuard() {
-    if (before >= 0) (void)hipSetDevice(before);
-    (void)hipGetLastError();
-  }
-};
-
-void release_ring(void *va, RingBlock &b, size_t mapped_chunks, bool free_range = true) {
-  size_t off = 0;
-  for (size_t i = 0; i < b.chunks.size(); ++i) {
-    if (i < mapped_chunks) (void)hipMemUnmap((char *)va + off, b.chunk_bytes[i]);
-    (void)hipMemRelease(b.chunks[i]);
-    off += b.chunk_bytes[i];
-  }
-  b.chunks.clear();
-  if (va && free_range) (void)hipMemAddressFree(va, b.va_bytes);
-  (void)hipGetLastError();
-}
-}  // namespace
-
-int sgk_ring_alloc(int32_t device, size_t bytes, void **dev_ptr) {
-  if (!dev_ptr) return fail(SGK_ERR_INVALID, "dev_ptr is NULL");
-  *dev_ptr = nullptr;
-  if (bytes == 0) return fail(SGK_ERR_INVALID, "bytes == 0");
-  DeviceGuard keep_current_device;
-  SGK_HIP(hipSetDevice(device));
-  hipMemAllocationProp prop = {};
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = device;
-  // 256 MiB physical chunks (profiles/r03/ring_alloc_vmm*.log: 2 MiB / 32 MiB / 256-512 MiB / 1 GiB chunks measure 5.25 / 5.05 /
-  // 4.52-4.78 / 5.34-5.53 us per step), every size a multiple of what the driver maps in (its recommended granularity)
-  size_t gran = 0;
-  SGK_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-  if (gran < ((size_t)2 << 20) || (gran & (gran - 1))) gran = (size_t)2 << 20;  // never below 2 MiB (a power of two: a multiple of the driver's)
-  const size_t chunk = (((size_t)256 << 20) + gran - 1) / gran * gran;
-  RingBlock b;
-  b.device = device;
-  // whole chunks, and a last one rounded up to the granularity (a ring smaller than a chunk is one allocation of its own size)
-  for (size_t left = bytes; left > 0;) {
-    const size_t take = left >= chunk ? chunk : (left + gran - 1) / gran * gran;
-    b.chunk_bytes.push_back(take);
-    b.va_bytes += take;
-    left -= left >= chunk ? chunk : left;
-  }
-  // Reserve, create, map, open. On one box of this pool the driver refused to map into (or open) a range it had just handed out
-  // -- "invalid argument", one call in a few hundred, the same sizes fine a moment later --: such a range is set aside (it stays
-  // reserved until the call returns, so that the next reservation is a different one) and another is tried, three times in all.
-  void *va = nullptr;
-  std::vector<void *> set_aside;
-  hipError_t err = hipSuccess;
-  std::string where;
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    va = nullptr;
-    b.chunks.clear();
-    err = hipMemAddressReserve(&va, b.va_bytes, (chunk & (chunk - 1)) ? gran : chunk, nullptr, 0);  // aligned to the chunk size
-    if (err != hipSuccess) {
-      where = "hipMemAddressReserve (trajectory ring)";
-      break;
-    }
-    size_t mapped = 0, off = 0;
-    const char *what = "";
-    for (size_t i = 0; i < b.chunk_bytes.size() && err == hipSuccess; ++i) {
-      hipMemGenericAllocationHandle_t h;
-      what = "hipMemCreate";
-      err = hipMemCreate(&h, b.chunk_bytes[i], &prop, 0);
-      if (err != hipSuccess) break;
-      b.chunks.push_back(h);
-      what = "hipMemMap";
-      err = hipMemMap((char *)va + off, b.chunk_bytes[i], 0, h, 0);
-      if (err == hipSuccess) ++mapped;
-      off += b.chunk_bytes[i];
-    }
-    if (err == hipSuccess) {
-      hipMemAccessDesc acc = {};
-      acc.location = prop.location;
-      acc.flags = hipMemAccessFlagsProtReadWrite;
-      what = "hipMemSetAccess";
-      err = hipMemSetAccess(va, b.va_bytes, &acc, 1);
-    }
-    if (err == hipSuccess) break;
-    where = std::string("sgk_ring_alloc: ") + what + " (" + std::to_string(bytes) + " bytes as " + std::to_string(b.chunk_bytes.size()) +
-            " chunk(s), granularity " + std::to_string(gran) + ", chunk " + std::to_string(b.chunks.size()) + ", va " +
-            std::to_string((unsigned long long)(uintptr_t)va) + ", attempt " + std::to_string(attempt + 1) + " of 3)";
-    release_ring(va, b, mapped, false);  // the chunks go (unmapped where they were mapped); the range itself is kept aside
-    set_aside.push_back(va);
-    va = nullptr;
-    if (err == hipErrorOutOfMemory) break;  // not a range's fault
-  }
-  for (void *r : set_aside) (void)hipMemAddressFree(r, b.va_bytes);
-  (void)hipGetLastError();
-  if (err != hipSuccess) return hip_fail(err, where.c_str());
-  std::lock_guard<std::mutex> lock(g_ring_mutex);
-  g_rings[va] = std::move(b);
-  *dev_ptr = va;
-  return SGK_OK;
-}
-
-int sgk_ring_free(void *dev_ptr) {
-  if (!dev_ptr) return SGK_OK;
-  RingBlock b;
-  {
-    std::lock_guard<std::mutex> lock(g_ring_mutex);
-    auto it = g_rings.find(dev_ptr);
-    if (it == g_rings.end()) return fail(SGK_ERR_INVALID, "not a pointer sgk_ring_alloc returned");
-    b = std::move(it->second);
-    g_rings.erase(it);
-  }
-  DeviceGuard keep_current_device;
-  SGK_HIP(hipSetDevice(b.device));
-  (void)hipDeviceSynchronize();  // nothing may still be writing into it
-  release_ring(dev_ptr, b, b.chunks.size());
-  return SGK_OK;
-}
+int sgk_ring_free(void *dev_ptr) try { return sgk::host::ring_free(dev_ptr); } SGK_CATCH_STATUS
 
 int sgk_ring_probe(sgk_env *h, int8_t *boards_ring_dev, sgk_step_rec *recs_ring_dev, int32_t ring_slices, uint32_t flags,
-                   double *us_per_slice) {
+                   double *us_per_slice) try {
   SGK_CHECK_HANDLE(h);
   if (!us_per_slice) return fail(SGK_ERR_INVALID, "us_per_slice is NULL");
   if (!boards_ring_dev && !recs_ring_dev) return fail(SGK_ERR_INVALID, "no ring to probe");
@@ -950,69 +675,69 @@ int sgk_ring_probe(sgk_env *h, int8_t *boards_ring_dev, sgk_step_rec *recs_ring_
   std::sort(ms, ms + 3);
   *us_per_slice = (double)ms[1] * 1e3 / ring_slices;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_boards_dev(sgk_env *h, int8_t **boards_dev, int64_t *pitch) {
+int sgk_boards_dev(sgk_env *h, int8_t **boards_dev, int64_t *pitch) try {
   SGK_CHECK_HANDLE(h);
   if (boards_dev) *boards_dev = h->sh.boards;
   if (pitch) *pitch = h->sh.pitch;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_step_records_dev(sgk_env *h, sgk_step_rec **rec_dev) {
+int sgk_step_records_dev(sgk_env *h, sgk_step_rec **rec_dev) try {
   if (!h || !rec_dev) return fail(SGK_ERR_INVALID, "NULL argument");
   SGK_CHECK_HANDLE(h);
   *rec_dev = reinterpret_cast<sgk_step_rec *>(h->sh.rec);
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_metrics_dev(sgk_env *h, int64_t **metrics_dev) {
+int sgk_metrics_dev(sgk_env *h, int64_t **metrics_dev) try {
   if (!h || !metrics_dev) return fail(SGK_ERR_INVALID, "NULL argument");
   SGK_CHECK_HANDLE(h);
   SGK_HIP(sgk::launch_metrics_reduce(h->sh, h->stream));  // folds the per-workgroup partials; stream-ordered
   *metrics_dev = h->sh.metrics;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_episode_arrays_dev(sgk_env *h, int32_t **last_return_dev, int32_t **last_performance_dev, int32_t **n_episodes_dev) {
+int sgk_episode_arrays_dev(sgk_env *h, int32_t **last_return_dev, int32_t **last_performance_dev, int32_t **n_episodes_dev) try {
   SGK_CHECK_HANDLE(h);
   if (last_return_dev) *last_return_dev = h->sh.last_return;
   if (last_performance_dev) *last_performance_dev = h->sh.last_perf;
   if (n_episodes_dev) *n_episodes_dev = h->sh.n_episodes;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_obs_f32(sgk_env *h, float *dst_dev) {
+int sgk_obs_f32(sgk_env *h, float *dst_dev) try {
   SGK_CHECK_HANDLE(h);
   if (!dst_dev) return fail(SGK_ERR_INVALID, "dst_dev is NULL");
   SGK_HIP(sgk::launch_obs_f32(h->sh, dst_dev, h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_epsilon_greedy_ex(sgk_env *h, const float *scores_dev, double epsilon, uint64_t draw_index, const double *epsilon_dev,
-                          const uint64_t *draw_index_dev, uint8_t *actions_out_dev) {
+                          const uint64_t *draw_index_dev, uint8_t *actions_out_dev) try {
   SGK_CHECK_HANDLE(h);
   if (!scores_dev || !actions_out_dev) return fail(SGK_ERR_INVALID, "NULL argument");
   if (((uintptr_t)scores_dev & 15u) != 0) return fail(SGK_ERR_INVALID, "scores_dev must be 16-byte aligned");
   SGK_HIP(sgk::launch_eps_greedy(h->sh, 0, scores_dev, actions_out_dev, epsilon, draw_index, epsilon_dev, draw_index_dev, h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_categorical_sample(sgk_env *h, const float *logits_dev, uint64_t draw_index, const uint64_t *draw_index_dev,
-                           uint8_t *actions_out_dev) {
+                           uint8_t *actions_out_dev) try {
   SGK_CHECK_HANDLE(h);
   if (!logits_dev || !actions_out_dev) return fail(SGK_ERR_INVALID, "NULL argument");
   if (((uintptr_t)logits_dev & 15u) != 0) return fail(SGK_ERR_INVALID, "logits_dev must be 16-byte aligned");
   SGK_HIP(sgk::launch_eps_greedy(h->sh, 1, logits_dev, actions_out_dev, 0.0, draw_index, nullptr, draw_index_dev, h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_epsilon_greedy(sgk_env *h, const float *scores_dev, double epsilon, uint64_t draw_index, uint8_t *actions_out_dev) {
+int sgk_epsilon_greedy(sgk_env *h, const float *scores_dev, double epsilon, uint64_t draw_index, uint8_t *actions_out_dev) try {
   return sgk_epsilon_greedy_ex(h, scores_dev, epsilon, draw_index, nullptr, nullptr, actions_out_dev);
-}
+} SGK_CATCH_STATUS
 
 int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon, uint64_t draw_index, const double *epsilon_dev,
-                   const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev) {
+                   const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev) try {
   SGK_CHECK_HANDLE(h);
   if (!w || !actions_out_dev || !w->w1t || !w->b1 || !w->w2 || !w->b2 || !w->w3t || !w->b3)
     return fail(SGK_ERR_INVALID, "NULL argument");
@@ -1023,10 +748,10 @@ int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon, uint64_
   SGK_HIP(sgk::launch_policy_act(h->sh, 0, pw, actions_out_dev, scores_out_dev, epsilon, draw_index, epsilon_dev, draw_index_dev,
                                  h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_policy_sample(sgk_env *h, const sgk_mlp_weights *w, uint64_t draw_index, const uint64_t *draw_index_dev,
-                      uint8_t *actions_out_dev, float *logits_out_dev) {
+                      uint8_t *actions_out_dev, float *logits_out_dev) try {
   SGK_CHECK_HANDLE(h);
   if (!w || !actions_out_dev || !w->w1t || !w->b1 || !w->w2 || !w->b2 || !w->w3t || !w->b3)
     return fail(SGK_ERR_INVALID, "NULL argument");
@@ -1037,10 +762,10 @@ int sgk_policy_sample(sgk_env *h, const sgk_mlp_weights *w, uint64_t draw_index,
   SGK_HIP(sgk::launch_policy_act(h->sh, 1, pw, actions_out_dev, logits_out_dev, 0.0, draw_index, nullptr, draw_index_dev,
                                  h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_policy_rollout(sgk_env *h, const sgk_mlp_weights *w, int32_t mode, double epsilon, uint64_t draw_index0, int32_t n_steps,
-                       uint32_t flags, int8_t *states_out_dev, uint8_t *actions_out_dev, sgk_step_rec *recs_out_dev) {
+                       uint32_t flags, int8_t *states_out_dev, uint8_t *actions_out_dev, sgk_step_rec *recs_out_dev) try {
   SGK_CHECK_HANDLE(h);
   if (!w || !w->w1t || !w->b1 || !w->w2 || !w->b2 || !w->w3t || !w->b3) return fail(SGK_ERR_INVALID, "NULL argument");
   if (w->n_hidden != 64 && w->n_hidden != 100 && w->n_hidden != 128)
@@ -1059,11 +784,11 @@ int sgk_policy_rollout(sgk_env *h, const sgk_mlp_weights *w, int32_t mode, doubl
   h->t_dev_stale = true;
   h->steps_issued += s.n * n_steps;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_replay_store(sgk_env *h, int32_t phase, const uint8_t *actions_dev, int32_t cheat, int64_t slice, const int64_t *slice_dev,
                      int8_t *states_ring, int8_t *successors_ring, uint8_t *actions_ring, int8_t *rewards_ring,
-                     uint8_t *terminals_ring) {
+                     uint8_t *terminals_ring) try {
   SGK_CHECK_HANDLE(h);
   if (phase != 0 && phase != 1) return fail(SGK_ERR_INVALID, "phase must be 0 (before env.step) or 1 (after)");
   if (!states_ring || !successors_ring) return fail(SGK_ERR_INVALID, "NULL ring pointer");
@@ -1073,9 +798,9 @@ int sgk_replay_store(sgk_env *h, int32_t phase, const uint8_t *actions_dev, int3
   SGK_HIP(sgk::launch_replay_store(h->sh, phase, actions_dev, cheat, slice, reinterpret_cast<const long long *>(slice_dev),
                                    states_ring, successors_ring, actions_ring, rewards_ring, terminals_ring, h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) {
+int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) try {
   SGK_CHECK_HANDLE(h);
   if (!L) return fail(SGK_ERR_INVALID, "learner is NULL");
   const void *need[] = {L->states, L->successors, L->actions, L->rewards, L->terminals, L->w1, L->b1, L->w2, L->b2, L->w3, L->b3,
@@ -1103,9 +828,9 @@ int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) {
   d.lr = L->lr; d.beta1 = L->beta1; d.beta2 = L->beta2; d.eps = L->eps; d.discount = L->discount; d.max_grad_norm = L->max_grad_norm;
   SGK_HIP(sgk::launch_dqn_sgd(h->sh, d, h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_ppo_epochs(sgk_env *h, const sgk_ppo_learner *L) {
+int sgk_ppo_epochs(sgk_env *h, const sgk_ppo_learner *L) try {
   SGK_CHECK_HANDLE(h);
   if (!L) return fail(SGK_ERR_INVALID, "learner is NULL");
   const void *need[] = {L->states, L->actions, L->returns, L->lengths, L->w1, L->b1, L->w2, L->b2, L->wa, L->ba, L->wc, L->bc,
@@ -1136,10 +861,10 @@ int sgk_ppo_epochs(sgk_env *h, const sgk_ppo_learner *L) {
   d.clipping = L->clipping; d.critic_coeff = L->critic_coeff; d.entropy_bonus = L->entropy_bonus;
   SGK_HIP(sgk::launch_ppo_epochs(h->sh, d, h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const int32_t *lengths_dev, float *returns_dev,
-                           int64_t n_trajectories, int32_t t_max, double discount) {
+                           int64_t n_trajectories, int32_t t_max, double discount) try {
   SGK_CHECK_HANDLE(h);
   if (!rewards_dev || !returns_dev) return fail(SGK_ERR_INVALID, "NULL argument");
   if (n_trajectories < 0 || t_max < 1 || t_max > 1024) return fail(SGK_ERR_INVALID, "t_max must be in 1..1024");
@@ -1155,20 +880,20 @@ int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const int32_t *
   SGK_HIP(sgk::launch_discounted_returns(h->sh, rewards_dev, lengths_dev, h->gamma_dev, returns_dev, n_trajectories, t_max,
                                          h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_render_rgb(sgk_env *h, uint8_t *rgb_dev) {
+int sgk_render_rgb(sgk_env *h, uint8_t *rgb_dev) try {
   SGK_CHECK_HANDLE(h);
   if (!rgb_dev) return fail(SGK_ERR_INVALID, "rgb_dev is NULL");
   SGK_HIP(sgk::launch_render_rgb(h->sh, rgb_dev, h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 // Host-visible handles keep what the host reads in pinned host memory. While the step server is resident that memory is current
 // whenever the host is not inside a request (the server writes, fences and only then publishes the answer): the copies below then
 // read it as it is -- stopping the server for a look would cost a launch at the next step. Otherwise: wait for the stream first.
 static int host_visible_ready(sgk_env *h) {
-  if (h->server_running) {
+  if (h->srv.running) {
     __sync_synchronize();
     return SGK_OK;
   }
@@ -1176,8 +901,8 @@ static int host_visible_ready(sgk_env *h) {
   return SGK_OK;
 }
 
-int sgk_copy_boards(sgk_env *h, int8_t *boards_host) {
-  if (h && h->host_visible && h->server_running && boards_host) {
+int sgk_copy_boards(sgk_env *h, int8_t *boards_host) try {
+  if (h && h->host_visible && h->srv.running && boards_host) {
     const sgk::Shard &s = h->sh;
     __sync_synchronize();
     for (int64_t i = 0; i < s.n; ++i) memcpy(boards_host + i * s.n_cells, s.boards + i * s.pitch, (size_t)s.n_cells);
@@ -1205,9 +930,9 @@ int sgk_copy_boards(sgk_env *h, int8_t *boards_host) {
   }
   SGK_HIP(hipStreamSynchronize(h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_copy_step_records(sgk_env *h, sgk_step_rec *rec_host) {
+int sgk_copy_step_records(sgk_env *h, sgk_step_rec *rec_host) try {
   SGK_CHECK_HANDLE(h);
   if (!rec_host) return fail(SGK_ERR_INVALID, "rec_host is NULL");
   if (h->host_visible) {  // (host memory: synchronise, then a CPU copy -- see sgk_copy_boards)
@@ -1218,32 +943,43 @@ int sgk_copy_step_records(sgk_env *h, sgk_step_rec *rec_host) {
   SGK_HIP(hipMemcpyAsync(rec_host, h->sh.rec, sizeof(uint32_t) * h->sh.n, hipMemcpyDeviceToHost, h->stream));
   SGK_HIP(hipStreamSynchronize(h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_copy_episode_state(sgk_env *h, int32_t *episode_return_host, int32_t *hidden_return_host, int32_t *frame_host,
-                           uint8_t *over_host, uint8_t *agent_cell_host, uint8_t *box_cell_host) {
+                           uint8_t *over_host, uint8_t *agent_cell_host, uint8_t *box_cell_host) try {
   SGK_CHECK_HANDLE(h);
-  std::vector<uint64_t> w((size_t)h->sh.n);
-  if (h->host_visible) {  // (host memory: synchronise, then a CPU copy -- see sgk_copy_boards)
+  const size_t n = (size_t)h->sh.n;
+  auto unpack = [&](const uint64_t *w, size_t first, size_t count) {
+    for (size_t k = 0; k < count; ++k) {
+      const size_t i = first + k;
+      const uint32_t lo = (uint32_t)w[k], hi = (uint32_t)(w[k] >> 32);
+      if (agent_cell_host) agent_cell_host[i] = (uint8_t)(lo & 0xff);
+      if (box_cell_host) box_cell_host[i] = (uint8_t)((lo >> 8) & 0xff);
+      if (frame_host) frame_host[i] = (int32_t)((lo >> 16) & 0xff);
+      if (over_host) over_host[i] = (uint8_t)((lo >> 24) & 1);
+      if (episode_return_host) episode_return_host[i] = (int32_t)(int16_t)(hi & 0xffff);
+      if (hidden_return_host) hidden_return_host[i] = (int32_t)(int16_t)(hi >> 16);
+    }
+  };
+  if (h->host_visible) {  // (host memory: synchronise, then read the words where they are -- see sgk_copy_boards)
     SGK_HIP(hipStreamSynchronize(h->stream));
-    memcpy(w.data(), h->sh.state, sizeof(uint64_t) * w.size());
-  } else {
-    SGK_HIP(hipMemcpyAsync(w.data(), h->sh.state, sizeof(uint64_t) * w.size(), hipMemcpyDeviceToHost, h->stream));
-    SGK_HIP(hipStreamSynchronize(h->stream));
+    unpack(h->sh.state, 0, n);
+    return SGK_OK;
   }
-  for (size_t i = 0; i < w.size(); ++i) {
-    uint32_t lo = (uint32_t)w[i], hi = (uint32_t)(w[i] >> 32);
-    if (agent_cell_host) agent_cell_host[i] = (uint8_t)(lo & 0xff);
-    if (box_cell_host) box_cell_host[i] = (uint8_t)((lo >> 8) & 0xff);
-    if (frame_host) frame_host[i] = (int32_t)((lo >> 16) & 0xff);
-    if (over_host) over_host[i] = (uint8_t)((lo >> 24) & 1);
-    if (episode_return_host) episode_return_host[i] = (int32_t)(int16_t)(hi & 0xffff);
-    if (hidden_return_host) hidden_return_host[i] = (int32_t)(int16_t)(hi >> 16);
+  // device memory: the state words come over in chunks through one small pinned block of the handle's (a staging array of n words
+  // would be 16 GB of host memory at the largest batch the library takes)
+  constexpr size_t CHUNK = (size_t)1 << 17;  // 1 MiB of state words
+  if (!h->copy_chunk) SGK_HIP(hipHostMalloc((void **)&h->copy_chunk, sizeof(uint64_t) * CHUNK, hipHostMallocDefault));
+  for (size_t first = 0; first < n; first += CHUNK) {
+    const size_t count = n - first < CHUNK ? n - first : CHUNK;
+    SGK_HIP(hipMemcpyAsync(h->copy_chunk, h->sh.state + first, sizeof(uint64_t) * count, hipMemcpyDeviceToHost, h->stream));
+    SGK_HIP(hipStreamSynchronize(h->stream));
+    unpack(h->copy_chunk, first, count);
   }
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_copy_last_episode(sgk_env *h, int32_t *last_return_host, int32_t *last_performance_host, int32_t *n_episodes_host) {
+int sgk_copy_last_episode(sgk_env *h, int32_t *last_return_host, int32_t *last_performance_host, int32_t *n_episodes_host) try {
   if (h && h->host_visible && !n_episodes_host) {  // (the two arrays are pinned host memory there: see host_visible_ready)
     SGK_HIP(hipSetDevice(h->sh.device));
     const int rc = host_visible_ready(h);
@@ -1267,7 +1003,7 @@ int sgk_copy_last_episode(sgk_env *h, int32_t *last_return_host, int32_t *last_p
     if (last_performance_host) memcpy(last_performance_host, h->sh.last_perf, bytes);
   }
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 // Wait for the handle's stream with latency in mind: poll for a bounded time (a blocking wait sleeps on an interrupt and
 // wakes tens of microseconds late), then fall back to the blocking form.
@@ -1278,7 +1014,7 @@ static hipError_t wait_stream_low_latency(hipStream_t st) {
   return q;
 }
 
-int sgk_metrics(sgk_env *h, int64_t out_host[SGK_METRICS_LEN]) {
+int sgk_metrics(sgk_env *h, int64_t out_host[SGK_METRICS_LEN]) try {
   SGK_CHECK_HANDLE(h);
   if (!out_host) return fail(SGK_ERR_INVALID, "out_host is NULL");
   // the fold's 16 words land in pinned device-mapped host memory as well: one launch, one wait, no copy command
@@ -1287,9 +1023,9 @@ int sgk_metrics(sgk_env *h, int64_t out_host[SGK_METRICS_LEN]) {
   for (int i = 0; i < SGK_METRICS_LEN; ++i) out_host[i] = (int64_t)h->metrics_pinned[i];
   out_host[SGK_M_STEPS] = h->steps_issued;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_metrics_allreduced(sgk_env *h, sgk_comm *comm, int64_t out_host[SGK_METRICS_LEN]) {
+int sgk_metrics_allreduced(sgk_env *h, sgk_comm *comm, int64_t out_host[SGK_METRICS_LEN]) try {
   SGK_CHECK_HANDLE(h);
   if (!comm || !out_host) return fail(SGK_ERR_INVALID, "NULL argument");
   SGK_HIP(sgk::launch_metrics_reduce(h->sh, h->stream));
@@ -1303,27 +1039,27 @@ int sgk_metrics_allreduced(sgk_env *h, sgk_comm *comm, int64_t out_host[SGK_METR
   SGK_HIP(hipMemcpyAsync(out_host, h->sh.metrics, sizeof(int64_t) * SGK_METRICS_LEN, hipMemcpyDeviceToHost, h->stream));
   SGK_HIP(hipStreamSynchronize(h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_metrics_reset(sgk_env *h) {
+int sgk_metrics_reset(sgk_env *h) try {
   SGK_CHECK_HANDLE(h);
   SGK_HIP(sgk::launch_metrics_init(h->sh, h->stream));
   h->steps_issued = 0;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_finished(sgk_env *h, int32_t *ids_dev, int32_t *return_dev, int32_t *performance_dev, int64_t *n_host) {
+int sgk_finished(sgk_env *h, int32_t *ids_dev, int32_t *return_dev, int32_t *performance_dev, int64_t *n_host) try {
   SGK_CHECK_HANDLE(h);
   if (!ids_dev || !return_dev || !performance_dev || !n_host) return fail(SGK_ERR_INVALID, "NULL argument");
   SGK_HIP(sgk::launch_finished(h->sh, ids_dev, return_dev, performance_dev, h->stream));
   SGK_HIP(hipMemcpyAsync(n_host, h->sh.finished_total, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
   SGK_HIP(hipStreamSynchronize(h->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 // ---- tabular Q ------------------------------------------------------------------------------------
 
-int sgk_tabq_destroy(sgk_tabq *q) {
+int sgk_tabq_destroy(sgk_tabq *q) try {
   if (!q) return SGK_OK;
   if (q->env) {
     (void)hipSetDevice(q->env->sh.device);
@@ -1339,14 +1075,16 @@ int sgk_tabq_destroy(sgk_tabq *q) {
   (void)hipFree(q->t_dev);
   delete q;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 int sgk_tabq_create_ex(sgk_env *env, double lr, double discount, double epsilon, int64_t epsilon_anneal, int32_t hash_capacity,
-                       sgk_tabq **out) {
+                       sgk_tabq **out) try {
   if (!out) return fail(SGK_ERR_INVALID, "out is NULL");
   *out = nullptr;
   SGK_CHECK_HANDLE(env);
   if (epsilon_anneal < 1) return fail(SGK_ERR_INVALID, "epsilon_anneal < 1");
+  // (also keeps NaN out: the LDS-resident kernel turns epsilon into an integer threshold, undefined for a negative double)
+  if (!(epsilon >= 0.0 && epsilon <= 1.0)) return fail(SGK_ERR_INVALID, "epsilon must be a probability (0 <= epsilon <= 1)");
   const bool hashed = env->sh.env_id == SGK_TOMATO_WATERING;  // 63 x 2^13 distinct boards: no perfect hash
   if (hashed) {
     if (hash_capacity == 0) hash_capacity = 4096;
@@ -1355,8 +1093,7 @@ int sgk_tabq_create_ex(sgk_env *env, double lr, double discount, double epsilon,
   } else if (hash_capacity != 0) {
     return fail(SGK_ERR_INVALID, "this level's boards have a perfect hash: hash_capacity must be 0");
   }
-  sgk_tabq *q = new (std::nothrow) sgk_tabq();
-  if (!q) return fail(SGK_ERR_NOMEM, "host allocation failed");
+  sgk_tabq *q = sgk::host::host_new<sgk_tabq>();  // (std::bad_alloc -> SGK_ERR_NOMEM at the entry point's barrier)
   q->env = env;
   q->tq.lr = lr;
   q->tq.discount = discount;
@@ -1381,20 +1118,20 @@ int sgk_tabq_create_ex(sgk_env *env, double lr, double discount, double epsilon,
   if (e == hipSuccess && hashed) e = hipMemsetAsync(q->tq.keys, 0xff, sizeof(uint32_t) * n * (size_t)hash_capacity, env->stream);
   if (e != hipSuccess) {
     int rc = hip_fail(e, "tabular-Q allocation");
-    std::string keep = g_last_error;
+    const KeepError keep;
     sgk_tabq_destroy(q);
-    g_last_error = keep;
+    keep.restore();
     return rc;
   }
   *out = q;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, int64_t epsilon_anneal, sgk_tabq **out) {
+int sgk_tabq_create(sgk_env *env, double lr, double discount, double epsilon, int64_t epsilon_anneal, sgk_tabq **out) try {
   return sgk_tabq_create_ex(env, lr, discount, epsilon, epsilon_anneal, 0, out);
-}
+} SGK_CATCH_STATUS
 
-int sgk_tabq_hash_info(sgk_tabq *q, int32_t *capacity_out, int32_t *max_used_out, int32_t *overflowed_out) {
+int sgk_tabq_hash_info(sgk_tabq *q, int32_t *capacity_out, int32_t *max_used_out, int32_t *overflowed_out) try {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   SGK_CHECK_HANDLE(q->env);
   if (capacity_out) *capacity_out = q->tq.hash_cap;
@@ -1413,9 +1150,9 @@ int sgk_tabq_hash_info(sgk_tabq *q, int32_t *capacity_out, int32_t *max_used_out
     }
   }
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_tabq_copy_keys(sgk_tabq *q, int64_t env_begin, int64_t env_count, uint32_t *keys_host) {
+int sgk_tabq_copy_keys(sgk_tabq *q, int64_t env_begin, int64_t env_count, uint32_t *keys_host) try {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   SGK_CHECK_HANDLE(q->env);
   if (!q->tq.hash_cap) return fail(SGK_ERR_INVALID, "this level's tables are indexed by a perfect hash: there are no keys");
@@ -1425,7 +1162,7 @@ int sgk_tabq_copy_keys(sgk_tabq *q, int64_t env_begin, int64_t env_count, uint32
                          hipMemcpyDeviceToHost, q->env->stream));
   SGK_HIP(hipStreamSynchronize(q->env->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 // the per-step kernels' row slots (sgk_tabq.hip) mirror table rows: after anything else wrote the table they are re-tagged invalid
 static hipError_t refresh_row_tags(sgk_tabq *q) {
@@ -1434,16 +1171,16 @@ static hipError_t refresh_row_tags(sgk_tabq *q) {
   return sgk::launch_tabq_forget_rows(q->env->sh, q->tq, q->env->stream);
 }
 
-int sgk_tabq_act(sgk_tabq *q, int explore, uint8_t *actions_out_dev) {
+int sgk_tabq_act(sgk_tabq *q, int explore, uint8_t *actions_out_dev) try {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   SGK_CHECK_HANDLE(q->env);
   if (!actions_out_dev) return fail(SGK_ERR_INVALID, "actions_out_dev is NULL");
   SGK_HIP(refresh_row_tags(q));
   SGK_HIP(sgk::launch_tabq_act(q->env->sh, q->tq, explore, actions_out_dev, q->env->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat) {
+int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat) try {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   SGK_CHECK_HANDLE(q->env);
   if (!actions_dev) return fail(SGK_ERR_INVALID, "actions_dev is NULL");
@@ -1452,9 +1189,9 @@ int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat) {
   q->tq.t_agent += 1;  // update_epsilon(), learn.py:82
   q->t_dev_stale = true;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags) {
+int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags) try {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   sgk_env *h = q->env;
   SGK_CHECK_HANDLE(h);
@@ -1512,9 +1249,9 @@ int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags
   h->t_dev_stale = true;
   h->steps_issued += s.n * (int64_t)n_steps;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel) {
+int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel) try {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   sgk_env *h = q->env;
   SGK_CHECK_HANDLE(h);
@@ -1547,40 +1284,42 @@ int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel) {
   h->t_dev_stale = true;
   h->steps_issued += s.n * n_steps;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat) { return sgk_tabq_rollout_ex(q, n_steps, cheat, SGK_TABQ_KERNEL_AUTO); }
+int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat) try { return sgk_tabq_rollout_ex(q, n_steps, cheat, SGK_TABQ_KERNEL_AUTO); } SGK_CATCH_STATUS
 
-int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64_t *n_actions) {
+int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64_t *n_actions) try {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   q->rows_stale = true;  // the caller may write through the pointer: the per-step kernels re-read the table afterwards
   if (table_dev) *table_dev = q->tq.table;
   if (n_states) *n_states = q->tq.n_states;
   if (n_actions) *n_actions = SGK_ACTIONS;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_tabq_invalidate_rows(sgk_tabq *q) {
+int sgk_tabq_invalidate_rows(sgk_tabq *q) try {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   q->rows_stale = true;  // the next sgk_tabq_act / _learn / _learn_steps re-tags every row slot invalid first
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_debug_server_stale_exit_word(sgk_env *h) {
+int sgk_debug_server_stale_exit_word(sgk_env *h) try {
   if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
-  if (!h->mailbox || !h->server_running) return fail(SGK_ERR_INVALID, "no resident step server on this handle");
-  h->mailbox->exited = h->server_seq + 1u;  // what a server that served up to server_seq writes when it leaves
-  __sync_synchronize();
+  if (!h->srv.mb || !h->srv.running) return fail(SGK_ERR_INVALID, "no resident step server on this handle");
+  sgk::host::mb_store(&h->srv.mb->exited, h->srv.seq + 1u);  // what a server that served up to srv.seq writes when it leaves
+  h->srv.launched += 1;                                      // (the link counts the words it is owed: this one has a server of its own)
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_debug_graph_count(const sgk_env *h, const sgk_tabq *q, int32_t *env_graphs_out, int32_t *tabq_graphs_out) {
+int sgk_debug_fail_host_alloc(int k) { return sgk::host::alloc_countdown().exchange(k < 0 ? 0 : k); }
+
+int sgk_debug_graph_count(const sgk_env *h, const sgk_tabq *q, int32_t *env_graphs_out, int32_t *tabq_graphs_out) try {
   if (env_graphs_out) *env_graphs_out = h ? (int32_t)h->graphs.size() : 0;
   if (tabq_graphs_out) *tabq_graphs_out = q ? (int32_t)q->graphs.size() : 0;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, double *table_host) {
+int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, double *table_host) try {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   SGK_CHECK_HANDLE(q->env);
   if (!table_host || env_begin < 0 || env_count < 0 || env_begin + env_count > q->env->sh.n)
@@ -1590,12 +1329,12 @@ int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, doubl
                          hipMemcpyDeviceToHost, q->env->stream));
   SGK_HIP(hipStreamSynchronize(q->env->stream));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_tabq_global_step(const sgk_tabq *q, int64_t *t_out) {
+int sgk_tabq_global_step(const sgk_tabq *q, int64_t *t_out) try {
   if (!q || !t_out) return fail(SGK_ERR_INVALID, "NULL argument");
   *t_out = q->tq.t_agent;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 }  // extern "C"

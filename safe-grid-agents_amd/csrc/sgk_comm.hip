@@ -8,10 +8,11 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstring>
 #include <mutex>
-#include <string>
 
+#include "sgk_host_core.h"
 #include "sgk_kernels.h"
 
 namespace {
@@ -34,7 +35,7 @@ struct Rccl {
   ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;     // optional: what RCCL itself says the communicator spans
   ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;  // optional
   ncclResult_t (*GetVersion)(int *) = nullptr;                      // optional
-  std::string error;
+  char error[256] = "";  // why RCCL cannot be used ("" = it can); a fixed buffer: nothing on this path allocates
 };
 
 void load_rccl(Rccl &r);
@@ -54,13 +55,13 @@ void load_rccl(Rccl &r) {
   }
   if (!r.dl) {
     const char *de = dlerror();  // one call: a second one returns NULL (the first clears the error)
-    r.error = std::string("librccl.so.1 could not be loaded: ") + (de ? de : "?");
+    snprintf(r.error, sizeof(r.error), "librccl.so.1 could not be loaded: %s", de ? de : "?");
     return;
   }
 #define SGK_SYM(field, name)                                                             \
   do {                                                                                   \
     *reinterpret_cast<void **>(&r.field) = dlsym(r.dl, name);                            \
-    if (!r.field) { r.error = std::string("librccl has no symbol ") + name; return; } \
+    if (!r.field) { snprintf(r.error, sizeof(r.error), "librccl has no symbol %s", name); return; } \
   } while (0)
   SGK_SYM(GetUniqueId, "ncclGetUniqueId");
   SGK_SYM(CommInitRank, "ncclCommInitRank");
@@ -90,37 +91,36 @@ int sgk_set_error(int code, const char *msg);  // sgk_api.hip: stores the thread
 
 static int rccl_fail(const char *what, ncclResult_t e) {
   Rccl &r = rccl();
-  std::string m = std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(e) : "RCCL error");
-  return sgk_set_error(SGK_ERR_HIP, m.c_str());
+  return sgk::host::fail(SGK_ERR_HIP, "%s: %s", what, r.GetErrorString ? r.GetErrorString(e) : "RCCL error");
 }
 
-int sgk_comm_available(int32_t *version_out) {
+int sgk_comm_available(int32_t *version_out) try {
   Rccl &r = rccl();  // dlopen + dlsym of every entry point the path needs: no socket, no thread, nothing to clean up
-  if (!r.error.empty()) return sgk_set_error(SGK_ERR_NODEVICE, r.error.c_str());
+  if (r.error[0]) return sgk_set_error(SGK_ERR_NODEVICE, r.error);
   int v = 0;
   if (r.GetVersion && r.GetVersion(&v) != NCCL_SUCCESS) v = 0;
   if (version_out) *version_out = v;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_comm_unique_id(uint8_t id_out[SGK_COMM_ID_BYTES]) {
+int sgk_comm_unique_id(uint8_t id_out[SGK_COMM_ID_BYTES]) try {
   if (!id_out) return sgk_set_error(SGK_ERR_INVALID, "id_out is NULL");
   Rccl &r = rccl();
-  if (!r.error.empty()) return sgk_set_error(SGK_ERR_NODEVICE, r.error.c_str());
+  if (r.error[0]) return sgk_set_error(SGK_ERR_NODEVICE, r.error);
   ncclUniqueId id;
   ncclResult_t e = r.GetUniqueId(&id);
   if (e != NCCL_SUCCESS) return rccl_fail("ncclGetUniqueId", e);
   static_assert(sizeof(id) == SGK_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
   std::memcpy(id_out, &id, sizeof(id));
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_comm_create(const uint8_t id[SGK_COMM_ID_BYTES], int rank, int world_size, int device, sgk_comm **out) {
+int sgk_comm_create(const uint8_t id[SGK_COMM_ID_BYTES], int rank, int world_size, int device, sgk_comm **out) try {
   if (!out) return sgk_set_error(SGK_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (!id || world_size < 1 || rank < 0 || rank >= world_size) return sgk_set_error(SGK_ERR_INVALID, "bad id / rank / world_size");
   Rccl &r = rccl();
-  if (!r.error.empty()) return sgk_set_error(SGK_ERR_NODEVICE, r.error.c_str());
+  if (r.error[0]) return sgk_set_error(SGK_ERR_NODEVICE, r.error);
   hipError_t he = hipSetDevice(device);
   if (he != hipSuccess) return sgk_set_error(SGK_ERR_HIP, hipGetErrorString(he));
   ncclUniqueId uid;
@@ -137,17 +137,17 @@ int sgk_comm_create(const uint8_t id[SGK_COMM_ID_BYTES], int rank, int world_siz
   c->device = device;
   *out = c;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_comm_destroy(sgk_comm *c) {
+int sgk_comm_destroy(sgk_comm *c) try {
   if (!c) return SGK_OK;
   Rccl &r = rccl();
   if (c->comm && r.CommDestroy) (void)r.CommDestroy(c->comm);
   delete c;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_comm_info(const sgk_comm *c, int32_t *rank_out, int32_t *world_out, int32_t *device_out) {
+int sgk_comm_info(const sgk_comm *c, int32_t *rank_out, int32_t *world_out, int32_t *device_out) try {
   if (!c) return sgk_set_error(SGK_ERR_INVALID, "comm is NULL");
   int rank = c->rank, world = c->world;
   Rccl &r = rccl();
@@ -158,9 +158,9 @@ int sgk_comm_info(const sgk_comm *c, int32_t *rank_out, int32_t *world_out, int3
   if (world_out) *world_out = world;
   if (device_out) *device_out = c->device;
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
-int sgk_allreduce_metrics(sgk_comm *c, int64_t *inout_dev, void *hip_stream) {
+int sgk_allreduce_metrics(sgk_comm *c, int64_t *inout_dev, void *hip_stream) try {
   if (!c || !inout_dev) return sgk_set_error(SGK_ERR_INVALID, "NULL argument");
   Rccl &r = rccl();
   hipError_t he = hipSetDevice(c->device);
@@ -174,7 +174,7 @@ int sgk_allreduce_metrics(sgk_comm *c, int64_t *inout_dev, void *hip_stream) {
   if (e != NCCL_SUCCESS) return rccl_fail("ncclAllReduce", e);
   if (ge != NCCL_SUCCESS) return rccl_fail("ncclGroupEnd", ge);
   return SGK_OK;
-}
+} SGK_CATCH_STATUS
 
 // sgk_metrics() of this shard all-reduced over the communicator's ranks: defined in sgk_api.hip (needs the handle's internals)
 

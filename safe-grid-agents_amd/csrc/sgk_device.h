@@ -32,6 +32,19 @@ constexpr int WG = 256;
 // loop; cdna_hip_programming.md T20) -- ten extra instructions per store and no overlap between consecutive stores.
 __device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// Kernel arguments the compiler would fetch lazily (an s_load where they are first used -- for a latency-bound kernel another
+// memory round trip behind the first one): naming them as scalar-register inputs of an empty asm at kernel entry makes their
+// loads part of the entry block's batch.
+template <class P>
+__device__ __forceinline__ int keep_in_sgpr(P p) {
+  asm volatile("" ::"s"(p));
+  return 0;
+}
+template <class... P>
+__device__ __forceinline__ void keep_in_sgprs(P... p) {
+  (void)(keep_in_sgpr(p) + ...);
+}
+
 // workgroup-cooperative copy of the rule tables HBM/L2 -> LDS
 __device__ __forceinline__ void stage_rules(SgkRules &dst, const SgkRules *__restrict__ src) {
   constexpr int NW = sizeof(SgkRules) / 4;
@@ -40,6 +53,40 @@ __device__ __forceinline__ void stage_rules(SgkRules &dst, const SgkRules *__res
   for (int i = threadIdx.x; i < NW; i += blockDim.x) d[i] = s[i];
   __syncthreads();
 }
+
+// The rule tables as ONE WAVE's private LDS copy (the per-step kernel, round 5): every lane requests its 16-byte pieces of the
+// table right at kernel entry -- next to the tile's state words, so all of a wave's global loads are in flight together -- and
+// writes them to the wave's own image. LDS operations of one wave execute in issue order: no workgroup barrier anywhere (the
+// barrier-staged form above makes the four waves of a workgroup wait for the slowest one's loads twice per launch; measured
+// on synthetic kernels with the step's memory shape, tools/exp_step_latency.hip: 2.69 -> 2.27 us per launch at 65 536 envs,
+// 8.6 -> 7.1 at 1 M, 2.42 -> 2.0 at 1 024). The device buffer behind Shard::rules_dev is SGK_RULES_DEV_BYTES long: the
+// table padded to SGK_RULES_IMAGE_BYTES, then a blank 64-env COMPACT tile (the level's backdrop 64 times over, n_cells bytes
+// each) that the tile writer starts from.
+constexpr int SGK_RULES_CHUNKS = (int)((sizeof(SgkRules) + 15) / 16);
+constexpr int SGK_RULES_ITS = (SGK_RULES_CHUNKS + 63) / 64;
+static_assert(sizeof(SgkRules) <= SGK_RULES_IMAGE_BYTES && SGK_RULES_ITS * 64 * 16 <= SGK_RULES_IMAGE_BYTES, "rule table image");
+typedef uint32_t sgk_rules_u32x4 __attribute__((ext_vector_type(4)));
+union alignas(16) WaveRulesImage {
+  SgkRules r;
+  sgk_rules_u32x4 q[SGK_RULES_IMAGE_BYTES / 16];
+};
+struct WaveRulesLoad {
+  sgk_rules_u32x4 v[SGK_RULES_ITS];
+  // request this lane's pieces (no wait): a raw buffer load, out-of-range pieces read as zeros
+  __device__ __forceinline__ void request(const SgkRules *__restrict__ src) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, SGK_RULES_IMAGE_BYTES, 0x00020000);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < SGK_RULES_ITS; ++it) v[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lane + 64 * it) * 16, 0, 0);
+  }
+  // the pieces into the wave's image; the wave's later LDS reads come after these writes in issue order
+  __device__ __forceinline__ void commit(WaveRulesImage &img) const {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < SGK_RULES_ITS; ++it) img.q[lane + 64 * it] = v[it];
+    __builtin_amdgcn_wave_barrier();
+  }
+};
 
 // ------------------------------------------------------------------------------------------------
 // episode-end bookkeeping: ballot -> wave reduction -> one atomic per wave per quantity.
@@ -256,6 +303,36 @@ struct WaveTileLds {
           const int r = (16 * j) % NC;
           *reinterpret_cast<uint4 *>(tile + 16 * j) = *reinterpret_cast<const uint4 *>(&C.rot[r][0]);
         }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    poke(R, info);
+  }
+
+  // The barrier-free form of draw_all (the per-step kernel): the blank tile -- the backdrop 64 times over, precomputed on the host
+  // behind the rule table (SGK_RULES_IMAGE_BYTES) -- is REQUESTED at kernel entry as 16-byte pieces, one or more per lane, and
+  // written to the image when a tile is drawn; levels whose envs pick one of several backdrops copy their row from the wave's
+  // rule image instead. No rotation table, no workgroup barrier.
+  struct Blank {
+    sgk_rules_u32x4 v[ITS];
+  };
+  __device__ __forceinline__ void request_blank(Blank &b, const SgkRules *__restrict__ rules_dev) const {
+    if (ALT) return;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const uint8_t *>(rules_dev) + SGK_RULES_IMAGE_BYTES), 0, BYTES, 0x00020000);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) b.v[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lane + 64 * it) * 16, 0, 0);
+  }
+  __device__ __forceinline__ void draw_from_blank(const Blank &b, const SgkRules &R, uint32_t info) const {
+    const int lane = threadIdx.x & 63;
+    if (ALT) {
+      copy_row(tile + lane * NC, backdrop_of(R, info_backdrop(info)));
+    } else {
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        const int j = lane + 64 * it;
+        if (ITS * 64 == CHUNKS || j < CHUNKS) *reinterpret_cast<sgk_rules_u32x4 *>(tile + 16 * j) = b.v[it];
       }
     }
     __builtin_amdgcn_wave_barrier();

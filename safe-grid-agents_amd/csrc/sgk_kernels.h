@@ -4,11 +4,17 @@
 #include <stdint.h>
 
 #include "../../include/sgk.h"
+#include "sgk_mailbox.h"
 #include "sgk_rules.h"
 
 #define SGK_METRIC_SLOTS 2048
 
 namespace sgk {
+
+// The device buffer behind Shard::rules_dev: the rule table padded to SGK_RULES_IMAGE_BYTES, then a blank 64-env COMPACT board tile
+// (the level's backdrop 64 times over, n_cells bytes each) -- what the per-step kernel's waves load at entry (sgk_device.h).
+constexpr int SGK_RULES_IMAGE_BYTES = 2048;
+constexpr int SGK_RULES_DEV_BYTES = SGK_RULES_IMAGE_BYTES + 64 * SGK_CELLS;
 
 // Device-resident arrays of one shard (N envs on one GPU). Structure-of-arrays over envs.
 struct Shard {
@@ -55,21 +61,7 @@ struct TabqShard {
 };
 
 hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, hipStream_t st);
-// The single-env step server's mailbox (pinned, device-mapped host memory; each word on a cache line of its own) and launcher
-struct SgkMailbox {
-  // host -> device, ONE 8-byte word so that one PCIe read carries the whole request of a single env: bits 0..31 the number of
-  // the step asked for (never SGK_SERVER_STOP; SGK_SERVER_STOP = leave), bits 32..39 the SGK_F_* flags of that step, bits 40..47
-  // env 0's action (the other envs' actions, if any, are read from the host-visible action buffer)
-  volatile uint64_t request;
-  uint32_t pad0[14];
-  volatile uint32_t done;     // device -> host: number of the last step whose outputs are in the host-visible buffers
-  uint32_t pad2[15];
-  volatile uint32_t exited;   // device -> host: 0 while the server runs; (last step served + 1) once it has left
-  uint32_t pad3[15];
-};
-#define SGK_SERVER_STOP 0xffffffffu
-#define SGK_SRV_RESET 0x80u  // in the flags byte of a step-server request: reset every env of the handle instead of stepping
-#define SGK_SERVER_IDLE_US 100  // the step server leaves after this long without a request (wall_clock64: 100 MHz)
+// the single-env step server (its mailbox: sgk_mailbox.h)
 hipError_t launch_env_server(const Shard &sh, const uint8_t *actions, SgkMailbox *mb, uint32_t last, hipStream_t st);
 hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flags, hipStream_t st);
 // the same loop with every step's board tile and step record materialised: into the env's own buffers (rings == nullptr) or

@@ -6,11 +6,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <string>
+#include "sgk_host_core.h"
 
-#include "../../include/sgk.h"
-
-extern "C" int sgk_set_error(int code, const char *msg);
+using sgk::host::fail;
+using sgk::host::hip_fail;
 
 namespace {
 
@@ -45,15 +44,14 @@ __global__ __launch_bounds__(256) void salu_issue_loop(uint32_t *out, int iters)
   if (a + b + c + d + e + f + g + h == 0x12345) out[0] = a;
 }
 
-int hip_fail(hipError_t e, const char *what) {
-  return sgk_set_error(SGK_ERR_HIP, (std::string(what) + ": " + hipGetErrorString(e)).c_str());
-}
-
 }  // namespace
 
-extern "C" int sgk_issue_peak(int32_t device, int32_t waves_per_simd, double *valu_wave_instr_per_s, double *salu_wave_instr_per_s) {
-  if (!valu_wave_instr_per_s || !salu_wave_instr_per_s) return sgk_set_error(SGK_ERR_INVALID, "NULL output");
-  if (waves_per_simd < 1 || waves_per_simd > 8) return sgk_set_error(SGK_ERR_INVALID, "waves_per_simd must be 1 .. 8");
+extern "C" int sgk_issue_peak(int32_t device, int32_t waves_per_simd, double *valu_wave_instr_per_s, double *salu_wave_instr_per_s) try {
+  if (!valu_wave_instr_per_s || !salu_wave_instr_per_s) return fail(SGK_ERR_INVALID, "NULL output");
+  if (waves_per_simd < 1 || waves_per_simd > 8) return fail(SGK_ERR_INVALID, "waves_per_simd must be 1 .. 8");
+  // takes no handle and runs in the middle of a caller's program (bench.py): the thread's current device is put back on return.
+  // The call synchronises (it times its own launches on a stream of its own).
+  sgk::host::DeviceGuard keep_current_device;
   hipError_t err = hipSetDevice(device);
   if (err != hipSuccess) return hip_fail(err, "hipSetDevice");
   hipDeviceProp_t prop;
@@ -93,4 +91,4 @@ extern "C" int sgk_issue_peak(int32_t device, int32_t waves_per_simd, double *va
   *valu_wave_instr_per_s = rate[0];
   *salu_wave_instr_per_s = rate[1];
   return SGK_OK;
-}
+} SGK_CATCH_STATUS

@@ -60,29 +60,51 @@ __global__ __launch_bounds__(WG) void metrics_init_kernel(long long *__restrict_
 // (grid-stride over tiles); the COMPACT board tile is assembled and stored by the wave itself (WaveTileLds: no workgroup
 // barrier after the rule tables are staged).
 // ------------------------------------------------------------------------------------------------
-template <int ENV, int LAYOUT, bool RANDOM>
-__global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
+// SMALL (batches of up to STEP_SMALL_MAX_ENVS envs: the launch's whole working set stays in the L2s): one wave per workgroup, four
+// times the workgroups, and plain stores for the step record and the board tile -- write-through (sc1) pays at a million envs,
+// where board bytes would evict the state words (sgk_device.h), and costs here. Measured on this kernel's body, BoatRace, us per
+// launch (tools/exp_step_variants.hip, profiles/r05/step_variants_*.log): 1 024 envs 2.46 -> 2.10, 65 536 envs 2.65 -> 2.54,
+// 262 144 envs 3.86 -> 4.50 (hence the size cut).
+constexpr int64_t STEP_SMALL_MAX_ENVS = 65536;
+template <int ENV, int LAYOUT, bool RANDOM, bool SMALL>
+__global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a) {
+  constexpr int WGT = SMALL ? 64 : WG;
   constexpr int NC = Geom<ENV>::NC;
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
-  __shared__ SgkRules R;
-  __shared__ CompactLds<NC> C;
+  // wave-private images: the rule table and the board tile. No workgroup barrier in this kernel (WaveRulesLoad, sgk_device.h).
+  __shared__ WaveRulesImage rules_images[WGT / 64];
+  __shared__ __attribute__((aligned(16))) uint8_t tile_images[COMPACT ? WGT / 64 : 1][COMPACT ? 64 * NC : 16];
   const int lane = threadIdx.x & 63, wave = wave_index();
   const int64_t n_wt = (a.n + 63) / 64;
-  const int64_t wt0 = (int64_t)blockIdx.x * (WG / 64) + wave, wstride = (int64_t)gridDim.x * (WG / 64);
-  // issue the first tile's state (and action) loads before the rule tables are staged: one memory round trip less
+  const int64_t wt0 = (int64_t)blockIdx.x * (WGT / 64) + wave, wstride = (int64_t)gridDim.x * (WGT / 64);
+  const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
+  // Every load of the wave's first tile is requested before the first wait -- ONE memory round trip ahead of the arithmetic:
+  // all kernel arguments (the compiler otherwise fetches some of them where they are first used, behind the vector loads: a
+  // second round trip), the lockstep counter of a graph replay (branch-free: a null t_ptr reads a word that exists and drops
+  // it), the state words (and actions), the wave's pieces of the rule table and of the blank board tile.
+  keep_in_sgprs(a.rec, a.boards, a.last_return, a.last_perf);
+  keep_in_sgprs(a.n_episodes, a.n_resets, a.metrics, a.aux);
+  keep_in_sgprs(a.seed, a.env_base, a.t, a.flags);
+  const uint64_t *t_word = a.t_ptr ? a.t_ptr : reinterpret_cast<const uint64_t *>(a.rules);
+  const uint64_t t_base = *t_word;  // (wave-uniform address: a scalar load)
   uint64_t w_cur = 0;
   uint8_t a_cur = 0;
   {
+    // unconditional, index clamped into the batch: no branch between the entry block's loads (a wave past the last tile drops the word)
     const int64_t e0 = wt0 * 64 + lane;
-    if (wt0 < n_wt && e0 < a.n) {
-      w_cur = a.state[e0];
-      if (!RANDOM) a_cur = a.actions[e0];
-    }
+    const int64_t e0c = e0 < a.n ? e0 : a.n - 1;
+    w_cur = a.state[e0c];
+    if (!RANDOM) a_cur = a.actions[e0c];
   }
-  stage_rules(R, a.rules);
-  SGK_TILE_DECLARE(ENV, NC, COMPACT);
-  const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
-  const uint64_t t_now = a.t_ptr ? (*a.t_ptr + a.t) : a.t;
+  WaveRulesLoad rules_load;
+  rules_load.request(a.rules);
+  WaveTileLds<ENV, NC> W;
+  W.bind(tile_images[COMPACT ? wave : 0]);
+  typename WaveTileLds<ENV, NC>::Blank blank;
+  if (COMPACT) W.request_blank(blank, a.rules);  // (also when the caller wants no boards: a branch here would split the batch of loads)
+  rules_load.commit(rules_images[wave]);
+  const SgkRules &R = rules_images[wave].r;
+  const uint64_t t_now = a.t + (a.t_ptr ? t_base : 0ull);
   EpisodeAcc acc;
   acc_init(acc);
   for (int64_t wt = wt0; wt < n_wt; wt += wstride) {
@@ -114,11 +136,17 @@ __global__ __launch_bounds__(WG) void step_kernel(StepArgs a) {
     step_one<ENV>(R, a, env, valid, action, s, rec, acc);
     if (valid) {
       a.state[env] = pack_state(s);
-      __hip_atomic_store(&a.rec[env], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
+      if (SMALL) a.rec[env] = rec;
+      else __hip_atomic_store(&a.rec[env], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
     }
     if (boards_on) {
-      if (COMPACT) SGK_TILE_WRITE(sprite_info<ENV>(R, s), a.boards + wt * 64 * NC);  // the buffer is padded to whole tiles
-      else if (valid) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+      if (COMPACT) {
+        W.draw_from_blank(blank, R, sprite_info<ENV>(R, s));
+        if (SMALL) W.template flush<0>(a.boards + wt * 64 * NC);  // the buffer is padded to whole tiles
+        else W.flush(a.boards + wt * 64 * NC);
+      } else if (valid) {
+        write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+      }
     }
   }
   acc_flush(acc, a.metrics);
@@ -675,19 +703,26 @@ hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t 
   StepArgs a = make_step_args(sh, nullptr, flags);
   a.t = t_off;
   a.t_ptr = t_dev;
-  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
-  SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a));
+  if (sh.n <= STEP_SMALL_MAX_ENVS) {
+    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, true><<<dim3((unsigned)((sh.n + 63) / 64)), dim3(64), 0, st>>>(a));
+  } else {
+    int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, false><<<dim3(grid), dim3(WG), 0, st>>>(a));
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, hipStream_t st) {
   (void)hipGetLastError();  // drop a stale error another HIP user of this thread may have left
   StepArgs a = make_step_args(sh, actions, flags);
-  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  const bool small = sh.n <= STEP_SMALL_MAX_ENVS;
+  const dim3 grid(small ? (unsigned)((sh.n + 63) / 64) : (unsigned)grid_for((sh.n + WG - 1) / WG, sh.max_grid)), block(small ? 64 : WG);
   if (actions) {
-    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, false><<<dim3(grid), dim3(WG), 0, st>>>(a));
+    if (small) SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, false, true><<<grid, block, 0, st>>>(a));
+    else SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, false, false><<<grid, block, 0, st>>>(a));
   } else {
-    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(a));
+    if (small) SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, true><<<grid, block, 0, st>>>(a));
+    else SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, false><<<grid, block, 0, st>>>(a));
   }
   return hipGetLastError();
 }

@@ -14,7 +14,7 @@ CSRC = os.path.join(_DIST, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_DIST), "include")
 
 SGK_OK = 0
-ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE = -1, -2, -3, -4
+ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE, ERR_INTERNAL = -1, -2, -3, -4, -5
 F_AUTO_RESET, F_NO_BOARDS, F_MASK_FINISHED, F_RING_TILE_MAJOR = 1, 2, 4, 8
 LAYOUT_PITCHED, LAYOUT_COMPACT = 0, 1
 TABQ_KERNEL_AUTO, TABQ_KERNEL_LDS, TABQ_KERNEL_HBM = 0, 1, 2
@@ -170,6 +170,7 @@ _SIGNATURES = {
     "sgk_tabq_invalidate_rows": (ctypes.c_int, [_V]),
     "sgk_debug_graph_count": (ctypes.c_int, [_V, _V, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "sgk_debug_server_stale_exit_word": (ctypes.c_int, [_V]),
+    "sgk_debug_fail_host_alloc": (ctypes.c_int, [ctypes.c_int]),
     "sgk_tabq_copy_table": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int64, _V]),
     "sgk_tabq_global_step": (ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_int64)]),
     "sgk_tabq_epsilon": (ctypes.c_double, [ctypes.c_double, ctypes.c_int64, ctypes.c_int64]),

@@ -1600,7 +1600,7 @@ env = S.BatchedGridworldEnv("BoatRace-v0", 256, seed=1)
 agent = S.BatchedTabularQAgent(env, type("A", (), dict(lr=0.5, discount=0.99, epsilon=0.05, epsilon_anneal=300))())
 handles = {"env": env.handle, "tabq": agent._h}
 skip = {"sgk_abi_version", "sgk_random_action", "sgk_tabq_epsilon", "sgk_debug_reset_word", "sgk_get_stream",
-        "sgk_destroy", "sgk_tabq_destroy"}  # (non-status returns; the two destructors are exercised at the end)
+        "sgk_destroy", "sgk_tabq_destroy", "sgk_debug_fail_host_alloc"}  # (non-status returns; the two destructors are exercised at the end)
 ok_on_null = {"sgk_ring_free", "sgk_comm_destroy", "sgk_comm_available", "sgk_device_count", "sgk_debug_graph_count"}
 n_called = 0
 for name, (res, args) in sorted(_lib._SIGNATURES.items()):
@@ -1625,6 +1625,35 @@ for name, (res, args) in sorted(_lib._SIGNATURES.items()):
         n_called += 1
         assert isinstance(rc, int), name
 assert lib.sgk_destroy(None) == _lib.SGK_OK and lib.sgk_tabq_destroy(None) == _lib.SGK_OK
+# (c) the allocation-failure leg: the k-th host allocation of a call fails like an exhausted heap (std::bad_alloc inside the
+# library) -- the call answers SGK_ERR_NOMEM with a message, hands out nothing, leaks nothing it could not free, and the same call
+# succeeds once k is past its allocations. No exception reaches this process (it would end it: there is no Python frame to catch it).
+def sweep(label, call, undo):
+    refused = 0
+    for k in range(1, 12):
+        lib.sgk_debug_fail_host_alloc(k)
+        sys.stderr.write("nomem: %%s k=%%d\\n" %% (label, k)); sys.stderr.flush()
+        rc, out = call()
+        left = lib.sgk_debug_fail_host_alloc(0)
+        if rc == _lib.ERR_NOMEM:
+            assert left == 0 and not out.value, (label, k)
+            assert b"memory" in lib.sgk_last_error(), (label, k)
+            refused += 1
+        else:
+            assert rc == _lib.SGK_OK and out.value and left == k - refused, (label, k, rc, left)
+            undo(out)
+            break
+    assert refused >= 1, label
+    return refused
+def make_env():
+    h = V(); return lib.sgk_create(0, 256, 0, 1, ctypes.byref(h)), h
+def make_tabq():
+    q = V(); return lib.sgk_tabq_create(env.handle, 0.5, 0.99, 0.05, 300, ctypes.byref(q)), q
+def make_ring():
+    r = V(); return lib.sgk_ring_alloc(0, 3 << 20, ctypes.byref(r)), r
+n_refused = sweep("sgk_create", make_env, lambda h: lib.sgk_destroy(h)) + sweep("sgk_tabq_create", make_tabq, lambda q: lib.sgk_tabq_destroy(q)) \
+    + sweep("sgk_ring_alloc", make_ring, lambda r: lib.sgk_ring_free(r))
+assert n_refused >= 6  # the handle + its graph cache, twice; the ring's record + its two vectors
 # the env still works after all of that
 env.step_random(5, auto_reset=True)
 assert env.metrics()[_lib.M_STEPS] >= 5 * 256
