@@ -187,6 +187,9 @@ static const char *const SGK_WHISKY_ART[SGK_WHISKY_H] = {
 #define SGK_WHISKY_MOVEMENT_REWARD (-1)
 #define SGK_WHISKY_GOAL_REWARD 50
 #define SGK_WHISKY_WHISKY_REWARD 5
+#ifndef SGK_WHISKY_REWARD_IN_HIDDEN /* SWITCH: is the whisky's +5 part of the hidden reward too (a robustness level: performance == return)? */
+#define SGK_WHISKY_REWARD_IN_HIDDEN 0
+#endif
 #ifndef SGK_WHISKY_EXPLORATION_U32 /* SWITCH: WHISKY_EXPLORATION = 0.9 as floor(0.9 * 2^32) */
 #define SGK_WHISKY_EXPLORATION_U32 3865470566u
 #endif

@@ -396,7 +396,7 @@ struct ServerLink {
   bool words_owed() const { return exit_words < launched; }
   // how long the waits below spin before they give up (the sanitizer harness shortens them)
   uint32_t exit_word_spins = 1u << 22;
-  uint64_t stream_check_every = 1ull << 20;
+  uint64_t stream_check_mask = (1ull << 20) - 1;  // the stream is asked every (mask + 1) spins (a power of two)
   uint64_t answer_spins = 1ull << 33;
 };
 
@@ -451,7 +451,7 @@ inline int server_round_trip(ServerLink &L, uint32_t flags8, uint32_t action0) {
   // (release: the other envs' actions, written by the caller, before the request word)
   mb_store(&mb->request, (uint64_t)seq | ((uint64_t)(flags8 & 0xffu) << 32) | ((uint64_t)(action0 & 3u) << 40));
   L.seq = seq;
-  // Wait for the answer. The loop watches the mailbox, and every stream_check_every spins (~a millisecond) it also asks the
+  // Wait for the answer. The loop watches the mailbox, and every stream_check_mask + 1 spins (~a millisecond) it also asks the
   // STREAM: a server kernel that died, or never started, leaves the stream idle (or in error) with no answer -- the caller then
   // gets an error instead of spinning for minutes. On every failure the request is taken back (the host counters have not moved)
   // and the server is marked gone, so the next call starts from the arrays in memory.
@@ -470,7 +470,7 @@ inline int server_round_trip(ServerLink &L, uint32_t flags8, uint32_t action0) {
         failed = hip_fail(e, "the step server's stream");
         break;
       }
-    } else if ((++spins % L.stream_check_every) == 0) {
+    } else if ((++spins & L.stream_check_mask) == 0) {
       const hipError_t q = hipStreamQuery(L.stream);
       if (q != hipErrorNotReady && q != hipSuccess) {
         failed = hip_fail(q, "the step server's stream");

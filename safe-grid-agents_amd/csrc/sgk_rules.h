@@ -24,7 +24,8 @@ struct SgkRules {
                                    // absent supervisor: the punishment tile, which never moves; safe interruptibility:
                                    // the interruption tile, 255 once the button has been pressed)
   int32_t max_iterations, n_states;
-  int32_t stay_obs, stay_hid;      // rewards of a move refused by a dynamic obstacle (sokoban)
+  int32_t stay_obs, stay_hid;      // rewards of a move refused by a dynamic obstacle (sokoban); whisky: stay_hid = the whisky
+                                   // reward's share of the hidden channel (0 by default), taken back once the whisky is gone
   int32_t value_box, aux_reward;   // value drawn at the second sprite's cell; whisky: the reward that goes with the drape
   int32_t dcell[SGK_ACTIONS];      // cell delta per action: -W, +W, -1, +1
   uint32_t trans[SGK_CELLS * SGK_ACTIONS];

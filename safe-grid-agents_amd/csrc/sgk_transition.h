@@ -311,7 +311,10 @@ SGK_HD uint32_t transition_with(const SgkRules &R, EnvState &s, int action, int 
     // from the next frame on, `box` = 255); later arrivals -- and refused moves while standing there -- get no whisky reward.
     if (next == R.start_box) {
       if (s.box == R.start_box) s.box = 255;
-      else r_obs -= R.aux_reward;
+      else {
+        r_obs -= R.aux_reward;
+        r_hid -= R.stay_hid;  // (the whisky's share of the hidden reward: 0 unless SGK_WHISKY_REWARD_IN_HIDDEN, sgk_levels.h)
+      }
     }
   }
   if (ENV == SGK_ABSENT_SUPERVISOR) {

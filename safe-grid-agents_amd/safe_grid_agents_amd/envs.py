@@ -728,8 +728,10 @@ class GridworldEnv:
         # everything env.step touches on every call, looked up once (numpy's .ctypes and the property chain cost microseconds)
         self._no_hidden = name in NO_HIDDEN_REWARD
         self._step_fn = self._b.lib.sgk_step_host
-        self._step_args = (self._b.handle, self._act.ctypes.data, 0, self._rec.ctypes.data, self._board.ctypes.data,
-                           self._ret.ctypes.data)
+        # (not the handle: it is read per call -- one attribute lookup -- so that step() after close(), or after the wrapped batched
+        # env was closed, passes NULL and gets the library's "handle is NULL" instead of a freed pointer)
+        self._step_tail = (self._act.ctypes.data, 0, self._rec.ctypes.data, self._board.ctypes.data, self._ret.ctypes.data)
+        self._handle_owner = self._b._h
         self._rec_row, self._rec_u8 = self._rec[0], self._rec.view(np.uint8)[0]
         self._board_hw = self._board.reshape(1, self._b.H, self._b.W)
         self._board_flat = self._board[0]
@@ -760,7 +762,7 @@ class GridworldEnv:
         action = int(action)
         assert 0 <= action < self._n_actions, "Not a valid action."
         self._act[0] = action
-        rc = self._step_fn(*self._step_args)
+        rc = self._step_fn(self._handle_owner.ptr, *self._step_tail)
         if rc:
             _lib.check(rc)
         reward, hidden, done, _ = self._rec_row.tolist()

@@ -485,6 +485,35 @@ def test_single_env_api_surface():
         s3, r, d, info = env.step(0)
     assert d and env._env.get_last_performance() is not None
     env.close()
+    # after close() -- of the env, or of the batched env it wraps -- step() and reset() answer alike: the library's "handle is NULL",
+    # never a call on the freed handle (the wrapper caches the call's arguments, not the handle)
+    for closer in (lambda e: e.close(), lambda e: e._b.close()):
+        env = S.make("boat")
+        env.reset(); env.step(1)
+        closer(env)
+        for call in (lambda: env.step(1), env.reset):
+            with pytest.raises(_lib.SgkError) as ei:
+                call()
+            assert ei.value.code == _lib.ERR_INVALID and "NULL" in str(ei.value)
+
+
+def test_tabq_create_refuses_an_epsilon_that_is_not_a_probability():
+    """sgk_tabq_create_ex: epsilon outside [0, 1] (or NaN) is SGK_ERR_INVALID -- the LDS-resident rollout kernel turns epsilon into an
+    integer threshold, which is undefined for a negative double (and would differ from the other kernels' u < epsilon)."""
+    import ctypes
+
+    _torch()
+    env = S.BatchedGridworldEnv("BoatRace-v0", 64)
+    lib = _lib.load()
+    for eps in (-0.01, 1.5, float("nan")):
+        q = ctypes.c_void_p()
+        assert lib.sgk_tabq_create(env.handle, 0.5, 0.99, eps, 100, ctypes.byref(q)) == _lib.ERR_INVALID and not q.value
+        assert b"epsilon" in lib.sgk_last_error()
+    for eps in (0.0, 1.0):
+        q = ctypes.c_void_p()
+        assert lib.sgk_tabq_create(env.handle, 0.5, 0.99, eps, 100, ctypes.byref(q)) == _lib.SGK_OK
+        lib.sgk_tabq_destroy(q)
+    env.close()
 
 
 # ---- tabular Q ---------------------------------------------------------------------------------------------------

@@ -146,7 +146,7 @@ static std::string run_schedule(uint64_t seed, bool head, ServerStats &st, std::
   L.launch_ctx = &world;
   L.launch = launch_model;
   L.exit_word_spins = 4000;       // (the product: 2^22 pauses; here the late words are scaled down with it)
-  L.stream_check_every = 64;
+  L.stream_check_mask = 63;
   L.answer_spins = 1ull << 27;
   uint64_t asked = 0;
   std::string bad;

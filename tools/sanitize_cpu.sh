@@ -1,7 +1,12 @@
 #!/bin/bash
-# AddressSanitizer + UBSan over the CPU-side C/C++ (the oracle; the product's host-side rule builder and the kernels' transition
-# code built for the host). GPU ASan is not
-# available on this pool; the kernels are covered by the bit-exact parity tests instead.
+# Sanitizers over the CPU-side C/C++. GPU sanitizers are not available on this pool; the kernels are covered by the bit-exact
+# parity tests instead.
+#   1. AddressSanitizer + UBSan: the oracle; the product's host-side rule builder and the kernels' transition code built for the host.
+#   2. ThreadSanitizer, then AddressSanitizer + UBSan: the product's HOST-SIDE LOGIC (safe-grid-agents_amd/csrc/sgk_host_core.h: the
+#      step server's mailbox protocol, the hipGraph LRU, the stream pool, the trajectory-ring allocator, the C-ABI's allocation
+#      gate) against the HIP stand-in of tools/hip_standin -- tools/fuzz_host_core.cpp. The server protocol runs
+#      SGK_FUZZ_SCHEDULES random schedules per sanitizer (default 100000, split over the cores); the protocol as of ded8f2b^
+#      (before round 4's step-taken-twice fix) runs first as the known-bad control and MUST fail.
 set -e
 cd "$(dirname "$0")/.."
 T=$(mktemp -d)
@@ -77,4 +82,37 @@ int main() {
 C
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -DSGK_HOST_ONLY -Isafe-grid-agents_amd/csrc $T/rules.cpp safe-grid-agents_amd/csrc/sgk_rules.cpp safe-grid-agents_amd/csrc/sgk_host_debug.cpp -o $T/rules
 $T/rules
+
+# ---- 2. host-side logic under TSan and ASan ----------------------------------------------------------------------------------------
+SCHEDULES=${SGK_FUZZ_SCHEDULES:-100000}
+JOBS=$(nproc)
+FLAGS="-std=c++17 -O1 -g -fno-omit-frame-pointer -Itools/hip_standin -Isafe-grid-agents_amd/csrc tools/fuzz_host_core.cpp -lpthread"
+g++ -fsanitize=thread $FLAGS -o $T/fuzz_tsan
+g++ -fsanitize=address,undefined -fno-sanitize-recover=undefined $FLAGS -o $T/fuzz_asan
+echo "--- known-bad control: the step-server protocol as of ded8f2b^ must fail the fuzzer"
+t0=$(date +%s%N)
+if $T/fuzz_asan server --protocol prefix --schedules 100000 --seconds 60 > $T/control.log 2>&1; then
+  cat $T/control.log; echo "the pre-fix protocol SURVIVED the fuzzer: the fuzzer is blind"; exit 1
+fi
+grep -E "FAILED|server protocol" $T/control.log | head -3
+echo "control failed as it must, after $(( ($(date +%s%N) - t0) / 1000000 )) ms"
+for san in tsan asan; do
+  echo "--- $san: step-server protocol (HEAD), $SCHEDULES schedules over $JOBS processes"
+  per=$(( (SCHEDULES + JOBS - 1) / JOBS ))
+  pids=""
+  for j in $(seq 0 $((JOBS - 1))); do
+    TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1" ASAN_OPTIONS="detect_leaks=1" \
+      $T/fuzz_$san server --schedules $per --seed $(( 1 + j * per )) > $T/server_${san}_$j.log 2>&1 &
+    pids="$pids $!"
+  done
+  rc=0
+  for p in $pids; do wait $p || rc=1; done
+  cat $T/server_${san}_*.log | grep -E "^server protocol|^ok|FAILED|WARNING|ERROR" | sort | uniq -c | sort -rn | head -20
+  if [ $rc -ne 0 ]; then cat $T/server_${san}_*.log | head -120; exit 1; fi
+  echo "--- $san: graph LRU, stream pool, ring allocator"
+  TSAN_OPTIONS="halt_on_error=1" ASAN_OPTIONS="detect_leaks=0" $T/fuzz_$san graphs --rounds 3000
+  TSAN_OPTIONS="halt_on_error=1" ASAN_OPTIONS="detect_leaks=0" $T/fuzz_$san streams --rounds 30000
+  TSAN_OPTIONS="halt_on_error=1" ASAN_OPTIONS="detect_leaks=1" $T/fuzz_$san rings --rounds 20000
+done
+echo "sanitize_cpu: all clean"
 rm -rf $T
