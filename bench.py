@@ -25,7 +25,7 @@ What is timed -- `--path`:
 The default run reports the other two as secondary objects (`rewritten_in_place`, `per_step_launches`) and the outputs-once
 kernel (`fused_rollout`: no per-step output exists), each with its own counter-based traffic figures.
 The ring's rate differs from allocation to allocation of the 3 GB, so the primary measurement is made
-`--rings` times (default 3), each on a FRESH ring of the same backing (the library's ring allocator `sgk_ring_alloc`: one virtual
+`--rings` times (default 5: 15 GB of the 288), each on a FRESH ring of the same backing (the library's ring allocator `sgk_ring_alloc`: one virtual
 range mapped from 256 MiB physical chunks; `--ring-backing torch` for plain blocks), earlier rings held while the next is timed:
 `value` is the MEDIAN ring's whole-job rate, `value_min` / `value_max` and `primary_rings` give the spread, and every ring
 is also timed with the library's store-only probe (`sgk_ring_probe`: the kernel's stores and nothing else) so that
@@ -468,7 +468,15 @@ def run_config(args):
         env = S.BatchedGridworldEnv(name, n, device=dev, seed=args.seed)
         agent = S.BatchedTabularQAgent(env, targs)
         agent.rollout(200)
-        dt = ev_time(env, lambda: agent.rollout(1000), 3) / 1000
+        steps_per_launch = 1000
+        dt = ev_time(env, lambda: agent.rollout(steps_per_launch), 3) / steps_per_launch
+        # the per-launch fixed cost (table load + store), from two launch lengths: t(K) = fixed + K * marginal
+        per_launch_us = {}
+        for K in (250, 500, 1000, 2000):
+            per_launch_us[str(K)] = ev_time(env, lambda: agent.rollout(K), 3) * 1e6 / K
+        marginal_us = (per_launch_us["2000"] * 2000 - per_launch_us["500"] * 500) / 1500.0
+        fixed_us = per_launch_us["500"] * 500 - marginal_us * 500
+        table_mb = n * agent.n_states * 4 * 8 / 1e6
         peak1 = S._lib.issue_peak(dev, 1)  # the kernel's residency: its Q image leaves room for ONE wave per SIMD
         peak8 = S._lib.issue_peak(dev, 8)
         kpath = os.path.join(ROOT, "profiles", "issue.json")
@@ -477,11 +485,19 @@ def run_config(args):
         if k:
             wave_steps = (n / 64.0) / dt
             valu = k["valu_per_wave_step"] * wave_steps
-            roof = {"bound": "valu-issue", "achieved": valu / 1e9, "peak": peak1[0] / 1e9, "unit": "G wave-instructions/s",
-                    "frac": valu / peak1[0], "peak_is": "sgk_issue_peak at 1 wave per SIMD, this process (what the LDS-resident Q image allows: "
-                    "4 waves of 64 agents per CU)", "frac_of_8_waves_per_simd_peak": valu / peak8[0], "peak_8_waves_per_simd": peak8[0] / 1e9,
+            # frac: against what the CHIP can issue (8 waves per SIMD), measured in this process. The kernel's own residency -- ONE
+            # wave per SIMD, all its 40 KB Q image per 64 agents leaves room for -- is the design's choice, not the chip's limit:
+            # the figure against that ceiling is kept beside it as frac_at_kernel_occupancy.
+            roof = {"bound": "valu-issue", "achieved": valu / 1e9, "peak": peak8[0] / 1e9, "unit": "G wave-instructions/s",
+                    "frac": valu / peak8[0], "peak_is": "sgk_issue_peak at 8 waves per SIMD, this process (the chip's VALU issue rate)",
+                    "frac_at_kernel_occupancy": valu / peak1[0], "peak_at_kernel_occupancy": peak1[0] / 1e9,
+                    "kernel_occupancy": "1 wave per SIMD: the LDS-resident Q image (40 960 B per 64 agents) allows 4 waves per CU",
                     "valu_per_wave_step": k["valu_per_wave_step"], "salu_per_wave_step": k["salu_per_wave_step"],
                     "lds_per_wave_step": k.get("lds_per_wave_step"), "source": k.get("source"), "kernel": "sgk::tabq_rollout_kernel<2>",
+                    "steps_per_launch": steps_per_launch, "us_per_step_in_a_launch_of": per_launch_us,
+                    "fixed_us_per_launch": fixed_us, "marginal_us_per_step": marginal_us,
+                    "fixed_cost_is": "loading every agent's table into LDS at entry and storing it at exit: %.0f MB in + %.0f MB out per launch"
+                                     % (table_mb, table_mb),
                     "survey_8d_bytes_per_agent_step": 196, "survey_8d_gbs": 196 * n / dt / 1e9,
                     "note": "tables resident in LDS: no HBM traffic per step (8(d)'s 196 B per agent-step would be %.1f TB/s)" % (196 * n / dt / 1e12)}
         out.update({"workload": "IslandNavigation + tabular-q, 262 144 private agents, fused LDS-resident rollout (1000 steps per launch)",
@@ -505,26 +521,81 @@ def run_config(args):
             dq.act_rollout(1000, epsilon=0.01)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3000
-        for _ in range(20):
-            dq.step(learn=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(300):
-            dq.step(learn=True)
-        torch.cuda.synchronize()
-        dt_learn = (time.perf_counter() - t0) / 300
+        def wall(fn, reps, warm=20):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps
+
+        # with learning: one lockstep iteration of dqn_learn for all envs = {replay.store(states), forward + act_explore,
+        # env.step, replay.store(successors ...), ONE SGD step (sgk_dqn_sgd_step), reset_done}. Eager (six library calls from
+        # Python) and replayed from one hipGraph; then each piece alone, back to back on the device (HIP events), so that
+        # what the pieces do not add up to is the host / launch time between them.
+        dt_learn = wall(lambda: dq.step(learn=True), 300)
+        dq.enable_graphs(learn=True)
+        dt_learn_graph = wall(lambda: dq.step_graphed(learn=True), 300)
+        acts = dq._actions
+        pieces = {
+            "replay_store_states": ev_time(env, lambda: dq.replay.store(env, 0), 200),
+            "forward_and_act_explore": ev_time(env, lambda: env.policy_act(dq._fw, 0.01, 0, out=acts), 200),
+            "env_step": ev_time(env, lambda: env.step(acts, auto_reset=False), 200),
+            "replay_store_successors": ev_time(env, lambda: dq.replay.store(env, 1, acts), 200),
+            "sgd_step": ev_time(env, lambda: dq.learn_batch(), 200),
+            "reset_done": ev_time(env, lambda: env.reset_done(), 200),
+        }
+        device_sum = sum(pieces.values())
+        with_learning = {
+            "us_per_lockstep_step": dt_learn_graph * 1e6, "value": n / dt_learn_graph, "how": "one hipGraph replay per lockstep step",
+            "eager_us_per_lockstep_step": dt_learn * 1e6, "eager_value": n / dt_learn,
+            "breakdown_us": {k: v * 1e6 for k, v in pieces.items()},
+            "breakdown_device_sum_us": device_sum * 1e6,
+            "acting_us": (pieces["forward_and_act_explore"] + pieces["env_step"] + pieces["reset_done"]) * 1e6,
+            "replay_store_us": (pieces["replay_store_states"] + pieces["replay_store_successors"]) * 1e6,
+            "sgd_us": pieces["sgd_step"] * 1e6,
+            "launch_and_sync_us": {"graph": (dt_learn_graph - device_sum) * 1e6, "eager": (dt_learn - device_sum) * 1e6},
+            "note": "one SGD step (batch 64, Adam amsgrad, ONE 1 024-lane workgroup: sgk::dqn_sgd_kernel) per lockstep step of all 32 768 "
+                    "envs; the reference's ratio is one SGD step per SINGLE env-step (value.py:113-117). Each piece is timed alone, "
+                    "200 launches back to back, so a piece is one launch boundary (~2 us) long at least."}
         nc = env.n_cells
         flops = 2.0 * (nc * nh + nh * nh + nh * 4)  # useful multiply-adds of one forward, x 2
         tf = flops * n / dt / 1e12
         out.update({"workload": "SideEffectsSokoban + deep-q (the reference's MLP %d-%d-%d-4, fp32), 32 768 envs: acting with frozen weights, "
                                 "1000 x {forward + eps-greedy + env.step + auto-reset} per launch (sgk_policy_rollout)" % (nc, nh, nh),
-                    "metric": "env-steps/s", "unit": "env-steps/s", "value": n / dt, "us_per_lockstep_step": dt * 1e6, "dtype": "f32",
+                    "metric": "env-steps/s", "unit": "env-steps/s", "value": n / dt, "acting_only": True,
+                    "value_with_learning": n / dt_learn_graph, "us_per_lockstep_step": dt * 1e6, "dtype": "f32",
+                    "q_body": "mlp (the reference's DeepQAgent, value.py:148-158; BASELINE.json's wording 'conv policy' has no counterpart "
+                              "in the reference's deep-q: the conv body below is a labelled non-parity option)",
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                  "useful_flops_per_env_step": flops, "kernel": "sgk::policy_rollout_kernel",
                                  "note": "useful multiply-adds only (the kernel pads the hidden width to MFMA tiles)"},
-                    "with_learning": {"us_per_lockstep_step": dt_learn * 1e6, "value": n / dt_learn,
-                                      "note": "one SGD step (batch 64, Adam amsgrad, fused kernel) per lockstep step of all 32 768 envs; the "
-                                              "reference's ratio is one SGD step per SINGLE env-step (value.py:113-117)"}})
+                    "with_learning": with_learning})
+        dq = None
+        # the conv Q-body (policy_cnn.py:17-81's trunk with a Q head; PyTorch / MIOpen): NOT the reference's deep-q, no parity claim
+        try:
+            cq = S.BatchedDeepQAgent(env, dargs, sgd_steps=1, replay_slices=8, q_body="cnn")
+            cq.warmup(8)
+            dt_cnn_act = wall(lambda: cq.step(learn=False), 100, warm=10)
+            dt_cnn_learn = wall(lambda: cq.step(learn=True), 100, warm=10)
+            cnn = {"q_body": "cnn", "parity": "none (not the reference's DeepQAgent)", "n_channels": cq.n_channels,
+                   "acting": {"us_per_lockstep_step": dt_cnn_act * 1e6, "value": n / dt_cnn_act,
+                              "how": "eager: obs cast, torch conv forward on all 32 768 boards, sgk_epsilon_greedy, sgk_step, reset_done"},
+                   "acting_plus_sgd": {"us_per_lockstep_step": dt_cnn_learn * 1e6, "value": n / dt_cnn_learn,
+                                       "how": "the same + two replay stores + one torch autograd SGD step (batch 64, Adam amsgrad fused)"}}
+            try:
+                cq.enable_graphs(learn=False)
+                dt_cnn_act_g = wall(lambda: cq.step_graphed(learn=False), 100, warm=10)
+                cnn["acting"]["graph_us_per_lockstep_step"] = dt_cnn_act_g * 1e6
+                cnn["acting"]["graph_value"] = n / dt_cnn_act_g
+            except Exception as exc:  # noqa: BLE001 -- a labelled extra: its failure must not cost the config's line
+                cnn["acting"]["graph_error"] = repr(exc)[:200]
+            out["conv_q_body_non_parity"] = cnn
+            cq = None
+        except Exception as exc:  # noqa: BLE001
+            out["conv_q_body_non_parity"] = {"error": repr(exc)[:300]}
         env.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_mlp(name, args.seed, nh)
@@ -556,7 +627,7 @@ def main():
     ap.add_argument("--ring-backing", choices=("ring", "torch"), default="ring",
                     help="memory of the PRIMARY trajectory ring: the library's ring allocator (sgk_ring_alloc: HIP virtual memory "
                          "management, 256 MiB physical chunks) or a plain torch.empty block")
-    ap.add_argument("--rings", type=int, default=3,
+    ap.add_argument("--rings", type=int, default=5,
                     help="how many fresh primary rings the timed region is repeated on (value = the median ring; path ring only)")
     ap.add_argument("--no-weak-line", action="store_true", help="skip the secondary 1M-envs-per-GPU measurement at N > 1")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
@@ -646,6 +717,7 @@ def run_rank(args):
                                 layout=args.layout)
     stream = env.torch_stream()
     comm = sdist.library_comm(env)  # the RCCL communicator of the metrics all-reduce is made HERE (N > 1), not inside a timed region
+    sdist.require_library_comm(comm, world, backend)  # N > 1 over RCCL never passes on torch.distributed's all-reduce unnoticed
     rccl_ranks = sdist.library_comm_ranks(env) if comm is not None else None
     L = max(1, args.lockstep_per_step)
     k_lock, w_lock = args.steps * L, args.warmup * L  # the timed region / the warm-up in lockstep steps

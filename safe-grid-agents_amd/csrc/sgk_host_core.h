@@ -394,6 +394,10 @@ struct ServerLink {
   // server that ends while the host is consuming an EARLIER server's late word was never waited for.)
   uint64_t launched = 0, exit_words = 0;
   bool words_owed() const { return exit_words < launched; }
+  // Words the bounded wait has already given up on once (two words that landed on top of each other count as one: the missing one
+  // never comes). They stay owed -- the mailbox is never freed -- but are not waited for again: a link in that state would otherwise
+  // pay the full bounded wait at every stop.
+  uint64_t given_up = 0;
   // how long the waits below spin before they give up (the sanitizer harness shortens them)
   uint32_t exit_word_spins = 1u << 22;
   uint64_t stream_check_mask = (1ull << 20) - 1;  // the stream is asked every (mask + 1) spins (a power of two)
@@ -410,14 +414,16 @@ inline bool take_exit_word(ServerLink &L) {
   if (mb_load(&L.mb->exited) == 0) return false;
   if (__atomic_exchange_n(const_cast<uint32_t *>(&L.mb->exited), 0u, __ATOMIC_ACQ_REL) == 0) return false;
   ++L.exit_words;
+  if (L.given_up > L.launched - L.exit_words) L.given_up = L.launched > L.exit_words ? L.launched - L.exit_words : 0;  // one came after all
   return true;
 }
 // The stream is idle: every server launched so far has ended and written its word. See them all, bounded (a stream in error has
 // no server to wait for; two words that landed on top of each other count as one: the link then stays "owed" for good, which
-// costs one mailbox that is never freed, never a write into freed memory).
+// costs one mailbox that is never freed and ONE expired wait, never a write into freed memory).
 inline void collect_exit_words(ServerLink &L) {
-  for (uint32_t spin = 0; L.words_owed() && spin < L.exit_word_spins; ++spin)
+  for (uint32_t spin = 0; L.exit_words + L.given_up < L.launched && spin < L.exit_word_spins; ++spin)
     if (!take_exit_word(L)) cpu_pause();
+  if (L.exit_words + L.given_up < L.launched) L.given_up = L.launched - L.exit_words;
 }
 
 // Ask the step server to leave and wait until it has: afterwards the handle's arrays in memory are current (state words, metric

@@ -159,6 +159,22 @@ def library_comm(env):
     return comm
 
 
+def require_library_comm(comm, world, backend):
+    """A multi-GPU run over RCCL must use the LIBRARY's communicator (sgk_comm_create / sgk_metrics_allreduced): a silent fall back to
+    torch.distributed's all-reduce would let a first 8-GPU run pass without ever executing the C-ABI's collective. Raises when there
+    is more than one rank on an RCCL-backed process group and `comm` (library_comm's result) is None -- unless the caller asked for
+    torch's path with SGK_METRICS_COLLECTIVE=torch. SGK_BENCH_REQUIRE_RCCL=1 applies the rule whatever the backend (the tests'
+    way to reach this exit on a one-GPU box, where two ranks can only talk over gloo)."""
+    forced = os.environ.get("SGK_BENCH_REQUIRE_RCCL") == "1"
+    if comm is not None or world <= 1 or (backend != "nccl" and not forced):
+        return
+    if os.environ.get("SGK_METRICS_COLLECTIVE", "sgk") == "torch":
+        return
+    raise RuntimeError("the library's RCCL communicator could not be made (sgk_comm_create; see the message above) and the metrics "
+                       "all-reduce would go through torch.distributed instead: refusing to report a multi-GPU line that never ran "
+                       "sgk_metrics_allreduced. Set SGK_METRICS_COLLECTIVE=torch to accept torch.distributed's all-reduce.")
+
+
 def library_comm_ranks(env):
     """How many ranks the library's RCCL communicator of this process spans (RCCL's own ncclCommCount through sgk_comm_info),
     or None when the metrics go through torch.distributed / there is one rank."""

@@ -18,7 +18,7 @@ SGK_BENCH_BACKEND=gloo SGK_BENCH_ONE_DEVICE=1 timeout 900 python bench.py --gpus
 bash tools/gpu_configs.sh ${T}_final > $O/gpu_configs.out 2>&1; tail -12 $O/gpu_configs.out | cut -c1-300
 bash tools/gpu_pmc_tabq.sh ${T}_final final > $O/gpu_pmc_tabq.out 2>&1; tail -4 $O/gpu_pmc_tabq.out | cut -c1-300
 timeout 900 python tools/bench_configs.py > $O/configs_1_to_5.log 2>&1
-timeout 900 python tools/bench_stream.py --envs BoatRace-v0 --sizes 1024,4096,16384,65536,262144,1048576 --ring 100 > $O/batch_sweep_1k_to_1m.log 2>&1
+timeout 900 python tools/bench_stream.py --envs BoatRace-v0 --sizes 1024,4096,16384,65536,131072,262144,524288,1048576 --ring 100 > $O/batch_sweep_1k_to_1m.log 2>&1
 timeout 900 python tools/bench_stream.py --envs BoatRace-v0,IslandNavigation-v0,SideEffectsSokoban-v0,DistributionalShift-v0,WhiskyGold-v0,AbsentSupervisor-v0,SafeInterruptibility-v0,ConveyorBelt-v0,TomatoWatering-v0,FriendFoe-v0 --ring 100 > $O/stream_all_envs.log 2>&1
 timeout 600 python tools/bench_single_env.py > $O/single_env.log 2>&1
 SGK_STEP_SERVER=0 timeout 600 python tools/bench_single_env.py > $O/single_env_launch_per_step.log 2>&1
@@ -27,6 +27,13 @@ export SGK_NO_BUILD=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-fused --sustain-seconds 0 > $O/bench_under_rocprof.log 2>&1
 for f in $(find $O/prof -name "*kernel_stats.csv"); do head -6 $f | cut -c1-200; cp $f $O/bench_kernel_stats.csv; done
 rm -rf $O/prof
+# config 2's kernel (one step_kernel launch per lockstep step) and config 4's learner (dqn_sgd_kernel) under the kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof2 -- python3 bench.py --config 2 --no-cpu-baseline > $O/config2_under_rocprof.log 2>&1
+for f in $(find $O/prof2 -name "*kernel_stats.csv"); do head -4 $f | cut -c1-200; cp $f $O/config2_kernel_stats.csv; done
+rm -rf $O/prof2
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof4 -- python3 tools/prof_deepq_learn.py > $O/dqn_learn_under_rocprof.log 2>&1
+for f in $(find $O/prof4 -name "*kernel_stats.csv"); do head -12 $f | cut -c1-200; cp $f $O/dqn_learn_kernel_stats.csv; done
+rm -rf $O/prof4
 if [ "$2" = "pmc" ]; then
   for n in 1048576 524288 262144 131072; do for mode in ring stream launch; do for ctr in FETCH_SIZE WRITE_SIZE; do
     tag=$([ $n = 1048576 ] && echo "" || echo "_n$n")
