@@ -548,25 +548,30 @@ def run_config(args):
             "reset_done": ev_time(env, lambda: env.reset_done(), 200),
         }
         device_sum = sum(pieces.values())
+        dt_best = min(dt_learn, dt_learn_graph)
         with_learning = {
-            "us_per_lockstep_step": dt_learn_graph * 1e6, "value": n / dt_learn_graph, "how": "one hipGraph replay per lockstep step",
+            "us_per_lockstep_step": dt_best * 1e6, "value": n / dt_best,
+            "how": "six library calls per lockstep step from Python" if dt_learn <= dt_learn_graph else "one hipGraph replay per lockstep step",
             "eager_us_per_lockstep_step": dt_learn * 1e6, "eager_value": n / dt_learn,
+            "graph_us_per_lockstep_step": dt_learn_graph * 1e6, "graph_value": n / dt_learn_graph,
             "breakdown_us": {k: v * 1e6 for k, v in pieces.items()},
             "breakdown_device_sum_us": device_sum * 1e6,
             "acting_us": (pieces["forward_and_act_explore"] + pieces["env_step"] + pieces["reset_done"]) * 1e6,
             "replay_store_us": (pieces["replay_store_states"] + pieces["replay_store_successors"]) * 1e6,
             "sgd_us": pieces["sgd_step"] * 1e6,
-            "launch_and_sync_us": {"graph": (dt_learn_graph - device_sum) * 1e6, "eager": (dt_learn - device_sum) * 1e6},
-            "note": "one SGD step (batch 64, Adam amsgrad, ONE 1 024-lane workgroup: sgk::dqn_sgd_kernel) per lockstep step of all 32 768 "
-                    "envs; the reference's ratio is one SGD step per SINGLE env-step (value.py:113-117). Each piece is timed alone, "
-                    "200 launches back to back, so a piece is one launch boundary (~2 us) long at least."}
+            "whole_step_minus_pieces_us": {"graph": (dt_learn_graph - device_sum) * 1e6, "eager": (dt_learn - device_sum) * 1e6},
+            "note": "one SGD step (batch 64, Adam amsgrad, ONE 1 024-lane workgroup: sgk::dqn_sgd_kernel, 41 us by the kernel trace: "
+                    "profiles/r05/dqn_learn_kernel_stats.csv) per lockstep step of all 32 768 envs; the reference's ratio is one SGD step per "
+                    "SINGLE env-step (value.py:113-117). Each piece is timed alone, 200 calls back to back from Python: a piece reads "
+                    "max(its kernel, one Python call ~ 5 us), so the pieces can add up to MORE than the whole step, whose calls overlap "
+                    "the previous kernels (whole_step_minus_pieces_us < 0)."}
         nc = env.n_cells
         flops = 2.0 * (nc * nh + nh * nh + nh * 4)  # useful multiply-adds of one forward, x 2
         tf = flops * n / dt / 1e12
         out.update({"workload": "SideEffectsSokoban + deep-q (the reference's MLP %d-%d-%d-4, fp32), 32 768 envs: acting with frozen weights, "
                                 "1000 x {forward + eps-greedy + env.step + auto-reset} per launch (sgk_policy_rollout)" % (nc, nh, nh),
                     "metric": "env-steps/s", "unit": "env-steps/s", "value": n / dt, "acting_only": True,
-                    "value_with_learning": n / dt_learn_graph, "us_per_lockstep_step": dt * 1e6, "dtype": "f32",
+                    "value_with_learning": n / dt_best, "us_per_lockstep_step": dt * 1e6, "dtype": "f32",
                     "q_body": "mlp (the reference's DeepQAgent, value.py:148-158; BASELINE.json's wording 'conv policy' has no counterpart "
                               "in the reference's deep-q: the conv body below is a labelled non-parity option)",
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
@@ -719,6 +724,8 @@ def run_rank(args):
     comm = sdist.library_comm(env)  # the RCCL communicator of the metrics all-reduce is made HERE (N > 1), not inside a timed region
     sdist.require_library_comm(comm, world, backend)  # N > 1 over RCCL never passes on torch.distributed's all-reduce unnoticed
     rccl_ranks = sdist.library_comm_ranks(env) if comm is not None else None
+    if comm is not None:
+        sdist.global_metrics(env)  # the communicator's FIRST collective (RCCL sets its channels up in it) happens here, outside every clock
     L = max(1, args.lockstep_per_step)
     k_lock, w_lock = args.steps * L, args.warmup * L  # the timed region / the warm-up in lockstep steps
     gpu_leg_ms = 0.0

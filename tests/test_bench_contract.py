@@ -96,7 +96,7 @@ def _check_contract(d, n_gpus, steps, warmup):
     # `value` is the median of the primary rings of THIS run; every fraction of the line follows from numbers inside the line
     pr = d["primary_rings"]
     assert d["value_min"] <= d["value"] <= d["value_max"] and sum(1 for p in pr if p["median"]) == 1
-    assert len(pr) == (3 if path == "ring" else 1) and [p for p in pr if p["median"]][0]["value"] == d["value"]
+    assert len(pr) == (5 if path == "ring" else 1) and [p for p in pr if p["median"]][0]["value"] == d["value"]
     assert sorted(p["value"] for p in pr)[(len(pr) - 1) // 2] == d["value"]
     if path == "ring":
         assert all(p["store_only_probe_us_per_step"] > 0 and p["kernel_over_probe"] > 0 and 0 < p["frac"] for p in pr)
@@ -217,7 +217,7 @@ def test_bench_config_objects_carry_their_own_roofline_and_cpu_baseline(k):
         assert abs(r["achieved"] - r["useful_flops_per_env_step"] * d["value"] / 1e12) <= 1e-6 * r["achieved"] and r["peak"] == 157.3
         assert d["acting_only"] is True and 0 < d["value_with_learning"] < d["value"]
         w = d["with_learning"]
-        assert w["value"] == d["value_with_learning"] and w["eager_value"] > 0
+        assert w["value"] == d["value_with_learning"] == max(w["eager_value"], w["graph_value"]) > 0
         b = w["breakdown_us"]
         assert set(b) == {"replay_store_states", "forward_and_act_explore", "env_step", "replay_store_successors", "sgd_step", "reset_done"}
         assert abs(w["breakdown_device_sum_us"] - sum(b.values())) < 1e-6 and abs(w["acting_us"] + w["replay_store_us"] + w["sgd_us"] - sum(b.values())) < 1e-6
