@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SGK_ABI_VERSION 2
+#define SGK_ABI_VERSION 3 /* 3: the tabular-Q tables in HBM are state-major (sgk_tabq_table_dev) */
 
 #if defined(__GNUC__)
 #define SGK_API __attribute__((visibility("default")))
@@ -79,6 +79,8 @@ extern "C" {
  *                       kernel record per launch).
  *   SGK_MAX_GRID=<n>    workgroups per launch of the grid-stride kernels (default 6 per CU; n >= 64); tools/sweep.py.
  *   SGK_STREAM_GRID=<n> workgroups per launch of the streamed rollout (default 16 per CU; n >= 64); likewise.
+ *   SGK_RING_NT=0|1     board tiles into a trajectory ring never / always as non-temporal stores (default: by ring size and slice
+ *                       count, sgk_step.hip: ring_stores_nt); the A/B knob behind profiles/r05/ring_nt_ab.log.
  *   SGK_STEP_SERVER=0   host-visible handles of <= 64 envs serve sgk_step_host with one launch per call instead of the resident
  *                       step server (the A/B of tools/bench_single_env.py).
  * The Python host adds SGK_LIB_PATH (another build of libsgk.so), SGK_NO_BUILD=1 (never start a build: set under profilers),
@@ -328,13 +330,17 @@ SGK_API int sgk_tabq_rollout(sgk_tabq *q, int64_t n_steps, int cheat);
 #define SGK_TABQ_KERNEL_LDS 1
 #define SGK_TABQ_KERNEL_HBM 2
 SGK_API int sgk_tabq_rollout_ex(sgk_tabq *q, int64_t n_steps, int cheat, int kernel);
-/* [n_envs][n_states][n_actions]. The per-step kernels (sgk_tabq_act / _learn / _learn_steps) keep a per-env copy of ONE table
+/* The tables where they live: [n_states][n_envs][n_actions] float64, STATE-major (ABI 3) -- the row of state s of agent e starts at
+ * ((s * n_envs) + e) * n_actions doubles: one lane = one agent, so a wave's 64 rows of a state are 2 KB contiguous (ABI 2 had
+ * [n_envs][n_states][n_actions]: 64 separate lines per row access of a wave). sgk_tabq_copy_table hands out the agent-major
+ * form. The per-step kernels (sgk_tabq_act / _learn / _learn_steps) keep a per-env copy of ONE table
  * row; this call invalidates those copies once. A caller that KEEPS the pointer (the zero-copy use) and writes the table through
  * it later calls sgk_tabq_invalidate_rows() after every such write, before the next per-step call. */
 SGK_API int sgk_tabq_table_dev(sgk_tabq *q, double **table_dev, int64_t *n_states, int64_t *n_actions);
 /* The table was written from outside the library (through sgk_tabq_table_dev's pointer): forget the kept rows. Cheap: a flag;
  * the re-tagging launch runs with the next per-step call. */
 SGK_API int sgk_tabq_invalidate_rows(sgk_tabq *q);
+/* agents env_begin .. env_begin + env_count - 1, agent by agent: table_host[env_count][n_states][n_actions]. Synchronises. */
 SGK_API int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, double *table_host);
 SGK_API int sgk_tabq_global_step(const sgk_tabq *q, int64_t *t_out);
 SGK_API double sgk_tabq_epsilon(double epsilon, int64_t epsilon_anneal, int64_t t); /* epsilon in force at global step t */

@@ -57,6 +57,7 @@ struct sgk_tabq {
   long long *t_dev = nullptr;  // device copy of tq.t_agent for graph replays
   bool t_dev_stale = true;
   bool rows_stale = false;     // the table was written outside the per-step kernels: their row slots must be re-tagged invalid
+  double *copy_stage = nullptr;  // pinned staging of sgk_tabq_copy_table (8 MiB, or one agent's table if that is larger)
   GraphCache graphs;           // (n_steps, cheat | flags << 1) -> captured sequence
   uint64_t graphs_seed = 0;    // the env seed the captured launches carry (sgk_set_seed after a capture drops the graphs)
 };
@@ -245,6 +246,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   }
   // the streaming rollout keeps a wave on its tile for a whole launch: up to 8 workgroups (32 waves) per CU in flight
   s.stream_grid = s.n_cus * 16;  // measured at 1 M envs: 8 per CU 3.94 us per step, 16 per CU 3.82 (profiles/r02)
+  if (const char *nt = getenv("SGK_RING_NT")) s.ring_nt_mode = nt[0] == '0' ? 0 : (nt[0] == '1' ? 1 : -1);
   if (const char *sg = getenv("SGK_STREAM_GRID")) {
     int v = atoi(sg);
     if (v >= 64) s.stream_grid = v;
@@ -1071,6 +1073,7 @@ int sgk_tabq_destroy(sgk_tabq *q) try {
   (void)hipFree(q->tq.keys);
   (void)hipFree(q->tq.hash_overflow);
   (void)hipFree(q->tq.row_cache);
+  if (q->copy_stage) (void)hipHostFree(q->copy_stage);
   (void)hipFree(q->actions);
   (void)hipFree(q->t_dev);
   delete q;
@@ -1324,10 +1327,22 @@ int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, doubl
   SGK_CHECK_HANDLE(q->env);
   if (!table_host || env_begin < 0 || env_count < 0 || env_begin + env_count > q->env->sh.n)
     return fail(SGK_ERR_INVALID, "bad range");
-  const size_t row = (size_t)q->tq.n_states * SGK_ACTIONS;
-  SGK_HIP(hipMemcpyAsync(table_host, q->tq.table + (size_t)env_begin * row, sizeof(double) * row * (size_t)env_count,
-                         hipMemcpyDeviceToHost, q->env->stream));
-  SGK_HIP(hipStreamSynchronize(q->env->stream));
+  // The table in HBM is state-major ([n_states][n][4], sgk_tabq.hip: row_of); the caller gets it agent by agent
+  // ([env_count][n_states][4]). A block of agents at a time: one strided copy of their columns of every state's plane into a
+  // pinned staging block of the handle's (8 MiB at most), transposed on the host.
+  const size_t ns = (size_t)q->tq.n_states, n = (size_t)q->env->sh.n, row_bytes = sizeof(double) * SGK_ACTIONS;
+  constexpr size_t STAGE_BYTES = (size_t)8 << 20;
+  const size_t e_max = std::max<size_t>(1, STAGE_BYTES / (ns * row_bytes));
+  if (!q->copy_stage) SGK_HIP(hipHostMalloc((void **)&q->copy_stage, std::max(STAGE_BYTES, ns * row_bytes), hipHostMallocDefault));
+  for (size_t e0 = 0; e0 < (size_t)env_count; e0 += e_max) {
+    const size_t cnt = std::min(e_max, (size_t)env_count - e0);
+    SGK_HIP(hipMemcpy2DAsync(q->copy_stage, cnt * row_bytes, q->tq.table + ((size_t)env_begin + e0) * SGK_ACTIONS, n * row_bytes,
+                             cnt * row_bytes, ns, hipMemcpyDeviceToHost, q->env->stream));
+    SGK_HIP(hipStreamSynchronize(q->env->stream));
+    for (size_t s = 0; s < ns; ++s)
+      for (size_t e = 0; e < cnt; ++e)
+        memcpy(table_host + ((e0 + e) * ns + s) * SGK_ACTIONS, q->copy_stage + (s * cnt + e) * SGK_ACTIONS, row_bytes);
+  }
   return SGK_OK;
 } SGK_CATCH_STATUS
 

@@ -21,6 +21,7 @@ struct Shard {
   int env_id = 0, layout = 0, device = 0;
   int n_cells = 0, pitch = 0, n_states = 0;
   int n_cus = 256, max_grid = 2048, stream_grid = 2048, rollout_grid = 2048;
+  int ring_nt_mode = -1;  // SGK_RING_NT: 0 / 1 = ring stores never / always non-temporal; -1 = by ring size and slices (sgk_step.hip)
   int64_t n = 0;
   uint64_t seed = 0, env_base = 0, lockstep_t = 0;
   SgkRules rules_host;
@@ -42,13 +43,13 @@ struct Shard {
 };
 
 struct TabqShard {
-  double *table = nullptr;   // [n][n_states][4] float64
+  double *table = nullptr;   // [n_states][n][4] float64, STATE-major: row (s, e) at ((s * n) + e) * 4 (sgk_tabq.hip: row_of)
   uint64_t *tags = nullptr;     // [n] low word: state index the last action was chosen from (0xffffffff = env was over);
                                 //     high word: state index of the row in row_cache (0xffffffff = none)
   double *row_cache = nullptr;  // [n][4] the Q row of the state named by the tag: what the per-step kernels hand each other
   // Levels whose boards have no perfect hash (tomato watering: 63 cells x 2^13 watered sets): every agent's table is an
   // open-addressing hash table of `hash_cap` slots (a power of two, 64 .. 2^24), keys[n][hash_cap] (0xffffffff = empty) beside the
-  // rows table[n][hash_cap][4]; a slot is claimed the first time a board is looked up -- the defaultdict of value.py:31-36.
+  // rows table[hash_cap][n][4]; a slot is claimed the first time a board is looked up -- the defaultdict of value.py:31-36.
   uint32_t *keys = nullptr;
   int32_t hash_cap = 0;          // 0: perfect-hash level
   int32_t *hash_overflow = nullptr;  // [2]: [0] set when some agent's table was full and a board found no row (it then reads zeros

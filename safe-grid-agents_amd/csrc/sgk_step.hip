@@ -737,6 +737,20 @@ hipError_t launch_rollout_random(const Shard &sh, int32_t n_steps, uint32_t flag
   return hipGetLastError();
 }
 
+// Board tiles into a trajectory ring as non-temporal write-through stores? Where the ring is larger than the Infinity Cache AND
+// has enough slices that a launch does not come back to a slice soon. Measured (round 5, BoatRace, us per lockstep step, plain /
+// non-temporal; profiles/r05/ring_nt_ab.log), by envs x slices (ring MB):
+//   1 M x 8 (243) 4.09 / 4.79    1 M x 32 (973) 4.49 / 5.02    1 M x 48 (1460) 5.78 / 5.11    1 M x 64 (1946) 6.15 / 5.51    1 M x 100 (3041) 5.80 / 5.56
+//   512 K x 16 (243) 2.26 / 2.48   512 K x 32 (487) 2.34 / 2.57   512 K x 64 (973) 3.06 / 2.58   512 K x 100 (1520) 3.15 / 2.56
+//   262 K x 32 (243) 1.18 / 1.33   262 K x 64 (487) 1.48 / 1.37   262 K x 100 (760) 1.61 / 1.38
+//   131 K x 64 (243) 0.61 / 0.64   131 K x 100 (380) 0.79 / 0.65   65 K x 100 (190) 0.48 / 0.49
+// Rounds 3-4 switched at 1.5 GB (from the 1 M-env rows alone): the per-GPU shares of a 2- / 4- / 8-GPU run (512 K / 262 K / 131 K
+// envs x 100 slices) were on the slow side of that rule by 18-22 %. SGK_RING_NT=0 / 1 (read at sgk_create) overrides the rule: the A/B knob.
+static int32_t ring_stores_nt(const Shard &sh, int64_t ring_bytes, int32_t ring_slices) {
+  if (sh.ring_nt_mode >= 0) return sh.ring_nt_mode;
+  return ring_slices >= 48 && ring_bytes > (256ll << 20);
+}
+
 hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flags, int8_t *boards_ring, uint32_t *recs_ring,
                                  int32_t ring, int32_t slice0, hipStream_t st) {
   (void)hipGetLastError();
@@ -748,7 +762,7 @@ hipError_t launch_rollout_stream(const Shard &sh, int32_t n_steps, uint32_t flag
               (int32_t)((flags & SGK_F_RING_TILE_MAJOR) != 0),
               // non-temporal only where the ring dwarfs the caches. Measured at 1 M BoatRace envs, same box, three repeats: a
               // 100-slice ring (3 GB) 6.32 vs 6.52 us per step with / without, a 32-slice ring (1 GB) 5.34 vs 4.90
-              (int32_t)((int64_t)(ring < 1 ? 1 : ring) * sh.n * (sh.n_cells + 4) > (3ll << 29))};
+              ring_stores_nt(sh, (int64_t)(ring < 1 ? 1 : ring) * sh.n * (sh.n_cells + 4), ring)};
   // (Lowering the residency to whole rounds -- 16 workgroups per CU at 4 resident instead of 3 rounds of 5 and a last one of 1 --
   // by padding the dynamic LDS was measured on a fast ring: 5.17-5.31 us per step at 2, 3, 4 and 5 per CU alike,
   // profiles/r03/stream_residency_ab.log. Not kept.)
@@ -802,7 +816,7 @@ hipError_t launch_ring_probe(const Shard &sh, int8_t *boards_ring, uint32_t *rec
   (void)hipGetLastError();
   int grid = grid_for((sh.n + WG - 1) / WG, sh.stream_grid);
   const int32_t tm = (flags & SGK_F_RING_TILE_MAJOR) != 0;
-  const int32_t nt = (int64_t)ring * sh.n * (sh.n_cells + 4) > (3ll << 29);  // as launch_rollout_stream decides it
+  const int32_t nt = ring_stores_nt(sh, (int64_t)ring * sh.n * (sh.n_cells + 4), ring);  // as launch_rollout_stream decides it
   SGK_DISPATCH_ENV(sh.env_id, (ring_probe_kernel<Geom<E>::NC><<<dim3(grid), dim3(WG), 0, st>>>(boards_ring, recs_ring, sh.n, ring, tm, nt)));
   return hipGetLastError();
 }

@@ -85,7 +85,7 @@ struct TabqArgs {
   int32_t *last_return, *last_perf, *n_episodes, *n_resets;
   double *aux;         // the env's float64 side state (Shard.aux)
   long long *metrics;
-  double *table;       // [n][n_states][4]
+  double *table;       // [n_states][n][4]: STATE-major (round 5) -- row_of() below
   uint64_t *tags;      // low word: state index the last action was chosen from (0xffffffff = env was over); high word: which
                        // state's row row_cache holds (0xffffffff: none)
   double *row_cache;   // [n][4] per-env copy of ONE table row, coalesced (32 B per env)
@@ -99,6 +99,13 @@ struct TabqArgs {
   int32_t cheat;
   uint32_t flags;
 };
+
+// The Q tables in HBM are STATE-major: table[state][agent][4], the 32-byte row of (state s, agent e) at ((s * n) + e) * 4 doubles.
+// One lane = one agent, so a wave's lanes sit side by side in every state's plane: the fused kernel's table load / store (each
+// agent's live rows into LDS and back, once per launch) is 64 consecutive rows = 2 KB contiguous per state instead of 64 rows
+// 0.8-41 KB apart, and the per-step kernels' row gathers share 128-byte lines between neighbours that are in the same state. (Rounds
+// 1-4 kept table[agent][state][4]: every row access of a wave was 64 separate lines.)
+__device__ __forceinline__ int64_t row_of(const int64_t n, int si, int64_t env) { return ((int64_t)si * n + env) * 4; }
 
 // Tomato watering: the board (the reference's dictionary key) shows the agent's cell and which tomatoes are watered -- or, while
 // the agent stands on the bucket, the delusion board (every cell watered), whatever the true set is. key = cell | shown set << 8
@@ -148,7 +155,7 @@ __device__ __forceinline__ void load_row(const TabqArgs &a, int64_t env, uint64_
                                          double &q3) {
   const double2 *row = ((uint32_t)(tag >> 32) == (uint32_t)si)
                            ? reinterpret_cast<const double2 *>(a.row_cache + env * 4)
-                           : reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + si) * 4);
+                           : reinterpret_cast<const double2 *>(a.table + row_of(a.n, si, env));
   const double2 q01 = row[0], q23 = row[1];
   q0 = q01.x; q1 = q01.y; q2 = q23.x; q3 = q23.y;
 }
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
     if (sn == sp) { n0 = p0; n1 = p1; n2 = p2; n3 = p3; }
     else if (sn < 0) { n0 = n1 = n2 = n3 = 0.0; }  // no row for the successor's board (full hash table): a fresh row's zeros
     else {
-      const double2 *rown = reinterpret_cast<const double2 *>(a.table + ((int64_t)env * a.n_states + sn) * 4);
+      const double2 *rown = reinterpret_cast<const double2 *>(a.table + row_of(a.n, sn, env));
       // (this scattered 32-byte read costs a whole 128-byte line: the fabric's read requests are ALL 128 bytes here --
       // TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ, none of 32 -- and a non-temporal load changes neither that nor the time for the
       // better: 15.6 -> 17.8 us per launch at 262 144 agents, profiles/r03/exp_tabq_learn_gather.log)
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
     // update is skipped)
     if (action < SGK_ACTIONS) {
       const double q_new = q_update(pick4(action, p0, p1, p2, p3), reward, v_next, a.lr, a.discount);
-      a.table[((int64_t)env * a.n_states + sp) * 4 + action] = q_new;
+      a.table[row_of(a.n, sp, env) + action] = q_new;
       if (sn == sp) {  // the agent did not move: its next row is the row just updated
         if (action == 0) n0 = q_new; else if (action == 1) n1 = q_new; else if (action == 2) n2 = q_new; else n3 = q_new;
       }
@@ -304,7 +311,6 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int32_t n_
   const SgkRules *__restrict__ Rg = a.rules;  // wave-uniform fields: scalar loads, once
   const int lane = threadIdx.x;
   const int n_live = Rg->n_live_slots, max_it = Rg->max_iterations;
-  const int S4 = a.n_states * 4;  // HBM row stride: tables are indexed by cell there
   const double rscale = Rg->reward_scale;
   const int start_slot = Rg->state_slot[Rg->start_agent];
   const int start_box = Rg->start_box, start_ext = Rg->start_ext;
@@ -331,10 +337,11 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int32_t n_
     const bool valid = env < a.n;
     // the tables' live rows -> the lane-minor LDS image: lane = agent, one 32-byte row per load pair
     {
-      const double *src = a.table + (valid ? env : env0) * (int64_t)S4;
+      const int64_t env_src = valid ? env : env0;  // (a lane past the batch's end reads its group's first agent: never written back)
       for (int r = 0; r < n_live; ++r) {
         const int cell = __builtin_amdgcn_readlane(my_cell, r);
-        const double2 v01 = reinterpret_cast<const double2 *>(src + cell * 4)[0], v23 = reinterpret_cast<const double2 *>(src + cell * 4)[1];
+        const double *src = a.table + row_of(a.n, cell, env_src);  // the wave's 64 rows of this state: 2 KB contiguous
+        const double2 v01 = reinterpret_cast<const double2 *>(src)[0], v23 = reinterpret_cast<const double2 *>(src)[1];
         Q[(r * 4 + 0) * AG + lane] = v01.x;
         Q[(r * 4 + 1) * AG + lane] = v01.y;
         Q[(r * 4 + 2) * AG + lane] = v23.x;
@@ -487,8 +494,8 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int32_t n_
       // step (row of the cell it stands on: the table in HBM -- this lane wrote nothing)
       if (valid && !live && n_steps > 0) {
         const int64_t t = t0 + n_steps - 1;
-        const double2 r01 = reinterpret_cast<const double2 *>(a.table + env * (int64_t)S4 + s.pos * 4)[0];
-        const double2 r23 = reinterpret_cast<const double2 *>(a.table + env * (int64_t)S4 + s.pos * 4)[1];
+        const double2 r01 = reinterpret_cast<const double2 *>(a.table + row_of(a.n, s.pos, env))[0];
+        const double2 r23 = reinterpret_cast<const double2 *>(a.table + row_of(a.n, s.pos, env))[1];
         int action = argmax4(r01.x, r01.y, r23.x, r23.y);
         const ExploreBlock xb = explore_block(a.seed, a.env_base + (uint64_t)env, t);
         double u;
@@ -500,11 +507,11 @@ __global__ __launch_bounds__(64) void tabq_rollout_kernel(TabqArgs a, int32_t n_
     }
     // the image back into the tables (a lane reads and writes its own column only: no barrier anywhere)
     if (live) {
-      double *dst = a.table + env * (int64_t)S4;
       for (int r = 0; r < n_live; ++r) {
         const int cell = __builtin_amdgcn_readlane(my_cell, r);
-        reinterpret_cast<double2 *>(dst + cell * 4)[0] = make_double2(Q[(r * 4 + 0) * AG + lane], Q[(r * 4 + 1) * AG + lane]);
-        reinterpret_cast<double2 *>(dst + cell * 4)[1] = make_double2(Q[(r * 4 + 2) * AG + lane], Q[(r * 4 + 3) * AG + lane]);
+        double *dst = a.table + row_of(a.n, cell, env);
+        reinterpret_cast<double2 *>(dst)[0] = make_double2(Q[(r * 4 + 0) * AG + lane], Q[(r * 4 + 1) * AG + lane]);
+        reinterpret_cast<double2 *>(dst)[1] = make_double2(Q[(r * 4 + 2) * AG + lane], Q[(r * 4 + 3) * AG + lane]);
       }
     }
   }
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
     if (valid) s = unpack_state(a.state[env]);
     load_episode_index<ENV>(s, a.n_resets, env, valid);
     const uint64_t ge = a.env_base + (uint64_t)env;
-    double *tab = a.table + (valid ? env : 0) * (int64_t)a.n_states * 4;
+    const int64_t env_tab = valid ? env : 0;  // this lane's column of every state's plane (row_of)
     AuxRegs ax;  // the env's float64 side state, in registers for the whole launch (friend or foe; dead code elsewhere)
     ax.init();
     if (HasAux<ENV>::value && valid) ax.load(a.aux + env * SGK_AUX_DOUBLES);
@@ -538,7 +545,8 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
     auto read_row = [&](int row, double &r0, double &r1, double &r2, double &r3) {
       r0 = r1 = r2 = r3 = 0.0;
       if (row >= 0) {
-        const double2 a01 = reinterpret_cast<const double2 *>(tab + row * 4)[0], a23 = reinterpret_cast<const double2 *>(tab + row * 4)[1];
+        const double2 *rp = reinterpret_cast<const double2 *>(a.table + row_of(a.n, row, env_tab));
+        const double2 a01 = rp[0], a23 = rp[1];
         r0 = a01.x; r1 = a01.y; r2 = a23.x; r3 = a23.y;
       }
     };
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(WG) void tabq_rollout_hbm_kernel(TabqArgs a, int64_
         const double reward = __dmul_rn(a.cheat ? (double)r_hid : (double)r_obs, R.reward_scale);
         const double q_sa = pick4(action, q0, q1, q2, q3);
         const double q_new = q_update(q_sa, reward, v_next, a.lr, a.discount);
-        tab[si_prev * 4 + action] = q_new;
+        a.table[row_of(a.n, si_prev, env_tab) + action] = q_new;
         if (si == si_prev) {  // refused move: the successor row is the row just updated
           if (action == 0) n0 = q_new; else if (action == 1) n1 = q_new; else if (action == 2) n2 = q_new; else n3 = q_new;
         }

@@ -211,7 +211,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError here == ABI drift; tests/test_abi.py checks every symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.sgk_abi_version() != 2:
+    if lib.sgk_abi_version() != 3:
         raise ImportError("libsgk ABI version mismatch")
     _lib = lib
     return lib

@@ -311,13 +311,15 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         _lib.check(self.lib.sgk_tabq_rollout_ex(self._h, int(n_steps), int(cheat), k))
 
     def table(self):
-        """The Q tables where they live: a float64 torch view [N, n_states, 4] over HBM (zero copy, sgk_tabq_table_dev). After
-        WRITING through a view that was obtained earlier, call invalidate_rows() before the next act / learn / learn_steps."""
+        """The Q tables where they live: a float64 torch view [N, n_states, 4] over HBM (zero copy, sgk_tabq_table_dev). The memory
+        is state-major ([n_states][N][4]: a wave's 64 agents side by side in every state's plane), so the view is a PERMUTED one
+        (not contiguous; element-wise reads and writes go through as usual). After WRITING through a view that was obtained
+        earlier, call invalidate_rows() before the next act / learn / learn_steps."""
         from .envs import _view
 
         p, ns, na = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
         _lib.check(self.lib.sgk_tabq_table_dev(self._h, ctypes.byref(p), ctypes.byref(ns), ctypes.byref(na)))
-        return _view(self, self.env.device, p.value, (self.env.n_envs, ns.value, na.value), "float64")
+        return _view(self, self.env.device, p.value, (ns.value, self.env.n_envs, na.value), "float64").permute(1, 0, 2)
 
     def invalidate_rows(self):
         """The table was written from outside (through table()): the per-step kernels forget the one row per env they keep."""

@@ -23,7 +23,7 @@ class TabqFixture:
         m = json.loads(str(z["meta"]))
         self.meta = m
         self.env, self.cheat, self.seed = m["env"], m["cheat"], m["seed"]
-        self.n, self.steps = m["n_agents"], m["steps"]
+        self.n, self.steps, self.eval_timesteps = m["n_agents"], m["steps"], m["eval_timesteps"]
         self.lr, self.discount, self.eps0, self.anneal = m["lr"], m["discount"], m["epsilon"], m["epsilon_anneal"]
         self.epsilon_used = m["epsilon_used"]  # hex f64, one per agent step (the same for every agent)
         self.agents = m["agents"]
@@ -57,6 +57,41 @@ class TabqFixture:
                     counts[k] += 1
                     maxs[k] = v if maxs[k] is None else max(maxs[k], v)
         return sums, counts, maxs
+
+
+    def eval_metrics(self):
+        """What the batch's metrics vector must hold after batched_default_eval: the reference's default_eval (eval.py:8-56) of every
+        agent -- each episode's (episode_return, get_last_performance()) as its track_metrics calls saw them."""
+        m = {"sum_return": 0, "sum_safety": 0, "sum_margin": 0, "sum_margin_pos": 0, "episodes": 0, "margin_pos_count": 0,
+             "max_return": None, "max_safety": None, "max_margin": None, "max_margin_pos": None}
+
+        def up(k, v):
+            m[k] = v if m[k] is None else max(m[k], v)
+
+        for a in self.agents:
+            assert len(a["eval_episodes"]) >= 1
+            for ret, perf in a["eval_episodes"]:
+                ret, perf = int(_num(ret)), int(_num(perf))
+                margin = ret - perf
+                m["sum_return"] += ret; m["sum_safety"] += perf; m["sum_margin"] += margin; m["episodes"] += 1
+                up("max_return", ret); up("max_safety", perf); up("max_margin", margin)
+                if margin > 0:
+                    m["sum_margin_pos"] += margin; m["margin_pos_count"] += 1
+                    up("max_margin_pos", margin)
+        return m
+
+
+def assert_eval_metrics(vec, fx, oracle_module):
+    """vec: the 16-word metrics vector after the evaluation (oracle or device)."""
+    O = oracle_module
+    want = fx.eval_metrics()
+    got = {"sum_return": vec[O.M_SUM_RETURN], "sum_safety": vec[O.M_SUM_SAFETY], "sum_margin": vec[O.M_SUM_MARGIN],
+           "sum_margin_pos": vec[O.M_SUM_MARGIN_POS], "episodes": vec[O.M_EPISODES], "margin_pos_count": vec[O.M_MARGIN_POS_COUNT],
+           "max_return": vec[O.M_MAX_RETURN], "max_safety": vec[O.M_MAX_SAFETY], "max_margin": vec[O.M_MAX_MARGIN],
+           "max_margin_pos": vec[O.M_MAX_MARGIN_POS]}
+    for k, v in want.items():
+        if v is not None:
+            assert int(got[k]) == v, (k, int(got[k]), v)
 
 
 class WarmupFixture:

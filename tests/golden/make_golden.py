@@ -465,6 +465,9 @@ def _random_action(seed, env, t):
     return (x[(t >> 4) & 3] >> (2 * (t & 15))) & 3
 
 
+EVAL_TIMESTEPS = 230  # default_eval after the training steps of the batched fixtures: at least this many greedy steps, whole episodes
+
+
 class _Budget(Exception):
     """Raised by the patched draw when the agent asks for step number `steps`: the reference loop stops there, mid-episode."""
 
@@ -576,6 +579,30 @@ def golden_batched_tabq(name, argv, n_agents, steps):
                 pass
             agent, env = captured["agent"], made[0]
             assert len(env.actions_log) == steps and len(eps_used) == steps
+            q_items_at_stop = [(key, np.array(row, dtype=np.float64)) for key, row in agent.Q.items()]  # (the evaluation below only
+            # ever adds all-zero rows: act() on a board not seen before, value.py:34-35)
+            state_at_stop = {"final_board": [int(x) for x in env._obs().ravel()],
+                             "episode_return_at_stop": RecordingWriter._num(env._env.episode_return)}
+            # ... and the reference's default_eval (eval.py:8-56) with the agent as trained so far, greedy, on the same env: whole
+            # episodes until at least EVAL_TIMESTEPS steps; every episode's (return, performance) as track_metrics sees them
+            import safe_grid_agents.common.eval as eval_mod
+            from safe_grid_agents.common.utils.meters import make_meters
+
+            tracked = []
+            orig_tm = eval_mod.track_metrics
+
+            def spy_tm(history, env_, eval=False, write=True):
+                tracked.append([RecordingWriter._num(env_._env.episode_return), RecordingWriter._num(env_._env.get_last_performance())])
+                return orig_tm(history, env_, eval=eval, write=write)
+
+            eval_mod.track_metrics = spy_tm
+            try:
+                eh = make_meters({})
+                eh["writer"], eh["period"] = RecordingWriter(), 0
+                eval_mod.default_eval(agent, env, eh, types.SimpleNamespace(eval_timesteps=EVAL_TIMESTEPS, eval_visualize_episodes=0))
+            finally:
+                eval_mod.track_metrics = orig_tm
+            eval_calls = [c for c in eh["writer"].calls if c[0] == "scalars"]
             if eps_used_all is None:
                 eps_used_all = eps_used
             assert eps_used == eps_used_all  # a function of the agent step alone
@@ -583,14 +610,16 @@ def golden_batched_tabq(name, argv, n_agents, steps):
             for c in writers[0].calls:
                 if c[0] == "scalar" and c[1].startswith("Train/") and c[1][6:] in episodes:
                     episodes[c[1][6:]].append(c[2])
-            for key, row in agent.Q.items():
+            for key, row in q_items_at_stop:
                 q_agent.append(index)
                 q_boards.append([int(x) for x in key])
                 q_rows.append(np.asarray(row, dtype=np.float64))
-            per_agent.append({"actions": "".join(str(int(a)) for a in env.actions_log), "episodes": episodes,
-                              "final_board": [int(x) for x in env._obs().ravel()],
-                              "episode_return_at_stop": RecordingWriter._num(env._env.episode_return),
-                              "epsilon_at_stop": float(agent.epsilon).hex()})
+            per_agent.append({"actions": "".join(str(int(a)) for a in env.actions_log[:steps]), "episodes": episodes,
+                              "final_board": state_at_stop["final_board"],
+                              "episode_return_at_stop": state_at_stop["episode_return_at_stop"],
+                              "epsilon_at_stop": float(agent.epsilon).hex(),
+                              "eval_actions": "".join(str(int(a)) for a in env.actions_log[steps:]),
+                              "eval_episodes": tracked, "eval_writer_calls": eval_calls})
     finally:
         gym.make, value_mod.np, value_mod.TabularQAgent.__init__ = orig_make, orig_np, orig_init
         ref_train.SummaryWriter = orig_writer
@@ -601,7 +630,7 @@ def golden_batched_tabq(name, argv, n_agents, steps):
         for t in (0, 1, 2, 3, steps - 1):
             assert _explore_draw(int(args.seed), index, t) == O.explore_draw(int(args.seed), index, t)
     meta = {"argv": argv, "env": _made_name(args), "cheat": bool(args.cheat), "seed": int(args.seed), "n_agents": n_agents,
-            "steps": steps, "lr": args.lr, "discount": args.discount, "epsilon": args.epsilon,
+            "steps": steps, "eval_timesteps": EVAL_TIMESTEPS, "lr": args.lr, "discount": args.discount, "epsilon": args.epsilon,
             "epsilon_anneal": args.epsilon_anneal, "epsilon_used": eps_used_all, "agents": per_agent,
             "draw_probe": {"%d,%d" % (i, t): [float(_explore_draw(int(args.seed), i, t)[0]).hex(), _explore_draw(int(args.seed), i, t)[1]]
                            for i in (0, 1, n_agents - 1) for t in (0, 1, 2, 3, steps - 1)}}

@@ -18,7 +18,7 @@ def _declared():
 def test_library_is_built_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     lib = _lib.load()
-    assert lib.sgk_abi_version() == 2
+    assert lib.sgk_abi_version() == 3
 
 
 def test_every_declared_symbol_is_exported_and_bound():

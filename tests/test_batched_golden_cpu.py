@@ -57,6 +57,23 @@ def test_oracle_tabq_rollout_reproduces_the_reference_agents(name):
             assert BG.hexes(agents[i].lookup(board)) == BG.hexes(q), (i, board.tolist())
         explored += len(rows)
     assert explored == len(fx.q_agent) > fx.n
+    # default_eval (eval.py:8-56) with every agent as trained so far, in the lockstep form of batched_default_eval: eval_timesteps - 1
+    # iterations of {greedy step, reset finished envs}, then steps without reset until every env's episode has ended
+    orc.reset()
+    em = O.metrics_new()
+    max_it = 100
+
+    def greedy():
+        return np.array([agents[i].act(orc.board(i)) for i in range(fx.n)], dtype=np.uint8)
+
+    for _ in range(fx.eval_timesteps - 1):
+        orc.rollout(1, seed=fx.seed, actions=greedy()[None], auto_reset=False, metrics=em)  # (seed: the envs' own draws)
+        for i in np.nonzero(orc.field("game_over"))[0]:
+            orc.reset(int(i))
+    for _ in range(max_it):
+        orc.rollout(1, seed=fx.seed, actions=greedy()[None], auto_reset=False, metrics=em)  # (seed: the envs' own draws)
+    assert orc.field("game_over").all()
+    BG.assert_eval_metrics(em, fx, O)
     # episodes really ended inside the fixture (the loop's reset path) and exploration really fired (both branches of value.py:37)
     assert int(m[O.M_EPISODES]) >= fx.n
     greedy_only = O.tabq_rollout(O.EnvBatch(fx.env, fx.n, seed=fx.seed),

@@ -87,6 +87,25 @@ def test_fused_tabq_rollout_kernels_reproduce_the_reference_agents(name, kernel)
         agent.close(); env.close()
 
 
+@pytest.mark.parametrize("name", BG.TABQ_FIXTURES)
+def test_batched_default_eval_reproduces_the_reference_default_eval(name):
+    """default_eval (eval.py:8-56) per agent, greedy, after the fixture's training steps == batched_default_eval on the device tables:
+    every episode's return and performance as the reference's track_metrics calls saw them, aggregated like the metrics vector."""
+    from oracle import oracle as O
+
+    _torch()
+    fx = BG.TabqFixture(name)
+    env = S.BatchedGridworldEnv(fx.env, fx.n, seed=fx.seed)
+    agent = S.BatchedTabularQAgent(env, fx.args())
+    try:
+        agent.rollout(fx.steps, cheat=fx.cheat)
+        bm = S.batched_default_eval(agent, env, fx.eval_timesteps)
+        BG.assert_eval_metrics(bm.vec, fx, O)
+        assert bm.episodes == sum(len(a["eval_episodes"]) for a in fx.agents)
+    finally:
+        agent.close(); env.close()
+
+
 @pytest.mark.parametrize("how", ["calls", "graph"])
 @pytest.mark.parametrize("name", BG.TABQ_FIXTURES)
 def test_drop_in_call_sequence_reproduces_the_reference_agents(name, how):
