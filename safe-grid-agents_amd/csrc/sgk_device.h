@@ -169,6 +169,57 @@ __device__ __forceinline__ void acc_flush(const EpisodeAcc &a, long long *__rest
   }
 }
 
+// The per-step kernel's episode metrics: the lanes that finished an episode ADD THEIR OWN figures to nine wave-private LDS words
+// (ds_add / ds_max: a handful of lanes, nine instructions, nothing to wait for) and the flush reads the words back -- instead of
+// nine wavefront reductions over all 64 lanes. It matters because the flush sits on the launch's critical path, at one wave per
+// SIMD: in a level whose episodes end all the time (IslandNavigation under random actions: 7 % of the envs per step) every wave
+// runs it on every launch. Measured at 65 536 IslandNavigation envs, us per launch (tools/exp_island_step.py,
+// profiles/r05/island_step.log): every env idle 2.73; episodes ending, reductions (64-bit sums) at the end of the kernel 4.09;
+// int32 reductions issued ahead of the stores 3.78 (3.20 with the flush switched off, 0.07 of the rest being the per-env episode
+// arrays); this form 3.53 on a box that runs 0.1 slower. The two global atomics the flush ends with are NOT the cost: a variant
+// that owned its slot and used plain stores measured the same.
+struct WaveEpisodeLds {
+  int *w;  // [16] wave-private: 0 s_ret, 1 s_perf, 2 s_mpos, 3 n_eps, 4 n_pos, 5 m_ret, 6 m_perf, 7 m_margin, 8 m_mpos
+  __device__ __forceinline__ void bind(int *words) {
+    w = words;
+    const int c = threadIdx.x & 63;
+    if (c < 16) w[c] = c >= 5 ? ACC_NEG : 0;
+    __builtin_amdgcn_wave_barrier();
+  }
+  // called by every lane; the lanes whose env finished an episode on this step contribute
+  // (raw ds_add_u32 / ds_max_i32: through atomicAdd() the compiler's atomic optimiser turns every same-address atomic into a
+  // wavefront reduction plus a one-lane atomic -- the nine reductions this exists to avoid, and then some: 3.8 -> 6.0 us)
+  __device__ __forceinline__ void add(bool finished, int ret, int perf) {
+    if (finished) {
+      const int margin = ret - perf, one = 1;
+      const uint32_t base = (uint32_t)(uintptr_t)w;  // the words' LDS byte address
+      asm volatile("ds_add_u32 %0, %1\n ds_add_u32 %0, %2 offset:4\n ds_add_u32 %0, %3 offset:12\n"
+                   "ds_max_i32 %0, %1 offset:20\n ds_max_i32 %0, %2 offset:24\n ds_max_i32 %0, %4 offset:28"
+                   :: "v"(base), "v"(ret), "v"(perf), "v"(one), "v"(margin) : "memory");
+      if (margin > 0)
+        asm volatile("ds_add_u32 %0, %1 offset:8\n ds_add_u32 %0, %2 offset:16\n ds_max_i32 %0, %1 offset:32"
+                     :: "v"(base), "v"(margin), "v"(one) : "memory");
+    }
+  }
+  // all 64 lanes; the words go to the workgroup's slot of the metrics slab (one vector atomic for the sums, one for the maxima)
+  __device__ __forceinline__ void flush(long long *__restrict__ slab) const {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the raw LDS atomics above are invisible to the compiler's own counting
+    __builtin_amdgcn_wave_barrier();
+    const int c = threadIdx.x & 63;
+    const int n_eps = w[3];  // (the same word in every lane: an LDS broadcast read)
+    if (n_eps == 0) return;  // wave-uniform
+    long long *slot = slab + (size_t)(blockIdx.x % SGK_METRIC_SLOTS) * SGK_METRICS_LEN;
+    if (c < 6) {
+      const int v = c == SGK_M_SUM_RETURN ? w[0] : c == SGK_M_SUM_SAFETY ? w[1] : c == SGK_M_SUM_MARGIN ? w[0] - w[1]
+                  : c == SGK_M_SUM_MARGIN_POS ? w[2] : c == SGK_M_EPISODES ? n_eps : w[4];
+      atomicAdd((unsigned long long *)&slot[c], (unsigned long long)(long long)v);
+    } else if (c >= SGK_M_MAX_RETURN && c <= SGK_M_MAX_MARGIN_POS) {
+      const int m = w[5 + (c - SGK_M_MAX_RETURN)];
+      if (c != SGK_M_MAX_MARGIN_POS || w[4] > 0) atomicMax(&slot[c], (long long)m);
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // streaming stores for the COMPACT board tiles: written once per step, 1 KiB contiguous per wave-instruction, never read
 // back by these kernels. `sc1` buffer stores are written through and DROPPED from the XCD's L2 (MI355X_MICROARCH.md, stores

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a) {
   // wave-private images: the rule table and the board tile. No workgroup barrier in this kernel (WaveRulesLoad, sgk_device.h).
   __shared__ WaveRulesImage rules_images[WGT / 64];
   __shared__ __attribute__((aligned(16))) uint8_t tile_images[COMPACT ? WGT / 64 : 1][COMPACT ? 64 * NC : 16];
+  __shared__ int episode_words[WGT / 64][16];
   const int lane = threadIdx.x & 63, wave = wave_index();
   const int64_t n_wt = (a.n + 63) / 64;
   const int64_t wt0 = (int64_t)blockIdx.x * (WGT / 64) + wave, wstride = (int64_t)gridDim.x * (WGT / 64);
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a) {
   rules_load.commit(rules_images[wave]);
   const SgkRules &R = rules_images[wave].r;
   const uint64_t t_now = a.t + (a.t_ptr ? t_base : 0ull);
-  EpisodeAcc acc;
-  acc_init(acc);
+  WaveEpisodeLds episodes;  // the wave's episode metrics of this launch (sgk_device.h)
+  episodes.bind(episode_words[wave]);
   for (int64_t wt = wt0; wt < n_wt; wt += wstride) {
     const int64_t env = wt * 64 + lane;
     const bool valid = env < a.n;
@@ -133,7 +134,11 @@ __global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a) {
       action = act_cur & 3;
     }
     uint32_t rec;
+    EpisodeAcc acc;  // this tile's: a lane finishes at most one episode per step
+    acc_init(acc);
     step_one<ENV>(R, a, env, valid, action, s, rec, acc);
+    episodes.add(acc.n_eps != 0, acc.s_ret, acc.s_perf);
+    if (wt + wstride >= n_wt) episodes.flush(a.metrics);  // the wave's last tile: the metrics go out ahead of this tile's stores
     if (valid) {
       a.state[env] = pack_state(s);
       if (SMALL) a.rec[env] = rec;
@@ -149,7 +154,6 @@ __global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a) {
       }
     }
   }
-  acc_flush(acc, a.metrics);
 }
 
 // ------------------------------------------------------------------------------------------------

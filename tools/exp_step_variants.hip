@@ -16,7 +16,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "sgk_device.h"
+#include "sgk_step.hip"  // the product's own kernels (step_kernel<...>), for the "library kernel" rows
 
 #define CK(x)                                                                   \
   do {                                                                          \
@@ -29,9 +29,9 @@
 
 using namespace sgk;
 
-template <int KN, int WGT>
+template <int KN, int WGT, int ENV = SGK_BOAT_RACE>
 __global__ __launch_bounds__(WGT) void variant(StepArgs a) {
-  constexpr int ENV = SGK_BOAT_RACE, NC = Geom<ENV>::NC;
+  constexpr int NC = Geom<ENV>::NC;
   __shared__ WaveRulesImage rules_images[WGT / 64];
   __shared__ __attribute__((aligned(16))) uint8_t tile_images[WGT / 64][64 * NC];
   const int lane = threadIdx.x & 63, wave = wave_index();
@@ -114,7 +114,9 @@ __global__ __launch_bounds__(WGT) void variant(StepArgs a) {
   if (!(KN & 1)) acc_flush(acc, a.metrics);
 }
 
-template <int KN, int WGT>
+__global__ void bump_counter(uint64_t *ctr, uint64_t v) { *ctr += v; }  // (as sgk_step_random's graphs end: the next replay draws new actions)
+
+template <int KN, int WGT, int ENV = SGK_BOAT_RACE>
 static void run(const char *label, StepArgs a, hipStream_t st, uint64_t *t_dev) {
   const int chain = 100, reps = 30;
   const int grid = (int)((a.n + WGT - 1) / WGT);
@@ -124,8 +126,9 @@ static void run(const char *label, StepArgs a, hipStream_t st, uint64_t *t_dev) 
   for (int i = 0; i < chain; ++i) {
     a.t = (uint64_t)i;
     a.t_ptr = t_dev;
-    hipLaunchKernelGGL((variant<KN, WGT>), dim3(grid), dim3(WGT), 0, st, a);
+    hipLaunchKernelGGL((variant<KN, WGT, ENV>), dim3(grid), dim3(WGT), 0, st, a);
   }
+  hipLaunchKernelGGL(bump_counter, dim3(1), dim3(1), 0, st, t_dev, (uint64_t)chain);
   CK(hipStreamEndCapture(st, &g));
   CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   hipEvent_t e0, e1;
@@ -146,6 +149,48 @@ static void run(const char *label, StepArgs a, hipStream_t st, uint64_t *t_dev) 
   fflush(stdout);
   CK(hipGraphExecDestroy(ge));
   CK(hipGraphDestroy(g));
+}
+
+template <int ENV, bool SMALL>
+static void run_product(const char *label, StepArgs a, hipStream_t st, uint64_t *t_dev) {
+  const int chain = 100, reps = 30;
+  const int wgt = SMALL ? 64 : 256;
+  const int grid = (int)((a.n + wgt - 1) / wgt);
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+  for (int i = 0; i < chain; ++i) {
+    a.t = (uint64_t)i;
+    a.t_ptr = t_dev;
+    hipLaunchKernelGGL((sgk::step_kernel<ENV, SGK_LAYOUT_COMPACT, true, SMALL>), dim3(grid), dim3(wgt), 0, st, a);
+  }
+  hipLaunchKernelGGL(bump_counter, dim3(1), dim3(1), 0, st, t_dev, (uint64_t)chain);
+  CK(hipStreamEndCapture(st, &g));
+  CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  std::vector<float> ms;
+  for (int r = 0; r < reps + 2; ++r) {
+    CK(hipEventRecord(e0, st));
+    CK(hipGraphLaunch(ge, st));
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    float t;
+    CK(hipEventElapsedTime(&t, e0, e1));
+    if (r >= 2) ms.push_back(t);
+  }
+  std::sort(ms.begin(), ms.end());
+  printf("%-64s wg %3d  median %6.3f us  best %6.3f us per launch\n", label, wgt, ms[ms.size() / 2] * 1e3 / chain, ms[0] * 1e3 / chain);
+  fflush(stdout);
+  CK(hipGraphExecDestroy(ge));
+  CK(hipGraphDestroy(g));
+}
+
+__global__ void read_slab(const long long *slab, long long *out) {
+  long long s = 0;
+  for (int i = 0; i < SGK_METRIC_SLOTS; ++i) s += slab[(size_t)i * SGK_METRICS_LEN + SGK_M_EPISODES];
+  *out = s;
 }
 
 __global__ void init_state(uint64_t *state, int64_t n, uint64_t w) {
@@ -214,6 +259,40 @@ int main(int argc, char **argv) {
     run<64, 64>("record as a plain store", a, st, t_dev);
     run<0, 128>("product body", a, st, t_dev);
     run<0, 256>("product body (again)", a, st, t_dev);
+  }
+  // the same body on IslandNavigation (48-cell boards, episodes ending all the time under random actions): what the episode-end
+  // bookkeeping costs where it actually runs
+  {
+    SgkRules RI;
+    if (sgk_build_rules(SGK_ISLAND_NAVIGATION, &RI) != 0) return 1;
+    std::vector<uint8_t> img(SGK_RULES_DEV_BYTES, 0);
+    memcpy(img.data(), &RI, sizeof(RI));
+    for (int e = 0; e < 64; ++e) memcpy(img.data() + SGK_RULES_IMAGE_BYTES + e * RI.n_cells, RI.templ, (size_t)RI.n_cells);
+    CK(hipMemcpy(rd, img.data(), img.size(), hipMemcpyHostToDevice));
+    CK(hipFree(a.boards));
+    CK(hipMalloc(&a.boards, n_pad * RI.n_cells));
+    hipLaunchKernelGGL(init_state, dim3(256), dim3(256), 0, st, a.state, n_pad, pack_state(initial_state(RI)));
+    CK(hipStreamSynchronize(st));
+    printf("IslandNavigation, same body\n");
+    for (int pass = 0; pass < 2; ++pass) {
+      run<0, 256, SGK_ISLAND_NAVIGATION>("product body", a, st, t_dev);
+      run<0, 64, SGK_ISLAND_NAVIGATION>("product body", a, st, t_dev);
+      run<1, 256, SGK_ISLAND_NAVIGATION>("- episode bookkeeping", a, st, t_dev);
+      run<1 | 32, 256, SGK_ISLAND_NAVIGATION>("- episode bookkeeping - reset branch", a, st, t_dev);
+      run<4, 256, SGK_ISLAND_NAVIGATION>("- board tile", a, st, t_dev);
+      run<1 | 4, 256, SGK_ISLAND_NAVIGATION>("- bookkeeping - board", a, st, t_dev);
+      run<64 | 128, 64, SGK_ISLAND_NAVIGATION>("record + board tile plain", a, st, t_dev);
+      run<64 | 128 | 1, 64, SGK_ISLAND_NAVIGATION>("record + board tile plain - bookkeeping", a, st, t_dev);
+      run_product<SGK_ISLAND_NAVIGATION, true>("the library's kernel (SMALL)", a, st, t_dev);
+      run_product<SGK_ISLAND_NAVIGATION, false>("the library's kernel", a, st, t_dev);
+    }
+    long long *cnt;
+    CK(hipMalloc(&cnt, 8));
+    hipLaunchKernelGGL(read_slab, dim3(1), dim3(1), 0, st, (const long long *)a.metrics, cnt);
+    CK(hipStreamSynchronize(st));
+    long long h = 0;
+    CK(hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost));
+    printf("episodes booked in the metrics slab so far: %lld\n", h);
   }
   return 0;
 }
