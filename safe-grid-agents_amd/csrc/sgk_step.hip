@@ -534,20 +534,45 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
   const bool no_boards = (mode_flags & 4) != 0;  // state words only (the caller steps with SGK_F_NO_BOARDS)
   constexpr int NC = Geom<ENV>::NC;
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
-  __shared__ SgkRules R;
-  __shared__ CompactLds<NC> C;
-  stage_rules(R, rules);
-  SGK_TILE_DECLARE(ENV, NC, COMPACT);
+  // like step_kernel: wave-private rule table and board tile, no workgroup barrier, every load of the wave's first tile -- its
+  // state words, its mask bytes, its pieces of the table and of the blank tile -- requested before the first wait (reset_done is
+  // one of the four launches of every lockstep step of the drop-in call sequences: its latency is their latency)
+  __shared__ WaveRulesImage rules_images[WG / 64];
+  __shared__ __attribute__((aligned(16))) uint8_t tile_images[COMPACT ? WG / 64 : 1][COMPACT ? 64 * NC : 16];
   const int lane = threadIdx.x & 63, wave = wave_index();
   const int64_t n_wt = (n + 63) / 64;
-  for (int64_t wt = (int64_t)blockIdx.x * (WG / 64) + wave; wt < n_wt; wt += (int64_t)gridDim.x * (WG / 64)) {
+  const int64_t wt0 = (int64_t)blockIdx.x * (WG / 64) + wave, wstride = (int64_t)gridDim.x * (WG / 64);
+  uint64_t w_cur = 0;
+  uint8_t m_cur = 1;
+  {
+    const int64_t e0 = wt0 * 64 + lane;
+    const int64_t e0c = e0 < n ? e0 : n - 1;  // (index clamped into the batch: a wave past the last tile drops the word)
+    w_cur = state[e0c];
+    if (mask) m_cur = mask[e0c];
+  }
+  WaveRulesLoad rules_load;
+  rules_load.request(rules);
+  WaveTileLds<ENV, NC> W;
+  W.bind(tile_images[COMPACT ? wave : 0]);
+  typename WaveTileLds<ENV, NC>::Blank blank;
+  if (COMPACT) W.request_blank(blank, rules);
+  rules_load.commit(rules_images[wave]);
+  const SgkRules &R = rules_images[wave].r;
+  for (int64_t wt = wt0; wt < n_wt; wt += wstride) {
     const int64_t env = wt * 64 + lane;
     const bool valid = env < n;
+    const EnvState cur = unpack_state(w_cur);
+    const bool masked = m_cur != 0;
+    {  // the next tile's words, while this one is worked on
+      const int64_t ne = (wt + wstride) * 64 + lane;
+      const bool nv = wt + wstride < n_wt && ne < n;
+      w_cur = nv ? state[ne] : 0;
+      m_cur = (nv && mask) ? mask[ne] : (uint8_t)1;
+    }
     EnvState s = initial_state(R);
     bool hit = false;
     if (valid) {
-      EnvState cur = unpack_state(state[env]);
-      hit = (mode == 2) ? false : (mode == 1 ? (cur.over != 0) : (mask == nullptr || mask[env] != 0));
+      hit = (mode == 2) ? false : (mode == 1 ? (cur.over != 0) : (mask == nullptr || masked));
       if (hit) {
         if (HasEnvDraws<ENV>::value) {  // every reset opens a new draw sequence: the counter is the key
           s.epi = n_resets[env] + 1;
@@ -564,7 +589,10 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
     const bool all = mode == 2 || (mode == 0 && mask == nullptr);
     if (no_boards) continue;
     if (COMPACT) {
-      if (all || __ballot(hit) != 0ull) SGK_TILE_WRITE(sprite_info<ENV>(R, s), boards + wt * 64 * NC);
+      if (all || __ballot(hit) != 0ull) {
+        W.draw_from_blank(blank, R, sprite_info<ENV>(R, s));
+        W.flush(boards + wt * 64 * NC);
+      }
     } else if (valid && (all || hit)) {
       write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
     }

@@ -165,17 +165,39 @@ __device__ __forceinline__ void keep_row(const TabqArgs &a, int64_t env, double 
   slot[1] = make_double2(q2, q3);
 }
 
+// Both per-step kernels follow step_kernel's entry (sgk_step.hip): a wave-private copy of the rule table, no workgroup barrier, and
+// the first iteration's independent loads -- state word, tag, step record, action -- requested together with the table's pieces
+// before the first wait; what remains in series is the row gather, whose address needs the state. They are two of the four
+// launches of every lockstep step of the drop-in call sequence: at up to ~10^5 agents their latency IS that sequence's cost.
 template <int ENV>
 __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, uint8_t *__restrict__ actions_out) {
-  __shared__ SgkRules R;
-  stage_rules(R, a.rules);
-  const int64_t t_agent = a.t_ptr ? (int64_t)*a.t_ptr + a.t_agent : a.t_agent;
+  __shared__ WaveRulesImage rules_images[WG / 64];
+  const int wave = wave_index();
+  const int64_t env0 = (int64_t)blockIdx.x * WG + threadIdx.x, stride = (int64_t)gridDim.x * WG;
+  const long long *t_word = a.t_ptr ? a.t_ptr : reinterpret_cast<const long long *>(a.rules);
+  const long long t_base = *t_word;  // (branch-free: a null t_ptr reads a word that exists and drops it)
+  uint64_t w_cur = 0, tag_cur = 0;
+  {
+    const int64_t e0c = env0 < a.n ? env0 : a.n - 1;
+    w_cur = a.state[e0c];
+    tag_cur = a.tags[e0c];
+  }
+  WaveRulesLoad rules_load;
+  rules_load.request(a.rules);
+  rules_load.commit(rules_images[wave]);
+  const SgkRules &R = rules_images[wave].r;
+  const int64_t t_agent = a.t_agent + (a.t_ptr ? (int64_t)t_base : 0);
   const double eps = explore ? epsilon_at(a.eps0, a.anneal, t_agent) : 0.0;
-  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
-    EnvState s = unpack_state(a.state[env]);
+  for (int64_t env = env0; env < a.n; env += stride) {
+    EnvState s = unpack_state(w_cur);
+    const uint64_t tag = tag_cur;
+    if (env + stride < a.n) {  // the next iteration's words
+      w_cur = a.state[env + stride];
+      tag_cur = a.tags[env + stride];
+    }
     const int si = state_index<ENV>(R, s, a, env);
     double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-    if (si >= 0) load_row(a, env, a.tags[env], si, q0, q1, q2, q3);  // (si < 0: a full hash table has no row for this board)
+    if (si >= 0) load_row(a, env, tag, si, q0, q1, q2, q3);  // (si < 0: a full hash table has no row for this board)
     int action = argmax4(q0, q1, q2, q3);
     if (explore) {
       uint64_t ge = a.env_base + (uint64_t)env;
@@ -193,16 +215,38 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
 
 template <int ENV>
 __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_t *__restrict__ actions) {
-  __shared__ SgkRules R;
-  stage_rules(R, a.rules);
-  for (int64_t env = (int64_t)blockIdx.x * WG + threadIdx.x; env < a.n; env += (int64_t)gridDim.x * WG) {
-    const uint64_t tag = a.tags[env];
+  __shared__ WaveRulesImage rules_images[WG / 64];
+  const int wave = wave_index();
+  const int64_t env0 = (int64_t)blockIdx.x * WG + threadIdx.x, stride = (int64_t)gridDim.x * WG;
+  uint64_t w_cur = 0, tag_cur = 0;
+  uint32_t rec_cur = 0;
+  uint8_t act_cur = 0;
+  {
+    const int64_t e0c = env0 < a.n ? env0 : a.n - 1;
+    tag_cur = a.tags[e0c];
+    w_cur = a.state[e0c];
+    rec_cur = a.rec[e0c];
+    act_cur = actions[e0c];
+  }
+  WaveRulesLoad rules_load;
+  rules_load.request(a.rules);
+  rules_load.commit(rules_images[wave]);
+  const SgkRules &R = rules_images[wave].r;
+  for (int64_t env = env0; env < a.n; env += stride) {
+    const uint64_t tag = tag_cur;
+    EnvState s = unpack_state(w_cur);
+    const uint32_t rec = rec_cur;
+    const uint8_t act_in = act_cur;
+    if (env + stride < a.n) {  // the next iteration's words
+      tag_cur = a.tags[env + stride];
+      w_cur = a.state[env + stride];
+      rec_cur = a.rec[env + stride];
+      act_cur = actions[env + stride];
+    }
     const uint32_t sp_tag = (uint32_t)tag;
     if (sp_tag == 0xffffffffu) continue;
     const int sp = (int)sp_tag;
-    EnvState s = unpack_state(a.state[env]);
-    uint32_t rec = a.rec[env];
-    int action = a.cheat ? (int)(rec >> 24) : (int)(actions[env] & 3);
+    int action = a.cheat ? (int)(rec >> 24) : (int)(act_in & 3);
     // (the reward as the reference's agent receives it: the integer record times what one unit is worth -- 1.0, or tomato
     // watering's REWARD_FACTOR per watered tomato, upstream's own float64 product)
     double reward = __dmul_rn(a.cheat ? (double)(int8_t)(rec >> 8) : (double)(int8_t)rec, R.reward_scale);
