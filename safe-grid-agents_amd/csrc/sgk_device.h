@@ -180,16 +180,26 @@ __device__ __forceinline__ void acc_flush(const EpisodeAcc &a, long long *__rest
 // that owned its slot and used plain stores measured the same.
 struct WaveEpisodeLds {
   int *w;  // [16] wave-private: 0 s_ret, 1 s_perf, 2 s_mpos, 3 n_eps, 4 n_pos, 5 m_ret, 6 m_perf, 7 m_margin, 8 m_mpos
+  bool used;  // wave-uniform: some lane of this wave has finished an episode in this launch (the words are initialised then)
   __device__ __forceinline__ void bind(int *words) {
     w = words;
-    const int c = threadIdx.x & 63;
-    if (c < 16) w[c] = c >= 5 ? ACC_NEG : 0;
-    __builtin_amdgcn_wave_barrier();
+    used = false;
   }
   // called by every lane; the lanes whose env finished an episode on this step contribute
   // (raw ds_add_u32 / ds_max_i32: through atomicAdd() the compiler's atomic optimiser turns every same-address atomic into a
   // wavefront reduction plus a one-lane atomic -- the nine reductions this exists to avoid, and then some: 3.8 -> 6.0 us)
+  // A wave in which nobody finished pays one ballot and one scalar branch: in BoatRace that is 99 launches of 100 (an earlier form
+  // that initialised the words at entry and read them back in every flush cost that level 0.16 us per launch at 65 536 envs).
   __device__ __forceinline__ void add(bool finished, int ret, int perf) {
+    if (__ballot(finished) == 0ull) return;  // wave-uniform
+    if (!used) {
+      const int c = threadIdx.x & 63;
+      if (c < 16) w[c] = c >= 5 ? ACC_NEG : 0;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the raw atomics below are ordered behind these stores by issue order; the
+                                                          // wait keeps the compiler's own counting honest
+      used = true;
+    }
     if (finished) {
       const int margin = ret - perf, one = 1;
       const uint32_t base = (uint32_t)(uintptr_t)w;  // the words' LDS byte address
@@ -203,11 +213,11 @@ struct WaveEpisodeLds {
   }
   // all 64 lanes; the words go to the workgroup's slot of the metrics slab (one vector atomic for the sums, one for the maxima)
   __device__ __forceinline__ void flush(long long *__restrict__ slab) const {
+    if (!used) return;  // wave-uniform
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the raw LDS atomics above are invisible to the compiler's own counting
     __builtin_amdgcn_wave_barrier();
     const int c = threadIdx.x & 63;
     const int n_eps = w[3];  // (the same word in every lane: an LDS broadcast read)
-    if (n_eps == 0) return;  // wave-uniform
     long long *slot = slab + (size_t)(blockIdx.x % SGK_METRIC_SLOTS) * SGK_METRICS_LEN;
     if (c < 6) {
       const int v = c == SGK_M_SUM_RETURN ? w[0] : c == SGK_M_SUM_SAFETY ? w[1] : c == SGK_M_SUM_MARGIN ? w[0] - w[1]
@@ -374,6 +384,14 @@ struct WaveTileLds {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int it = 0; it < ITS; ++it) b.v[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lane + 64 * it) * 16, 0, 0);
+  }
+  // Name the blank tile's registers as used HERE: the wait for their loads then sits where the caller puts this -- before its first
+  // store. Loads and stores share one counter on gfx950 (vmcnt): a wait for these loads placed behind the step's state / record
+  // stores is also a wait for those stores' trip to memory, in the middle of the kernel.
+  __device__ __forceinline__ void blank_arrived(Blank &b) const {
+    if (ALT) return;
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) asm volatile("" : "+v"(b.v[it]));
   }
   __device__ __forceinline__ void draw_from_blank(const Blank &b, const SgkRules &R, uint32_t info) const {
     const int lane = threadIdx.x & 63;

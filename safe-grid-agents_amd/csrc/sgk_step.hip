@@ -104,22 +104,32 @@ __global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a) {
   typename WaveTileLds<ENV, NC>::Blank blank;
   if (COMPACT) W.request_blank(blank, a.rules);  // (also when the caller wants no boards: a branch here would split the batch of loads)
   rules_load.commit(rules_images[wave]);
+  if (COMPACT) W.blank_arrived(blank);  // (requested with the table's pieces, in with them: no load is left for a wait behind a store)
   const SgkRules &R = rules_images[wave].r;
   const uint64_t t_now = a.t + (a.t_ptr ? t_base : 0ull);
   WaveEpisodeLds episodes;  // the wave's episode metrics of this launch (sgk_device.h)
   episodes.bind(episode_words[wave]);
-  for (int64_t wt = wt0; wt < n_wt; wt += wstride) {
+  // A wave that has worked its last tile must LEAVE without waiting for anything: on gfx950 loads and stores share one counter, so a
+  // wait for the next tile's prefetched words is also a wait for this tile's stores to be acknowledged -- and the compiler, left to
+  // itself, put that wait in front of the loop's exit test (a launch 0.1-0.45 us longer at every size: the wave's end and the
+  // stores' trip to memory in series instead of side by side). Hence: no loop at all for SMALL (grid == tiles: one tile per wave),
+  // and for the rest the prefetched words are taken over behind the exit and behind an opaque use.
+  for (int64_t wt = wt0; wt < n_wt;) {
     const int64_t env = wt * 64 + lane;
     const bool valid = env < a.n;
     // this tile's state word was requested before the rule tables were staged / while the previous tile ran
     EnvState s = unpack_state(w_cur);
     const uint8_t act_cur = a_cur;
-    {
-      const int64_t nt = wt + wstride;
-      const int64_t ne = nt * 64 + lane;
-      const bool nv = nt < n_wt && ne < a.n;
-      w_cur = nv ? a.state[ne] : 0;
-      if (!RANDOM) a_cur = nv ? a.actions[ne] : (uint8_t)0;
+    const int64_t wt_next = wt + wstride;
+    const bool more = !SMALL && wt_next < n_wt;  // wave-uniform
+    uint64_t w_next = 0;
+    uint32_t a_next = 0;
+    if (more) {
+      const int64_t ne = wt_next * 64 + lane;
+      if (ne < a.n) {
+        w_next = a.state[ne];
+        if (!RANDOM) a_next = a.actions[ne];
+      }
     }
     if (!valid) s = initial_state(R);
     load_episode_index<ENV>(s, a.n_resets, env, valid);
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a) {
     acc_init(acc);
     step_one<ENV>(R, a, env, valid, action, s, rec, acc);
     episodes.add(acc.n_eps != 0, acc.s_ret, acc.s_perf);
-    if (wt + wstride >= n_wt) episodes.flush(a.metrics);  // the wave's last tile: the metrics go out ahead of this tile's stores
+    if (!more) episodes.flush(a.metrics);  // the wave's last tile: the metrics go out ahead of this tile's stores
     if (valid) {
       a.state[env] = pack_state(s);
       if (SMALL) a.rec[env] = rec;
@@ -153,6 +163,11 @@ __global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a) {
         write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
       }
     }
+    if (!more) break;
+    asm volatile("" : "+v"(w_next), "+v"(a_next));  // (the wait for the prefetch belongs HERE, on the way to the next tile)
+    w_cur = w_next;
+    a_cur = (uint8_t)a_next;
+    wt = wt_next;
   }
 }
 
@@ -406,7 +421,10 @@ __global__ __launch_bounds__(WG, STREAM ? STREAM_MIN_WAVES : 1) void rollout_ran
       }
       // this step's outputs, as env.step returns them: the record (reward, hidden reward, done, executed action) ...
       const uint32_t rk = pack_rec(last_obs, last_hid, last_done, last_action);
-      if (valid) *recs_p = rk;  // (plain stores: write-through dwords cost a fabric write each)
+      if (valid) {
+        if (o.recs && o.ring_nt == 2) __builtin_nontemporal_store(rk, recs_p);  // (experiment: SGK_RING_NT=2)
+        else *recs_p = rk;  // (plain stores: write-through dwords cost a fabric write each)
+      }
       // ... and the successor board: one tile store per wave wherever the destination takes whole tiles
       if (boards_on) {
         const uint32_t now = sprite_info<ENV>(R, s);
@@ -558,16 +576,23 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
   if (COMPACT) W.request_blank(blank, rules);
   rules_load.commit(rules_images[wave]);
   const SgkRules &R = rules_images[wave].r;
-  for (int64_t wt = wt0; wt < n_wt; wt += wstride) {
+  if (COMPACT) W.blank_arrived(blank);  // (every load of the wave is in before its first store goes out: one counter for both)
+  for (int64_t wt = wt0; wt < n_wt;) {
     const int64_t env = wt * 64 + lane;
     const bool valid = env < n;
     const EnvState cur = unpack_state(w_cur);
     const bool masked = m_cur != 0;
-    {  // the next tile's words, while this one is worked on
-      const int64_t ne = (wt + wstride) * 64 + lane;
-      const bool nv = wt + wstride < n_wt && ne < n;
-      w_cur = nv ? state[ne] : 0;
-      m_cur = (nv && mask) ? mask[ne] : (uint8_t)1;
+    // the next tile's words, while this one is worked on -- taken over behind the loop's exit (step_kernel has the reason)
+    const int64_t wt_next = wt + wstride;
+    const bool more = wt_next < n_wt;  // wave-uniform
+    uint64_t w_next = 0;
+    uint32_t m_next = 1;
+    if (more) {
+      const int64_t ne = wt_next * 64 + lane;
+      if (ne < n) {
+        w_next = state[ne];
+        if (mask) m_next = mask[ne];
+      }
     }
     EnvState s = initial_state(R);
     bool hit = false;
@@ -587,15 +612,21 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
     // boards: every tile when re-materialising (mode 2) or resetting everything; otherwise only the tiles (rows) a reset
     // touched -- the others already show their envs' states, and rewriting them is most of this kernel's traffic
     const bool all = mode == 2 || (mode == 0 && mask == nullptr);
-    if (no_boards) continue;
-    if (COMPACT) {
-      if (all || __ballot(hit) != 0ull) {
-        W.draw_from_blank(blank, R, sprite_info<ENV>(R, s));
-        W.flush(boards + wt * 64 * NC);
+    if (!no_boards) {
+      if (COMPACT) {
+        if (all || __ballot(hit) != 0ull) {
+          W.draw_from_blank(blank, R, sprite_info<ENV>(R, s));
+          W.flush(boards + wt * 64 * NC);
+        }
+      } else if (valid && (all || hit)) {
+        write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
       }
-    } else if (valid && (all || hit)) {
-      write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
     }
+    if (!more) break;
+    asm volatile("" : "+v"(w_next), "+v"(m_next));
+    w_cur = w_next;
+    m_cur = (uint8_t)m_next;
+    wt = wt_next;
   }
 }
 
@@ -838,7 +869,8 @@ __global__ __launch_bounds__(WG) void ring_probe_kernel(int8_t *boards, uint32_t
       }
       if (recs) {
         uint32_t *r = tile_major ? recs + (wt * (int64_t)ring + s) * 64 + lane : recs + (int64_t)s * n + wt * 64 + lane;
-        *r = 0u;
+        if (nt == 2) __builtin_nontemporal_store(0u, r);
+        else *r = 0u;
       }
     }
   }

@@ -188,12 +188,16 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
   const SgkRules &R = rules_images[wave].r;
   const int64_t t_agent = a.t_agent + (a.t_ptr ? (int64_t)t_base : 0);
   const double eps = explore ? epsilon_at(a.eps0, a.anneal, t_agent) : 0.0;
-  for (int64_t env = env0; env < a.n; env += stride) {
+  for (int64_t env = env0; env < a.n;) {
     EnvState s = unpack_state(w_cur);
     const uint64_t tag = tag_cur;
-    if (env + stride < a.n) {  // the next iteration's words
-      w_cur = a.state[env + stride];
-      tag_cur = a.tags[env + stride];
+    // the next iteration's words: requested now, taken over behind the loop's exit (a thread on its last env leaves without a wait:
+    // step_kernel, sgk_step.hip, has the reason)
+    const bool more = env + stride < a.n;
+    uint64_t w_next = 0, tag_next = 0;
+    if (more) {
+      w_next = a.state[env + stride];
+      tag_next = a.tags[env + stride];
     }
     const int si = state_index<ENV>(R, s, a, env);
     double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
@@ -210,6 +214,11 @@ __global__ __launch_bounds__(WG) void tabq_act_kernel(TabqArgs a, int explore, u
     actions_out[env] = (uint8_t)action;
     a.tags[env] = (uint64_t)((s.over || si < 0) ? 0xffffffffu : (uint32_t)si) | ((uint64_t)(uint32_t)si << 32);  // si = -1: "no row kept"
     keep_row(a, env, q0, q1, q2, q3);  // learn() reads Q[s][.] from here
+    if (!more) break;
+    asm volatile("" : "+v"(w_next), "+v"(tag_next));
+    w_cur = w_next;
+    tag_cur = tag_next;
+    env += stride;
   }
 }
 
@@ -232,19 +241,22 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
   rules_load.request(a.rules);
   rules_load.commit(rules_images[wave]);
   const SgkRules &R = rules_images[wave].r;
-  for (int64_t env = env0; env < a.n; env += stride) {
+  for (int64_t env = env0; env < a.n;) {
     const uint64_t tag = tag_cur;
     EnvState s = unpack_state(w_cur);
     const uint32_t rec = rec_cur;
     const uint8_t act_in = act_cur;
-    if (env + stride < a.n) {  // the next iteration's words
-      tag_cur = a.tags[env + stride];
-      w_cur = a.state[env + stride];
-      rec_cur = a.rec[env + stride];
-      act_cur = actions[env + stride];
+    const bool more = env + stride < a.n;  // (the next iteration's words: as in tabq_act_kernel)
+    uint64_t tag_next = 0, w_next = 0;
+    uint32_t rec_next = 0, act_next = 0;
+    if (more) {
+      tag_next = a.tags[env + stride];
+      w_next = a.state[env + stride];
+      rec_next = a.rec[env + stride];
+      act_next = actions[env + stride];
     }
     const uint32_t sp_tag = (uint32_t)tag;
-    if (sp_tag == 0xffffffffu) continue;
+    if (sp_tag != 0xffffffffu) {
     const int sp = (int)sp_tag;
     int action = a.cheat ? (int)(rec >> 24) : (int)(act_in & 3);
     // (the reward as the reference's agent receives it: the integer record times what one unit is worth -- 1.0, or tomato
@@ -277,6 +289,14 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
     }
     keep_row(a, env, n0, n1, n2, n3);  // the next act() is in s'
     a.tags[env] = (uint64_t)(uint32_t)sp | ((uint64_t)(uint32_t)sn << 32);
+    }
+    if (!more) break;
+    asm volatile("" : "+v"(tag_next), "+v"(w_next), "+v"(rec_next), "+v"(act_next));
+    tag_cur = tag_next;
+    w_cur = w_next;
+    rec_cur = rec_next;
+    act_cur = (uint8_t)act_next;
+    env += stride;
   }
 }
 
