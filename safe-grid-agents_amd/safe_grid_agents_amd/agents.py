@@ -228,7 +228,8 @@ class DeepQAgent(_EpsilonMixin, BaseActor, BaseLearner, BaseExplorer):
 
 # ---- batched tabular Q on the GPU -------------------------------------------------------------------
 class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
-    """N private TabularQAgents (one per env of a BatchedGridworldEnv), tables [N][n_states][4] float64 in HBM.
+    """N private TabularQAgents (one per env of a BatchedGridworldEnv), tables float64 in HBM, state-major: [n_states][N][4]
+    (table() / table_host() present them agent by agent, [N][n_states][4]).
 
     Same hyper-parameter names as the reference (`args.lr`, `.discount`, `.epsilon`, `.epsilon_anneal`). The
     dictionary key (flattened board) becomes a perfect-hash state index (agent cell, or agent cell x box cell);
