@@ -9,7 +9,8 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 TABQ_FIXTURES = ["batched_tabq_boat.npz", "batched_tabq_island.npz", "batched_tabq_sokoban_cheat.npz",
-                 "batched_tabq_whisky_cheat.npz"]
+                 "batched_tabq_whisky_cheat.npz", "batched_tabq_lava.npz", "batched_tabq_super.npz",
+                 "batched_tabq_interrupt_cheat.npz", "batched_tabq_belt.npz", "batched_tabq_bandit.npz", "batched_tabq_tomato.npz"]
 WARMUP_FIXTURES = ["batched_warmup_boat.npz", "batched_warmup_island.npz", "batched_warmup_sokoban.npz"]
 
 
@@ -31,6 +32,16 @@ class TabqFixture:
         self.actions = np.array([[int(c) for c in a["actions"]] for a in self.agents], dtype=np.uint8).T.copy()
         self.q_agent, self.q_boards, self.q_rows = z["q_agent"], z["q_boards"], z["q_rows"]
         self.final_boards = np.array([a["final_board"] for a in self.agents], dtype=np.int8)
+        # what one unit of the integer rewards is worth: the reference sees floats on TomatoWatering (count * REWARD_FACTOR, summed
+        # step by step), the batch counts tomatoes
+        self.scale = 0.02 if self.env == "TomatoWatering-v0" else 1.0
+
+    def units(self, v):
+        """A reference reward / return (hex float or int) in the batch's integer units."""
+        x = _num(v) / self.scale
+        r = int(round(x))
+        assert abs(x - r) < 1e-6 * max(1.0, abs(x)), (v, x)
+        return r
 
     def args(self):
         import types
@@ -50,9 +61,7 @@ class TabqFixture:
         for a in self.agents:
             for k in sums:
                 for v in a["episodes"][k]:
-                    v = _num(v)
-                    assert float(v).is_integer()
-                    v = int(v)
+                    v = self.units(v)
                     sums[k] += v
                     counts[k] += 1
                     maxs[k] = v if maxs[k] is None else max(maxs[k], v)
@@ -71,7 +80,7 @@ class TabqFixture:
         for a in self.agents:
             assert len(a["eval_episodes"]) >= 1
             for ret, perf in a["eval_episodes"]:
-                ret, perf = int(_num(ret)), int(_num(perf))
+                ret, perf = self.units(ret), self.units(perf)
                 margin = ret - perf
                 m["sum_return"] += ret; m["sum_safety"] += perf; m["sum_margin"] += margin; m["episodes"] += 1
                 up("max_return", ret); up("max_safety", perf); up("max_margin", margin)

@@ -770,6 +770,21 @@ def main():
                         ["-S", "123", "-C", "sokoban", "tabular-q", "-l", ".1", "-e", "0.1", "-dl", "1000"], 64, 1600)
     golden_batched_tabq("batched_tabq_whisky_cheat.npz",
                         ["-S", "4", "-C", "-D", "0.95", "whisky", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"], 64, 1500)
+    # ... and the other six levels: each has its own state indexing in the kernels (cell x supervisor, cell x button, cell x object, cell x
+    # room type; TomatoWatering: per-agent hash tables and rewards worth 0.02 each), its own draws and, FriendFoe, state that outlives
+    # episodes
+    golden_batched_tabq("batched_tabq_lava.npz",
+                        ["-S", "11", "-D", "0.9", "lava", "tabular-q", "-l", ".3", "-e", "0.1", "-dl", "800"], 48, 1200)
+    golden_batched_tabq("batched_tabq_super.npz",
+                        ["-S", "6", "-D", "0.95", "super", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"], 48, 1200)
+    golden_batched_tabq("batched_tabq_interrupt_cheat.npz",
+                        ["-S", "8", "-C", "-D", "0.95", "interrupt", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"], 48, 1200)
+    golden_batched_tabq("batched_tabq_belt.npz",
+                        ["-S", "9", "-D", "0.95", "belt", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"], 48, 1200)
+    golden_batched_tabq("batched_tabq_bandit.npz",
+                        ["-S", "12", "-D", "0.95", "bandit", "tabular-q", "-l", ".4", "-e", "0.2", "-dl", "600"], 48, 1000)
+    golden_batched_tabq("batched_tabq_tomato.npz",
+                        ["-S", "10", "-D", "0.95", "tomato", "tabular-q", "-l", ".4", "-e", "0.15", "-dl", "700"], 16, 900)
     golden_batched_warmup("batched_warmup_boat.npz", "BoatRace-v0", 0x5AFE, 64, 330)
     golden_batched_warmup("batched_warmup_island.npz", "IslandNavigation-v0", 9, 64, 330)
     golden_batched_warmup("batched_warmup_sokoban.npz", "SideEffectsSokoban-v0", 17, 64, 330)

@@ -47,7 +47,7 @@ def test_oracle_tabq_rollout_reproduces_the_reference_agents(name):
     bad = np.argwhere(acts != fx.actions)
     assert bad.size == 0, ("first differing (step, agent)", bad[0].tolist())
     assert (orc.boards() == fx.final_boards).all()
-    assert orc.field("episode_return").tolist() == [int(BG._num(a["episode_return_at_stop"])) for a in fx.agents]
+    assert orc.field("episode_return").tolist() == [fx.units(a["episode_return_at_stop"]) for a in fx.agents]
     assert_metrics(m, fx, fx.n * fx.steps)
     explored = 0
     for i in range(fx.n):

@@ -28,6 +28,8 @@ def _assert_tables_are_the_reference_dictionaries(env, agent, fx):
     index that board hashes to, as float64 bit patterns; and the device holds no other non-zero row."""
     from test_gpu_parity import _board_of_state
 
+    if env.name == "TomatoWatering-v0":
+        return _assert_hashed_tables_are_the_reference_dictionaries(env, agent, fx)
     tab = agent.table_host()
     index_of = {}
     for si in range(agent.n_states):
@@ -48,12 +50,41 @@ def _assert_tables_are_the_reference_dictionaries(env, agent, fx):
         assert nz <= claimed, (i, sorted(nz - claimed))
 
 
+def _assert_hashed_tables_are_the_reference_dictionaries(env, agent, fx):
+    """TomatoWatering: per-agent hash tables. Every occupied slot's key -> the board it names (rendered from the product's level tables)
+    -> that board's row in the reference agent's dictionary, bit for bit (a slot whose board the reference never looked up holds zeros);
+    and every non-zero row of the reference is found in some slot."""
+    import hostlib
+    import test_tables_cpu as TT
+
+    R = TT._rules(hostlib.load(), S.ENV_IDS[env.name])
+    cap, used, overflowed = agent.hash_info()
+    assert not overflowed and 0 < used < cap
+    keys, tab = agent.keys_host(), agent.table_host()
+    for i in range(fx.n):
+        want = {b.astype(np.int8).tobytes(): q for b, q in fx.rows_of(i)}
+        found = set()
+        for slot in np.nonzero(keys[i] != 0xFFFFFFFF)[0]:
+            key = int(keys[i, slot])
+            cell, shown = key & 0xFF, key >> 8
+            board = TT._product_board(env.name, R, cell, shown & 0x1FFF, 0).astype(np.int8).tobytes()
+            q = want.get(board)
+            if q is None:
+                assert not np.abs(tab[i, slot]).any(), (i, hex(key))
+            else:
+                assert BG.hexes(tab[i, slot]) == BG.hexes(q), (i, hex(key))
+                found.add(board)
+        missing = [b for b, q in want.items() if b not in found and np.abs(q).any()]
+        assert not missing, (i, len(missing))
+        assert not np.abs(tab[i][keys[i] == 0xFFFFFFFF]).any()  # unclaimed slots are untouched
+
+
 def _assert_final_state(env, agent, fx):
     assert agent.t == fx.steps
     assert float(agent.epsilon).hex() == fx.agents[0]["epsilon_at_stop"]
     assert (env.boards_host().reshape(fx.n, -1) == fx.final_boards).all()
     st = env.episode_state_host()
-    assert st["episode_return"].tolist() == [int(BG._num(a["episode_return_at_stop"])) for a in fx.agents]
+    assert st["episode_return"].tolist() == [fx.units(a["episode_return_at_stop"]) for a in fx.agents]
     got = env.metrics()
     for k, v in expected_metrics(fx, fx.n * fx.steps).items():
         assert int(got[k]) == v, (k, int(got[k]), v)
