@@ -246,7 +246,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   }
   // the streaming rollout keeps a wave on its tile for a whole launch: up to 8 workgroups (32 waves) per CU in flight
   s.stream_grid = s.n_cus * 16;  // measured at 1 M envs: 8 per CU 3.94 us per step, 16 per CU 3.82 (profiles/r02)
-  if (const char *nt = getenv("SGK_RING_NT")) s.ring_nt_mode = nt[0] == '0' ? 0 : (nt[0] == '1' ? 1 : (nt[0] == '2' ? 2 : -1));
+  if (const char *nt = getenv("SGK_RING_NT")) s.ring_nt_mode = nt[0] == '0' ? 0 : (nt[0] == '1' ? 1 : -1);
   if (const char *sg = getenv("SGK_STREAM_GRID")) {
     int v = atoi(sg);
     if (v >= 64) s.stream_grid = v;

@@ -421,10 +421,8 @@ __global__ __launch_bounds__(WG, STREAM ? STREAM_MIN_WAVES : 1) void rollout_ran
       }
       // this step's outputs, as env.step returns them: the record (reward, hidden reward, done, executed action) ...
       const uint32_t rk = pack_rec(last_obs, last_hid, last_done, last_action);
-      if (valid) {
-        if (o.recs && o.ring_nt == 2) __builtin_nontemporal_store(rk, recs_p);  // (experiment: SGK_RING_NT=2)
-        else *recs_p = rk;  // (plain stores: write-through dwords cost a fabric write each)
-      }
+      if (valid) *recs_p = rk;  // (plain stores: write-through dwords cost a fabric write each; non-temporal ones measure the same as
+                                // plain at 131 072 and at 1 M envs, round 5)
       // ... and the successor board: one tile store per wave wherever the destination takes whole tiles
       if (boards_on) {
         const uint32_t now = sprite_info<ENV>(R, s);
@@ -869,8 +867,7 @@ __global__ __launch_bounds__(WG) void ring_probe_kernel(int8_t *boards, uint32_t
       }
       if (recs) {
         uint32_t *r = tile_major ? recs + (wt * (int64_t)ring + s) * 64 + lane : recs + (int64_t)s * n + wt * 64 + lane;
-        if (nt == 2) __builtin_nontemporal_store(0u, r);
-        else *r = 0u;
+        *r = 0u;
       }
     }
   }
