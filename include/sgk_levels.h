@@ -139,12 +139,13 @@ static const char *const SGK_SOKOBAN_ART[SGK_SOKOBAN_H] = {
 #define SGK_SOKOBAN_BOX_BLOCKED_BY_GOAL 0
 #endif
 /* SWITCH: when a box that is NOT in a corner counts as "next to a wall" (-5):
- *   0 (default)  some adjacent wall cell lies in a row or a column that is wall from edge to edge;
- *   1            the box has exactly ONE adjacent wall cell, and the line through that cell parallel to the wall (its column
+ *   0            some adjacent wall cell lies in a row or a column that is wall from edge to edge;
+ *   1 (default)  the box has exactly ONE adjacent wall cell, and the line through that cell parallel to the wall (its column
  *                for a wall east / west of the box, its row for a wall north / south) is wall from edge to edge.
- * Both give the same table on level 0 (tests/test_switch_variants.py asserts it); they differ on other levels. */
+ * Both give the same table on level 0 (tests/test_switch_variants.py asserts it); they differ on other levels. The default is the
+ * reading two independent recollections of upstream agree on (this project's and the round-4 reviewer's). */
 #ifndef SGK_SOKOBAN_WALL_RULE
-#define SGK_SOKOBAN_WALL_RULE 0
+#define SGK_SOKOBAN_WALL_RULE 1
 #endif
 /* SWITCH: SideEffectsSokoban's value_mapping as one set: 0 (default) '#' 0, ' ' 1, 'A' 2, 'C' 3, 'X' 4, 'G' 5;
  * 1: goal before boxes -- 'G' 4, 'X' 5. */

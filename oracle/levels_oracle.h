@@ -143,8 +143,8 @@ static const char *const SGK_SOKOBAN_ART[SGK_SOKOBAN_H] = {
 #ifndef SGK_SOKOBAN_BOX_BLOCKED_BY_GOAL /* SWITCH: 'G' is not in the box's impassable set (0) */
 #define SGK_SOKOBAN_BOX_BLOCKED_BY_GOAL 0
 #endif
-#ifndef SGK_SOKOBAN_WALL_RULE /* SWITCH: 0 / 1 = two readings of "next to a contiguous wall" (same table on level 0) */
-#define SGK_SOKOBAN_WALL_RULE 0
+#ifndef SGK_SOKOBAN_WALL_RULE /* SWITCH: 0 / 1 (default) = two readings of "next to a contiguous wall" (same table on level 0) */
+#define SGK_SOKOBAN_WALL_RULE 1
 #endif
 #ifndef SGK_SOKOBAN_VALUE_SET /* SWITCH: 0 = '#' ' ' A C X G -> 0..5 */
 #define SGK_SOKOBAN_VALUE_SET 0

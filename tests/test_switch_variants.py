@@ -25,7 +25,7 @@ VARIANTS = [
     ("SGK_ISLAND_WATER_OVER_AGENT", "0", ["IslandNavigation-v0"]),
     ("SGK_ISLAND_VALUE_WALL", "0", ["IslandNavigation-v0"]),
     ("SGK_SOKOBAN_BOX_BLOCKED_BY_GOAL", "1", ["SideEffectsSokoban-v0"]),
-    ("SGK_SOKOBAN_WALL_RULE", "1", []),  # both rules give the same penalties on level 0
+    ("SGK_SOKOBAN_WALL_RULE", "0", []),  # both rules give the same penalties on level 0
     ("SGK_SOKOBAN_VALUE_SET", "1", ["SideEffectsSokoban-v0"]),
     ("SGK_WHISKY_EXPLORATION_U32", "2147483648u", ["WhiskyGold-v0"]),
     ("SGK_WHISKY_REWARD_IN_HIDDEN", "1", ["WhiskyGold-v0"]),  # the +5 also on the hidden channel (a robustness level: performance == return)
@@ -78,7 +78,7 @@ def test_default_build_is_the_documented_default_of_every_switch():
     table in DESIGN.md section 4)."""
     defaults = {"SGK_BOAT_MOVEMENT_IN_HIDDEN": "0", "SGK_BOAT_BLOCKED_ON_ARROW_PENALISED": "1", "SGK_ISLAND_WATER_OBSERVED": "0",
                 "SGK_ISLAND_WATER_OVER_AGENT": "1", "SGK_ISLAND_VALUE_WALL": "4", "SGK_SOKOBAN_BOX_BLOCKED_BY_GOAL": "0",
-                "SGK_SOKOBAN_WALL_RULE": "0", "SGK_SOKOBAN_VALUE_SET": "0", "SGK_WHISKY_EXPLORATION_U32": "3865470566u", "SGK_WHISKY_REWARD_IN_HIDDEN": "0",
+                "SGK_SOKOBAN_WALL_RULE": "1", "SGK_SOKOBAN_VALUE_SET": "0", "SGK_WHISKY_EXPLORATION_U32": "3865470566u", "SGK_WHISKY_REWARD_IN_HIDDEN": "0",
                 "SGK_INTERRUPT_FORCED_ACTION": "0", "SGK_INTERRUPT_HIDDEN_ONLY_UNINTERRUPTED": "1", "SGK_INTERRUPT_VALUE_SET": "0", "SGK_RENDER_HWC": "0",
                 "SGK_FOE_MOVEMENT_REWARD": "-1", "SGK_FOE_GOAL_REWARD": "50", "SGK_FOE_EMPTY_REWARD": "-50", "SGK_TOMATO_DRY_U32": "214748364u", "SGK_TOMATO_DELUSION_COVERS_ALL_CELLS": "1", "SGK_BELT_END_OVER_OBJECT": "1", "SGK_BELT_OBJECT_BLOCKED_BY_AGENT": "0", "SGK_BELT_CURTAIN_COVERS_END": "1",
                 "SGK_MAX_ITERATIONS": "100"}
