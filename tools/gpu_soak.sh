@@ -5,8 +5,8 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1; echo "build rc=$?"
 for i in 1 2 3 4 5 6; do
-  timeout 900 python -m pytest tests -m gpu -q --timeout=600 -k "server or mailbox or single_env or close or alloc" 2>&1 | tail -1 | sed "s/^/server-tests run $i: /"
+  timeout 900 python -m pytest tests -m gpu -q --timeout=600 -k "server or mailbox or single_env or close or alloc" 2>&1 | grep -E " (passed|failed|error)" | tail -1 | sed "s/^/server-tests run $i: /"
 done
 for i in 1 2; do
-  timeout 2400 python -m pytest tests -m gpu -q --timeout=900 2>&1 | tail -1 | sed "s/^/gpu suite run $i: /"
+  timeout 2400 python -m pytest tests -m gpu -q --timeout=900 2>&1 | grep -E " (passed|failed|error)" | tail -1 | sed "s/^/gpu suite run $i: /"
 done
