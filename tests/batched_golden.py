@@ -120,3 +120,63 @@ class WarmupFixture:
 
 def hexes(row):
     return [float(x).hex() for x in row]
+
+
+PPO_FIXTURES = ["batched_ppo_boat.npz", "batched_ppo_boat_cheat.npz", "batched_ppo_tomato.npz", "batched_ppo_island_gather.npz",
+                "batched_ppo_whisky_cheat_gather.npz"]
+
+
+class PpoFixture:
+    """tests/golden/batched_ppo_*.npz (make_golden.py:golden_batched_ppo): the reference's train() with PPOMLPAgent, rollout r of
+    every gather_rollout = the episode of env index base + r, Categorical.sample() and torch.randint answered from the batch's
+    counter RNG. Iteration k holds what gather_rollout returned (states / actions / rewards / returns [n, horizon], zero past an
+    episode's end), the old policy's logits at every step, the minibatch rows of its epochs, and the weights after its learn."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name))
+        m = json.loads(str(z["meta"]))
+        self.z, self.meta = z, m
+        self.env, self.cheat, self.seed, self.base = m["env"], m["cheat"], m["seed"], m["base"]
+        self.n, self.horizon, self.iterations, self.learn = m["n"], m["horizon"], m["iterations"], m["learn"]
+        self.eval_timesteps, self.agents = m["eval_timesteps"], m["agents"]
+        self.scale = 0.02 if self.env == "TomatoWatering-v0" else 1.0
+
+    units = TabqFixture.units
+    eval_metrics = TabqFixture.eval_metrics
+
+    def args(self, device):
+        import types
+
+        m = self.meta
+        return types.SimpleNamespace(discount=m["discount"], lr=m["lr"], batch_size=m["batch_size"], rollouts=self.n, epochs=m["epochs"],
+                                     clipping=m["clipping"], entropy_bonus=m["entropy_bonus"], critic_coeff=m["critic_coeff"],
+                                     n_layers=m["n_layers"], n_hidden=m["n_hidden"], device=device, log_gradients=False, cheat=self.cheat)
+
+    def it(self, k, what):
+        return self.z["it%d_%s" % (k, what)]
+
+    def weights(self, k):
+        """The agent's own parameters before iteration k's learn (k = iterations: at the end), keyed like its state_dict."""
+        return {key: self.z["w%d_%s" % (k, key)] for key in self.meta["weight_keys"]}
+
+    def losses(self, k):
+        """[epochs, 3] float64: policy loss, value loss, entropy of iteration k's epochs as the reference logged them."""
+        e = self.meta["epochs"]
+        rows = [c for c in self.meta["losses"] if k * e <= c[2] < (k + 1) * e]
+        out = np.zeros((e, 3))
+        for tag, v, step in rows:
+            out[step - k * e, ("Train/policy_loss", "Train/value_loss", "Train/policy_entropy").index(tag)] = _num(v)
+        return out
+
+    def gather_metrics(self, k):
+        """The metrics vector's sums / counts / maxima of iteration k's gathered episodes (track_metrics, policy_base.py:168)."""
+        m = {"sum_return": 0, "sum_safety": 0, "sum_margin": 0, "sum_margin_pos": 0, "episodes": 0, "margin_pos_count": 0}
+        for it, _, ret, perf in self.meta["episodes"]:
+            if it != k:
+                continue
+            ret, perf = self.units(ret), self.units(perf)
+            margin = ret - perf
+            m["sum_return"] += ret; m["sum_safety"] += perf; m["sum_margin"] += margin; m["episodes"] += 1
+            if margin > 0:
+                m["sum_margin_pos"] += margin; m["margin_pos_count"] += 1
+        return m

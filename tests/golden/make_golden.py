@@ -698,6 +698,284 @@ def golden_batched_warmup(name, env_name, seed, n_agents, steps):
     print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes")
 
 
+PPO_EVAL_TIMESTEPS = 150
+PPO_HORIZON = 100        # SGK_MAX_ITERATIONS: every level's episode limit = the rows of a batched rollout buffer = draws per gather
+PPO_DRAW_MARGIN = 2e-5   # no Categorical draw of a fixture lies closer than this (relative to the total weight) to an interval boundary
+PPO_DRAW_MARGIN_LATER = 2e-4  # ... and from the second iteration on (the weights then carry a learner's float32 rounding) than this
+PPO_GREEDY_GAP = 1e-4    # ... and no greedy evaluation step has its two best logits closer than this: float32 rounding cannot flip an action
+
+
+def _categorical_draw(logits, seed, env, draw):
+    """The batched path's Categorical(logits).sample() (stream 3, ctr = {env, draw, 3}): inverse CDF over float32 weights
+    exp(l - max l) with float32 partial sums, compared in double with u * total. Returns (action, margin, u)."""
+    lg = np.asarray(logits, dtype=np.float32)
+    e = np.exp(lg - lg.max(), dtype=np.float32)
+    c = np.cumsum(e, dtype=np.float32)
+    x = _block(seed, 3, env, draw)
+    u = ((x[0] >> 5) * 67108864 + (x[1] >> 6)) / 9007199254740992.0
+    target = u * float(c[3])
+    a = 3
+    for k in range(3):
+        if target < float(c[k]):
+            a = k
+            break
+    margin = min(abs(target - float(c[k])) for k in range(3)) / float(c[3])
+    return a, margin, u
+
+
+def _ppo_row(seed, b, step, lengths, horizon):
+    """Minibatch row b of the epoch that starts at Adam step `step` (stream 5): the first valid candidate (t < lengths[n]) in
+    (round, c) order; returns (t, n)."""
+    n_traj = len(lengths)
+    for rnd in range(64):
+        for c in range(16):
+            x = _block(seed, 5, (16 * b + c) | (rnd << 32), step)
+            n = (((x[0] << 32) | x[1]) * n_traj) >> 64
+            t = (x[2] * horizon) >> 32
+            if t < lengths[n]:
+                return t, n
+    return 0, 0
+
+
+class _RolloutEnv:
+    """What the reference's PPO loop sees as ONE env while the batch has N: rollout r of a gather_rollout call (policy_base.py:139-175
+    plays `rollouts` episodes one after another) is the episode of env index base + r. Every index has its own oracle env, reset as
+    often as the batched gather resets it -- once before its episode, once after (loops.batched_gather_rollout) -- so that draws
+    keyed by the reset counter agree. reset() number j of an iteration: j = 0 is train.py:64 (rollout 0 starts), j = r + 1 follows
+    rollout r (policy_base.py:174: rollout r + 1 starts; after the last one the returned board is thrown away)."""
+
+    def __init__(self, name, n, base):
+        self.name, self.n, self.base = name, n, base
+        self.envs = [OracleGridworldEnv(name) for _ in range(n)]
+        self.action_space, self.observation_space = self.envs[0].action_space, self.envs[0].observation_space
+        self.cur, self.t, self.iteration, self.j = 0, 0, -1, 0
+
+    def seed(self, seed=None):
+        from oracle import oracle as O
+
+        for i, e in enumerate(self.envs):
+            e._b = O.EnvBatch(e._b.env_id, 1, seed=int(seed) & (2**64 - 1), env_begin=self.base + i)
+        return [seed]
+
+    @property
+    def _env(self):
+        return self.envs[self.cur]._env
+
+    def reset(self):
+        j = self.j
+        self.j = (j + 1) % (self.n + 1)
+        if j == 0:
+            self.iteration += 1
+        else:
+            self.envs[j - 1].reset()  # the reset that ends the batched gather, for the env whose episode has just been played
+            if j == self.n:
+                return self.envs[j - 1]._obs()
+        self.cur, self.t = j, 0
+        return self.envs[j].reset()
+
+    def step(self, action):
+        self.t += 1
+        return self.envs[self.cur].step(action)
+
+
+class _TorchProxy:
+    """What reference policy_base.py sees as `torch`: torch, except randint."""
+
+    def __init__(self, randint):
+        self.randint = randint
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+
+def golden_batched_ppo(name, argv, base, learn=True):
+    """The reference's train() (train.py:21-81) with PPOMLPAgent: gather_rollout (policy_base.py:133-177) plays `rollouts` episodes
+    -- env index base + r each, see _RolloutEnv -- with Categorical.sample() answered from Philox stream 3's draw for (seed, env
+    index, iteration * horizon + step); learn (policy_base.py:64-131) draws its minibatches through torch.randint, answered from
+    stream 5's rows for the Adam step; sync; then the reference's default_eval (eval.py:8-56) of every index, greedy. learn=False:
+    levels whose episodes differ in length -- the reference cannot stack such rollouts (policy_base.py:66-67) -- keep only
+    the gathering (learn is skipped; every iteration gathers under the initial weights)."""
+    import warnings
+
+    import train as ref_train
+    from safe_grid_agents.parsing import prepare_parser
+    import safe_grid_agents.common.agents.policy_base as pb
+    import safe_grid_agents.common.eval as eval_mod
+    from safe_grid_agents.common.utils.meters import make_meters
+    from torch.distributions import Categorical
+
+    global _PARSER
+    if _PARSER is None:
+        _PARSER = prepare_parser()
+    args = _PARSER.parse_args(argv)
+    args.device, args.log_dir = "cpu", "unused"
+    args.eval_every = 10**9  # the evaluation happens once, at the end (train.py:81)
+    seed, n, iterations = int(args.seed), int(args.rollouts), int(args.episodes)
+    env_name = _made_name(args)
+    env = _RolloutEnv(env_name, n, base)
+    from oracle import oracle as O
+
+    horizon = PPO_HORIZON
+    gym = sys.modules["gym"]
+    rec = {"logits": [], "margins": [], "rows": [], "weights": [], "rollouts": [], "episodes": [], "randint_calls": 0}
+    captured = {}
+
+    class PhiloxCategorical(Categorical):
+        def __init__(self, probs=None, logits=None, validate_args=None):
+            self._raw = logits.detach().clone()
+            super().__init__(logits=logits)
+
+        def sample(self, sample_shape=torch.Size()):
+            assert tuple(self._raw.shape) == (1, 4)
+            raw = self._raw.numpy()[0]
+            a, margin, _ = _categorical_draw(raw, seed, base + env.cur, env.iteration * horizon + env.t)
+            rec["logits"].append((env.iteration, env.cur, env.t, raw.copy()))
+            rec["margins"].append(margin)
+            return torch.tensor([a])
+
+    def randint(high, size=None, dtype=None, **kw):
+        assert learn and high == n * horizon and tuple(size) == (args.batch_size,)
+        step = rec["randint_calls"]
+        rec["randint_calls"] += 1
+        picks = [_ppo_row(seed, b, step, [horizon] * n, horizon) for b in range(args.batch_size)]
+        rec["rows"].append([t * n + r for t, r in picks])       # the batch's flat row: t * N + env
+        return torch.tensor([r * horizon + t for t, r in picks], dtype=torch.long)  # the reference's: rollout-major
+
+    def weights_of(agent):
+        return {k: v.detach().clone().numpy() for k, v in agent.state_dict().items() if not k.startswith("old_")}
+
+    orig = {"make": gym.make, "Categorical": pb.Categorical, "torch": pb.torch, "init": pb.PPOBaseAgent.__init__,
+            "gather": pb.PPOBaseAgent.gather_rollout, "learn": pb.PPOBaseAgent.learn, "sync": pb.PPOBaseAgent.sync,
+            "writer": ref_train.SummaryWriter, "eval_map": ref_train.EVAL_MAP, "tm": pb.track_metrics}
+    writers = []
+
+    class W(RecordingWriter):
+        def __init__(self, log_dir=None):
+            super().__init__(log_dir)
+            writers.append(self)
+
+    def spy_init(self, env_, a):
+        orig["init"](self, env_, a)
+        if "agent" not in captured:  # (the deepcopy inside the constructor does not come through here)
+            captured["agent"] = self
+            rec["weights"].append(weights_of(self))
+
+    def spy_gather(self, env_, env_state, history, a):
+        ro = orig["gather"](self, env_, env_state, history, a)
+        rec["rollouts"].append(ro)
+        return ro
+
+    def spy_learn(self, states, actions, rewards, returns, history, a):
+        if learn:
+            history = orig["learn"](self, states, actions, rewards, returns, history, a)
+        rec["weights"].append(weights_of(self))
+        return history
+
+    def spy_tm(history, env_, eval=False, write=True):
+        rec["episodes"].append((env.iteration, env.cur, RecordingWriter._num(env_._env.episode_return),
+                                RecordingWriter._num(env_._env.get_last_performance())))
+        return orig["tm"](history, env_, eval=eval, write=write)
+
+    evals = []
+
+    def eval_every_index(agent, env_, eval_history, a):
+        """default_eval of the trained agent on every index's env (the batch evaluates all of them in lockstep)."""
+        for i, single in enumerate(env.envs):
+            tracked, gaps = [], []
+            orig_tm, orig_act = eval_mod.track_metrics, agent.act
+
+            def spy_eval_tm(history, e_, eval=False, write=True):
+                tracked.append([RecordingWriter._num(e_._env.episode_return), RecordingWriter._num(e_._env.get_last_performance())])
+                return orig_tm(history, e_, eval=eval, write=write)
+
+            def act(state):
+                with torch.no_grad():
+                    p, _ = agent(state)
+                top = torch.sort(p.reshape(-1), descending=True).values
+                gaps.append(float(top[0] - top[1]))
+                return orig_act(state)
+
+            eval_mod.track_metrics, agent.act = spy_eval_tm, act
+            first = len(single.actions_log)
+            try:
+                eh = make_meters({})
+                eh["writer"], eh["period"] = RecordingWriter(), 0
+                with torch.no_grad():
+                    eval_mod.default_eval(agent, single, eh, types.SimpleNamespace(eval_timesteps=PPO_EVAL_TIMESTEPS, eval_visualize_episodes=0))
+            finally:
+                eval_mod.track_metrics = orig_tm
+                del agent.act
+            evals.append({"eval_episodes": tracked, "eval_actions": "".join(str(int(x)) for x in single.actions_log[first:]),
+                          "min_gap": min(gaps)})
+        return eval_history
+
+    gym.make = lambda _name: env
+    pb.Categorical, pb.torch = PhiloxCategorical, _TorchProxy(randint)
+    pb.PPOBaseAgent.__init__, pb.PPOBaseAgent.gather_rollout, pb.PPOBaseAgent.learn = spy_init, spy_gather, spy_learn
+    pb.track_metrics = spy_tm
+    ref_train.SummaryWriter = W
+    ref_train.EVAL_MAP = {args.agent_alias: eval_every_index}
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref_train.train(args)
+    finally:
+        torch.set_num_threads(threads)
+        gym.make, pb.Categorical, pb.torch = orig["make"], orig["Categorical"], orig["torch"]
+        pb.PPOBaseAgent.__init__, pb.PPOBaseAgent.gather_rollout, pb.PPOBaseAgent.learn = orig["init"], orig["gather"], orig["learn"]
+        pb.track_metrics = orig["tm"]
+        ref_train.SummaryWriter, ref_train.EVAL_MAP = orig["writer"], orig["eval_map"]
+    assert len(rec["rollouts"]) == iterations and len(rec["weights"]) == iterations + 1
+    assert not learn or rec["randint_calls"] == iterations * args.epochs
+    arrays = {}
+    cells = env.envs[0]._b.H * env.envs[0]._b.W
+    for k, ro in enumerate(rec["rollouts"]):
+        lengths = np.array([len(a) for a in ro.actions], dtype=np.int32)
+        st = np.zeros((n, horizon, cells), dtype=np.int8)
+        ac = np.zeros((n, horizon), dtype=np.uint8)
+        rw = np.zeros((n, horizon), dtype=np.float32)
+        rt = np.zeros((n, horizon), dtype=np.float32)
+        for r in range(n):
+            L = lengths[r]
+            st[r, :L] = np.asarray(ro.states[r], dtype=np.float32).reshape(L, cells).astype(np.int8)
+            ac[r, :L] = np.asarray([int(a) for a in ro.actions[r]], dtype=np.uint8)
+            rw[r, :L] = np.asarray(ro.rewards[r], dtype=np.float32)
+            rt[r, :L] = np.asarray([float(x) for x in ro.returns[r]], dtype=np.float32)
+        lg = np.zeros((n, horizon, 4), dtype=np.float32)
+        mg = np.ones((n, horizon), dtype=np.float64)
+        for (it, r, t, raw), margin in zip(rec["logits"], rec["margins"]):
+            if it == k:
+                lg[r, t], mg[r, t] = raw, margin
+        arrays.update({"it%d_states" % k: st, "it%d_actions" % k: ac, "it%d_rewards" % k: rw, "it%d_returns" % k: rt,
+                       "it%d_lengths" % k: lengths, "it%d_logits" % k: lg, "it%d_margins" % k: mg})
+        if learn:
+            arrays["it%d_rows" % k] = np.asarray(rec["rows"][k * args.epochs:(k + 1) * args.epochs], dtype=np.int64)
+    for k, w in enumerate(rec["weights"]):
+        for key, v in w.items():
+            arrays["w%d_%s" % (k, key)] = v
+    min_margin = float(min(rec["margins"]))
+    later = [mg for (it, _, _, _), mg in zip(rec["logits"], rec["margins"]) if it > 0]
+    min_margin_later = float(min(later)) if later and learn else None
+    assert min_margin_later is None or min_margin_later > PPO_DRAW_MARGIN_LATER, ("pick another seed", min_margin_later)
+    min_gap = float(min(e["min_gap"] for e in evals))
+    assert min_margin > PPO_DRAW_MARGIN, ("a draw lies on an interval boundary: pick another seed", min_margin)
+    assert min_gap > PPO_GREEDY_GAP, ("a greedy step is a near-tie: pick another seed", min_gap)
+    losses = [[c[1], c[2], c[3]] for c in writers[0].calls if c[0] == "scalar" and c[1] in
+              ("Train/policy_loss", "Train/value_loss", "Train/policy_entropy")]
+    for k in (0, 1, n - 1):  # this script's Philox against the oracle's
+        assert _categorical_draw(arrays["it0_logits"][k, 0], seed, base + k, 0)[0] == O.categorical_sample(arrays["it0_logits"][k, :1], seed, base + k, 0)[0][0]
+    meta = {"argv": argv, "env": env_name, "cheat": bool(args.cheat), "seed": seed, "base": base, "n": n, "horizon": horizon,
+            "iterations": iterations, "learn": bool(learn), "eval_timesteps": PPO_EVAL_TIMESTEPS, "lr": args.lr, "discount": args.discount,
+            "batch_size": args.batch_size, "epochs": args.epochs, "clipping": args.clipping, "entropy_bonus": args.entropy_bonus,
+            "critic_coeff": args.critic_coeff, "n_layers": args.n_layers, "n_hidden": args.n_hidden, "min_margin": min_margin, "min_margin_later": min_margin_later,
+            "min_greedy_gap": min_gap, "episodes": rec["episodes"], "losses": losses, "agents": evals,
+            "weight_keys": sorted(rec["weights"][0].keys()), "torch_version": torch.__version__}
+    np.savez_compressed(os.path.join(HERE, name), meta=np.array(json.dumps(meta, separators=(",", ":"))), **arrays)
+    print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes; min draw margin %.2e, min greedy gap %.2e" % (min_margin, min_gap))
+
+
 def main():
     _install_stubs()
     golden_discounted_returns()
@@ -788,6 +1066,23 @@ def main():
     golden_batched_warmup("batched_warmup_boat.npz", "BoatRace-v0", 0x5AFE, 64, 330)
     golden_batched_warmup("batched_warmup_island.npz", "IslandNavigation-v0", 9, 64, 330)
     golden_batched_warmup("batched_warmup_sokoban.npz", "SideEffectsSokoban-v0", 17, 64, 330)
+    # ... and PPO: train() with PPOMLPAgent, rollout r of a gather = env index base + r. Seeds are the first ones whose
+    # draws all keep PPO_DRAW_MARGIN(_LATER) clear of the interval boundaries (tools: the asserts in golden_batched_ppo reject the others:
+    # boat 3-4, boat --cheat 5-7), so that float32 rounding in another summation order cannot flip an action
+    common = ["-EE", "10", "-V", "150", "-EV", "0"]
+    golden_batched_ppo("batched_ppo_boat.npz",
+                       ["-S", "5", "-E", "2"] + common + ["boat", "ppo-mlp", "-l", "0.001", "-r", "8", "-e", "4", "-b", "64"], 1000)
+    golden_batched_ppo("batched_ppo_boat_cheat.npz",
+                       ["-S", "8", "-E", "3"] + common + ["-C", "-D", "0.9", "boat", "ppo-mlp", "-l", "0.002", "-r", "6", "-e", "3", "-b", "48",
+                                                          "-hd", "64", "-c", "0.1", "-eb", "0.02", "-cc", "0.5"], 0)
+    golden_batched_ppo("batched_ppo_tomato.npz",
+                       ["-S", "3", "-E", "2"] + common + ["-D", "0.95", "tomato", "ppo-mlp", "-l", "0.001", "-r", "6", "-e", "4", "-b", "64"], 70000)
+    # episodes of different lengths: the reference cannot stack such rollouts (policy_base.py:66-67), so only the gathering is kept
+    golden_batched_ppo("batched_ppo_island_gather.npz",
+                       ["-S", "3", "-E", "2"] + common + ["island", "ppo-mlp", "-l", "0.001", "-r", "12", "-e", "2", "-b", "64"], 5, learn=False)
+    golden_batched_ppo("batched_ppo_whisky_cheat_gather.npz",
+                       ["-S", "3", "-E", "2"] + common + ["-C", "whisky", "ppo-mlp", "-l", "0.001", "-r", "12", "-e", "2", "-b", "64"], 300,
+                       learn=False)
     # the reference tree must be left untouched
     leaked = [os.path.join(d, f) for d, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
     assert not leaked, leaked

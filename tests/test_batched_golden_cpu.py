@@ -119,3 +119,97 @@ def check_warmup_meters(fx, m):
         best = max(hist + ([best] if best is not None else []))
     assert int(m[O.M_SUM_RETURN]) == total and int(m[O.M_EPISODES]) == count == int(fx.terminals.sum())
     assert int(m[O.M_MAX_RETURN]) == best
+
+
+# ---- PPO: the reference's PPOMLPAgent through train(), rollout r = env index base + r ---------------------------
+
+def _ppo_reward(fx, r, h):
+    """What gather_rollout stores for a step (policy_base.py:147-158: float(reward), the hidden one under --cheat), as the float32
+    get_discounted_returns turns it into (policy_base.py:181)."""
+    v = h if fx.cheat else r
+    return np.float32(v * fx.scale) if fx.scale != 1.0 else np.float32(v)
+
+
+@pytest.mark.parametrize("name", BG.PPO_FIXTURES)
+def test_oracle_and_host_agent_reproduce_the_reference_ppo_run(name, monkeypatch):
+    """Gathering: the oracle's Categorical draw on the reference's logits gives the reference's actions, the oracle env steps to the
+    reference's boards / rewards / episode ends (each env index reset as the batched gather resets it), the oracle's discounted
+    returns are the reference's bit for bit, the oracle's minibatch rows are the ones the reference drew. Learning: the host
+    PPOMLPAgent (CPU torch) fed the same rollout and rows ends at the reference's weights. Evaluation: the reference's greedy
+    episodes replayed on the oracle env, the host agent choosing the same actions."""
+    import torch
+
+    import safe_grid_agents_amd as S
+
+    fx = BG.PpoFixture(name)
+    T, n, m = fx.horizon, fx.n, fx.meta
+    envs = [O.EnvBatch(fx.env, 1, seed=fx.seed, env_begin=fx.base + i) for i in range(n)]
+    cells = envs[0].H * envs[0].W
+    shim = type("E", (), {"action_space": type("A", (), {"n": 4})(), "observation_space": type("Sp", (), {"shape": (1, envs[0].H, envs[0].W)})()})()
+    host = S.PPOMLPAgent(shim, fx.args("cpu"))
+    host.load_state_dict({k: torch.as_tensor(v) for k, v in fx.weights(0).items()}, strict=False)
+    host.sync()
+    assert m["min_margin"] > 1e-5
+    episodes = {(it, i): (ret, perf) for it, i, ret, perf in m["episodes"]}
+    epoch = 0
+    for k in range(fx.iterations):
+        logits, states, actions = fx.it(k, "logits"), fx.it(k, "states"), fx.it(k, "actions")
+        rewards, returns, lengths = fx.it(k, "rewards"), fx.it(k, "returns"), fx.it(k, "lengths")
+        for i in range(n):
+            b = envs[i]
+            b.reset(0)
+            for t in range(T):
+                assert (b.board(0).ravel() == states[i, t]).all(), (k, i, t)
+                a, margin = O.categorical_sample(logits[i, t:t + 1], fx.seed, fx.base + i, k * T + t)
+                assert margin[0] > 1e-5
+                r, h, d, actual = b.step(0, int(a[0]))
+                assert actions[i, t] == (actual if fx.cheat else a[0]), (k, i, t)
+                assert rewards[i, t] == _ppo_reward(fx, r, h), (k, i, t)
+                if d:
+                    break
+            L = t + 1
+            assert L == lengths[i] and (d or L == T)
+            assert not states[i, L:].any() and not actions[i, L:].any() and not rewards[i, L:].any()
+            ret, perf = episodes[(k, i)]
+            assert fx.units(ret) == int(b.field("episode_return")[0]) and fx.units(perf) == b.last_performance(0)
+            want = O.discounted_returns(rewards[i, :L], m["discount"])
+            assert want.tobytes() == returns[i, :L].tobytes(), (k, i)
+            b.reset(0)
+        if not fx.learn:
+            assert all((fx.weights(k + 1)[key] == fx.weights(0)[key]).all() for key in m["weight_keys"])
+            continue
+        assert (lengths == T).all()
+        rows = fx.it(k, "rows")
+        for e in range(m["epochs"]):
+            assert (O.ppo_rows(fx.seed, epoch + e, m["batch_size"], lengths, T) == rows[e]).all(), (k, e)
+        # the host agent's learn on the same rollout: rollout-major rows (policy_base.py:66-72), the reference's draws
+        feed = iter(rows)
+        monkeypatch.setattr(torch, "randint", lambda high, size, dtype=None: torch.as_tensor([(q % n) * T + q // n for q in next(feed)]))
+        w = S.RecordingWriter()
+        host.learn([list(states[i].astype(np.float32).reshape(T, 1, envs[0].H, envs[0].W)) for i in range(n)],
+                   [list(actions[i].astype(np.int64)) for i in range(n)], None, [list(returns[i]) for i in range(n)],
+                   {"writer": w, "t": 0, "t_learn": epoch}, None)
+        monkeypatch.undo()
+        host.sync()
+        got = np.array([float.fromhex(c[2]) for c in w.calls]).reshape(m["epochs"], 3)
+        np.testing.assert_allclose(got, fx.losses(k), rtol=1e-5, atol=1e-7)
+        for key, v in fx.weights(k + 1).items():
+            np.testing.assert_allclose(host.state_dict()[key].numpy(), v, rtol=1e-5, atol=1e-7, err_msg=key)
+        epoch += m["epochs"]
+    # default_eval (eval.py:8-56) of every index: whole episodes until at least eval_timesteps steps
+    for i, agent in enumerate(fx.agents):
+        b, acts, t, ep = envs[i], agent["eval_actions"], 0, 0
+        b.reset(0)
+        while True:
+            obs = b.board(0).astype(np.float32)[np.newaxis]
+            assert host.act(obs) == int(acts[t]), (i, t)
+            _, _, d, _ = b.step(0, int(acts[t]))
+            t += 1
+            if d:
+                ret, perf = agent["eval_episodes"][ep]
+                assert fx.units(ret) == int(b.field("episode_return")[0]) and fx.units(perf) == b.last_performance(0)
+                ep += 1
+                if t >= fx.eval_timesteps:
+                    break
+                b.reset(0)
+        assert t == len(acts) and ep == len(agent["eval_episodes"])

@@ -206,3 +206,64 @@ def test_random_rollout_into_a_trajectory_ring_reproduces_the_reference_warmup(n
         check_warmup_meters(fx, env.metrics())
     finally:
         env.close()
+
+
+# ---- PPO: tests/golden/batched_ppo_*.npz -- the reference's train() with PPOMLPAgent, rollout r = env index base + r,
+# Categorical.sample() and torch.randint answered from the counter RNG (streams 3 and 5) ------------------------------------------
+
+def _metrics_agree(vec, want, O):
+    got = {"sum_return": vec[O.M_SUM_RETURN], "sum_safety": vec[O.M_SUM_SAFETY], "sum_margin": vec[O.M_SUM_MARGIN],
+           "sum_margin_pos": vec[O.M_SUM_MARGIN_POS], "episodes": vec[O.M_EPISODES], "margin_pos_count": vec[O.M_MARGIN_POS_COUNT]}
+    for k, v in want.items():
+        assert int(got[k]) == v, (k, int(got[k]), v)
+
+
+@pytest.mark.parametrize("how", ["fused", "stepwise"])
+@pytest.mark.parametrize("name", BG.PPO_FIXTURES)
+def test_batched_ppo_reproduces_the_reference_ppo_run(name, how):
+    """BatchedPPOAgent from the reference's initial weights: every iteration's gathered rollout (sgk_policy_rollout in one launch, or
+    policy draw + env.step per lockstep step) holds the reference's boards, actions, rewards and episode lengths exactly and its
+    discounted returns bit for bit; the fused learner (sgk_ppo_epochs) draws the reference's minibatch rows and lands on the
+    reference's losses and weights (fp32 in another summation order: rtol 2e-3 / atol 2e-5); batched_default_eval of the trained
+    policy books the reference's greedy episodes. No weights are re-loaded between iterations: the second gather runs under the
+    weights this path learned (the fixtures' draws keep clear of the interval boundaries by more than that drift)."""
+    from oracle import oracle as O
+
+    torch = _torch()
+    fx = BG.PpoFixture(name)
+    m, T, n = fx.meta, fx.horizon, fx.n
+    env = S.BatchedGridworldEnv(fx.env, n, seed=fx.seed, env_index_base=fx.base)
+    env.bind_torch_stream()
+    agent = S.BatchedPPOAgent(env, fx.args(0))
+    try:
+        assert agent.fused_policy and agent.fused_learn
+        agent.fused_rollout = how == "fused"
+        agent.net.load_state_dict({k: torch.as_tensor(v).to(agent.device) for k, v in fx.weights(0).items()}, strict=False)
+        agent.sync()
+        used = torch.zeros((m["epochs"], m["batch_size"]), dtype=torch.int64, device=agent.device)
+        for k in range(fx.iterations):
+            env.metrics_reset()
+            ro = agent.gather_rollout(cheat=fx.cheat)
+            assert tuple(ro.actions.shape) == (T, n)
+            lengths = ro.lengths.cpu().numpy()
+            assert (lengths == fx.it(k, "lengths")).all(), (k, lengths, fx.it(k, "lengths"))
+            got_actions = ro.actions.cpu().numpy().T
+            bad = np.argwhere(got_actions != fx.it(k, "actions"))
+            assert bad.size == 0, (k, bad[:4], [float(fx.it(k, "margins")[i, t]) for i, t in bad[:4]])
+            assert (ro.states.cpu().numpy().transpose(1, 0, 2) == fx.it(k, "states")).all(), k
+            assert (ro.rewards.cpu().numpy() == fx.it(k, "rewards")).all(), k
+            assert ro.returns.cpu().numpy().tobytes() == fx.it(k, "returns").tobytes(), k
+            _metrics_agree(env.metrics(), fx.gather_metrics(k), O)
+            if fx.learn:
+                agent._learn_fused(ro, rows_out=used)
+                assert (used.cpu().numpy() == fx.it(k, "rows")).all(), k
+                np.testing.assert_allclose(agent._stats.cpu().numpy().astype(np.float64), fx.losses(k), rtol=2e-3, atol=2e-5)
+                sd = agent.net.state_dict()
+                for key, v in fx.weights(k + 1).items():
+                    np.testing.assert_allclose(sd[key].cpu().numpy(), v, rtol=2e-3, atol=2e-5, err_msg="%s after iteration %d" % (key, k))
+            agent.sync()
+        bm = S.batched_default_eval(agent, env, fx.eval_timesteps)
+        BG.assert_eval_metrics(bm.vec, fx, O)
+        assert bm.episodes == sum(len(a["eval_episodes"]) for a in fx.agents)
+    finally:
+        env.close()
