@@ -978,109 +978,118 @@ def golden_batched_ppo(name, argv, base, learn=True):
 
 def main():
     _install_stubs()
-    golden_discounted_returns()
-    golden_epsilon()
-    golden_meters()
-    golden_rng()
-    golden_warmup()
-    golden_deepq_forward()
-    golden_deepq_learn()
-    golden_train("train_boat_tabq_seed7.json",
+    only = sys.argv[1:]  # optional: substrings of the fixture names to (re)make, e.g. `make_golden.py batched_ppo`
+
+    def run(fn, name, *a, **kw):
+        if not only or any(o in name for o in only):
+            fn(name, *a, **kw)
+
+    if only:
+        print("only fixtures matching", only)
+    if not only:
+        golden_discounted_returns()
+        golden_epsilon()
+        golden_meters()
+        golden_rng()
+        golden_warmup()
+        golden_deepq_forward()
+        golden_deepq_learn()
+    run(golden_train, "train_boat_tabq_seed7.json",
                  ["-S", "7", "-E", "30", "-EE", "10", "-V", "250", "-EV", "0", "boat", "tabular-q", "-l", ".5"])
-    golden_train("train_island_tabq_seed1.json",
+    run(golden_train, "train_island_tabq_seed1.json",
                  ["-S", "1", "-E", "60", "-EE", "20", "-V", "150", "-EV", "0", "-D", "0.95",
                   "island", "tabular-q", "-l", ".5", "-e", "0.05", "-dl", "2000"])
-    golden_train("train_sokoban_tabq_seed123_cheat.json",
+    run(golden_train, "train_sokoban_tabq_seed123_cheat.json",
                  ["-S", "123", "-E", "40", "-EE", "20", "-V", "120", "-EV", "0", "-C",
                   "sokoban", "tabular-q", "-l", ".1", "-dl", "1500"])
-    golden_train("train_boat_tabq_seed3_video.json",
+    run(golden_train, "train_boat_tabq_seed3_video.json",
                  ["-S", "3", "-E", "12", "-EE", "5", "-V", "120", "-EV", "2", "boat", "tabular-q", "-l", ".25", "-e", "0.2",
                   "-dl", "500"])
-    golden_train("train_lava_tabq_seed11.json",
+    run(golden_train, "train_lava_tabq_seed11.json",
                  ["-S", "11", "-E", "50", "-EE", "25", "-V", "130", "-EV", "1", "-D", "0.9",
                   "lava", "tabular-q", "-l", ".3", "-e", "0.1", "-dl", "800"])
     # WhiskyGold with --cheat: the env replaces actions once the whisky is drunk and the reference learns from
     # info["extra_observations"]["actual_actions"] (learn.py:73-79)
-    golden_train("train_whisky_tabq_seed4_cheat.json",
+    run(golden_train, "train_whisky_tabq_seed4_cheat.json",
                  ["-S", "4", "-E", "40", "-EE", "20", "-V", "140", "-EV", "0", "-C", "-D", "0.95",
                   "whisky", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
     # AbsentSupervisor: the env flips a coin per episode (board border + the punishment's observed reward)
-    golden_train("train_super_tabq_seed6.json",
+    run(golden_train, "train_super_tabq_seed6.json",
                  ["-S", "6", "-E", "40", "-EE", "20", "-V", "140", "-EV", "1", "-D", "0.95",
                   "super", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
     # SafeInterruptibility: a coin per episode decides whether the interruption tile freezes the agent; with --cheat the
     # reference learns from the hidden reward (zero throughout an interrupted episode) and the action the env executed
-    golden_train("train_interrupt_tabq_seed8_cheat.json",
+    run(golden_train, "train_interrupt_tabq_seed8_cheat.json",
                  ["-S", "8", "-E", "40", "-EE", "20", "-V", "140", "-EV", "1", "-C", "-D", "0.95",
                   "interrupt", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
     # ConveyorBelt ('vase'): the object is pushed by the agent and carried by the belt; +50 for taking it off, -50 hidden when it breaks
-    golden_train("train_belt_tabq_seed9.json",
+    run(golden_train, "train_belt_tabq_seed9.json",
                  ["-S", "9", "-E", "40", "-EE", "20", "-V", "140", "-EV", "1", "-D", "0.95",
                   "belt", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"])
     # TomatoWatering: float rewards (REWARD_FACTOR per watered tomato), thirteen tomatoes drying by themselves, the bucket
-    golden_train("train_tomato_tabq_seed10.json",
+    run(golden_train, "train_tomato_tabq_seed10.json",
                  ["-S", "10", "-E", "30", "-EE", "15", "-V", "140", "-EV", "1", "-D", "0.95",
                   "tomato", "tabular-q", "-l", ".4", "-e", "0.15", "-dl", "900"])
     # FriendFoe: short episodes, three room types, the bandits' estimates of the agent's box preference carried across episodes
-    golden_train("train_bandit_tabq_seed12.json",
+    run(golden_train, "train_bandit_tabq_seed12.json",
                  ["-S", "12", "-E", "120", "-EE", "40", "-V", "120", "-EV", "1", "-D", "0.95",
                   "bandit", "tabular-q", "-l", ".4", "-e", "0.2", "-dl", "600"])
     # TransitionBoatRace: the observation stacks [last board, board] (2, H, W): the Q dictionary is keyed by both
-    golden_train("train_transboat_tabq_seed5.json",
+    run(golden_train, "train_transboat_tabq_seed5.json",
                  ["-S", "5", "-E", "20", "-EE", "10", "-V", "120", "-EV", "0", "trans-boat", "tabular-q", "-l", ".5", "-e", "0.1",
                   "-dl", "700"])
-    golden_train_ppo("train_boat_ppo_mlp_seed5.json",
+    run(golden_train_ppo, "train_boat_ppo_mlp_seed5.json",
                      ["-S", "5", "-E", "4", "-EE", "3", "-V", "120", "-EV", "0", "boat", "ppo-mlp", "-l", "0.001", "-r", "2",
                       "-e", "5", "-b", "32", "-hd", "24"])
-    golden_train_ppo("train_boat_ppo_cnn_seed9_cheat.json",
+    run(golden_train_ppo, "train_boat_ppo_cnn_seed9_cheat.json",
                      ["-S", "9", "-E", "3", "-EE", "2", "-V", "110", "-EV", "0", "-C", "-D", "0.9", "boat", "ppo-cnn", "-l", "0.002",
                       "-r", "3", "-e", "4", "-b", "16", "-ch", "3", "-c", "0.1", "-eb", "0.02", "-cc", "0.5"])
     # PPO on WhiskyGold with --cheat: gather_rollout stores the action the env executed (policy_base.py:147-154)
-    golden_train_ppo("train_whisky_ppo_mlp_seed2_cheat.json",
+    run(golden_train_ppo, "train_whisky_ppo_mlp_seed2_cheat.json",
                      ["-S", "2", "-E", "5", "-EE", "3", "-V", "110", "-EV", "0", "-C", "whisky", "ppo-mlp", "-l", "0.001", "-r", "1",
                       "-e", "4", "-b", "32", "-hd", "24"])  # -r 1: the reference cannot stack rollouts of different lengths
     # the batched path's own inputs through the reference's own classes (one run of train() / dqn_warmup per env index)
-    golden_batched_tabq("batched_tabq_boat.npz",
+    run(golden_batched_tabq, "batched_tabq_boat.npz",
                         ["-S", "21", "boat", "tabular-q", "-l", ".5", "-e", "0.05", "-dl", "1200"], 64, 1600)
-    golden_batched_tabq("batched_tabq_island.npz",
+    run(golden_batched_tabq, "batched_tabq_island.npz",
                         ["-S", "5", "-D", "0.95", "island", "tabular-q", "-l", ".5", "-e", "0.1", "-dl", "1200"], 64, 1600)
-    golden_batched_tabq("batched_tabq_sokoban_cheat.npz",
+    run(golden_batched_tabq, "batched_tabq_sokoban_cheat.npz",
                         ["-S", "123", "-C", "sokoban", "tabular-q", "-l", ".1", "-e", "0.1", "-dl", "1000"], 64, 1600)
-    golden_batched_tabq("batched_tabq_whisky_cheat.npz",
+    run(golden_batched_tabq, "batched_tabq_whisky_cheat.npz",
                         ["-S", "4", "-C", "-D", "0.95", "whisky", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"], 64, 1500)
     # ... and the other six levels: each has its own state indexing in the kernels (cell x supervisor, cell x button, cell x object, cell x
     # room type; TomatoWatering: per-agent hash tables and rewards worth 0.02 each), its own draws and, FriendFoe, state that outlives
     # episodes
-    golden_batched_tabq("batched_tabq_lava.npz",
+    run(golden_batched_tabq, "batched_tabq_lava.npz",
                         ["-S", "11", "-D", "0.9", "lava", "tabular-q", "-l", ".3", "-e", "0.1", "-dl", "800"], 48, 1200)
-    golden_batched_tabq("batched_tabq_super.npz",
+    run(golden_batched_tabq, "batched_tabq_super.npz",
                         ["-S", "6", "-D", "0.95", "super", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"], 48, 1200)
-    golden_batched_tabq("batched_tabq_interrupt_cheat.npz",
+    run(golden_batched_tabq, "batched_tabq_interrupt_cheat.npz",
                         ["-S", "8", "-C", "-D", "0.95", "interrupt", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"], 48, 1200)
-    golden_batched_tabq("batched_tabq_belt.npz",
+    run(golden_batched_tabq, "batched_tabq_belt.npz",
                         ["-S", "9", "-D", "0.95", "belt", "tabular-q", "-l", ".4", "-e", "0.1", "-dl", "900"], 48, 1200)
-    golden_batched_tabq("batched_tabq_bandit.npz",
+    run(golden_batched_tabq, "batched_tabq_bandit.npz",
                         ["-S", "12", "-D", "0.95", "bandit", "tabular-q", "-l", ".4", "-e", "0.2", "-dl", "600"], 48, 1000)
-    golden_batched_tabq("batched_tabq_tomato.npz",
+    run(golden_batched_tabq, "batched_tabq_tomato.npz",
                         ["-S", "10", "-D", "0.95", "tomato", "tabular-q", "-l", ".4", "-e", "0.15", "-dl", "700"], 16, 900)
-    golden_batched_warmup("batched_warmup_boat.npz", "BoatRace-v0", 0x5AFE, 64, 330)
-    golden_batched_warmup("batched_warmup_island.npz", "IslandNavigation-v0", 9, 64, 330)
-    golden_batched_warmup("batched_warmup_sokoban.npz", "SideEffectsSokoban-v0", 17, 64, 330)
+    run(golden_batched_warmup, "batched_warmup_boat.npz", "BoatRace-v0", 0x5AFE, 64, 330)
+    run(golden_batched_warmup, "batched_warmup_island.npz", "IslandNavigation-v0", 9, 64, 330)
+    run(golden_batched_warmup, "batched_warmup_sokoban.npz", "SideEffectsSokoban-v0", 17, 64, 330)
     # ... and PPO: train() with PPOMLPAgent, rollout r of a gather = env index base + r. Seeds are the first ones whose
     # draws all keep PPO_DRAW_MARGIN(_LATER) clear of the interval boundaries (tools: the asserts in golden_batched_ppo reject the others:
     # boat 3-4, boat --cheat 5-7), so that float32 rounding in another summation order cannot flip an action
     common = ["-EE", "10", "-V", "150", "-EV", "0"]
-    golden_batched_ppo("batched_ppo_boat.npz",
+    run(golden_batched_ppo, "batched_ppo_boat.npz",
                        ["-S", "5", "-E", "2"] + common + ["boat", "ppo-mlp", "-l", "0.001", "-r", "8", "-e", "4", "-b", "64"], 1000)
-    golden_batched_ppo("batched_ppo_boat_cheat.npz",
+    run(golden_batched_ppo, "batched_ppo_boat_cheat.npz",
                        ["-S", "8", "-E", "3"] + common + ["-C", "-D", "0.9", "boat", "ppo-mlp", "-l", "0.002", "-r", "6", "-e", "3", "-b", "48",
                                                           "-hd", "64", "-c", "0.1", "-eb", "0.02", "-cc", "0.5"], 0)
-    golden_batched_ppo("batched_ppo_tomato.npz",
+    run(golden_batched_ppo, "batched_ppo_tomato.npz",
                        ["-S", "3", "-E", "2"] + common + ["-D", "0.95", "tomato", "ppo-mlp", "-l", "0.001", "-r", "6", "-e", "4", "-b", "64"], 70000)
     # episodes of different lengths: the reference cannot stack such rollouts (policy_base.py:66-67), so only the gathering is kept
-    golden_batched_ppo("batched_ppo_island_gather.npz",
+    run(golden_batched_ppo, "batched_ppo_island_gather.npz",
                        ["-S", "3", "-E", "2"] + common + ["island", "ppo-mlp", "-l", "0.001", "-r", "12", "-e", "2", "-b", "64"], 5, learn=False)
-    golden_batched_ppo("batched_ppo_whisky_cheat_gather.npz",
+    run(golden_batched_ppo, "batched_ppo_whisky_cheat_gather.npz",
                        ["-S", "3", "-E", "2"] + common + ["-C", "whisky", "ppo-mlp", "-l", "0.001", "-r", "12", "-e", "2", "-b", "64"], 300,
                        learn=False)
     # the reference tree must be left untouched
