@@ -9,7 +9,10 @@
  * Conventions: flat C, plain pointers and sizes. Every function returns SGK_OK (0) or a negative
  * SGK_ERR_* and leaves a message for sgk_last_error() (thread-local, a fixed buffer: reporting an error allocates nothing).
  * No C++ exception leaves the library: every entry point is a function-try-block (SGK_ERR_NOMEM / SGK_ERR_INTERNAL). Handles are opaque and
- * thread-compatible (one thread at a time per handle). Pointers named *_dev are DEVICE pointers
+ * thread-compatible (one thread at a time per handle; different handles may be driven from different threads at the same time: the
+ * library serialises its own hipGraph captures and makes no synchronous legacy-stream call on a handle's path -- on ROCm such a call
+ * from ANY thread invalidates a capture in progress on any stream -- and records a capture again when a caller's own synchronous
+ * call, e.g. PyTorch's, invalidated it). Pointers named *_dev are DEVICE pointers
  * valid on the handle's GPU (e.g. torch tensor.data_ptr()); pointers named *_host are host memory.
  * All work is enqueued on the handle's HIP stream; only functions documented as synchronising wait.
  */

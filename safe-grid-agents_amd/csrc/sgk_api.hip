@@ -84,6 +84,39 @@ static int server_round_trip(sgk_env *h, uint32_t flags8, uint32_t action0) {
   return sgk::host::server_round_trip(h->srv, flags8, action0);
 }
 
+namespace {
+// `record(cap)` between hipStreamBeginCapture and hipStreamEndCapture on `cap`, instantiated into *exec. Captures are serialised
+// against each other and against the library's device-wide synchronous calls (sgk::capture_mutex); one that a foreign synchronous
+// call invalidated all the same (hipErrorStreamCaptureInvalidated) is recorded again, a few times.
+template <class Record>
+int capture_graph(hipStream_t cap, const char *what, Record record, hipGraphExec_t *exec) {
+  for (int attempt = 0;; ++attempt) {
+    hipGraph_t graph = nullptr;
+    hipError_t be, le = hipSuccess, ce = hipSuccess;
+    {
+      std::lock_guard<std::mutex> one_capture_at_a_time(sgk::host::capture_mutex());
+      be = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+      if (be == hipSuccess) {
+        le = record(cap);
+        ce = hipStreamEndCapture(cap, &graph);
+      }
+    }
+    if (be == hipSuccess && le == hipSuccess && ce == hipSuccess) {
+      hipError_t ie = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate");
+      return SGK_OK;
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    const hipError_t first = be != hipSuccess ? be : (le != hipSuccess ? le : ce);
+    const bool disturbed = be == hipSuccess && (le == hipErrorStreamCaptureInvalidated || ce == hipErrorStreamCaptureInvalidated ||
+                                                le == hipErrorStreamCaptureImplicit || ce == hipErrorStreamCaptureImplicit);
+    if (!disturbed || attempt >= 4) return hip_fail(first, be != hipSuccess ? "hipStreamBeginCapture" : what);
+  }
+}
+}  // namespace
+
 extern "C" {
 
 const char *sgk_last_error(void) { return sgk::host::error_buffer(); }
@@ -301,7 +334,10 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
     memset(image, 0, sizeof(image));
     memcpy(image, &s.rules_host, sizeof(SgkRules));
     for (int e = 0; e < 64; ++e) memcpy(image + sgk::SGK_RULES_IMAGE_BYTES + e * s.n_cells, s.rules_host.templ, (size_t)s.n_cells);
-    SGK_TRY(hipMemcpy(s.rules_dev, image, sizeof(image), hipMemcpyHostToDevice));  // synchronous: `image` dies with this block
+    // on the handle's stream, not hipMemcpy: a synchronous legacy-stream copy collides with another thread's graph capture
+    // (sgk::capture_mutex); waited for here because `image` dies with this block
+    SGK_TRY(hipMemcpyAsync(s.rules_dev, image, sizeof(image), hipMemcpyHostToDevice, h->stream));
+    SGK_TRY(hipStreamSynchronize(h->stream));
   }
   SGK_TRY(hipMemsetAsync(s.rec, 0, sizeof(uint32_t) * n_pad, h->stream));
   SGK_TRY(hipMemsetAsync(s.last_return, 0, sizeof(int32_t) * n_pad, h->stream));
@@ -533,22 +569,18 @@ static int ensure_step_graph(sgk_env *h, int32_t n_steps, uint32_t flags, hipGra
   auto key = std::make_pair(n_steps, flags);
   hipGraphExec_t exec = h->graphs.find(key);
   if (!exec) {
-    hipGraph_t graph = nullptr;
-    hipStream_t cap = h->own_stream;  // never the caller's stream: it may be the NULL stream, which cannot be captured
-    SGK_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-    hipError_t le = hipSuccess;
-    for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k) le = sgk::launch_step_counter(s, h->t_dev, (uint64_t)k, flags, cap);
-    if (le == hipSuccess) {
-      (void)hipGetLastError();
-      hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, cap, h->t_dev, (uint64_t)n_steps);
-      le = hipGetLastError();
-    }
-    hipError_t ce = hipStreamEndCapture(cap, &graph);
-    if (le != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); return hip_fail(le, "capture step kernels"); }
-    if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture");
-    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate");
+    // (never the caller's stream: it may be the NULL stream, which cannot be captured)
+    int rc = capture_graph(h->own_stream, "capture step kernels", [&](hipStream_t cap) {
+      hipError_t le = hipSuccess;
+      for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k) le = sgk::launch_step_counter(s, h->t_dev, (uint64_t)k, flags, cap);
+      if (le == hipSuccess) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, cap, h->t_dev, (uint64_t)n_steps);
+        le = hipGetLastError();
+      }
+      return le;
+    }, &exec);
+    if (rc != SGK_OK) return rc;
     h->graphs.insert(key, exec, h->stream);
   }
   *out = exec;
@@ -876,7 +908,8 @@ int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const int32_t *
     float tab[1024];
     for (int t = 0; t < 1024; ++t) tab[t] = (float)std::pow(discount, (double)t);  // Python: float ** int, then float32
     SGK_HIP(hipStreamSynchronize(h->stream));  // a previous launch may still read the old table
-    SGK_HIP(hipMemcpy(h->gamma_dev, tab, sizeof(tab), hipMemcpyHostToDevice));
+    SGK_HIP(hipMemcpyAsync(h->gamma_dev, tab, sizeof(tab), hipMemcpyHostToDevice, h->stream));  // (not hipMemcpy: sgk::capture_mutex)
+    SGK_HIP(hipStreamSynchronize(h->stream));  // `tab` is on the stack
     h->gamma_discount = discount;
   }
   SGK_HIP(sgk::launch_discounted_returns(h->sh, rewards_dev, lengths_dev, h->gamma_dev, returns_dev, n_trajectories, t_max,
@@ -1213,30 +1246,25 @@ int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags
   auto key = std::make_pair(n_steps, (uint32_t)(cheat ? 1u : 0u) | (flags << 1));
   hipGraphExec_t exec = q->graphs.find(key);
   if (!exec) {
-    hipGraph_t graph = nullptr;
-    hipStream_t cap = h->own_stream;
     sgk::TabqShard tq = q->tq;
     tq.t_ptr = q->t_dev;
-    SGK_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-    hipError_t le = hipSuccess;
-    for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k) {
-      tq.t_agent = k;  // offset from *t_dev
-      le = sgk::launch_tabq_act(s, tq, 1, q->actions, cap);
-      if (le == hipSuccess) le = sgk::launch_step(s, q->actions, flags, cap);
-      if (le == hipSuccess) le = sgk::launch_tabq_learn(s, tq, q->actions, cheat, cap);
-      if (le == hipSuccess) le = sgk::launch_reset(s, nullptr, 1 | ((flags & SGK_F_NO_BOARDS) ? 4 : 0), cap);
-    }
-    if (le == hipSuccess) {
-      (void)hipGetLastError();
-      hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, cap, reinterpret_cast<uint64_t *>(q->t_dev), (uint64_t)n_steps);
-      le = hipGetLastError();
-    }
-    hipError_t ce = hipStreamEndCapture(cap, &graph);
-    if (le != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); return hip_fail(le, "capture the tabular-Q step sequence"); }
-    if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture");
-    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate");
+    int rc = capture_graph(h->own_stream, "capture the tabular-Q step sequence", [&](hipStream_t cap) {
+      hipError_t le = hipSuccess;
+      for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k) {
+        tq.t_agent = k;  // offset from *t_dev
+        le = sgk::launch_tabq_act(s, tq, 1, q->actions, cap);
+        if (le == hipSuccess) le = sgk::launch_step(s, q->actions, flags, cap);
+        if (le == hipSuccess) le = sgk::launch_tabq_learn(s, tq, q->actions, cheat, cap);
+        if (le == hipSuccess) le = sgk::launch_reset(s, nullptr, 1 | ((flags & SGK_F_NO_BOARDS) ? 4 : 0), cap);
+      }
+      if (le == hipSuccess) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(add_counter_kernel, dim3(1), dim3(1), 0, cap, reinterpret_cast<uint64_t *>(q->t_dev), (uint64_t)n_steps);
+        le = hipGetLastError();
+      }
+      return le;
+    }, &exec);
+    if (rc != SGK_OK) return rc;
     q->graphs.insert(key, exec, h->stream);
   }
   SGK_HIP(refresh_row_tags(q));

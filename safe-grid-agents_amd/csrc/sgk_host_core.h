@@ -194,6 +194,18 @@ inline StreamPool &stream_pool() {
   return p;
 }
 
+// Graph captures (hipStreamBeginCapture .. hipStreamEndCapture) and the library's device-wide synchronous calls exclude each other.
+// On ROCm 7 a synchronous legacy-stream call (hipMemcpy, hipDeviceSynchronize) made by ANY thread while ANY stream of the process is
+// capturing fails with hipErrorStreamCaptureImplicit and invalidates that capture -- thread-local capture mode and non-blocking
+// streams notwithstanding (found by the GPU soak of round 5: one thread's sgk_create uploading its rule table while another
+// thread's handle recorded its step graph, 2 failures in 17 runs of the suite). The library itself no longer makes such calls on a
+// handle's path (uploads go through the handle's stream); sgk_ring_free's device synchronisation takes this mutex, and so does
+// every capture. A capture invalidated by somebody else's synchronous call (the caller's own, PyTorch's) is retried.
+inline std::mutex &capture_mutex() {
+  static std::mutex m;
+  return m;
+}
+
 // The entry points that take no handle run at arbitrary points of the caller's program (sgk_ring_free: from destructors;
 // sgk_issue_peak: in the middle of a bench); whatever device they work on, the thread's current device is what it was when they
 // return.
@@ -354,7 +366,10 @@ inline int ring_free(void *dev_ptr) {
   if (!b) return fail(SGK_ERR_INVALID, "not a pointer sgk_ring_alloc returned");
   DeviceGuard keep_current_device;
   hipError_t e = hipSetDevice(b->device);
-  if (e == hipSuccess) (void)hipDeviceSynchronize();  // nothing may still be writing into it
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> no_capture_meanwhile(capture_mutex());
+    (void)hipDeviceSynchronize();  // nothing may still be writing into it
+  }
   release_ring(dev_ptr, *b, b->chunks.size());  // (on a device that cannot be selected any more the driver calls fail by themselves)
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice (sgk_ring_free)");
   return SGK_OK;

@@ -1738,6 +1738,80 @@ def test_handles_driven_from_concurrent_threads_stay_exact():
 
 
 @pytest.mark.gpu
+def test_a_graph_capture_in_one_thread_survives_handle_creation_in_another():
+    """One thread keeps recording new step graphs (a new launch count every call: hipStreamBeginCapture .. EndCapture on its
+    handle's stream) while another creates and destroys handles (rule-table upload) and a third changes the discount table of
+    sgk_discounted_returns. On ROCm a synchronous legacy-stream copy made while ANY stream of the process is capturing fails and
+    invalidates that capture; the library's uploads go through the handle's stream and captures are serialised and retried
+    (sgk_host_core.h: capture_mutex). Found by the GPU soak of round 5 as a 1-in-8 flake of the test above; with the library as
+    it was (tools/gpu_soak.sh, SGK_LIB_PATH=.../libsgk_before.so) this test fails within its first second."""
+    torch = _torch()
+    import threading
+    import time
+
+    errors, stop = [], threading.Event()
+    counts = {"captures": 0, "creates": 0, "tables": 0}
+    seed, n = 77, 900
+
+    def capturer():
+        try:
+            env, orc, t = S.BatchedGridworldEnv("BoatRace-v0", n, seed=seed), O.EnvBatch("BoatRace-v0", n, seed=seed), 0
+            k = 4
+            while not stop.is_set():
+                env.step_random(k, auto_reset=True, fused=False)  # (n_steps, flags) not seen before: a new capture
+                orc.rollout(k, seed=seed, t_begin=t, auto_reset=True)
+                t, k = t + k, 4 + (k - 3) % 90
+                counts["captures"] += 1
+            assert_same_state(env, orc, "capturing thread")
+            env.close()
+        except BaseException as err:  # noqa: BLE001
+            errors.append(("capturer", repr(err)))
+            stop.set()
+
+    def creator():
+        try:
+            while not stop.is_set():
+                env = S.BatchedGridworldEnv("IslandNavigation-v0", 256, seed=3)
+                env.step_random(2, auto_reset=True)
+                env.close()
+                counts["creates"] += 1
+        except BaseException as err:  # noqa: BLE001
+            errors.append(("creator", repr(err)))
+            stop.set()
+
+    rewards = torch.ones((8, 50), dtype=torch.float32, device="cuda")
+    returns = torch.zeros_like(rewards)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    last = {}
+
+    def discounter():  # (no torch work in here: the handle runs on a torch side stream, the tensors exist already)
+        try:
+            env = S.BatchedGridworldEnv("BoatRace-v0", 64, seed=1)
+            env.bind_torch_stream(side)
+            while not stop.is_set():
+                last["d"] = 0.5 + 0.4 * ((counts["tables"] % 97) / 97.0)  # a new table every call: one upload each
+                env.discounted_returns(rewards, last["d"], out=returns)
+                counts["tables"] += 1
+            env.close()
+        except BaseException as err:  # noqa: BLE001
+            errors.append(("discounter", repr(err)))
+            stop.set()
+
+    threads = [threading.Thread(target=f) for f in (capturer, creator, discounter)]
+    for th in threads:
+        th.start()
+    time.sleep(4.0)
+    stop.set()
+    for th in threads:
+        th.join(120)
+    assert not errors, (errors, counts)
+    assert counts["captures"] > 50 and counts["creates"] > 50 and counts["tables"] > 50, counts
+    torch.cuda.synchronize()
+    assert returns[0].cpu().numpy().tobytes() == O.discounted_returns(np.ones(50, dtype=np.float32), last["d"]).tobytes()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ENVS + ["TransitionBoatRace-v0"])
 def test_single_env_random_call_sequences_equal_the_oracle_env(name):
     """The gym-shaped single env under a random sequence of calls -- steps (also after the episode is over), resets in the middle of
