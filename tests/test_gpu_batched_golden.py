@@ -218,7 +218,7 @@ def _metrics_agree(vec, want, O):
         assert int(got[k]) == v, (k, int(got[k]), v)
 
 
-@pytest.mark.parametrize("how", ["fused", "stepwise"])
+@pytest.mark.parametrize("how", ["fused", "stepwise", "torch"])
 @pytest.mark.parametrize("name", BG.PPO_FIXTURES)
 def test_batched_ppo_reproduces_the_reference_ppo_run(name, how):
     """BatchedPPOAgent from the reference's initial weights: every iteration's gathered rollout (sgk_policy_rollout in one launch, or
@@ -238,6 +238,8 @@ def test_batched_ppo_reproduces_the_reference_ppo_run(name, how):
     try:
         assert agent.fused_policy and agent.fused_learn
         agent.fused_rollout = how == "fused"
+        if how == "torch":
+            agent.fused_policy = agent.fused_learn = False
         agent.net.load_state_dict({k: torch.as_tensor(v).to(agent.device) for k, v in fx.weights(0).items()}, strict=False)
         agent.sync()
         used = torch.zeros((m["epochs"], m["batch_size"]), dtype=torch.int64, device=agent.device)
@@ -254,10 +256,16 @@ def test_batched_ppo_reproduces_the_reference_ppo_run(name, how):
             assert (ro.rewards.cpu().numpy() == fx.it(k, "rewards")).all(), k
             assert ro.returns.cpu().numpy().tobytes() == fx.it(k, "returns").tobytes(), k
             _metrics_agree(env.metrics(), fx.gather_metrics(k), O)
-            if fx.learn:
+            if fx.learn and how == "torch":
+                w = S.RecordingWriter()
+                agent.learn(ro, {"writer": w, "t": 0, "t_learn": 0}, rows=list(fx.it(k, "rows")))  # (every episode lasts T steps: flat rows)
+                got = np.array([float.fromhex(c[2]) for c in w.calls]).reshape(m["epochs"], 3)
+                np.testing.assert_allclose(got, fx.losses(k), rtol=2e-3, atol=2e-5)
+            elif fx.learn:
                 agent._learn_fused(ro, rows_out=used)
                 assert (used.cpu().numpy() == fx.it(k, "rows")).all(), k
                 np.testing.assert_allclose(agent._stats.cpu().numpy().astype(np.float64), fx.losses(k), rtol=2e-3, atol=2e-5)
+            if fx.learn:
                 sd = agent.net.state_dict()
                 for key, v in fx.weights(k + 1).items():
                     np.testing.assert_allclose(sd[key].cpu().numpy(), v, rtol=2e-3, atol=2e-5, err_msg="%s after iteration %d" % (key, k))
