@@ -84,39 +84,6 @@ static int server_round_trip(sgk_env *h, uint32_t flags8, uint32_t action0) {
   return sgk::host::server_round_trip(h->srv, flags8, action0);
 }
 
-namespace {
-// `record(cap)` between hipStreamBeginCapture and hipStreamEndCapture on `cap`, instantiated into *exec. Captures are serialised
-// against each other and against the library's device-wide synchronous calls (sgk::capture_mutex); one that a foreign synchronous
-// call invalidated all the same (hipErrorStreamCaptureInvalidated) is recorded again, a few times.
-template <class Record>
-int capture_graph(hipStream_t cap, const char *what, Record record, hipGraphExec_t *exec) {
-  for (int attempt = 0;; ++attempt) {
-    hipGraph_t graph = nullptr;
-    hipError_t be, le = hipSuccess, ce = hipSuccess;
-    {
-      std::lock_guard<std::mutex> one_capture_at_a_time(sgk::host::capture_mutex());
-      be = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
-      if (be == hipSuccess) {
-        le = record(cap);
-        ce = hipStreamEndCapture(cap, &graph);
-      }
-    }
-    if (be == hipSuccess && le == hipSuccess && ce == hipSuccess) {
-      hipError_t ie = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate");
-      return SGK_OK;
-    }
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipGetLastError();
-    const hipError_t first = be != hipSuccess ? be : (le != hipSuccess ? le : ce);
-    const bool disturbed = be == hipSuccess && (le == hipErrorStreamCaptureInvalidated || ce == hipErrorStreamCaptureInvalidated ||
-                                                le == hipErrorStreamCaptureImplicit || ce == hipErrorStreamCaptureImplicit);
-    if (!disturbed || attempt >= 4) return hip_fail(first, be != hipSuccess ? "hipStreamBeginCapture" : what);
-  }
-}
-}  // namespace
-
 extern "C" {
 
 const char *sgk_last_error(void) { return sgk::host::error_buffer(); }
@@ -570,7 +537,7 @@ static int ensure_step_graph(sgk_env *h, int32_t n_steps, uint32_t flags, hipGra
   hipGraphExec_t exec = h->graphs.find(key);
   if (!exec) {
     // (never the caller's stream: it may be the NULL stream, which cannot be captured)
-    int rc = capture_graph(h->own_stream, "capture step kernels", [&](hipStream_t cap) {
+    int rc = sgk::host::capture_graph(h->own_stream, "capture step kernels", [&](hipStream_t cap) {
       hipError_t le = hipSuccess;
       for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k) le = sgk::launch_step_counter(s, h->t_dev, (uint64_t)k, flags, cap);
       if (le == hipSuccess) {
@@ -1248,7 +1215,7 @@ int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags
   if (!exec) {
     sgk::TabqShard tq = q->tq;
     tq.t_ptr = q->t_dev;
-    int rc = capture_graph(h->own_stream, "capture the tabular-Q step sequence", [&](hipStream_t cap) {
+    int rc = sgk::host::capture_graph(h->own_stream, "capture the tabular-Q step sequence", [&](hipStream_t cap) {
       hipError_t le = hipSuccess;
       for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k) {
         tq.t_agent = k;  // offset from *t_dev

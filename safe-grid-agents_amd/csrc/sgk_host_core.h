@@ -206,6 +206,37 @@ inline std::mutex &capture_mutex() {
   return m;
 }
 
+// `record(cap)` between hipStreamBeginCapture and hipStreamEndCapture on `cap`, instantiated into *exec. Captures are serialised
+// against each other and against the library's device-wide synchronous calls (capture_mutex); one that a foreign synchronous
+// call invalidated all the same (hipErrorStreamCaptureInvalidated) is recorded again, a few times.
+template <class Record>
+int capture_graph(hipStream_t cap, const char *what, Record record, hipGraphExec_t *exec) {
+  for (int attempt = 0;; ++attempt) {
+    hipGraph_t graph = nullptr;
+    hipError_t be, le = hipSuccess, ce = hipSuccess;
+    {
+      std::lock_guard<std::mutex> one_capture_at_a_time(capture_mutex());
+      be = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+      if (be == hipSuccess) {
+        le = record(cap);
+        ce = hipStreamEndCapture(cap, &graph);
+      }
+    }
+    if (be == hipSuccess && le == hipSuccess && ce == hipSuccess) {
+      hipError_t ie = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ie != hipSuccess) return hip_fail(ie, "hipGraphInstantiate");
+      return SGK_OK;
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    const hipError_t first = be != hipSuccess ? be : (le != hipSuccess ? le : ce);
+    const bool disturbed = be == hipSuccess && (le == hipErrorStreamCaptureInvalidated || ce == hipErrorStreamCaptureInvalidated ||
+                                                le == hipErrorStreamCaptureImplicit || ce == hipErrorStreamCaptureImplicit);
+    if (!disturbed || attempt >= 4) return hip_fail(first, be != hipSuccess ? "hipStreamBeginCapture" : what);
+  }
+}
+
 // The entry points that take no handle run at arbitrary points of the caller's program (sgk_ring_free: from destructors;
 // sgk_issue_peak: in the middle of a bench); whatever device they work on, the thread's current device is what it was when they
 // return.

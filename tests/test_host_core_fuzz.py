@@ -55,3 +55,21 @@ def test_graph_cache_stream_pool_and_ring_allocator_bookkeeping(fuzzers, what, r
     for san in ("asan", "tsan"):
         p = _run(fuzzers[san], what, "--rounds", rounds)
         assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (san, p.stdout[-600:], p.stderr[-1500:])
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_graph_captures_survive_synchronous_calls_of_other_threads(fuzzers, san):
+    """ROCm's rule as MI355X showed it (EXPERIMENTS R5.12), modelled in the stand-in: a synchronous legacy-stream call from any thread
+    invalidates every capture in progress. The capture as the library made it until round 5 (no mutex, no retry) dies of the
+    library's own sgk_ring_free -- the control, which must fail; capture_graph beside sgk_ring_free and a thread of foreign
+    synchronous calls hands back only complete graphs, retries the disturbed ones, gives up (with an error) after five disturbed
+    attempts, and no synchronous call of the product ever meets a capture."""
+    p = _run(fuzzers[san], "captures", "--rounds", "1500", "--protocol", "prefix")
+    assert p.returncode != 0 and "FAILED (as it must)" in p.stdout, p.stdout[-600:]
+    p = _run(fuzzers[san], "captures", "--rounds", "1500", "--seed", "3")
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.stdout[-800:], p.stderr[-1500:])
+    assert "synchronous calls of the product that met a capture: 0" in p.stdout
+    import re
+
+    m = re.search(r"(\d+) recorded in full, (\d+) given up", p.stdout)
+    assert int(m.group(1)) > 1000 and int(m.group(2)) > 0  # both the retry and the give-up path ran

@@ -381,9 +381,127 @@ static int fuzz_rings(uint64_t rounds, uint64_t seed) {
   return 0;
 }
 
+// Graph captures against the synchronous calls that invalidate them (ROCm's rule, modelled in the stand-in; EXPERIMENTS R5.12).
+// `protected_`: the product's capture_graph (serialised on capture_mutex, retried) beside the product's sgk_ring_free, whose device
+// synchronisation takes the same mutex, and a "foreign" thread making synchronous legacy-stream calls of its own at random times (the
+// caller's code, PyTorch). Checked: no synchronous call of the PRODUCT ever meets a capture; every graph that capture_graph hands
+// back holds all its nodes (none instantiated from a truncated capture); a capture gives up -- with an error, not a graph -- only
+// after five disturbed attempts; nothing leaks. !protected_ is the control: the capture as the library made it until round 5 (no
+// mutex, no retry) beside the same ring thread: it must fail.
+static int fuzz_captures(uint64_t rounds, uint64_t seed, bool protected_) {
+  std::atomic<bool> stop{false};
+  std::atomic<uint64_t> ok{0}, gave_up{0}, truncated{0}, old_style_failures{0}, rings{0}, foreign_calls{0};
+  std::atomic<int> failed{0};
+  std::atomic<uint64_t> attempts_hist[8] = {};
+  std::atomic<int> storm{0};  // capturers in a storm round: the foreign thread calls without pause, so every attempt is disturbed
+  auto capturer = [&](uint64_t s) {
+    std::mt19937_64 rng(s);
+    hipStream_t stream = nullptr;
+    (void)hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    for (uint64_t r = 0; r < rounds && !failed.load(); ++r) {
+      const bool in_storm = protected_ && rng() % 60 == 0;
+      const int nodes = in_storm ? 40 : 1 + (int)(rng() % 40);
+      const uint32_t pause = in_storm ? 20000 : (uint32_t)(rng() % 200);
+      if (in_storm) storm++;
+      int attempts = 0;
+      auto record = [&](hipStream_t cap) {
+        ++attempts;
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < nodes && e == hipSuccess; ++k) {
+          e = standin::capture_node(cap);
+          standin::spin(pause);
+        }
+        return e;
+      };
+      hipGraphExec_t exec = nullptr;
+      if (protected_) {
+        const int rc = capture_graph(stream, "capture (harness)", record, &exec);
+        attempts_hist[attempts < 7 ? attempts : 7]++;
+        if (in_storm) storm--;
+        if (rc == SGK_OK) {
+          if (!exec || exec->id != nodes) { truncated++; failed.store(1); }
+          ok++;
+        } else {
+          if (exec) failed.store(1);
+          if (!strstr(error_buffer(), "capture")) failed.store(1);  // the message names what failed
+          gave_up++;
+        }
+      } else {  // the library's capture until round 5
+        hipGraph_t graph = nullptr;
+        (void)hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+        const hipError_t le = record(stream);
+        const hipError_t ce = hipStreamEndCapture(stream, &graph);
+        if (le != hipSuccess || ce != hipSuccess) old_style_failures++;
+        if (graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) failed.store(1);
+        if (graph) (void)hipGraphDestroy(graph);
+      }
+      if (exec) (void)hipGraphExecDestroy(exec);
+    }
+    (void)hipStreamDestroy(stream);
+  };
+  auto ring_thread = [&] {  // the product's own device-wide synchronous call: sgk_ring_free
+    while (!stop.load()) {
+      void *p = nullptr;
+      if (ring_alloc(0, (size_t)3 << 20, &p) == SGK_OK) {
+        if (ring_free(p) != SGK_OK) failed.store(1);
+        rings++;
+      }
+      standin::spin(500);
+    }
+  };
+  auto foreign_thread = [&](uint64_t s) {  // somebody else's hipMemcpy
+    standin::foreign_caller() = true;
+    std::mt19937_64 rng(s);
+    while (!stop.load()) {
+      (void)hipMemcpy(nullptr, nullptr, 0, hipMemcpyHostToDevice);
+      foreign_calls++;
+      if (storm.load() > 0) {  // every attempt of the storm round's capture is to be disturbed: the give-up path
+        std::this_thread::yield();
+        continue;
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(20 + rng() % 400));
+    }
+  };
+  std::vector<std::thread> aux;
+  aux.emplace_back(ring_thread);
+  if (protected_) aux.emplace_back(foreign_thread, seed * 77 + 1);
+  std::vector<std::thread> caps;
+  for (int i = 0; i < 3; ++i) caps.emplace_back(capturer, seed * 1000 + (uint64_t)i);
+  for (std::thread &t : caps) t.join();
+  stop.store(true);
+  for (std::thread &t : aux) t.join();
+  standin::CaptureBook &b = standin::captures();
+  std::lock_guard<std::mutex> lock(b.m);
+  printf("captures: %llu recorded in full, %llu given up after five disturbed attempts, %llu rings freed meanwhile, %llu foreign synchronous "
+         "calls (%ld met a capture, %ld captures invalidated); synchronous calls of the product that met a capture: %ld\n",
+         (unsigned long long)ok.load(), (unsigned long long)gave_up.load(), (unsigned long long)rings.load(),
+         (unsigned long long)foreign_calls.load(), b.sync_calls_during_a_capture, b.invalidated, b.of_them_by_the_product);
+  if (protected_) {
+    printf("attempts per capture:");
+    for (int i = 1; i < 8; ++i) printf(" %d: %llu", i, (unsigned long long)attempts_hist[i].load());
+    printf("\n");
+  }
+  if (!protected_) {
+    printf("control (no mutex, no retry): %llu captures died of the product's own sgk_ring_free\n", (unsigned long long)old_style_failures.load());
+    if (old_style_failures.load() == 0 || b.of_them_by_the_product == 0) { printf("FAILED: the control did not fail\n"); return 1; }
+    printf("FAILED (as it must): captures invalidated by the library's own synchronous call\n");
+    return 1;
+  }
+  std::lock_guard<std::mutex> glock(standin::graphs().m);
+  if (failed.load() || truncated.load() || b.of_them_by_the_product || b.misuse || !b.live_graphs.empty() || !b.capturing.empty() ||
+      !standin::graphs().live.empty() || standin::graphs().double_destroys) {
+    printf("FAILED: failed=%d truncated=%llu product syncs in a capture=%ld misuse=%ld graphs leaked=%zu execs leaked=%zu\n", failed.load(),
+           (unsigned long long)truncated.load(), b.of_them_by_the_product, b.misuse, b.live_graphs.size(), standin::graphs().live.size());
+    return 1;
+  }
+  if (b.invalidated == 0) { printf("FAILED: no capture was ever disturbed: the run tests nothing\n"); return 1; }
+  printf("ok\n");
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s server|graphs|streams|rings [--schedules N] [--rounds N] [--seed S] [--protocol head|prefix] [--seconds T]\n", argv[0]);
+    fprintf(stderr, "usage: %s server|graphs|streams|rings|captures [--schedules N] [--rounds N] [--seed S] [--protocol head|prefix] [--seconds T]\n", argv[0]);
     return 2;
   }
   uint64_t schedules = 2000, rounds = 2000, seed = 1;
@@ -400,5 +518,6 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "graphs")) return fuzz_graphs(rounds, seed);
   if (!strcmp(argv[1], "streams")) return fuzz_streams(rounds, seed);
   if (!strcmp(argv[1], "rings")) return fuzz_rings(rounds, seed);
+  if (!strcmp(argv[1], "captures")) return fuzz_captures(rounds, seed, head);
   return 2;
 }

@@ -8,6 +8,9 @@
 //                 and an idle worker; a closure may hand back a LATE WRITE -- something that lands some time after the stream
 //                 already reads idle, the way a server's exit word was seen to land on MI355X (EXPERIMENTS R4.10)
 //   graph exec    a heap record; destroying one twice, or leaking one, is reported
+//   capture       hipStreamBeginCapture .. EndCapture with ROCm 7's rule as MI355X showed it (EXPERIMENTS R5.12), not CUDA's: a
+//                 synchronous legacy-stream call (hipDeviceSynchronize, hipMemcpy) from ANY thread while ANY stream is capturing fails
+//                 with hipErrorStreamCaptureImplicit and invalidates every capture in progress, whatever the capture mode
 //   VMM           address ranges, physical handles and mappings as bookkeeping only (no memory behind them), every misuse an
 //                 error code as from the driver, optional fault injection (standin::vmm().fail_one_in)
 #pragma once
@@ -27,7 +30,8 @@
 #include <vector>
 
 typedef int hipError_t;
-enum : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101, hipErrorNotReady = 600, hipErrorUnknown = 999 };
+enum : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101, hipErrorNotReady = 600,
+              hipErrorStreamCaptureInvalidated = 901, hipErrorStreamCaptureImplicit = 906, hipErrorUnknown = 999 };
 inline const char *hipGetErrorString(hipError_t e) {
   switch (e) {
     case hipSuccess: return "no error";
@@ -35,6 +39,8 @@ inline const char *hipGetErrorString(hipError_t e) {
     case hipErrorOutOfMemory: return "out of memory";
     case hipErrorInvalidDevice: return "invalid device ordinal";
     case hipErrorNotReady: return "device not ready";
+    case hipErrorStreamCaptureInvalidated: return "operation failed due to a previous error during capture";
+    case hipErrorStreamCaptureImplicit: return "operation would make the legacy stream depend on a capturing blocking stream";
     default: return "unknown error";
   }
 }
@@ -165,7 +171,80 @@ inline hipError_t hipStreamSynchronize(hipStream_t s) {
   return hipSuccess;
 }
 inline hipError_t hipStreamQuery(hipStream_t s) { return (!s || s->idle()) ? hipSuccess : hipErrorNotReady; }
-inline hipError_t hipDeviceSynchronize() { return hipSuccess; }  // (the harness synchronises its streams itself)
+
+// ---- stream capture -----------------------------------------------------------------------------------------------------------------
+namespace standin {
+struct Graph { int nodes; };
+struct CaptureBook {
+  std::mutex m;
+  std::map<Stream *, std::pair<int, bool>> capturing;  // stream -> (nodes recorded so far, invalidated)
+  std::set<Graph *> live_graphs;
+  long sync_calls_during_a_capture = 0;  // legacy-stream synchronous calls that found a capture in progress ...
+  long of_them_by_the_product = 0;       // ... and were not marked as somebody else's (foreign_caller): must stay 0
+  long invalidated = 0, misuse = 0;
+};
+inline CaptureBook &captures() {
+  static CaptureBook b;
+  return b;
+}
+inline bool &foreign_caller() {  // the harness sets it in threads that play the caller's own code / PyTorch
+  static thread_local bool f = false;
+  return f;
+}
+// what every synchronous legacy-stream call does first
+inline hipError_t legacy_sync_check() {
+  CaptureBook &b = captures();
+  std::lock_guard<std::mutex> lock(b.m);
+  if (b.capturing.empty()) return hipSuccess;
+  b.sync_calls_during_a_capture++;
+  if (!foreign_caller()) b.of_them_by_the_product++;
+  for (auto &c : b.capturing)
+    if (!c.second.second) { c.second.second = true; b.invalidated++; }
+  return hipErrorStreamCaptureImplicit;
+}
+// a kernel launch into a capturing stream (the harness's `record` callbacks call it once per node)
+inline hipError_t capture_node(Stream *s) {
+  CaptureBook &b = captures();
+  std::lock_guard<std::mutex> lock(b.m);
+  auto it = b.capturing.find(s);
+  if (it == b.capturing.end()) { b.misuse++; return hipErrorInvalidValue; }
+  if (it->second.second) return hipErrorStreamCaptureInvalidated;
+  it->second.first++;
+  return hipSuccess;
+}
+}  // namespace standin
+typedef standin::Graph *hipGraph_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+inline hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
+  standin::CaptureBook &b = standin::captures();
+  std::lock_guard<std::mutex> lock(b.m);
+  if (!s || b.capturing.count(s)) { b.misuse++; return hipErrorInvalidValue; }
+  b.capturing[s] = {0, false};
+  return hipSuccess;
+}
+inline hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t *graph) {
+  standin::CaptureBook &b = standin::captures();
+  std::lock_guard<std::mutex> lock(b.m);
+  *graph = nullptr;
+  auto it = b.capturing.find(s);
+  if (it == b.capturing.end()) { b.misuse++; return hipErrorInvalidValue; }
+  const std::pair<int, bool> c = it->second;
+  b.capturing.erase(it);
+  if (c.second) return hipErrorStreamCaptureInvalidated;
+  *graph = new standin::Graph{c.first};
+  b.live_graphs.insert(*graph);
+  return hipSuccess;
+}
+inline hipError_t hipGraphDestroy(hipGraph_t g) {
+  standin::CaptureBook &b = standin::captures();
+  std::lock_guard<std::mutex> lock(b.m);
+  if (!b.live_graphs.erase(g)) { b.misuse++; return hipErrorInvalidValue; }
+  delete g;
+  return hipSuccess;
+}
+inline hipError_t hipDeviceSynchronize() { return standin::legacy_sync_check(); }  // (the harness synchronises its streams itself)
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1 };
+inline hipError_t hipMemcpy(void *, const void *, size_t, hipMemcpyKind) { return standin::legacy_sync_check(); }
 
 // ---- graph execs ------------------------------------------------------------------------------------------------------------------
 namespace standin {
@@ -187,6 +266,14 @@ inline GraphExec *make_graph_exec(int id) {
 }
 }  // namespace standin
 typedef standin::GraphExec *hipGraphExec_t;
+inline hipError_t hipGraphInstantiate(hipGraphExec_t *exec, hipGraph_t g, void *, void *, size_t) {
+  {
+    std::lock_guard<std::mutex> lock(standin::captures().m);
+    if (!standin::captures().live_graphs.count(g)) { standin::captures().misuse++; return hipErrorInvalidValue; }
+  }
+  *exec = standin::make_graph_exec(g->nodes);  // (id = the node count: the harness checks that no truncated graph was instantiated)
+  return hipSuccess;
+}
 inline hipError_t hipGraphExecDestroy(hipGraphExec_t g) {
   {
     std::lock_guard<std::mutex> lock(standin::graphs().m);

@@ -4,7 +4,7 @@
 #   1. AddressSanitizer + UBSan: the oracle; the product's host-side rule builder and the kernels' transition code built for the host.
 #   2. ThreadSanitizer, then AddressSanitizer + UBSan: the product's HOST-SIDE LOGIC (safe-grid-agents_amd/csrc/sgk_host_core.h: the
 #      step server's mailbox protocol, the hipGraph LRU, the stream pool, the trajectory-ring allocator, the C-ABI's allocation
-#      gate) against the HIP stand-in of tools/hip_standin -- tools/fuzz_host_core.cpp. The server protocol runs
+#      gate, graph capture against synchronous legacy-stream calls) against the HIP stand-in of tools/hip_standin -- tools/fuzz_host_core.cpp. The server protocol runs
 #      SGK_FUZZ_SCHEDULES random schedules per sanitizer (default 100000, split over the cores); the protocol as of ded8f2b^
 #      (before round 4's step-taken-twice fix) runs first as the known-bad control and MUST fail.
 set -e
@@ -113,6 +113,12 @@ for san in tsan asan; do
   TSAN_OPTIONS="halt_on_error=1" ASAN_OPTIONS="detect_leaks=0" $T/fuzz_$san graphs --rounds 3000
   TSAN_OPTIONS="halt_on_error=1" ASAN_OPTIONS="detect_leaks=0" $T/fuzz_$san streams --rounds 30000
   TSAN_OPTIONS="halt_on_error=1" ASAN_OPTIONS="detect_leaks=1" $T/fuzz_$san rings --rounds 20000
+  echo "--- $san: graph captures against synchronous legacy-stream calls (ROCm's rule: EXPERIMENTS R5.12); the capture of rounds 1-4 first, as the control"
+  if TSAN_OPTIONS="halt_on_error=1" ASAN_OPTIONS="detect_leaks=0" $T/fuzz_$san captures --rounds 3000 --protocol prefix > $T/capture_control.log 2>&1; then
+    cat $T/capture_control.log; echo "the unprotected capture SURVIVED: the stand-in's capture rule is blind"; exit 1
+  fi
+  grep -E "^control|FAILED" $T/capture_control.log | head -3
+  TSAN_OPTIONS="halt_on_error=1" ASAN_OPTIONS="detect_leaks=0" $T/fuzz_$san captures --rounds 20000
 done
 echo "sanitize_cpu: all clean"
 rm -rf $T
