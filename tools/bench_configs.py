@@ -102,11 +102,18 @@ def stepwise():
 for _ in range(20):
     stepwise()
 dt = wall_time(stepwise, 200)
-out.append({"config": 3, "what": "same, drop-in call sequence act_explore/step/learn/reset_done made from Python (4 launches per step, HBM tables)",
+out.append({"config": 3, "what": "same, drop-in call sequence act_explore/step/learn/reset_done made from Python (4 launches per step, HBM tables), "
+                                 "the handle on its own stream: every call orders itself against torch's current stream (6 event record + wait pairs per step)",
             "us_per_step": dt * 1e6, "env_steps_per_s": n / dt, "alg_GBs": 196 * n / dt / 1e9})
 agent.learn_steps(100)
 dt = ev_time(env, lambda: agent.learn_steps(100), 10) / 100
 out.append({"config": 3, "what": "same four launches per step replayed from one hipGraph per 100 steps (sgk_tabq_learn_steps)",
+            "us_per_step": dt * 1e6, "env_steps_per_s": n / dt, "alg_GBs": 196 * n / dt / 1e9})
+env.bind_torch_stream()  # the same four calls with the handle on torch's stream: no ordering calls (EXPERIMENTS R5.13)
+for _ in range(20):
+    stepwise()
+dt = wall_time(stepwise, 200)
+out.append({"config": 3, "what": "same four calls from Python after env.bind_torch_stream()",
             "us_per_step": dt * 1e6, "env_steps_per_s": n / dt, "alg_GBs": 196 * n / dt / 1e9})
 agent.close(); env.close()
 
