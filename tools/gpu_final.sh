@@ -1,10 +1,10 @@
 #!/bin/bash
-# Everything the docs quote, in one GPU call: bash tools/gpu_final.sh <round tag, e.g. r04> [pmc]. Logs land in
+# Everything the docs quote, in one GPU call: bash tools/gpu_final.sh <round tag, e.g. r05> [pmc]. Logs land in
 # gpurun_out/<tag>_final/ (copy what is to be judged into profiles/<tag>/). With `pmc` also the FETCH_SIZE / WRITE_SIZE passes of the
 # three bench kernels that profiles/traffic.json is made from (24 profiler runs: ~15 minutes).
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-T=${1:-r04}; O=gpurun_out/${T}_final; mkdir -p $O
+T=${1:-r05}; O=gpurun_out/${T}_final; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -1 $O/smoke.log
 timeout 2400 python -m pytest tests -m gpu -q --timeout=900 > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log | grep -v "RCCL\|HIP ver\|ROCm\|Hostname\|Librccl" | cut -c1-300
 # the driver's bench command, three processes
