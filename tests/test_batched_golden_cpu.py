@@ -161,7 +161,9 @@ def test_oracle_and_host_agent_reproduce_the_reference_ppo_run(name, monkeypatch
             for t in range(T):
                 assert (b.board(0).ravel() == states[i, t]).all(), (k, i, t)
                 a, margin = O.categorical_sample(logits[i, t:t + 1], fx.seed, fx.base + i, k * T + t)
-                assert margin[0] > 1e-5
+                # the oracle's own margin of every draw: clear of the interval boundaries by what the generator promised (2e-5; 2e-4 once
+                # the weights carry a learner's rounding), so float32 rounding in another summation order cannot flip an action
+                assert margin[0] > (2e-4 if fx.learn and k > 0 else 2e-5), (k, i, t, margin[0])
                 r, h, d, actual = b.step(0, int(a[0]))
                 assert actions[i, t] == (actual if fx.cheat else a[0]), (k, i, t)
                 assert rewards[i, t] == _ppo_reward(fx, r, h), (k, i, t)
