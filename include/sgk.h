@@ -376,10 +376,20 @@ SGK_API int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon,
                            float *scores_out_dev);
 
 /* ---- DeepQAgent.learn (reference value.py:113-136) for the default topology as ONE kernel --------------------------- */
-/* Minibatch sampling from a device replay ring (uniform with replacement, contain.py:19-22; counter RNG stream 4 keyed by
- * the Adam step), Q-network and target-network forward, TD target r + discount * max_a' Q_target(s', a') * (1 - terminal),
- * mse_loss, backward, clip_grad_norm_(max_grad_norm), Adam(amsgrad) update -- the Linear(n_cells, H)-ReLU-Linear(H, H)-ReLU-
- * Linear(H, 4) network of value.py:148-158 with H = 100 (the reference default) or 64, batch <= 64. All pointers are device pointers; float32.
+/* What the kernel does, by reference line: ReplayBuffer.sample (contain.py:19-22, called at value.py:116) -- uniform with
+ * replacement from a device replay ring, counter RNG stream 4 keyed by the Adam step; Q(states).gather(actions) (value.py:119);
+ * target_Q(successors).max(1) with the terminal rows zeroed (value.py:120-121); expected = discount * next_Q + reward
+ * (value.py:122); F.mse_loss (value.py:123); backward + clip_grad_norm_(max_grad_norm) (value.py:127-128); Adam(amsgrad)
+ * (value.py:87,134) -- for the Linear(n_cells, H)-ReLU-Linear(H, H)-ReLU-Linear(H, 4) network of value.py:148-158 with H = 100
+ * (the reference default) or 64, batch <= 64. replay.add (value.py:114) is sgk_replay_store; the TensorBoard scalar
+ * (value.py:124) is the caller's, from loss_out.
+ * loss_mode selects what F.mse_loss sees:
+ *   SGK_DQN_LOSS_REFERENCE (0)  value.py:119-123 AS WRITTEN: Qs is [B,1], expected_Qs is [B], mse_loss broadcasts the pair to
+ *                               [B,B]: loss = mean over (i, j) of (Q_i - e_j)^2, so dL/dQ_i = (2/B) (Q_i - mean_j e_j) --
+ *                               every sample regresses towards the minibatch's mean target. Pinned to reference output
+ *                               (tests/golden/deepq_learn.npz, batched_dqn_*.npz).
+ *   SGK_DQN_LOSS_PER_SAMPLE (1) NOT the reference: the squeezed form, loss = mean_i (Q_i - e_i)^2 (textbook DQN).
+ * All pointers are device pointers; float32.
  *   replay ring   states / successors int8 [slices][n_envs][n_cells], actions uint8, rewards int8, terminals uint8 (0/1),
  *                 each [slices][n_envs]; the first slices_filled slices hold data
  *   w1..b3        the Q-network's parameters in torch layout ([out][in]), UPDATED IN PLACE
@@ -387,19 +397,26 @@ SGK_API int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon,
  *   m, v, vmax    Adam's exp_avg, exp_avg_sq, max_exp_avg_sq for w1, b1, w2, b2, w3, b3 (same shapes), updated
  *   tw1t, tw2t    the target network's hidden weights transposed; tb1, tb2, tw3 ([4][H]), tb3 as they are
  *   step          Adam's step counter (int64, device), incremented;   loss_out: float, or NULL
+ *   rows          NULL (the kernel draws the minibatch, stream 4), or int64 [batch]: the caller's transition indices
+ *                 slice * n_envs + env (an external sampler; an index outside the stored transitions reads transition 0)
+ *   rows_out      NULL, or int64 [batch]: receives the indices this step trained on
  * fp32 with a different summation order than rocBLAS: equal to torch's step to fp32 tolerance, not bit for bit. */
+#define SGK_DQN_LOSS_REFERENCE 0
+#define SGK_DQN_LOSS_PER_SAMPLE 1
 typedef struct sgk_dqn_learner {
   const int8_t *states, *successors;
   const uint8_t *actions;
   const int8_t *rewards;
   const uint8_t *terminals;
-  int32_t slices_filled, n_hidden, batch, pad0; /* slices_filled * n_envs < 2^31 (32-bit transition indices) */
+  int32_t slices_filled, n_hidden, batch, loss_mode; /* slices_filled * n_envs < 2^31 (32-bit transition indices); SGK_DQN_LOSS_* */
   float *w1, *b1, *w2, *b2, *w3, *b3, *w1t, *w2t, *w3t;
   float *m[6], *v[6], *vmax[6];
   const float *tw1t, *tb1, *tw2t, *tb2, *tw3, *tb3;
   int64_t *step;
   float *loss_out;
   double lr, beta1, beta2, eps, discount, max_grad_norm;
+  const int64_t *rows; /* or NULL */
+  int64_t *rows_out;   /* or NULL */
 } sgk_dqn_learner;
 SGK_API int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *learner);
 

@@ -812,6 +812,8 @@ int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) try {
     if (!L->m[i] || !L->v[i] || !L->vmax[i]) return fail(SGK_ERR_INVALID, "NULL Adam state in sgk_dqn_learner");
   if ((L->n_hidden != 64 && L->n_hidden != 100) || L->batch < 1 || L->batch > 64 || L->slices_filled < 1)
     return fail(SGK_ERR_INVALID, "sgk_dqn_sgd_step needs n_hidden 64 or 100 (the reference default), 1 <= batch <= 64, slices_filled >= 1");
+  if (L->loss_mode != SGK_DQN_LOSS_REFERENCE && L->loss_mode != SGK_DQN_LOSS_PER_SAMPLE)
+    return fail(SGK_ERR_INVALID, "loss_mode must be SGK_DQN_LOSS_REFERENCE (0) or SGK_DQN_LOSS_PER_SAMPLE (1)");
   if ((int64_t)L->slices_filled * h->sh.n > (int64_t)INT32_MAX)
     return fail(SGK_ERR_INVALID, "the minibatch is drawn with 32-bit transition indices: slices_filled * n_envs must stay below 2^31");
   if (sgk::dqn_sgd_lds_bytes(h->sh.n_cells, L->n_hidden) > 160u * 1024u)
@@ -825,7 +827,8 @@ int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) try {
   d.tw1t = L->tw1t; d.tb1 = L->tb1; d.tw2t = L->tw2t; d.tb2 = L->tb2; d.tw3 = L->tw3; d.tb3 = L->tb3;
   d.step = reinterpret_cast<long long *>(L->step);
   d.loss_out = L->loss_out;
-  d.n_hidden = L->n_hidden; d.batch = L->batch;
+  d.n_hidden = L->n_hidden; d.batch = L->batch; d.loss_mode = L->loss_mode;
+  d.rows = reinterpret_cast<const long long *>(L->rows); d.rows_out = reinterpret_cast<long long *>(L->rows_out);
   d.lr = L->lr; d.beta1 = L->beta1; d.beta2 = L->beta2; d.eps = L->eps; d.discount = L->discount; d.max_grad_norm = L->max_grad_norm;
   SGK_HIP(sgk::launch_dqn_sgd(h->sh, d, h->stream));
   return SGK_OK;

@@ -103,6 +103,9 @@ struct DqnLearner {
   long long *step;
   float *loss_out;
   int n_hidden, batch;
+  int loss_mode;  // SGK_DQN_LOSS_*
+  const long long *rows;  // caller's minibatch or null
+  long long *rows_out;    // minibatch used, or null
   double lr, beta1, beta2, eps, discount, max_grad_norm;
 };  // (the replay's int8 rewards are in units of the level's reward_scale: launch_dqn_sgd takes it from the shard's rules)
 hipError_t launch_replay_store(const Shard &sh, int phase, const uint8_t *actions, int cheat, int64_t head, const long long *head_dev,

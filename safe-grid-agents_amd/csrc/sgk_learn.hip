@@ -7,9 +7,11 @@
 // lanes' addresses consecutive (a transposed copy of W1 / W2 / W3 is kept current by the update itself; the fused policy
 // kernels read W1^T and W3^T from it).
 //
-// fp32 throughout, same formulas as torch (mse_loss mean reduction, clip coefficient max_norm / (norm + 1e-6) clamped to 1,
-// Adam with bias corrections and amsgrad); the summation order inside the dot products differs from rocBLAS, so parity with
-// torch's step is to fp32 tolerance (tests: 1e-5 relative after one step), not bit for bit.
+// fp32 throughout, same formulas as torch (mse_loss over the [B,1]-vs-[B] broadcast of value.py:119-123 by default -- loss_mode,
+// see the kernel; clip coefficient max_norm / (norm + 1e-6) clamped to 1, Adam with bias corrections and amsgrad); the summation
+// order inside the dot products differs from rocBLAS / torch's CPU kernels, so parity is to fp32 tolerance, not bit for bit: the
+// reference's own DeepQAgent runs (tests/golden/batched_dqn_*.npz, 320-330 steps across three target syncs) are reproduced with
+// every action equal, losses and weights within rtol 2e-4 (tests/test_gpu_batched_golden.py).
 #include <atomic>
 
 #include "sgk_device.h"
@@ -37,7 +39,10 @@ struct LearnArgs {
   const float *tw1t, *tb1, *tw2t, *tb2, *tw3, *tb3;
   long long *step;   // Adam step counter on the device
   float *loss_out;   // may be null
+  const long long *rows;  // the caller's minibatch (transition indices into the ring), or null: drawn here
+  long long *rows_out;    // the minibatch used, or null
   int32_t n_hidden, batch;
+  int32_t loss_mode;  // 0 = the reference's [B,1]-vs-[B] broadcast mse_loss (value.py:119-123), 1 = per-sample (squeezed) mse_loss
   uint64_t seed;  // minibatch indices: Philox stream 4, ctr = {sample, 0, Adam step before this update, 4}
   float lr, beta1, beta2, eps, discount, max_norm;
   double reward_scale;  // what one unit of the int8 rewards is worth (SgkRules.reward_scale; 1 except tomato watering): the
@@ -291,10 +296,16 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   if (t < LB) {
     int id = 0;
     if (t < B) {
-      uint32_t x[4];
-      philox4x32_10((uint32_t)t, 0u, (uint32_t)*a.step, 4u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
-      const unsigned long long r = ((unsigned long long)x[0] << 32) | x[1];
-      id = (int)__umul64hi(r, (unsigned long long)a.total);
+      if (a.rows) {
+        const long long r = a.rows[t];
+        id = (r >= 0 && r < a.total) ? (int)r : 0;  // (an index outside the stored transitions reads transition 0, not wild memory)
+      } else {
+        uint32_t x[4];
+        philox4x32_10((uint32_t)t, 0u, (uint32_t)*a.step, 4u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
+        const unsigned long long r = ((unsigned long long)x[0] << 32) | x[1];
+        id = (int)__umul64hi(r, (unsigned long long)a.total);
+      }
+      if (a.rows_out) a.rows_out[t] = id;
     }
     L.idx[t] = id;
     L.act[t] = a.actions[id] & 3;
@@ -338,14 +349,28 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   head_forward(L.Bq, H, L.w3, L.b3, L.q);
   stage_rows<H>(L.ST, a.w2, H);  // W2 as it is ([j][k]): the back-propagation through layer 2 wants it in this orientation
   __syncthreads();
-  // ---- loss = mean((q_sa - y)^2) with y = r + discount * max_a' Q_target(s', a') * (1 - terminal); dL/dq on the taken action ----
+  // ---- the loss on y_j = r_j + discount * max_a' Q_target(s'_j, a') * (1 - terminal_j) and q_i = Q(s_i, a_i); dL/dq on the taken action.
+  // loss_mode 0 (the reference, value.py:119-123): Qs is [B,1] and expected_Qs [B], so F.mse_loss broadcasts them to [B,B]:
+  //   loss = mean_{i,j} (q_i - y_j)^2 = mean_i (q_i - ybar)^2 + mean_j (y_j - ybar)^2,   dL/dq_i = (2 / B) (q_i - ybar),  ybar = mean_j y_j
+  //   (every sample is pulled towards the minibatch's MEAN target). loss_mode 1 (not the reference): the per-sample form,
+  //   loss = mean_i (q_i - y_i)^2, dL/dq_i = (2 / B) (q_i - y_i).
   float sq = 0.0f;
-  if (t < LB) {
-    float g = 0.0f;
+  if (t < LB) {  // (exactly wave 0: the wave reduction below runs with all 64 lanes)
+    float g = 0.0f, target = 0.0f, qsa = 0.0f;
     if (t < B) {
       const float nq = fmaxf(fmaxf(L.tq[t * 4], L.tq[t * 4 + 1]), fmaxf(L.tq[t * 4 + 2], L.tq[t * 4 + 3]));
-      const float target = a.discount * (L.term[t] ? 0.0f : nq) + L.rew[t];
-      const float d = L.q[t * 4 + L.act[t]] - target;
+      target = a.discount * (L.term[t] ? 0.0f : nq) + L.rew[t];
+      qsa = L.q[t * 4 + L.act[t]];
+    }
+    if (a.loss_mode == 0) {
+      const float ybar = __ockl_wfred_add_f32(target) / (float)B;  // (lanes >= B hold 0)
+      if (t < B) {
+        const float d = qsa - ybar, e = target - ybar;
+        sq = fmaf(d, d, e * e);
+        g = 2.0f * d / (float)B;
+      }
+    } else if (t < B) {
+      const float d = qsa - target;
       sq = d * d;
       g = 2.0f * d / (float)B;
     }
@@ -939,6 +964,7 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
   for (int i = 0; i < 6; ++i) { a.m[i] = L.m[i]; a.v[i] = L.v[i]; a.vmax[i] = L.vmax[i]; }
   a.tw1t = L.tw1t; a.tb1 = L.tb1; a.tw2t = L.tw2t; a.tb2 = L.tb2; a.tw3 = L.tw3; a.tb3 = L.tb3;
   a.step = L.step; a.loss_out = L.loss_out; a.n_hidden = L.n_hidden; a.batch = L.batch;
+  a.loss_mode = L.loss_mode; a.rows = L.rows; a.rows_out = L.rows_out;
   a.reward_scale = sh.rules_host.reward_scale;
   a.seed = sh.seed;
   a.lr = (float)L.lr; a.beta1 = (float)L.beta1; a.beta2 = (float)L.beta2; a.eps = (float)L.eps; a.discount = (float)L.discount;

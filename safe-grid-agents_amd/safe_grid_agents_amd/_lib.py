@@ -18,6 +18,7 @@ ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE, ERR_INTERNAL = -1, -2, -3, -4, -5
 F_AUTO_RESET, F_NO_BOARDS, F_MASK_FINISHED, F_RING_TILE_MAJOR = 1, 2, 4, 8
 LAYOUT_PITCHED, LAYOUT_COMPACT = 0, 1
 TABQ_KERNEL_AUTO, TABQ_KERNEL_LDS, TABQ_KERNEL_HBM = 0, 1, 2
+DQN_LOSS_REFERENCE, DQN_LOSS_PER_SAMPLE = 0, 1  # sgk_dqn_learner.loss_mode: value.py:119-123 as written ([B,1] vs [B] broadcast) / squeezed
 MEM_HOST_VISIBLE = 0x100
 BOAT_RACE, ISLAND_NAVIGATION, SIDE_EFFECTS_SOKOBAN, DISTRIBUTIONAL_SHIFT, WHISKY_GOLD, ABSENT_SUPERVISOR = 0, 1, 2, 3, 4, 5
 SAFE_INTERRUPTIBILITY = 6
@@ -54,11 +55,12 @@ class SgkMlpWeights(ctypes.Structure):
 class SgkDqnLearner(ctypes.Structure):
     _V6 = ctypes.c_void_p * 6
     _fields_ = ([(k, ctypes.c_void_p) for k in ("states", "successors", "actions", "rewards", "terminals")]
-                + [(k, ctypes.c_int32) for k in ("slices_filled", "n_hidden", "batch", "pad0")]
+                + [(k, ctypes.c_int32) for k in ("slices_filled", "n_hidden", "batch", "loss_mode")]
                 + [(k, ctypes.c_void_p) for k in ("w1", "b1", "w2", "b2", "w3", "b3", "w1t", "w2t", "w3t")]
                 + [("m", _V6), ("v", _V6), ("vmax", _V6)]
                 + [(k, ctypes.c_void_p) for k in ("tw1t", "tb1", "tw2t", "tb2", "tw3", "tb3", "step", "loss_out")]
-                + [(k, ctypes.c_double) for k in ("lr", "beta1", "beta2", "eps", "discount", "max_grad_norm")])
+                + [(k, ctypes.c_double) for k in ("lr", "beta1", "beta2", "eps", "discount", "max_grad_norm")]
+                + [("rows", ctypes.c_void_p), ("rows_out", ctypes.c_void_p)])
 
 
 class SgkPpoLearner(ctypes.Structure):

@@ -9,8 +9,15 @@ schedule, epsilon-greedy = Categorical(eps/n + (1 - eps) on the argmax), uniform
 What necessarily differs, and is stated next to any number: the reference does ONE SGD step on 64
 samples per SINGLE env-step of its single env; with N envs in lockstep one call produces N transitions, so the ratio is
 a parameter here: `sgd_steps` SGD steps of `batch_size` samples per LOCKSTEP step, replay of `replay_slices` x N
-transitions (a ring of whole lockstep slices). The [B,1]-vs-[B] mse_loss broadcast of value.py:119-123 is NOT kept here
-(shapes are squeezed): this is a different training schedule anyway, parity is claimed only for forward / argmax / policy.
+transitions (a ring of whole lockstep slices). With N = 1, sgd_steps = 1 and replay_slices = replay_capacity the schedule IS
+the reference's, and tests/golden/batched_dqn_*.npz (the reference's own DeepQAgent + dqn_warmup + dqn_learn, its random
+calls answered from the counter RNG) is reproduced: actions exactly, losses and weights to fp32 tolerance.
+
+Kept AS WRITTEN, because it is what the reference computes (`reference_loss_broadcast=True`, the default): the [B,1]-vs-[B]
+mse_loss broadcast of value.py:119-123 (loss = mean over (i, j) of (Q_i - e_j)^2: every sample regresses towards the
+minibatch's mean target); the target network's own random initialisation (value.py:82-84: no sync before the first
+`sync_every`); dqn_warmup's `state` that is never advanced inside an episode (warmup.py:17-21: every warm-up row keeps its
+episode's first board as `state`). Each has a switch to the textbook form, labelled non-reference.
 
 `q_body="cnn"` (NOT the reference's DeepQAgent, which is an MLP: value.py:148-158 -- offered because BASELINE.json's config 4 is
 worded "conv policy"): the Q-network is the convolutional body of the reference's PPO agent (policy_cnn.py:17-81: n_layers 3x3
@@ -113,7 +120,11 @@ def _ConvQ(nn, height, width, channels, n_layers, n_actions):
 class BatchedDeepQAgent:
     reads_boards = True  # acts on the materialised cells (batched_default_eval must keep writing them)
 
-    def __init__(self, env, args, sgd_steps=1, replay_slices=8, fused_learn=True, q_body=None):
+    def __init__(self, env, args, sgd_steps=1, replay_slices=8, fused_learn=True, q_body=None, reference_loss_broadcast=True,
+                 sync_target_at_start=False):
+        """reference_loss_broadcast: F.mse_loss on Qs [B,1] vs expected_Qs [B] as value.py:119-123 writes it (False: squeezed, the
+        textbook per-sample loss -- NOT the reference). sync_target_at_start: copy Q into the target network in the constructor
+        (NOT the reference: value.py:82-84 initialises the two networks independently)."""
         import torch
 
         self.torch = torch
@@ -133,7 +144,9 @@ class BatchedDeepQAgent:
         self.fused_learn = False  # set below; sync_target_Q looks at it
         self.Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
         self.target_Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
-        self.sync_target_Q()
+        self.reference_loss_broadcast = bool(reference_loss_broadcast)
+        if sync_target_at_start:
+            self.sync_target_Q()
         # capturable: Adam's step counters live on the device, so optim.step() can be recorded in a hipGraph; fused: one
         # kernel for all parameters instead of a dozen foreach kernels (learning iteration 483 -> 266 us, same box)
         self.optim = torch.optim.Adam(self.Q.parameters(), lr=self.lr, amsgrad=True, capturable=True, fused=True)
@@ -198,9 +211,10 @@ class BatchedDeepQAgent:
         self._fl["tw1t"].copy_(self.target_Q[0][0].weight.data.t())
         self._fl["tw2t"].copy_(self.target_Q[1][0][0].weight.data.t())
 
-    def _learn_batch_fused(self):
+    def _learn_batch_fused(self, rows=None, rows_out=None):
         """One call of sgk_dqn_sgd_step; the kernel also keeps W1^T / W2^T / W3^T current, so the fused policy kernel needs no
-        refresh afterwards."""
+        refresh afterwards. rows: int64 device tensor [batch] of transition indices (slice * n_envs + env) to train on instead of
+        the kernel's own draw; rows_out: int64 device tensor [batch] that receives the indices used."""
         import ctypes
 
         from . import _lib
@@ -213,11 +227,12 @@ class BatchedDeepQAgent:
         L = _lib.SgkDqnLearner(
             states=ptr(rp.states), successors=ptr(rp.successors), actions=ptr(rp.actions), rewards=ptr(rp.rewards),
             terminals=ptr(rp.terminals), slices_filled=int(rp.filled), n_hidden=int(q[1].numel()), batch=int(self.batch_size),
-            pad0=0, w1=ptr(q[0]), b1=ptr(q[1]), w2=ptr(q[2]), b2=ptr(q[3]), w3=ptr(q[4]), b3=ptr(q[5]), w1t=ptr(fw["w1t"]),
+            loss_mode=_lib.DQN_LOSS_REFERENCE if self.reference_loss_broadcast else _lib.DQN_LOSS_PER_SAMPLE, w1=ptr(q[0]), b1=ptr(q[1]), w2=ptr(q[2]), b2=ptr(q[3]), w3=ptr(q[4]), b3=ptr(q[5]), w1t=ptr(fw["w1t"]),
             w2t=ptr(fl["w2t"]), w3t=ptr(fw["w3t"]), m=arr(fl["m"]), v=arr(fl["v"]), vmax=arr(fl["vmax"]), tw1t=ptr(fl["tw1t"]),
             tb1=ptr(t1.bias.data), tw2t=ptr(fl["tw2t"]), tb2=ptr(t2.bias.data), tw3=ptr(t3.weight.data), tb3=ptr(t3.bias.data),
             step=ptr(fl["step"]), loss_out=ptr(fl["loss"]), lr=self.lr, beta1=0.9, beta2=0.999, eps=1e-8,
-            discount=self.discount, max_grad_norm=10.0)
+            discount=self.discount, max_grad_norm=10.0, rows=None if rows is None else ptr(rows),
+            rows_out=None if rows_out is None else ptr(rows_out))
         env = self.env
         env._sync_torch_to_lib()
         _lib.check(env.lib.sgk_dqn_sgd_step(env._h.ptr, ctypes.byref(L)))
@@ -289,7 +304,10 @@ class BatchedDeepQAgent:
             next_q = self.target_Q(successors.float()).max(1)[0]
             next_q = torch.where(terminals, torch.zeros_like(next_q), next_q)
             expected = self.discount * next_q + (rewards.double() * float(self.env.reward_scale)).float()  # f64 product, then f32
-        loss = torch.nn.functional.mse_loss(q_sa, expected)
+        if self.reference_loss_broadcast:  # value.py:119-123: mse_loss([B,1], [B]) = the mean over the [B,B] broadcast
+            loss = (q_sa.unsqueeze(1) - expected.unsqueeze(0)).square().mean()
+        else:
+            loss = torch.nn.functional.mse_loss(q_sa, expected)
         self.optim.zero_grad(set_to_none=True)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(self.Q.parameters(), 10.0)
@@ -412,13 +430,40 @@ class BatchedDeepQAgent:
         if learn and t % self.sync_every == self.sync_every - 1:
             self.sync_target_Q()
 
-    def warmup(self, n_steps):
-        """dqn_warmup (warmup.py:8-23): fill the replay with random-action slices."""
+    def warmup(self, n_steps, reference_state=True):
+        """dqn_warmup (warmup.py:8-23) for every env in ONE launch of the streamed random rollout (sgk_rollout_random_stream, the
+        headline kernel): RandomAgent's actions from counter-RNG stream 0, every step's successor board straight into the replay's
+        `successors` ring, the step records into a scratch ring that three strided copies split into actions / rewards / terminals.
+        reference_state=True keeps warmup.py:17-21 as written: `state` is assigned at env.reset() only, so every row of an episode
+        stores the episode's FIRST board as its state; False stores the board each action was taken on.
+        (A finished episode's row holds the next episode's first board as successor -- the ring convention; DeepQAgent.learn zeroes
+        next_Q there, value.py:121, and never reads it. The stored action is the executed one: WhiskyGold's replaced actions
+        appear as executed.)"""
         torch = self.torch
-        env = self.env
-        for _ in range(n_steps):
-            self.replay.store(env, 0)
-            actions = torch.randint(0, self.action_n, (env.n_envs,), device=self.device).to(torch.uint8)
-            env.step(actions, auto_reset=False)
-            self.replay.store(env, 1, actions)
-            env.reset_done()
+        env, rp = self.env, self.replay
+        n_steps = int(n_steps)
+        if n_steps <= 0:
+            return
+        if n_steps > rp.slices:
+            raise ValueError("warmup(%d) exceeds the replay ring of %d slices" % (n_steps, rp.slices))
+        n, cells = env.n_envs, env.n_cells
+        initial = env.boards().reshape(n, cells).clone()  # (a copy also when the rows are pitched: the view's logical shape is [N,1,H,W])
+        recs = torch.empty((rp.slices, n, 4), dtype=torch.int8, device=self.device)
+        first = rp.head
+        env.rollout_random_stream(n_steps, boards=rp.successors, recs=recs, first_slice=first)
+        idx = (first + torch.arange(n_steps, device=self.device)) % rp.slices
+        rec = recs[idx]
+        rp.actions[idx] = rec[:, :, 3].contiguous().view(torch.uint8)
+        rp.rewards[idx] = rec[:, :, 0]
+        term = rec[:, :, 2] != 0
+        rp.terminals[idx] = term
+        before = torch.cat([initial[None], rp.successors[idx][:-1]])  # the board every step acted on
+        if reference_state:
+            starts = torch.cat([torch.ones((1, n), dtype=torch.bool, device=self.device), term[:-1]])  # step k opens an episode
+            k = torch.arange(n_steps, device=self.device)[:, None] * starts
+            k = torch.cummax(k, dim=0).values
+            before = before.gather(0, k[:, :, None].expand(-1, -1, cells))
+        rp.states[idx] = before
+        rp.head = (first + n_steps) % rp.slices
+        rp.filled = min(rp.filled + n_steps, rp.slices)
+        rp.head_dev_stale = True

@@ -180,3 +180,51 @@ class PpoFixture:
             if margin > 0:
                 m["sum_margin_pos"] += margin; m["margin_pos_count"] += 1
         return m
+
+
+DQN_FIXTURES = ["batched_dqn_sokoban.npz", "batched_dqn_boat_cheat.npz"]
+
+
+class DqnFixture:
+    """tests/golden/batched_dqn_*.npz (make_golden.py:golden_batched_dqn): the reference's train() with its DeepQAgent, dqn_warmup and
+    dqn_learn on ONE env index, np.random.randint / Categorical.sample / np.random.choice answered from the batch's counter RNG (streams
+    0 / 2 / 4). Holds both networks' initial weights, the replay after the warm-up (row k = warm-up step k), every agent step's action,
+    epsilon, loss, Q-values and minibatch ring slots, the weights at every sync and at the end, and the final greedy evaluation."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name))
+        m = json.loads(str(z["meta"]))
+        self.z, self.meta = z, m
+        self.env, self.cheat, self.seed, self.index, self.steps = m["env"], m["cheat"], m["seed"], m["index"], m["steps"]
+        self.capacity, self.batch, self.sync_every = m["replay_capacity"], m["batch_size"], m["sync_every"]
+        self.eval_timesteps = m["eval_timesteps"]
+        self.agents = [{"eval_episodes": m["eval_episodes"], "eval_actions": m["eval_actions"]}]
+        self.epsilon_used = [float.fromhex(e) for e in m["epsilon_used"]]
+        self.actions, self.losses, self.rows, self.scores, self.gaps = z["actions"], z["losses"], z["rows"], z["scores"], z["gaps"]
+        self.explored = np.array(m["explored"], dtype=bool)
+        self.scale = 1.0
+
+    units = TabqFixture.units
+    eval_metrics = TabqFixture.eval_metrics
+
+    def args(self):
+        import types
+
+        m = self.meta
+        return types.SimpleNamespace(discount=m["discount"], lr=m["lr"], batch_size=m["batch_size"], sync_every=m["sync_every"],
+                                     epsilon=m["epsilon"], epsilon_anneal=m["epsilon_anneal"], n_layers=m["n_layers"],
+                                     n_hidden=m["n_hidden"], replay_capacity=m["replay_capacity"], cheat=self.cheat)
+
+    def weights(self, tag):
+        """tag: init_Q, init_T, final_Q, final_T, sync<i>_Q -> arrays keyed like the network's state_dict."""
+        return {key: self.z["%s_%s" % (tag, key.replace(".", "_"))] for key in self.meta["weight_keys"]}
+
+    def warm(self, what):
+        return self.z["warm_" + what]
+
+    def episode_metrics(self):
+        """Sums / counts of the training episodes the reference's track_metrics booked (Train/returns, ... per episode)."""
+        e = self.meta["episodes"]
+        rets = [self.units(v) for v in e["returns"]]
+        perfs = [self.units(v) for v in e["safeties"]]
+        return {"episodes": len(rets), "sum_return": sum(rets), "sum_safety": sum(perfs)}

@@ -359,11 +359,22 @@ def golden_deepq_learn():
         def _lift(self, x, dtype=torch.float32, grad=False):
             return super()._lift(x, dtype=torch.bool if dtype == torch.uint8 else dtype, grad=grad)
 
-    H, W, B, STEPS, SYNC_AT = 6, 6, 8, 14, 7
+    import safe_grid_agents.common.utils.contain as contain_mod
+
+    H, W, B, STEPS, SYNC_AT, HIDDEN = 6, 6, 8, 14, 7, 64  # (64 hidden units: a width sgk_dqn_sgd_step is built for, so the kernel can be fed these steps)
     env = types.SimpleNamespace(action_space=types.SimpleNamespace(n=4),
                                 observation_space=types.SimpleNamespace(shape=(H, W)))
     args = types.SimpleNamespace(device="cpu", log_gradients=False, epsilon=0.01, epsilon_anneal=1000,
-                                 discount=0.99, lr=1e-3, batch_size=B, n_layers=2, n_hidden=32, replay_capacity=10)
+                                 discount=0.99, lr=1e-3, batch_size=B, n_layers=2, n_hidden=HIDDEN, replay_capacity=10)
+    sampled = []
+
+    def recording_choice(n, size):  # contain.py:21's own call, on numpy's global stream; the positions it returns are recorded
+        ix = np.random.choice(n, size)
+        sampled.append((int(n), [int(i) for i in ix]))
+        return ix
+
+    orig_contain_np = contain_mod.np
+    contain_mod.np = _NumpyProxy(choice=recording_choice)
     threads = torch.get_num_threads()
     torch.set_num_threads(1)
     try:
@@ -390,6 +401,8 @@ def golden_deepq_learn():
                     agent.sync_target_Q()
     finally:
         torch.set_num_threads(threads)
+        contain_mod.np = orig_contain_np
+    assert [n for n, _ in sampled] == [min(k + 1, 10) for k in range(STEPS)]
 
     def hexes(sd):  # float32 arrays: an .npz keeps the bits
         return {k.replace(".", "_"): v.detach().numpy().copy() for k, v in sd.items()}
@@ -399,7 +412,8 @@ def golden_deepq_learn():
         states=np.stack(fed["states"]), successors=np.stack(fed["successors"]), actions=np.array(fed["actions"]),
         rewards=np.array(fed["rewards"]), terminals=np.array(fed["terminals"]),
         losses=np.array([float.fromhex(c[2]) for c in writer.calls if c[1] == "Train/value_loss"], dtype=np.float64),
-        meta=np.array(json.dumps({"H": H, "W": W, "batch_size": B, "steps": STEPS, "sync_after_step": SYNC_AT, "n_hidden": 32,
+        sample_ix=np.array([ix for _, ix in sampled], dtype=np.int64),  # [steps, B] positions in the deque (0 = oldest) each learn() trained on
+        meta=np.array(json.dumps({"H": H, "W": W, "batch_size": B, "steps": STEPS, "sync_after_step": SYNC_AT, "n_hidden": HIDDEN,
                                   "n_layers": 2, "replay_capacity": 10, "lr": 1e-3, "discount": 0.99, "torch_seed": 23,
                                   "numpy_seed": 31, "torch": torch.__version__,
                                   "shim": "terminals lifted as bool instead of uint8 (value.py:179)"})),
@@ -976,6 +990,256 @@ def golden_batched_ppo(name, argv, base, learn=True):
     print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes; min draw margin %.2e, min greedy gap %.2e" % (min_margin, min_gap))
 
 
+DQN_EVAL_TIMESTEPS = 150
+DQN_GREEDY_GAP = 2e-4  # no greedy decision of a fixture (training steps that do not explore, and the evaluation) has its two best
+#                        Q-values closer than this: the float32 drift of another summation order cannot flip an action (measured on the
+#                        MI355X over the 320-330 steps of the two fixtures: max |Q_kernel - Q_reference| = 1.7e-6 / 3.6e-7). Seeds are the
+#                        first that pass (sokoban 17; boat --cheat 29-34 rejected, 35).
+
+
+def _minibatch_index(seed, b, step, total):
+    """Stream 4: sample b of the SGD step that starts at Adam step `step` -> transition index in [0, total) (floor(u64 * total))."""
+    x = _block(seed, 4, b, step)
+    return ((((x[0] << 32) | x[1]) * total) >> 64)
+
+
+def _eps_greedy_draw(seed, env, draw):
+    """Stream 2: (53-bit uniform, uniform action) of env index `env` for draw number `draw` (the agent's step counter)."""
+    x = _block(seed, 2, env, draw)
+    return ((x[0] >> 5) * 67108864 + (x[1] >> 6)) / 9007199254740992.0, x[2] & 3
+
+
+class _BoardEnv(_IndexedEnv):
+    """The one adaptation on the env side: DeepQAgent sizes its network as observation_space.shape[0] * shape[1] (value.py:66-67), which
+    is the board only for 2-D observations -- with safe-grid-gym's (1, H, W) it builds Linear(H, ...) and fails at the first forward
+    (SURVEY 8(c)). This env hands out the (H, W) board without the channel axis; every value is the same."""
+
+    def __init__(self, name):
+        super().__init__(name)
+        self.observation_space = type(self.observation_space)(shape=(self._b.H, self._b.W))
+
+    def reset(self):
+        return super().reset()[0]
+
+    def step(self, action):
+        obs, r, d, info = super().step(action)
+        return obs[0], r, d, info
+
+
+def golden_batched_dqn(name, argv, index, steps):
+    """The reference's train() (train.py:21-70) with its DeepQAgent (value.py:61-187), dqn_warmup (warmup.py:8-23) and dqn_learn
+    (learn.py:29-58) on env index `index`, `steps` agent steps, every random call it makes answered from the batched path's counter RNG:
+      dummy.py:16      np.random.randint(0, 4)            stream 0, the warm-up's lockstep step
+      value.py:94-96   Categorical(probs).sample()        stream 2, the agent's step: with probability epsilon the uniform action, else the argmax
+                                                          (the distribution value.py:98-111 builds: eps/4 everywhere + (1 - eps) on the argmax)
+      contain.py:21    np.random.choice(len, batch_size)  stream 4, the Adam step: the ring slots the kernel draws, as deque positions
+    The ONE shim on the agent: a subclass whose _lift turns a requested uint8 into bool (value.py:121,179: torch >= 2 rejects uint8
+    masks; the torch of the reference's day read them as boolean masks). Every other line that runs is the reference's own, including
+    the [B,1]-vs-[B] mse_loss broadcast (value.py:119-123), the independently initialised target network (value.py:82-84) and the
+    warm-up's `state` that is only assigned at reset (warmup.py:17-21). Then the reference's default_eval (eval.py:8-56), greedy.
+    Recorded: both networks' initial weights, the replay after the warm-up, every step's action / epsilon / loss / greedy gap, the
+    weights after the last step and at every sync, the evaluation's episodes."""
+    import warnings
+
+    import train as ref_train
+    from safe_grid_agents.parsing import prepare_parser
+    import safe_grid_agents.common.agents.value as value_mod
+    import safe_grid_agents.common.agents.dummy as dummy_mod
+    import safe_grid_agents.common.utils.contain as contain_mod
+    import safe_grid_agents.common.eval as eval_mod
+    from safe_grid_agents.common.utils.meters import make_meters
+    from torch.distributions import Categorical
+    from oracle import oracle as O
+
+    global _PARSER
+    if _PARSER is None:
+        _PARSER = prepare_parser()
+    args = _PARSER.parse_args(argv)
+    args.device, args.log_dir = "cpu", "unused"
+    args.episodes, args.eval_every = 10**9, 10**9  # the draw budget ends the run
+    seed, cap, batch = int(args.seed), int(args.replay_capacity), int(args.batch_size)
+    st = {"warm": 0, "t": 0, "learn": 0}
+    rec = {"eps": [], "gaps": [], "explored": [], "rows": [], "scores": [], "sync_weights": []}
+    captured, writers, made = {}, [], []
+
+    class MaskAsBool(value_mod.DeepQAgent):
+        def __init__(self, env, a):
+            super().__init__(env, a)
+            captured["agent"] = self
+            captured["init_Q"] = {k: v.clone().numpy() for k, v in self.Q.state_dict().items()}
+            captured["init_T"] = {k: v.clone().numpy() for k, v in self.target_Q.state_dict().items()}
+
+        def _lift(self, x, dtype=torch.float32, grad=False):
+            return super()._lift(x, dtype=torch.bool if dtype == torch.uint8 else dtype, grad=grad)
+
+        def sync_target_Q(self):
+            super().sync_target_Q()
+            rec["sync_weights"].append((st["t"], {k: v.clone().numpy() for k, v in self.Q.state_dict().items()}))
+
+    def randint(lo, hi):
+        assert (lo, hi) == (0, 4)
+        t = st["warm"]
+        st["warm"] = t + 1
+        return _random_action(seed, index, t)
+
+    def choice(n, size):
+        assert n == cap and size == batch, (n, size)  # the warm-up filled the buffer (warmup.py:14: replay_capacity steps)
+        step = st["learn"]
+        st["learn"] = step + 1
+        slots = [_minibatch_index(seed, b, step, cap) for b in range(batch)]
+        rec["rows"].append(slots)
+        head = (step + 1) % cap  # value.py:114 has just appended learn step `step`'s transition: ring slot step % cap; deque[0] is slot `head`
+        return np.array([(s_ - head) % cap for s_ in slots])
+
+    class PhiloxCategorical(Categorical):
+        def sample(self, sample_shape=torch.Size()):
+            t = st["t"]
+            if t == steps:
+                raise _Budget()
+            agent = captured["agent"]
+            probs = self.probs.numpy()
+            assert probs.shape == (4,)
+            u, a = _eps_greedy_draw(seed, index, t)
+            explore = u < agent.epsilon
+            sc = captured["last_scores"]
+            top = np.sort(sc)[::-1]
+            greedy = int(np.argmax(sc))
+            assert agent.epsilon >= 1.0 or int(np.argmax(probs)) == greedy
+            rec["eps"].append(float(agent.epsilon).hex())
+            rec["explored"].append(bool(explore))
+            rec["gaps"].append(float(top[0] - top[1]))
+            rec["scores"].append(sc.copy())
+            st["t"] = t + 1
+            return torch.tensor(a if explore else greedy)
+
+    orig_act = value_mod.DeepQAgent.act
+
+    def spy_act(self, state):  # value.py:89-92 itself, plus a look at the scores it ranks
+        out = orig_act(self, state)
+        with torch.no_grad():
+            captured["last_scores"] = self.Q(self._lift(state.flatten()).reshape(1, -1)).numpy()[0].copy()
+        return out
+
+    def make(env_name):
+        env = _BoardEnv(env_name)
+        env.env_index = index
+        made.append(env)
+        return env
+
+    class W(RecordingWriter):
+        def __init__(self, log_dir=None):
+            super().__init__(log_dir)
+            writers.append(self)
+
+    replay_after_warmup = {}
+    orig_warmup = ref_train.WARMUP_MAP["deep-q"]
+
+    def spy_warmup(agent, env, history, a):
+        out = orig_warmup(agent, env, history, a)
+        buf = list(agent.replay._buffer)
+        assert len(buf) == cap and st["warm"] == cap
+        replay_after_warmup.update(
+            states=np.stack([e.state.ravel() for e in buf]).astype(np.int8), successors=np.stack([e.successor.ravel() for e in buf]).astype(np.int8),
+            actions=np.asarray([e.action for e in buf], dtype=np.uint8), rewards=np.asarray([e.reward for e in buf], dtype=np.int32),
+            terminals=np.asarray([e.terminal for e in buf], dtype=np.uint8))
+        return out
+
+    gym = sys.modules["gym"]
+    orig = {"make": gym.make, "dummy_np": dummy_mod.np, "contain_np": contain_mod.np, "Categorical": value_mod.Categorical,
+            "agent": ref_train.AGENT_MAP["deep-q"], "writer": ref_train.SummaryWriter}
+    gym.make, ref_train.SummaryWriter = make, W
+    dummy_mod.np = _NumpyProxy(randint=randint, seed=lambda s_: None)
+    contain_mod.np = _NumpyProxy(choice=choice)
+    value_mod.Categorical = PhiloxCategorical
+    value_mod.DeepQAgent.act = spy_act
+    ref_train.AGENT_MAP["deep-q"] = MaskAsBool
+    ref_train.WARMUP_MAP["deep-q"] = spy_warmup
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # the broadcast warning of mse_loss
+            try:
+                ref_train.train(args)
+                raise AssertionError("the reference loop outlived its draw budget")
+            except _Budget:
+                pass
+            agent, env = captured["agent"], made[0]
+            assert len(env.actions_log) == cap + steps and st["learn"] == steps
+            final_Q = {k: v.clone().numpy() for k, v in agent.Q.state_dict().items()}
+            final_T = {k: v.clone().numpy() for k, v in agent.target_Q.state_dict().items()}
+            state_at_stop = {"final_board": [int(x) for x in env._obs().ravel()],
+                             "episode_return_at_stop": RecordingWriter._num(env._env.episode_return)}
+            # the reference's default_eval with the agent as trained so far, on the same env
+            tracked, eval_gaps = [], []
+            orig_tm = eval_mod.track_metrics
+
+            def spy_tm(history, env_, eval=False, write=True):
+                tracked.append([RecordingWriter._num(env_._env.episode_return), RecordingWriter._num(env_._env.get_last_performance())])
+                return orig_tm(history, env_, eval=eval, write=write)
+
+            def eval_act(self, state):
+                out = spy_act(self, state)
+                top = np.sort(captured["last_scores"])[::-1]
+                eval_gaps.append(float(top[0] - top[1]))
+                return out
+
+            eval_mod.track_metrics = spy_tm
+            value_mod.DeepQAgent.act = eval_act
+            try:
+                eh = make_meters({})
+                eh["writer"], eh["period"] = RecordingWriter(), 0
+                with torch.no_grad():
+                    eval_mod.default_eval(agent, env, eh, types.SimpleNamespace(eval_timesteps=DQN_EVAL_TIMESTEPS, eval_visualize_episodes=0))
+            finally:
+                eval_mod.track_metrics = orig_tm
+    finally:
+        torch.set_num_threads(threads)
+        gym.make, ref_train.SummaryWriter = orig["make"], orig["writer"]
+        dummy_mod.np, contain_mod.np, value_mod.Categorical = orig["dummy_np"], orig["contain_np"], orig["Categorical"]
+        value_mod.DeepQAgent.act = orig_act
+        ref_train.AGENT_MAP["deep-q"] = orig["agent"]
+        ref_train.WARMUP_MAP["deep-q"] = orig_warmup
+    calls = writers[0].calls
+    losses = np.array([float.fromhex(c[2]) for c in calls if c[0] == "scalar" and c[1] == "Train/value_loss"], dtype=np.float64)
+    eps_written = [c[2] for c in calls if c[0] == "scalar" and c[1] == "Train/epsilon"]
+    assert len(losses) == steps
+    episodes = {"returns": [], "safeties": [], "margins": [], "margins_support": []}
+    for c in calls:
+        if c[0] == "scalar" and c[1].startswith("Train/") and c[1][6:] in episodes:
+            episodes[c[1][6:]].append(c[2])
+    greedy_gaps = [g for g, e in zip(rec["gaps"], rec["explored"]) if not e]
+    min_gap, min_eval_gap = (min(greedy_gaps) if greedy_gaps else None), min(eval_gaps)
+    assert min_gap is None or min_gap > DQN_GREEDY_GAP, ("a greedy training step is a near-tie: pick another seed", min_gap)
+    assert min_eval_gap > DQN_GREEDY_GAP, ("a greedy evaluation step is a near-tie: pick another seed", min_eval_gap)
+    # this script's Philox against the oracle's
+    for t in (0, 1, steps - 1):
+        sc = rec["scores"][t]
+        assert int(env.actions_log[cap + t]) == int(O.eps_greedy(sc[None], float.fromhex(rec["eps"][t]), seed, index, t)[0])
+        assert rec["rows"][t] == [int(x) for x in O.minibatch_indices(seed, t, batch, cap)]
+    meta = {"argv": argv, "env": _made_name(args), "cheat": bool(args.cheat), "seed": seed, "index": index, "steps": steps,
+            "eval_timesteps": DQN_EVAL_TIMESTEPS, "lr": args.lr, "discount": args.discount, "epsilon": args.epsilon,
+            "epsilon_anneal": args.epsilon_anneal, "replay_capacity": cap, "sync_every": int(args.sync_every), "batch_size": batch,
+            "n_layers": int(args.n_layers), "n_hidden": int(args.n_hidden), "epsilon_used": rec["eps"], "epsilon_written": eps_written,
+            "explored": [int(e) for e in rec["explored"]], "min_greedy_gap": min_gap, "min_eval_gap": min_eval_gap,
+            "syncs_at": [t for t, _ in rec["sync_weights"]], "episodes": episodes, "final_board": state_at_stop["final_board"],
+            "episode_return_at_stop": state_at_stop["episode_return_at_stop"], "eval_episodes": tracked,
+            "eval_actions": "".join(str(int(a)) for a in env.actions_log[cap + steps:]), "torch_version": torch.__version__,
+            "weight_keys": list(final_Q.keys()),
+            "shims": ["terminals lifted as bool instead of uint8 (value.py:179)", "the env hands out (H, W) boards (value.py:66-67)"]}
+    arrays = {"actions": np.asarray(env.actions_log[cap:cap + steps], dtype=np.uint8), "losses": losses,
+              "rows": np.asarray(rec["rows"], dtype=np.int64), "gaps": np.asarray(rec["gaps"], dtype=np.float64),
+              "scores": np.stack(rec["scores"]).astype(np.float32)}
+    arrays.update({"warm_" + k: v for k, v in replay_after_warmup.items()})
+    for tag, sd in (("init_Q_", captured["init_Q"]), ("init_T_", captured["init_T"]), ("final_Q_", final_Q), ("final_T_", final_T)):
+        arrays.update({tag + k.replace(".", "_"): v for k, v in sd.items()})
+    for i, (_, sd) in enumerate(rec["sync_weights"]):
+        arrays.update({"sync%d_Q_" % i + k.replace(".", "_"): v for k, v in sd.items()})
+    np.savez_compressed(os.path.join(HERE, name), meta=np.array(json.dumps(meta, separators=(",", ":"))), **arrays)
+    print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes; min greedy gap %s (training), %.2e (evaluation); explored %d of %d; "
+          "syncs at %s; losses %.4g .. %.4g" % (min_gap, min_eval_gap, sum(rec["explored"]), steps, meta["syncs_at"], losses[0], losses[-1]))
+
+
 def main():
     _install_stubs()
     only = sys.argv[1:]  # optional: substrings of the fixture names to (re)make, e.g. `make_golden.py batched_ppo`
@@ -986,14 +1250,11 @@ def main():
 
     if only:
         print("only fixtures matching", only)
-    if not only:
-        golden_discounted_returns()
-        golden_epsilon()
-        golden_meters()
-        golden_rng()
-        golden_warmup()
-        golden_deepq_forward()
-        golden_deepq_learn()
+    for fn, produces in ((golden_discounted_returns, "discounted_returns.json"), (golden_epsilon, "epsilon_schedule.json"),
+                         (golden_meters, "meters.json"), (golden_rng, "numpy_rng.json"), (golden_warmup, "dqn_warmup.json"),
+                         (golden_deepq_forward, "deepq_forward.npz"), (golden_deepq_learn, "deepq_learn.npz")):
+        if not only or any(o in produces for o in only):
+            fn()
     run(golden_train, "train_boat_tabq_seed7.json",
                  ["-S", "7", "-E", "30", "-EE", "10", "-V", "250", "-EV", "0", "boat", "tabular-q", "-l", ".5"])
     run(golden_train, "train_island_tabq_seed1.json",
@@ -1092,6 +1353,13 @@ def main():
     run(golden_batched_ppo, "batched_ppo_whisky_cheat_gather.npz",
                        ["-S", "3", "-E", "2"] + common + ["-C", "whisky", "ppo-mlp", "-l", "0.001", "-r", "12", "-e", "2", "-b", "64"], 300,
                        learn=False)
+    # ... and DeepQ (closes A12): train() with DeepQAgent + dqn_warmup + dqn_learn on ONE env index, 300+ agent steps crossing
+    # sync_target_Q; reproduced on the GPU by an N = 1 BatchedDeepQAgent (sgk_policy_act + sgk_replay_store + sgk_dqn_sgd_step)
+    run(golden_batched_dqn, "batched_dqn_sokoban.npz",
+                       ["-S", "17", "sokoban", "deep-q", "-l", "0.001", "-e", "0.05", "-dl", "150", "-r", "200", "-s", "100"], 3, 330)
+    run(golden_batched_dqn, "batched_dqn_boat_cheat.npz",
+                       ["-S", "35", "-C", "-D", "0.9", "boat", "deep-q", "-l", "0.002", "-e", "0.1", "-dl", "120", "-r", "160", "-s", "120",
+                        "-b", "48", "-hd", "64"], 70000, 320)
     # the reference tree must be left untouched
     leaked = [os.path.join(d, f) for d, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc")]
     assert not leaked, leaked

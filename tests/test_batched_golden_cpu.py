@@ -215,3 +215,110 @@ def test_oracle_and_host_agent_reproduce_the_reference_ppo_run(name, monkeypatch
                     break
                 b.reset(0)
         assert t == len(acts) and ep == len(agent["eval_episodes"])
+
+
+# ---- DeepQ: tests/golden/batched_dqn_*.npz (the reference's train() with DeepQAgent + dqn_warmup + dqn_learn on one env index) --------
+
+@pytest.mark.parametrize("name", BG.DQN_FIXTURES)
+def test_host_deepq_train_reproduces_the_reference_dqn_run(name, monkeypatch):
+    """This repo's host mirror -- trainer.train, loops.dqn_warmup / dqn_learn / whiler, agents.DeepQAgent / ReplayBuffer / RandomAgent --
+    on the oracle's env of the fixture's env index, its three random calls answered from the oracle's counter-RNG restatements
+    (orc_random_action, orc_eps_greedy, orc_minibatch_index: the functions the GPU tests check the kernels' draws against): every
+    action, every Train/value_loss (same torch CPU ops in the same order: in practice bit-equal, rtol 1e-5 for another torch build) and
+    the final weights equal what the reference's own classes produced. Links the oracle's draw functions and the host agent to
+    reference output; the GPU test links the kernels to the same file."""
+    import types
+    import warnings
+
+    import torch
+
+    import safe_grid_agents_amd as S
+    from oracle.gym_shim import OracleGridworldEnv
+
+    fx = BG.DqnFixture(name)
+    m = fx.meta
+    cap, steps, seed, index = fx.capacity, fx.steps, fx.seed, fx.index
+    st = {"warm": 0, "t": 0, "learn": 0}
+
+    class Budget(Exception):
+        pass
+
+    class IndexedEnv(OracleGridworldEnv):  # the env of this index as the batch creates it
+        def __init__(self, env_name):
+            super().__init__(env_name)
+            self._b = O.EnvBatch(self._b.env_id, 1, seed=seed, env_begin=index)
+
+    class PhiloxDeepQ(S.DeepQAgent):
+        def act_explore(self, state):  # value.py:94-96 with Categorical.sample() answered from stream 2
+            if st["t"] == steps:
+                raise Budget()
+            probs = self.policy(state).probs.numpy()
+            with torch.no_grad():
+                sc = self.Q(self._lift(np.asarray(state).flatten()).reshape(1, -1)).numpy()
+            a = int(O.eps_greedy(sc, self.epsilon, seed, index, st["t"])[0])
+            assert probs[a] > 0 and abs(probs.sum() - 1) < 1e-6
+            st["t"] += 1
+            return a
+
+    def randint(lo, hi):
+        st["warm"] += 1
+        return int(O.random_action(seed, index, st["warm"] - 1))
+
+    def choice(n, size):
+        assert n == cap
+        step = st["learn"]
+        st["learn"] += 1
+        slots = O.minibatch_indices(seed, step, size, cap)
+        assert (slots == fx.rows[step]).all()
+        return (slots - (step + 1) % cap) % cap  # ring slot -> position in the deque (position 0 = the slot written next)
+
+    monkeypatch.setattr(np.random, "randint", randint)
+    monkeypatch.setattr(np.random, "choice", choice)
+    monkeypatch.setitem(S.trainer.AGENT_MAP, "deep-q", PhiloxDeepQ)
+    args = types.SimpleNamespace(seed=seed, env_alias={v: k for k, v in S.ENV_MAP.items()}[fx.env], agent_alias="deep-q", episodes=10**9,
+                                 eval_every=10**9, eval_timesteps=fx.eval_timesteps, eval_visualize_episodes=0, discount=m["discount"],
+                                 cheat=fx.cheat, log_dir=None, device="cpu", lr=m["lr"], epsilon=m["epsilon"],
+                                 epsilon_anneal=m["epsilon_anneal"], replay_capacity=cap, sync_every=fx.sync_every, n_layers=m["n_layers"],
+                                 n_hidden=m["n_hidden"], batch_size=fx.batch, log_gradients=False)
+    writers, agents = [], []
+    orig_init = PhiloxDeepQ.__init__
+
+    def init(self, env, a):
+        orig_init(self, env, a)
+        for net, tag in ((self.Q, "init_Q"), (self.target_Q, "init_T")):
+            net.load_state_dict({k: torch.as_tensor(v) for k, v in fx.weights(tag).items()})
+        agents.append(self)
+
+    monkeypatch.setattr(PhiloxDeepQ, "__init__", init)
+    envs = []
+
+    def factory(env_name):
+        envs.append(IndexedEnv(env_name))
+        return envs[-1]
+
+    def wf(d):
+        writers.append(S.RecordingWriter(d))
+        return writers[-1]
+
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with pytest.raises(Budget):
+                S.train(args, env_factory=factory, writer_factory=wf)
+    finally:
+        torch.set_num_threads(threads)
+    agent, env = agents[0], envs[0]
+    assert st == {"warm": cap, "t": steps, "learn": steps}
+    assert env.actions_log[:cap] == fx.warm("actions").tolist()
+    assert env.actions_log[cap:] == fx.actions.tolist()
+    calls = writers[0].calls
+    losses = np.array([float.fromhex(c[2]) if isinstance(c[2], str) else float(c[2]) for c in calls if c[1] == "Train/value_loss"])
+    np.testing.assert_allclose(losses, fx.losses, rtol=1e-5)
+    eps = [c[2] for c in calls if c[1] == "Train/epsilon"]
+    assert eps == m["epsilon_written"]
+    for tag, net in (("final_Q", agent.Q), ("final_T", agent.target_Q)):
+        for k, v in fx.weights(tag).items():
+            np.testing.assert_allclose(net.state_dict()[k].numpy(), v, rtol=1e-4, atol=1e-6, err_msg=tag + " " + k)
+    assert env._obs().ravel().astype(np.int8).tolist() == m["final_board"]

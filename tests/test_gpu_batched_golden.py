@@ -275,3 +275,88 @@ def test_batched_ppo_reproduces_the_reference_ppo_run(name, how):
         assert bm.episodes == sum(len(a["eval_episodes"]) for a in fx.agents)
     finally:
         env.close()
+
+
+# ---- DeepQ (A12): tests/golden/batched_dqn_*.npz -- the reference's train() with DeepQAgent + dqn_warmup + dqn_learn on one env index,
+# its random calls answered from the counter RNG (streams 0 / 2 / 4) -------------------------------------------------------------------
+
+def _load_q(torch, net, sd, device):
+    net.load_state_dict({k: torch.as_tensor(v).to(device) for k, v in sd.items()})
+
+
+@pytest.mark.parametrize("name", BG.DQN_FIXTURES)
+def test_batched_deepq_n1_reproduces_the_reference_dqn_run(name):
+    """An N = 1 BatchedDeepQAgent (sgd_steps = 1, replay ring = replay_capacity slices) from the reference's initial weights:
+    warmup() (the streamed random rollout, one launch) leaves the replay the reference's dqn_warmup left (including warmup.py:17-21's
+    never-advanced `state`); then every lockstep step = sgk_replay_store + sgk_policy_act + sgk_step + sgk_dqn_sgd_step (loss_mode =
+    the reference's [B,1]-vs-[B] broadcast, value.py:119-123) takes the reference's action exactly, draws the reference's minibatch,
+    logs the reference's Train/value_loss and, across three sync_target_Q, lands on the reference's weights (fp32 in another summation
+    order: see the tolerances below); batched_default_eval of the result books the reference's greedy evaluation episodes."""
+    from oracle import oracle as O
+
+    torch = _torch()
+    fx = BG.DqnFixture(name)
+    env = S.BatchedGridworldEnv(fx.env, 1, seed=fx.seed, env_index_base=fx.index)
+    env.bind_torch_stream()
+    agent = S.BatchedDeepQAgent(env, fx.args(), sgd_steps=1, replay_slices=fx.capacity)
+    try:
+        assert agent.fused_policy and agent.fused_learn and agent.reference_loss_broadcast
+        _load_q(torch, agent.Q, fx.weights("init_Q"), agent.device)
+        _load_q(torch, agent.target_Q, fx.weights("init_T"), agent.device)
+        agent._refresh_fused_weights()
+        agent._fl["w2t"].copy_(agent.Q[1][0][0].weight.data.t())
+        agent._refresh_target_transposes()
+        reset_board = env.boards_host().reshape(-1).copy()
+        # ---- dqn_warmup ----
+        agent.warmup(fx.capacity)
+        rp = agent.replay
+        assert rp.filled == fx.capacity and rp.head == 0
+        term = fx.warm("terminals") != 0
+        assert (rp.states[:, 0].cpu().numpy() == fx.warm("states")).all()
+        want_succ = np.where(term[:, None], reset_board[None], fx.warm("successors"))  # (the ring's convention at an episode's last step)
+        assert (rp.successors[:, 0].cpu().numpy() == want_succ).all()
+        assert (rp.actions[:, 0].cpu().numpy() == fx.warm("actions")).all()
+        assert (rp.rewards[:, 0].cpu().numpy().astype(np.int32) == fx.warm("rewards")).all()
+        assert (rp.terminals[:, 0].cpu().numpy() == term).all()
+        # ---- dqn_learn, step by step (train.py:62-70: every episode starts from a reset) ----
+        env.reset()
+        env.metrics_reset()
+        got_actions, got_losses, drift = [], [], 0.0
+        syncs = 0
+        for t in range(fx.steps):
+            assert agent.epsilon == fx.epsilon_used[t], (t, agent.epsilon, fx.epsilon_used[t])
+            sc = agent.scores().cpu().numpy()[0]
+            drift = max(drift, float(np.abs(sc - fx.scores[t]).max()))
+            a = agent.step(learn=True, cheat=fx.cheat)
+            got_actions.append(int(a[0]))
+            got_losses.append(float(agent.last_loss))
+            assert got_actions[-1] == int(fx.actions[t]), (t, got_actions[-1], int(fx.actions[t]), sc, fx.scores[t], float(fx.gaps[t]),
+                                                           bool(fx.explored[t]), drift)
+            if t % fx.sync_every == fx.sync_every - 1:  # the reference's Q at this sync_target_Q
+                for key, v in fx.weights("sync%d_Q" % syncs).items():
+                    np.testing.assert_allclose(agent.target_Q.state_dict()[key].cpu().numpy(), v, rtol=DQN_RTOL, atol=DQN_ATOL,
+                                               err_msg="%s at sync %d" % (key, syncs))
+                syncs += 1
+        assert syncs == len(fx.meta["syncs_at"]) >= 1
+        print("%s: max |Q - reference Q| over %d steps = %.3g (smallest greedy gap of the fixture %.3g)" % (name, fx.steps, drift,
+                                                                                                        fx.meta["min_greedy_gap"]))
+        np.testing.assert_allclose(np.array(got_losses), fx.losses, rtol=DQN_LOSS_RTOL, atol=1e-6)
+        for tag, net in (("final_Q", agent.Q), ("final_T", agent.target_Q)):
+            for key, v in fx.weights(tag).items():
+                np.testing.assert_allclose(net.state_dict()[key].cpu().numpy(), v, rtol=DQN_RTOL, atol=DQN_ATOL, err_msg="%s %s" % (tag, key))
+        assert int(agent._fl["step"].cpu()) == fx.steps and agent.t == fx.steps
+        assert (env.boards_host().reshape(-1) == np.array(fx.meta["final_board"], dtype=np.int8)).all()
+        assert int(env.episode_state_host()["episode_return"][0]) == fx.units(fx.meta["episode_return_at_stop"])
+        m = env.metrics()
+        want = fx.episode_metrics()
+        assert int(m[O.M_EPISODES]) == want["episodes"] and int(m[O.M_SUM_RETURN]) == want["sum_return"]
+        assert int(m[O.M_SUM_SAFETY]) == want["sum_safety"]
+        # ---- default_eval, greedy ----
+        bm = S.batched_default_eval(agent, env, fx.eval_timesteps)
+        BG.assert_eval_metrics(bm.vec, fx, O)
+    finally:
+        env.close()
+
+
+# weights after 300+ Adam(amsgrad) steps in float32 with another summation order than torch's CPU kernels
+DQN_RTOL, DQN_ATOL, DQN_LOSS_RTOL = 2e-4, 2e-5, 2e-4

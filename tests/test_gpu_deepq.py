@@ -12,6 +12,16 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def _assert_adam_close(got, want, lr, n_steps, what):
+    """Parameters after n_steps Adam steps, float32 in two summation orders: rtol 2e-4 / atol 2e-6 -- except that Adam's first steps
+    divide every gradient element by its own magnitude, so the few elements whose gradient is a sum cancelling to rounding level
+    (relative error of the sum ~1e-3) move by lr x that error per step: at most 0.5 % of a tensor's elements may lie outside the
+    tolerance, and none by more than 1e-2 x lr x n_steps."""
+    bad = np.abs(got - want) > 2e-6 + 2e-4 * np.abs(want)
+    assert bad.mean() <= 5e-3, (what, int(bad.sum()), bad.size)
+    assert np.abs(got - want).max() <= 1e-2 * lr * n_steps + 2e-6 + 2e-4 * np.abs(want).max(), (what, float(np.abs(got - want).max()))
+
+
 def _args(**kw):
     d = dict(discount=0.99, lr=1e-3, batch_size=64, sync_every=20, epsilon=0.05, epsilon_anneal=200, n_layers=2,
              n_hidden=100)
@@ -305,18 +315,25 @@ def test_fused_greedy_eval_and_act_rollout_equal_the_stepwise_paths(name):
 
 @pytest.mark.parametrize("name,hidden,batch", [("SideEffectsSokoban-v0", 100, 64), ("BoatRace-v0", 64, 32), ("DistributionalShift-v0", 100, 48),
                                                ("TomatoWatering-v0", 100, 64), ("ConveyorBelt-v0", 64, 48), ("FriendFoe-v0", 100, 32)])
-def test_fused_dqn_sgd_step_equals_torch_autograd_adam(name, hidden, batch):
+@pytest.mark.parametrize("broadcast", [True, False], ids=["reference_broadcast_loss", "per_sample_loss"])
+def test_fused_dqn_sgd_step_equals_torch_autograd_adam(name, hidden, batch, broadcast):
     """sgk_dqn_sgd_step (sampling, both forwards, TD target, MSE, backward, clip_grad_norm_(10), Adam amsgrad in ONE kernel)
     vs the same update by torch on the CPU in fp32 with the minibatch the kernel's counter RNG selects (indices restated by
-    the oracle). Floating point, different summation order: parameters and loss agree to rtol 2e-4 / atol 2e-6 over three
-    consecutive steps; the transposed copies the kernel maintains equal the updated weights exactly."""
+    the oracle). broadcast: F.mse_loss on Qs [B,1] against expected_Qs [B], the shapes value.py:119-123 hands it (the kernel's
+    SGK_DQN_LOSS_REFERENCE, the default); else the squeezed per-sample loss (SGK_DQN_LOSS_PER_SAMPLE). Floating point, different
+    summation order: parameters (see _assert_adam_close) and loss (rtol 2e-4) agree over three consecutive steps; the transposed copies
+    the kernel maintains equal the updated weights exactly. (The reference's own learn() output is pinned by
+    test_fused_dqn_sgd_step_reproduces_the_reference_learn_steps and tests/test_gpu_batched_golden.py.)"""
+    import warnings
+
     import torch
 
     torch.manual_seed(13)
     n, seed, slices = 600, 41, 4
     env = S.BatchedGridworldEnv(name, n, seed=seed)
     env.bind_torch_stream()
-    agent = S.BatchedDeepQAgent(env, _args(n_hidden=hidden, batch_size=batch, lr=1e-2, discount=0.9), replay_slices=slices)
+    agent = S.BatchedDeepQAgent(env, _args(n_hidden=hidden, batch_size=batch, lr=1e-2, discount=0.9), replay_slices=slices,
+                                reference_loss_broadcast=broadcast)
     assert agent.fused_learn
     with torch.no_grad():
         for p in agent.Q.parameters():
@@ -339,24 +356,80 @@ def test_fused_dqn_sgd_step_equals_torch_autograd_adam(name, hidden, batch):
     for step in range(3):
         loss_gpu = float(agent.learn_batch().cpu())
         ix = torch.as_tensor(O.minibatch_indices(seed, step, batch, slices * n))
-        q_sa = cpu_q(st[ix].float()).gather(1, ac[ix].long().unsqueeze(1)).squeeze(1)
+        q_sa = cpu_q(st[ix].float()).gather(1, ac[ix].long().unsqueeze(1))  # [B, 1], as value.py:119
         with torch.no_grad():
             nq = cpu_t(su[ix].float()).max(1)[0]
             nq = torch.where(te[ix], torch.zeros_like(nq), nq)
             expected = 0.9 * nq + (rw[ix].double() * float(env.reward_scale)).float()  # the replay holds integer rewards (tomato: counts)
-        loss = torch.nn.functional.mse_loss(q_sa, expected)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # torch warns about exactly this broadcast
+            loss = torch.nn.functional.mse_loss(q_sa if broadcast else q_sa.squeeze(1), expected)
         opt.zero_grad()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(cpu_q.parameters(), 10.0)
         opt.step()
         assert abs(loss_gpu - float(loss.detach())) <= 2e-4 * abs(float(loss.detach())) + 2e-6, (step, loss_gpu, float(loss.detach()))
         for (k, v), (k2, v2) in zip(agent.Q.state_dict().items(), cpu_q.state_dict().items()):
-            np.testing.assert_allclose(v.cpu().numpy(), v2.numpy(), rtol=2e-4, atol=2e-6, err_msg="%s step %d" % (k, step))
+            _assert_adam_close(v.cpu().numpy(), v2.numpy(), 1e-2, step + 1, "%s step %d" % (k, step))
     assert int(agent._fl["step"].cpu()) == 3
     assert (agent._fw["w1t"].cpu() == agent.Q[0][0].weight.data.t().cpu()).all()
     assert (agent._fl["w2t"].cpu() == agent.Q[1][0][0].weight.data.t().cpu()).all()
     assert (agent._fw["w3t"].cpu() == agent.Q[2].weight.data.t().cpu()).all()
     env.close()
+
+
+def test_fused_dqn_sgd_step_reproduces_the_reference_learn_steps():
+    """tests/golden/deepq_learn.npz -- the reference's own DeepQAgent.learn (value.py:113-136) called 14 times, its replay positions
+    recorded -- through sgk_dqn_sgd_step: the same transitions written into a 10-slot device ring (slot = step % capacity, as the
+    deque evicts), the same minibatch handed in as `rows`, a target sync after step 7. Every step's loss and the final weights of
+    the Q-network equal the reference's to fp32 tolerance (another summation order): this is the kernel against reference output,
+    including the [B,1]-vs-[B] mse_loss broadcast -- the losses of the squeezed form differ from step 2 on by far more."""
+    import json
+    import os
+
+    import torch
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "deepq_learn.npz"))
+    meta = json.loads(str(z["meta"]))
+    cap, B, steps = meta["replay_capacity"], meta["batch_size"], meta["steps"]
+    assert (meta["H"], meta["W"]) == (6, 6) and meta["n_hidden"] in (64, 100)
+    outs = {}
+    for broadcast in (True, False):
+        env = S.BatchedGridworldEnv("SideEffectsSokoban-v0", 1, seed=1)  # a 6 x 6 level: the handle gives the kernel its board size
+        env.bind_torch_stream()
+        agent = S.BatchedDeepQAgent(env, _args(n_hidden=meta["n_hidden"], batch_size=B, lr=meta["lr"], discount=meta["discount"]),
+                                    replay_slices=cap, reference_loss_broadcast=broadcast)
+        assert agent.fused_learn
+        dev = agent.device
+        for net, tag in ((agent.Q, "init_Q_"), (agent.target_Q, "init_T_")):
+            net.load_state_dict({k: torch.as_tensor(z[tag + k.replace(".", "_")]).to(dev) for k in net.state_dict().keys()})
+        agent._refresh_fused_weights()
+        agent._fl["w2t"].copy_(agent.Q[1][0][0].weight.data.t())
+        agent._refresh_target_transposes()
+        rp = agent.replay
+        losses = []
+        used = torch.zeros(B, dtype=torch.int64, device=dev)
+        for k in range(steps):
+            slot = k % cap  # ReplayBuffer.add (contain.py:15-17): the deque evicts its oldest entry = the ring overwrites slot k % capacity
+            rp.states[slot, 0] = torch.as_tensor(z["states"][k].reshape(-1).astype(np.int8)).to(dev)
+            rp.successors[slot, 0] = torch.as_tensor(z["successors"][k].reshape(-1).astype(np.int8)).to(dev)
+            rp.actions[slot, 0] = int(z["actions"][k])
+            rp.rewards[slot, 0] = int(z["rewards"][k])
+            rp.terminals[slot, 0] = bool(z["terminals"][k])
+            rp.filled = min(k + 1, cap)
+            oldest = (k + 1) % cap if k + 1 >= cap else 0  # the ring slot of deque position 0
+            rows = torch.as_tensor((oldest + z["sample_ix"][k]) % rp.filled, dtype=torch.int64).to(dev)
+            losses.append(float(agent._learn_batch_fused(rows=rows, rows_out=used).cpu()))
+            assert (used.cpu() == rows.cpu()).all()
+            if k + 1 == meta["sync_after_step"]:
+                agent.sync_target_Q()
+        outs[broadcast] = (np.array(losses), {k: v.cpu().numpy() for k, v in agent.Q.state_dict().items()})
+        env.close()
+    losses, final = outs[True]
+    np.testing.assert_allclose(losses, z["losses"], rtol=2e-4)
+    for k, v in final.items():
+        np.testing.assert_allclose(v, z["final_Q_" + k.replace(".", "_")], rtol=2e-4, atol=2e-6, err_msg=k)
+    assert not np.allclose(outs[False][0][1:], z["losses"][1:], rtol=1e-2)  # the per-sample loss is another computation
 
 
 def test_train_batched_cli_deepq():
@@ -390,7 +463,7 @@ def test_conv_q_body_option_shapes_env_parity_and_learning_on_boat_race():
     env.bind_torch_stream()
     orc = O.EnvBatch("BoatRace-v0", n)
     agent = S.BatchedDeepQAgent(env, _args(lr=2e-3, epsilon=0.1, epsilon_anneal=150, sync_every=25, n_channels=4), sgd_steps=2,
-                                replay_slices=16, q_body="cnn")
+                                replay_slices=16, q_body="cnn", reference_loss_broadcast=False)  # (the textbook loss: the test asks for learning)
     assert agent.q_body == "cnn" and not agent.fused_policy and not agent.fused_learn
     obs = env.obs_f32()
     q = agent.scores(obs)
