@@ -441,7 +441,7 @@ def run_config(args):
     out = {"config": args.config, "n_gpus": 1, "data": "synthetic", "higher_is_better": True}
     if args.config == 2:
         name, n = "BoatRace-v0", 65536
-        env = S.BatchedGridworldEnv(name, n, device=dev, seed=args.seed, layout="compact")
+        env = S.BatchedGridworldEnv(name, n, device=dev, seed=args.seed, layout="compact", stream="own")
         env.step_random(200, auto_reset=True)
         per = {}
         per["launch"] = ev_time(env, lambda: env.step_random(100, auto_reset=True), 20) / 100
@@ -465,7 +465,7 @@ def run_config(args):
     elif args.config == 3:
         name, n = "IslandNavigation-v0", 262144
         targs = types.SimpleNamespace(lr=0.5, discount=0.99, epsilon=0.01, epsilon_anneal=100000)
-        env = S.BatchedGridworldEnv(name, n, device=dev, seed=args.seed)
+        env = S.BatchedGridworldEnv(name, n, device=dev, seed=args.seed, stream="own")
         agent = S.BatchedTabularQAgent(env, targs)
         agent.rollout(200)
         steps_per_launch = 1000
@@ -718,8 +718,10 @@ def run_rank(args):
             rb, rr, info = e.alloc_trajectory_ring(RING_SLICES, backing="torch")
         return (rb, rr), info
 
+    # (stream="own": the handle's private stream, made torch's current stream for the timed region -- the configuration every round
+    # measured; the wrapper's default would be torch's default stream, the device's NULL stream)
     env = S.BatchedGridworldEnv(args.env, n_local, device=local_rank, seed=args.seed, env_index_base=base,
-                                layout=args.layout)
+                                layout=args.layout, stream="own")
     stream = env.torch_stream()
     comm = sdist.library_comm(env)  # the RCCL communicator of the metrics all-reduce is made HERE (N > 1), not inside a timed region
     sdist.require_library_comm(comm, world, backend)  # N > 1 over RCCL never passes on torch.distributed's all-reduce unnoticed
@@ -868,7 +870,7 @@ def run_rank(args):
         del ring, held
         per = 1 << 20
         wenv = S.BatchedGridworldEnv(args.env, per, device=local_rank, seed=args.seed, env_index_base=rank * per,
-                                     layout=args.layout)
+                                     layout=args.layout, stream="own")
         wring, winfo = alloc_ring(wenv, args.ring_backing) if args.path == "ring" else (None, None)
         w_el, w_ms, _ = timed_steps(wenv, k_lock, w_lock, barrier, sdist.global_metrics, path=args.path, ring=wring)
         w_el, w_ms = max_over_ranks(w_el, w_ms)

@@ -10,9 +10,11 @@
  * SGK_ERR_* and leaves a message for sgk_last_error() (thread-local, a fixed buffer: reporting an error allocates nothing).
  * No C++ exception leaves the library: every entry point is a function-try-block (SGK_ERR_NOMEM / SGK_ERR_INTERNAL). Handles are opaque and
  * thread-compatible (one thread at a time per handle; different handles may be driven from different threads at the same time: the
- * library serialises its own hipGraph captures and makes no synchronous legacy-stream call on a handle's path -- on ROCm such a call
- * from ANY thread invalidates a capture in progress on any stream -- and records a capture again when a caller's own synchronous
- * call, e.g. PyTorch's, invalidated it). Pointers named *_dev are DEVICE pointers
+ * library serialises its own hipGraph captures against each other and against its own synchronous legacy-stream calls -- on ROCm such a
+ * call from ANY thread invalidates a capture in progress on any stream. A handle on a stream of its own or on a caller's non-NULL
+ * stream makes none on its path; a handle bound to the device's NULL stream (sgk_use_default_stream: PyTorch's default) waits for
+ * that stream in its synchronising entry points, and takes the capture lock while it does. A capture that a caller's own synchronous
+ * call, e.g. PyTorch's, invalidated all the same is recorded again). Pointers named *_dev are DEVICE pointers
  * valid on the handle's GPU (e.g. torch tensor.data_ptr()); pointers named *_host are host memory.
  * All work is enqueued on the handle's HIP stream; only functions documented as synchronising wait.
  */
@@ -65,6 +67,7 @@ extern "C" {
 #define SGK_F_AUTO_RESET 1u /* an env whose episode ends is reset in the same step (after its episode is recorded) */
 #define SGK_F_NO_BOARDS 2u  /* do not materialise observation boards this call (they go stale until the next writing call) */
 #define SGK_F_RING_TILE_MAJOR 8u /* sgk_rollout_random_stream: the trajectory rings are laid out tile-major (see there) */
+#define SGK_F_SEPARATE_LAUNCHES 16u /* sgk_tabq_learn_steps: four launches per lockstep step instead of one */
 #define SGK_F_MASK_FINISHED 4u /* sgk_policy_rollout: rows of states_out / actions_out of an env whose episode is over are zeros */
 
 /* board layouts (sgk_create_ex) */
@@ -318,10 +321,20 @@ SGK_API int sgk_tabq_act(sgk_tabq *q, int explore, uint8_t *actions_out_dev);
 /* learn + update_epsilon after sgk_step (value.py:44-58; learn.py:72-82). cheat != 0 learns from the hidden
  * reward and the actual action. */
 SGK_API int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat);
-/* n_steps of the drop-in call sequence {sgk_tabq_act(explore), sgk_step, sgk_tabq_learn, sgk_reset_done} -- tabq_learn's loop
- * body (reference learn.py:61-85) with train.py:62-70's reset after done -- as four launches per lockstep step replayed from
- * ONE hipGraph per (n_steps, cheat, flags): the agent step counter lives in device memory. flags: SGK_F_NO_BOARDS or 0.
- * Same results as the four calls made n_steps times. */
+/* ONE lockstep step of tabq_learn (reference learn.py:61-85 inside train.py:62-70) for every (env, agent) pair in ONE launch:
+ * act_explore (value.py:37-42) -> env.step (learn.py:69) -> learn (value.py:44-52; --cheat: learn.py:72-79) -> update_epsilon
+ * (value.py:54-58) -> env.reset() of the envs whose episode ended (train.py:62-64). Same results, bit for bit, as the four calls
+ * {sgk_tabq_act(explore = 1), sgk_step, sgk_tabq_learn, sgk_reset_done}, and the same things left for the caller to read: the
+ * step records as sgk_step writes them (sgk_step_records_dev), the boards (sgk_boards_dev: of the new episode's first state
+ * where the step ended one, as sgk_reset_done leaves them; flags = SGK_F_NO_BOARDS skips them), the episode arrays, the metrics.
+ * actions_out_dev: uint8 [n_envs] that receives the chosen actions, or NULL. May be mixed freely with the per-step calls and the
+ * rollouts. */
+SGK_API int sgk_tabq_step(sgk_tabq *q, int cheat, uint32_t flags, uint8_t *actions_out_dev);
+/* n_steps lockstep steps of tabq_learn replayed from ONE hipGraph per (n_steps, cheat, flags): n_steps launches of sgk_tabq_step's
+ * kernel (the agent step counter lives in device memory). flags: SGK_F_NO_BOARDS and / or SGK_F_SEPARATE_LAUNCHES -- the latter
+ * records the drop-in call sequence {sgk_tabq_act(explore), sgk_step, sgk_tabq_learn, sgk_reset_done} instead, four launches
+ * per lockstep step (the form of rounds 2-5; kept for A/B and because it exercises the per-step kernels). Same results either
+ * way, and the same as the calls made n_steps times. */
 SGK_API int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags);
 /* n_steps of {act_explore, env.step, learn, update_epsilon, reset on done} in one launch
  * (reference learn.py:61-85 inside train.py:62-70) */

@@ -38,6 +38,7 @@ struct sgk_env {
   uint8_t *pinned = nullptr;         // host staging for sgk_step_host: [actions n][rec 4n][state 8n][boards n*n_cells]
   uint64_t *copy_chunk = nullptr;    // pinned staging of sgk_copy_episode_state: 2^17 state words at a time
   hipEvent_t order_events[2] = {nullptr, nullptr};  // sgk_stream_wait / sgk_stream_signal
+  hipEvent_t switch_event = nullptr;                // sgk_set_stream / sgk_use_default_stream: old stream -> new stream
   long long *metrics_pinned = nullptr;  // [SGK_METRICS_LEN] pinned device-mapped host words the reduce kernel also writes
   float *gamma_dev = nullptr;        // [1024] float32(discount ** t) for sgk_discounted_returns
   double gamma_discount = -1.0;
@@ -154,7 +155,7 @@ int sgk_destroy(sgk_env *h) try {
   if (!h) return SGK_OK;
   (void)hipSetDevice(h->sh.device);
   (void)stop_server(h);
-  (void)hipStreamSynchronize(h->stream);  // nullptr = the NULL stream
+  (void)sgk::host::wait_stream(h->stream);  // nullptr = the NULL stream
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   h->graphs.clear();
   sgk::Shard &s = h->sh;
@@ -181,6 +182,7 @@ int sgk_destroy(sgk_env *h) try {
   if (h->metrics_pinned) (void)hipHostFree(h->metrics_pinned);
   for (int i = 0; i < 2; ++i)
     if (h->order_events[i]) (void)hipEventDestroy(h->order_events[i]);
+  if (h->switch_event) (void)hipEventDestroy(h->switch_event);
   if (h->own_stream) return_stream(h->sh.device, h->own_stream);  // (idle: synchronised above)
   delete h;
   return SGK_OK;
@@ -304,7 +306,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
     // on the handle's stream, not hipMemcpy: a synchronous legacy-stream copy collides with another thread's graph capture
     // (sgk::capture_mutex); waited for here because `image` dies with this block
     SGK_TRY(hipMemcpyAsync(s.rules_dev, image, sizeof(image), hipMemcpyHostToDevice, h->stream));
-    SGK_TRY(hipStreamSynchronize(h->stream));
+    SGK_TRY(sgk::host::wait_stream(h->stream));
   }
   SGK_TRY(hipMemsetAsync(s.rec, 0, sizeof(uint32_t) * n_pad, h->stream));
   SGK_TRY(hipMemsetAsync(s.last_return, 0, sizeof(int32_t) * n_pad, h->stream));
@@ -316,7 +318,7 @@ int sgk_create_ex(int env_id, int64_t n_envs, int device, uint64_t seed, uint64_
   SGK_TRY(sgk::launch_metrics_reduce(s, h->stream));
   SGK_TRY(sgk::launch_aux_init(s, h->stream));
   SGK_TRY(sgk::launch_reset(s, nullptr, 0, h->stream));  // gym.make leaves the env ready; reset() is still idempotent
-  SGK_TRY(hipStreamSynchronize(h->stream));
+  SGK_TRY(sgk::host::wait_stream(h->stream));
 #undef SGK_TRY
   *out = h;
   return SGK_OK;
@@ -348,7 +350,7 @@ int sgk_copy_bandit_policy(sgk_env *h, double *out_host) try {
   if (!out_host) return fail(SGK_ERR_INVALID, "out_host is NULL");
   if (!h->sh.aux) return fail(SGK_ERR_INVALID, "this level keeps no bandit estimates (FriendFoe does)");
   hipError_t e = hipMemcpyAsync(out_host, h->sh.aux, sizeof(double) * SGK_AUX_DOUBLES * (size_t)h->sh.n, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = sgk::host::wait_stream(h->stream);
   return e == hipSuccess ? SGK_OK : hip_fail(e, "sgk_copy_bandit_policy");
 } SGK_CATCH_STATUS
 
@@ -374,24 +376,49 @@ int sgk_get_info(const sgk_env *h, sgk_info *out) try {
   return SGK_OK;
 } SGK_CATCH_STATUS
 
+// The handle moves to another stream: what it has enqueued so far (table memsets, uploads, earlier launches) happens-before
+// whatever the new stream is given -- an event recorded on the old stream, waited for by the new one. (Found in round 6 when the
+// Python wrapper began to follow torch's current stream by default: sgk_tabq_create zeroes 6.4 GB of tables on the stream the handle
+// has at that moment, and a rollout launched on the stream it was moved to a moment later started before the memset had finished.)
+// A stream that is being captured is left alone: the capture's owner (torch's graph recipe) has ordered it against the surrounding
+// work already, and neither an event from outside the capture nor a touch of the legacy stream is legal there.
+static int switch_stream(sgk_env *h, hipStream_t next) {
+  if (next == h->stream) return SGK_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (next && hipStreamIsCapturing(next, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    cs = hipStreamCaptureStatusNone;
+  }
+  hipStreamCaptureStatus cs_old = hipStreamCaptureStatusNone;
+  if (h->stream && hipStreamIsCapturing(h->stream, &cs_old) != hipSuccess) {
+    (void)hipGetLastError();
+    cs_old = hipStreamCaptureStatusNone;
+  }
+  if (cs == hipStreamCaptureStatusNone && cs_old == hipStreamCaptureStatusNone) {
+    if (!h->switch_event) SGK_HIP(hipEventCreateWithFlags(&h->switch_event, hipEventDisableTiming));
+    SGK_HIP(hipEventRecord(h->switch_event, h->stream));
+    SGK_HIP(hipStreamWaitEvent(next, h->switch_event, 0));
+  }
+  h->stream = next;
+  return SGK_OK;
+}
+
 int sgk_set_stream(sgk_env *h, void *hip_stream) try {
   SGK_CHECK_HANDLE(h);  // (also stops the step server: it runs on the stream that is about to change)
-  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;  // graphs are captured on own_stream and stay valid
-  return SGK_OK;
+  return switch_stream(h, hip_stream ? (hipStream_t)hip_stream : h->own_stream);  // graphs are captured on own_stream and stay valid
 } SGK_CATCH_STATUS
 
 int sgk_set_seed(sgk_env *h, uint64_t seed) try {
   SGK_CHECK_HANDLE(h);
   h->sh.seed = seed;  // kernel argument of every later launch; captured step graphs carry the old seed and are dropped
-  (void)hipStreamSynchronize(h->stream);  // a replay of a graph about to be destroyed may still be in flight
+  (void)sgk::host::wait_stream(h->stream);  // a replay of a graph about to be destroyed may still be in flight
   h->graphs.clear();
   return SGK_OK;
 } SGK_CATCH_STATUS
 
 int sgk_use_default_stream(sgk_env *h) try {
   SGK_CHECK_HANDLE(h);
-  h->stream = nullptr;  // the device's NULL (legacy default) stream: where PyTorch queues work unless told otherwise
-  return SGK_OK;
+  return switch_stream(h, nullptr);  // the device's NULL (legacy default) stream: where PyTorch queues work unless told otherwise
 } SGK_CATCH_STATUS
 
 void *sgk_get_stream(const sgk_env *h) { return h ? (void *)h->stream : nullptr; }
@@ -489,8 +516,8 @@ int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_s
     // latency matters here, not CPU time: poll instead of a blocking wait (bounded, then fall back to the blocking form)
     {
       hipError_t q = hipErrorNotReady;
-      for (int spin = 0; spin < 2000000 && q == hipErrorNotReady; ++spin) q = hipStreamQuery(h->stream);
-      if (q == hipErrorNotReady) q = hipStreamSynchronize(h->stream);
+      for (int spin = 0; h->stream && spin < 2000000 && q == hipErrorNotReady; ++spin) q = hipStreamQuery(h->stream);  // (not the NULL stream: wait_stream)
+      if (q == hipErrorNotReady) q = sgk::host::wait_stream(h->stream);
       if (q != hipSuccess) return hip_fail(q, "sgk_step_host wait");
     }
     if (rec_host) memcpy(rec_host, s.rec, 4 * n);
@@ -519,7 +546,7 @@ int sgk_step_host(sgk_env *h, const uint8_t *actions_host, uint32_t flags, sgk_s
     }
     SGK_HIP(hipMemcpyAsync(h->pinned + off_boards, src, bbytes, hipMemcpyDeviceToHost, h->stream));
   }
-  SGK_HIP(hipStreamSynchronize(h->stream));
+  SGK_HIP(sgk::host::wait_stream(h->stream));
   if (rec_host) memcpy(rec_host, h->pinned + off_rec, 4 * n);
   if (boards_host) memcpy(boards_host, h->pinned + off_boards, bbytes);
   if (episode_return_host) {
@@ -877,9 +904,9 @@ int sgk_discounted_returns(sgk_env *h, const float *rewards_dev, const int32_t *
   if (h->gamma_discount != discount) {
     float tab[1024];
     for (int t = 0; t < 1024; ++t) tab[t] = (float)std::pow(discount, (double)t);  // Python: float ** int, then float32
-    SGK_HIP(hipStreamSynchronize(h->stream));  // a previous launch may still read the old table
+    SGK_HIP(sgk::host::wait_stream(h->stream));  // a previous launch may still read the old table
     SGK_HIP(hipMemcpyAsync(h->gamma_dev, tab, sizeof(tab), hipMemcpyHostToDevice, h->stream));  // (not hipMemcpy: sgk::capture_mutex)
-    SGK_HIP(hipStreamSynchronize(h->stream));  // `tab` is on the stack
+    SGK_HIP(sgk::host::wait_stream(h->stream));  // `tab` is on the stack
     h->gamma_discount = discount;
   }
   SGK_HIP(sgk::launch_discounted_returns(h->sh, rewards_dev, lengths_dev, h->gamma_dev, returns_dev, n_trajectories, t_max,
@@ -902,7 +929,7 @@ static int host_visible_ready(sgk_env *h) {
     __sync_synchronize();
     return SGK_OK;
   }
-  SGK_HIP(hipStreamSynchronize(h->stream));
+  SGK_HIP(sgk::host::wait_stream(h->stream));
   return SGK_OK;
 }
 
@@ -922,7 +949,7 @@ int sgk_copy_boards(sgk_env *h, int8_t *boards_host) try {
     // pointers is carried out by the runtime on the calling thread at once -- it is not ordered behind the kernels of the stream --
     // so env.reset() now and then returned the board of the step BEFORE the reset kernel had written: one stale observation in
     // ~5 000 resets, caught by the reference's train() goldens on the single env.)
-    SGK_HIP(hipStreamSynchronize(h->stream));
+    SGK_HIP(sgk::host::wait_stream(h->stream));
     for (int64_t i = 0; i < s.n; ++i) memcpy(boards_host + i * s.n_cells, s.boards + i * s.pitch, (size_t)s.n_cells);
     return SGK_OK;
   }
@@ -933,7 +960,7 @@ int sgk_copy_boards(sgk_env *h, int8_t *boards_host) try {
     SGK_HIP(sgk::launch_dense_boards(s, h->dense_scratch, h->stream));
     SGK_HIP(hipMemcpyAsync(boards_host, h->dense_scratch, bytes, hipMemcpyDeviceToHost, h->stream));
   }
-  SGK_HIP(hipStreamSynchronize(h->stream));
+  SGK_HIP(sgk::host::wait_stream(h->stream));
   return SGK_OK;
 } SGK_CATCH_STATUS
 
@@ -941,12 +968,12 @@ int sgk_copy_step_records(sgk_env *h, sgk_step_rec *rec_host) try {
   SGK_CHECK_HANDLE(h);
   if (!rec_host) return fail(SGK_ERR_INVALID, "rec_host is NULL");
   if (h->host_visible) {  // (host memory: synchronise, then a CPU copy -- see sgk_copy_boards)
-    SGK_HIP(hipStreamSynchronize(h->stream));
+    SGK_HIP(sgk::host::wait_stream(h->stream));
     memcpy(rec_host, h->sh.rec, sizeof(uint32_t) * (size_t)h->sh.n);
     return SGK_OK;
   }
   SGK_HIP(hipMemcpyAsync(rec_host, h->sh.rec, sizeof(uint32_t) * h->sh.n, hipMemcpyDeviceToHost, h->stream));
-  SGK_HIP(hipStreamSynchronize(h->stream));
+  SGK_HIP(sgk::host::wait_stream(h->stream));
   return SGK_OK;
 } SGK_CATCH_STATUS
 
@@ -967,7 +994,7 @@ int sgk_copy_episode_state(sgk_env *h, int32_t *episode_return_host, int32_t *hi
     }
   };
   if (h->host_visible) {  // (host memory: synchronise, then read the words where they are -- see sgk_copy_boards)
-    SGK_HIP(hipStreamSynchronize(h->stream));
+    SGK_HIP(sgk::host::wait_stream(h->stream));
     unpack(h->sh.state, 0, n);
     return SGK_OK;
   }
@@ -978,7 +1005,7 @@ int sgk_copy_episode_state(sgk_env *h, int32_t *episode_return_host, int32_t *hi
   for (size_t first = 0; first < n; first += CHUNK) {
     const size_t count = n - first < CHUNK ? n - first : CHUNK;
     SGK_HIP(hipMemcpyAsync(h->copy_chunk, h->sh.state + first, sizeof(uint64_t) * count, hipMemcpyDeviceToHost, h->stream));
-    SGK_HIP(hipStreamSynchronize(h->stream));
+    SGK_HIP(sgk::host::wait_stream(h->stream));
     unpack(h->copy_chunk, first, count);
   }
   return SGK_OK;
@@ -1002,7 +1029,7 @@ int sgk_copy_last_episode(sgk_env *h, int32_t *last_return_host, int32_t *last_p
     if (last_performance_host)
       SGK_HIP(hipMemcpyAsync(last_performance_host, h->sh.last_perf, bytes, hipMemcpyDeviceToHost, h->stream));
   }
-  SGK_HIP(hipStreamSynchronize(h->stream));
+  SGK_HIP(sgk::host::wait_stream(h->stream));
   if (h->host_visible) {  // host memory: read with the CPU once the stream is idle (a host-to-host hipMemcpyAsync is not stream-ordered)
     if (last_return_host) memcpy(last_return_host, h->sh.last_return, bytes);
     if (last_performance_host) memcpy(last_performance_host, h->sh.last_perf, bytes);
@@ -1014,8 +1041,8 @@ int sgk_copy_last_episode(sgk_env *h, int32_t *last_return_host, int32_t *last_p
 // wakes tens of microseconds late), then fall back to the blocking form.
 static hipError_t wait_stream_low_latency(hipStream_t st) {
   hipError_t q = hipErrorNotReady;
-  for (int spin = 0; spin < 200000 && q == hipErrorNotReady; ++spin) q = hipStreamQuery(st);  // ~0.1 s at most
-  if (q == hipErrorNotReady) q = hipStreamSynchronize(st);
+  for (int spin = 0; st && spin < 200000 && q == hipErrorNotReady; ++spin) q = hipStreamQuery(st);  // ~0.1 s at most; the NULL stream goes to wait_stream
+  if (q == hipErrorNotReady) q = sgk::host::wait_stream(st);
   return q;
 }
 
@@ -1042,7 +1069,7 @@ int sgk_metrics_allreduced(sgk_env *h, sgk_comm *comm, int64_t out_host[SGK_METR
   int rc = sgk_allreduce_metrics(comm, h->sh.metrics, (void *)h->stream);
   if (rc != SGK_OK) return rc;
   SGK_HIP(hipMemcpyAsync(out_host, h->sh.metrics, sizeof(int64_t) * SGK_METRICS_LEN, hipMemcpyDeviceToHost, h->stream));
-  SGK_HIP(hipStreamSynchronize(h->stream));
+  SGK_HIP(sgk::host::wait_stream(h->stream));
   return SGK_OK;
 } SGK_CATCH_STATUS
 
@@ -1058,7 +1085,7 @@ int sgk_finished(sgk_env *h, int32_t *ids_dev, int32_t *return_dev, int32_t *per
   if (!ids_dev || !return_dev || !performance_dev || !n_host) return fail(SGK_ERR_INVALID, "NULL argument");
   SGK_HIP(sgk::launch_finished(h->sh, ids_dev, return_dev, performance_dev, h->stream));
   SGK_HIP(hipMemcpyAsync(n_host, h->sh.finished_total, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-  SGK_HIP(hipStreamSynchronize(h->stream));
+  SGK_HIP(sgk::host::wait_stream(h->stream));
   return SGK_OK;
 } SGK_CATCH_STATUS
 
@@ -1068,7 +1095,7 @@ int sgk_tabq_destroy(sgk_tabq *q) try {
   if (!q) return SGK_OK;
   if (q->env) {
     (void)hipSetDevice(q->env->sh.device);
-    (void)hipStreamSynchronize(q->env->stream);
+    (void)sgk::host::wait_stream(q->env->stream);
   }
   q->graphs.clear();
   (void)hipFree(q->tq.table);
@@ -1143,7 +1170,7 @@ int sgk_tabq_hash_info(sgk_tabq *q, int32_t *capacity_out, int32_t *max_used_out
   if (capacity_out) *capacity_out = q->tq.hash_cap;
   int32_t ov = 0;
   SGK_HIP(hipMemcpyAsync(&ov, q->tq.hash_overflow, sizeof(ov), hipMemcpyDeviceToHost, q->env->stream));
-  SGK_HIP(hipStreamSynchronize(q->env->stream));
+  SGK_HIP(sgk::host::wait_stream(q->env->stream));
   if (overflowed_out) *overflowed_out = ov;
   if (max_used_out) {
     *max_used_out = 0;
@@ -1152,7 +1179,7 @@ int sgk_tabq_hash_info(sgk_tabq *q, int32_t *capacity_out, int32_t *max_used_out
       SGK_HIP(hipMemsetAsync(scratch, 0, sizeof(int32_t), q->env->stream));
       SGK_HIP(sgk::launch_tabq_hash_used(q->env->sh, q->tq, scratch, q->env->stream));
       SGK_HIP(hipMemcpyAsync(max_used_out, scratch, sizeof(int32_t), hipMemcpyDeviceToHost, q->env->stream));
-      SGK_HIP(hipStreamSynchronize(q->env->stream));
+      SGK_HIP(sgk::host::wait_stream(q->env->stream));
     }
   }
   return SGK_OK;
@@ -1166,7 +1193,7 @@ int sgk_tabq_copy_keys(sgk_tabq *q, int64_t env_begin, int64_t env_count, uint32
   const size_t cap = (size_t)q->tq.hash_cap;
   SGK_HIP(hipMemcpyAsync(keys_host, q->tq.keys + (size_t)env_begin * cap, sizeof(uint32_t) * cap * (size_t)env_count,
                          hipMemcpyDeviceToHost, q->env->stream));
-  SGK_HIP(hipStreamSynchronize(q->env->stream));
+  SGK_HIP(sgk::host::wait_stream(q->env->stream));
   return SGK_OK;
 } SGK_CATCH_STATUS
 
@@ -1197,19 +1224,38 @@ int sgk_tabq_learn(sgk_tabq *q, const uint8_t *actions_dev, int cheat) try {
   return SGK_OK;
 } SGK_CATCH_STATUS
 
+int sgk_tabq_step(sgk_tabq *q, int cheat, uint32_t flags, uint8_t *actions_out_dev) try {
+  if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
+  sgk_env *h = q->env;
+  SGK_CHECK_HANDLE(h);
+  if (flags & ~(uint32_t)SGK_F_NO_BOARDS) return fail(SGK_ERR_INVALID, "only SGK_F_NO_BOARDS is meaningful here");
+  SGK_HIP(refresh_row_tags(q));
+  SGK_HIP(sgk::launch_tabq_step(h->sh, q->tq, cheat, flags, actions_out_dev, h->stream));
+  q->tq.t_agent += 1;  // update_epsilon(), learn.py:82
+  q->t_dev_stale = true;
+  h->sh.lockstep_t += 1;
+  h->t_dev_stale = true;
+  h->steps_issued += h->sh.n;
+  return SGK_OK;
+} SGK_CATCH_STATUS
+
 int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags) try {
   if (!q) return fail(SGK_ERR_INVALID, "handle is NULL");
   sgk_env *h = q->env;
   SGK_CHECK_HANDLE(h);
   if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
-  if (flags & ~(uint32_t)SGK_F_NO_BOARDS) return fail(SGK_ERR_INVALID, "only SGK_F_NO_BOARDS is meaningful here");
+  if (flags & ~(uint32_t)(SGK_F_NO_BOARDS | SGK_F_SEPARATE_LAUNCHES))
+    return fail(SGK_ERR_INVALID, "only SGK_F_NO_BOARDS and SGK_F_SEPARATE_LAUNCHES are meaningful here");
   if (n_steps == 0) return SGK_OK;
   sgk::Shard &s = h->sh;
-  // tabq_learn's loop body (reference learn.py:61-85 inside train.py:62-70) as the four launches of the drop-in call sequence --
-  // act_explore, env.step, learn (+ update_epsilon), reset of the finished envs -- captured ONCE per (n_steps, cheat, flags) and
-  // replayed: the agent step counter lives in device memory, so a replay needs no new arguments.
+  const bool separate = (flags & SGK_F_SEPARATE_LAUNCHES) != 0;
+  const uint32_t kflags = flags & SGK_F_NO_BOARDS;
+  // tabq_learn's loop body (reference learn.py:61-85 inside train.py:62-70) -- act_explore, env.step, learn (+ update_epsilon),
+  // reset of the finished envs -- as ONE launch per lockstep step (tabq_step_kernel), or as the four launches of the drop-in
+  // call sequence (SGK_F_SEPARATE_LAUNCHES), captured ONCE per (n_steps, cheat, flags) and replayed: the agent step counter lives
+  // in device memory, so a replay needs no new arguments.
   if (q->graphs_seed != s.seed) {  // env.seed() re-keyed the exploration draws: the recorded kernel arguments are stale
-    (void)hipStreamSynchronize(h->stream);
+    (void)sgk::host::wait_stream(h->stream);
     q->graphs.clear();
     q->graphs_seed = s.seed;
   }
@@ -1222,10 +1268,14 @@ int sgk_tabq_learn_steps(sgk_tabq *q, int32_t n_steps, int cheat, uint32_t flags
       hipError_t le = hipSuccess;
       for (int32_t k = 0; k < n_steps && le == hipSuccess; ++k) {
         tq.t_agent = k;  // offset from *t_dev
+        if (!separate) {
+          le = sgk::launch_tabq_step(s, tq, cheat, kflags, q->actions, cap);
+          continue;
+        }
         le = sgk::launch_tabq_act(s, tq, 1, q->actions, cap);
-        if (le == hipSuccess) le = sgk::launch_step(s, q->actions, flags, cap);
+        if (le == hipSuccess) le = sgk::launch_step(s, q->actions, kflags, cap);
         if (le == hipSuccess) le = sgk::launch_tabq_learn(s, tq, q->actions, cheat, cap);
-        if (le == hipSuccess) le = sgk::launch_reset(s, nullptr, 1 | ((flags & SGK_F_NO_BOARDS) ? 4 : 0), cap);
+        if (le == hipSuccess) le = sgk::launch_reset(s, nullptr, 1 | (kflags ? 4 : 0), cap);
       }
       if (le == hipSuccess) {
         (void)hipGetLastError();
@@ -1336,7 +1386,7 @@ int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, doubl
     const size_t cnt = std::min(e_max, (size_t)env_count - e0);
     SGK_HIP(hipMemcpy2DAsync(q->copy_stage, cnt * row_bytes, q->tq.table + ((size_t)env_begin + e0) * SGK_ACTIONS, n * row_bytes,
                              cnt * row_bytes, ns, hipMemcpyDeviceToHost, q->env->stream));
-    SGK_HIP(hipStreamSynchronize(q->env->stream));
+    SGK_HIP(sgk::host::wait_stream(q->env->stream));
     for (size_t s = 0; s < ns; ++s)
       for (size_t e = 0; e < cnt; ++e)
         memcpy(table_host + ((e0 + e) * ns + s) * SGK_ACTIONS, q->copy_stage + (s * cnt + e) * SGK_ACTIONS, row_bytes);

@@ -206,6 +206,15 @@ inline std::mutex &capture_mutex() {
   return m;
 }
 
+// Wait for a handle's stream. A handle bound to the device's NULL stream (sgk_use_default_stream: where PyTorch queues its work
+// unless told otherwise) waits with hipStreamSynchronize(NULL) -- one of the synchronous legacy-stream calls described above --,
+// so that wait excludes the library's captures like the other device-wide calls do.
+inline hipError_t wait_stream(hipStream_t st) {
+  if (st) return hipStreamSynchronize(st);
+  std::lock_guard<std::mutex> no_capture_meanwhile(capture_mutex());
+  return hipStreamSynchronize(nullptr);
+}
+
 // `record(cap)` between hipStreamBeginCapture and hipStreamEndCapture on `cap`, instantiated into *exec. Captures are serialised
 // against each other and against the library's device-wide synchronous calls (capture_mutex); one that a foreign synchronous
 // call invalidated all the same (hipErrorStreamCaptureInvalidated) is recorded again, a few times.

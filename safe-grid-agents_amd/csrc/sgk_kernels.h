@@ -140,6 +140,8 @@ hipError_t launch_tabq_act(const Shard &sh, const TabqShard &tq, int explore, ui
 hipError_t launch_tabq_forget_rows(const Shard &sh, const TabqShard &tq, hipStream_t st);
 hipError_t launch_tabq_hash_used(const Shard &sh, const TabqShard &tq, int32_t *max_used_dev, hipStream_t st);
 hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t *actions, int cheat, hipStream_t st);
+// one lockstep step of tabq_learn in one launch (act_explore, env.step, learn, reset of the finished envs); actions_out may be null
+hipError_t launch_tabq_step(const Shard &sh, const TabqShard &tq, int cheat, uint32_t flags, uint8_t *actions_out, hipStream_t st);
 hipError_t launch_tabq_rollout(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st);
 hipError_t launch_tabq_rollout_hbm(const Shard &sh, const TabqShard &tq, int64_t n_steps, int cheat, hipStream_t st);
 size_t tabq_rollout_lds_bytes(const Shard &sh);

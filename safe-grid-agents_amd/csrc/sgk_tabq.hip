@@ -301,6 +301,185 @@ __global__ __launch_bounds__(WG) void tabq_learn_kernel(TabqArgs a, const uint8_
 }
 
 // ------------------------------------------------------------------------------------------------
+// ONE launch per lockstep step of tabq_learn (reference learn.py:61-85 inside train.py:62-70): act_explore -> env.step -> learn ->
+// update_epsilon -> reset of the finished envs for every (env, agent) pair, with everything a caller of the per-step API sees
+// left in place -- the step record as sgk_step writes it, the board (of the new episode's first state where the step ended
+// one: what reset_done leaves), the chosen action, the episode arrays and metrics. The four launches it replaces each re-read
+// the state word and a table row and paid a launch boundary (8.9 us per step at 1 024 agents, 26 at 262 144 IslandNavigation).
+// Structure = step_kernel's (sgk_step.hip): one wave = one 64-env tile, wave-private rule table and board tile, no workgroup
+// barrier, every independent load of the tile -- state word, row tag, the kept row -- requested before the first wait; then the
+// one dependent gather a step needs (the successor's row) and, for an env that finished, the start state's row.
+// The row hand-off of the per-step kernels is kept up (row_cache + tags, table written through), so this step, tabq_act /
+// tabq_learn and the rollout kernels can be mixed freely.
+// ------------------------------------------------------------------------------------------------
+template <int ENV, int LAYOUT, bool SMALL>
+__global__ __launch_bounds__(SMALL ? 64 : WG) void tabq_step_kernel(TabqArgs a, uint8_t *__restrict__ actions_out) {
+  constexpr int WGT = SMALL ? 64 : WG;
+  constexpr int NC = Geom<ENV>::NC;
+  constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
+  __shared__ WaveRulesImage rules_images[WGT / 64];
+  __shared__ __attribute__((aligned(16))) uint8_t tile_images[COMPACT ? WGT / 64 : 1][COMPACT ? 64 * NC : 16];
+  __shared__ int episode_words[WGT / 64][16];
+  const int lane = threadIdx.x & 63, wave = wave_index();
+  const int64_t n_wt = (a.n + 63) / 64;
+  const int64_t wt0 = (int64_t)blockIdx.x * (WGT / 64) + wave, wstride = (int64_t)gridDim.x * (WGT / 64);
+  const bool boards_on = !(a.flags & SGK_F_NO_BOARDS);
+  const long long *t_word = a.t_ptr ? a.t_ptr : reinterpret_cast<const long long *>(a.rules);
+  const long long t_base = *t_word;  // (branch-free: a null t_ptr reads a word that exists and drops it)
+  uint64_t w_cur = 0, tag_cur = 0;
+  double2 c01_cur = make_double2(0.0, 0.0), c23_cur = c01_cur;
+  {
+    const int64_t e0 = wt0 * 64 + lane;
+    const int64_t e0c = e0 < a.n ? e0 : a.n - 1;
+    w_cur = a.state[e0c];
+    tag_cur = a.tags[e0c];
+    c01_cur = reinterpret_cast<const double2 *>(a.row_cache + e0c * 4)[0];
+    c23_cur = reinterpret_cast<const double2 *>(a.row_cache + e0c * 4)[1];
+  }
+  WaveRulesLoad rules_load;
+  rules_load.request(a.rules);
+  WaveTileLds<ENV, NC> W;
+  W.bind(tile_images[COMPACT ? wave : 0]);
+  typename WaveTileLds<ENV, NC>::Blank blank;
+  if (COMPACT) W.request_blank(blank, a.rules);
+  rules_load.commit(rules_images[wave]);
+  if (COMPACT) W.blank_arrived(blank);
+  const SgkRules &R = rules_images[wave].r;
+  const int64_t t_agent = a.t_agent + (a.t_ptr ? (int64_t)t_base : 0);
+  const double eps = epsilon_at(a.eps0, a.anneal, t_agent);
+  WaveEpisodeLds episodes;
+  episodes.bind(episode_words[wave]);
+  StepArgs sa;  // what step_one reads (no auto-reset: the successor's row is looked up before the env is reset, below)
+  sa.rules = a.rules; sa.state = a.state; sa.actions = nullptr; sa.rec = a.rec; sa.boards = a.boards;
+  sa.last_return = a.last_return; sa.last_perf = a.last_perf; sa.n_episodes = a.n_episodes; sa.n_resets = a.n_resets;
+  sa.aux = a.aux; sa.metrics = a.metrics; sa.n = a.n; sa.seed = a.seed; sa.env_base = a.env_base; sa.t = 0; sa.t_ptr = nullptr;
+  sa.flags = 0;
+  for (int64_t wt = wt0; wt < n_wt;) {
+    const int64_t env = wt * 64 + lane;
+    const bool valid = env < a.n;
+    EnvState s = unpack_state(w_cur);
+    const uint64_t tag = tag_cur;
+    const double2 c01 = c01_cur, c23 = c23_cur;
+    const int64_t wt_next = wt + wstride;
+    const bool more = !SMALL && wt_next < n_wt;  // wave-uniform
+    uint64_t w_next = 0, tag_next = 0;
+    double2 c01_next = make_double2(0.0, 0.0), c23_next = c01_next;
+    if (more) {
+      const int64_t ne = wt_next * 64 + lane;
+      if (ne < a.n) {
+        w_next = a.state[ne];
+        tag_next = a.tags[ne];
+        c01_next = reinterpret_cast<const double2 *>(a.row_cache + ne * 4)[0];
+        c23_next = reinterpret_cast<const double2 *>(a.row_cache + ne * 4)[1];
+      }
+    }
+    if (!valid) s = initial_state(R);
+    load_episode_index<ENV>(s, a.n_resets, env, valid);
+    const bool live = valid && !s.over;
+    const uint64_t ge = a.env_base + (uint64_t)env;
+    // ---- act_explore (value.py:33-42) on the row of the state the agent is in ----
+    const int si = valid ? state_index<ENV>(R, s, a, env) : -1;
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    if (si >= 0) {
+      if ((uint32_t)(tag >> 32) == (uint32_t)si) { q0 = c01.x; q1 = c01.y; q2 = c23.x; q3 = c23.y; }
+      else {
+        const double2 *row = reinterpret_cast<const double2 *>(a.table + row_of(a.n, si, env));
+        const double2 r01 = row[0], r23 = row[1];
+        q0 = r01.x; q1 = r01.y; q2 = r23.x; q3 = r23.y;
+      }
+    }
+    int action = argmax4(q0, q1, q2, q3);
+    {
+      const ExploreBlock x = explore_block(a.seed, ge, t_agent);
+      double u;
+      int ea;
+      explore_draw(x, t_agent, u, ea);
+      if (u < eps) action = ea;
+    }
+    if (actions_out && valid) actions_out[env] = (uint8_t)action;
+    // ---- env.step (learn.py:69) ----
+    uint32_t rec;
+    EpisodeAcc acc;
+    acc_init(acc);
+    step_one<ENV>(R, sa, env, valid, action, s, rec, acc);  // a finished episode leaves s.over = 1
+    episodes.add(acc.n_eps != 0, acc.s_ret, acc.s_perf);
+    // ---- the rows the rest of the step needs, requested TOGETHER (one dependent round trip, not two): the successor's row for
+    // learn, and -- where the episode is over -- the row of the state the next episode starts in (train.py:62-64: env.reset()) ----
+    int sn = si;
+    if (live) sn = state_index<ENV>(R, s, a, env);  // the board the agent sees after the step, terminal or not (value.py:46: no mask)
+    const bool over = valid && s.over;
+    int sr = -1;
+    if (over) {
+      const int epi = s.epi + 1;
+      bump_reset_count<ENV>(a.n_resets, env);
+      s = initial_state(R);
+      s.epi = epi;
+      begin_episode<ENV>(R, s, a.seed, ge, aux_of<ENV>(a.aux, env));
+      sr = state_index<ENV>(R, s, a, env);
+    }
+    double n0 = q0, n1 = q1, n2 = q2, n3 = q3;
+    if (live && sn != si) {
+      n0 = n1 = n2 = n3 = 0.0;  // (sn < 0: a full hash table has no row for this board -- a fresh row's zeros)
+      if (sn >= 0) {
+        const double2 *rown = reinterpret_cast<const double2 *>(a.table + row_of(a.n, sn, env));
+        const double2 n01 = rown[0], n23 = rown[1];
+        n0 = n01.x; n1 = n01.y; n2 = n23.x; n3 = n23.y;
+      }
+    }
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+    if (sr >= 0) {  // (read BEFORE this step's update is stored: patched below when it is the updated row)
+      const double2 *rowr = reinterpret_cast<const double2 *>(a.table + row_of(a.n, sr, env));
+      const double2 r01 = rowr[0], r23 = rowr[1];
+      r0 = r01.x; r1 = r01.y; r2 = r23.x; r3 = r23.y;
+    }
+    // ---- learn (value.py:44-52; learn.py:72-79 under --cheat): the successor's row as it is before the update ----
+    if (live) {
+      const int learnt = a.cheat ? (int)(rec >> 24) : action;
+      if (si >= 0 && learnt < SGK_ACTIONS) {
+        const double reward = __dmul_rn(a.cheat ? (double)(int8_t)(rec >> 8) : (double)(int8_t)rec, R.reward_scale);
+        const int an = argmax4(n0, n1, n2, n3);
+        const double v_next = pick4(an, n0, n1, n2, n3);
+        const double q_new = q_update(pick4(learnt, q0, q1, q2, q3), reward, v_next, a.lr, a.discount);
+        a.table[row_of(a.n, si, env) + learnt] = q_new;
+        if (sn == si) {  // the agent did not move: its next row is the row just updated
+          if (learnt == 0) n0 = q_new; else if (learnt == 1) n1 = q_new; else if (learnt == 2) n2 = q_new; else n3 = q_new;
+        }
+        if (sr == si) {  // the new episode starts in the state just learnt from
+          if (learnt == 0) r0 = q_new; else if (learnt == 1) r1 = q_new; else if (learnt == 2) r2 = q_new; else r3 = q_new;
+        }
+      }
+    }
+    if (over) {  // the next step acts in the new episode's first state
+      sn = sr;
+      n0 = r0; n1 = r1; n2 = r2; n3 = r3;
+    }
+    if (!more) episodes.flush(a.metrics);
+    if (valid) {
+      a.state[env] = pack_state(s);
+      a.rec[env] = rec;
+      keep_row(a, env, n0, n1, n2, n3);  // the next step acts in this state
+      a.tags[env] = 0xffffffffull | ((uint64_t)(uint32_t)sn << 32);  // no action pending; the kept row's state (sn = -1: none)
+    }
+    if (boards_on) {
+      if (COMPACT) {
+        W.draw_from_blank(blank, R, sprite_info<ENV>(R, s));
+        if (SMALL) W.template flush<0>(a.boards + wt * 64 * NC);
+        else W.flush(a.boards + wt * 64 * NC);
+      } else if (valid) {
+        write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+      }
+    }
+    if (!more) break;
+    asm volatile("" : "+v"(w_next), "+v"(tag_next));
+    w_cur = w_next;
+    tag_cur = tag_next;
+    c01_cur = c01_next;
+    c23_cur = c23_next;
+    wt = wt_next;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused learning rollout, tables resident in LDS: one wave = 64 private agents for the whole launch (n_steps of
 // act_explore -> env.step -> learn -> update_epsilon -> reset on done; reference learn.py:61-85 inside train.py:62-70).
 //
@@ -762,6 +941,23 @@ hipError_t launch_tabq_learn(const Shard &sh, const TabqShard &tq, const uint8_t
   a.cheat = cheat;
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
   SGK_DISPATCH_ENV(sh.env_id, tabq_learn_kernel<E><<<dim3(grid), dim3(WG), 0, st>>>(a, actions));
+  return hipGetLastError();
+}
+
+// As step_kernel's SMALL form: one wave per workgroup, plain stores. Above that the launch is bound by bytes, not by its shape:
+// IslandNavigation 7.6 / 15 / 57 us at 131 072 / 262 144 / 1 048 576 agents whatever the form or the grid (one wave per workgroup
+// everywhere, 512 .. 4 096 workgroups of 256: all within 14.2-16.7 at 262 144, profiles/r06/tabq_step_grid.log) -- about 230 bytes
+// per agent and step at ~4 TB/s: the kept row and tag (80 B read + written), the state word and record (20 B), the successor row's
+// 128-byte line for 32 useful bytes out of a 403 MB set of tables that no cache holds, and the 8-byte update into such a line.
+constexpr int64_t TABQ_STEP_SMALL_MAX_ENVS = 65536;
+hipError_t launch_tabq_step(const Shard &sh, const TabqShard &tq, int cheat, uint32_t flags, uint8_t *actions_out, hipStream_t st) {
+  (void)hipGetLastError();
+  TabqArgs a = make_tabq_args(sh, tq, flags);
+  a.cheat = cheat;
+  const bool small = sh.n <= TABQ_STEP_SMALL_MAX_ENVS;
+  const dim3 grid(small ? (unsigned)((sh.n + 63) / 64) : (unsigned)grid_for((sh.n + WG - 1) / WG, sh.max_grid)), block(small ? 64 : WG);
+  if (small) SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, tabq_step_kernel<E, L, true><<<grid, block, 0, st>>>(a, actions_out));
+  else SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, tabq_step_kernel<E, L, false><<<grid, block, 0, st>>>(a, actions_out));
   return hipGetLastError();
 }
 

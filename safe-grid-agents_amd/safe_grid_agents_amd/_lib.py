@@ -15,7 +15,7 @@ INCLUDE = os.path.join(os.path.dirname(_DIST), "include")
 
 SGK_OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE, ERR_INTERNAL = -1, -2, -3, -4, -5
-F_AUTO_RESET, F_NO_BOARDS, F_MASK_FINISHED, F_RING_TILE_MAJOR = 1, 2, 4, 8
+F_AUTO_RESET, F_NO_BOARDS, F_MASK_FINISHED, F_RING_TILE_MAJOR, F_SEPARATE_LAUNCHES = 1, 2, 4, 8, 16
 LAYOUT_PITCHED, LAYOUT_COMPACT = 0, 1
 TABQ_KERNEL_AUTO, TABQ_KERNEL_LDS, TABQ_KERNEL_HBM = 0, 1, 2
 DQN_LOSS_REFERENCE, DQN_LOSS_PER_SAMPLE = 0, 1  # sgk_dqn_learner.loss_mode: value.py:119-123 as written ([B,1] vs [B] broadcast) / squeezed
@@ -165,6 +165,7 @@ _SIGNATURES = {
     "sgk_tabq_act": (ctypes.c_int, [_V, ctypes.c_int, _V]),
     "sgk_tabq_learn": (ctypes.c_int, [_V, _V, ctypes.c_int]),
     "sgk_tabq_learn_steps": (ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_int, ctypes.c_uint32]),
+    "sgk_tabq_step": (ctypes.c_int, [_V, ctypes.c_int, ctypes.c_uint32, _V]),
     "sgk_tabq_rollout": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int]),
     "sgk_tabq_rollout_ex": (ctypes.c_int, [_V, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "sgk_tabq_table_dev": (ctypes.c_int, [_V, ctypes.POINTER(_V), ctypes.POINTER(ctypes.c_int64),

@@ -249,6 +249,7 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         # levels without a perfect hash of their boards (TomatoWatering): slots of each agent's hash table, 0 = the library's default
         # (args.hash_capacity, else SGK_TABQ_HASH_CAPACITY: the reference's flag grammar has no such option to extend)
         self.hash_capacity = int(getattr(args, "hash_capacity", 0) or os.environ.get("SGK_TABQ_HASH_CAPACITY", 0) or 0)
+        env._follow()  # the tables are zeroed on the stream the handle enqueues on
         _lib.check(self.lib.sgk_tabq_create_ex(env.handle, self.lr, self.discount, self.epsilon0, self.epsilon_anneal,
                                                self.hash_capacity, ctypes.byref(h)))
         self._h = h
@@ -295,20 +296,35 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
 
     def learn(self, state=None, action=None, reward=None, successor=None, cheat=False):
         """Uses the env's last step records and current state words; `action` defaults to the last act*() output."""
-        actions = self._actions if action is None else action
+        actions = self._actions if action is None else self.env._actions_arg(action)
         self.env._sync_torch_to_lib()
         _lib.check(self.lib.sgk_tabq_learn(self._h, ctypes.c_void_p(actions.data_ptr()), int(cheat)))
 
-    def learn_steps(self, n_steps, cheat=False, write_boards=False):
-        """n_steps of the drop-in call sequence act_explore -> env.step -> learn -> reset_done (four launches per lockstep
-        step) replayed from one hipGraph (sgk_tabq_learn_steps): no Python, no host round trip between the launches."""
+    def step(self, cheat=False, write_boards=True):
+        """ONE lockstep step of tabq_learn for every (env, agent) pair in ONE launch (sgk_tabq_step): act_explore -> env.step ->
+        learn -> update_epsilon -> reset of the finished envs (learn.py:61-85 inside train.py:62-70). Returns
+        (actions, (boards, reward, done, info)): the chosen actions (uint8 [N], valid until the next call) and env.step's tuple --
+        views of the step records as sgk_step writes them and of the boards (an env whose episode ended shows its next
+        episode's first board, as after reset_done). Same results as act_explore / env.step / learn / reset_done."""
         flags = 0 if write_boards else _lib.F_NO_BOARDS
+        self.env._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_tabq_step(self._h, int(cheat), flags, ctypes.c_void_p(self._actions.data_ptr())))
+        self.env._sync_lib_to_torch()
+        return self._actions, self.env._step_outputs()
+
+    def learn_steps(self, n_steps, cheat=False, write_boards=False, separate_launches=False):
+        """n_steps lockstep steps of tabq_learn replayed from one hipGraph (sgk_tabq_learn_steps): no Python, no host round trip
+        between the launches. One launch per step (the kernel of step()); separate_launches=True records the drop-in call
+        sequence act_explore -> env.step -> learn -> reset_done instead (four launches per step: rounds 2-5's form)."""
+        flags = (0 if write_boards else _lib.F_NO_BOARDS) | (_lib.F_SEPARATE_LAUNCHES if separate_launches else 0)
+        self.env._follow()
         _lib.check(self.lib.sgk_tabq_learn_steps(self._h, int(n_steps), int(cheat), flags))
 
     def rollout(self, n_steps, cheat=False, kernel="auto"):
         """n_steps of {act_explore, env.step, learn, update_epsilon, reset on done} fused on the GPU. `kernel`: "auto", or
         "lds" / "hbm" to name the kernel (tables resident in LDS / rows in HBM; same results)."""
         k = {"auto": _lib.TABQ_KERNEL_AUTO, "lds": _lib.TABQ_KERNEL_LDS, "hbm": _lib.TABQ_KERNEL_HBM}[kernel]
+        self.env._follow()
         _lib.check(self.lib.sgk_tabq_rollout_ex(self._h, int(n_steps), int(cheat), k))
 
     def table(self):
@@ -329,6 +345,7 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
     def table_host(self, env_begin=0, env_count=None):
         env_count = self.env.n_envs - env_begin if env_count is None else env_count
         out = np.empty((env_count, self.n_states, self.action_n), dtype=np.float64)
+        self.env._follow()
         _lib.check(self.lib.sgk_tabq_copy_table(self._h, env_begin, env_count, out.ctypes.data))
         return out
 
@@ -337,6 +354,7 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         (0xffffffff = empty; agent cell | shown watered set << 8, 0x2000 = the bucket's delusion board); rows as in table_host()."""
         env_count = self.env.n_envs - env_begin if env_count is None else env_count
         out = np.empty((env_count, self.n_states), dtype=np.uint32)
+        self.env._follow()
         _lib.check(self.lib.sgk_tabq_copy_keys(self._h, env_begin, env_count, out.ctypes.data))
         return out
 
@@ -352,6 +370,7 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
     def hash_info(self):
         """(capacity, slots used by the fullest agent, overflowed) -- capacity 0 for perfect-hash levels."""
         c, u, o = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        self.env._follow()
         _lib.check(self.lib.sgk_tabq_hash_info(self._h, ctypes.byref(c), ctypes.byref(u), ctypes.byref(o)))
         return c.value, u.value, bool(o.value)
 
@@ -359,6 +378,7 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         """The cheap form of check_hash_tables (a 4-byte copy, no slot count): raise when some board found its agent's table full.
         The batched trainer calls it at every period's synchronisation point."""
         c, o = ctypes.c_int32(), ctypes.c_int32()
+        self.env._follow()
         _lib.check(self.lib.sgk_tabq_hash_info(self._h, ctypes.byref(c), None, ctypes.byref(o)))
         if o.value:
             self.check_hash_tables()

@@ -130,7 +130,8 @@ class BatchedDeepQAgent:
         self.torch = torch
         self.env = env
         self.q_body = q_body or getattr(args, "q_body", None) or "mlp"
-        assert self.q_body in ("mlp", "cnn"), "q_body must be 'mlp' (the reference's DeepQAgent) or 'cnn' (non-parity option)"
+        if self.q_body not in ("mlp", "cnn"):
+            raise ValueError("q_body must be 'mlp' (the reference's DeepQAgent) or 'cnn' (non-parity option)")
         self.n_channels = int(getattr(args, "n_channels", None) or 5)  # policy_cnn.py's default (agent_parser_configs.yaml:107-111)
         self.device = "cuda:%d" % env.device
         self.action_n = env.action_space.n
@@ -220,6 +221,9 @@ class BatchedDeepQAgent:
         from . import _lib
 
         rp, fl, fw = self.replay, self._fl, self._fw
+        for t, what in ((rows, "rows"), (rows_out, "rows_out")):
+            if t is not None:
+                self.env._check(t, what, shape=(self.batch_size,), dtypes=("int64",))
         q = [p.data for p in self.Q.parameters()]
         t1, t2, t3 = self.target_Q[0][0], self.target_Q[1][0][0], self.target_Q[2]
         ptr = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
@@ -253,7 +257,8 @@ class BatchedDeepQAgent:
         """n_steps of acting with the current (frozen) Q-network in one launch: forward, epsilon-greedy draw with a FIXED
         epsilon, env.step (evaluation and data collection; learning schedules epsilon per step and uses step())."""
         weights = self.greedy_weights()
-        assert weights is not None, "act_rollout needs the fused policy kernel (two layers of 64 / 100 / 128 units)"
+        if weights is None:
+            raise ValueError("act_rollout needs the fused policy kernel (two layers of 64 / 100 / 128 units)")
         self.env.policy_rollout(weights, n_steps, mode="greedy", epsilon=epsilon, draw_index0=self.t, auto_reset=auto_reset)
         self.t += int(n_steps)
 
@@ -388,7 +393,8 @@ class BatchedDeepQAgent:
         if (learn, cheat) in self._graphs:
             return
         if learn:
-            assert self.replay.filled == self.replay.slices, "fill the replay ring (warmup) before capturing the learn graph"
+            if self.replay.filled != self.replay.slices:
+                raise ValueError("fill the replay ring (warmup) before capturing the learn graph")
         env = self.env
         if learn:
             self.replay.head_dev.fill_(self.replay.head)
@@ -407,7 +413,7 @@ class BatchedDeepQAgent:
             with torch.cuda.graph(graph):
                 env.bind_torch_stream(torch.cuda.current_stream(self.device))  # the capture stream
                 self._captured_iteration(learn, cheat)
-            env.bind_torch_stream(torch.cuda.current_stream(self.device))
+            env.bind_torch_stream()  # follow torch's current stream again: replays are launched on it
         env.account_steps(-1)  # the recorded (not executed) sgk_step bumped the host-side counters once
         self._graphs[(learn, cheat)] = graph
 

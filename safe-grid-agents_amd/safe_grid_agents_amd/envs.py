@@ -138,14 +138,21 @@ class BatchedGridworldEnv:
     everything returned is a torch tensor VIEW of library memory in HBM (valid until the next call that
     writes it; `.clone()` to keep).
 
-    Streams: the handle starts on a stream of its own, and every call that takes or returns tensors orders itself against torch's
-    current stream (an event record + wait each way, ~12 us a pair on ROCm). A loop that calls per lockstep step -- act_explore /
-    step / learn / reset_done -- should call `bind_torch_stream()` once: the library then enqueues on torch's stream and the four
-    calls cost 16-28 us per step instead of 88-103 (EXPERIMENTS R5.13). The fused entry points (agent.rollout, step_random,
-    rollout_random_stream, policy_rollout) make one call per rollout and do not care.
+    Streams (`stream=`): "torch" (default) -- the library enqueues its kernels on torch's CURRENT stream of the device, looked up
+    again at every call (a `with torch.cuda.stream(...)` block or a graph capture is followed), so env steps and torch ops are
+    ordered by the stream itself: the per-step drop-in sequence act_explore / step / learn / reset_done costs 16-28 us per lockstep
+    step from Python. "own" -- the handle keeps a private stream and every call that takes or returns tensors orders itself against
+    torch's current stream with an event record + wait each way (~12 us a pair on ROCm: 88-103 us for the same four calls,
+    EXPERIMENTS R5.13); for callers that want the env to run beside torch work, and for the single-env step server.
+    `bind_torch_stream(stream)` pins the handle to one given torch stream; `bind_torch_stream()` returns to following;
+    `use_own_stream()` to the private stream. The fused entry points (agent.rollout, step_random, rollout_random_stream,
+    policy_rollout) make one call per rollout and do not care.
+
+    Arguments are checked with exceptions, not asserts (`python -O` keeps them): a tensor of the wrong size, dtype or device is a
+    ValueError, never a pointer handed to a kernel.
     """
 
-    def __init__(self, name, n_envs, device=0, seed=0, env_index_base=0, layout="compact", host_visible=False):
+    def __init__(self, name, n_envs, device=0, seed=0, env_index_base=0, layout="compact", host_visible=False, stream="torch"):
         if name not in ENV_IDS:
             raise KeyError("unknown or out-of-scope env %r; available: %s" % (name, sorted(ENV_IDS)))
         self.name = name
@@ -170,9 +177,14 @@ class BatchedGridworldEnv:
         self._views = None
         self._finished_bufs = None
         self._tstream = None
-        self._bound = False
         self._events = None
         self._outputs = None
+        if stream not in ("torch", "own"):
+            raise ValueError("stream must be 'torch' (enqueue on torch's current stream) or 'own' (a private stream), not %r" % (stream,))
+        # "follow": torch's current stream, re-read at every call; "pinned": one torch stream (bind_torch_stream(s)); "own": private
+        self._mode = "follow" if stream == "torch" else "own"
+        self._bound_ptr = None  # the raw stream the library currently enqueues on (follow / pinned); None = its own stream
+        self._raw_current = None
 
     # ---- plumbing -------------------------------------------------------------------------------
     @property
@@ -181,32 +193,78 @@ class BatchedGridworldEnv:
 
     @property
     def stream_ptr(self):
-        return self.lib.sgk_get_stream(self._h.ptr)
+        """The HIP stream the library enqueues on, as an integer (0 = the device's NULL stream)."""
+        return self.lib.sgk_get_stream(self._h.ptr) or 0
+
+    @property
+    def _bound(self):
+        """True when the library enqueues on a torch stream (no cross-stream events needed)."""
+        return self._mode != "own"
+
+    def _current_raw(self):
+        """torch's current stream of this device as a raw hipStream_t value (0 = the NULL stream)."""
+        fn = self._raw_current
+        if fn is None:
+            import torch
+
+            raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # an int straight from the C extension: ~0.2 us
+            if raw is not None:
+                fn = lambda d=self.device: raw(d)  # noqa: E731
+            else:
+                fn = lambda d=self.device: torch.cuda.current_stream(d).cuda_stream  # noqa: E731
+            self._raw_current = fn
+        return fn()
+
+    def _set_raw(self, ptr):
+        if ptr == self._bound_ptr:
+            return
+        if ptr == 0:  # torch's default stream IS the NULL stream; a NULL argument to sgk_set_stream would mean "own stream"
+            _lib.check(self.lib.sgk_use_default_stream(self._h.ptr))
+        else:
+            _lib.check(self.lib.sgk_set_stream(self._h.ptr, ctypes.c_void_p(ptr)))
+        self._bound_ptr = ptr
+        self._tstream = None
+
+    def _follow(self):
+        """In "torch" mode: make the library enqueue on whatever torch's current stream is NOW. Every method that launches or waits
+        calls this first (one C call and an integer compare when nothing changed)."""
+        if self._mode == "follow":
+            self._set_raw(self._current_raw())
 
     def torch_stream(self):
-        """The library's own HIP stream as a torch.cuda.ExternalStream. torch does not own it; the library never destroys it
+        """The stream the library enqueues on, as a torch stream: torch's current stream when following it, the pinned stream, or
+        the library's own HIP stream as a torch.cuda.ExternalStream. torch does not own the latter; the library never destroys it
         either (streams of closed envs wait in a pool for the next env of the device), so torch-side objects that remember it --
         pinned host tensors copied on it record an event there when they are freed -- stay valid after close()."""
         import torch
 
+        if self._mode == "follow":
+            self._follow()
+            return torch.cuda.current_stream(self.device)
         if self._tstream is None:
             self._tstream = torch.cuda.ExternalStream(self.stream_ptr, device="cuda:%d" % self.device)
         return self._tstream
 
     def bind_torch_stream(self, stream=None):
-        """Enqueue the library's kernels on a torch stream (default: torch's current stream) so that env steps and
-        torch ops (the Q-network) are ordered by the stream itself, with no cross-stream events."""
-        import torch
-
-        stream = stream or torch.cuda.current_stream(self.device)
-        if stream.cuda_stream == 0:  # torch's default stream IS the NULL stream; a NULL argument would mean "own stream"
-            _lib.check(self.lib.sgk_use_default_stream(self._h.ptr))
-        else:
-            _lib.check(self.lib.sgk_set_stream(self._h.ptr, ctypes.c_void_p(stream.cuda_stream)))
+        """Enqueue the library's kernels on a torch stream so that env steps and torch ops (the Q-network) are ordered by the
+        stream itself, with no cross-stream events. With a stream: pinned to it until told otherwise. Without: follow torch's
+        current stream from now on (the constructor's default)."""
+        if stream is None:
+            self._mode = "follow"
+            self._follow()
+            return
+        self._mode = "pinned"
+        self._set_raw(int(stream.cuda_stream))
         self._tstream = stream
-        self._bound = True
+
+    def use_own_stream(self):
+        """Back to the handle's private stream; calls that take or return tensors order themselves against torch's current stream
+        with events."""
+        _lib.check(self.lib.sgk_set_stream(self._h.ptr, None))
+        self._mode, self._bound_ptr, self._tstream = "own", None, None
 
     def synchronize(self):
+        self._follow()
         _lib.check(self.lib.sgk_synchronize(self._h.ptr))
 
     def close(self):
@@ -237,24 +295,90 @@ class BatchedGridworldEnv:
         return self._views
 
     def _sync_torch_to_lib(self):
-        """Make the library's stream wait for work queued on torch's current stream (e.g. the policy net)."""
-        if self._bound:
+        """Make the library's stream wait for work queued on torch's current stream (e.g. the policy net): nothing to do when the
+        library enqueues on that very stream."""
+        if self._mode == "follow":
+            self._set_raw(self._current_raw())
+            return
+        if self._mode == "pinned":
             return
         import torch
 
         _lib.check(self.lib.sgk_stream_wait(self._h.ptr, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     def _sync_lib_to_torch(self):
-        if self._bound:
+        if self._mode != "own":
             return
         import torch
 
         _lib.check(self.lib.sgk_stream_signal(self._h.ptr, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
+    def _check(self, t, what, numel=None, shape=None, dtypes=None, contiguous=True):
+        """A tensor argument that a kernel will read or write through its raw pointer: on THIS device, of the expected dtype and
+        size, dense. ValueError otherwise (not assert: `python -O` must not turn a wrong tensor into a wild pointer)."""
+        import torch
+
+        if not isinstance(t, torch.Tensor):
+            raise ValueError("%s must be a torch tensor on cuda:%d, not %s" % (what, self.device, type(t).__name__))
+        if not t.is_cuda or t.device.index != self.device:
+            raise ValueError("%s lives on %s; this env's kernels run on cuda:%d" % (what, t.device, self.device))
+        if dtypes is not None and str(t.dtype).replace("torch.", "") not in dtypes:
+            raise ValueError("%s has dtype %s, expected %s" % (what, t.dtype, " or ".join(dtypes)))
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError("%s has shape %s, expected %s" % (what, tuple(t.shape), tuple(shape)))
+        if numel is not None and t.numel() != numel:
+            raise ValueError("%s has %d elements, expected %d" % (what, t.numel(), numel))
+        if contiguous and not t.is_contiguous():
+            raise ValueError("%s must be contiguous" % what)
+        return t
+
+    def _actions_arg(self, actions):
+        """uint8 [N] on this device from what the caller passed: a host array / list is uploaded, an integer tensor of another
+        width is narrowed (argmax gives int64), everything else is a ValueError."""
+        import torch
+
+        if not isinstance(actions, torch.Tensor):
+            actions = torch.as_tensor(np.asarray(actions, dtype=np.uint8), device="cuda:%d" % self.device)
+        if actions.dtype != torch.uint8:
+            if actions.dtype.is_floating_point or actions.dtype.is_complex or actions.dtype == torch.bool:
+                raise ValueError("actions have dtype %s, expected uint8 (or another integer type)" % actions.dtype)
+            actions = actions.to(torch.uint8)
+        return self._check(actions.contiguous(), "actions", numel=self.n_envs, dtypes=("uint8",))
+
+    def _weights_arg(self, weights):
+        """sgk_mlp_weights from the dict of float32 device tensors w1t [cells, H], b1 [H], w2 [H, H], b2 [H], w3t [H, 4], b3 [4]."""
+        try:
+            h = int(weights["b1"].numel())
+        except (KeyError, TypeError, AttributeError):
+            raise ValueError("weights must be a dict of float32 device tensors w1t, b1, w2, b2, w3t, b3") from None
+        shapes = {"w1t": (self.n_cells, h), "b1": (h,), "w2": (h, h), "b2": (h,), "w3t": (h, 4), "b3": (4,)}
+        for k, shape in shapes.items():
+            if k not in weights:
+                raise ValueError("weights lack %r" % k)
+            self._check(weights[k], "weights[%r]" % k, shape=shape, dtypes=("float32",))
+        return _lib.SgkMlpWeights(*(ctypes.c_void_p(weights[k].data_ptr()) for k in ("w1t", "b1", "w2", "b2", "w3t", "b3")), h)
+
+    def _scalar_arg(self, v, what, dtype):
+        """(pointer or None, scalar): a 1-element device tensor is read by the launch itself (graph replays), a number is passed."""
+        import torch
+
+        if isinstance(v, torch.Tensor):
+            self._check(v, what, numel=1, dtypes=(dtype,))
+            return ctypes.c_void_p(v.data_ptr()), 0
+        return None, v
+
+    def _out_actions(self, out):
+        import torch
+
+        if out is None:
+            return torch.empty(self.n_envs, dtype=torch.uint8, device="cuda:%d" % self.device)
+        return self._check(out, "out", numel=self.n_envs, dtypes=("uint8",))
+
     # ---- gym-shaped API -------------------------------------------------------------------------
     def seed(self, seed=None):
         """env.seed(seed) (reference train.py:52): the envs are deterministic; this re-keys the counter RNG that drives
         step_random / exploration draws from now on."""
+        self._follow()
         if seed is not None:
             _lib.check(self.lib.sgk_set_seed(self._h.ptr, int(seed) & (2**64 - 1)))
         return [seed]
@@ -265,14 +389,17 @@ class BatchedGridworldEnv:
 
     def reset(self, mask=None):
         if mask is None:
+            self._follow()
             _lib.check(self.lib.sgk_reset(self._h.ptr, None))
         else:
+            self._check(mask, "mask", numel=self.n_envs, dtypes=("uint8", "bool"))
             self._sync_torch_to_lib()
             _lib.check(self.lib.sgk_reset(self._h.ptr, ctypes.c_void_p(mask.data_ptr())))
         self._sync_lib_to_torch()
         return self.boards()
 
     def reset_done(self):
+        self._follow()
         _lib.check(self.lib.sgk_reset_done(self._h.ptr))
         self._sync_lib_to_torch()
         return self.boards()
@@ -288,15 +415,8 @@ class BatchedGridworldEnv:
         return self._outputs
 
     def step(self, actions, auto_reset=False, write_boards=True):
-        """actions: torch uint8 tensor [N] on this GPU."""
-        import torch
-
-        if not isinstance(actions, torch.Tensor):
-            actions = torch.as_tensor(np.asarray(actions, dtype=np.uint8), device="cuda:%d" % self.device)
-        if actions.dtype != torch.uint8:
-            actions = actions.to(torch.uint8)
-        actions = actions.contiguous()
-        assert actions.numel() == self.n_envs and actions.is_cuda
+        """actions: torch uint8 tensor [N] on this GPU (another integer dtype is narrowed; a host array is uploaded)."""
+        actions = self._actions_arg(actions)
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_step(self._h.ptr, ctypes.c_void_p(actions.data_ptr()), flags))
@@ -305,6 +425,7 @@ class BatchedGridworldEnv:
 
     def step_repeat(self, actions, n_steps, auto_reset=True, write_boards=True):
         """SingleActionAgent over the batch (reference dummy.py:19-30): env i repeats actions[i] for n_steps steps."""
+        actions = self._actions_arg(actions)
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_step_repeat(self._h.ptr, ctypes.c_void_p(actions.data_ptr()), int(n_steps), flags))
@@ -315,6 +436,7 @@ class BatchedGridworldEnv:
         """n_steps lockstep steps with RandomAgent-style actions from the counter RNG (no torch sync: pure library work).
         fused=False: one launch per step (hipGraph replay); fused=True: ONE launch, outputs materialised after the last step
         only; fused="stream": ONE launch with every step's boards and records materialised (rollout_random_stream)."""
+        self._follow()
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
         if fused == "stream":
             _lib.check(self.lib.sgk_rollout_random_stream(self._h.ptr, int(n_steps), flags, None, None, 1, 0))
@@ -330,16 +452,19 @@ class BatchedGridworldEnv:
         env's own buffers. layout="tile": the rings are tile-major, boards [n_tiles, ring, 64, n_cells] / recs
         [n_tiles, ring, 64, 4] with n_tiles = ceil(N / 64) (`ring_slices` re-orders one to [ring, N, ...]): one contiguous
         run per wave and launch -- the HBM write rate of the env's own buffers instead of the slice-major layout's."""
-        assert layout in ("slice", "tile")
+        if layout not in ("slice", "tile"):
+            raise ValueError("layout must be 'slice' or 'tile'")
         ring = 1
         n_tiles = (self.n_envs + 63) // 64
-        for t, tail in ((boards, self.n_cells), (recs, 4)):
+        for t, tail, what in ((boards, self.n_cells, "boards ring"), (recs, 4, "recs ring")):
             if t is not None:
+                if t.dim() != (4 if layout == "tile" else 3):
+                    raise ValueError("%s must have %d dimensions" % (what, 4 if layout == "tile" else 3))
                 want = (n_tiles, int(t.shape[1]), 64, tail) if layout == "tile" else (int(t.shape[0]), self.n_envs, tail)
-                assert t.is_cuda and t.is_contiguous() and tuple(t.shape) == want, "ring must be %s contiguous" % (want,)
+                self._check(t, what, shape=want, dtypes=("int8",))
                 ring = int(t.shape[1] if layout == "tile" else t.shape[0])
-        if boards is not None and recs is not None:
-            assert boards.shape[1 if layout == "tile" else 0] == recs.shape[1 if layout == "tile" else 0]
+        if boards is not None and recs is not None and boards.shape[1 if layout == "tile" else 0] != recs.shape[1 if layout == "tile" else 0]:
+            raise ValueError("the boards ring and the recs ring must have the same number of slices")
         ptr = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())  # noqa: E731
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_RING_TILE_MAJOR if layout == "tile" else 0)
         self._sync_torch_to_lib()
@@ -350,7 +475,15 @@ class BatchedGridworldEnv:
     def probe_trajectory_ring(self, boards=None, recs=None, layout="slice"):
         """Microseconds per slice a store-bound streamed rollout needs into THESE rings (sgk_ring_probe: the streamed kernel's
         stores and nothing else over every slice; the rings hold zeros afterwards)."""
-        assert layout in ("slice", "tile") and (boards is not None or recs is not None)
+        if layout not in ("slice", "tile") or (boards is None and recs is None):
+            raise ValueError("probe_trajectory_ring needs layout 'slice' or 'tile' and at least one ring")
+        n_tiles = (self.n_envs + 63) // 64
+        for t, tail, what in ((boards, self.n_cells, "boards ring"), (recs, 4, "recs ring")):
+            if t is not None:
+                if t.dim() != (4 if layout == "tile" else 3):
+                    raise ValueError("%s must have %d dimensions" % (what, 4 if layout == "tile" else 3))
+                self._check(t, what, dtypes=("int8",),
+                            shape=(n_tiles, int(t.shape[1]), 64, tail) if layout == "tile" else (int(t.shape[0]), self.n_envs, tail))
         ring = int((boards if boards is not None else recs).shape[1 if layout == "tile" else 0])
         ptr = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())  # noqa: E731
         us = ctypes.c_double(0.0)
@@ -374,7 +507,8 @@ class BatchedGridworldEnv:
         ptr = ctypes.c_void_p()
         _lib.check(self.lib.sgk_ring_alloc(self.device, nbytes, ctypes.byref(ptr)))
         t = torch.as_tensor(_RingMemory(self.lib, ptr.value, tuple(int(d) for d in shape)), device=dev)
-        assert t.data_ptr() == ptr.value and t.dtype == torch.int8
+        if t.data_ptr() != ptr.value or t.dtype != torch.int8:
+            raise RuntimeError("torch did not adopt the ring memory in place")
         return t
 
     def alloc_trajectory_ring(self, slices, candidates=1, layout="slice", with_boards=True, with_recs=True, min_bytes=1 << 30,
@@ -392,7 +526,8 @@ class BatchedGridworldEnv:
         not probed = nan, when nothing had to be chosen)."""
         import torch
 
-        assert layout in ("slice", "tile") and (with_boards or with_recs) and slices >= 1 and backing in ("ring", "torch")
+        if layout not in ("slice", "tile") or not (with_boards or with_recs) or slices < 1 or backing not in ("ring", "torch"):
+            raise ValueError("alloc_trajectory_ring: layout 'slice'|'tile', backing 'ring'|'torch', slices >= 1, boards and / or recs")
         n_tiles = (self.n_envs + 63) // 64
         dev = "cuda:%d" % self.device
         total = slices * self.n_envs * ((self.n_cells if with_boards else 0) + (4 if with_recs else 0))
@@ -436,6 +571,7 @@ class BatchedGridworldEnv:
     def prepare_step_random(self, n_steps, auto_reset=True, write_boards=True):
         """Build the hipGraph step_random(n_steps, ...) replays without stepping (sgk_step_random_prepare): callers that time
         a region prepare every chunk size they will use first."""
+        self._follow()
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
         _lib.check(self.lib.sgk_step_random_prepare(self._h.ptr, int(n_steps), flags))
 
@@ -444,17 +580,11 @@ class BatchedGridworldEnv:
         `epsilon` / `draw_index` may be 1-element device tensors (float64 / int64): the launch then reads them from HBM."""
         import torch
 
-        scores = scores.contiguous()
-        assert scores.dtype == torch.float32 and scores.shape == (self.n_envs, 4) and scores.is_cuda
-        if out is None:
-            out = torch.empty(self.n_envs, dtype=torch.uint8, device=scores.device)
-        eps_p = draw_p = None
-        if isinstance(epsilon, torch.Tensor):
-            assert epsilon.dtype == torch.float64 and epsilon.is_cuda
-            eps_p, epsilon = ctypes.c_void_p(epsilon.data_ptr()), 0.0
-        if isinstance(draw_index, torch.Tensor):
-            assert draw_index.dtype == torch.int64 and draw_index.is_cuda
-            draw_p, draw_index = ctypes.c_void_p(draw_index.data_ptr()), 0
+        scores = self._check(scores.contiguous() if isinstance(scores, torch.Tensor) else scores, "scores", shape=(self.n_envs, 4),
+                             dtypes=("float32",))
+        out = self._out_actions(out)
+        eps_p, epsilon = self._scalar_arg(epsilon, "epsilon", "float64")
+        draw_p, draw_index = self._scalar_arg(draw_index, "draw_index", "int64")
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_epsilon_greedy_ex(self._h.ptr, ctypes.c_void_p(scores.data_ptr()), float(epsilon),
                                                   int(draw_index), eps_p, draw_p, ctypes.c_void_p(out.data_ptr())))
@@ -465,18 +595,12 @@ class BatchedGridworldEnv:
         """Q-network forward (Linear-ReLU-Linear-ReLU-Linear, n_hidden 100) + act_explore for every env in one HIP launch,
         straight from the int8 boards. `weights`: dict of contiguous float32 device tensors w1t [cells,100], b1, w2
         [100,100], b2, w3t [100,4], b3. epsilon / draw_index: scalars or 1-element device tensors (float64 / int64)."""
-        import torch
-
-        if out is None:
-            out = torch.empty(self.n_envs, dtype=torch.uint8, device="cuda:%d" % self.device)
-        w = _lib.SgkMlpWeights(*(ctypes.c_void_p(weights[k].data_ptr()) for k in ("w1t", "b1", "w2", "b2", "w3t", "b3")),
-                               int(weights["b1"].numel()))
-        eps_p = draw_p = None
-        if isinstance(epsilon, torch.Tensor):
-            eps_p, epsilon = ctypes.c_void_p(epsilon.data_ptr()), 0.0
-        if isinstance(draw_index, torch.Tensor):
-            draw_p, draw_index = ctypes.c_void_p(draw_index.data_ptr()), 0
-        sp = None if scores_out is None else ctypes.c_void_p(scores_out.data_ptr())
+        out = self._out_actions(out)
+        w = self._weights_arg(weights)
+        eps_p, epsilon = self._scalar_arg(epsilon, "epsilon", "float64")
+        draw_p, draw_index = self._scalar_arg(draw_index, "draw_index", "int64")
+        sp = None if scores_out is None else ctypes.c_void_p(self._check(scores_out, "scores_out", shape=(self.n_envs, 4),
+                                                                         dtypes=("float32",)).data_ptr())
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_policy_act(self._h.ptr, ctypes.byref(w), float(epsilon), int(draw_index), eps_p, draw_p,
                                            ctypes.c_void_p(out.data_ptr()), sp))
@@ -488,14 +612,10 @@ class BatchedGridworldEnv:
         [N] drawn from Categorical(logits) with the counter RNG. `draw_index`: int or a 1-element int64 device tensor."""
         import torch
 
-        logits = logits.contiguous()
-        assert logits.dtype == torch.float32 and logits.shape == (self.n_envs, 4) and logits.is_cuda
-        if out is None:
-            out = torch.empty(self.n_envs, dtype=torch.uint8, device=logits.device)
-        draw_p = None
-        if isinstance(draw_index, torch.Tensor):
-            assert draw_index.dtype == torch.int64 and draw_index.is_cuda
-            draw_p, draw_index = ctypes.c_void_p(draw_index.data_ptr()), 0
+        logits = self._check(logits.contiguous() if isinstance(logits, torch.Tensor) else logits, "logits", shape=(self.n_envs, 4),
+                             dtypes=("float32",))
+        out = self._out_actions(out)
+        draw_p, draw_index = self._scalar_arg(draw_index, "draw_index", "int64")
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_categorical_sample(self._h.ptr, ctypes.c_void_p(logits.data_ptr()), int(draw_index), draw_p,
                                                    ctypes.c_void_p(out.data_ptr())))
@@ -505,16 +625,11 @@ class BatchedGridworldEnv:
     def policy_sample(self, weights, draw_index, out=None, logits_out=None):
         """PPOMLPAgent (default topology) trunk + actor forward and the Categorical draw for every env in one HIP launch,
         straight from the int8 boards. `weights` as for policy_act (w3t / b3 = the actor head)."""
-        import torch
-
-        if out is None:
-            out = torch.empty(self.n_envs, dtype=torch.uint8, device="cuda:%d" % self.device)
-        w = _lib.SgkMlpWeights(*(ctypes.c_void_p(weights[k].data_ptr()) for k in ("w1t", "b1", "w2", "b2", "w3t", "b3")),
-                               int(weights["b1"].numel()))
-        draw_p = None
-        if isinstance(draw_index, torch.Tensor):
-            draw_p, draw_index = ctypes.c_void_p(draw_index.data_ptr()), 0
-        lp = None if logits_out is None else ctypes.c_void_p(logits_out.data_ptr())
+        out = self._out_actions(out)
+        w = self._weights_arg(weights)
+        draw_p, draw_index = self._scalar_arg(draw_index, "draw_index", "int64")
+        lp = None if logits_out is None else ctypes.c_void_p(self._check(logits_out, "logits_out", shape=(self.n_envs, 4),
+                                                                         dtypes=("float32",)).data_ptr())
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_policy_sample(self._h.ptr, ctypes.byref(w), int(draw_index), draw_p,
                                               ctypes.c_void_p(out.data_ptr()), lp))
@@ -528,22 +643,22 @@ class BatchedGridworldEnv:
         epsilon (DeepQ acting with frozen weights). Optional device outputs: states int8 [n_steps, N, cells] (the board
         each action was chosen on), actions uint8 [n_steps, N], recs int8 [n_steps, N, 4]; with mask_finished the states /
         actions entries of an env whose episode is over are zeros (it idles when auto_reset is off)."""
-        w = _lib.SgkMlpWeights(*(ctypes.c_void_p(weights[k].data_ptr()) for k in ("w1t", "b1", "w2", "b2", "w3t", "b3")),
-                               int(weights["b1"].numel()))
+        w = self._weights_arg(weights)
+        if mode not in ("greedy", "sample"):
+            raise ValueError("mode must be 'greedy' or 'sample'")
 
-        def ptr(t, shape, what):
+        def ptr(t, shape, what, dtype):
             if t is None:
                 return None
-            assert t.is_cuda and t.is_contiguous() and tuple(t.shape) == shape, "%s: expected contiguous %r" % (what, shape)
-            return ctypes.c_void_p(t.data_ptr())
+            return ctypes.c_void_p(self._check(t, what, shape=shape, dtypes=(dtype,)).data_ptr())
 
         n = self.n_envs
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_policy_rollout(
             self._h.ptr, ctypes.byref(w), {"greedy": 0, "sample": 1}[mode], float(epsilon), int(draw_index0), int(n_steps),
             (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_MASK_FINISHED if mask_finished else 0),
-            ptr(states, (n_steps, n, self.n_cells), "states"),
-            ptr(actions, (n_steps, n), "actions"), ptr(recs, (n_steps, n, 4), "recs")))
+            ptr(states, (n_steps, n, self.n_cells), "states", "int8"),
+            ptr(actions, (n_steps, n), "actions", "uint8"), ptr(recs, (n_steps, n, 4), "recs", "int8")))
         self._sync_lib_to_torch()
 
     def ppo_epochs(self, learner):
@@ -559,13 +674,15 @@ class BatchedGridworldEnv:
         reference's float32 rounding order (bit-exact)."""
         import torch
 
-        rewards = rewards.contiguous()
-        assert rewards.dtype == torch.float32 and rewards.dim() == 2 and rewards.is_cuda
+        rewards = self._check(rewards.contiguous() if isinstance(rewards, torch.Tensor) else rewards, "rewards", dtypes=("float32",))
+        if rewards.dim() != 2:
+            raise ValueError("rewards must be [n_trajectories, T]")
         if out is None:
             out = torch.zeros_like(rewards)
+        self._check(out, "out", shape=tuple(rewards.shape), dtypes=("float32",))
         lp = None
         if lengths is not None:
-            lengths = lengths.to(torch.int32).contiguous()
+            lengths = self._check(lengths, "lengths", numel=rewards.shape[0], contiguous=False).to(torch.int32).contiguous()
             lp = ctypes.c_void_p(lengths.data_ptr())
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_discounted_returns(self._h.ptr, ctypes.c_void_p(rewards.data_ptr()), lp,
@@ -584,6 +701,7 @@ class BatchedGridworldEnv:
 
         if out is None:
             out = torch.empty((self.n_envs, self.n_cells), dtype=torch.float32, device="cuda:%d" % self.device)
+        self._check(out, "out", shape=(self.n_envs, self.n_cells), dtypes=("float32",))
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_obs_f32(self._h.ptr, ctypes.c_void_p(out.data_ptr())))
         self._sync_lib_to_torch()
@@ -596,6 +714,7 @@ class BatchedGridworldEnv:
         if out is None:
             shape = (self.n_envs, self.H, self.W, 3) if self.info.render_hwc else (self.n_envs, 3, self.H, self.W)
             out = torch.empty(shape, dtype=torch.uint8, device="cuda:%d" % self.device)
+        self._check(out, "out", numel=self.n_envs * 3 * self.H * self.W, dtypes=("uint8",))
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_render_rgb(self._h.ptr, ctypes.c_void_p(out.data_ptr())))
         self._sync_lib_to_torch()
@@ -603,16 +722,19 @@ class BatchedGridworldEnv:
 
     # ---- host copies (synchronising) --------------------------------------------------------------
     def boards_host(self):
+        self._follow()
         out = np.empty((self.n_envs, 1, self.H, self.W), dtype=np.int8)
         _lib.check(self.lib.sgk_copy_boards(self._h.ptr, out.ctypes.data))
         return out
 
     def step_records_host(self):
+        self._follow()
         out = np.empty((self.n_envs, 4), dtype=np.int8)
         _lib.check(self.lib.sgk_copy_step_records(self._h.ptr, out.ctypes.data))
         return out
 
     def episode_state_host(self):
+        self._follow()
         n = self.n_envs
         ret, hid, frame = (np.empty(n, dtype=np.int32) for _ in range(3))
         over, cell, box = (np.empty(n, dtype=np.uint8) for _ in range(3))
@@ -624,11 +746,13 @@ class BatchedGridworldEnv:
     def last_performance_host(self):
         """last_episode_host()["last_performance"] alone: what get_last_performance() reads (on a host-visible handle a plain read
         of pinned host memory that leaves the resident step server where it is)."""
+        self._follow()
         perf = np.empty(self.n_envs, dtype=np.int32)
         _lib.check(self.lib.sgk_copy_last_episode(self._h.ptr, None, perf.ctypes.data, None))
         return perf
 
     def last_episode_host(self):
+        self._follow()
         n = self.n_envs
         a, b, c = (np.empty(n, dtype=np.int32) for _ in range(3))
         _lib.check(self.lib.sgk_copy_last_episode(self._h.ptr, a.ctypes.data, b.ctypes.data, c.ctypes.data))
@@ -646,11 +770,13 @@ class BatchedGridworldEnv:
     def bandit_policy(self):
         """FriendFoe: environment_data['bandit'] of every env -- float64 [n_envs, 3 bandit types, 2 boxes], the exponentially
         smoothed probability that the agent opens box 0 / box 1 in an episode of that type (kept across episodes)."""
+        self._follow()
         out = np.empty((self.n_envs, 3, 2), dtype=np.float64)
         _lib.check(self.lib.sgk_copy_bandit_policy(self._h.ptr, out.ctypes.data))
         return out
 
     def metrics(self):
+        self._follow()
         out = np.zeros(_lib.METRICS_LEN, dtype=np.int64)
         _lib.check(self.lib.sgk_metrics(self._h.ptr, out.ctypes.data))
         return out
@@ -659,6 +785,7 @@ class BatchedGridworldEnv:
         return self._device_views()["metrics"]
 
     def metrics_reset(self):
+        self._follow()
         _lib.check(self.lib.sgk_metrics_reset(self._h.ptr))
 
     def finished(self):
@@ -706,7 +833,8 @@ class GridworldEnv:
 
     def __init__(self, name, device=0):
         self.use_transitions = name in TRANSITION_ENVS  # observation = [last board, board], shape (2, H, W)
-        self._b = BatchedGridworldEnv(TRANSITION_ENVS.get(name, name), 1, device=device, host_visible=True, layout="pitched")
+        # (a stream of its own: the step server is a kernel that stays resident on the handle's stream between steps)
+        self._b = BatchedGridworldEnv(TRANSITION_ENVS.get(name, name), 1, device=device, host_visible=True, layout="pitched", stream="own")
         self.name = name
         self.action_space = self._b.action_space
         self.observation_space = self._b.observation_space
@@ -766,7 +894,8 @@ class GridworldEnv:
         if hasattr(action, "item"):  # np.int64 (value.py:35) or a 1-element tensor (value.py:92 via eval.py:35-36)
             action = action.item()
         action = int(action)
-        assert 0 <= action < self._n_actions, "Not a valid action."
+        if not 0 <= action < self._n_actions:  # (the reference's convention for a bad action, dummy.py:27 -- raised, so that -O keeps it)
+            raise AssertionError("Not a valid action.")
         self._act[0] = action
         rc = self._step_fn(self._handle_owner.ptr, *self._step_tail)
         if rc:

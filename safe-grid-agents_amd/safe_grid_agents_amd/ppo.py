@@ -367,12 +367,12 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         env = self.env
         steps = self._buffers["actions"].shape[0]
         if self._gather_graph is None:
-            cur = torch.cuda.current_stream(self.device)
+            cur, following = torch.cuda.current_stream(self.device), env._mode == "follow"
             graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(graph):
                 env.bind_torch_stream(torch.cuda.current_stream(self.device))  # the capture stream
                 self._gather_steps()
-            env.bind_torch_stream(cur)
+            env.bind_torch_stream(None if following else cur)
             env.account_steps(-steps)  # the recorded (not executed) sgk_step calls bumped the host-side counters
             self._gather_graph = graph
         self._draw_dev.fill_(self.draws)
@@ -447,13 +447,15 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         T, n = rollout.actions.shape
         L = _lib.SgkPpoLearner()
         ptr = lambda t: ctypes.c_void_p(t.data_ptr())
-        for t in (rollout.states, rollout.actions, rollout.returns, rollout.lengths):
-            assert t.is_cuda and t.is_contiguous()
-        assert rollout.states.dtype == torch.int8 and rollout.returns.dtype == torch.float32 and rollout.lengths.dtype == torch.int32
+        chk = self.env._check  # ValueError for a tensor of the wrong device / dtype / shape: the kernel takes raw pointers
+        chk(rollout.states, "rollout.states", shape=(T, n, self.env.n_cells), dtypes=("int8",))
+        chk(rollout.actions, "rollout.actions", shape=(T, n), dtypes=("uint8",))
+        chk(rollout.returns, "rollout.returns", shape=(n, T), dtypes=("float32",))
+        chk(rollout.lengths, "rollout.lengths", shape=(n,), dtypes=("int32",))
         L.states, L.actions, L.returns, L.lengths = ptr(rollout.states), ptr(rollout.actions), ptr(rollout.returns), ptr(rollout.lengths)
         L.horizon, L.n_hidden, L.batch, L.n_epochs, L.n_trajectories = T, own[1].numel(), self.batch_size, self.epochs, n
         for k, t in zip(("w1", "b1", "w2", "b2", "wa", "ba", "wc", "bc"), own):
-            assert t.is_contiguous()
+            chk(t, "parameter " + k, dtypes=("float32",))
             setattr(L, k, ptr(t))
         L.w1t, L.w2t = ptr(pl["w1t"]), ptr(pl["w2t"])
         for i in range(8):
@@ -467,10 +469,10 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
             t_ix, n_ix = valid.nonzero(as_tuple=True)
             flat = t_ix * n + n_ix
             keep = torch.stack([flat[torch.as_tensor(r, device=self.device)] for r in rows]).to(torch.int64).contiguous()
-            assert tuple(keep.shape) == (self.epochs, self.batch_size)
+            chk(keep, "rows", shape=(self.epochs, self.batch_size), dtypes=("int64",))
             L.rows = ptr(keep)
         if rows_out is not None:  # int64 [epochs, batch_size] on the device: receives the flat rows t * N + env used
-            assert rows_out.dtype == torch.int64 and rows_out.is_contiguous() and tuple(rows_out.shape) == (self.epochs, self.batch_size)
+            chk(rows_out, "rows_out", shape=(self.epochs, self.batch_size), dtypes=("int64",))
             L.rows_out = ptr(rows_out)
         g = self.net.optim.param_groups[0]
         L.lr, (L.beta1, L.beta2), L.eps = float(g["lr"]), g["betas"], float(g["eps"])

@@ -137,11 +137,12 @@ def test_batched_default_eval_reproduces_the_reference_default_eval(name):
         agent.close(); env.close()
 
 
-@pytest.mark.parametrize("how", ["calls", "graph"])
+@pytest.mark.parametrize("how", ["calls", "step", "graph", "graph_separate"])
 @pytest.mark.parametrize("name", BG.TABQ_FIXTURES)
 def test_drop_in_call_sequence_reproduces_the_reference_agents(name, how):
-    """act_explore -> env.step -> learn -> reset_done as four launches per lockstep step, made from Python (every step's actions
-    compared with the reference agents') and replayed from a hipGraph (sgk_tabq_learn_steps)."""
+    """One lockstep step of tabq_learn, four ways: "calls" = act_explore -> env.step -> learn -> reset_done as four launches made
+    from Python, "step" = the same as ONE launch (sgk_tabq_step) -- every step's actions compared with the reference agents' --,
+    "graph" = sgk_tabq_learn_steps (a hipGraph of the one-launch step), "graph_separate" = a hipGraph of the four launches."""
     _torch()
     fx = BG.TabqFixture(name)
     env = S.BatchedGridworldEnv(fx.env, fx.n, seed=fx.seed)
@@ -154,13 +155,18 @@ def test_drop_in_call_sequence_reproduces_the_reference_agents(name, how):
                 env.step(a, auto_reset=False, write_boards=(t == fx.steps - 1))
                 agent.learn(action=a, cheat=fx.cheat)
                 env.reset_done()
+        elif how == "step":
+            for t in range(fx.steps):
+                a, _ = agent.step(cheat=fx.cheat, write_boards=(t == fx.steps - 1))
+                assert a.cpu().numpy().tolist() == fx.actions[t].tolist(), t
         else:
+            sep = how == "graph_separate"
             done = 0
             for k in (100, 100, 7, 1, 500):
-                agent.learn_steps(k, cheat=fx.cheat)
+                agent.learn_steps(k, cheat=fx.cheat, separate_launches=sep)
                 done += k
-            agent.learn_steps(fx.steps - done - 1, cheat=fx.cheat)
-            agent.learn_steps(1, cheat=fx.cheat, write_boards=True)
+            agent.learn_steps(fx.steps - done - 1, cheat=fx.cheat, separate_launches=sep)
+            agent.learn_steps(1, cheat=fx.cheat, write_boards=True, separate_launches=sep)
         _assert_final_state(env, agent, fx)
         _assert_tables_are_the_reference_dictionaries(env, agent, fx)
     finally:
