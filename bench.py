@@ -542,10 +542,12 @@ def run_config(args):
         pieces = {
             "replay_store_states": ev_time(env, lambda: dq.replay.store(env, 0), 200),
             "forward_and_act_explore": ev_time(env, lambda: env.policy_act(dq._fw, 0.01, 0, out=acts), 200),
-            "env_step": ev_time(env, lambda: env.step(acts, auto_reset=False), 200),
+            # env.step and reset_done as ONE piece, in the order the lockstep step makes them: timed apart and back to back (as rounds
+            # 3-5 did) most timed steps run on envs whose episode is over -- the idle path -- and every reset after the first has
+            # nothing to reset, which read both pieces ~1.3 us short
+            "env_step_and_reset_done": ev_time(env, lambda: (env.step(acts, auto_reset=False), env.reset_done()), 200),
             "replay_store_successors": ev_time(env, lambda: dq.replay.store(env, 1, acts), 200),
             "sgd_step": ev_time(env, lambda: dq.learn_batch(), 200),
-            "reset_done": ev_time(env, lambda: env.reset_done(), 200),
         }
         device_sum = sum(pieces.values())
         dt_best = min(dt_learn, dt_learn_graph)
@@ -556,12 +558,12 @@ def run_config(args):
             "graph_us_per_lockstep_step": dt_learn_graph * 1e6, "graph_value": n / dt_learn_graph,
             "breakdown_us": {k: v * 1e6 for k, v in pieces.items()},
             "breakdown_device_sum_us": device_sum * 1e6,
-            "acting_us": (pieces["forward_and_act_explore"] + pieces["env_step"] + pieces["reset_done"]) * 1e6,
+            "acting_us": (pieces["forward_and_act_explore"] + pieces["env_step_and_reset_done"]) * 1e6,
             "replay_store_us": (pieces["replay_store_states"] + pieces["replay_store_successors"]) * 1e6,
             "sgd_us": pieces["sgd_step"] * 1e6,
             "whole_step_minus_pieces_us": {"graph": (dt_learn_graph - device_sum) * 1e6, "eager": (dt_learn - device_sum) * 1e6},
-            "note": "one SGD step (batch 64, Adam amsgrad, ONE 1 024-lane workgroup: sgk::dqn_sgd_kernel, 41 us by the kernel trace: "
-                    "profiles/r05/dqn_learn_kernel_stats.csv) per lockstep step of all 32 768 envs; the reference's ratio is one SGD step per "
+            "note": "one SGD step (batch 64, Adam amsgrad, ONE 1 024-lane workgroup: sgk::dqn_sgd_kernel, 39 us, timeline "
+                    "profiles/r06/dqn_timeline_after.log) per lockstep step of all 32 768 envs; the reference's ratio is one SGD step per "
                     "SINGLE env-step (value.py:113-117). Each piece is timed alone, 200 calls back to back from Python: a piece reads "
                     "max(its kernel, one Python call ~ 5 us), so the pieces can add up to MORE than the whole step, whose calls overlap "
                     "the previous kernels (whole_step_minus_pieces_us < 0)."}

@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define SGK_ABI_VERSION 3 /* 3: the tabular-Q tables in HBM are state-major (sgk_tabq_table_dev) */
+#define SGK_ABI_VERSION 4 /* 3: the tabular-Q tables in HBM are state-major (sgk_tabq_table_dev); 4: sgk_tabq_step, sgk_dqn_learner's
+                             loss_mode / rows / rows_out, SGK_F_SEPARATE_LAUNCHES, the sgk_debug_* hooks are off unless asked for */
 
 #if defined(__GNUC__)
 #define SGK_API __attribute__((visibility("default")))
@@ -521,7 +522,9 @@ SGK_API int sgk_reward_scale(sgk_env *h, double *scale_out);
  * the agent opens box 0 / box 1 in an episode of that type -- copied to host memory. SGK_ERR_INVALID for any other level. */
 SGK_API int sgk_copy_bandit_policy(sgk_env *h, double *out_host);
 
-/* ---- host-only debug hooks for the CPU test-suite (no GPU needed; never used by a product path) ------- */
+/* ---- test hooks (never used by a product path) -------------------------------------------------------
+ * Every sgk_debug_* entry point answers only in a process that set SGK_ENABLE_TEST_HOOKS=1 in its environment BEFORE the library was
+ * loaded (the variable is read once, at load); otherwise it returns SGK_ERR_INVALID (sgk_debug_reset_word: ~0) and does nothing. */
 /* The kernels' transition function, evaluated on the host for one (agent cell, box cell, action):
  * out = {next agent cell, next box cell, observed reward, hidden reward, terminal | mode bit after the step << 1};
  * `box_cell` carries the state word's mode bit BEFORE the step in bit 8. */

@@ -22,6 +22,12 @@ M_LEN = 16
  M_MAX_RETURN, M_MAX_SAFETY, M_MAX_MARGIN, M_MAX_MARGIN_POS) = range(12)
 
 
+def _ok(rc):
+    """A C call that must succeed (not `assert call() == 0`: python -O would drop the call with the assert)."""
+    if rc != 0:
+        raise RuntimeError("oracle call failed: %r" % (rc,))
+
+
 def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     if os.environ.get("SGK_ORACLE_SO"):
@@ -111,7 +117,7 @@ def _env_id(name_or_id):
 
 def shape(env):
     H, W = ctypes.c_int(), ctypes.c_int()
-    assert lib().orc_shape(_env_id(env), ctypes.byref(H), ctypes.byref(W)) == 0
+    _ok(lib().orc_shape(_env_id(env), ctypes.byref(H), ctypes.byref(W)))
     return H.value, W.value
 
 
@@ -166,7 +172,7 @@ class EnvBatch:
         self.rec = L.orc_sizeof()
         self.buf = ctypes.create_string_buffer(self.rec * max(self.n, 1))
         self.base = ctypes.addressof(self.buf)
-        assert L.orc_init_batch(self.base, self.n, self.env_id, int(seed), int(env_begin), int(bool(reset))) == 0
+        _ok(L.orc_init_batch(self.base, self.n, self.env_id, int(seed), int(env_begin), int(bool(reset))))
 
     def ptr(self, i=0):
         return self.base + i * self.rec
@@ -195,7 +201,7 @@ class EnvBatch:
 
     def render_rgb(self, i):
         out = np.empty((3, self.H, self.W), dtype=np.uint8)
-        assert lib().orc_render_rgb(self.ptr(i), out.ctypes.data) == 0
+        _ok(lib().orc_render_rgb(self.ptr(i), out.ctypes.data))
         return out
 
     def boards(self):
@@ -239,7 +245,8 @@ class EnvBatch:
         a_ptr = None
         if actions is not None:
             actions = np.ascontiguousarray(actions, dtype=np.uint8)
-            assert actions.shape == (n_steps, self.n)
+            if actions.shape != (n_steps, self.n):
+                raise ValueError("actions must be [n_steps, n]")
             a_ptr = actions.ctypes.data
         lib().orc_rollout(self.base, self.n, env_begin, seed, t_begin, n_steps, int(auto_reset), a_ptr,
                           rec.ctypes.data, None if metrics is None else metrics.ctypes.data)

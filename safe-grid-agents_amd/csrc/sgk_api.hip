@@ -41,6 +41,8 @@ struct sgk_env {
   hipEvent_t switch_event = nullptr;                // sgk_set_stream / sgk_use_default_stream: old stream -> new stream
   long long *metrics_pinned = nullptr;  // [SGK_METRICS_LEN] pinned device-mapped host words the reduce kernel also writes
   float *gamma_dev = nullptr;        // [1024] float32(discount ** t) for sgk_discounted_returns
+  void *learn_scratch = nullptr;     // (-DSGK_DQN_MULTI_WG experiment build: the four-workgroup learner's barrier words + partial gradients)
+  size_t learn_scratch_bytes = 0;
   double gamma_discount = -1.0;
   // the single-env step server (sgk_step.hip, env_server_kernel): a resident wave that serves sgk_step_host through a mailbox
   sgk::host::ServerLink srv;           // srv.mb: pinned device-mapped host memory (host_visible handles of <= 64 envs); the protocol:
@@ -108,7 +110,20 @@ double sgk_tabq_epsilon(double epsilon, int64_t epsilon_anneal, int64_t t) try {
   return sgk::host_epsilon_at(epsilon, epsilon_anneal, t);
 } SGK_CATCH_VALUE(0.0)
 
+// The sgk_debug_* entry points are test hooks (one makes the next host allocation fail, one plants a stale word in a mailbox): they
+// answer only in a process that set SGK_ENABLE_TEST_HOOKS=1 BEFORE it loaded the library (read once, when the library is loaded: a
+// program cannot be talked into arming them later). tests/conftest.py sets it; nothing on a product path does.
+static const bool test_hooks_on = [] {
+  const char *v = getenv("SGK_ENABLE_TEST_HOOKS");
+  return v && v[0] == '1' && v[1] == 0;
+}();
+#define SGK_TEST_HOOK_ONLY()                                                                                                   \
+  do {                                                                                                                         \
+    if (!test_hooks_on) return fail(SGK_ERR_INVALID, "test hook: set SGK_ENABLE_TEST_HOOKS=1 before the library is loaded");  \
+  } while (0)
+
 int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int action, int32_t out[5]) try {
+  SGK_TEST_HOOK_ONLY();
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
   if (agent_cell < 0 || agent_cell >= R.n_cells || action < 0 || action >= SGK_ACTIONS) return fail(SGK_ERR_INVALID, "bad cell/action");
@@ -121,6 +136,7 @@ int sgk_debug_host_transition(int env_id, int agent_cell, int box_cell, int acti
 
 int sgk_debug_host_step(int env_id, uint64_t state_word, int n_resets, int action, uint64_t seed, uint64_t env_index,
                         uint64_t *state_word_out, int32_t out[4], double *aux_env) try {
+  SGK_TEST_HOOK_ONLY();
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
   if (action < 0 || action >= SGK_ACTIONS || !state_word_out || !out) return fail(SGK_ERR_INVALID, "bad action / NULL output");
@@ -132,12 +148,14 @@ int sgk_debug_host_step(int env_id, uint64_t state_word, int n_resets, int actio
 } SGK_CATCH_STATUS
 
 uint64_t sgk_debug_reset_word(int env_id, uint64_t seed, uint64_t env_index, int n_resets, const double *aux_env) try {
+  if (!test_hooks_on) return ~0ull;  // (the "unknown env" answer: no state word)
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return ~0ull;
   return sgk::host_reset_word(R, seed, env_index, n_resets, aux_env);
 } SGK_CATCH_VALUE(~0ull)
 
 int sgk_debug_level(int env_id, int32_t dims[4], uint8_t templ[64], uint8_t agent_value[64]) try {
+  SGK_TEST_HOOK_ONLY();
   SgkRules R;
   if (sgk_build_rules(env_id, &R) != 0) return fail(SGK_ERR_INVALID, "unknown env_id");
   if (!dims || !templ || !agent_value) return fail(SGK_ERR_INVALID, "NULL output");
@@ -177,6 +195,7 @@ int sgk_destroy(sgk_env *h) try {
   (void)hipFree(s.finished_total); (void)hipFree(h->t_dev); (void)hipFree(h->dense_scratch);
   (void)hipFree(h->actions_scratch);
   (void)hipFree(h->gamma_dev);
+  (void)hipFree(h->learn_scratch);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->copy_chunk) (void)hipHostFree(h->copy_chunk);
   if (h->metrics_pinned) (void)hipHostFree(h->metrics_pinned);
@@ -856,6 +875,28 @@ int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) try {
   d.loss_out = L->loss_out;
   d.n_hidden = L->n_hidden; d.batch = L->batch; d.loss_mode = L->loss_mode;
   d.rows = reinterpret_cast<const long long *>(L->rows); d.rows_out = reinterpret_cast<long long *>(L->rows_out);
+  d.scratch = nullptr;
+#ifdef SGK_DQN_MULTI_WG
+  // EXPERIMENT build only (sgk_learn.hip): the four-workgroup kernel needs a scratch block of the handle's, made on the first call
+  // (not inside a stream capture); SGK_DQN_WORKGROUPS=1 in the environment keeps the one-workgroup kernel (the A/B of profiles/r06).
+  static const bool one_workgroup = [] { const char *v = getenv("SGK_DQN_WORKGROUPS"); return v && v[0] == '1' && v[1] == 0; }();
+  if (!one_workgroup) {
+    const size_t need = sgk::dqn_sgd_scratch_bytes(h->sh.n_cells, L->n_hidden);
+    if (h->learn_scratch_bytes < need) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (h->stream) (void)hipStreamIsCapturing(h->stream, &cs);
+      if (cs != hipStreamCaptureStatusNone) return fail(SGK_ERR_INVALID, "the first sgk_dqn_sgd_step of a handle allocates: call it once before capturing it");
+      SGK_HIP(sgk::host::wait_stream(h->stream));
+      (void)hipFree(h->learn_scratch);
+      h->learn_scratch = nullptr;
+      h->learn_scratch_bytes = 0;
+      SGK_HIP(hipMalloc(&h->learn_scratch, need));
+      SGK_HIP(hipMemsetAsync(h->learn_scratch, 0, need, h->stream));
+      h->learn_scratch_bytes = need;
+    }
+    d.scratch = h->learn_scratch;
+  }
+#endif
   d.lr = L->lr; d.beta1 = L->beta1; d.beta2 = L->beta2; d.eps = L->eps; d.discount = L->discount; d.max_grad_norm = L->max_grad_norm;
   SGK_HIP(sgk::launch_dqn_sgd(h->sh, d, h->stream));
   return SGK_OK;
@@ -1355,6 +1396,7 @@ int sgk_tabq_invalidate_rows(sgk_tabq *q) try {
 } SGK_CATCH_STATUS
 
 int sgk_debug_server_stale_exit_word(sgk_env *h) try {
+  SGK_TEST_HOOK_ONLY();
   if (!h) return fail(SGK_ERR_INVALID, "handle is NULL");
   if (!h->srv.mb || !h->srv.running) return fail(SGK_ERR_INVALID, "no resident step server on this handle");
   sgk::host::mb_store(&h->srv.mb->exited, h->srv.seq + 1u);  // what a server that served up to srv.seq writes when it leaves
@@ -1362,9 +1404,13 @@ int sgk_debug_server_stale_exit_word(sgk_env *h) try {
   return SGK_OK;
 } SGK_CATCH_STATUS
 
-int sgk_debug_fail_host_alloc(int k) { return sgk::host::alloc_countdown().exchange(k < 0 ? 0 : k); }
+int sgk_debug_fail_host_alloc(int k) {
+  if (!test_hooks_on) return SGK_ERR_INVALID;  // (never armed in a process that did not ask for the hooks)
+  return sgk::host::alloc_countdown().exchange(k < 0 ? 0 : k);
+}
 
 int sgk_debug_graph_count(const sgk_env *h, const sgk_tabq *q, int32_t *env_graphs_out, int32_t *tabq_graphs_out) try {
+  SGK_TEST_HOOK_ONLY();
   if (env_graphs_out) *env_graphs_out = h ? (int32_t)h->graphs.size() : 0;
   if (tabq_graphs_out) *tabq_graphs_out = q ? (int32_t)q->graphs.size() : 0;
   return SGK_OK;
@@ -1382,10 +1428,24 @@ int sgk_tabq_copy_table(sgk_tabq *q, int64_t env_begin, int64_t env_count, doubl
   constexpr size_t STAGE_BYTES = (size_t)8 << 20;
   const size_t e_max = std::max<size_t>(1, STAGE_BYTES / (ns * row_bytes));
   if (!q->copy_stage) SGK_HIP(hipHostMalloc((void **)&q->copy_stage, std::max(STAGE_BYTES, ns * row_bytes), hipHostMallocDefault));
+  // (a plane is n x 32 bytes: from 2^26 agents on that is a source pitch of 2 GiB and more, beyond what a 2-D copy may take
+  // (hipDeviceAttributeMaxPitch) -- the planes' pieces are then copied one by one)
+  int max_pitch = 0;
+  if (hipDeviceGetAttribute(&max_pitch, hipDeviceAttributeMaxPitch, q->env->sh.device) != hipSuccess) {
+    (void)hipGetLastError();
+    max_pitch = 0;
+  }
+  const bool two_d = max_pitch > 0 && n * row_bytes <= (size_t)max_pitch;
   for (size_t e0 = 0; e0 < (size_t)env_count; e0 += e_max) {
     const size_t cnt = std::min(e_max, (size_t)env_count - e0);
-    SGK_HIP(hipMemcpy2DAsync(q->copy_stage, cnt * row_bytes, q->tq.table + ((size_t)env_begin + e0) * SGK_ACTIONS, n * row_bytes,
-                             cnt * row_bytes, ns, hipMemcpyDeviceToHost, q->env->stream));
+    const double *src = q->tq.table + ((size_t)env_begin + e0) * SGK_ACTIONS;
+    if (two_d) {
+      SGK_HIP(hipMemcpy2DAsync(q->copy_stage, cnt * row_bytes, src, n * row_bytes, cnt * row_bytes, ns, hipMemcpyDeviceToHost, q->env->stream));
+    } else {
+      for (size_t st = 0; st < ns; ++st)
+        SGK_HIP(hipMemcpyAsync(q->copy_stage + st * cnt * SGK_ACTIONS, src + st * n * SGK_ACTIONS, cnt * row_bytes, hipMemcpyDeviceToHost,
+                               q->env->stream));
+    }
     SGK_HIP(sgk::host::wait_stream(q->env->stream));
     for (size_t s = 0; s < ns; ++s)
       for (size_t e = 0; e < cnt; ++e)

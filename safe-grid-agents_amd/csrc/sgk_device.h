@@ -178,6 +178,11 @@ __device__ __forceinline__ void acc_flush(const EpisodeAcc &a, long long *__rest
 // int32 reductions issued ahead of the stores 3.78 (3.20 with the flush switched off, 0.07 of the rest being the per-env episode
 // arrays); this form 3.53 on a box that runs 0.1 slower. The two global atomics the flush ends with are NOT the cost: a variant
 // that owned its slot and used plain stores measured the same.
+// The words are 32-bit (ds_add_u32): a wave's sums over ONE launch must stay below 2^31 -- tiles per wave x 64 lanes x the largest
+// |episode return| in reward units. The per-step kernels book at most one episode per env and launch: at the largest batch the
+// library accepts (2^31 - 512 envs over the 6 144 waves of a full grid = 5 462 tiles per wave) that is 3.5 x 10^5 episodes per
+// wave, times at most 1 300 units (tomato watering: 13 tomatoes x 100 steps; the other levels stay within +-150) = 4.5 x 10^8.
+// A level whose returns could exceed ~6 000 units would have to flush a wave's words more often (flush() is 64-bit from there on).
 struct WaveEpisodeLds {
   int *w;  // [16] wave-private: 0 s_ret, 1 s_perf, 2 s_mpos, 3 n_eps, 4 n_pos, 5 m_ret, 6 m_perf, 7 m_margin, 8 m_mpos
   bool used;  // wave-uniform: some lane of this wave has finished an episode in this launch (the words are initialised then)

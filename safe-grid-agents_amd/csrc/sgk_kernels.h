@@ -106,12 +106,14 @@ struct DqnLearner {
   int loss_mode;  // SGK_DQN_LOSS_*
   const long long *rows;  // caller's minibatch or null
   long long *rows_out;    // minibatch used, or null
+  void *scratch;          // null; (-DSGK_DQN_MULTI_WG experiment build: dqn_sgd_scratch_bytes() of zeroed device memory = run the four-workgroup kernel)
   double lr, beta1, beta2, eps, discount, max_grad_norm;
 };  // (the replay's int8 rewards are in units of the level's reward_scale: launch_dqn_sgd takes it from the shard's rules)
 hipError_t launch_replay_store(const Shard &sh, int phase, const uint8_t *actions, int cheat, int64_t head, const long long *head_dev,
                                int8_t *states, int8_t *successors, uint8_t *r_actions, int8_t *r_rewards, uint8_t *r_terminals,
                                hipStream_t st);
 size_t dqn_sgd_lds_bytes(int n_cells, int n_hidden);
+size_t dqn_sgd_scratch_bytes(int n_cells, int n_hidden);
 hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st);
 struct PpoLearner {
   const int8_t *states;

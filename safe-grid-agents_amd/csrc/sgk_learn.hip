@@ -20,6 +20,19 @@ extern "C" __device__ float __ockl_wfred_add_f32(float);
 
 namespace sgk {
 
+// -DSGK_LEARN_TIMELINE (tools/gpu_dqn_timeline.sh builds it into a library of its own, never the product's): lane 0 stamps
+// wall_clock64() (100 MHz) behind every barrier of dqn_sgd_kernel; sgk_debug_learn_stamps() reads them back.
+#ifdef SGK_LEARN_TIMELINE
+__device__ unsigned long long learn_stamps[32];
+// (stamps 30 / 31: the shader clock counter, s_memtime, at the first and at the latest stamp: in-kernel clock = their difference over
+// the wall-clock difference x 100 MHz)
+#define SGK_STAMP(i) do { if (threadIdx.x == 0) { learn_stamps[i] = wall_clock64(); learn_stamps[(i) == 0 ? 30 : 31] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define SGK_MSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { learn_stamps[i] = wall_clock64(); learn_stamps[(i) == 0 ? 30 : 31] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define SGK_STAMP(i) do { } while (0)
+#define SGK_MSTAMP(i) do { } while (0)
+#endif
+
 constexpr int LWG = 1024;    // lanes of the one workgroup
 constexpr int LB = 64;       // samples per minibatch handled (batch <= 64)
 
@@ -72,6 +85,36 @@ __device__ __forceinline__ void stage_rows(float *dst, const float *__restrict__
   for (int i = threadIdx.x * 4; i < rows * H; i += LWG * 4) {
     const int r = i / H, c = i - r * H;
     *reinterpret_cast<f4 *>(dst + r * WS + c) = *reinterpret_cast<const f4 *>(src + i);
+  }
+}
+
+// stage_rows() in two halves: the loads into registers BEFORE a compute phase, the LDS stores behind it -- the matrix's trip from
+// L2 runs in the shadow of the phase instead of in front of the next one (one staging buffer, re-filled per layer: the
+// activations of 64 samples leave LDS no room for a second)
+template <int H, int ROWS>
+struct RowsInFlight {
+  static constexpr int N = (ROWS * H / 4 + LWG - 1) / LWG;
+  f4 v[N];
+};
+template <int H, int ROWS>
+__device__ __forceinline__ void rows_request(RowsInFlight<H, ROWS> &r, const float *__restrict__ src) {
+#pragma unroll
+  for (int n = 0; n < RowsInFlight<H, ROWS>::N; ++n) {
+    const int i = ((int)threadIdx.x + n * LWG) * 4;
+    r.v[n] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    if (i < ROWS * H) r.v[n] = *reinterpret_cast<const f4 *>(src + i);
+  }
+}
+template <int H, int ROWS>
+__device__ __forceinline__ void rows_commit(float *dst, const RowsInFlight<H, ROWS> &r) {
+  constexpr int WS = weight_stride(H);
+#pragma unroll
+  for (int n = 0; n < RowsInFlight<H, ROWS>::N; ++n) {
+    const int i = ((int)threadIdx.x + n * LWG) * 4;
+    if (i < ROWS * H) {
+      const int rr = i / H, c = i - rr * H;
+      *reinterpret_cast<f4 *>(dst + rr * WS + c) = r.v[n];
+    }
   }
 }
 
@@ -193,6 +236,25 @@ __device__ __forceinline__ f4 weight_grad_mfma(const float *d, int DS, int row0,
   return acc;
 }
 
+// The same tile with the operands exchanged: the result comes out TRANSPOSED in the C layout -- lane (col, grp), register r =
+// G[row0 + col][col0 + 4 grp + r]: four CONSECUTIVE columns of one row, i.e. 16 contiguous bytes of a row-major [rows][cols] tensor.
+// The owner's Adam traffic on w, m, v and vmax is then four 16-byte loads and four 16-byte stores per quad instead of sixteen and
+// sixteen dword ones (one CU's memory pipeline was what bounded that phase: 13 us for 13.9 k parameters).
+template <class T>
+__device__ __forceinline__ f4 weight_grad_mfma_t(const float *d, int DS, int row0, const T *x, int XS, int col0, int lane) {
+  const int col = lane & 15, grp = lane >> 4;
+  f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  float av[LB / 4], bv[LB / 4];
+#pragma unroll
+  for (int s = 0; s < LB / 4; ++s) {
+    av[s] = load_x1(x + (4 * s + grp) * XS, col0 + col);
+    bv[s] = d[(4 * s + grp) * DS + row0 + col];
+  }
+#pragma unroll
+  for (int s = 0; s < LB / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+  return acc;
+}
+
 // Column sums on the matrix cores (a bias gradient): S[r] = sum_b d[b][row0 + r] over the LB samples -- the same tile product
 // with a B operand of ones. Lane (col, grp), register r = S[4 grp + r], the same in every column. A 64-iteration serial loop
 // per bias lane (64 dependent LDS reads, two waves busy, fourteen idle) cost 2-3 us per layer.
@@ -218,14 +280,21 @@ __device__ __forceinline__ float block_sum(float x, float *scratch) {  // scratc
 }
 
 struct AdamCoef {
-  float lr_bc1, bc2_sqrt, beta1, beta2, eps;
+  float lr_bc1, inv_bc2_sqrt, beta1, beta2, eps;  // lr / bias_correction1, 1 / sqrt(bias_correction2)
 };
 
+// One element of Adam(amsgrad), torch's formulas: exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq = beta2 * exp_avg_sq + (1 - beta2) grad^2;
+// denom = sqrt(max_exp_avg_sq) / sqrt(bias_correction2) + eps; param -= lr / bias_correction1 * exp_avg / denom.
+// The square root and the two quotients use the hardware's one-ulp forms (v_sqrt_f32, v_rcp_f32; 1 / sqrt(bias_correction2) is
+// formed once per launch): with IEEE sqrtf() and `/` the phase was VALU-bound -- ~60 instructions per element, 28 element slots per
+// lane, four waves per SIMD at four cycles per wave64 instruction = 11 of the 13 us the timeline showed -- and a relative 1e-7 in
+// an update that is itself ~1e-3 of the weight is far inside what the float32 summation order already differs by.
 __device__ __forceinline__ float adam_scalar(float p, float &m, float &v, float &vmax, float g, const AdamCoef &c) {
-  m = m + (1.0f - c.beta1) * (g - m);  // exp_avg.lerp_(grad, 1 - beta1)
+  m = m + (1.0f - c.beta1) * (g - m);
   v = c.beta2 * v + (1.0f - c.beta2) * g * g;
   vmax = fmaxf(vmax, v);
-  return p - c.lr_bc1 * (m / (sqrtf(vmax) / c.bc2_sqrt + c.eps));
+  const float denom = __builtin_amdgcn_sqrtf(vmax) * c.inv_bc2_sqrt + c.eps;
+  return p - c.lr_bc1 * (m * __builtin_amdgcn_rcpf(denom));
 }
 
 // Adam on four consecutive parameters (16-byte aligned); returns the updated values
@@ -284,6 +353,7 @@ __device__ __forceinline__ LearnLds carve(unsigned char *base, int KP, int H) {
 
 template <int K0, int H>
 __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
+  SGK_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char learn_smem[];
   const int B = a.batch;
   constexpr int KP = (K0 + 3) & ~3;  // row stride of the board matrices (padding columns hold zeros)
@@ -292,28 +362,14 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   const int lane = t & 63, wave = t >> 6, col = lane & 15, grp = lane >> 4;
   constexpr int MT = (H + 15) / 16, KT1 = (K0 + 15) / 16;  // 16-wide tiles along neurons / along board cells
 
-  // ---- minibatch: uniform with replacement over the stored transitions (contain.py:19-22), counter RNG ----
-  if (t < LB) {
-    int id = 0;
-    if (t < B) {
-      if (a.rows) {
-        const long long r = a.rows[t];
-        id = (r >= 0 && r < a.total) ? (int)r : 0;  // (an index outside the stored transitions reads transition 0, not wild memory)
-      } else {
-        uint32_t x[4];
-        philox4x32_10((uint32_t)t, 0u, (uint32_t)*a.step, 4u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
-        const unsigned long long r = ((unsigned long long)x[0] << 32) | x[1];
-        id = (int)__umul64hi(r, (unsigned long long)a.total);
-      }
-      if (a.rows_out) a.rows_out[t] = id;
-    }
-    L.idx[t] = id;
-    L.act[t] = a.actions[id] & 3;
-    L.rew[t] = (float)((double)a.rewards[id] * a.reward_scale);
-    L.term[t] = a.terminals[id] ? 1 : 0;
-  }
-  // the small tensors and the first weight matrix travel meanwhile
-  stage_rows<H>(L.ST, a.tw1t, K0);
+  // ---- entry: ONE dependent chain of two memory round trips (the Adam step counter, then everything keyed by it) ----
+  // minibatch: uniform with replacement over the stored transitions (contain.py:19-22), counter RNG. The index of the sample whose
+  // bytes a lane fetches is derived by that lane (16 lanes per sample, each the same draw): the board gather needs no exchange
+  // through LDS behind the draw, so indices, scalars and both boards travel together (they were two round trips and a barrier).
+  const long long step0 = *a.step;
+  // the first weight matrix and the small tensors are independent of it: requested first, so that they are in flight meanwhile
+  RowsInFlight<H, K0> first;
+  rows_request<H, K0>(first, a.tw1t);
   stage(L.w3, a.w3, 4 * H);
   stage(L.tw3, a.tw3, 4 * H);
   stage(L.b1, a.b1, H);
@@ -321,34 +377,85 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   stage(L.tb1, a.tb1, H);
   stage(L.tb2, a.tb2, H);
   if (t < 4) { L.b3[t] = a.b3[t]; L.tb3[t] = a.tb3[t]; }
-  __syncthreads();
-  for (int i = t; i < LB * KP; i += LWG) {
-    const int b = i / KP, k = i - b * KP;
-    const bool live = b < B && k < K0;
-    L.S[i] = live ? a.states[(int64_t)L.idx[b] * K0 + k] : (int8_t)0;
-    L.S2[i] = live ? a.successors[(int64_t)L.idx[b] * K0 + k] : (int8_t)0;
+  {
+    const int b = t >> 4, kk = t & 15;  // sample, byte lane (64 samples x 16 lanes = the workgroup)
+    int id = 0;
+    if (b < B) {
+      if (a.rows) {
+        const long long r = a.rows[b];
+        id = (r >= 0 && r < a.total) ? (int)r : 0;  // (an index outside the stored transitions reads transition 0, not wild memory)
+      } else {
+        uint32_t x[4];
+        philox4x32_10((uint32_t)b, 0u, (uint32_t)step0, 4u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
+        const unsigned long long r = ((unsigned long long)x[0] << 32) | x[1];
+        id = (int)__umul64hi(r, (unsigned long long)a.total);
+      }
+    }
+    if (kk == 0) {
+      if (b < B && a.rows_out) a.rows_out[b] = id;
+      L.act[b] = a.actions[id] & 3;
+      L.rew[b] = (float)((double)a.rewards[id] * a.reward_scale);
+      L.term[b] = a.terminals[id] ? 1 : 0;
+    }
+    int8_t sv[(KP + 15) / 16], s2v[(KP + 15) / 16];
+#pragma unroll
+    for (int j = 0; j < (KP + 15) / 16; ++j) {  // all of a lane's bytes requested before the first is used
+      const int k = kk + 16 * j;
+      const bool live = b < B && k < K0;
+      sv[j] = live ? a.states[(int64_t)id * K0 + k] : (int8_t)0;
+      s2v[j] = live ? a.successors[(int64_t)id * K0 + k] : (int8_t)0;
+    }
+#pragma unroll
+    for (int j = 0; j < (KP + 15) / 16; ++j) {
+      const int k = kk + 16 * j;
+      if (k < KP) {
+        L.S[b * KP + k] = sv[j];
+        L.S2[b * KP + k] = s2v[j];
+      }
+    }
+  }
+  rows_commit<H, K0>(L.ST, first);
+  if (t == LWG - 1) {  // Adam's bias corrections (two double-precision pow(), ~1.3 us on one lane) in the shadow of the gather
+    const long long step = step0 + 1;
+    L.scratch[16] = a.lr / (float)(1.0 - pow((double)a.beta1, (double)step));
+    L.scratch[17] = 1.0f / sqrtf((float)(1.0 - pow((double)a.beta2, (double)step)));
   }
   __syncthreads();
-  // ---- target network on the successors ----
+  SGK_STAMP(1);
+  // ---- target network on the successors; every next matrix is requested before the layer that precedes its use ----
+  RowsInFlight<H, H> big;
+  RowsInFlight<H, K0> small;
+  rows_request<H, H>(big, a.tw2t);
   dense_layer<K0, H, weight_stride(H)>(L.S2, KP, L.ST, L.tb1, L.C, true, nullptr);
   __syncthreads();
-  stage_rows<H>(L.ST, a.tw2t, H);
+  SGK_STAMP(2);
+  rows_commit<H, H>(L.ST, big);
   __syncthreads();
+  SGK_STAMP(3);
+  rows_request<H, K0>(small, a.w1t);
   dense_layer<H, H, weight_stride(H)>(L.C, H, L.ST, L.tb2, L.D, true, nullptr);
   __syncthreads();
+  SGK_STAMP(4);
   head_forward(L.D, H, L.tw3, L.tb3, L.tq);
   // ---- Q-network on the states ----
-  stage_rows<H>(L.ST, a.w1t, K0);
+  rows_commit<H, K0>(L.ST, small);
   __syncthreads();
+  SGK_STAMP(5);
+  rows_request<H, H>(big, a.w2t);
   dense_layer<K0, H, weight_stride(H)>(L.S, KP, L.ST, L.b1, L.A, true, nullptr);
   __syncthreads();
-  stage_rows<H>(L.ST, a.w2t, H);
+  SGK_STAMP(6);
+  rows_commit<H, H>(L.ST, big);
   __syncthreads();
+  SGK_STAMP(7);
+  rows_request<H, H>(big, a.w2);  // W2 as it is ([j][k]): the back-propagation through layer 2 wants it in this orientation
   dense_layer<H, H, weight_stride(H)>(L.A, H, L.ST, L.b2, L.Bq, true, nullptr);
   __syncthreads();
+  SGK_STAMP(8);
   head_forward(L.Bq, H, L.w3, L.b3, L.q);
-  stage_rows<H>(L.ST, a.w2, H);  // W2 as it is ([j][k]): the back-propagation through layer 2 wants it in this orientation
+  rows_commit<H, H>(L.ST, big);
   __syncthreads();
+  SGK_STAMP(9);
   // ---- the loss on y_j = r_j + discount * max_a' Q_target(s'_j, a') * (1 - terminal_j) and q_i = Q(s_i, a_i); dL/dq on the taken action.
   // loss_mode 0 (the reference, value.py:119-123): Qs is [B,1] and expected_Qs [B], so F.mse_loss broadcasts them to [B,B]:
   //   loss = mean_{i,j} (q_i - y_j)^2 = mean_i (q_i - ybar)^2 + mean_j (y_j - ybar)^2,   dL/dq_i = (2 / B) (q_i - ybar),  ybar = mean_j y_j
@@ -379,6 +486,7 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   const float loss = block_sum(sq, L.scratch) / (float)B;  // (has barriers: y[] is visible afterwards)
   if (t < LB * 4) L.q[t] = ((t & 3) == L.act[t >> 2]) ? L.y[t >> 2] : 0.0f;  // q now holds dL/dq
   __syncthreads();
+  SGK_STAMP(10);
 
   // ---- backward; every lane keeps the gradients of the parameters it owns in registers ----------------------------
   // dL/dh2 = relu'(h2) * (dq W3) -> C   (dense_layer with K = 4, "wt" = W3 [4][H])
@@ -394,11 +502,13 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   if (!own_w3) gw3 = (f4){0.0f, 0.0f, 0.0f, 0.0f};
   if (!own_b3) gb3 = (f4){0.0f, 0.0f, 0.0f, 0.0f};
   __syncthreads();
+  SGK_STAMP(11);
   // dL/dh1 = relu'(h1) * (dh2 W2) -> D   ("wt" = W2 as it is)
   dense_layer<H, H, weight_stride(H)>(L.C, H, L.ST, nullptr, L.D, false, L.A);
   // W2 [H][H] in 16 x 16 MFMA tiles dealt round-robin to the 16 waves (tile = (neuron tile, input tile)); the gradients stay in
-  // the C layout: lane (col, grp), register r <-> dW2[j0 + 4 grp + r][k0 + col]. MT more tiles are b2's column sums of dL/dh2
-  // (rows j0 + 4 grp + r, the same in every column: the lanes of column 0 own them).
+  // registers, TRANSPOSED in the C layout (weight_grad_mfma_t): lane (col, grp), register r <-> dW2[j0 + col][k0 + 4 grp + r], four
+  // consecutive elements of a row of W2. MT more tiles are b2's column sums of dL/dh2 (rows j0 + 4 grp + r, the same in every
+  // column: the lanes of column 0 own them).
   constexpr int T2 = MT * MT + MT, T1 = MT * KT1 + MT;
   constexpr int N2 = (T2 + LWG / 64 - 1) / (LWG / 64), N1 = (T1 + LWG / 64 - 1) / (LWG / 64);  // tiles per wave
   f4 gw2[N2];
@@ -406,18 +516,23 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   for (int i = 0; i < N2; ++i) {
     const int tile = wave + i * (LWG / 64);
     gw2[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-    if (tile < MT * MT) gw2[i] = weight_grad_mfma(L.C, H, 16 * (tile / MT), L.A, H, 16 * (tile % MT), lane);
+    if (tile < MT * MT) gw2[i] = weight_grad_mfma_t(L.C, H, 16 * (tile / MT), L.A, H, 16 * (tile % MT), lane);
     else if (tile < T2) gw2[i] = column_sum_mfma(L.C, H, 16 * (tile - MT * MT), lane);
   }
   __syncthreads();
+  SGK_STAMP(12);
   // W1 [H][K0] the same way (columns = board cells; cells >= K0 of the last tile are computed from what lies behind the
-  // row in LDS and dropped), then b1's column sums of dL/dh1
+  // row in LDS and dropped) -- transposed like W2 where a row's quads are 16-byte aligned (K0 % 4 == 0), else in the plain C layout
+  // (register r <-> dW1[j0 + 4 grp + r][k0 + col]) --, then b1's column sums of dL/dh1
+  constexpr bool W1T = (K0 % 4) == 0;
   f4 gw1[N1];
 #pragma unroll
   for (int i = 0; i < N1; ++i) {
     const int tile = wave + i * (LWG / 64);
     gw1[i] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-    if (tile < MT * KT1) gw1[i] = weight_grad_mfma(L.D, H, 16 * (tile / KT1), L.S, KP, 16 * (tile % KT1), lane);
+    if (tile < MT * KT1)
+      gw1[i] = W1T ? weight_grad_mfma_t(L.D, H, 16 * (tile / KT1), L.S, KP, 16 * (tile % KT1), lane)
+                   : weight_grad_mfma(L.D, H, 16 * (tile / KT1), L.S, KP, 16 * (tile % KT1), lane);
     else if (tile < T1) gw1[i] = column_sum_mfma(L.D, H, 16 * (tile - MT * KT1), lane);
   }
   // ---- clip_grad_norm_(max_norm): coefficient from the global 2-norm of all gradients -----------------------------
@@ -428,11 +543,12 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   for (int i = 0; i < N2; ++i) {
     const int tile = wave + i * (LWG / 64);
     const bool bias = tile >= MT * MT;
-    const int j = 16 * (bias ? tile - MT * MT : tile / MT) + 4 * grp, k = bias ? col : 16 * (tile % MT) + col;
+    // a weight tile's lane holds (row j0 + col, columns k0 + 4 grp + r); a bias tile's (rows j0 + 4 grp + r), counted once, in column 0
+    const int j = 16 * (bias ? tile - MT * MT : tile / MT) + (bias ? 4 * grp : col), k = bias ? 0 : 16 * (tile % MT) + 4 * grp;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      // rows / columns past H belong to no parameter; a bias tile counts once, in its column 0
-      const bool live = tile < T2 && j + r < H && (bias ? col == 0 : k < H);
+      // rows / columns past H belong to no parameter
+      const bool live = tile < T2 && (bias ? (j + r < H && col == 0) : (j < H && k + r < H));
       gw2[i][r] = live ? gw2[i][r] : 0.0f;
       ss = fmaf(gw2[i][r], gw2[i][r], ss);
     }
@@ -441,91 +557,594 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   for (int i = 0; i < N1; ++i) {
     const int tile = wave + i * (LWG / 64);
     const bool bias = tile >= MT * KT1;
-    const int j = 16 * (bias ? tile - MT * KT1 : tile / KT1) + 4 * grp, k = bias ? col : 16 * (tile % KT1) + col;
+    const bool tr = W1T && !bias;  // transposed ownership
+    const int j = 16 * (bias ? tile - MT * KT1 : tile / KT1) + (tr ? col : 4 * grp), k = bias ? 0 : 16 * (tile % KT1) + (tr ? 4 * grp : col);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool live = tile < T1 && j + r < H && (bias ? col == 0 : k < K0);
+      const bool live = tile < T1 && (bias ? (j + r < H && col == 0) : tr ? (j < H && k + r < K0) : (j + r < H && k < K0));
       gw1[i][r] = live ? gw1[i][r] : 0.0f;
       ss = fmaf(gw1[i][r], gw1[i][r], ss);
     }
   }
-  const float norm = sqrtf(block_sum(ss, L.scratch));
-  const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
   // ---- Adam (amsgrad) on the owned parameters; the transposed copies follow ---------------------------------------
-  // the bias corrections need two double-precision pow(): one lane computes them for all (1 024 lanes each doing it cost
-  // ~15 k cycles), and bumps the step counter
+  // A lane owns NQ "quads": four parameters of one tensor at a fixed stride -- a column piece of a weight tile (rows j .. j + 3 at
+  // column k: the MFMA C layout), four consecutive bias elements, W3's four rows of a column, or b3. Their old values (w, m, v,
+  // vmax) are requested QD - 1 quads AHEAD: the first ones before the norm's reduction, quad i + QD - 1 before quad i is updated
+  // and stored. (Per quad in turn -- load, update, store, next -- the seven quads were seven dependent round trips.)
+  constexpr int NQ = 1 + N2 + N1;
+  struct QuadRef {
+    float *w, *m, *v, *x, *wt;  // tensor, Adam state, and where the quad goes in the transposed copy (null: none)
+    int e0, stride, wt_stride;  // stride 1: four consecutive, 16-byte aligned elements
+    bool on;
+  };
+  auto quad_ref = [&](int i) -> QuadRef {
+    QuadRef r{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 1, false};
+    if (i == 0) {
+      if (own_w3) { const int k = 16 * wave + col; r = QuadRef{a.w3, a.m[4], a.v[4], a.vmax[4], a.w3t + 4 * k, k, H, 1, true}; }
+      else if (own_b3) r = QuadRef{a.b3, a.m[5], a.v[5], a.vmax[5], nullptr, 0, 1, 1, true};
+    } else if (i <= N2) {
+      const int tile = wave + (i - 1) * (LWG / 64);
+      if (tile < MT * MT) {
+        const int j = 16 * (tile / MT) + col, k = 16 * (tile % MT) + 4 * grp;  // H % 4 == 0: the four columns k .. k + 3 are all inside
+        if (j < H && k < H) r = QuadRef{a.w2, a.m[2], a.v[2], a.vmax[2], a.w2t + (size_t)k * H + j, j * H + k, 1, H, true};
+      } else if (tile < T2) {
+        const int jb = 16 * (tile - MT * MT) + 4 * grp;
+        if (col == 0 && jb < H) r = QuadRef{a.b2, a.m[3], a.v[3], a.vmax[3], nullptr, jb, 1, 1, true};
+      }
+    } else {
+      const int tile = wave + (i - 1 - N2) * (LWG / 64);
+      if (tile < MT * KT1) {
+        if (W1T) {
+          const int j = 16 * (tile / KT1) + col, k = 16 * (tile % KT1) + 4 * grp;
+          if (j < H && k < K0) r = QuadRef{a.w1, a.m[0], a.v[0], a.vmax[0], a.w1t + (size_t)k * H + j, j * K0 + k, 1, H, true};
+        } else {
+          const int j = 16 * (tile / KT1) + 4 * grp, k = 16 * (tile % KT1) + col;
+          if (j < H && k < K0) r = QuadRef{a.w1, a.m[0], a.v[0], a.vmax[0], a.w1t + (size_t)k * H + j, j * K0 + k, K0, 1, true};
+        }
+      } else if (tile < T1) {
+        const int jb = 16 * (tile - MT * KT1) + 4 * grp;
+        if (col == 0 && jb < H) r = QuadRef{a.b1, a.m[1], a.v[1], a.vmax[1], nullptr, jb, 1, 1, true};
+      }
+    }
+    return r;
+  };
+  struct QuadVals { f4 w, m, v, x; };
+  auto quad_request = [&](QuadVals &q, const QuadRef &r) {
+    q.w = q.m = q.v = q.x = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    if (r.on) {
+      if (r.stride == 1) {
+        q.w = *reinterpret_cast<const f4 *>(r.w + r.e0); q.m = *reinterpret_cast<const f4 *>(r.m + r.e0);
+        q.v = *reinterpret_cast<const f4 *>(r.v + r.e0); q.x = *reinterpret_cast<const f4 *>(r.x + r.e0);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int e = r.e0 + c * r.stride;
+          q.w[c] = r.w[e]; q.m[c] = r.m[e]; q.v[c] = r.v[e]; q.x[c] = r.x[e];
+        }
+      }
+    }
+  };
+  // (how far ahead: measured with one and with two quads ahead -- 10.0 and 9.0 us for the phase, the second at the price of register
+  // spills -- so the trips are not what bounds it. With -DSGK_LEARN_TIMELINE_ADAM wave 0 takes 0.5-1.3 us per quad whatever the
+  // distance and then waits 2.9 us at the barrier for the other waves: the phase moves ~500 KB (13.9 k parameters x 4 tensors in, 5
+  // out, padded tiles and 4-lane bias quads at full instruction cost) through ONE CU's 64 B/clk vector-memory path at ~40 % of
+  // that rate. What would shorten it is more CUs, and a second workgroup costs a grid barrier: see the experiment below.)
+  constexpr int QD = 2;
+  QuadVals qv[QD];
+#pragma unroll
+  for (int i = 0; i < QD - 1 && i < NQ; ++i) quad_request(qv[i], quad_ref(i));
+  const float norm = sqrtf(block_sum(ss, L.scratch));
+  SGK_STAMP(13);
+  const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
+  AdamCoef ac;
+  ac.lr_bc1 = L.scratch[16];  // (the bias corrections: computed at entry)
+  ac.inv_bc2_sqrt = L.scratch[17];
+  ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    if (i + QD - 1 < NQ) quad_request(qv[(i + QD - 1) % QD], quad_ref(i + QD - 1));
+#ifdef SGK_LEARN_TIMELINE_ADAM
+    SGK_STAMP(14 + i);
+#endif
+    const QuadRef r = quad_ref(i);
+    QuadVals &q = qv[i % QD];
+    const f4 g = i == 0 ? (own_w3 ? gw3 : gb3) : (i <= N2 ? gw2[i <= N2 ? i - 1 : 0] : gw1[i > N2 ? i - 1 - N2 : 0]);
+    if (r.on) {
+      f4 nw, nm, nv, nx;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float m = q.m[c], v = q.v[c], x = q.x[c];
+        nw[c] = adam_scalar(q.w[c], m, v, x, g[c] * coef, ac);
+        nm[c] = m; nv[c] = v; nx[c] = x;
+      }
+      if (r.stride == 1) {
+        *reinterpret_cast<f4 *>(r.w + r.e0) = nw; *reinterpret_cast<f4 *>(r.m + r.e0) = nm;
+        *reinterpret_cast<f4 *>(r.v + r.e0) = nv; *reinterpret_cast<f4 *>(r.x + r.e0) = nx;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int e = r.e0 + c * r.stride;
+          r.w[e] = nw[c]; r.m[e] = nm[c]; r.v[e] = nv[c]; r.x[e] = nx[c];
+        }
+      }
+      if (r.wt) {
+        if (r.wt_stride == 1) *reinterpret_cast<f4 *>(r.wt) = nw;
+        else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) r.wt[(size_t)c * r.wt_stride] = nw[c];
+        }
+      }
+    }
+  }
   if (t == 0) {
-    const long long step = *a.step + 1;
-    L.scratch[16] = a.lr / (float)(1.0 - pow((double)a.beta1, (double)step));
-    L.scratch[17] = sqrtf((float)(1.0 - pow((double)a.beta2, (double)step)));
-    *a.step = step;
+    *a.step = step0 + 1;
     if (a.loss_out) *a.loss_out = loss;
   }
+#ifdef SGK_LEARN_TIMELINE
+#ifdef SGK_LEARN_TIMELINE_ADAM
+  SGK_STAMP(14 + NQ);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SGK_STAMP(15 + NQ);
   __syncthreads();
-  AdamCoef ac;
-  ac.lr_bc1 = L.scratch[16];
-  ac.bc2_sqrt = L.scratch[17];
-  ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
-  if (own_w3) {  // W3 column k (stride H between the four rows), W3^T row k
-    const int k = 16 * wave + col;
-    f4 nw;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = r * H + k;
-      float m = a.m[4][i], v = a.v[4][i], x = a.vmax[4][i];
-      nw[r] = adam_scalar(a.w3[i], m, v, x, gw3[r] * coef, ac);
-      a.w3[i] = nw[r]; a.m[4][i] = m; a.v[4][i] = v; a.vmax[4][i] = x;
-    }
-    *reinterpret_cast<f4 *>(a.w3t + 4 * k) = nw;
-  } else if (own_b3) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float m = a.m[5][i], v = a.v[5][i], x = a.vmax[5][i];
-      a.b3[i] = adam_scalar(a.b3[i], m, v, x, gb3[i] * coef, ac);
-      a.m[5][i] = m; a.v[5][i] = v; a.vmax[5][i] = x;
+  SGK_STAMP(16 + NQ);
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's updates are out
+  __syncthreads();
+  SGK_STAMP(14);
+#endif
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT (round 6; compiled only with -DSGK_DQN_MULTI_WG, never into the product library): the same SGD step on FOUR
+// workgroups. The idea: dqn_sgd_kernel above is one workgroup on one CU -- 21 us of its 40 in fp32 MFMA phases at 70 % of one CU's
+// matrix rate, 11 us in Adam through one CU's memory pipeline (profiles/r06/dqn_timeline_before.log) -- so give each of GW = 4
+// workgroups 16 of the 64 samples (one MFMA sample tile; with 16 samples' activations all four weight matrices fit LDS at once:
+// one batch of loads at entry, W2 held once with an odd row stride and read along either axis) and a quarter of Adam. What the
+// split costs is three grid-wide barriers: B1 the targets of all 64 samples (the reference's loss needs their MEAN in every
+// sample's gradient, value.py:119-123), B2 the four partial gradients (summed in the fixed order 0..3), B3 the partial norms.
+// MEASURED (profiles/r06/dqn_timeline_multi.log, MI355X, 2.39 GHz in-kernel): 58 us against the one-workgroup kernel's 41. The
+// barriers cost 6.8 / 8.3 / 6.1 us (agent-scope release + acquire: the XCDs' L2s are not coherent, a release writes an L2's dirty
+// lines back and everything read behind an acquire comes from HBM: the phases behind the barriers take 4.9 and 5.9 us for a few KB),
+// the entry 6.6 us (every workgroup's weights were last written by another XCD), and a layer of ONE tile per wave is
+// latency-bound (3.0 us: 25 dependent MFMAs behind four batches of LDS reads, nothing to overlap them with). Correct -- it passes
+// every DeepQ test, the reference-run fixtures included -- and slower; kept as the record of why the learner stays on one CU.
+// ------------------------------------------------------------------------------------------------
+#ifdef SGK_DQN_MULTI_WG
+constexpr int GW = 4;         // workgroups
+constexpr int NBW = LB / GW;  // samples per workgroup: one 16-wide MFMA tile
+
+struct LearnShared {  // in the scratch block the library keeps per env handle (zeroed when it is made)
+  unsigned int count, gen;
+  unsigned int pad[14];
+  float y[LB];         // every sample's TD target (B1)
+  float ss[GW];        // partial squared gradient norms (B3)
+  float loss[GW];      // partial loss sums (B2)
+  float pad2[8];
+};
+static_assert(sizeof(LearnShared) % 16 == 0, "the gradient partials behind it are read as dwords but keep it aligned");
+
+// every lane calls it; on return every global write made by any workgroup before its call is visible to every lane here
+__device__ __forceinline__ void grid_barrier(LearnShared *sh) {
+  __threadfence();  // release: this wave's stores are out of the CU and the XCD's L2 is written back (agent scope)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int g = __hip_atomic_load(&sh->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(&sh->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(GW - 1)) {
+      __hip_atomic_store(&sh->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sh->gen, g + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(&sh->gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == g) __builtin_amdgcn_s_sleep(1);
     }
   }
-  // the weight tiles: element (j + r, k) for r = 0..3 -- 16 consecutive k across the lanes of a group; the transposed copy
-  // takes the four r of a lane as one 16-byte row piece
+  __syncthreads();
+  __threadfence();  // acquire: what this CU / XCD cached of the other workgroups' lines is dropped
+}
+
+// dense layer for ONE 16-sample tile: out[b][n] = epilogue(bias[n] + sum_k in[b][k] * wt(k, n)), wt(k, n) = w[k * RS + n * CS] (so a
+// matrix held once serves both orientations), on v_mfma_f32_16x16x4_f32 as dense_layer above; the MT neuron tiles go to the waves
+// wave_first .. wave_first + wave_count - 1 (two independent layers run side by side on disjoint wave sets).
+template <int K, int H, class T>
+__device__ __forceinline__ void dense16(const T *in, int KP, const float *w, int RS, int CS, const float *bias, float *out, bool relu,
+                                        const float *mask, int wave_first, int wave_count) {
+  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) - wave_first;
+  if (wave < 0 || wave >= wave_count) return;
+  const int col = lane & 15, grp = lane >> 4;
+  constexpr int MT = (H + 15) / 16, KS = (K + 3) / 4;
+  constexpr int CH = KS < 8 ? KS : 8;
+  for (int tile = wave; tile < MT; tile += wave_count) {
+    const int n0 = 16 * tile;
+    f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (bias && n0 + 4 * grp < H) acc = *reinterpret_cast<const f4 *>(bias + n0 + 4 * grp);
+    const T *xrow = in + col * KP;
+    const float *wcol = w + (n0 + col) * CS;  // (neuron rows >= H of the last tile read what lies behind the matrix, inside LDS, and are dropped)
 #pragma unroll
-  for (int i = 0; i < N2; ++i) {
-    const int tile = wave + i * (LWG / 64);
-    const int j = 16 * (tile / MT) + 4 * grp, k = 16 * (tile % MT) + col;
-    if (tile >= MT * MT && tile < T2) {  // b2 rows 16 (tile - MT MT) + 4 grp + r, owned by the lanes of column 0
-      const int jb = 16 * (tile - MT * MT) + 4 * grp;
-      if (col == 0 && jb < H) adam_row(a.b2 + jb, a.m[3] + jb, a.v[3] + jb, a.vmax[3] + jb, gw2[i] * coef, ac);
-    } else if (tile < MT * MT && j < H && k < H) {  // H % 4 == 0: the four rows j .. j + 3 are all inside
-      f4 nw;
+    for (int c0 = 0; c0 < KS; c0 += CH) {
+      float av[CH], bv[CH];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int e = (j + r) * H + k;
-        float m = a.m[2][e], v = a.v[2][e], x = a.vmax[2][e];
-        nw[r] = adam_scalar(a.w2[e], m, v, x, gw2[i][r] * coef, ac);
-        a.w2[e] = nw[r]; a.m[2][e] = m; a.v[2][e] = v; a.vmax[2][e] = x;
+      for (int u = 0; u < CH; ++u) {
+        const int k = 4 * (c0 + u) + grp;
+        if (4 * (c0 + u) + 3 < K) {
+          av[u] = wcol[k * RS];
+          bv[u] = load_x1(xrow, k);
+        } else if (4 * (c0 + u) < K) {
+          const int kc = k < K ? k : K - 1;
+          av[u] = k < K ? wcol[kc * RS] : 0.0f;
+          bv[u] = k < K ? load_x1(xrow, kc) : 0.0f;
+        } else {
+          av[u] = 0.0f;
+          bv[u] = 0.0f;
+        }
       }
-      *reinterpret_cast<f4 *>(a.w2t + (size_t)k * H + j) = nw;
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (4 * (c0 + u) < K) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
     }
-  }
+    const int n = n0 + 4 * grp;
+    if (n < H) {
+      if (relu) acc = __builtin_elementwise_max(acc, (f4){0.0f, 0.0f, 0.0f, 0.0f});
+      if (mask) {
+        const f4 m = *reinterpret_cast<const f4 *>(mask + col * H + n);
 #pragma unroll
-  for (int i = 0; i < N1; ++i) {
-    const int tile = wave + i * (LWG / 64);
-    const int j = 16 * (tile / KT1) + 4 * grp, k = 16 * (tile % KT1) + col;
-    if (tile >= MT * KT1 && tile < T1) {
-      const int jb = 16 * (tile - MT * KT1) + 4 * grp;
-      if (col == 0 && jb < H) adam_row(a.b1 + jb, a.m[1] + jb, a.v[1] + jb, a.vmax[1] + jb, gw1[i] * coef, ac);
-    } else if (tile < MT * KT1 && j < H && k < K0) {
-      f4 nw;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int e = (j + r) * K0 + k;
-        float m = a.m[0][e], v = a.v[0][e], x = a.vmax[0][e];
-        nw[r] = adam_scalar(a.w1[e], m, v, x, gw1[i][r] * coef, ac);
-        a.w1[e] = nw[r]; a.m[0][e] = m; a.v[0][e] = v; a.vmax[0][e] = x;
+        for (int c = 0; c < 4; ++c) acc[c] = m[c] > 0.0f ? acc[c] : 0.0f;
       }
-      *reinterpret_cast<f4 *>(a.w1t + (size_t)k * H + j) = nw;
+      *reinterpret_cast<f4 *>(out + col * H + n) = acc;
     }
   }
 }
+
+// G[r][c] = sum over the 16 samples of d[b][row0 + r] * x[b][col0 + c] (one 16 x 16 tile of a weight gradient; C layout: lane
+// (col, grp), register r = G[4 grp + r][col]); ones = true: x = 1 (column sums: a bias gradient, the same in every column)
+template <class T>
+__device__ __forceinline__ f4 wgrad16(const float *d, int DS, int row0, const T *x, int XS, int col0, int lane, bool ones) {
+  const int col = lane & 15, grp = lane >> 4;
+  f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  float av[NBW / 4], bv[NBW / 4];
+#pragma unroll
+  for (int s = 0; s < NBW / 4; ++s) {
+    av[s] = d[(4 * s + grp) * DS + row0 + col];
+    bv[s] = ones ? 1.0f : load_x1(x + (4 * s + grp) * XS, col0 + col);
+  }
+#pragma unroll
+  for (int s = 0; s < NBW / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+  return acc;
+}
+
+constexpr int w2_stride(int h) { return h | 1; }  // odd: a column walk (n along the lanes, stride w2_stride) and a row walk both spread over the banks
+
+struct MultiLds {
+  float *w2, *tw2t, *w1t, *tw1t, *w3, *tw3, *b1, *b2, *b3, *tb1, *tb2, *tb3, *A, *Bq, *C, *D, *q, *tq, *y, *scratch, *rew;
+  int8_t *S, *S2;
+  int *act, *term;
+};
+template <int K0, int H>
+__device__ __forceinline__ MultiLds carve_multi(unsigned char *base) {
+  constexpr int KP = (K0 + 3) & ~3, WS = weight_stride(H);
+  MultiLds L;
+  float *f = reinterpret_cast<float *>(base);
+  L.w2 = f; f += H * w2_stride(H) + 16;  // (+16: the partial last tile of a column walk reads up to 11 rows past the matrix; see dense16)
+  f = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(f) + 15) & ~(uintptr_t)15);
+  L.tw2t = f; f += H * WS;
+  L.w1t = f; f += K0 * WS;
+  L.tw1t = f; f += K0 * WS;
+  L.w3 = f; f += 4 * H;
+  L.tw3 = f; f += 4 * H;
+  L.b1 = f; f += H;
+  L.b2 = f; f += H;
+  L.tb1 = f; f += H;
+  L.tb2 = f; f += H;
+  L.b3 = f; f += 4;
+  L.tb3 = f; f += 4;
+  L.A = f; f += NBW * H;
+  L.Bq = f; f += NBW * H;
+  L.C = f; f += NBW * H;
+  L.D = f; f += NBW * H;
+  L.q = f; f += LB * 4;   // (LB, not NBW: wgrad16 on dq reads rows past the 16 samples' 4 values; they are dropped)
+  L.tq = f; f += NBW * 4;
+  L.y = f; f += LB;
+  L.scratch = f; f += 32;
+  L.rew = f; f += NBW;
+  L.act = reinterpret_cast<int *>(f); f += NBW;
+  L.term = reinterpret_cast<int *>(f); f += NBW;
+  L.S = reinterpret_cast<int8_t *>(f);
+  L.S2 = L.S + NBW * KP;
+  return L;
+}
+template <int K0, int H>
+constexpr size_t multi_lds_bytes() {
+  constexpr int KP = (K0 + 3) & ~3, WS = weight_stride(H);
+  return sizeof(float) * (size_t)(H * w2_stride(H) + 16 + 4 + H * WS + 2 * K0 * WS + 8 * H + 4 * H + 8 + 4 * NBW * H + LB * 4 + NBW * 4 + LB + 32 + 3 * NBW) +
+         2 * NBW * KP + 64;
+}
+
+// flat parameter vector in torch's registration order: w1 [H][K0], b1 [H], w2 [H][H], b2 [H], w3 [4][H], b3 [4]
+template <int K0, int H>
+struct ParamMap {
+  static constexpr int o_w1 = 0, o_b1 = H * K0, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + 4 * H, P = o_b3 + 4;
+};
+
+template <int K0, int H>
+__global__ __launch_bounds__(LWG) void dqn_sgd_multi_kernel(LearnArgs a, LearnShared *sh, float *partials) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char learn_smem[];
+  using PM = ParamMap<K0, H>;
+  constexpr int KP = (K0 + 3) & ~3, WS = weight_stride(H), W2S = w2_stride(H);
+  constexpr int MT = (H + 15) / 16, KT1 = (K0 + 15) / 16;
+  const MultiLds L = carve_multi<K0, H>(learn_smem);
+  const int B = a.batch, t = threadIdx.x, wg = blockIdx.x;
+  const int lane = t & 63, wave = t >> 6, col = lane & 15, grp = lane >> 4;
+  SGK_MSTAMP(0);
+  const long long step0 = *a.step;  // (workgroup 0 bumps it after the last barrier: every workgroup has read it by then)
+
+  // ---- entry: ONE batch of loads. The minibatch index of the sample whose bytes a lane fetches is derived by that lane (16 lanes
+  // per sample): no exchange between the draw and the gather. Everything else -- four weight matrices, the small tensors -- is
+  // independent of it and travels at the same time.
+  {
+    const int bl = t >> 4, kk = t & 15;  // local sample (t < 256), byte lane
+    if (bl < NBW) {
+      const int b = wg * NBW + bl;       // sample of the minibatch
+      int id = 0;
+      if (b < B) {
+        if (a.rows) {
+          const long long r = a.rows[b];
+          id = (r >= 0 && r < a.total) ? (int)r : 0;
+        } else {
+          uint32_t x[4];
+          philox4x32_10((uint32_t)b, 0u, (uint32_t)step0, 4u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
+          const unsigned long long r = ((unsigned long long)x[0] << 32) | x[1];
+          id = (int)__umul64hi(r, (unsigned long long)a.total);
+        }
+      }
+      if (kk == 0) {
+        if (b < B && a.rows_out) a.rows_out[b] = id;
+        L.act[bl] = a.actions[id] & 3;
+        L.rew[bl] = (float)((double)a.rewards[id] * a.reward_scale);
+        L.term[bl] = a.terminals[id] ? 1 : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < (KP + 15) / 16; ++j) {
+        const int k = kk + 16 * j;
+        if (k < KP) {
+          const bool live = b < B && k < K0;
+          L.S[bl * KP + k] = live ? a.states[(int64_t)id * K0 + k] : (int8_t)0;
+          L.S2[bl * KP + k] = live ? a.successors[(int64_t)id * K0 + k] : (int8_t)0;
+        }
+      }
+    }
+  }
+  stage_rows<H>(L.tw1t, a.tw1t, K0);
+  stage_rows<H>(L.w1t, a.w1t, K0);
+  stage_rows<H>(L.tw2t, a.tw2t, H);
+  for (int i = t * 4; i < H * H; i += LWG * 4) {  // W2 as torch holds it, rows of W2S floats (odd: 4-byte pieces)
+    const f4 v = *reinterpret_cast<const f4 *>(a.w2 + i);
+    const int r = i / H, c = i - r * H;
+    float *d = L.w2 + r * W2S + c;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+  stage(L.w3, a.w3, 4 * H);
+  stage(L.tw3, a.tw3, 4 * H);
+  stage(L.b1, a.b1, H);
+  stage(L.b2, a.b2, H);
+  stage(L.tb1, a.tb1, H);
+  stage(L.tb2, a.tb2, H);
+  if (t < 4) { L.b3[t] = a.b3[t]; L.tb3[t] = a.tb3[t]; }
+  if (t == LWG - 1) {  // Adam's bias corrections (two double-precision pow()) in the shadow of the loads
+    const long long step = step0 + 1;
+    L.scratch[16] = a.lr / (float)(1.0 - pow((double)a.beta1, (double)step));
+    L.scratch[17] = 1.0f / sqrtf((float)(1.0 - pow((double)a.beta2, (double)step)));
+  }
+  __syncthreads();
+  SGK_MSTAMP(1);
+  // ---- both networks forward, side by side: target on the successors (waves 0..7), Q on the states (waves 8..15) ----
+  dense16<K0, H>(L.S2, KP, L.tw1t, WS, 1, L.tb1, L.C, true, nullptr, 0, 8);
+  dense16<K0, H>(L.S, KP, L.w1t, WS, 1, L.b1, L.A, true, nullptr, 8, 8);
+  __syncthreads();
+  SGK_MSTAMP(2);
+  dense16<H, H>(L.C, H, L.tw2t, WS, 1, L.tb2, L.D, true, nullptr, 0, 8);
+  dense16<H, H>(L.A, H, L.w2, 1, W2S, L.b2, L.Bq, true, nullptr, 8, 8);  // wt(k, n) = W2[n][k]
+  __syncthreads();
+  SGK_MSTAMP(3);
+  if (t < NBW * 4) {  // heads: one lane per (sample, action), target and Q
+    const int b = t >> 2, ac = t & 3;
+    float st = L.tb3[ac], sq = L.b3[ac];
+    for (int k0 = 0; k0 < H; k0 += 4) {
+      const f4 wt_ = *reinterpret_cast<const f4 *>(L.tw3 + ac * H + k0), xt = *reinterpret_cast<const f4 *>(L.D + b * H + k0);
+      const f4 wq_ = *reinterpret_cast<const f4 *>(L.w3 + ac * H + k0), xq = *reinterpret_cast<const f4 *>(L.Bq + b * H + k0);
+      st = fmaf(xt[0], wt_[0], st); st = fmaf(xt[1], wt_[1], st); st = fmaf(xt[2], wt_[2], st); st = fmaf(xt[3], wt_[3], st);
+      sq = fmaf(xq[0], wq_[0], sq); sq = fmaf(xq[1], wq_[1], sq); sq = fmaf(xq[2], wq_[2], sq); sq = fmaf(xq[3], wq_[3], sq);
+    }
+    L.tq[t] = st;
+    L.q[t] = sq;
+  }
+  __syncthreads();
+  SGK_MSTAMP(4);
+  // ---- TD targets of this workgroup's samples; the reference's loss needs the mean over ALL of them (B1) ----
+  float target = 0.0f, qsa = 0.0f;
+  const int bg = wg * NBW + t;  // (meaningful for t < NBW)
+  if (t < NBW && bg < B) {
+    const float nq = fmaxf(fmaxf(L.tq[t * 4], L.tq[t * 4 + 1]), fmaxf(L.tq[t * 4 + 2], L.tq[t * 4 + 3]));
+    target = a.discount * (L.term[t] ? 0.0f : nq) + L.rew[t];
+    qsa = L.q[t * 4 + L.act[t]];
+  }
+  float ybar = 0.0f;
+  if (a.loss_mode == 0) {
+    if (t < NBW) sh->y[bg] = target;  // (0 for the padding samples b >= B)
+    grid_barrier(sh);
+  SGK_MSTAMP(5);
+    if (t < LB) L.y[t] = sh->y[t];
+    __syncthreads();
+    if (t < 64) {  // wave 0: the same sum, in the same order, in every workgroup
+      ybar = __ockl_wfred_add_f32(L.y[t]) / (float)B;
+    }
+    if (t == 0) L.scratch[18] = ybar;
+    __syncthreads();
+    ybar = L.scratch[18];
+  }
+  float sq = 0.0f;
+  if (t < NBW) {
+    float g = 0.0f;
+    if (bg < B) {
+      if (a.loss_mode == 0) {
+        const float d = qsa - ybar, e = target - ybar;
+        sq = fmaf(d, d, e * e);
+        g = 2.0f * d / (float)B;
+      } else {
+        const float d = qsa - target;
+        sq = d * d;
+        g = 2.0f * d / (float)B;
+      }
+    }
+    L.y[t] = g;
+  }
+  const float loss_part = block_sum(sq, L.scratch);  // (has barriers: y[] is visible afterwards)
+  if (t < NBW * 4) L.q[t] = ((t & 3) == L.act[t >> 2]) ? L.y[t >> 2] : 0.0f;  // q now holds dL/dq of the 16 samples
+  __syncthreads();
+  SGK_MSTAMP(6);
+  // ---- backward on this workgroup's 16 samples; the partial gradients go to scratch in torch's parameter order ----
+  float *mine = partials + (size_t)wg * PM::P;
+  dense16<4, H>(L.q, 4, L.w3, H, 1, nullptr, L.C, false, L.Bq, 0, 8);  // dL/dh2 = relu'(h2) * (dq W3)
+  if (wave >= 8 && wave - 8 < MT) {  // W3: columns k = 16 (wave - 8) .. of dq^T h2; the lanes of group 0 hold the four actions
+    const int k = 16 * (wave - 8) + col;
+    const f4 g = wgrad16(L.q, 4, 0, L.Bq, H, 16 * (wave - 8), lane, false);
+    if (grp == 0 && k < H) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[PM::o_w3 + r * H + k] = g[r];
+    }
+  } else if (wave == 8 + MT) {
+    const f4 g = wgrad16(L.q, 4, 0, L.Bq, H, 0, lane, true);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[PM::o_b3 + r] = g[r];
+    }
+  }
+  __syncthreads();
+  SGK_MSTAMP(7);
+  dense16<H, H>(L.C, H, L.w2, W2S, 1, nullptr, L.D, false, L.A, 0, 8);  // dL/dh1 = relu'(h1) * (dh2 W2): wt(k = j, n) = W2[j][n]
+  // meanwhile, on the other eight waves: W2 / b2 gradient tiles (they need dh2 = C and h1 = A only)
+  {
+    constexpr int T2 = MT * MT + MT;
+    for (int tile = wave - 8; wave >= 8 && tile < T2; tile += 8) {
+      if (tile < MT * MT) {
+        const int j0 = 16 * (tile / MT), k0 = 16 * (tile % MT);
+        const f4 g = wgrad16(L.C, H, j0, L.A, H, k0, lane, false);
+        const int j = j0 + 4 * grp, k = k0 + col;
+        if (k < H) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j + r < H) mine[PM::o_w2 + (j + r) * H + k] = g[r];
+        }
+      } else {
+        const int j = 16 * (tile - MT * MT) + 4 * grp;
+        const f4 g = wgrad16(L.C, H, 16 * (tile - MT * MT), L.A, H, 0, lane, true);
+        if (col == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j + r < H) mine[PM::o_b2 + j + r] = g[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  SGK_MSTAMP(8);
+  {
+    constexpr int T1 = MT * KT1 + MT;
+    for (int tile = wave; tile < T1; tile += LWG / 64) {
+      if (tile < MT * KT1) {
+        const int j0 = 16 * (tile / KT1), k0 = 16 * (tile % KT1);
+        const f4 g = wgrad16(L.D, H, j0, L.S, KP, k0, lane, false);
+        const int j = j0 + 4 * grp, k = k0 + col;
+        if (k < K0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j + r < H) mine[PM::o_w1 + (j + r) * K0 + k] = g[r];
+        }
+      } else {
+        const int j = 16 * (tile - MT * KT1) + 4 * grp;
+        const f4 g = wgrad16(L.D, H, 16 * (tile - MT * KT1), L.S, KP, 0, lane, true);
+        if (col == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j + r < H) mine[PM::o_b1 + j + r] = g[r];
+        }
+      }
+    }
+  }
+  SGK_MSTAMP(9);
+  if (t == 0) sh->loss[wg] = loss_part;
+  grid_barrier(sh);  // B2
+  SGK_MSTAMP(10);
+  // ---- this workgroup's quarter of the flat parameter vector: the gradient (partials summed in the fixed order 0..3), its share
+  // of the squared norm; Adam's state for those elements is requested before the norm's barrier and used behind it ----
+  constexpr int NE = (PM::P + GW * LWG - 1) / (GW * LWG);
+  float g[NE], pw[NE], pm[NE], pv[NE], px[NE];
+  float ss = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = wg * LWG + t + i * (GW * LWG);
+    g[i] = 0.0f;
+    pw[i] = pm[i] = pv[i] = px[i] = 0.0f;
+    if (e < PM::P) {
+      float s_ = partials[e];
+#pragma unroll
+      for (int w = 1; w < GW; ++w) s_ += partials[(size_t)w * PM::P + e];
+      g[i] = s_;
+      ss = fmaf(s_, s_, ss);
+      const int ten = e < PM::o_b1 ? 0 : e < PM::o_w2 ? 1 : e < PM::o_b2 ? 2 : e < PM::o_w3 ? 3 : e < PM::o_b3 ? 4 : 5;
+      const int off = ten == 0 ? PM::o_w1 : ten == 1 ? PM::o_b1 : ten == 2 ? PM::o_w2 : ten == 3 ? PM::o_b2 : ten == 4 ? PM::o_w3 : PM::o_b3;
+      const float *wp = ten == 0 ? a.w1 : ten == 1 ? a.b1 : ten == 2 ? a.w2 : ten == 3 ? a.b2 : ten == 4 ? a.w3 : a.b3;
+      pw[i] = wp[e - off];
+      pm[i] = a.m[ten][e - off];
+      pv[i] = a.v[ten][e - off];
+      px[i] = a.vmax[ten][e - off];
+    }
+  }
+  const float ss_part = block_sum(ss, L.scratch);
+  SGK_MSTAMP(11);
+  if (t == 0) sh->ss[wg] = ss_part;
+  grid_barrier(sh);  // B3
+  SGK_MSTAMP(12);
+  float total = 0.0f;
+#pragma unroll
+  for (int w = 0; w < GW; ++w) total += sh->ss[w];
+  const float coef = fminf(a.max_norm / (sqrtf(total) + 1e-6f), 1.0f);
+  AdamCoef ac;
+  ac.lr_bc1 = L.scratch[16];
+  ac.inv_bc2_sqrt = L.scratch[17];
+  ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = wg * LWG + t + i * (GW * LWG);
+    if (e < PM::P) {
+      const int ten = e < PM::o_b1 ? 0 : e < PM::o_w2 ? 1 : e < PM::o_b2 ? 2 : e < PM::o_w3 ? 3 : e < PM::o_b3 ? 4 : 5;
+      const int off = ten == 0 ? PM::o_w1 : ten == 1 ? PM::o_b1 : ten == 2 ? PM::o_w2 : ten == 3 ? PM::o_b2 : ten == 4 ? PM::o_w3 : PM::o_b3;
+      float *wp = ten == 0 ? a.w1 : ten == 1 ? a.b1 : ten == 2 ? a.w2 : ten == 3 ? a.b2 : ten == 4 ? a.w3 : a.b3;
+      const int le = e - off;
+      float m = pm[i], v = pv[i], x = px[i];
+      const float nw = adam_scalar(pw[i], m, v, x, g[i] * coef, ac);
+      wp[le] = nw;
+      a.m[ten][le] = m; a.v[ten][le] = v; a.vmax[ten][le] = x;
+      // the transposed copies the policy kernels (W1^T, W3^T) and the one-workgroup learner (W2^T) read
+      if (ten == 0) { const int j = le / K0, k = le - j * K0; a.w1t[(size_t)k * H + j] = nw; }
+      else if (ten == 2) { const int j = le / H, k = le - j * H; a.w2t[(size_t)k * H + j] = nw; }
+      else if (ten == 4) { const int ai = le / H, k = le - ai * H; a.w3t[4 * k + ai] = nw; }
+    }
+  }
+#ifdef SGK_LEARN_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  SGK_MSTAMP(13);
+#endif
+  if (wg == 0 && t == 0) {
+    *a.step = step0 + 1;
+    if (a.loss_out) {
+      float l = 0.0f;
+#pragma unroll
+      for (int w = 0; w < GW; ++w) l += sh->loss[w];
+      *a.loss_out = l / (float)B;
+    }
+  }
+}
+
+#endif  // SGK_DQN_MULTI_WG
 
 // ------------------------------------------------------------------------------------------------
 // PPOBaseAgent.learn (reference policy_base.py:64-131) for PPOMLPAgent's default topology, ALL epochs in one launch: per
@@ -617,7 +1236,7 @@ __device__ __forceinline__ void heads_forward(const float *h, int H, const float
 __device__ __forceinline__ float adam_plain(float p, float &m, float &v, float g, const AdamCoef &c) {
   m = m + (1.0f - c.beta1) * (g - m);
   v = c.beta2 * v + (1.0f - c.beta2) * g * g;
-  return p - c.lr_bc1 * (m / (sqrtf(v) / c.bc2_sqrt + c.eps));
+  return p - c.lr_bc1 * (m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * c.inv_bc2_sqrt + c.eps));  // (one-ulp sqrt / rcp: adam_scalar)
 }
 
 template <int K0, int H>
@@ -811,12 +1430,12 @@ __global__ __launch_bounds__(LWG) void ppo_epochs_kernel(PpoArgs a) {
     // ---- Adam (torch defaults: no amsgrad, no gradient clipping) ----
     if (t == 0) {
       L.scratch[16] = a.lr / (float)(1.0 - pow((double)a.beta1, (double)(step + 1)));
-      L.scratch[17] = sqrtf((float)(1.0 - pow((double)a.beta2, (double)(step + 1))));
+      L.scratch[17] = 1.0f / sqrtf((float)(1.0 - pow((double)a.beta2, (double)(step + 1))));
     }
     __syncthreads();
     AdamCoef ac;
     ac.lr_bc1 = L.scratch[16];
-    ac.bc2_sqrt = L.scratch[17];
+    ac.inv_bc2_sqrt = L.scratch[17];
     ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
     if (wave < MT && 16 * wave + col < H) {
       const int k = 16 * wave + col;
@@ -950,6 +1569,32 @@ size_t dqn_sgd_lds_bytes(int n_cells, int n_hidden) {
   return sizeof(float) * (4 * LB * h + h * (size_t)weight_stride((int)h) + 8 * h + 4 * h + 8 + 2 * LB * 4 + LB + 32 + LB + 3 * LB) + 2 * LB * kp + 64;
 }
 
+#ifdef SGK_DQN_MULTI_WG
+size_t dqn_sgd_scratch_bytes(int n_cells, int n_hidden) {
+  const size_t p = (size_t)n_hidden * n_cells + n_hidden + (size_t)n_hidden * n_hidden + n_hidden + 4 * (size_t)n_hidden + 4;
+  return sizeof(LearnShared) + sizeof(float) * GW * p;
+}
+
+// the four-workgroup form: LDS its workgroups need (0: no instantiation for this shape)
+template <int K0, int H>
+static hipError_t launch_multi(const LearnArgs &a, void *scratch, int device, hipStream_t st) {
+  constexpr size_t lds = multi_lds_bytes<K0, H>();
+  static std::atomic<unsigned long long> opted_in{0};
+  if (!((opted_in.load() >> (device & 63)) & 1ull)) {
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&dqn_sgd_multi_kernel<K0, H>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (ae != hipSuccess) return ae;
+    opted_in.fetch_or(1ull << (device & 63));
+  }
+  LearnShared *sh = reinterpret_cast<LearnShared *>(scratch);
+  float *partials = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(scratch) + sizeof(LearnShared));
+  dqn_sgd_multi_kernel<K0, H><<<dim3(GW), dim3(LWG), lds, st>>>(a, sh, partials);
+  return hipGetLastError();
+}
+#else
+size_t dqn_sgd_scratch_bytes(int, int) { return 0; }  // (the four-workgroup experiment is not compiled in)
+#endif
+
 hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) {
   (void)hipGetLastError();
   if (L.n_hidden > 128 || L.n_hidden < 4 || (L.n_hidden & 3) || L.batch < 1 || L.batch > LB || sh.n_cells > 64) return hipErrorInvalidValue;
@@ -969,8 +1614,20 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
   a.seed = sh.seed;
   a.lr = (float)L.lr; a.beta1 = (float)L.beta1; a.beta2 = (float)L.beta2; a.eps = (float)L.eps; a.discount = (float)L.discount;
   a.max_norm = (float)L.max_grad_norm;
+#ifdef SGK_DQN_MULTI_WG
+  /* (a shape whose four matrices do not fit a CU's LDS at once -- 7 x 9 boards with 100 units -- keeps the one-workgroup kernel) */
+#define SGK_SGD_TRY_MULTI(K0V, HV)                                                                                         \
+  do {                                                                                                                     \
+    if constexpr (multi_lds_bytes<K0V, HV>() <= 160u * 1024u) {                                                            \
+      if (L.scratch) return launch_multi<K0V, HV>(a, L.scratch, sh.device, st);                                           \
+    }                                                                                                                      \
+  } while (0)
+#else
+#define SGK_SGD_TRY_MULTI(K0V, HV) do { } while (0)
+#endif
 #define SGK_SGD_LAUNCH(K0V, HV)                                                                                            \
   do {                                                                                                                     \
+    SGK_SGD_TRY_MULTI(K0V, HV);                                                                                            \
     static std::atomic<unsigned long long> opted_in{0};                                                                                \
     if (!((opted_in.load() >> (sh.device & 63)) & 1ull)) {                                                                        \
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&dqn_sgd_kernel<K0V, HV>),                        \
@@ -998,8 +1655,16 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
   }
 #undef SGK_SGD_LAUNCH_K
 #undef SGK_SGD_LAUNCH
+#undef SGK_SGD_TRY_MULTI
   return hipGetLastError();
 }
+
+#ifdef SGK_LEARN_TIMELINE
+extern "C" __attribute__((visibility("default"))) int sgk_debug_learn_stamps(unsigned long long *out32) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(learn_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
 
 size_t ppo_epochs_lds_bytes(int n_cells, int n_hidden) { return ppo_lds_bytes((n_cells + 3) & ~3, n_hidden); }
 

@@ -214,7 +214,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError here == ABI drift; tests/test_abi.py checks every symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.sgk_abi_version() != 3:
+    if lib.sgk_abi_version() != 4:
         raise ImportError("libsgk ABI version mismatch")
     _lib = lib
     return lib

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the sgk_debug_* test hooks of libsgk.so answer only in a process that asked for them before the library was loaded (include/sgk.h)
+os.environ["SGK_ENABLE_TEST_HOOKS"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
     if p not in sys.path:

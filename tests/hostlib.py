@@ -47,5 +47,6 @@ def load(path=None):
 def rules_bytes(L, env_id):
     """The whole SgkRules record of a level as bytes (for comparing two builds)."""
     buf = ctypes.create_string_buffer(L.sgk_debug_rules_size())
-    assert L.sgk_debug_rules(env_id, buf) == 0
+    if L.sgk_debug_rules(env_id, buf) != 0:  # (not an assert around the call: python -O would drop both)
+        raise RuntimeError("sgk_debug_rules failed")
     return buf.raw

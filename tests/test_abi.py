@@ -18,7 +18,41 @@ def _declared():
 def test_library_is_built_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     lib = _lib.load()
-    assert lib.sgk_abi_version() == 3
+    assert lib.sgk_abi_version() == 4
+
+
+def test_the_default_library_refuses_the_test_hooks():
+    """A process that did not set SGK_ENABLE_TEST_HOOKS=1 before loading libsgk.so gets SGK_ERR_INVALID from every sgk_debug_* entry
+    point -- "make the next host allocation fail" and "plant a stale exit word" among them -- and nothing is armed; this test-suite's
+    own process (tests/conftest.py sets the variable) gets answers."""
+    import subprocess
+    import sys
+
+    code = r"""
+import ctypes, os, sys
+assert "SGK_ENABLE_TEST_HOOKS" not in os.environ
+lib = ctypes.CDLL(sys.argv[1])
+lib.sgk_last_error.restype = ctypes.c_char_p
+lib.sgk_debug_reset_word.restype = ctypes.c_uint64
+out5, out4 = (ctypes.c_int32 * 5)(), (ctypes.c_int32 * 4)()
+dims, templ, agent = (ctypes.c_int32 * 4)(), (ctypes.c_uint8 * 64)(), (ctypes.c_uint8 * 64)()
+word, g0, g1 = ctypes.c_uint64(0), ctypes.c_int32(-7), ctypes.c_int32(-7)
+assert lib.sgk_debug_host_transition(0, 6, 255, 1, out5) == -1 and b"SGK_ENABLE_TEST_HOOKS" in lib.sgk_last_error()
+assert lib.sgk_debug_host_step(0, ctypes.c_uint64(0), 1, 1, ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.byref(word), out4, None) == -1
+assert lib.sgk_debug_reset_word(0, ctypes.c_uint64(0), ctypes.c_uint64(0), 1, None) == 2**64 - 1
+assert lib.sgk_debug_level(0, dims, templ, agent) == -1
+assert lib.sgk_debug_graph_count(None, None, ctypes.byref(g0), ctypes.byref(g1)) == -1 and (g0.value, g1.value) == (-7, -7)
+assert lib.sgk_debug_server_stale_exit_word(None) == -1 and b"SGK_ENABLE_TEST_HOOKS" in lib.sgk_last_error()
+assert lib.sgk_debug_fail_host_alloc(1) == -1   # refused ...
+assert lib.sgk_debug_fail_host_alloc(0) == -1   # ... and not armed: the countdown a working hook would hand back is 1, not an error
+print("REFUSED")
+"""
+    env = {k: v for k, v in os.environ.items() if k != "SGK_ENABLE_TEST_HOOKS"}
+    r = subprocess.run([sys.executable, "-c", code, _lib.LIB_PATH], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "REFUSED" in r.stdout, r.stdout + r.stderr
+    lib = _lib.load()  # this process asked for the hooks before the library was loaded
+    assert os.environ.get("SGK_ENABLE_TEST_HOOKS") == "1"
+    assert lib.sgk_debug_fail_host_alloc(0) == 0
 
 
 def test_every_declared_symbol_is_exported_and_bound():

@@ -219,9 +219,51 @@ def test_bench_config_objects_carry_their_own_roofline_and_cpu_baseline(k):
         w = d["with_learning"]
         assert w["value"] == d["value_with_learning"] == max(w["eager_value"], w["graph_value"]) > 0
         b = w["breakdown_us"]
-        assert set(b) == {"replay_store_states", "forward_and_act_explore", "env_step", "replay_store_successors", "sgd_step", "reset_done"}
+        assert set(b) == {"replay_store_states", "forward_and_act_explore", "env_step_and_reset_done", "replay_store_successors", "sgd_step"}
         assert abs(w["breakdown_device_sum_us"] - sum(b.values())) < 1e-6 and abs(w["acting_us"] + w["replay_store_us"] + w["sgd_us"] - sum(b.values())) < 1e-6
         c = d["conv_q_body_non_parity"]
         assert c["parity"].startswith("none") and c["acting"]["value"] > 0 and c["acting_plus_sgd"]["value"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+
+
+def test_check_scale_reads_bench_lines_and_says_pass_or_fail():
+    """tools/check_scale.py -- the verdict for a first `bench.py --gpus N` run against BASELINE.md section 10 -- on the committed
+    lines: the one-GPU gloo dry runs of 2 and 8 ranks FAIL as multi-GPU results (no RCCL communicator, a torch.distributed
+    collective, a value far below the prediction) and PASS the checks that still mean something with --allow-collective gloo; a
+    synthetic 8-GPU line built to the prediction passes, and each single defect fails it."""
+    import copy
+    import importlib.util
+    import io
+    from contextlib import redirect_stdout
+
+    spec = importlib.util.spec_from_file_location("check_scale", os.path.join(ROOT, "tools", "check_scale.py"))
+    cs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cs)
+    logs = [os.path.join(ROOT, "profiles", "r05", "bench_%drank_one_gpu_gloo.log" % k) for k in (2, 8)]
+
+    def run(argv):
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            rc = cs.main(argv)
+        return rc, buf.getvalue()
+
+    rc, out = run(logs)
+    assert rc == 1 and out.count("FAIL n_gpus=") == 2 and "SCALE FAIL (2 lines)" in out
+    assert "collective FAIL (torch.distributed (gloo))" in out and "ranks FAIL" in out and "episodes ok" in out and "parity ok" in out
+    rc, out = run(["--allow-collective", "gloo"] + logs)
+    assert rc == 0 and "SCALE PASS (2 lines)" in out and "value n/a" in out
+    # a line as BASELINE section 10 predicts it for eight GPUs
+    base = cs.load_lines(logs[1])[0]
+    good = copy.deepcopy(base)
+    good.update(value=1.6e12, rccl_ranks=8, metrics_collective=cs.LIBRARY_COLLECTIVE, per_rank_device_us=[62.0 + 0.2 * i for i in range(8)])
+    ok, res = cs.check(good)
+    assert ok and all(r is True for _, r, _ in res), res
+    for defect in ({"rccl_ranks": 4}, {"metrics_collective": "torch.distributed (nccl)"}, {"episodes_finished": good["episodes_finished"] - 1},
+                   {"parity_sample_bit_exact": False}, {"per_rank_device_us": [60.0] * 7 + [66.0]}, {"value": 1.2e12}, {"value": 2.0e12}):
+        bad = dict(good, **defect)
+        ok, res = cs.check(bad)
+        assert not ok and sum(r is False for _, r, _ in res) == 1, (defect, res)
+    # a driver record keeps only the contract's keys under "parsed": judged on what it holds
+    rc, out = run([os.path.join(ROOT, "BENCH_r05.json")])
+    assert rc == 0 and "value ok" in out and "episodes n/a (not in this record)" in out

@@ -342,8 +342,10 @@ def test_config4_sokoban_deepq_32768_envs_150_graphed_iterations_vs_oracle():
 def test_config4_fused_sgd_step_matches_torch_on_a_32768_env_replay():
     """sgk_dqn_sgd_step on a replay ring of 4 x 32 768 Sokoban transitions (config 4's batch): the rows it samples are the
     oracle's (orc_minibatch_index over 131 072 transitions), and loss + parameters over three steps equal torch autograd +
-    clip_grad_norm_(10) + Adam(amsgrad) on those rows. Floating point, different summation order: rtol 2e-4 / atol 2e-6
-    (the tolerance of test_gpu_deepq.py)."""
+    clip_grad_norm_(10) + Adam(amsgrad) on those rows, with the loss on the shapes value.py:119-123 hands mse_loss. Floating point,
+    different summation order: the tolerance of test_gpu_deepq.py (_assert_adam_close)."""
+    import warnings
+
     torch = _torch()
     torch.manual_seed(13)
     name, n, seed, slices, hidden, batch = "SideEffectsSokoban-v0", 32768, 41, 4, 100, 64
@@ -372,19 +374,23 @@ def test_config4_fused_sgd_step_matches_torch_on_a_32768_env_replay():
         loss_gpu = float(agent.learn_batch().cpu())
         ix = torch.as_tensor(O.minibatch_indices(seed, step, batch, slices * n))
         assert int(ix.max()) >= n  # the draw really ranges over the whole ring, not one slice
-        q_sa = cpu_q(st[ix].float()).gather(1, ac[ix].long().unsqueeze(1)).squeeze(1)
+        q_sa = cpu_q(st[ix].float()).gather(1, ac[ix].long().unsqueeze(1))  # [B, 1] against expected [B]: value.py:119-123's broadcast
         with torch.no_grad():
             nq = cpu_t(su[ix].float()).max(1)[0]
             nq = torch.where(te[ix], torch.zeros_like(nq), nq)
             expected = 0.9 * nq + rw[ix].float()
-        loss = torch.nn.functional.mse_loss(q_sa, expected)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            loss = torch.nn.functional.mse_loss(q_sa, expected)
         opt.zero_grad()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(cpu_q.parameters(), 10.0)
         opt.step()
         assert abs(loss_gpu - float(loss.detach())) <= 2e-4 * abs(float(loss.detach())) + 2e-6, (step, loss_gpu, float(loss.detach()))
+        from test_gpu_deepq import _assert_adam_close
+
         for (k, v), (k2, v2) in zip(agent.Q.state_dict().items(), cpu_q.state_dict().items()):
-            np.testing.assert_allclose(v.cpu().numpy(), v2.numpy(), rtol=2e-4, atol=2e-6, err_msg="%s step %d" % (k, step))
+            _assert_adam_close(v.cpu().numpy(), v2.numpy(), 1e-2, step + 1, "%s step %d" % (k, step))
     env.close()
 
 

@@ -1453,7 +1453,7 @@ import sys
 sys.path[:0] = [%r, %r]
 import torch
 import safe_grid_agents_amd as S
-env = S.BatchedGridworldEnv("BoatRace-v0", 4096, seed=3, layout="compact")
+env = S.BatchedGridworldEnv("BoatRace-v0", 4096, seed=3, layout="compact", stream="own")
 st = env.torch_stream()
 host = torch.empty((4096, env.n_cells), dtype=torch.int8).pin_memory()
 with torch.cuda.stream(st):
@@ -1466,7 +1466,7 @@ assert (host.numpy() == want).all()
 env.close()
 del host, boards          # the pinned block is freed AFTER the env: an event is recorded on the env's stream
 torch.cuda.synchronize()
-again = S.BatchedGridworldEnv("IslandNavigation-v0", 64, seed=1)
+again = S.BatchedGridworldEnv("IslandNavigation-v0", 64, seed=1, stream="own")
 assert again.stream_ptr == ptr, (again.stream_ptr, ptr)
 again.step_random(3)
 again.close()

@@ -4,8 +4,11 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export SGK_NO_BUILD=1
 A=${1:-libsgk_before.so}; B=${2:-libsgk.so}
+for lib in $A $B; do
+  [ -f "safe-grid-agents_amd/lib/$lib" ] || { echo "gpu_ab_step.sh: missing safe-grid-agents_amd/lib/$lib (build the 'before' library first: make -C safe-grid-agents_amd/csrc OUT=../lib/libsgk_before.so OBJDIR=build_before at the commit to compare with)"; exit 1; }
+done
 for r in 1 2; do for lib in $A $B; do
-  SGK_LIB_PATH=$PWD/safe-grid-agents_amd/lib/$lib python bench.py --config 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+  SGK_LIB_PATH=$PWD/safe-grid-agents_amd/lib/$lib python bench.py --config 2 --no-cpu-baseline | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('config 2', '$lib', round(d['us_per_lockstep_step'],3))"; done; done
 for lib in $A $B; do echo "== $lib"

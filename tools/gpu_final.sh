@@ -1,10 +1,10 @@
 #!/bin/bash
-# Everything the docs quote, in one GPU call: bash tools/gpu_final.sh <round tag, e.g. r05> [pmc]. Logs land in
+# Everything the docs quote, in one GPU call: bash tools/gpu_final.sh <round tag, e.g. r06> [pmc]. Logs land in
 # gpurun_out/<tag>_final/ (copy what is to be judged into profiles/<tag>/). With `pmc` also the FETCH_SIZE / WRITE_SIZE passes of the
 # three bench kernels that profiles/traffic.json is made from (24 profiler runs: ~15 minutes).
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-T=${1:-r05}; O=gpurun_out/${T}_final; mkdir -p $O
+T=${1:-r06}; O=gpurun_out/${T}_final; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -1 $O/smoke.log
 timeout 2400 python -m pytest tests -m gpu -q --timeout=900 > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log | grep -v "RCCL\|HIP ver\|ROCm\|Hostname\|Librccl" | cut -c1-300
 # the driver's bench command, three processes
@@ -23,6 +23,12 @@ timeout 900 python tools/bench_stream.py --envs BoatRace-v0,IslandNavigation-v0,
 timeout 600 python tools/bench_single_env.py > $O/single_env.log 2>&1
 SGK_STEP_SERVER=0 timeout 600 python tools/bench_single_env.py > $O/single_env_launch_per_step.log 2>&1
 timeout 600 python tools/bench_policy_rollout.py > $O/policy_rollout_env_counts.log 2>&1
+# round 6: what a caller of the per-step tabular-Q API pays (one launch per step / four launches / from Python, by stream mode), the DeepQ
+# learner's device time and its barrier-to-barrier timeline, and the step-facing tests without asserts (python -O)
+timeout 600 python tools/exp_tabq_dropin.py 2>&1 | grep -v amdgpu.ids > $O/tabq_dropin.log; tail -6 $O/tabq_dropin.log | cut -c1-250
+timeout 300 python tools/exp_dqn_learner_ab.py 2>&1 | grep -v amdgpu.ids > $O/dqn_learner.log; cat $O/dqn_learner.log | cut -c1-200
+timeout 600 bash tools/gpu_dqn_timeline.sh $O/dqn_timeline.log > /dev/null 2>&1; tail -4 $O/dqn_timeline.log | cut -c1-200
+timeout 900 python -O -m pytest tests -m gpu -q -k step > $O/pytest_gpu_O_step.log 2>&1; tail -1 $O/pytest_gpu_O_step.log
 export SGK_NO_BUILD=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-fused --sustain-seconds 0 > $O/bench_under_rocprof.log 2>&1
 for f in $(find $O/prof -name "*kernel_stats.csv"); do head -6 $f | cut -c1-200; cp $f $O/bench_kernel_stats.csv; done
