@@ -500,7 +500,16 @@ def run_config(args):
                                      % (table_mb, table_mb),
                     "survey_8d_bytes_per_agent_step": 196, "survey_8d_gbs": 196 * n / dt / 1e9,
                     "note": "tables resident in LDS: no HBM traffic per step (8(d)'s 196 B per agent-step would be %.1f TB/s)" % (196 * n / dt / 1e12)}
+        # what a caller who needs every step's observation pays instead (device time per lockstep step, 100-step hipGraphs): ONE launch
+        # per step (sgk_tabq_step's kernel; round 6) with and without the boards, and the four launches of the drop-in call sequence
+        per_step_api = {
+            "one_launch_per_step_us": ev_time(env, lambda: agent.learn_steps(100), 10) / 100 * 1e6,
+            "one_launch_per_step_with_boards_us": ev_time(env, lambda: agent.learn_steps(100, write_boards=True), 10) / 100 * 1e6,
+            "four_launches_per_step_us": ev_time(env, lambda: agent.learn_steps(100, separate_launches=True), 10) / 100 * 1e6,
+            "kernel": "sgk::tabq_step_kernel (act_explore + env.step + learn + reset of finished envs)",
+            "bound": "HBM: ~230 B per agent-step (kept row + tag 80 B, state + record 20 B, the successor row's 128-B line, the 8-B update)"}
         out.update({"workload": "IslandNavigation + tabular-q, 262 144 private agents, fused LDS-resident rollout (1000 steps per launch)",
+                    "per_step_api": per_step_api,
                     "metric": "agent-steps/s", "unit": "agent-steps/s", "value": n / dt, "us_per_lockstep_step": dt * 1e6, "dtype": "f64",
                     "roofline": roof})
         agent.close(); env.close()
