@@ -414,6 +414,10 @@ SGK_API int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon,
  *   rows          NULL (the kernel draws the minibatch, stream 4), or int64 [batch]: the caller's transition indices
  *                 slice * n_envs + env (an external sampler; an index outside the stored transitions reads transition 0)
  *   rows_out      NULL, or int64 [batch]: receives the indices this step trained on
+ * Two launches on the handle's stream: everything up to the clipped-gradient's norm in one 1 024-lane workgroup, then Adam(amsgrad) and
+ * the transposed copies with one lane per parameter over the whole chip (the gradient crosses in a scratch block of the handle's, made
+ * on the handle's FIRST call: call once before recording the step in a hipGraph). Adam's square root and quotient use the hardware's
+ * one-ulp v_sqrt_f32 / v_rcp_f32.
  * fp32 with a different summation order than rocBLAS: equal to torch's step to fp32 tolerance, not bit for bit. */
 #define SGK_DQN_LOSS_REFERENCE 0
 #define SGK_DQN_LOSS_PER_SAMPLE 1

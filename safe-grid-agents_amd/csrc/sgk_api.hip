@@ -41,7 +41,7 @@ struct sgk_env {
   hipEvent_t switch_event = nullptr;                // sgk_set_stream / sgk_use_default_stream: old stream -> new stream
   long long *metrics_pinned = nullptr;  // [SGK_METRICS_LEN] pinned device-mapped host words the reduce kernel also writes
   float *gamma_dev = nullptr;        // [1024] float32(discount ** t) for sgk_discounted_returns
-  void *learn_scratch = nullptr;     // (-DSGK_DQN_MULTI_WG experiment build: the four-workgroup learner's barrier words + partial gradients)
+  void *learn_scratch = nullptr;     // sgk_dqn_sgd_step: the gradient between its two launches (made on first use)
   size_t learn_scratch_bytes = 0;
   double gamma_discount = -1.0;
   // the single-env step server (sgk_step.hip, env_server_kernel): a resident wave that serves sgk_step_host through a mailbox
@@ -875,17 +875,24 @@ int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) try {
   d.loss_out = L->loss_out;
   d.n_hidden = L->n_hidden; d.batch = L->batch; d.loss_mode = L->loss_mode;
   d.rows = reinterpret_cast<const long long *>(L->rows); d.rows_out = reinterpret_cast<long long *>(L->rows_out);
+  // Adam runs as a second launch over the whole chip (sgk_learn.hip: AdamHeader): it needs a scratch block of the handle's for the
+  // gradient, made on the first call -- NOT inside a stream capture: warm the learner up before recording it, as
+  // BatchedDeepQAgent.enable_graphs does. SGK_DQN_ONE_LAUNCH=1 in the environment when the library is loaded keeps the update inside
+  // the one kernel (the A/B knob of profiles/r06).
+  static const bool one_launch = [] { const char *v = getenv("SGK_DQN_ONE_LAUNCH"); return v && v[0] == '1' && v[1] == 0; }();
   d.scratch = nullptr;
+  d.multi_wg = 0;
 #ifdef SGK_DQN_MULTI_WG
-  // EXPERIMENT build only (sgk_learn.hip): the four-workgroup kernel needs a scratch block of the handle's, made on the first call
-  // (not inside a stream capture); SGK_DQN_WORKGROUPS=1 in the environment keeps the one-workgroup kernel (the A/B of profiles/r06).
-  static const bool one_workgroup = [] { const char *v = getenv("SGK_DQN_WORKGROUPS"); return v && v[0] == '1' && v[1] == 0; }();
-  if (!one_workgroup) {
+  static const bool four_workgroups = [] { const char *v = getenv("SGK_DQN_WORKGROUPS"); return v && v[0] == '4' && v[1] == 0; }();
+  d.multi_wg = four_workgroups ? 1 : 0;
+#endif
+  if (!one_launch || d.multi_wg) {
     const size_t need = sgk::dqn_sgd_scratch_bytes(h->sh.n_cells, L->n_hidden);
     if (h->learn_scratch_bytes < need) {
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
       if (h->stream) (void)hipStreamIsCapturing(h->stream, &cs);
-      if (cs != hipStreamCaptureStatusNone) return fail(SGK_ERR_INVALID, "the first sgk_dqn_sgd_step of a handle allocates: call it once before capturing it");
+      if (cs != hipStreamCaptureStatusNone)
+        return fail(SGK_ERR_INVALID, "the first sgk_dqn_sgd_step of a handle allocates its scratch block: call it once before capturing it");
       SGK_HIP(sgk::host::wait_stream(h->stream));
       (void)hipFree(h->learn_scratch);
       h->learn_scratch = nullptr;
@@ -896,7 +903,6 @@ int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) try {
     }
     d.scratch = h->learn_scratch;
   }
-#endif
   d.lr = L->lr; d.beta1 = L->beta1; d.beta2 = L->beta2; d.eps = L->eps; d.discount = L->discount; d.max_grad_norm = L->max_grad_norm;
   SGK_HIP(sgk::launch_dqn_sgd(h->sh, d, h->stream));
   return SGK_OK;

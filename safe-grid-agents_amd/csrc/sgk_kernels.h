@@ -106,7 +106,8 @@ struct DqnLearner {
   int loss_mode;  // SGK_DQN_LOSS_*
   const long long *rows;  // caller's minibatch or null
   long long *rows_out;    // minibatch used, or null
-  void *scratch;          // null; (-DSGK_DQN_MULTI_WG experiment build: dqn_sgd_scratch_bytes() of zeroed device memory = run the four-workgroup kernel)
+  void *scratch;          // dqn_sgd_scratch_bytes() of device memory (zeroed once): Adam runs as a second, chip-wide launch; null: inside the one kernel
+  int multi_wg;           // (-DSGK_DQN_MULTI_WG experiment build only) run the four-workgroup kernel on `scratch`
   double lr, beta1, beta2, eps, discount, max_grad_norm;
 };  // (the replay's int8 rewards are in units of the level's reward_scale: launch_dqn_sgd takes it from the shard's rules)
 hipError_t launch_replay_store(const Shard &sh, int phase, const uint8_t *actions, int cheat, int64_t head, const long long *head_dev,

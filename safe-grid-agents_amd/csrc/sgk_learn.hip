@@ -12,6 +12,7 @@
 // order inside the dot products differs from rocBLAS / torch's CPU kernels, so parity is to fp32 tolerance, not bit for bit: the
 // reference's own DeepQAgent runs (tests/golden/batched_dqn_*.npz, 320-330 steps across three target syncs) are reproduced with
 // every action equal, losses and weights within rtol 2e-4 (tests/test_gpu_batched_golden.py).
+#include <algorithm>
 #include <atomic>
 
 #include "sgk_device.h"
@@ -54,6 +55,7 @@ struct LearnArgs {
   float *loss_out;   // may be null
   const long long *rows;  // the caller's minibatch (transition indices into the ring), or null: drawn here
   long long *rows_out;    // the minibatch used, or null
+  float *adam_scratch;    // null: Adam inside dqn_sgd_kernel; else AdamHeader + the flat gradient go here and dqn_adam_kernel follows
   int32_t n_hidden, batch;
   int32_t loss_mode;  // 0 = the reference's [B,1]-vs-[B] broadcast mse_loss (value.py:119-123), 1 = per-sample (squeezed) mse_loss
   uint64_t seed;  // minibatch indices: Philox stream 4, ctr = {sample, 0, Adam step before this update, 4}
@@ -351,6 +353,22 @@ __device__ __forceinline__ LearnLds carve(unsigned char *base, int KP, int H) {
   return L;
 }
 
+// flat parameter vector in torch's registration order: w1 [H][K0], b1 [H], w2 [H][H], b2 [H], w3 [4][H], b3 [4]
+template <int K0, int H>
+struct ParamMap {
+  static constexpr int o_w1 = 0, o_b1 = H * K0, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + 4 * H, P = o_b3 + 4;
+};
+
+// Two launches instead of one (round 6): the SGD step's last phase -- Adam on 13.9 k parameters -- moves ~500 KB through ONE CU's
+// vector-memory path and took 10 of the kernel's 39 us (profiles/r06/dqn_timeline.log). With a.adam_scratch set, dqn_sgd_kernel stops
+// behind the norm: it stores the gradient (flat, torch's parameter order, 16 bytes per lane where the MFMA layout gives four
+// consecutive elements) and {clip coefficient, lr / bias_correction1, 1 / sqrt(bias_correction2)} to the handle's scratch block, and
+// dqn_adam_kernel -- one lane per parameter, every CU, coalesced -- applies the update behind the kernel boundary (a boundary costs
+// ~1.5 us; a grid barrier inside one launch 6-8: the experiment further down).
+struct AdamHeader {
+  float coef, lr_bc1, inv_bc2_sqrt, pad;
+};
+
 template <int K0, int H>
 __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   SGK_STAMP(0);
@@ -576,34 +594,36 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
     float *w, *m, *v, *x, *wt;  // tensor, Adam state, and where the quad goes in the transposed copy (null: none)
     int e0, stride, wt_stride;  // stride 1: four consecutive, 16-byte aligned elements
     bool on;
+    int flat;                   // the tensor's offset in the flat parameter vector (ParamMap)
   };
+  using PM = ParamMap<K0, H>;
   auto quad_ref = [&](int i) -> QuadRef {
-    QuadRef r{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 1, false};
+    QuadRef r{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 1, false, 0};
     if (i == 0) {
-      if (own_w3) { const int k = 16 * wave + col; r = QuadRef{a.w3, a.m[4], a.v[4], a.vmax[4], a.w3t + 4 * k, k, H, 1, true}; }
-      else if (own_b3) r = QuadRef{a.b3, a.m[5], a.v[5], a.vmax[5], nullptr, 0, 1, 1, true};
+      if (own_w3) { const int k = 16 * wave + col; r = QuadRef{a.w3, a.m[4], a.v[4], a.vmax[4], a.w3t + 4 * k, k, H, 1, true, PM::o_w3}; }
+      else if (own_b3) r = QuadRef{a.b3, a.m[5], a.v[5], a.vmax[5], nullptr, 0, 1, 1, true, PM::o_b3};
     } else if (i <= N2) {
       const int tile = wave + (i - 1) * (LWG / 64);
       if (tile < MT * MT) {
         const int j = 16 * (tile / MT) + col, k = 16 * (tile % MT) + 4 * grp;  // H % 4 == 0: the four columns k .. k + 3 are all inside
-        if (j < H && k < H) r = QuadRef{a.w2, a.m[2], a.v[2], a.vmax[2], a.w2t + (size_t)k * H + j, j * H + k, 1, H, true};
+        if (j < H && k < H) r = QuadRef{a.w2, a.m[2], a.v[2], a.vmax[2], a.w2t + (size_t)k * H + j, j * H + k, 1, H, true, PM::o_w2};
       } else if (tile < T2) {
         const int jb = 16 * (tile - MT * MT) + 4 * grp;
-        if (col == 0 && jb < H) r = QuadRef{a.b2, a.m[3], a.v[3], a.vmax[3], nullptr, jb, 1, 1, true};
+        if (col == 0 && jb < H) r = QuadRef{a.b2, a.m[3], a.v[3], a.vmax[3], nullptr, jb, 1, 1, true, PM::o_b2};
       }
     } else {
       const int tile = wave + (i - 1 - N2) * (LWG / 64);
       if (tile < MT * KT1) {
         if (W1T) {
           const int j = 16 * (tile / KT1) + col, k = 16 * (tile % KT1) + 4 * grp;
-          if (j < H && k < K0) r = QuadRef{a.w1, a.m[0], a.v[0], a.vmax[0], a.w1t + (size_t)k * H + j, j * K0 + k, 1, H, true};
+          if (j < H && k < K0) r = QuadRef{a.w1, a.m[0], a.v[0], a.vmax[0], a.w1t + (size_t)k * H + j, j * K0 + k, 1, H, true, PM::o_w1};
         } else {
           const int j = 16 * (tile / KT1) + 4 * grp, k = 16 * (tile % KT1) + col;
-          if (j < H && k < K0) r = QuadRef{a.w1, a.m[0], a.v[0], a.vmax[0], a.w1t + (size_t)k * H + j, j * K0 + k, K0, 1, true};
+          if (j < H && k < K0) r = QuadRef{a.w1, a.m[0], a.v[0], a.vmax[0], a.w1t + (size_t)k * H + j, j * K0 + k, K0, 1, true, PM::o_w1};
         }
       } else if (tile < T1) {
         const int jb = 16 * (tile - MT * KT1) + 4 * grp;
-        if (col == 0 && jb < H) r = QuadRef{a.b1, a.m[1], a.v[1], a.vmax[1], nullptr, jb, 1, 1, true};
+        if (col == 0 && jb < H) r = QuadRef{a.b1, a.m[1], a.v[1], a.vmax[1], nullptr, jb, 1, 1, true, PM::o_b1};
       }
     }
     return r;
@@ -630,6 +650,34 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   // out, padded tiles and 4-lane bias quads at full instruction cost) through ONE CU's 64 B/clk vector-memory path at ~40 % of
   // that rate. What would shorten it is more CUs, and a second workgroup costs a grid barrier: see the experiment below.)
   constexpr int QD = 2;
+  if (a.adam_scratch) {  // (wave-uniform) two launches: the gradient leaves here, dqn_adam_kernel applies it
+    float *gout = a.adam_scratch + sizeof(AdamHeader) / sizeof(float);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const QuadRef r = quad_ref(i);
+      const f4 g = i == 0 ? (own_w3 ? gw3 : gb3) : (i <= N2 ? gw2[i <= N2 ? i - 1 : 0] : gw1[i > N2 ? i - 1 - N2 : 0]);
+      if (r.on) {
+        if (r.stride == 1) *reinterpret_cast<f4 *>(gout + r.flat + r.e0) = g;
+        else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) gout[r.flat + r.e0 + c * r.stride] = g[c];
+        }
+      }
+    }
+    const float norm2 = sqrtf(block_sum(ss, L.scratch));
+    if (t == 0) {
+      AdamHeader hd;
+      hd.coef = fminf(a.max_norm / (norm2 + 1e-6f), 1.0f);
+      hd.lr_bc1 = L.scratch[16];
+      hd.inv_bc2_sqrt = L.scratch[17];
+      hd.pad = 0.0f;
+      *reinterpret_cast<AdamHeader *>(a.adam_scratch) = hd;
+      *a.step = step0 + 1;
+      if (a.loss_out) *a.loss_out = loss;
+    }
+    SGK_STAMP(13);
+    return;
+  }
   QuadVals qv[QD];
 #pragma unroll
   for (int i = 0; i < QD - 1 && i < NQ; ++i) quad_request(qv[i], quad_ref(i));
@@ -693,6 +741,32 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
   SGK_STAMP(14);
 #endif
 #endif
+}
+
+// Adam(amsgrad) + the transposed copies, one lane per parameter (the second launch of sgk_dqn_sgd_step: see AdamHeader above)
+template <int K0, int H>
+__global__ __launch_bounds__(256) void dqn_adam_kernel(LearnArgs a) {
+  using PM = ParamMap<K0, H>;
+  const AdamHeader hd = *reinterpret_cast<const AdamHeader *>(a.adam_scratch);
+  const float *g = a.adam_scratch + sizeof(AdamHeader) / sizeof(float);
+  AdamCoef ac;
+  ac.lr_bc1 = hd.lr_bc1;
+  ac.inv_bc2_sqrt = hd.inv_bc2_sqrt;
+  ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
+  const int e = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (e >= PM::P) return;
+  const int ten = e < PM::o_b1 ? 0 : e < PM::o_w2 ? 1 : e < PM::o_b2 ? 2 : e < PM::o_w3 ? 3 : e < PM::o_b3 ? 4 : 5;
+  const int off = ten == 0 ? PM::o_w1 : ten == 1 ? PM::o_b1 : ten == 2 ? PM::o_w2 : ten == 3 ? PM::o_b2 : ten == 4 ? PM::o_w3 : PM::o_b3;
+  float *wp = ten == 0 ? a.w1 : ten == 1 ? a.b1 : ten == 2 ? a.w2 : ten == 3 ? a.b2 : ten == 4 ? a.w3 : a.b3;
+  const int le = e - off;
+  float m = a.m[ten][le], v = a.v[ten][le], x = a.vmax[ten][le];
+  const float nw = adam_scalar(wp[le], m, v, x, g[e] * hd.coef, ac);
+  wp[le] = nw;
+  a.m[ten][le] = m; a.v[ten][le] = v; a.vmax[ten][le] = x;
+  // the transposed copies the policy kernels (W1^T, W3^T) and the next step's forward (W2^T) read
+  if (ten == 0) { const int j = le / K0, k = le - j * K0; a.w1t[(size_t)k * H + j] = nw; }
+  else if (ten == 2) { const int j = le / H, k = le - j * H; a.w2t[(size_t)k * H + j] = nw; }
+  else if (ten == 4) { const int ai = le / H, k = le - ai * H; a.w3t[4 * k + ai] = nw; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -856,12 +930,6 @@ constexpr size_t multi_lds_bytes() {
   return sizeof(float) * (size_t)(H * w2_stride(H) + 16 + 4 + H * WS + 2 * K0 * WS + 8 * H + 4 * H + 8 + 4 * NBW * H + LB * 4 + NBW * 4 + LB + 32 + 3 * NBW) +
          2 * NBW * KP + 64;
 }
-
-// flat parameter vector in torch's registration order: w1 [H][K0], b1 [H], w2 [H][H], b2 [H], w3 [4][H], b3 [4]
-template <int K0, int H>
-struct ParamMap {
-  static constexpr int o_w1 = 0, o_b1 = H * K0, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + 4 * H, P = o_b3 + 4;
-};
 
 template <int K0, int H>
 __global__ __launch_bounds__(LWG) void dqn_sgd_multi_kernel(LearnArgs a, LearnShared *sh, float *partials) {
@@ -1569,12 +1637,18 @@ size_t dqn_sgd_lds_bytes(int n_cells, int n_hidden) {
   return sizeof(float) * (4 * LB * h + h * (size_t)weight_stride((int)h) + 8 * h + 4 * h + 8 + 2 * LB * 4 + LB + 32 + LB + 3 * LB) + 2 * LB * kp + 64;
 }
 
-#ifdef SGK_DQN_MULTI_WG
+// the handle's scratch block: AdamHeader + the flat gradient (two-launch Adam); in the experiment build also the four-workgroup
+// kernel's barrier words and partial gradients, whichever is larger
 size_t dqn_sgd_scratch_bytes(int n_cells, int n_hidden) {
   const size_t p = (size_t)n_hidden * n_cells + n_hidden + (size_t)n_hidden * n_hidden + n_hidden + 4 * (size_t)n_hidden + 4;
-  return sizeof(LearnShared) + sizeof(float) * GW * p;
+  size_t need = sizeof(AdamHeader) + sizeof(float) * p;
+#ifdef SGK_DQN_MULTI_WG
+  need = std::max(need, sizeof(LearnShared) + sizeof(float) * GW * p);
+#endif
+  return (need + 255) & ~(size_t)255;
 }
 
+#ifdef SGK_DQN_MULTI_WG
 // the four-workgroup form: LDS its workgroups need (0: no instantiation for this shape)
 template <int K0, int H>
 static hipError_t launch_multi(const LearnArgs &a, void *scratch, int device, hipStream_t st) {
@@ -1591,8 +1665,6 @@ static hipError_t launch_multi(const LearnArgs &a, void *scratch, int device, hi
   dqn_sgd_multi_kernel<K0, H><<<dim3(GW), dim3(LWG), lds, st>>>(a, sh, partials);
   return hipGetLastError();
 }
-#else
-size_t dqn_sgd_scratch_bytes(int, int) { return 0; }  // (the four-workgroup experiment is not compiled in)
 #endif
 
 hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) {
@@ -1610,6 +1682,7 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
   a.tw1t = L.tw1t; a.tb1 = L.tb1; a.tw2t = L.tw2t; a.tb2 = L.tb2; a.tw3 = L.tw3; a.tb3 = L.tb3;
   a.step = L.step; a.loss_out = L.loss_out; a.n_hidden = L.n_hidden; a.batch = L.batch;
   a.loss_mode = L.loss_mode; a.rows = L.rows; a.rows_out = L.rows_out;
+  a.adam_scratch = (L.scratch && !L.multi_wg) ? reinterpret_cast<float *>(L.scratch) : nullptr;
   a.reward_scale = sh.rules_host.reward_scale;
   a.seed = sh.seed;
   a.lr = (float)L.lr; a.beta1 = (float)L.beta1; a.beta2 = (float)L.beta2; a.eps = (float)L.eps; a.discount = (float)L.discount;
@@ -1619,7 +1692,7 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
 #define SGK_SGD_TRY_MULTI(K0V, HV)                                                                                         \
   do {                                                                                                                     \
     if constexpr (multi_lds_bytes<K0V, HV>() <= 160u * 1024u) {                                                            \
-      if (L.scratch) return launch_multi<K0V, HV>(a, L.scratch, sh.device, st);                                           \
+      if (L.scratch && L.multi_wg) return launch_multi<K0V, HV>(a, L.scratch, sh.device, st);                             \
     }                                                                                                                      \
   } while (0)
 #else
@@ -1636,6 +1709,11 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
       opted_in.fetch_or(1ull << (sh.device & 63));                                                                         \
     }                                                                                                                      \
     dqn_sgd_kernel<K0V, HV><<<dim3(1), dim3(LWG), lds, st>>>(a);                                                           \
+    if (a.adam_scratch) {                                                                                                  \
+      hipError_t le = hipGetLastError();                                                                                   \
+      if (le != hipSuccess) return le;                                                                                     \
+      dqn_adam_kernel<K0V, HV><<<dim3((ParamMap<K0V, HV>::P + 255) / 256), dim3(256), 0, st>>>(a);                         \
+    }                                                                                                                      \
   } while (0)
 #define SGK_SGD_LAUNCH_K(K0V)                                                                                              \
   do {                                                                                                                     \

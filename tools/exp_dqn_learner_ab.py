@@ -1,7 +1,7 @@
 """sgk_dqn_sgd_step (config 4's learner: Sokoban 36-100-100-4, batch 64, replay of 8 x 32 768 transitions), device time per call from HIP
-events over 300 back-to-back calls, and one lockstep step of dqn_learn with learning (graph replay, host clock). The product library
-has one kernel (one workgroup); against a -DSGK_DQN_MULTI_WG build (SGK_LIB_PATH, tools/gpu_dqn_timeline.sh ... multi) SGK_DQN_WORKGROUPS=4
-/ =1 picks the four-workgroup experiment / the product's kernel."""
+events over 300 back-to-back calls, and one lockstep step of dqn_learn with learning (graph replay, host clock). Default: the
+one-workgroup kernel + Adam as a second, chip-wide launch; SGK_DQN_ONE_LAUNCH=1: Adam inside the one kernel (rounds 1-5's form).
+(Against a -DSGK_DQN_MULTI_WG build -- SGK_LIB_PATH, tools/gpu_dqn_timeline.sh ... multi -- SGK_DQN_WORKGROUPS=4 picks the four-workgroup experiment.)"""
 import os, sys, time, types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "safe-grid-agents_amd")):
@@ -35,6 +35,6 @@ for name, hidden, batch in (("SideEffectsSokoban-v0", 100, 64), ("SideEffectsSok
         dq.step_graphed(learn=True)
     torch.cuda.synchronize()
     step_us = (time.perf_counter() - t0) / 300 * 1e6
-    print("workgroups=%s %-22s hidden %3d batch %2d: sgk_dqn_sgd_step %6.2f us per call | lockstep step with learning (graph) %6.2f us = %.3g env-steps/s"
-          % (os.environ.get("SGK_DQN_WORKGROUPS", "1"), name, hidden, batch, sgd_us, step_us, n / step_us * 1e6), flush=True)
+    print("%s %-22s hidden %3d batch %2d: sgk_dqn_sgd_step %6.2f us per call | lockstep step with learning (graph) %6.2f us = %.3g env-steps/s"
+          % ("adam-inside-the-kernel" if os.environ.get("SGK_DQN_ONE_LAUNCH") == "1" else "two-launches(default)", name, hidden, batch, sgd_us, step_us, n / step_us * 1e6), flush=True)
     env.close()

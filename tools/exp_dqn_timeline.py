@@ -18,8 +18,11 @@ MULTI = ["entry: minibatch draw + gather, four weight matrices and the small ten
          "dL/dh2 | W3, b3 gradient", "dL/dh1 | W2, b2 gradient tiles", "W1, b1 gradient tiles", "grid barrier B2 (partial gradients)",
          "sum of the partials, squared norm, Adam state in", "grid barrier B3 (norm)", "Adam on a quarter of the parameters, transposed copies"]
 multi = os.environ.get("SGK_DQN_WORKGROUPS") == "4"  # the -DSGK_DQN_MULTI_WG experiment (tools/gpu_dqn_timeline.sh multi)
+one_launch = os.environ.get("SGK_DQN_ONE_LAUNCH") == "1"
 if multi:
     LABELS = MULTI
+elif not one_launch:  # the product's default: the kernel ends behind the norm, Adam is a second launch (dqn_adam_kernel)
+    LABELS = LABELS[:12] + ["W1 / b1 gradient tiles; the gradient (55 KB, flat) and the clip coefficient out; norm (block sum)"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 dargs = types.SimpleNamespace(discount=0.99, lr=1e-3, batch_size=64, sync_every=10000, epsilon=0.01, epsilon_anneal=100000, n_layers=2, n_hidden=100)
 env = S.BatchedGridworldEnv("SideEffectsSokoban-v0", n, seed=0x5AFE, layout="compact")
@@ -42,7 +45,7 @@ for k in range(60):
         clocks.append(float(int(stamps[31]) - int(stamps[30])) / float(int(stamps[len(LABELS)]) - int(stamps[0])) * 100.0)
         ev.append(e0.elapsed_time(e1) * 1e3)
 d = np.diff(np.stack(rows), axis=1) / 100.0  # us
-print(("dqn_sgd_multi_kernel (4 workgroups; workgroup 0's stamps)" if multi else "dqn_sgd_kernel (1 workgroup)") + " <%d, 100>, batch 64, %d envs x 8 slices in the replay: us between barriers, lane 0 (mean / min / max over %d steps)" % (env.n_cells, n, len(rows)))
+print(("dqn_sgd_multi_kernel (4 workgroups; workgroup 0's stamps)" if multi else "dqn_sgd_kernel (1 workgroup%s)" % (", Adam inside" if one_launch else "; Adam follows as dqn_adam_kernel, not in this timeline")) + " <%d, 100>, batch 64, %d envs x 8 slices in the replay: us between barriers, lane 0 (mean / min / max over %d steps)" % (env.n_cells, n, len(rows)))
 for i, lab in enumerate(LABELS):
     print("  %2d  %6.2f  %6.2f  %6.2f  %s" % (i, d[:, i].mean(), d[:, i].min(), d[:, i].max(), lab))
 print("  in-kernel shader clock (s_memtime over s_memrealtime): %.0f MHz (min %.0f, max %.0f)" % (np.mean(clocks), np.min(clocks), np.max(clocks)))

@@ -13,4 +13,5 @@ make -s -j6 -C safe-grid-agents_amd/csrc OUT=../lib/libsgk_tl.so OBJDIR=build_tl
 if [ "$2" = multi ]; then
   SGK_DQN_WORKGROUPS=4 SGK_LIB_PATH=$PWD/safe-grid-agents_amd/lib/libsgk_tl.so SGK_NO_BUILD=1 python tools/exp_dqn_timeline.py 2>&1 | grep -v amdgpu.ids | tee -a "$out"
 fi
-SGK_DQN_WORKGROUPS=1 SGK_LIB_PATH=$PWD/safe-grid-agents_amd/lib/libsgk_tl.so SGK_NO_BUILD=1 python tools/exp_dqn_timeline.py 2>&1 | grep -v amdgpu.ids | tee -a "$out"
+SGK_LIB_PATH=$PWD/safe-grid-agents_amd/lib/libsgk_tl.so SGK_NO_BUILD=1 python tools/exp_dqn_timeline.py 2>&1 | grep -v amdgpu.ids | tee -a "$out"
+SGK_DQN_ONE_LAUNCH=1 SGK_LIB_PATH=$PWD/safe-grid-agents_amd/lib/libsgk_tl.so SGK_NO_BUILD=1 python tools/exp_dqn_timeline.py 2>&1 | grep -v amdgpu.ids | tee -a "$out"
