@@ -549,30 +549,27 @@ def run_config(args):
         dt_learn_graph = wall(lambda: dq.step_graphed(learn=True), 300)
         acts = dq._actions
         pieces = {
-            "replay_store_states": ev_time(env, lambda: dq.replay.store(env, 0), 200),
             "forward_and_act_explore": ev_time(env, lambda: env.policy_act(dq._fw, 0.01, 0, out=acts), 200),
-            # env.step and reset_done as ONE piece, in the order the lockstep step makes them: timed apart and back to back (as rounds
-            # 3-5 did) most timed steps run on envs whose episode is over -- the idle path -- and every reset after the first has
-            # nothing to reset, which read both pieces ~1.3 us short
-            "env_step_and_reset_done": ev_time(env, lambda: (env.step(acts, auto_reset=False), env.reset_done()), 200),
-            "replay_store_successors": ev_time(env, lambda: dq.replay.store(env, 1, acts), 200),
+            # env.step (+ the replay add's second half) and reset_done (+ the add's first half for the next step): the two fused
+            # launches of round 6, timed as ONE piece in the order the lockstep step makes them -- timed apart and back to back most
+            # timed steps would run on envs whose episode is over and every reset after the first would have nothing to reset
+            "env_step_store_and_reset_done_store": ev_time(env, lambda: (dq.replay.step_store(env, acts), dq.replay.reset_store(env)), 200),
             "sgd_step": ev_time(env, lambda: dq.learn_batch(), 200),
         }
         device_sum = sum(pieces.values())
         dt_best = min(dt_learn, dt_learn_graph)
         with_learning = {
             "us_per_lockstep_step": dt_best * 1e6, "value": n / dt_best,
-            "how": "six library calls per lockstep step from Python" if dt_learn <= dt_learn_graph else "one hipGraph replay per lockstep step",
+            "how": "four library calls (five launches) per lockstep step from Python" if dt_learn <= dt_learn_graph else "one hipGraph replay per lockstep step",
             "eager_us_per_lockstep_step": dt_learn * 1e6, "eager_value": n / dt_learn,
             "graph_us_per_lockstep_step": dt_learn_graph * 1e6, "graph_value": n / dt_learn_graph,
             "breakdown_us": {k: v * 1e6 for k, v in pieces.items()},
             "breakdown_device_sum_us": device_sum * 1e6,
-            "acting_us": (pieces["forward_and_act_explore"] + pieces["env_step_and_reset_done"]) * 1e6,
-            "replay_store_us": (pieces["replay_store_states"] + pieces["replay_store_successors"]) * 1e6,
+            "acting_and_replay_store_us": (pieces["forward_and_act_explore"] + pieces["env_step_store_and_reset_done_store"]) * 1e6,
             "sgd_us": pieces["sgd_step"] * 1e6,
             "whole_step_minus_pieces_us": {"graph": (dt_learn_graph - device_sum) * 1e6, "eager": (dt_learn - device_sum) * 1e6},
-            "note": "one SGD step (batch 64, Adam amsgrad, ONE 1 024-lane workgroup: sgk::dqn_sgd_kernel, 39 us, timeline "
-                    "profiles/r06/dqn_timeline_after.log) per lockstep step of all 32 768 envs; the reference's ratio is one SGD step per "
+            "note": "one SGD step (batch 64, Adam amsgrad: sgk::dqn_sgd_kernel, one 1 024-lane workgroup, 30 us + sgk::dqn_adam_kernel over the chip, "
+                    "5 us; profiles/r06/dqn_learn_kernel_stats.csv, dqn_timeline.log) per lockstep step of all 32 768 envs; the reference's ratio is one SGD step per "
                     "SINGLE env-step (value.py:113-117). Each piece is timed alone, 200 calls back to back from Python: a piece reads "
                     "max(its kernel, one Python call ~ 5 us), so the pieces can add up to MORE than the whole step, whose calls overlap "
                     "the previous kernels (whole_step_minus_pieces_us < 0)."}

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SGK_ABI_VERSION 4 /* 3: the tabular-Q tables in HBM are state-major (sgk_tabq_table_dev); 4: sgk_tabq_step, sgk_dqn_learner's
+#define SGK_ABI_VERSION 4 /* 3: the tabular-Q tables in HBM are state-major (sgk_tabq_table_dev); 4: sgk_tabq_step, sgk_step_store, sgk_reset_done_store, sgk_dqn_learner's
                              loss_mode / rows / rows_out, SGK_F_SEPARATE_LAUNCHES, the sgk_debug_* hooks are off unless asked for */
 
 #if defined(__GNUC__)
@@ -388,6 +388,24 @@ typedef struct sgk_mlp_weights {
 SGK_API int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon, uint64_t draw_index,
                            const double *epsilon_dev, const uint64_t *draw_index_dev, uint8_t *actions_out_dev,
                            float *scores_out_dev);
+
+/* The two halves of the replay add FUSED into the launches around them (round 6; a lockstep step of dqn_learn -- learn.py:29-58 -- is
+ * then sgk_policy_act, sgk_step_store, sgk_dqn_sgd_step, sgk_reset_done_store: four calls instead of six):
+ *   sgk_step_store        env.step(actions) for every env (learn.py:38; no auto-reset) AND ReplayBuffer.add's second half (contain.py:15-17
+ *                         via value.py:114): the successor boards, the action, the reward (cheat != 0: the hidden reward and the executed
+ *                         action, learn.py:41-47) and the terminal flag go into slice `slice` of the rings, next to the step's usual
+ *                         outputs. = sgk_step + sgk_replay_store(phase 1).
+ *   sgk_reset_done_store  env.reset() of the envs whose episode is over (train.py:62-64) AND the add's first half for the NEXT step:
+ *                         every env's board -- what its next action is chosen on -- goes into slice `slice` of the states ring.
+ *                         = sgk_reset_done + sgk_replay_store(phase 0).
+ * slice_dev non-NULL (graph replays): the slice is (*slice_dev + slice) % ring_slices, read by the launch. Rings as for
+ * sgk_replay_store: boards int8 [slices][n_envs][n_cells], the others [slices][n_envs]. flags: SGK_F_NO_BOARDS or 0 (the env's own
+ * board buffer; the rings always receive theirs). */
+SGK_API int sgk_step_store(sgk_env *h, const uint8_t *actions_dev, uint32_t flags, int32_t cheat, int64_t slice, const int64_t *slice_dev,
+                           int32_t ring_slices, int8_t *successors_ring, uint8_t *actions_ring, int8_t *rewards_ring,
+                           uint8_t *terminals_ring);
+SGK_API int sgk_reset_done_store(sgk_env *h, uint32_t flags, int64_t slice, const int64_t *slice_dev, int32_t ring_slices,
+                                 int8_t *states_ring);
 
 /* ---- DeepQAgent.learn (reference value.py:113-136) for the default topology as ONE kernel --------------------------- */
 /* What the kernel does, by reference line: ReplayBuffer.sample (contain.py:19-22, called at value.py:116) -- uniform with

@@ -847,6 +847,30 @@ int sgk_replay_store(sgk_env *h, int32_t phase, const uint8_t *actions_dev, int3
   return SGK_OK;
 } SGK_CATCH_STATUS
 
+int sgk_step_store(sgk_env *h, const uint8_t *actions_dev, uint32_t flags, int32_t cheat, int64_t slice, const int64_t *slice_dev,
+                   int32_t ring_slices, int8_t *successors_ring, uint8_t *actions_ring, int8_t *rewards_ring, uint8_t *terminals_ring) try {
+  SGK_CHECK_HANDLE(h);
+  if (!actions_dev) return fail(SGK_ERR_INVALID, "actions_dev is NULL");
+  if (flags & ~(uint32_t)SGK_F_NO_BOARDS) return fail(SGK_ERR_INVALID, "only SGK_F_NO_BOARDS is meaningful here (the finished envs are reset by sgk_reset_done[_store])");
+  if (!successors_ring || !actions_ring || !rewards_ring || !terminals_ring) return fail(SGK_ERR_INVALID, "NULL ring pointer");
+  if (slice < 0 || ring_slices < 0 || (slice_dev && ring_slices < 1)) return fail(SGK_ERR_INVALID, "bad slice / ring_slices");
+  SGK_HIP(sgk::launch_step_store(h->sh, actions_dev, flags, cheat ? 1 : 0, slice, reinterpret_cast<const long long *>(slice_dev), ring_slices,
+                                 successors_ring, actions_ring, rewards_ring, terminals_ring, h->stream));
+  h->sh.lockstep_t += 1;
+  h->t_dev_stale = true;
+  h->steps_issued += h->sh.n;
+  return SGK_OK;
+} SGK_CATCH_STATUS
+
+int sgk_reset_done_store(sgk_env *h, uint32_t flags, int64_t slice, const int64_t *slice_dev, int32_t ring_slices, int8_t *states_ring) try {
+  SGK_CHECK_HANDLE(h);
+  if (flags & ~(uint32_t)SGK_F_NO_BOARDS) return fail(SGK_ERR_INVALID, "only SGK_F_NO_BOARDS is meaningful here");
+  if (!states_ring) return fail(SGK_ERR_INVALID, "NULL ring pointer");
+  if (slice < 0 || ring_slices < 0 || (slice_dev && ring_slices < 1)) return fail(SGK_ERR_INVALID, "bad slice / ring_slices");
+  SGK_HIP(sgk::launch_reset_done_store(h->sh, flags, slice, reinterpret_cast<const long long *>(slice_dev), ring_slices, states_ring, h->stream));
+  return SGK_OK;
+} SGK_CATCH_STATUS
+
 int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) try {
   SGK_CHECK_HANDLE(h);
   if (!L) return fail(SGK_ERR_INVALID, "learner is NULL");

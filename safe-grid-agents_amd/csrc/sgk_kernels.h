@@ -110,6 +110,11 @@ struct DqnLearner {
   int multi_wg;           // (-DSGK_DQN_MULTI_WG experiment build only) run the four-workgroup kernel on `scratch`
   double lr, beta1, beta2, eps, discount, max_grad_norm;
 };  // (the replay's int8 rewards are in units of the level's reward_scale: launch_dqn_sgd takes it from the shard's rules)
+// env.step + the second half of ReplayBuffer.add / reset_done + the first half for the next step, one launch each (sgk_step.hip)
+hipError_t launch_step_store(const Shard &sh, const uint8_t *actions, uint32_t flags, int cheat, int64_t slice, const long long *slice_dev,
+                             int32_t ring, int8_t *successors, uint8_t *r_actions, int8_t *r_rewards, uint8_t *r_terminals, hipStream_t st);
+hipError_t launch_reset_done_store(const Shard &sh, uint32_t flags, int64_t slice, const long long *slice_dev, int32_t ring, int8_t *states,
+                                   hipStream_t st);
 hipError_t launch_replay_store(const Shard &sh, int phase, const uint8_t *actions, int cheat, int64_t head, const long long *head_dev,
                                int8_t *states, int8_t *successors, uint8_t *r_actions, int8_t *r_rewards, uint8_t *r_terminals,
                                hipStream_t st);

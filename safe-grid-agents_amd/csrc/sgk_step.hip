@@ -66,8 +66,45 @@ __global__ __launch_bounds__(WG) void metrics_init_kernel(long long *__restrict_
 // launch (tools/exp_step_variants.hip, profiles/r05/step_variants_*.log): 1 024 envs 2.46 -> 2.10, 65 536 envs 2.65 -> 2.54,
 // 262 144 envs 3.86 -> 4.50 (hence the size cut).
 constexpr int64_t STEP_SMALL_MAX_ENVS = 65536;
-template <int ENV, int LAYOUT, bool RANDOM, bool SMALL>
-__global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a) {
+
+// ReplayBuffer.add's second half (reference contain.py:15-17, called from value.py:114 right after env.step, learn.py:38-48) fused
+// into the step (sgk_step_store): the successor board, the action, the reward (hidden under --cheat) and the terminal flag of every
+// env go into slice `slice` of a device replay ring next to the step's usual outputs -- one launch instead of sgk_step +
+// sgk_replay_store(phase 1). Also used by reset_kernel for the first half (the board the next action is chosen on -> states ring).
+struct StepStore {
+  int8_t *boards;       // ring [slices][n][NC] that receives this launch's boards
+  uint8_t *actions;     // rings [slices][n]; null for the reset kernel
+  int8_t *rewards;
+  uint8_t *terminals;
+  long long slice;      // slice index ...
+  const long long *slice_dev;  // ... or, when non-null (graph replays), (*slice_dev + slice) % ring
+  int32_t ring;         // slices of the ring (for the modulo; 0: no modulo)
+  int32_t cheat;        // store the hidden reward and the executed action (learn.py:41-47)
+  int32_t tiles_ok;     // n * NC % 16 == 0: whole 64-env tiles go through the tile writer
+};
+__device__ __forceinline__ long long store_slice(const StepStore &st) {
+  long long sl = st.slice;
+  if (st.slice_dev) sl += *st.slice_dev;
+  if (st.ring > 0) sl %= st.ring;
+  return sl;
+}
+// this wave's board tile (in `W`, drawn) -> rows wt * 64 .. of slice `sl` of the ring: the tile writer where the slice's rows are
+// 16-byte aligned and the tile is whole, else lane by lane from the LDS image
+template <class Tile, int NC>
+__device__ __forceinline__ void store_tile(const Tile &W, const StepStore &st, long long sl, int64_t n, int64_t wt, int lane) {
+  int8_t *dst = st.boards + ((int64_t)sl * n + wt * 64) * NC;
+  if (st.tiles_ok && wt * 64 + 64 <= n) {
+    W.template flush<0>(dst);
+  } else {
+    __builtin_amdgcn_wave_barrier();
+    if (wt * 64 + lane < n)
+      for (int c = 0; c < NC; ++c) dst[lane * NC + c] = (int8_t)W.tile[lane * NC + c];
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int ENV, int LAYOUT, bool RANDOM, bool SMALL, bool STORE = false>
+__global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a, StepStore st) {
   constexpr int WGT = SMALL ? 64 : WG;
   constexpr int NC = Geom<ENV>::NC;
   constexpr bool COMPACT = (LAYOUT == SGK_LAYOUT_COMPACT);
@@ -88,6 +125,7 @@ __global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a) {
   keep_in_sgprs(a.seed, a.env_base, a.t, a.flags);
   const uint64_t *t_word = a.t_ptr ? a.t_ptr : reinterpret_cast<const uint64_t *>(a.rules);
   const uint64_t t_base = *t_word;  // (wave-uniform address: a scalar load)
+  const long long st_slice = STORE ? store_slice(st) : 0;  // (its scalar load goes out with the others)
   uint64_t w_cur = 0;
   uint8_t a_cur = 0;
   {
@@ -153,14 +191,25 @@ __global__ __launch_bounds__(SMALL ? 64 : WG) void step_kernel(StepArgs a) {
       a.state[env] = pack_state(s);
       if (SMALL) a.rec[env] = rec;
       else __hip_atomic_store(&a.rec[env], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
+      if (STORE) {  // contain.py:15-17's action / reward / terminal of this transition
+        const int64_t at = (int64_t)st_slice * a.n + env;
+        // (& 3: an executed "stay", action 4 under a non-default SGK_INTERRUPT_FORCED_ACTION, has no Q column: stored as UP)
+        st.actions[at] = st.cheat ? (uint8_t)((rec >> 24) & 3u) : (uint8_t)(act_cur & 3);
+        st.rewards[at] = st.cheat ? (int8_t)(rec >> 8) : (int8_t)rec;
+        st.terminals[at] = (uint8_t)((rec >> 16) & 1u);
+      }
     }
-    if (boards_on) {
+    if (boards_on || STORE) {
       if (COMPACT) {
         W.draw_from_blank(blank, R, sprite_info<ENV>(R, s));
-        if (SMALL) W.template flush<0>(a.boards + wt * 64 * NC);  // the buffer is padded to whole tiles
-        else W.flush(a.boards + wt * 64 * NC);
+        if (boards_on) {
+          if (SMALL) W.template flush<0>(a.boards + wt * 64 * NC);  // the buffer is padded to whole tiles
+          else W.flush(a.boards + wt * 64 * NC);
+        }
+        if (STORE) store_tile<WaveTileLds<ENV, NC>, NC>(W, st, st_slice, a.n, wt, lane);
       } else if (valid) {
-        write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+        if (boards_on) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, a.boards, env, s);
+        if (STORE) write_row_bytes<ENV, NC>(R, st.boards + ((int64_t)st_slice * a.n + env) * NC, s);
       }
     }
     if (!more) break;
@@ -542,10 +591,10 @@ __global__ __launch_bounds__(WG, STREAM ? STREAM_MIN_WAVES : 1) void rollout_ran
 // env.reset(): mode 0 = all envs (mask == nullptr) or masked envs; mode 1 = exactly the envs whose episode
 // is over; mode 2 = no state change, only re-materialise the boards from the state words
 // ------------------------------------------------------------------------------------------------
-template <int ENV, int LAYOUT>
+template <int ENV, int LAYOUT, bool STORE = false>
 __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64_t *state, int8_t *boards,
                                                    const uint8_t *mask, int mode_flags, int64_t n, uint64_t seed, uint64_t env_base,
-                                                   int32_t *__restrict__ n_resets, const double *__restrict__ aux) {
+                                                   int32_t *__restrict__ n_resets, const double *__restrict__ aux, StepStore st) {
   const int mode = mode_flags & 3;
   const bool no_boards = (mode_flags & 4) != 0;  // state words only (the caller steps with SGK_F_NO_BOARDS)
   constexpr int NC = Geom<ENV>::NC;
@@ -572,6 +621,7 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
   W.bind(tile_images[COMPACT ? wave : 0]);
   typename WaveTileLds<ENV, NC>::Blank blank;
   if (COMPACT) W.request_blank(blank, rules);
+  const long long st_slice = STORE ? store_slice(st) : 0;
   rules_load.commit(rules_images[wave]);
   const SgkRules &R = rules_images[wave].r;
   if (COMPACT) W.blank_arrived(blank);  // (every load of the wave is in before its first store goes out: one counter for both)
@@ -610,14 +660,18 @@ __global__ __launch_bounds__(WG) void reset_kernel(const SgkRules *rules, uint64
     // boards: every tile when re-materialising (mode 2) or resetting everything; otherwise only the tiles (rows) a reset
     // touched -- the others already show their envs' states, and rewriting them is most of this kernel's traffic
     const bool all = mode == 2 || (mode == 0 && mask == nullptr);
-    if (!no_boards) {
+    if (!no_boards || STORE) {
       if (COMPACT) {
-        if (all || __ballot(hit) != 0ull) {
+        const bool touched = all || __ballot(hit) != 0ull;
+        if (touched || STORE) {
           W.draw_from_blank(blank, R, sprite_info<ENV>(R, s));
-          W.flush(boards + wt * 64 * NC);
+          if (touched && !no_boards) W.flush(boards + wt * 64 * NC);
+          // (STORE: the boards the next actions are chosen on -- EVERY env's, reset or not -- are the next transitions' states)
+          if (STORE) store_tile<WaveTileLds<ENV, NC>, NC>(W, st, st_slice, n, wt, lane);
         }
-      } else if (valid && (all || hit)) {
-        write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
+      } else if (valid) {
+        if (!no_boards && (all || hit)) write_board_pitched<ENV, Geom<ENV>::PITCH>(R, boards, env, s);
+        if (STORE) write_row_bytes<ENV, NC>(R, st.boards + ((int64_t)st_slice * n + env) * NC, s);
       }
     }
     if (!more) break;
@@ -765,10 +819,10 @@ hipError_t launch_step_counter(const Shard &sh, const uint64_t *t_dev, uint64_t 
   a.t = t_off;
   a.t_ptr = t_dev;
   if (sh.n <= STEP_SMALL_MAX_ENVS) {
-    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, true><<<dim3((unsigned)((sh.n + 63) / 64)), dim3(64), 0, st>>>(a));
+    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, true><<<dim3((unsigned)((sh.n + 63) / 64)), dim3(64), 0, st>>>(a, StepStore{}));
   } else {
     int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
-    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, false><<<dim3(grid), dim3(WG), 0, st>>>(a));
+    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, false><<<dim3(grid), dim3(WG), 0, st>>>(a, StepStore{}));
   }
   return hipGetLastError();
 }
@@ -779,12 +833,34 @@ hipError_t launch_step(const Shard &sh, const uint8_t *actions, uint32_t flags, 
   const bool small = sh.n <= STEP_SMALL_MAX_ENVS;
   const dim3 grid(small ? (unsigned)((sh.n + 63) / 64) : (unsigned)grid_for((sh.n + WG - 1) / WG, sh.max_grid)), block(small ? 64 : WG);
   if (actions) {
-    if (small) SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, false, true><<<grid, block, 0, st>>>(a));
-    else SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, false, false><<<grid, block, 0, st>>>(a));
+    if (small) SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, false, true><<<grid, block, 0, st>>>(a, StepStore{}));
+    else SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, false, false><<<grid, block, 0, st>>>(a, StepStore{}));
   } else {
-    if (small) SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, true><<<grid, block, 0, st>>>(a));
-    else SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, false><<<grid, block, 0, st>>>(a));
+    if (small) SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, true><<<grid, block, 0, st>>>(a, StepStore{}));
+    else SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, true, false><<<grid, block, 0, st>>>(a, StepStore{}));
   }
+  return hipGetLastError();
+}
+
+static StepStore make_store(const Shard &sh, int8_t *boards_ring, uint8_t *r_actions, int8_t *r_rewards, uint8_t *r_terminals, int64_t slice,
+                            const long long *slice_dev, int32_t ring, int cheat) {
+  StepStore s;
+  s.boards = boards_ring; s.actions = r_actions; s.rewards = r_rewards; s.terminals = r_terminals;
+  s.slice = slice; s.slice_dev = slice_dev; s.ring = ring; s.cheat = cheat;
+  s.tiles_ok = ((sh.n * sh.n_cells) % 16 == 0 && ((uintptr_t)boards_ring & 15u) == 0) ? 1 : 0;
+  return s;
+}
+
+// env.step + ReplayBuffer.add's second half in one launch (sgk_step_store)
+hipError_t launch_step_store(const Shard &sh, const uint8_t *actions, uint32_t flags, int cheat, int64_t slice, const long long *slice_dev,
+                             int32_t ring, int8_t *successors, uint8_t *r_actions, int8_t *r_rewards, uint8_t *r_terminals, hipStream_t st) {
+  (void)hipGetLastError();
+  StepArgs a = make_step_args(sh, actions, flags);
+  const StepStore so = make_store(sh, successors, r_actions, r_rewards, r_terminals, slice, slice_dev, ring, cheat);
+  const bool small = sh.n <= STEP_SMALL_MAX_ENVS;
+  const dim3 grid(small ? (unsigned)((sh.n + 63) / 64) : (unsigned)grid_for((sh.n + WG - 1) / WG, sh.max_grid)), block(small ? 64 : WG);
+  if (small) SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, false, true, true><<<grid, block, 0, st>>>(a, so));
+  else SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, step_kernel<E, L, false, false, true><<<grid, block, 0, st>>>(a, so));
   return hipGetLastError();
 }
 
@@ -887,7 +963,22 @@ hipError_t launch_reset(const Shard &sh, const uint8_t *mask, int mode, hipStrea
   int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
   SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
                           reset_kernel<E, L><<<dim3(grid), dim3(WG), 0, st>>>(sh.rules_dev, sh.state,
-                                              sh.boards, mask, mode, sh.n, sh.seed, sh.env_base, sh.n_resets, sh.aux));
+                                              sh.boards, mask, mode, sh.n, sh.seed, sh.env_base, sh.n_resets, sh.aux, StepStore{}));
+  return hipGetLastError();
+}
+
+// sgk_reset_done + ReplayBuffer.add's first half for the NEXT step in one launch (sgk_reset_done_store): the envs whose episode is
+// over are reset, then every env's board -- what the next action is chosen on -- goes into slice (slice [+ *slice_dev]) % ring of
+// the states ring
+hipError_t launch_reset_done_store(const Shard &sh, uint32_t flags, int64_t slice, const long long *slice_dev, int32_t ring, int8_t *states,
+                                   hipStream_t st) {
+  (void)hipGetLastError();
+  int grid = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+  const StepStore so = make_store(sh, states, nullptr, nullptr, nullptr, slice, slice_dev, ring, 0);
+  const int mode = 1 | ((flags & SGK_F_NO_BOARDS) ? 4 : 0);
+  SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout,
+                          reset_kernel<E, L, true><<<dim3(grid), dim3(WG), 0, st>>>(sh.rules_dev, sh.state,
+                                              sh.boards, nullptr, mode, sh.n, sh.seed, sh.env_base, sh.n_resets, sh.aux, so));
   return hipGetLastError();
 }
 

@@ -308,6 +308,7 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         episode's first board, as after reset_done). Same results as act_explore / env.step / learn / reset_done."""
         flags = 0 if write_boards else _lib.F_NO_BOARDS
         self.env._sync_torch_to_lib()
+        self.env._version += 1
         _lib.check(self.lib.sgk_tabq_step(self._h, int(cheat), flags, ctypes.c_void_p(self._actions.data_ptr())))
         self.env._sync_lib_to_torch()
         return self._actions, self.env._step_outputs()
@@ -318,6 +319,7 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         sequence act_explore -> env.step -> learn -> reset_done instead (four launches per step: rounds 2-5's form)."""
         flags = (0 if write_boards else _lib.F_NO_BOARDS) | (_lib.F_SEPARATE_LAUNCHES if separate_launches else 0)
         self.env._follow()
+        self.env._version += 1
         _lib.check(self.lib.sgk_tabq_learn_steps(self._h, int(n_steps), int(cheat), flags))
 
     def rollout(self, n_steps, cheat=False, kernel="auto"):
@@ -325,6 +327,7 @@ class BatchedTabularQAgent(BaseActor, BaseLearner, BaseExplorer):
         "lds" / "hbm" to name the kernel (tables resident in LDS / rows in HBM; same results)."""
         k = {"auto": _lib.TABQ_KERNEL_AUTO, "lds": _lib.TABQ_KERNEL_LDS, "hbm": _lib.TABQ_KERNEL_HBM}[kernel]
         self.env._follow()
+        self.env._version += 1
         _lib.check(self.lib.sgk_tabq_rollout_ex(self._h, int(n_steps), int(cheat), k))
 
     def table(self):

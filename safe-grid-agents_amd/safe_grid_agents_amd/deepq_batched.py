@@ -43,6 +43,8 @@ class DeviceReplay:
         self.filled = 0    # slices holding data
         self.head_dev = torch.zeros(1, dtype=torch.long, device=device)  # the same head, for graph-captured adds
         self.head_dev_stale = False
+        # env._version at which states[head] was filled with the boards the next action is chosen on (reset_store below; None: not)
+        self.ready_version = None
 
     def __len__(self):
         return self.filled * self.n
@@ -82,6 +84,30 @@ class DeviceReplay:
 
     def note_replayed_add(self):
         self._advance()
+
+    # ---- the two halves of the add fused into the launches around them (sgk_step_store / sgk_reset_done_store) ----
+    def states_ready(self, env):
+        """states[head] already holds the boards the next action will be chosen on (the previous step's reset_store put them there and
+        nothing has changed the envs since)."""
+        return self.ready_version is not None and self.ready_version == env._version
+
+    def step_store(self, env, actions, cheat=False, captured=False):
+        """env.step(actions) + the add's second half in one launch; advances the host head unless captured."""
+        rings = (self.successors, self.actions, self.rewards, self.terminals)
+        if captured:
+            env.step_store(actions, 0, rings, cheat=cheat, slice_dev=self.head_dev)
+        else:
+            env.step_store(actions, self.head, rings, cheat=cheat)
+            self._advance()
+            self.head_dev_stale = True
+
+    def reset_store(self, env, captured=False):
+        """reset_done() + the add's first half for the NEXT step (states[head] = the boards after the reset) in one launch."""
+        if captured:
+            env.reset_done_store(self.states, 0, slice_dev=self.head_dev)
+        else:
+            env.reset_done_store(self.states, self.head)
+        self.ready_version = env._version
 
     def sample(self, batch):
         """Uniform with replacement over everything stored (contain.py:19-22), indices drawn on the device."""
@@ -326,9 +352,9 @@ class BatchedDeepQAgent:
     def step(self, learn=True, cheat=False, explore=True):
         """One lockstep iteration of dqn_learn for every env: act_explore -> env.step -> replay.add -> learn ->
         update_epsilon -> (sync target) -> reset finished envs (the episode loop of train.py:62-70)."""
-        env = self.env
-        if learn:
-            self.replay.store(env, 0)  # the boards the agents act on are the transitions' states
+        env, rp = self.env, self.replay
+        if learn and not rp.states_ready(env):
+            rp.store(env, 0)  # the boards the agents act on are the transitions' states (already there when the previous step left them)
         if self.fused_policy:
             if self._fw_stale:
                 self._refresh_fused_weights()
@@ -336,16 +362,21 @@ class BatchedDeepQAgent:
         else:
             env.obs_f32(self._obs)
             actions = self.act_explore(self._obs) if explore else self.act(self._obs)
-        env.step(actions, auto_reset=False)
         if learn:
-            self.replay.store(env, 1, actions, cheat)  # successor boards, action, reward (hidden when cheating), terminal
+            # env.step + the rest of the add in ONE launch: successor boards, action, reward (hidden when cheating), terminal
+            rp.step_store(env, actions, cheat)
             for _ in range(self.sgd_steps):
                 self.learn_batch()
+        else:
+            env.step(actions, auto_reset=False)
         t = self.t
         self.update_epsilon()
         if learn and t % self.sync_every == self.sync_every - 1:
             self.sync_target_Q()
-        env.reset_done()
+        if learn:
+            rp.reset_store(env)  # reset_done + the NEXT transition's states in one launch
+        else:
+            env.reset_done()
         return actions
 
     # ---- the same lockstep iteration replayed from ONE hipGraph (torch.cuda.CUDAGraph) -------------------------------
@@ -354,10 +385,10 @@ class BatchedDeepQAgent:
     # plain launches on the capture stream) removes that: everything that varies between replays lives in device memory
     # (epsilon scalar, replay ring head, Adam's capturable step counter).
     def _captured_iteration(self, learn, cheat=False):
+        """act -> step (+ the add's second half) -> [SGD] -> reset (+ the NEXT transition's states): states[head] must hold the current
+        boards when it starts (enable_graphs / step_graphed see to it: DeviceReplay.states_ready)."""
         torch = self.torch
         env = self.env
-        if learn:
-            self.replay.store(env, 0, captured=True)
         if self.fused_policy:  # epsilon and the draw index are read from device memory: they advance between replays
             if (learn and not self.fused_learn) or self._fw_stale:
                 self._refresh_fused_weights()  # recorded in the learn graph: torch's update leaves the transposes behind
@@ -376,13 +407,15 @@ class BatchedDeepQAgent:
             explore = torch.rand(n, device=self.device) < self._eps_dev
             rand_a = torch.randint(0, self.action_n, (n,), device=self.device)
             actions = torch.where(explore, rand_a, greedy).to(torch.uint8)
-        env.step(actions, auto_reset=False)
         if learn:
-            self.replay.store(env, 1, actions, cheat, captured=True)  # --cheat: hidden reward + executed action (learn.py:41-47)
+            self.replay.step_store(env, actions, cheat, captured=True)  # --cheat: hidden reward + executed action (learn.py:41-47)
             self.replay.head_dev.add_(1).remainder_(self.replay.slices)
             for _ in range(self.sgd_steps):
                 self.learn_batch()
-        env.reset_done()
+            self.replay.reset_store(env, captured=True)  # (head_dev already names the next slice)
+        else:
+            env.step(actions, auto_reset=False)
+            env.reset_done()
 
     def enable_graphs(self, learn=True, cheat=False):
         """Capture one lockstep iteration. Needs a full replay ring (run warmup(replay_slices) first) so that the sampling
@@ -404,6 +437,8 @@ class BatchedDeepQAgent:
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
                 env.bind_torch_stream(side)
+                if learn and not self.replay.states_ready(env):
+                    self.replay.store(env, 0, captured=True)  # states[head_dev] = the boards the first recorded action is chosen on
                 for _ in range(3):  # warm-up on the side stream (allocator, lazy init), as the capture recipe requires
                     self._captured_iteration(learn, cheat)
                     if learn:
@@ -415,6 +450,8 @@ class BatchedDeepQAgent:
                 self._captured_iteration(learn, cheat)
             env.bind_torch_stream()  # follow torch's current stream again: replays are launched on it
         env.account_steps(-1)  # the recorded (not executed) sgk_step bumped the host-side counters once
+        if learn:
+            self.replay.ready_version = env._version  # the last warm-up iteration's reset_store filled states[head]
         self._graphs[(learn, cheat)] = graph
 
     def step_graphed(self, learn=True, cheat=False):
@@ -427,10 +464,15 @@ class BatchedDeepQAgent:
             self.replay.head_dev_stale = False
         if self.fused_policy and self._fw_stale and not learn:
             self._refresh_fused_weights()  # the no-learning graph does not record the transposes
+        if learn and not self.replay.states_ready(self.env):
+            self.replay.store(self.env, 0, captured=True)  # (something else moved the envs since the last learning step)
         self._graphs[(learn, cheat)].replay()
         self.env.account_steps(1)
         if learn:
             self.replay.note_replayed_add()
+            self.replay.ready_version = self.env._version  # the replayed reset_store filled states[head]
+        else:
+            self.replay.ready_version = None
         t = self.t
         self.update_epsilon()
         if learn and t % self.sync_every == self.sync_every - 1:

@@ -183,6 +183,7 @@ class BatchedGridworldEnv:
             raise ValueError("stream must be 'torch' (enqueue on torch's current stream) or 'own' (a private stream), not %r" % (stream,))
         # "follow": torch's current stream, re-read at every call; "pinned": one torch stream (bind_torch_stream(s)); "own": private
         self._mode = "follow" if stream == "torch" else "own"
+        self._version = 0  # bumped by every call that changes env states: what a consumer (the replay's fused stores) compares
         self._bound_ptr = None  # the raw stream the library currently enqueues on (follow / pinned); None = its own stream
         self._raw_current = None
 
@@ -388,6 +389,7 @@ class BatchedGridworldEnv:
         return self._device_views()["boards"]
 
     def reset(self, mask=None):
+        self._version += 1
         if mask is None:
             self._follow()
             _lib.check(self.lib.sgk_reset(self._h.ptr, None))
@@ -400,6 +402,7 @@ class BatchedGridworldEnv:
 
     def reset_done(self):
         self._follow()
+        self._version += 1
         _lib.check(self.lib.sgk_reset_done(self._h.ptr))
         self._sync_lib_to_torch()
         return self.boards()
@@ -419,6 +422,7 @@ class BatchedGridworldEnv:
         actions = self._actions_arg(actions)
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
         self._sync_torch_to_lib()
+        self._version += 1
         _lib.check(self.lib.sgk_step(self._h.ptr, ctypes.c_void_p(actions.data_ptr()), flags))
         self._sync_lib_to_torch()
         return self._step_outputs()
@@ -428,9 +432,48 @@ class BatchedGridworldEnv:
         actions = self._actions_arg(actions)
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
         self._sync_torch_to_lib()
+        self._version += 1
         _lib.check(self.lib.sgk_step_repeat(self._h.ptr, ctypes.c_void_p(actions.data_ptr()), int(n_steps), flags))
         self._sync_lib_to_torch()
         return self._step_outputs()
+
+    def step_store(self, actions, slice_index, rings, cheat=False, slice_dev=None, write_boards=True):
+        """env.step(actions) (no auto-reset) and ReplayBuffer.add's second half in ONE launch (sgk_step_store): the successor boards,
+        action, reward (hidden + executed action under cheat) and terminal flag of every env go into slice `slice_index` of `rings` =
+        (successors int8 [S, N, cells], actions uint8 [S, N], rewards int8 [S, N], terminals bool / uint8 [S, N]). slice_dev: a
+        1-element int64 device tensor added to slice_index modulo S by the launch itself (graph replays)."""
+        actions = self._actions_arg(actions)
+        succ, ract, rrew, rterm = rings
+        S_ = int(succ.shape[0])
+        self._check(succ, "successors ring", shape=(S_, self.n_envs, self.n_cells), dtypes=("int8",))
+        self._check(ract, "actions ring", shape=(S_, self.n_envs), dtypes=("uint8",))
+        self._check(rrew, "rewards ring", shape=(S_, self.n_envs), dtypes=("int8",))
+        self._check(rterm, "terminals ring", shape=(S_, self.n_envs), dtypes=("bool", "uint8"))
+        sd = None
+        if slice_dev is not None:
+            sd = ctypes.c_void_p(self._check(slice_dev, "slice_dev", numel=1, dtypes=("int64",)).data_ptr())
+        ptr = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
+        self._version += 1
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_step_store(self._h.ptr, ptr(actions), 0 if write_boards else _lib.F_NO_BOARDS, int(bool(cheat)),
+                                           int(slice_index), sd, S_, ptr(succ), ptr(ract), ptr(rrew), ptr(rterm)))
+        self._sync_lib_to_torch()
+        return self._step_outputs()
+
+    def reset_done_store(self, states_ring, slice_index, slice_dev=None, write_boards=True):
+        """reset_done() and ReplayBuffer.add's first half for the NEXT step in ONE launch (sgk_reset_done_store): after the reset every
+        env's board goes into slice `slice_index` (+ *slice_dev, modulo the ring) of states_ring int8 [S, N, cells]."""
+        S_ = int(states_ring.shape[0])
+        self._check(states_ring, "states ring", shape=(S_, self.n_envs, self.n_cells), dtypes=("int8",))
+        sd = None
+        if slice_dev is not None:
+            sd = ctypes.c_void_p(self._check(slice_dev, "slice_dev", numel=1, dtypes=("int64",)).data_ptr())
+        self._version += 1
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_reset_done_store(self._h.ptr, 0 if write_boards else _lib.F_NO_BOARDS, int(slice_index), sd, S_,
+                                                 ctypes.c_void_p(states_ring.data_ptr())))
+        self._sync_lib_to_torch()
+        return self.boards()
 
     def step_random(self, n_steps=1, auto_reset=True, fused=False, write_boards=True):
         """n_steps lockstep steps with RandomAgent-style actions from the counter RNG (no torch sync: pure library work).
@@ -438,6 +481,7 @@ class BatchedGridworldEnv:
         only; fused="stream": ONE launch with every step's boards and records materialised (rollout_random_stream)."""
         self._follow()
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (0 if write_boards else _lib.F_NO_BOARDS)
+        self._version += 1
         if fused == "stream":
             _lib.check(self.lib.sgk_rollout_random_stream(self._h.ptr, int(n_steps), flags, None, None, 1, 0))
             return self._step_outputs()
@@ -468,6 +512,7 @@ class BatchedGridworldEnv:
         ptr = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())  # noqa: E731
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_RING_TILE_MAJOR if layout == "tile" else 0)
         self._sync_torch_to_lib()
+        self._version += 1
         _lib.check(self.lib.sgk_rollout_random_stream(self._h.ptr, int(n_steps), flags, ptr(boards), ptr(recs), ring, int(first_slice)))
         self._sync_lib_to_torch()
         return self._step_outputs()
@@ -653,6 +698,7 @@ class BatchedGridworldEnv:
             return ctypes.c_void_p(self._check(t, what, shape=shape, dtypes=(dtype,)).data_ptr())
 
         n = self.n_envs
+        self._version += 1
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_policy_rollout(
             self._h.ptr, ctypes.byref(w), {"greedy": 0, "sample": 1}[mode], float(epsilon), int(draw_index0), int(n_steps),
@@ -693,6 +739,7 @@ class BatchedGridworldEnv:
 
     def account_steps(self, n_steps):
         """After replaying an external graph that contains step() launches: advance the host-side counters."""
+        self._version += 1
         _lib.check(self.lib.sgk_account_steps(self._h.ptr, int(n_steps)))
 
     def obs_f32(self, out=None):

@@ -219,8 +219,8 @@ def test_bench_config_objects_carry_their_own_roofline_and_cpu_baseline(k):
         w = d["with_learning"]
         assert w["value"] == d["value_with_learning"] == max(w["eager_value"], w["graph_value"]) > 0
         b = w["breakdown_us"]
-        assert set(b) == {"replay_store_states", "forward_and_act_explore", "env_step_and_reset_done", "replay_store_successors", "sgd_step"}
-        assert abs(w["breakdown_device_sum_us"] - sum(b.values())) < 1e-6 and abs(w["acting_us"] + w["replay_store_us"] + w["sgd_us"] - sum(b.values())) < 1e-6
+        assert set(b) == {"forward_and_act_explore", "env_step_store_and_reset_done_store", "sgd_step"}
+        assert abs(w["breakdown_device_sum_us"] - sum(b.values())) < 1e-6 and abs(w["acting_and_replay_store_us"] + w["sgd_us"] - sum(b.values())) < 1e-6
         c = d["conv_q_body_non_parity"]
         assert c["parity"].startswith("none") and c["acting"]["value"] > 0 and c["acting_plus_sgd"]["value"] > 0
     cb = d["cpu_baseline"]

@@ -487,3 +487,66 @@ def test_conv_q_body_option_shapes_env_parity_and_learning_on_boat_race():
     greedy = S.BatchMetrics(env.metrics()).meter("returns")["avg"]
     assert greedy > -40.0, greedy  # a random walk averages about -62 observed return per 100-step episode
     env.close()
+
+
+@pytest.mark.parametrize("cheat", [False, True], ids=["plain", "cheat"])
+@pytest.mark.parametrize("layout", ["compact", "pitched"])
+@pytest.mark.parametrize("name,n", [("SideEffectsSokoban-v0", 1), ("BoatRace-v0", 600), ("WhiskyGold-v0", 4133), ("IslandNavigation-v0", 70000),
+                                    ("TomatoWatering-v0", 1000), ("FriendFoe-v0", 777)])
+def test_fused_step_store_and_reset_store_equal_the_separate_launches(name, n, layout, cheat):
+    """sgk_step_store (= sgk_step + sgk_replay_store phase 1) and sgk_reset_done_store (= sgk_reset_done + phase 0 for the next step)
+    against the launches they fuse, slice by slice over a wrapping 5-slice ring: the rings, the env's own boards / records / state words
+    and the metrics are identical; with the slice read from device memory (graph form) too. Sizes: one env, ragged last tiles, both
+    forms of the step kernel (one wave per workgroup up to 65 536 envs, grid-stride above)."""
+    import torch
+
+    S_, steps, seed = 5, 23, 19
+    dev = "cuda"
+    envs = [S.BatchedGridworldEnv(name, n, seed=seed, layout=layout) for _ in range(3)]
+    reps = [S.DeviceReplay(n, e.n_cells, S_, dev) for e in envs]
+    for r in reps:
+        for t in (r.states, r.successors, r.actions, r.rewards):
+            t.fill_(-7 if t.dtype == torch.int8 else 9)
+        r.terminals.fill_(False)
+    sep, fus, cap = zip(envs, reps)
+    g = torch.Generator(device=dev).manual_seed(3)
+    try:
+        for k in range(steps):
+            acts = torch.randint(0, 4, (n,), device=dev, generator=g).to(torch.uint8)
+            # the separate launches
+            e, r = sep
+            r.store(e, 0)
+            e.step(acts, auto_reset=False)
+            r.store(e, 1, acts, cheat)
+            e.reset_done()
+            # fused, slice index from the host
+            e, r = fus
+            if not r.states_ready(e):
+                assert k == 0
+                r.store(e, 0)
+            r.step_store(e, acts, cheat)
+            r.reset_store(e)
+            # fused, slice index read by the launch from device memory
+            e, r = cap
+            if k == 0:
+                r.head_dev.fill_(r.head)
+                r.store(e, 0, captured=True)
+            r.step_store(e, acts, cheat, captured=True)
+            r.head_dev.add_(1).remainder_(S_)
+            r.note_replayed_add()
+            r.reset_store(e, captured=True)
+        ref_e, ref_r = sep
+        # (the fused forms have already written the NEXT transition's states into slice `head`: the separate form has not yet)
+        ref_r.store(ref_e, 0)
+        for e, r in (fus, cap):
+            for what in ("states", "successors", "actions", "rewards", "terminals"):
+                a, b = getattr(ref_r, what).cpu().numpy(), getattr(r, what).cpu().numpy()
+                assert (a == b).all(), (what, np.argwhere(a != b)[:3].tolist())
+            assert r.head == ref_r.head and r.filled == ref_r.filled == S_
+            assert (e.boards_host() == ref_e.boards_host()).all() and (e.step_records_host() == ref_e.step_records_host()).all()
+            st, st0 = e.episode_state_host(), ref_e.episode_state_host()
+            assert all((st[k2] == st0[k2]).all() for k2 in st)
+            assert (e.metrics() == ref_e.metrics()).all() and e.lockstep_t == ref_e.lockstep_t
+    finally:
+        for e in envs:
+            e.close()

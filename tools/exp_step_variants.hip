@@ -162,7 +162,7 @@ static void run_product(const char *label, StepArgs a, hipStream_t st, uint64_t 
   for (int i = 0; i < chain; ++i) {
     a.t = (uint64_t)i;
     a.t_ptr = t_dev;
-    hipLaunchKernelGGL((sgk::step_kernel<ENV, SGK_LAYOUT_COMPACT, true, SMALL>), dim3(grid), dim3(wgt), 0, st, a);
+    hipLaunchKernelGGL((sgk::step_kernel<ENV, SGK_LAYOUT_COMPACT, true, SMALL>), dim3(grid), dim3(wgt), 0, st, a, sgk::StepStore{});
   }
   hipLaunchKernelGGL(bump_counter, dim3(1), dim3(1), 0, st, t_dev, (uint64_t)chain);
   CK(hipStreamEndCapture(st, &g));
