@@ -587,17 +587,24 @@ def run_config(args):
                                  "note": "useful multiply-adds only (the kernel pads the hidden width to MFMA tiles)"},
                     "with_learning": with_learning})
         dq = None
-        # the conv Q-body (policy_cnn.py:17-81's trunk with a Q head; PyTorch / MIOpen): NOT the reference's deep-q, no parity claim
+        # the conv Q-body (policy_cnn.py:17-81's trunk with a Q head): NOT the reference's deep-q, no parity claim. Acting: the forward +
+        # act_explore in one hand-written kernel (sgk_convq_act, im2col GEMMs on fp32 MFMA); the torch / MIOpen composition timed beside it
         try:
             cq = S.BatchedDeepQAgent(env, dargs, sgd_steps=1, replay_slices=8, q_body="cnn")
             cq.warmup(8)
             dt_cnn_act = wall(lambda: cq.step(learn=False), 100, warm=10)
             dt_cnn_learn = wall(lambda: cq.step(learn=True), 100, warm=10)
-            cnn = {"q_body": "cnn", "parity": "none (not the reference's DeepQAgent)", "n_channels": cq.n_channels,
+            dt_cnn_kernel = wall(lambda: cq.act_explore(), 100, warm=10)
+            C, cells = cq.n_channels, env.n_cells
+            conv_flops = 2.0 * cells * (9 * C + 2 * 9 * C * C + C + 4 * C)  # multiply-adds x 2 per board: L1, L2 + head, 1x1, linear
+            cnn = {"q_body": "cnn", "parity": "none (not the reference's DeepQAgent)", "n_channels": C, "fused_kernel": bool(cq.fused_conv),
                    "acting": {"us_per_lockstep_step": dt_cnn_act * 1e6, "value": n / dt_cnn_act,
-                              "how": "eager: obs cast, torch conv forward on all 32 768 boards, sgk_epsilon_greedy, sgk_step, reset_done"},
+                              "how": "eager, three launches: sgk_convq_act (conv forward + act_explore), sgk_step, sgk_reset_done",
+                              "forward_and_act_explore_us": dt_cnn_kernel * 1e6, "useful_flops_per_board": conv_flops,
+                              "forward_tflops": n * conv_flops / dt_cnn_kernel / 1e12},
                    "acting_plus_sgd": {"us_per_lockstep_step": dt_cnn_learn * 1e6, "value": n / dt_cnn_learn,
-                                       "how": "the same + two replay stores + one torch autograd SGD step (batch 64, Adam amsgrad fused)"}}
+                                       "how": "the same with the replay add fused into step / reset + one torch autograd SGD step (batch 64, Adam "
+                                              "amsgrad fused)"}}
             try:
                 cq.enable_graphs(learn=False)
                 dt_cnn_act_g = wall(lambda: cq.step_graphed(learn=False), 100, warm=10)
@@ -605,6 +612,19 @@ def run_config(args):
                 cnn["acting"]["graph_value"] = n / dt_cnn_act_g
             except Exception as exc:  # noqa: BLE001 -- a labelled extra: its failure must not cost the config's line
                 cnn["acting"]["graph_error"] = repr(exc)[:200]
+            cq = None
+            try:
+                tq = S.BatchedDeepQAgent(env, dargs, sgd_steps=1, replay_slices=8, q_body="cnn", fused_conv=False)
+                dt_t = wall(lambda: tq.step(learn=False), 100, warm=10)
+                cnn["acting_torch_composition"] = {
+                    "us_per_lockstep_step": dt_t * 1e6, "value": n / dt_t,
+                    "how": "eager: obs cast, torch / MIOpen conv forward on all boards, sgk_epsilon_greedy, sgk_step, reset_done"}
+                tq.enable_graphs(learn=False)
+                dt_tg = wall(lambda: tq.step_graphed(learn=False), 100, warm=10)
+                cnn["acting_torch_composition"]["graph_us_per_lockstep_step"] = dt_tg * 1e6
+                tq = None
+            except Exception as exc:  # noqa: BLE001
+                cnn["acting_torch_composition"] = {"error": repr(exc)[:200]}
             out["conv_q_body_non_parity"] = cnn
             cq = None
         except Exception as exc:  # noqa: BLE001

@@ -847,6 +847,21 @@ int sgk_replay_store(sgk_env *h, int32_t phase, const uint8_t *actions_dev, int3
   return SGK_OK;
 } SGK_CATCH_STATUS
 
+int sgk_convq_act(sgk_env *h, const sgk_convq_weights *w, double epsilon, uint64_t draw_index, const double *epsilon_dev,
+                  const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev) try {
+  SGK_CHECK_HANDLE(h);
+  if (!w || !actions_out_dev || !w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->wb || !w->bb || !w->wh || !w->bh || !w->wl || !w->bl)
+    return fail(SGK_ERR_INVALID, "NULL argument");
+  if (w->n_layers != 2) return fail(SGK_ERR_INVALID, "sgk_convq_act is built for n_layers == 2 (two 3 x 3 convolutions in the trunk)");
+  if (w->n_channels != 4 && w->n_channels != 5 && w->n_channels != 8)
+    return fail(SGK_ERR_INVALID, "sgk_convq_act is built for n_channels in {4, 5 (policy_cnn.py's default), 8}");
+  if (scores_out_dev && ((uintptr_t)scores_out_dev & 15u)) return fail(SGK_ERR_INVALID, "scores_out_dev must be 16-byte aligned");
+  sgk::ConvQWeights cw{w->w1, w->b1, w->w2, w->b2, w->wb, w->bb, w->wh, w->bh, w->wl, w->bl};
+  SGK_HIP(sgk::launch_convq_act(h->sh, cw, w->n_channels, actions_out_dev, scores_out_dev, epsilon, draw_index, epsilon_dev, draw_index_dev,
+                                h->stream));
+  return SGK_OK;
+} SGK_CATCH_STATUS
+
 int sgk_step_store(sgk_env *h, const uint8_t *actions_dev, uint32_t flags, int32_t cheat, int64_t slice, const int64_t *slice_dev,
                    int32_t ring_slices, int8_t *successors_ring, uint8_t *actions_ring, int8_t *rewards_ring, uint8_t *terminals_ring) try {
   SGK_CHECK_HANDLE(h);

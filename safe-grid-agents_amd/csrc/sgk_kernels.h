@@ -90,6 +90,16 @@ hipError_t launch_policy_rollout(const Shard &sh, int mode, const PolicyWeights 
                                  uint32_t flags, int8_t *states_out, uint8_t *actions_out, uint32_t *recs_out, hipStream_t st);
 hipError_t launch_eps_greedy(const Shard &sh, int mode, const float *scores, uint8_t *actions, double eps, uint64_t draw,
                              const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
+// the conv Q-body's forward + act_explore in one launch (sgk_convq.hip; a labelled NON-parity option: the reference's DeepQAgent is an MLP)
+struct ConvQWeights {
+  const float *w1, *b1;  // conv3x3 1 -> C   [C][1][3][3], [C]
+  const float *w2, *b2;  // conv3x3 C -> C   [C][C][3][3], [C]
+  const float *wb, *bb;  // conv1x1 1 -> C   [C][1][1][1], [C]   (the residual bottleneck)
+  const float *wh, *bh;  // conv3x3 C -> C   (head)
+  const float *wl, *bl;  // linear C*H*W -> 4   [4][C*H*W], [4]
+};
+hipError_t launch_convq_act(const Shard &sh, const ConvQWeights &w, int n_channels, uint8_t *actions, float *scores, double eps, uint64_t draw,
+                            const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
 // DeepQAgent.learn as one kernel (sgk_learn.hip); all pointers are device pointers
 struct DqnLearner {
   const int8_t *states, *successors;

@@ -52,6 +52,11 @@ class SgkMlpWeights(ctypes.Structure):
                 ("w3t", ctypes.c_void_p), ("b3", ctypes.c_void_p), ("n_hidden", ctypes.c_int32)]
 
 
+class SgkConvQWeights(ctypes.Structure):
+    _fields_ = ([(k, ctypes.c_void_p) for k in ("w1", "b1", "w2", "b2", "wb", "bb", "wh", "bh", "wl", "bl")]
+                + [("n_channels", ctypes.c_int32), ("n_layers", ctypes.c_int32)])
+
+
 class SgkDqnLearner(ctypes.Structure):
     _V6 = ctypes.c_void_p * 6
     _fields_ = ([(k, ctypes.c_void_p) for k in ("states", "successors", "actions", "rewards", "terminals")]
@@ -133,6 +138,7 @@ _SIGNATURES = {
     "sgk_epsilon_greedy_ex": (ctypes.c_int, [_V, _V, ctypes.c_double, ctypes.c_uint64, _V, _V, _V]),
     "sgk_policy_act": (ctypes.c_int, [_V, ctypes.POINTER(SgkMlpWeights), ctypes.c_double, ctypes.c_uint64, _V, _V, _V, _V]),
     "sgk_dqn_sgd_step": (ctypes.c_int, [_V, ctypes.POINTER(SgkDqnLearner)]),
+    "sgk_convq_act": (ctypes.c_int, [_V, ctypes.POINTER(SgkConvQWeights), ctypes.c_double, ctypes.c_uint64, _V, _V, _V, _V]),
     "sgk_step_store": (ctypes.c_int, [_V, _V, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int64, _V, ctypes.c_int32, _V, _V, _V, _V]),
     "sgk_reset_done_store": (ctypes.c_int, [_V, ctypes.c_uint32, ctypes.c_int64, _V, ctypes.c_int32, _V]),
     "sgk_ppo_epochs": (ctypes.c_int, [_V, ctypes.POINTER(SgkPpoLearner)]),

@@ -147,7 +147,7 @@ class BatchedDeepQAgent:
     reads_boards = True  # acts on the materialised cells (batched_default_eval must keep writing them)
 
     def __init__(self, env, args, sgd_steps=1, replay_slices=8, fused_learn=True, q_body=None, reference_loss_broadcast=True,
-                 sync_target_at_start=False):
+                 sync_target_at_start=False, fused_conv=True):
         """reference_loss_broadcast: F.mse_loss on Qs [B,1] vs expected_Qs [B] as value.py:119-123 writes it (False: squeezed, the
         textbook per-sample loss -- NOT the reference). sync_target_at_start: copy Q into the target network in the constructor
         (NOT the reference: value.py:82-84 initialises the two networks independently)."""
@@ -190,6 +190,15 @@ class BatchedDeepQAgent:
                         "w2": l2.weight.data, "b2": l2.bias.data, "w3t": torch.empty((n_hidden, 4), device=self.device),
                         "b3": l3.bias.data}
             self._fw_stale = True
+        # the conv body's forward + act_explore as ONE kernel (sgk_convq_act; the kernel reads torch's parameters in place)
+        self.fused_conv = (fused_conv and self.q_body == "cnn" and n_layers == 2 and self.n_channels in (4, 5, 8) and self.action_n == 4
+                           and (int(env.H), int(env.W)) in ((5, 5), (6, 5), (6, 6), (6, 8), (7, 7), (7, 8), (7, 9)))
+        if self.fused_conv:
+            q = self.Q
+            self._cw = {"w1": q.network[0][0].weight.data, "b1": q.network[0][0].bias.data, "w2": q.network[1][0].weight.data,
+                        "b2": q.network[1][0].bias.data, "wb": q.bottleneck.weight.data, "bb": q.bottleneck.bias.data,
+                        "wh": q.head_cnn[0].weight.data, "bh": q.head_cnn[0].bias.data, "wl": q.head_linear.weight.data,
+                        "bl": q.head_linear.bias.data}
         # DeepQAgent.learn as ONE kernel (sgk_dqn_sgd_step: sampling, both forwards, TD target, backward, grad clip, Adam
         # amsgrad) for the two-layer topology with up to 128 units and minibatches up to 64; else torch autograd + Adam
         lds_need = 4 * (4 * 64 * n_hidden + n_hidden * n_hidden + 12 * n_hidden + 872) + 128 * ((env.n_cells + 3) & ~3) + 64
@@ -305,6 +314,8 @@ class BatchedDeepQAgent:
             if self._fw_stale:
                 self._refresh_fused_weights()
             return self.env.policy_act(self._fw, 0.0, self.t, out=self._actions)
+        if self.fused_conv and obs is None:
+            return self._conv_act(0.0, self.t)
         return self.scores(obs).argmax(1).to(self.torch.uint8)
 
     def act_explore(self, obs=None):
@@ -315,6 +326,8 @@ class BatchedDeepQAgent:
             if self._fw_stale:
                 self._refresh_fused_weights()
             return self.env.policy_act(self._fw, self.epsilon, self.t, out=self._actions)
+        if self.fused_conv and obs is None:
+            return self._conv_act(self.epsilon, self.t)
         scores = self.scores(obs)
         if self.action_n == 4:
             return self.env.epsilon_greedy(scores, self.epsilon, self.t, out=self._actions)
@@ -323,6 +336,9 @@ class BatchedDeepQAgent:
         explore = torch.rand(n, device=self.device) < self.epsilon
         rand_a = torch.randint(0, self.action_n, (n,), device=self.device)
         return torch.where(explore, rand_a, greedy).to(torch.uint8)
+
+    def _conv_act(self, epsilon, draw_index, scores_out=None):
+        return self.env.convq_act(self._cw, epsilon, draw_index, self.n_channels, out=self._actions, scores_out=scores_out)
 
     def learn_batch(self):
         torch = self.torch
@@ -359,6 +375,8 @@ class BatchedDeepQAgent:
             if self._fw_stale:
                 self._refresh_fused_weights()
             actions = env.policy_act(self._fw, self.epsilon if explore else 0.0, self.t, out=self._actions)
+        elif self.fused_conv:
+            actions = self._conv_act(self.epsilon if explore else 0.0, self.t)
         else:
             env.obs_f32(self._obs)
             actions = self.act_explore(self._obs) if explore else self.act(self._obs)
@@ -393,6 +411,8 @@ class BatchedDeepQAgent:
             if (learn and not self.fused_learn) or self._fw_stale:
                 self._refresh_fused_weights()  # recorded in the learn graph: torch's update leaves the transposes behind
             actions = env.policy_act(self._fw, self._eps_dev, self._draw_dev, out=self._actions)
+        elif self.fused_conv:
+            actions = self._conv_act(self._eps_dev, self._draw_dev)
         elif self.action_n == 4:
             env.obs_f32(self._obs)
             with torch.no_grad():

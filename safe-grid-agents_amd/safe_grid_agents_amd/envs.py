@@ -58,6 +58,8 @@ ENV_MAP = {
     "trans-boat": "TransitionBoatRace-v0",
 }
 
+_TORCH = [None]   # the torch module, once imported (envs.py itself imports without it)
+_DTYPES = {}      # tuple of dtype names -> frozenset of torch dtypes (BatchedGridworldEnv._check)
 _TYPESTR = {"int8": "|i1", "uint8": "|u1", "int32": "<i4", "int64": "<i8", "float64": "<f8", "uint32": "<u4"}
 
 
@@ -316,16 +318,26 @@ class BatchedGridworldEnv:
 
     def _check(self, t, what, numel=None, shape=None, dtypes=None, contiguous=True):
         """A tensor argument that a kernel will read or write through its raw pointer: on THIS device, of the expected dtype and
-        size, dense. ValueError otherwise (not assert: `python -O` must not turn a wrong tensor into a wild pointer)."""
-        import torch
+        size, dense. ValueError otherwise (not assert: `python -O` must not turn a wrong tensor into a wild pointer). On the per-step
+        path this runs several times per lockstep step: the passing case is a handful of attribute reads (dtype names are resolved
+        to torch dtypes once)."""
+        torch = _TORCH[0]
+        if torch is None:
+            import torch
 
+            _TORCH[0] = torch
         if not isinstance(t, torch.Tensor):
             raise ValueError("%s must be a torch tensor on cuda:%d, not %s" % (what, self.device, type(t).__name__))
-        if not t.is_cuda or t.device.index != self.device:
+        dev = t.device
+        if dev.type != "cuda" or dev.index != self.device:
             raise ValueError("%s lives on %s; this env's kernels run on cuda:%d" % (what, t.device, self.device))
-        if dtypes is not None and str(t.dtype).replace("torch.", "") not in dtypes:
-            raise ValueError("%s has dtype %s, expected %s" % (what, t.dtype, " or ".join(dtypes)))
-        if shape is not None and tuple(t.shape) != tuple(shape):
+        if dtypes is not None:
+            allowed = _DTYPES.get(dtypes)
+            if allowed is None:
+                allowed = _DTYPES[dtypes] = frozenset(getattr(torch, d) for d in dtypes)
+            if t.dtype not in allowed:
+                raise ValueError("%s has dtype %s, expected %s" % (what, t.dtype, " or ".join(dtypes)))
+        if shape is not None and t.shape != shape and tuple(t.shape) != tuple(shape):
             raise ValueError("%s has shape %s, expected %s" % (what, tuple(t.shape), tuple(shape)))
         if numel is not None and t.numel() != numel:
             raise ValueError("%s has %d elements, expected %d" % (what, t.numel(), numel))
@@ -336,15 +348,20 @@ class BatchedGridworldEnv:
     def _actions_arg(self, actions):
         """uint8 [N] on this device from what the caller passed: a host array / list is uploaded, an integer tensor of another
         width is narrowed (argmax gives int64), everything else is a ValueError."""
-        import torch
+        torch = _TORCH[0]
+        if torch is None:
+            import torch
 
+            _TORCH[0] = torch
         if not isinstance(actions, torch.Tensor):
             actions = torch.as_tensor(np.asarray(actions, dtype=np.uint8), device="cuda:%d" % self.device)
         if actions.dtype != torch.uint8:
             if actions.dtype.is_floating_point or actions.dtype.is_complex or actions.dtype == torch.bool:
                 raise ValueError("actions have dtype %s, expected uint8 (or another integer type)" % actions.dtype)
             actions = actions.to(torch.uint8)
-        return self._check(actions.contiguous(), "actions", numel=self.n_envs, dtypes=("uint8",))
+        if not actions.is_contiguous():
+            actions = actions.contiguous()
+        return self._check(actions, "actions", numel=self.n_envs, dtypes=("uint8",), contiguous=False)
 
     def _weights_arg(self, weights):
         """sgk_mlp_weights from the dict of float32 device tensors w1t [cells, H], b1 [H], w2 [H, H], b2 [H], w3t [H, 4], b3 [4]."""
@@ -649,6 +666,31 @@ class BatchedGridworldEnv:
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_policy_act(self._h.ptr, ctypes.byref(w), float(epsilon), int(draw_index), eps_p, draw_p,
                                            ctypes.c_void_p(out.data_ptr()), sp))
+        self._sync_lib_to_torch()
+        return out
+
+    def convq_act(self, weights, epsilon, draw_index, n_channels, n_layers=2, out=None, scores_out=None):
+        """The conv Q-body's forward on every env's board + act_explore in ONE launch (sgk_convq_act; a labelled non-parity option:
+        the reference's DeepQAgent is an MLP). `weights`: dict of contiguous float32 device tensors in torch's layouts -- w1 [C,1,3,3],
+        b1, w2 [C,C,3,3], b2, wb [C,1,1,1], bb, wh [C,C,3,3], bh, wl [4, C * cells], bl. epsilon / draw_index: scalars or 1-element
+        device tensors (float64 / int64)."""
+        C = int(n_channels)
+        shapes = {"w1": (C, 1, 3, 3), "b1": (C,), "w2": (C, C, 3, 3), "b2": (C,), "wb": (C, 1, 1, 1), "bb": (C,), "wh": (C, C, 3, 3),
+                  "bh": (C,), "wl": (4, C * self.n_cells), "bl": (4,)}
+        for k, shape in shapes.items():
+            if k not in weights:
+                raise ValueError("weights lack %r" % k)
+            self._check(weights[k], "weights[%r]" % k, shape=shape, dtypes=("float32",))
+        w = _lib.SgkConvQWeights(*(ctypes.c_void_p(weights[k].data_ptr()) for k in ("w1", "b1", "w2", "b2", "wb", "bb", "wh", "bh", "wl", "bl")),
+                                 C, int(n_layers))
+        out = self._out_actions(out)
+        eps_p, epsilon = self._scalar_arg(epsilon, "epsilon", "float64")
+        draw_p, draw_index = self._scalar_arg(draw_index, "draw_index", "int64")
+        sp = None if scores_out is None else ctypes.c_void_p(self._check(scores_out, "scores_out", shape=(self.n_envs, 4),
+                                                                         dtypes=("float32",)).data_ptr())
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_convq_act(self._h.ptr, ctypes.byref(w), float(epsilon), int(draw_index), eps_p, draw_p,
+                                          ctypes.c_void_p(out.data_ptr()), sp))
         self._sync_lib_to_torch()
         return out
 

@@ -1,0 +1,115 @@
+"""sgk_convq_act: the conv Q-body's forward + act_explore in one launch (a labelled NON-PARITY option: the reference's DeepQAgent is an
+MLP, value.py:148-158; the body is policy_cnn.py:17-81's with a Q head). Floating point, another summation order than MIOpen / rocBLAS:
+scores agree with the torch module on the same weights to rtol 1e-4 / atol 2e-5; the draw on top of the kernel's own scores is integer
+work and bit-exact against sgk_epsilon_greedy (itself pinned to the oracle in test_gpu_deepq.py)."""
+import types
+
+import numpy as np
+import pytest
+
+import safe_grid_agents_amd as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(**kw):
+    d = dict(discount=0.99, lr=1e-3, batch_size=64, sync_every=20, epsilon=0.05, epsilon_anneal=200, n_layers=2, n_hidden=100)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def _agent(name, n, channels, layout="compact", seed=5, **kw):
+    import torch
+
+    torch.manual_seed(seed)
+    env = S.BatchedGridworldEnv(name, n, seed=seed, layout=layout)
+    env.step_random(17, auto_reset=True)  # boards in every phase of an episode
+    agent = S.BatchedDeepQAgent(env, _args(n_channels=channels), q_body="cnn", **kw)
+    with torch.no_grad():  # biases away from their tiny default range, so that a dropped bias shows
+        for p in agent.Q.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.3, 0.3)
+    return env, agent
+
+
+@pytest.mark.parametrize("layout", ["compact", "pitched"])
+@pytest.mark.parametrize("channels", [4, 5, 8])
+@pytest.mark.parametrize("name,n", [("BoatRace-v0", 1), ("BoatRace-v0", 1000), ("SideEffectsSokoban-v0", 4133), ("IslandNavigation-v0", 600),
+                                    ("DistributionalShift-v0", 257), ("WhiskyGold-v0", 48), ("AbsentSupervisor-v0", 333),
+                                    ("ConveyorBelt-v0", 100), ("TomatoWatering-v0", 90), ("FriendFoe-v0", 500)])
+def test_convq_scores_match_the_torch_module_and_the_draw_is_epsilon_greedy_on_them(name, n, channels, layout):
+    import torch
+
+    env, agent = _agent(name, n, channels, layout)
+    assert agent.fused_conv
+    want = agent.scores().cpu().numpy()
+    got_t = torch.empty((n, 4), dtype=torch.float32, device=agent.device)
+    greedy = agent._conv_act(0.0, 7, scores_out=got_t).clone()
+    torch.cuda.synchronize()
+    got = got_t.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5)
+    # greedy = argmax of the kernel's own scores (first maximum, as torch.argmax and the reference's max(1) break ties)
+    assert (greedy.cpu().numpy() == got.argmax(1)).all()
+    for eps, t in ((0.3, 11), (1.0, 0), (0.05, 123456789)):
+        a = agent._conv_act(eps, t).clone()
+        b = env.epsilon_greedy(got_t, eps, t)
+        assert (a.cpu().numpy() == b.cpu().numpy()).all(), (eps, t)
+    # device-resident epsilon / draw index (the graph form)
+    eps_dev = torch.tensor([0.3], dtype=torch.float64, device=agent.device)
+    draw_dev = torch.tensor([11], dtype=torch.int64, device=agent.device)
+    a = agent._conv_act(eps_dev, draw_dev).clone()
+    assert (a.cpu().numpy() == env.epsilon_greedy(got_t, 0.3, 11).cpu().numpy()).all()
+    env.close()
+
+
+def test_convq_step_and_graph_take_the_actions_of_the_torch_composition():
+    """agent.step() / step_graphed() with the fused conv kernel against the same agent driven through torch's conv + sgk_epsilon_greedy:
+    the same boards after 40 lockstep steps wherever the two score sets order the actions identically (greedy ties within fp32 rounding
+    are possible in principle: the test asks for >= 99.9 % identical envs and exact equality on a seed where there is none)."""
+    import torch
+
+    n = 2048
+    env_a, fused = _agent("SideEffectsSokoban-v0", n, 5)
+    env_b, plain = _agent("SideEffectsSokoban-v0", n, 5, fused_conv=False)
+    assert fused.fused_conv and not plain.fused_conv
+    plain.Q.load_state_dict(fused.Q.state_dict())
+    fused.enable_graphs(learn=False)  # (its warm-up iterations step the envs: both batches start from a reset below)
+    env_a.reset()
+    env_b.reset()
+    assert (env_a.boards().cpu().numpy() == env_b.boards().cpu().numpy()).all()
+    for k in range(40):
+        fused.step(learn=False)
+        plain.step(learn=False)
+    same = (env_a.boards().cpu().numpy() == env_b.boards().cpu().numpy()).reshape(n, -1).all(axis=1)
+    assert same.mean() >= 0.999, same.mean()
+    for k in range(10):
+        fused.step_graphed(learn=False)
+        plain.step(learn=False)
+    torch.cuda.synchronize()
+    same = (env_a.boards().cpu().numpy() == env_b.boards().cpu().numpy()).reshape(n, -1).all(axis=1)
+    assert same.mean() >= 0.999, same.mean()
+    assert fused.t == plain.t == 50
+    env_a.close()
+    env_b.close()
+
+
+def test_convq_act_refuses_what_it_is_not_built_for():
+    import torch
+
+    env, agent = _agent("BoatRace-v0", 64, 5)
+    w = dict(agent._cw)
+    with pytest.raises(ValueError):
+        env.convq_act({k: v for k, v in w.items() if k != "wl"}, 0.0, 0, 5)
+    with pytest.raises(ValueError):
+        env.convq_act({**w, "w2": w["w2"].double()}, 0.0, 0, 5)
+    with pytest.raises(ValueError):
+        env.convq_act({**w, "wl": w["wl"][:, :-1].contiguous()}, 0.0, 0, 5)
+    with pytest.raises(RuntimeError):
+        env.convq_act(w, 0.0, 0, 5, n_layers=3)
+    six = {k: torch.zeros((6,) + tuple(v.shape[1:]) if v.dim() > 1 and k != "wl" else ((4, 6 * 25) if k == "wl" else (6,) if k != "bl" else (4,)),
+                          device=v.device) for k, v in w.items()}
+    six["w2"] = torch.zeros((6, 6, 3, 3), device=agent.device)
+    six["wh"] = torch.zeros((6, 6, 3, 3), device=agent.device)
+    with pytest.raises(RuntimeError):
+        env.convq_act(six, 0.0, 0, 6)
+    env.close()
