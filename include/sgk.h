@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SGK_ABI_VERSION 4 /* 3: the tabular-Q tables in HBM are state-major (sgk_tabq_table_dev); 4: sgk_tabq_step, sgk_step_store, sgk_reset_done_store, sgk_convq_act, sgk_dqn_learner's
+#define SGK_ABI_VERSION 4 /* 3: the tabular-Q tables in HBM are state-major (sgk_tabq_table_dev); 4: sgk_tabq_step, sgk_step_store, sgk_reset_done_store, sgk_convq_act, sgk_convq_sample, sgk_dqn_learner's
                              loss_mode / rows / rows_out, SGK_F_SEPARATE_LAUNCHES, the sgk_debug_* hooks are off unless asked for */
 
 #if defined(__GNUC__)
@@ -389,22 +389,28 @@ SGK_API int sgk_policy_act(sgk_env *h, const sgk_mlp_weights *w, double epsilon,
                            const double *epsilon_dev, const uint64_t *draw_index_dev, uint8_t *actions_out_dev,
                            float *scores_out_dev);
 
-/* ---- a convolutional Q-body (NOT the reference's DeepQAgent, which is an MLP: value.py:148-158) -------------------------------- */
-/* BASELINE.json words config 4 as "conv policy"; the batched agent therefore offers, as a labelled non-parity option, the body of the
- * reference's PPO-CNN (policy_cnn.py:17-81) with a Q head:
- *     trunk = relu(conv3x3(relu(conv3x3(x, 1 -> C)), C -> C)) + conv1x1(x, 1 -> C);   Q = linear(flatten(relu(conv3x3(trunk, C -> C))), 4)
- * sgk_convq_act: that forward on every env's board AND act_explore on the four scores (sgk_epsilon_greedy's draw: Philox stream 2) in
- * one launch -- im2col GEMMs on fp32 MFMA over zero-bordered activation planes in LDS. Weights in torch's layouts, float32, device:
- *   w1 [C][1][3][3], w2 / wh [C][C][3][3], wb [C][1][1][1], wl [4][C * n_cells]; biases b1 b2 bb bh [C], bl [4].
- * n_channels in {4, 5 (policy_cnn's default), 8}, n_layers == 2 (two 3 x 3 convolutions in the trunk). epsilon / draw_index as in
- * sgk_epsilon_greedy_ex. scores_out_dev: float32 [n_envs][4], 16-byte aligned, or NULL. Scores agree with the torch module to fp32
- * tolerance (another summation order than MIOpen / rocBLAS). */
+/* ---- the reference's convolutional body (PPOCNNAgent, policy_cnn.py:17-81) with a four-way head, forward + draw in one launch ------ */
+/*     trunk = relu(conv3x3(relu(conv3x3(x, 1 -> C)), C -> C)) + conv1x1(x, 1 -> C)                    policy_cnn.py:19-44, 70
+ *     out   = linear(flatten(relu(conv3x3(trunk, C -> C))), C * n_cells -> 4)                         policy_cnn.py:46-55, 72-74
+ * on every env's board -- im2col GEMMs on fp32 MFMA over zero-bordered activation planes in LDS -- and then one of two draws:
+ *   sgk_convq_sample: PPOBaseAgent.act_explore (policy_base.py:54-64) of a PPOCNNAgent -- `out` are the ACTOR's logits (wh / bh =
+ *     actor_cnn, wl / bl = actor_linear; the critic head is not needed to act) and the action is Categorical(logits).sample(),
+ *     sgk_categorical_sample's draw (Philox stream 3). This is the reference's ppo-cnn gather_rollout step (policy_base.py:145).
+ *   sgk_convq_act: DeepQAgent.act_explore's epsilon-greedy draw (sgk_epsilon_greedy's: Philox stream 2) on `out` as four Q-values. The
+ *     reference's DeepQAgent is an MLP (value.py:148-158): a Q-network of this shape is the batched agent's labelled NON-PARITY
+ *     option (BASELINE.json words config 4 as "conv policy"). epsilon / draw_index as in sgk_epsilon_greedy_ex.
+ * Weights in torch's layouts, float32, device: w1 [C][1][3][3], w2 / wh [C][C][3][3], wb [C][1][1][1], wl [4][C * n_cells]; biases
+ * b1 b2 bb bh [C], bl [4]. n_channels in {4, 5 (the reference's default, agent_parser_configs.yaml:107-111), 8}, n_layers == 2 (the
+ * reference's default: two 3 x 3 convolutions in the trunk). scores_out_dev / logits_out_dev: float32 [n_envs][4], 16-byte aligned, or
+ * NULL. The outputs agree with the torch module to fp32 tolerance (another summation order than MIOpen / rocBLAS). */
 typedef struct sgk_convq_weights {
   const float *w1, *b1, *w2, *b2, *wb, *bb, *wh, *bh, *wl, *bl;
   int32_t n_channels, n_layers;
 } sgk_convq_weights;
 SGK_API int sgk_convq_act(sgk_env *h, const sgk_convq_weights *w, double epsilon, uint64_t draw_index, const double *epsilon_dev,
                           const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev);
+SGK_API int sgk_convq_sample(sgk_env *h, const sgk_convq_weights *w, uint64_t draw_index, const uint64_t *draw_index_dev,
+                             uint8_t *actions_out_dev, float *logits_out_dev);
 
 /* The two halves of the replay add FUSED into the launches around them (round 6; a lockstep step of dqn_learn -- learn.py:29-58 -- is
  * then sgk_policy_act, sgk_step_store, sgk_dqn_sgd_step, sgk_reset_done_store: four calls instead of six):

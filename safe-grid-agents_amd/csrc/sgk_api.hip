@@ -847,19 +847,29 @@ int sgk_replay_store(sgk_env *h, int32_t phase, const uint8_t *actions_dev, int3
   return SGK_OK;
 } SGK_CATCH_STATUS
 
-int sgk_convq_act(sgk_env *h, const sgk_convq_weights *w, double epsilon, uint64_t draw_index, const double *epsilon_dev,
-                  const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev) try {
+static int convq_launch(sgk_env *h, const sgk_convq_weights *w, int mode, double epsilon, uint64_t draw_index, const double *epsilon_dev,
+                        const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev) {
   SGK_CHECK_HANDLE(h);
   if (!w || !actions_out_dev || !w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->wb || !w->bb || !w->wh || !w->bh || !w->wl || !w->bl)
     return fail(SGK_ERR_INVALID, "NULL argument");
-  if (w->n_layers != 2) return fail(SGK_ERR_INVALID, "sgk_convq_act is built for n_layers == 2 (two 3 x 3 convolutions in the trunk)");
+  if (w->n_layers != 2) return fail(SGK_ERR_INVALID, "the fused conv body is built for n_layers == 2 (two 3 x 3 convolutions in the trunk)");
   if (w->n_channels != 4 && w->n_channels != 5 && w->n_channels != 8)
-    return fail(SGK_ERR_INVALID, "sgk_convq_act is built for n_channels in {4, 5 (policy_cnn.py's default), 8}");
-  if (scores_out_dev && ((uintptr_t)scores_out_dev & 15u)) return fail(SGK_ERR_INVALID, "scores_out_dev must be 16-byte aligned");
+    return fail(SGK_ERR_INVALID, "the fused conv body is built for n_channels in {4, 5 (policy_cnn.py's default), 8}");
+  if (scores_out_dev && ((uintptr_t)scores_out_dev & 15u)) return fail(SGK_ERR_INVALID, "the scores / logits output must be 16-byte aligned");
   sgk::ConvQWeights cw{w->w1, w->b1, w->w2, w->b2, w->wb, w->bb, w->wh, w->bh, w->wl, w->bl};
-  SGK_HIP(sgk::launch_convq_act(h->sh, cw, w->n_channels, actions_out_dev, scores_out_dev, epsilon, draw_index, epsilon_dev, draw_index_dev,
-                                h->stream));
+  SGK_HIP(sgk::launch_convq_act(h->sh, cw, w->n_channels, mode, actions_out_dev, scores_out_dev, epsilon, draw_index, epsilon_dev,
+                                draw_index_dev, h->stream));
   return SGK_OK;
+}
+
+int sgk_convq_act(sgk_env *h, const sgk_convq_weights *w, double epsilon, uint64_t draw_index, const double *epsilon_dev,
+                  const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev) try {
+  return convq_launch(h, w, 0, epsilon, draw_index, epsilon_dev, draw_index_dev, actions_out_dev, scores_out_dev);
+} SGK_CATCH_STATUS
+
+int sgk_convq_sample(sgk_env *h, const sgk_convq_weights *w, uint64_t draw_index, const uint64_t *draw_index_dev, uint8_t *actions_out_dev,
+                     float *logits_out_dev) try {
+  return convq_launch(h, w, 1, 0.0, draw_index, nullptr, draw_index_dev, actions_out_dev, logits_out_dev);
 } SGK_CATCH_STATUS
 
 int sgk_step_store(sgk_env *h, const uint8_t *actions_dev, uint32_t flags, int32_t cheat, int64_t slice, const int64_t *slice_dev,

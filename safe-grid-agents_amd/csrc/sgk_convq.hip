@@ -166,7 +166,7 @@ __global__ __launch_bounds__(CQ_WG, CQ_WAVES_FOR(C)) void convq_act_kernel(
     const int8_t *__restrict__ boards, int pitch, const float *__restrict__ w1r, const float *__restrict__ b1r, const float *__restrict__ w2r,
     const float *__restrict__ b2r, const float *__restrict__ wbr, const float *__restrict__ bbr, const float *__restrict__ whr,
     const float *__restrict__ bhr, const float *__restrict__ wlr, const float *__restrict__ blr, uint8_t *__restrict__ actions,
-    float *__restrict__ scores_out, int64_t n, double eps, uint64_t seed, uint64_t env_base, uint64_t draw,
+    float *__restrict__ scores_out, int64_t n, int mode, double eps, uint64_t seed, uint64_t env_base, uint64_t draw,
     const double *__restrict__ eps_ptr, const uint64_t *__restrict__ draw_ptr) {
   typedef ConvQGeom<HH, WW, C> G;
   extern __shared__ __attribute__((aligned(16))) unsigned char convq_smem[];
@@ -331,7 +331,9 @@ __global__ __launch_bounds__(CQ_WG, CQ_WAVES_FOR(C)) void convq_act_kernel(
         const float q0 = __shfl(tot, l0), q1 = __shfl(tot, l0 + 1), q2 = __shfl(tot, l0 + 2), q3 = __shfl(tot, l0 + 3);
         const int64_t env = env0 + e;
         if (live && a == 0 && env < n) {
-          actions[env] = (uint8_t)pick_action<0>(q0, q1, q2, q3, env_base + (uint64_t)env, draw, seed, eps);
+          // mode 0: DeepQAgent.act_explore's epsilon-greedy draw on four scores; mode 1: Categorical(logits).sample() (PPOCNNAgent)
+          actions[env] = (uint8_t)(mode == 0 ? pick_action<0>(q0, q1, q2, q3, env_base + (uint64_t)env, draw, seed, eps)
+                                             : pick_action<1>(q0, q1, q2, q3, env_base + (uint64_t)env, draw, seed, eps));
           if (scores_out) *reinterpret_cast<float4 *>(scores_out + 4 * env) = make_float4(q0, q1, q2, q3);
         }
       }
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(CQ_WG, CQ_WAVES_FOR(C)) void convq_act_kernel(
   }
 }
 
-hipError_t launch_convq_act(const Shard &sh, const ConvQWeights &w, int n_channels, uint8_t *actions, float *scores, double eps, uint64_t draw,
+hipError_t launch_convq_act(const Shard &sh, const ConvQWeights &w, int n_channels, int mode, uint8_t *actions, float *scores, double eps, uint64_t draw,
                             const double *eps_dev, const uint64_t *draw_dev, hipStream_t st) {
   (void)hipGetLastError();
   const int H = sh.rules_host.height, W = sh.rules_host.width;
@@ -359,7 +361,7 @@ hipError_t launch_convq_act(const Shard &sh, const ConvQWeights &w, int n_channe
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(CQ_WAVES_FOR(CV), (160u * 1024u) / lds));                                \
     const int grid = grid_for(n_pass, sh.n_cus * per_cu);                                                                  \
     convq_act_kernel<HV, WV, CV><<<dim3(grid), dim3(CQ_WG), lds, st>>>(sh.boards, sh.pitch, w.w1, w.b1, w.w2, w.b2, w.wb, w.bb, w.wh, w.bh, \
-                                                                       w.wl, w.bl, actions, scores, sh.n, eps, sh.seed,    \
+                                                                       w.wl, w.bl, actions, scores, sh.n, mode, eps, sh.seed, \
                                                                        sh.env_base, draw, eps_dev, draw_dev);              \
   } while (0)
 #define SGK_CONVQ_LAUNCH_C(HV, WV)                                                                                         \

@@ -98,7 +98,8 @@ struct ConvQWeights {
   const float *wh, *bh;  // conv3x3 C -> C   (head)
   const float *wl, *bl;  // linear C*H*W -> 4   [4][C*H*W], [4]
 };
-hipError_t launch_convq_act(const Shard &sh, const ConvQWeights &w, int n_channels, uint8_t *actions, float *scores, double eps, uint64_t draw,
+// mode 0: epsilon-greedy on the four scores (DeepQAgent.act_explore); 1: Categorical(logits = scores).sample() (PPOBaseAgent.act_explore)
+hipError_t launch_convq_act(const Shard &sh, const ConvQWeights &w, int n_channels, int mode, uint8_t *actions, float *scores, double eps, uint64_t draw,
                             const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
 // DeepQAgent.learn as one kernel (sgk_learn.hip); all pointers are device pointers
 struct DqnLearner {

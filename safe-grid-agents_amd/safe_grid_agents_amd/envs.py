@@ -669,11 +669,7 @@ class BatchedGridworldEnv:
         self._sync_lib_to_torch()
         return out
 
-    def convq_act(self, weights, epsilon, draw_index, n_channels, n_layers=2, out=None, scores_out=None):
-        """The conv Q-body's forward on every env's board + act_explore in ONE launch (sgk_convq_act; a labelled non-parity option:
-        the reference's DeepQAgent is an MLP). `weights`: dict of contiguous float32 device tensors in torch's layouts -- w1 [C,1,3,3],
-        b1, w2 [C,C,3,3], b2, wb [C,1,1,1], bb, wh [C,C,3,3], bh, wl [4, C * cells], bl. epsilon / draw_index: scalars or 1-element
-        device tensors (float64 / int64)."""
+    def _convq_weights(self, weights, n_channels, n_layers):
         C = int(n_channels)
         shapes = {"w1": (C, 1, 3, 3), "b1": (C,), "w2": (C, C, 3, 3), "b2": (C,), "wb": (C, 1, 1, 1), "bb": (C,), "wh": (C, C, 3, 3),
                   "bh": (C,), "wl": (4, C * self.n_cells), "bl": (4,)}
@@ -681,8 +677,15 @@ class BatchedGridworldEnv:
             if k not in weights:
                 raise ValueError("weights lack %r" % k)
             self._check(weights[k], "weights[%r]" % k, shape=shape, dtypes=("float32",))
-        w = _lib.SgkConvQWeights(*(ctypes.c_void_p(weights[k].data_ptr()) for k in ("w1", "b1", "w2", "b2", "wb", "bb", "wh", "bh", "wl", "bl")),
-                                 C, int(n_layers))
+        return _lib.SgkConvQWeights(*(ctypes.c_void_p(weights[k].data_ptr()) for k in ("w1", "b1", "w2", "b2", "wb", "bb", "wh", "bh", "wl", "bl")),
+                                    C, int(n_layers))
+
+    def convq_act(self, weights, epsilon, draw_index, n_channels, n_layers=2, out=None, scores_out=None):
+        """A conv Q-body's forward on every env's board + DeepQAgent.act_explore in ONE launch (sgk_convq_act; a labelled non-parity
+        option: the reference's DeepQAgent is an MLP). `weights`: dict of contiguous float32 device tensors in torch's layouts -- w1
+        [C,1,3,3], b1, w2 [C,C,3,3], b2, wb [C,1,1,1], bb, wh [C,C,3,3], bh, wl [4, C * cells], bl. epsilon / draw_index: scalars or
+        1-element device tensors (float64 / int64)."""
+        w = self._convq_weights(weights, n_channels, n_layers)
         out = self._out_actions(out)
         eps_p, epsilon = self._scalar_arg(epsilon, "epsilon", "float64")
         draw_p, draw_index = self._scalar_arg(draw_index, "draw_index", "int64")
@@ -691,6 +694,20 @@ class BatchedGridworldEnv:
         self._sync_torch_to_lib()
         _lib.check(self.lib.sgk_convq_act(self._h.ptr, ctypes.byref(w), float(epsilon), int(draw_index), eps_p, draw_p,
                                           ctypes.c_void_p(out.data_ptr()), sp))
+        self._sync_lib_to_torch()
+        return out
+
+    def convq_sample(self, weights, draw_index, n_channels, n_layers=2, out=None, logits_out=None):
+        """PPOCNNAgent's trunk + actor forward (policy_cnn.py:66-74) on every env's board + PPOBaseAgent.act_explore
+        (Categorical(logits).sample(), policy_base.py:54-64) in ONE launch (sgk_convq_sample). `weights` as for convq_act with wh / bh
+        = actor_cnn and wl / bl = actor_linear; draw_index: scalar or 1-element int64 device tensor."""
+        w = self._convq_weights(weights, n_channels, n_layers)
+        out = self._out_actions(out)
+        draw_p, draw_index = self._scalar_arg(draw_index, "draw_index", "int64")
+        lp = None if logits_out is None else ctypes.c_void_p(self._check(logits_out, "logits_out", shape=(self.n_envs, 4),
+                                                                         dtypes=("float32",)).data_ptr())
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_convq_sample(self._h.ptr, ctypes.byref(w), int(draw_index), draw_p, ctypes.c_void_p(out.data_ptr()), lp))
         self._sync_lib_to_torch()
         return out
 

@@ -236,7 +236,9 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
 
       * ppo-mlp with two layers of 100 (the reference default), 64 or 128 units: sgk_policy_sample -- trunk + actor forward from the
         int8 boards and the Categorical draw fused (no observation tensor, no softmax/multinomial kernels);
-      * any other body (ppo-cnn, other widths): the torch forward on the float32 observation (sgk_obs_f32) followed by
+      * ppo-cnn with two trunk layers (the reference default) and 4, 5 (the default) or 8 channels: sgk_convq_sample -- trunk + actor
+        head (policy_cnn.py:66-74) as im2col GEMMs on fp32 MFMA and the Categorical draw fused, straight from the int8 boards;
+      * any other body (other depths / widths): the torch forward on the float32 observation (sgk_obs_f32) followed by
         sgk_categorical_sample on the logits.
 
     The action stream comes from the counter RNG (keyed by global env index and the agent's draw counter), so it does not
@@ -245,7 +247,7 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
 
     reads_boards = True  # acts on the materialised cells (batched_default_eval must keep writing them)
 
-    def __init__(self, env, args, body="mlp", graph_epochs=True):
+    def __init__(self, env, args, body="mlp", graph_epochs=True, fused_conv=True):
         import types
 
         cfg = types.SimpleNamespace(**vars(args))
@@ -272,7 +274,7 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         self._stats = torch.zeros((self.epochs, 3), dtype=torch.float32, device=self.device)  # policy loss, value loss, entropy
         self._actions = torch.empty(env.n_envs, dtype=torch.uint8, device=self.device)
         self._obs = torch.empty((env.n_envs, env.n_cells), dtype=torch.float32, device=self.device)
-        hidden = int(getattr(args, "n_hidden", 0))  # ppo-cnn has no such flag
+        hidden = int(getattr(args, "n_hidden", 0) or 0)  # ppo-cnn has no such flag
         self.fused_policy = (body == "mlp" and int(args.n_layers) == 2 and hidden in (64, 100, 128) and self.action_n == 4
                              and env.n_cells in (25, 30, 36, 48, 49, 56, 63))
         # learn() as ONE launch (sgk_ppo_epochs) where that kernel applies; Adam's state then lives in self._pl
@@ -285,6 +287,22 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
                         "w2": l2.weight.data, "b2": l2.bias.data, "w3t": torch.empty((hidden, 4), device=self.device),
                         "b3": head.bias.data}
             self._refresh_fused_weights()
+
+        # ppo-cnn: trunk + actor forward + draw in one launch (sgk_convq_sample); the kernel reads the torch parameters in place
+        # (load_state_dict in sync() copies in place: the old policy's tensors stay aliased)
+        self.fused_conv = (bool(fused_conv) and body == "cnn" and int(args.n_layers) == 2 and int(args.n_channels) in (4, 5, 8)
+                           and self.action_n == 4
+                           and tuple(int(v) for v in env.observation_space.shape[-2:]) in ((5, 5), (6, 5), (6, 6), (6, 8), (7, 7), (7, 8), (7, 9)))
+        if self.fused_conv:
+            self.n_channels = int(args.n_channels)
+            self._cw_old, self._cw = self._conv_weights(self.net.old_policy), self._conv_weights(self.net)
+
+    @staticmethod
+    def _conv_weights(net):
+        return {"w1": net.network[0][0].weight.data, "b1": net.network[0][0].bias.data, "w2": net.network[1][0][0].weight.data,
+                "b2": net.network[1][0][0].bias.data, "wb": net.bottleneck.weight.data, "bb": net.bottleneck.bias.data,
+                "wh": net.actor_cnn[0].weight.data, "bh": net.actor_cnn[0].bias.data, "wl": net.actor_linear.weight.data,
+                "bl": net.actor_linear.bias.data}
 
     def _refresh_fused_weights(self):
         old = self.net.old_policy  # load_state_dict copies in place: the untransposed tensors stay aliased
@@ -313,6 +331,8 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
 
     def act(self, boards=None):
         """PPOBaseAgent.act for every env: argmax of the current policy's logits (reference policy_base.py:47-52)."""
+        if self.fused_conv and boards is None:
+            return self.env.convq_act(self._cw, 0.0, 0, self.n_channels, out=self._actions)  # epsilon 0: the argmax, first maximum
         return self.logits().argmax(-1).to(torch.uint8)
 
     def act_explore(self, boards=None, out=None):
@@ -320,6 +340,8 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         out = self._actions if out is None else out
         if self.fused_policy:
             self.env.policy_sample(self._fw, self.draws, out=out)
+        elif self.fused_conv:
+            self.env.convq_sample(self._cw_old, self.draws, self.n_channels, out=out)
         else:
             self.env.categorical_sample(self.logits(old=True), self.draws, out=out)
         self.draws += 1
@@ -355,7 +377,10 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
         record = env._device_views()["rec"]
         boards = env.boards().reshape(n, -1)
         for t in range(buf["actions"].shape[0]):
-            env.categorical_sample(self.logits(old=True), self._draw_dev, out=buf["actions"][t])
+            if self.fused_conv:
+                env.convq_sample(self._cw_old, self._draw_dev, self.n_channels, out=buf["actions"][t])
+            else:
+                env.categorical_sample(self.logits(old=True), self._draw_dev, out=buf["actions"][t])
             self._draw_dev.add_(1)
             buf["states"][t].copy_(boards)
             env.step(buf["actions"][t], auto_reset=False)

@@ -126,6 +126,8 @@ def hexes(row):
 
 PPO_FIXTURES = ["batched_ppo_boat.npz", "batched_ppo_boat_cheat.npz", "batched_ppo_tomato.npz", "batched_ppo_island_gather.npz",
                 "batched_ppo_whisky_cheat_gather.npz"]
+# the reference's PPOCNNAgent (policy_cnn.py; 5 / 8 / 4 channels): what sgk_convq_sample fuses
+PPO_CNN_FIXTURES = ["batched_ppo_cnn_boat.npz", "batched_ppo_cnn_sokoban_gather.npz", "batched_ppo_cnn_island_cheat_gather.npz"]
 
 
 class PpoFixture:
@@ -152,7 +154,8 @@ class PpoFixture:
         m = self.meta
         return types.SimpleNamespace(discount=m["discount"], lr=m["lr"], batch_size=m["batch_size"], rollouts=self.n, epochs=m["epochs"],
                                      clipping=m["clipping"], entropy_bonus=m["entropy_bonus"], critic_coeff=m["critic_coeff"],
-                                     n_layers=m["n_layers"], n_hidden=m["n_hidden"], device=device, log_gradients=False, cheat=self.cheat)
+                                     n_layers=m["n_layers"], n_hidden=m["n_hidden"], n_channels=m.get("n_channels"), device=device,
+                                     log_gradients=False, cheat=self.cheat)
 
     def it(self, k, what):
         return self.z["it%d_%s" % (k, what)]

@@ -903,8 +903,8 @@ def golden_batched_ppo(name, argv, base, learn=True):
                 return orig_tm(history, e_, eval=eval, write=write)
 
             def act(state):
-                with torch.no_grad():
-                    p, _ = agent(state)
+                with torch.no_grad():  # (lifted as the reference's own act lifts it, policy_base.py:47-50: the CNN needs a tensor)
+                    p, _ = agent(torch.tensor(state, requires_grad=False, dtype=torch.float32, device=agent.device))
                 top = torch.sort(p.reshape(-1), descending=True).values
                 gaps.append(float(top[0] - top[1]))
                 return orig_act(state)
@@ -983,7 +983,8 @@ def golden_batched_ppo(name, argv, base, learn=True):
     meta = {"argv": argv, "env": env_name, "cheat": bool(args.cheat), "seed": seed, "base": base, "n": n, "horizon": horizon,
             "iterations": iterations, "learn": bool(learn), "eval_timesteps": PPO_EVAL_TIMESTEPS, "lr": args.lr, "discount": args.discount,
             "batch_size": args.batch_size, "epochs": args.epochs, "clipping": args.clipping, "entropy_bonus": args.entropy_bonus,
-            "critic_coeff": args.critic_coeff, "n_layers": args.n_layers, "n_hidden": args.n_hidden, "min_margin": min_margin, "min_margin_later": min_margin_later,
+            "critic_coeff": args.critic_coeff, "n_layers": args.n_layers, "n_hidden": getattr(args, "n_hidden", None),
+            "n_channels": getattr(args, "n_channels", None), "agent": args.agent_alias, "min_margin": min_margin, "min_margin_later": min_margin_later,
             "min_greedy_gap": min_gap, "episodes": rec["episodes"], "losses": losses, "agents": evals,
             "weight_keys": sorted(rec["weights"][0].keys()), "torch_version": torch.__version__}
     np.savez_compressed(os.path.join(HERE, name), meta=np.array(json.dumps(meta, separators=(",", ":"))), **arrays)
@@ -1352,6 +1353,15 @@ def main():
                        ["-S", "3", "-E", "2"] + common + ["island", "ppo-mlp", "-l", "0.001", "-r", "12", "-e", "2", "-b", "64"], 5, learn=False)
     run(golden_batched_ppo, "batched_ppo_whisky_cheat_gather.npz",
                        ["-S", "3", "-E", "2"] + common + ["-C", "whisky", "ppo-mlp", "-l", "0.001", "-r", "12", "-e", "2", "-b", "64"], 300,
+                       learn=False)
+    # ... and the reference's PPOCNNAgent (policy_cnn.py): its gather_rollout is what sgk_convq_sample fuses (trunk + actor forward + draw)
+    run(golden_batched_ppo, "batched_ppo_cnn_boat.npz",
+                       ["-S", "1", "-E", "2"] + common + ["boat", "ppo-cnn", "-l", "0.001", "-r", "8", "-e", "2", "-b", "64"], 2000)
+    run(golden_batched_ppo, "batched_ppo_cnn_sokoban_gather.npz",
+                       ["-S", "1", "-E", "2"] + common + ["sokoban", "ppo-cnn", "-l", "0.001", "-r", "12", "-e", "2", "-b", "64", "-ch", "8"], 40,
+                       learn=False)
+    run(golden_batched_ppo, "batched_ppo_cnn_island_cheat_gather.npz",
+                       ["-S", "1", "-E", "2"] + common + ["-C", "island", "ppo-cnn", "-l", "0.001", "-r", "12", "-e", "2", "-b", "64", "-ch", "4"], 70000,
                        learn=False)
     # ... and DeepQ (closes A12): train() with DeepQAgent + dqn_warmup + dqn_learn on ONE env index, 300+ agent steps crossing
     # sync_target_Q; reproduced on the GPU by an N = 1 BatchedDeepQAgent (sgk_policy_act + sgk_replay_store + sgk_dqn_sgd_step)

@@ -130,12 +130,12 @@ def _ppo_reward(fx, r, h):
     return np.float32(v * fx.scale) if fx.scale != 1.0 else np.float32(v)
 
 
-@pytest.mark.parametrize("name", BG.PPO_FIXTURES)
+@pytest.mark.parametrize("name", BG.PPO_FIXTURES + BG.PPO_CNN_FIXTURES)
 def test_oracle_and_host_agent_reproduce_the_reference_ppo_run(name, monkeypatch):
     """Gathering: the oracle's Categorical draw on the reference's logits gives the reference's actions, the oracle env steps to the
     reference's boards / rewards / episode ends (each env index reset as the batched gather resets it), the oracle's discounted
     returns are the reference's bit for bit, the oracle's minibatch rows are the ones the reference drew. Learning: the host
-    PPOMLPAgent (CPU torch) fed the same rollout and rows ends at the reference's weights. Evaluation: the reference's greedy
+    PPOMLPAgent / PPOCNNAgent (CPU torch) fed the same rollout and rows ends at the reference's weights. Evaluation: the reference's greedy
     episodes replayed on the oracle env, the host agent choosing the same actions."""
     import torch
 
@@ -146,7 +146,7 @@ def test_oracle_and_host_agent_reproduce_the_reference_ppo_run(name, monkeypatch
     envs = [O.EnvBatch(fx.env, 1, seed=fx.seed, env_begin=fx.base + i) for i in range(n)]
     cells = envs[0].H * envs[0].W
     shim = type("E", (), {"action_space": type("A", (), {"n": 4})(), "observation_space": type("Sp", (), {"shape": (1, envs[0].H, envs[0].W)})()})()
-    host = S.PPOMLPAgent(shim, fx.args("cpu"))
+    host = (S.PPOCNNAgent if m.get("agent") == "ppo-cnn" else S.PPOMLPAgent)(shim, fx.args("cpu"))  # (policy_mlp.py / policy_cnn.py)
     host.load_state_dict({k: torch.as_tensor(v) for k, v in fx.weights(0).items()}, strict=False)
     host.sync()
     assert m["min_margin"] > 1e-5

@@ -283,6 +283,68 @@ def test_batched_ppo_reproduces_the_reference_ppo_run(name, how):
         env.close()
 
 
+@pytest.mark.parametrize("how", ["fused", "graph", "torch"])
+@pytest.mark.parametrize("name", BG.PPO_CNN_FIXTURES)
+def test_batched_ppo_cnn_reproduces_the_reference_ppo_cnn_run(name, how):
+    """The reference's PPOCNNAgent (policy_cnn.py) run by its own train(): BatchedPPOAgent(body="cnn") from the reference's initial
+    weights gathers the reference's rollouts -- boards, actions, rewards, episode lengths exactly, returns bit for bit -- with the
+    trunk + actor forward + Categorical draw of every lockstep step in ONE hand-written launch (sgk_convq_sample: `fused` eager,
+    `graph` the second gather replayed from a hipGraph) or through the torch module + sgk_categorical_sample (`torch`); learn() (torch
+    autograd on the conv body, the reference's minibatch rows) lands on the reference's losses and weights to rtol 2e-3 / atol 2e-5,
+    the second gather runs under those weights, and batched_default_eval (greedy: the same kernel with epsilon 0) books the reference's
+    evaluation episodes. 5, 8 and 4 channels; the fixtures' draws keep clear of the interval boundaries by more than fp32 drift."""
+    from oracle import oracle as O
+
+    torch = _torch()
+    fx = BG.PpoFixture(name)
+    m, T, n = fx.meta, fx.horizon, fx.n
+    assert m["agent"] == "ppo-cnn"
+    env = S.BatchedGridworldEnv(fx.env, n, seed=fx.seed, env_index_base=fx.base)
+    env.bind_torch_stream()
+    agent = S.BatchedPPOAgent(env, fx.args(0), body="cnn", fused_conv=how != "torch")
+    try:
+        assert agent.fused_conv == (how != "torch") and not agent.fused_policy
+        agent.graph_gather = how == "graph"
+        agent.net.load_state_dict({k: torch.as_tensor(v).to(agent.device) for k, v in fx.weights(0).items()}, strict=False)
+        agent.sync()
+        for k in range(fx.iterations):
+            env.metrics_reset()
+            ro = agent.gather_rollout(cheat=fx.cheat)
+            lengths = ro.lengths.cpu().numpy()
+            assert (lengths == fx.it(k, "lengths")).all(), (k, lengths, fx.it(k, "lengths"))
+            got_actions = ro.actions.cpu().numpy().T
+            bad = np.argwhere(got_actions != fx.it(k, "actions"))
+            assert bad.size == 0, (k, bad[:4], [float(fx.it(k, "margins")[i, t]) for i, t in bad[:4]])
+            assert (ro.states.cpu().numpy().transpose(1, 0, 2) == fx.it(k, "states")).all(), k
+            assert (ro.rewards.cpu().numpy() == fx.it(k, "rewards")).all(), k
+            assert ro.returns.cpu().numpy().tobytes() == fx.it(k, "returns").tobytes(), k
+            _metrics_agree(env.metrics(), fx.gather_metrics(k), O)
+            if fx.learn:
+                w = S.RecordingWriter()
+                agent.learn(ro, {"writer": w, "t": 0, "t_learn": 0}, rows=list(fx.it(k, "rows")))
+                got = np.array([float.fromhex(c[2]) for c in w.calls]).reshape(m["epochs"], 3)
+                np.testing.assert_allclose(got, fx.losses(k), rtol=2e-3, atol=2e-5)
+                sd = agent.net.state_dict()
+                for key, v in fx.weights(k + 1).items():
+                    np.testing.assert_allclose(sd[key].cpu().numpy(), v, rtol=2e-3, atol=2e-5, err_msg="%s after iteration %d" % (key, k))
+            agent.sync()
+        if how == "graph":
+            assert agent._gather_graph is not None
+        # the logits the kernel computes at the first step of a fresh episode == the reference's (fp32, another summation order)
+        env.reset()
+        logits = torch.empty((n, 4), dtype=torch.float32, device=agent.device)
+        if how != "torch":
+            agent.net.old_policy.load_state_dict({k: torch.as_tensor(v).to(agent.device) for k, v in fx.weights(0).items()}, strict=False)
+            env.convq_sample(agent._cw_old, 0, agent.n_channels, logits_out=logits)
+            np.testing.assert_allclose(logits.cpu().numpy(), fx.it(0, "logits")[:, 0], rtol=1e-4, atol=2e-5)
+            agent.sync()
+        bm = S.batched_default_eval(agent, env, fx.eval_timesteps)
+        BG.assert_eval_metrics(bm.vec, fx, O)
+        assert bm.episodes == sum(len(a["eval_episodes"]) for a in fx.agents)
+    finally:
+        env.close()
+
+
 # ---- DeepQ (A12): tests/golden/batched_dqn_*.npz -- the reference's train() with DeepQAgent + dqn_warmup + dqn_learn on one env index,
 # its random calls answered from the counter RNG (streams 0 / 2 / 4) -------------------------------------------------------------------
 

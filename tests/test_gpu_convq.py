@@ -62,6 +62,45 @@ def test_convq_scores_match_the_torch_module_and_the_draw_is_epsilon_greedy_on_t
     env.close()
 
 
+@pytest.mark.parametrize("channels", [4, 5, 8])
+@pytest.mark.parametrize("name,n", [("BoatRace-v0", 1000), ("SideEffectsSokoban-v0", 777), ("DistributionalShift-v0", 130), ("FriendFoe-v0", 65)])
+def test_convq_sample_is_the_ppo_cnn_actor_forward_and_the_categorical_draw(name, n, channels):
+    """sgk_convq_sample = PPOCNNAgent's trunk + actor head (policy_cnn.py:66-74) + PPOBaseAgent.act_explore (policy_base.py:54-64):
+    the logits match the torch module's to fp32 tolerance, and the action is sgk_categorical_sample's draw on the kernel's own logits
+    bit for bit (that draw is pinned to the oracle and to the reference's runs elsewhere); device-resident draw index too."""
+    import torch
+
+    torch.manual_seed(channels)
+    env = S.BatchedGridworldEnv(name, n, seed=3)
+    env.step_random(11, auto_reset=True)
+    args = types.SimpleNamespace(discount=0.99, lr=1e-3, batch_size=64, rollouts=n, epochs=2, clipping=0.2, entropy_bonus=0.01,
+                                 critic_coeff=1.0, n_layers=2, n_channels=channels, device="cuda:0", log_gradients=False, cheat=False)
+    agent = S.BatchedPPOAgent(env, args, body="cnn")
+    assert agent.fused_conv
+    with torch.no_grad():
+        for p in agent.net.old_policy.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.3, 0.3)
+    want = agent.logits(old=True).cpu().numpy()
+    got_t = torch.empty((n, 4), dtype=torch.float32, device=agent.device)
+    for draw in (0, 7, 123456789012):
+        a = env.convq_sample(agent._cw_old, draw, channels, logits_out=got_t).clone()
+        np.testing.assert_allclose(got_t.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
+        assert (a.cpu().numpy() == env.categorical_sample(got_t, draw).cpu().numpy()).all(), draw
+    draw_dev = torch.tensor([7], dtype=torch.int64, device=agent.device)
+    a = env.convq_sample(agent._cw_old, draw_dev, channels).clone()
+    assert (a.cpu().numpy() == env.categorical_sample(got_t, 7).cpu().numpy()).all()
+    # act_explore advances the draw index as the per-step route does; act() is the argmax of the CURRENT policy
+    first = agent.act_explore().clone()
+    assert agent.draws == 1 and (first.cpu().numpy() == env.categorical_sample(got_t, 0).cpu().numpy()).all()
+    cur = agent.logits().cpu().numpy()
+    greedy = agent.act().cpu().numpy()
+    top2 = np.sort(cur, axis=1)
+    clear = (top2[:, -1] - top2[:, -2]) > 1e-4
+    assert (greedy[clear] == cur.argmax(1)[clear]).all()
+    env.close()
+
+
 def test_convq_step_and_graph_take_the_actions_of_the_torch_composition():
     """agent.step() / step_graphed() with the fused conv kernel against the same agent driven through torch's conv + sgk_epsilon_greedy:
     the same boards after 40 lockstep steps wherever the two score sets order the actions identically (greedy ties within fp32 rounding
