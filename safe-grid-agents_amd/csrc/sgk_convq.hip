@@ -1,9 +1,14 @@
-// sgk_convq.hip -- a convolutional Q-body's forward + act_explore for every env in ONE launch (sgk_convq_act).
+// sgk_convq.hip -- the reference's convolutional body, forward + draw for every env in ONE launch (sgk_convq_sample, sgk_convq_act).
 //
-// NOT the reference's DeepQAgent (an MLP: value.py:148-158) -- BASELINE.json words config 4 as "conv policy", so the batched agent
-// offers the body of the reference's PPO-CNN (policy_cnn.py:17-81) with a Q head as a labelled non-parity option (q_body="cnn"):
-//     trunk = relu(conv3x3(relu(conv3x3(x, 1 -> C)), C -> C)) + conv1x1(x, 1 -> C)          (n_layers = 2)
-//     Q     = linear(flatten(relu(conv3x3(trunk, C -> C))), C * H * W -> 4)
+// The network is PPOCNNAgent's (policy_cnn.py:17-81) trunk and ONE four-way head:
+//     trunk = relu(conv3x3(relu(conv3x3(x, 1 -> C)), C -> C)) + conv1x1(x, 1 -> C)          (n_layers = 2, the reference's default)
+//     out   = linear(flatten(relu(conv3x3(trunk, C -> C))), C * H * W -> 4)
+//   * sgk_convq_sample: head = actor_cnn / actor_linear, action = Categorical(logits = out).sample() -- PPOBaseAgent.act_explore
+//     (policy_base.py:54-64) as ppo-cnn's gather_rollout calls it per step (policy_base.py:145). Pinned to the reference's own ppo-cnn
+//     runs (tests/golden/batched_ppo_cnn_*.npz).
+//   * sgk_convq_act: `out` read as four Q-values + DeepQAgent.act_explore's epsilon-greedy draw -- the batched DeepQ agent's labelled
+//     NON-PARITY option q_body="cnn" (the reference's DeepQAgent is an MLP: value.py:148-158; BASELINE.json words config 4 as "conv
+//     policy").
 // Through PyTorch / MIOpen that forward costs 390 us per lockstep step at 32 768 envs (six tiny-spatial convolutions, an observation
 // cast, a dozen launches); it is 18.7 k multiply-adds per 6 x 6 board.
 //

@@ -52,8 +52,9 @@ def run_reference_batch(name, n, hidden=100, epochs=16):
           f"sgk_ppo_epochs {ms['kernel']:.3f} ms ({1e3 * ms['kernel'] / epochs:.1f} us/epoch)", flush=True)
     env.close()
 
-def run_unfused_gather(name, n, body, hidden=100):
-    """Bodies without a fused kernel: the T-step gather loop eager vs replayed from one hipGraph."""
+def run_unfused_gather(name, n, body, hidden=100, fused_conv=False):
+    """Bodies without a fused ROLLOUT kernel: the T-step gather loop eager vs replayed from one hipGraph. fused_conv: ppo-cnn's trunk +
+    actor forward + draw as one launch per step (sgk_convq_sample) instead of the torch module + sgk_categorical_sample."""
     ms = {}
     for graphed in (False, True):
         torch.manual_seed(0)
@@ -61,7 +62,7 @@ def run_unfused_gather(name, n, body, hidden=100):
         env.bind_torch_stream()
         a = types.SimpleNamespace(discount=0.99, lr=1e-3, batch_size=64, rollouts=1, epochs=4, clipping=0.2, entropy_bonus=0.01,
                                   critic_coeff=1.0, n_layers=2, n_hidden=hidden, n_channels=5, device=0, log_gradients=False, cheat=False)
-        agent = S.BatchedPPOAgent(env, a, body=body)
+        agent = S.BatchedPPOAgent(env, a, body=body, fused_conv=fused_conv)
         agent.graph_gather = graphed
         for it in range(4):
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -69,9 +70,15 @@ def run_unfused_gather(name, n, body, hidden=100):
             torch.cuda.synchronize(); t1 = time.perf_counter()
         ms[graphed] = 1e3 * (t1 - t0)
         env.close()
-    print(f"{name} n={n} body={body} H={hidden} unfused gather: eager {ms[False]:.1f} ms, one hipGraph {ms[True]:.1f} ms "
+    print(f"{name} n={n} body={body} H={hidden} {'sgk_convq_sample' if fused_conv else 'unfused'} gather: eager {ms[False]:.1f} ms "
+          f"({1e3 * ms[False] / ro.actions.shape[0]:.1f} us/lockstep), one hipGraph {ms[True]:.1f} ms "
           f"({1e3 * ms[True] / ro.actions.shape[0]:.1f} us/lockstep)", flush=True)
 
+for name in ("BoatRace-v0", "SideEffectsSokoban-v0"):  # ppo-cnn's gather: the fused conv kernel against the torch module
+    run_unfused_gather(name, 32768, "cnn", fused_conv=True)
+    run_unfused_gather(name, 32768, "cnn", fused_conv=False)
+if len(sys.argv) > 1 and sys.argv[1] == "cnn":
+    sys.exit(0)
 for n in (1024, 32768):
     run_unfused_gather("BoatRace-v0", n, "cnn")
     run_unfused_gather("BoatRace-v0", n, "mlp", hidden=32)
