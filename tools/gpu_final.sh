@@ -29,6 +29,12 @@ timeout 600 python tools/exp_tabq_dropin.py 2>&1 | grep -v amdgpu.ids > $O/tabq_
 timeout 300 python tools/exp_dqn_learner_ab.py 2>&1 | grep -v amdgpu.ids > $O/dqn_learner.log; cat $O/dqn_learner.log | cut -c1-200
 timeout 600 bash tools/gpu_dqn_timeline.sh $O/dqn_timeline.log > /dev/null 2>&1; tail -4 $O/dqn_timeline.log | cut -c1-200
 timeout 900 python -O -m pytest tests -m gpu -q -k step > $O/pytest_gpu_O_step.log 2>&1; tail -1 $O/pytest_gpu_O_step.log
+# round 6: the conv body's kernel (sgk_convq_sample / sgk_convq_act) per level and channel count, ppo-cnn's gather through it and through
+# the torch module, and the kernel under the kernel trace + SQ counters (issue / MFMA busy / LDS)
+timeout 600 python tools/exp_convq.py 2>&1 | grep -v amdgpu.ids > $O/convq_levels.log; cat $O/convq_levels.log | cut -c1-250
+timeout 600 python tools/bench_ppo.py cnn 2>&1 | grep -v amdgpu.ids > $O/ppo_cnn_gather.log; cat $O/ppo_cnn_gather.log | cut -c1-250
+timeout 900 bash tools/gpu_pmc_convq.sh > $O/convq_pmc.out 2>&1; cp gpurun_out/pmc_convq_summary.json $O/convq_pmc_summary.json 2>/dev/null
+for f in $(find gpurun_out/convq_trace -name "*kernel_stats.csv" 2>/dev/null); do cp $f $O/convq_kernel_stats.csv; head -3 $f | cut -c1-200; done
 export SGK_NO_BUILD=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-fused --sustain-seconds 0 > $O/bench_under_rocprof.log 2>&1
 for f in $(find $O/prof -name "*kernel_stats.csv"); do head -6 $f | cut -c1-200; cp $f $O/bench_kernel_stats.csv; done
