@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SGK_ABI_VERSION 4 /* 3: the tabular-Q tables in HBM are state-major (sgk_tabq_table_dev); 4: sgk_tabq_step, sgk_step_store, sgk_reset_done_store, sgk_convq_act, sgk_convq_sample, sgk_dqn_learner's
+#define SGK_ABI_VERSION 4 /* 3: the tabular-Q tables in HBM are state-major (sgk_tabq_table_dev); 4: sgk_tabq_step, sgk_step_store, sgk_reset_done_store, sgk_convq_act, sgk_convq_sample, sgk_convq_rollout, sgk_dqn_learner's
                              loss_mode / rows / rows_out, SGK_F_SEPARATE_LAUNCHES, the sgk_debug_* hooks are off unless asked for */
 
 #if defined(__GNUC__)
@@ -411,6 +411,15 @@ SGK_API int sgk_convq_act(sgk_env *h, const sgk_convq_weights *w, double epsilon
                           const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev);
 SGK_API int sgk_convq_sample(sgk_env *h, const sgk_convq_weights *w, uint64_t draw_index, const uint64_t *draw_index_dev,
                              uint8_t *actions_out_dev, float *logits_out_dev);
+/* n_steps of {that forward, the draw, env.step} in ONE launch: the inner loop of PPOBaseAgent.gather_rollout (policy_base.py:142-163:
+ * old_policy.act_explore -> env.step -> store state / action / reward) for a PPOCNNAgent -- what sgk_policy_rollout is for the MLP
+ * bodies, and with its arguments: mode 0 = epsilon-greedy with a fixed epsilon (acting with a frozen conv Q-network), 1 = Categorical
+ * sample; step k draws with index draw_index0 + k; flags: SGK_F_AUTO_RESET, SGK_F_MASK_FINISHED (the states / actions entries of an env
+ * whose episode is over are zeros; it idles when auto-reset is off). Optional outputs: states_out_dev int8 [n_steps][n_envs][n_cells]
+ * (the board each action was chosen on), actions_out_dev uint8 [n_steps][n_envs], recs_out_dev [n_steps][n_envs]. The envs' own
+ * boards are materialised at the end. */
+SGK_API int sgk_convq_rollout(sgk_env *h, const sgk_convq_weights *w, int32_t mode, double epsilon, uint64_t draw_index0, int32_t n_steps,
+                              uint32_t flags, int8_t *states_out_dev, uint8_t *actions_out_dev, sgk_step_rec *recs_out_dev);
 
 /* The two halves of the replay add FUSED into the launches around them (round 6; a lockstep step of dqn_learn -- learn.py:29-58 -- is
  * then sgk_policy_act, sgk_step_store, sgk_dqn_sgd_step, sgk_reset_done_store: four calls instead of six):

@@ -847,20 +847,46 @@ int sgk_replay_store(sgk_env *h, int32_t phase, const uint8_t *actions_dev, int3
   return SGK_OK;
 } SGK_CATCH_STATUS
 
-static int convq_launch(sgk_env *h, const sgk_convq_weights *w, int mode, double epsilon, uint64_t draw_index, const double *epsilon_dev,
-                        const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev) {
-  SGK_CHECK_HANDLE(h);
-  if (!w || !actions_out_dev || !w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->wb || !w->bb || !w->wh || !w->bh || !w->wl || !w->bl)
+static int convq_weights_ok(const sgk_convq_weights *w) {
+  if (!w || !w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->wb || !w->bb || !w->wh || !w->bh || !w->wl || !w->bl)
     return fail(SGK_ERR_INVALID, "NULL argument");
   if (w->n_layers != 2) return fail(SGK_ERR_INVALID, "the fused conv body is built for n_layers == 2 (two 3 x 3 convolutions in the trunk)");
   if (w->n_channels != 4 && w->n_channels != 5 && w->n_channels != 8)
     return fail(SGK_ERR_INVALID, "the fused conv body is built for n_channels in {4, 5 (policy_cnn.py's default), 8}");
+  return SGK_OK;
+}
+
+static int convq_launch(sgk_env *h, const sgk_convq_weights *w, int mode, double epsilon, uint64_t draw_index, const double *epsilon_dev,
+                        const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev) {
+  SGK_CHECK_HANDLE(h);
+  if (int rc = convq_weights_ok(w)) return rc;
+  if (!actions_out_dev) return fail(SGK_ERR_INVALID, "NULL argument");
   if (scores_out_dev && ((uintptr_t)scores_out_dev & 15u)) return fail(SGK_ERR_INVALID, "the scores / logits output must be 16-byte aligned");
   sgk::ConvQWeights cw{w->w1, w->b1, w->w2, w->b2, w->wb, w->bb, w->wh, w->bh, w->wl, w->bl};
   SGK_HIP(sgk::launch_convq_act(h->sh, cw, w->n_channels, mode, actions_out_dev, scores_out_dev, epsilon, draw_index, epsilon_dev,
                                 draw_index_dev, h->stream));
   return SGK_OK;
 }
+
+int sgk_convq_rollout(sgk_env *h, const sgk_convq_weights *w, int32_t mode, double epsilon, uint64_t draw_index0, int32_t n_steps,
+                      uint32_t flags, int8_t *states_out_dev, uint8_t *actions_out_dev, sgk_step_rec *recs_out_dev) try {
+  SGK_CHECK_HANDLE(h);
+  if (int rc = convq_weights_ok(w)) return rc;
+  if (mode != 0 && mode != 1) return fail(SGK_ERR_INVALID, "mode must be 0 (epsilon-greedy) or 1 (categorical)");
+  if (n_steps < 0) return fail(SGK_ERR_INVALID, "n_steps < 0");
+  if (flags & ~(uint32_t)(SGK_F_AUTO_RESET | SGK_F_MASK_FINISHED))
+    return fail(SGK_ERR_INVALID, "only SGK_F_AUTO_RESET and SGK_F_MASK_FINISHED are meaningful here");
+  if (n_steps == 0) return SGK_OK;
+  sgk::Shard &s = h->sh;
+  sgk::ConvQWeights cw{w->w1, w->b1, w->w2, w->b2, w->wb, w->bb, w->wh, w->bh, w->wl, w->bl};
+  SGK_HIP(sgk::launch_convq_rollout(s, cw, w->n_channels, mode, epsilon, draw_index0, n_steps, flags, states_out_dev, actions_out_dev,
+                                    reinterpret_cast<uint32_t *>(recs_out_dev), h->stream));
+  SGK_HIP(sgk::launch_reset(s, nullptr, 2, h->stream));  // materialise the boards of the final states
+  s.lockstep_t += (uint64_t)n_steps;
+  h->t_dev_stale = true;
+  h->steps_issued += s.n * n_steps;
+  return SGK_OK;
+} SGK_CATCH_STATUS
 
 int sgk_convq_act(sgk_env *h, const sgk_convq_weights *w, double epsilon, uint64_t draw_index, const double *epsilon_dev,
                   const uint64_t *draw_index_dev, uint8_t *actions_out_dev, float *scores_out_dev) try {

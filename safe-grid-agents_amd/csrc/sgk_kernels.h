@@ -101,6 +101,9 @@ struct ConvQWeights {
 // mode 0: epsilon-greedy on the four scores (DeepQAgent.act_explore); 1: Categorical(logits = scores).sample() (PPOBaseAgent.act_explore)
 hipError_t launch_convq_act(const Shard &sh, const ConvQWeights &w, int n_channels, int mode, uint8_t *actions, float *scores, double eps, uint64_t draw,
                             const double *eps_dev, const uint64_t *draw_dev, hipStream_t st);
+// n_steps of {conv forward, draw, env.step} in one launch (sgk_convq_rollout.hip); outputs as for launch_policy_rollout
+hipError_t launch_convq_rollout(const Shard &sh, const ConvQWeights &w, int n_channels, int mode, double eps, uint64_t draw0, int32_t n_steps,
+                                uint32_t flags, int8_t *states_out, uint8_t *actions_out, uint32_t *recs_out, hipStream_t st);
 // DeepQAgent.learn as one kernel (sgk_learn.hip); all pointers are device pointers
 struct DqnLearner {
   const int8_t *states, *successors;

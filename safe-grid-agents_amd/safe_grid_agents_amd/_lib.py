@@ -140,6 +140,8 @@ _SIGNATURES = {
     "sgk_dqn_sgd_step": (ctypes.c_int, [_V, ctypes.POINTER(SgkDqnLearner)]),
     "sgk_convq_act": (ctypes.c_int, [_V, ctypes.POINTER(SgkConvQWeights), ctypes.c_double, ctypes.c_uint64, _V, _V, _V, _V]),
     "sgk_convq_sample": (ctypes.c_int, [_V, ctypes.POINTER(SgkConvQWeights), ctypes.c_uint64, _V, _V, _V]),
+    "sgk_convq_rollout": (ctypes.c_int, [_V, ctypes.POINTER(SgkConvQWeights), ctypes.c_int32, ctypes.c_double, ctypes.c_uint64, ctypes.c_int32,
+                                         ctypes.c_uint32, _V, _V, _V]),
     "sgk_step_store": (ctypes.c_int, [_V, _V, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int64, _V, ctypes.c_int32, _V, _V, _V, _V]),
     "sgk_reset_done_store": (ctypes.c_int, [_V, ctypes.c_uint32, ctypes.c_int64, _V, ctypes.c_int32, _V]),
     "sgk_ppo_epochs": (ctypes.c_int, [_V, ctypes.POINTER(SgkPpoLearner)]),

@@ -282,6 +282,8 @@ class BatchedDeepQAgent:
 
     def greedy_weights(self):
         """Q-network weights in the fused kernels' layout (greedy evaluation, batched_default_eval), or None."""
+        if self.fused_conv:
+            return self._cw  # (torch's own tensors: sgk_convq_rollout reads them in place)
         if not self.fused_policy:
             return None
         if self._fw_stale:
@@ -293,8 +295,11 @@ class BatchedDeepQAgent:
         epsilon, env.step (evaluation and data collection; learning schedules epsilon per step and uses step())."""
         weights = self.greedy_weights()
         if weights is None:
-            raise ValueError("act_rollout needs the fused policy kernel (two layers of 64 / 100 / 128 units)")
-        self.env.policy_rollout(weights, n_steps, mode="greedy", epsilon=epsilon, draw_index0=self.t, auto_reset=auto_reset)
+            raise ValueError("act_rollout needs a fused policy kernel (two layers of 64 / 100 / 128 units, or the conv body)")
+        if self.fused_conv:
+            self.env.convq_rollout(weights, n_steps, self.n_channels, mode="greedy", epsilon=epsilon, draw_index0=self.t, auto_reset=auto_reset)
+        else:
+            self.env.policy_rollout(weights, n_steps, mode="greedy", epsilon=epsilon, draw_index0=self.t, auto_reset=auto_reset)
         self.t += int(n_steps)
 
     def _refresh_fused_weights(self):

@@ -711,6 +711,30 @@ class BatchedGridworldEnv:
         self._sync_lib_to_torch()
         return out
 
+    def convq_rollout(self, weights, n_steps, n_channels, mode="sample", epsilon=0.0, draw_index0=0, auto_reset=False, states=None,
+                      actions=None, recs=None, mask_finished=False, n_layers=2):
+        """n_steps of {conv body forward, action draw, env.step} in ONE HIP launch (sgk_convq_rollout): `weights` as for convq_sample
+        / convq_act; mode "sample" = Categorical(logits) (ppo-cnn's gather_rollout), "greedy" = epsilon-greedy with a fixed epsilon.
+        Outputs as for policy_rollout."""
+        w = self._convq_weights(weights, n_channels, n_layers)
+        if mode not in ("greedy", "sample"):
+            raise ValueError("mode must be 'greedy' or 'sample'")
+
+        def ptr(t, shape, what, dtype):
+            if t is None:
+                return None
+            return ctypes.c_void_p(self._check(t, what, shape=shape, dtypes=(dtype,)).data_ptr())
+
+        n = self.n_envs
+        self._version += 1
+        self._sync_torch_to_lib()
+        _lib.check(self.lib.sgk_convq_rollout(
+            self._h.ptr, ctypes.byref(w), {"greedy": 0, "sample": 1}[mode], float(epsilon), int(draw_index0), int(n_steps),
+            (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_MASK_FINISHED if mask_finished else 0),
+            ptr(states, (n_steps, n, self.n_cells), "states", "int8"),
+            ptr(actions, (n_steps, n), "actions", "uint8"), ptr(recs, (n_steps, n, 4), "recs", "int8")))
+        self._sync_lib_to_torch()
+
     def categorical_sample(self, logits, draw_index, out=None):
         """PPOBaseAgent.act_explore for every env (reference policy_base.py:54-64): logits float32 [N, 4] -> uint8 actions
         [N] drawn from Categorical(logits) with the counter RNG. `draw_index`: int or a 1-element int64 device tensor."""

@@ -180,10 +180,16 @@ def batched_default_eval(agent, env, eval_timesteps):
     env.metrics_reset()
     env.reset()
     weights = agent.greedy_weights() if hasattr(agent, "greedy_weights") else None
-    if weights is not None:  # fused MLP policy: each phase is one sgk_policy_rollout launch (auto-reset == step + reset_done)
+    if weights is not None:  # fused policy: each phase is one sgk_policy_rollout / sgk_convq_rollout launch (auto-reset == step + reset_done)
+        if "wh" in weights:  # a conv body
+            def rollout(k, auto_reset):
+                env.convq_rollout(weights, k, int(weights["b1"].numel()), mode="greedy", epsilon=0.0, auto_reset=auto_reset)
+        else:
+            def rollout(k, auto_reset):
+                env.policy_rollout(weights, k, mode="greedy", epsilon=0.0, auto_reset=auto_reset)
         if int(eval_timesteps) > 1:
-            env.policy_rollout(weights, int(eval_timesteps) - 1, mode="greedy", epsilon=0.0, auto_reset=True)
-        env.policy_rollout(weights, int(env.info.max_iterations), mode="greedy", epsilon=0.0, auto_reset=False)
+            rollout(int(eval_timesteps) - 1, True)
+        rollout(int(env.info.max_iterations), False)
         return BatchMetrics(env.metrics(), env.reward_scale)
     for _ in range(max(int(eval_timesteps) - 1, 0)):
         env.step(agent.act(), auto_reset=False, write_boards=boards)
@@ -233,8 +239,12 @@ def batched_gather_rollout(policy, env, discount, cheat=False, horizon=None, buf
     fused = getattr(policy, "fused_rollout", None)  # -> (MLP weights, first draw index): the whole loop is one launch
     if fused is not None:
         weights, draw0 = fused()
-        env.policy_rollout(weights, T, mode="sample", draw_index0=draw0, auto_reset=False, states=states, actions=actions,
-                           recs=recs, mask_finished=True)  # entries past an episode's end are stored as zeros by the kernel
+        if "wh" in weights:  # a conv body (PPOCNNAgent): sgk_convq_rollout
+            env.convq_rollout(weights, T, int(weights["b1"].numel()), mode="sample", draw_index0=draw0, auto_reset=False, states=states,
+                              actions=actions, recs=recs, mask_finished=True)
+        else:
+            env.policy_rollout(weights, T, mode="sample", draw_index0=draw0, auto_reset=False, states=states, actions=actions,
+                               recs=recs, mask_finished=True)  # entries past an episode's end are stored as zeros by the kernel
     elif getattr(policy, "run_steps", None) is not None:  # the policy runs the T steps itself (a recorded hipGraph)
         policy.run_steps()
     else:

@@ -323,6 +323,8 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
     def greedy_weights(self):
         """The CURRENT policy's trunk + actor weights in the fused kernels' layout (greedy evaluation, batched_default_eval),
         or None when the fused kernels do not apply."""
+        if self.fused_conv and self.fused_rollout:
+            return self._cw  # (torch's own tensors, read in place by sgk_convq_rollout)
         if not self.fused_policy:
             return None
         net = self.net
@@ -359,9 +361,10 @@ class BatchedPPOAgent(BaseActor, BaseLearner, BaseExplorer):
             self._buffers, self._graph = rollout_buffers(self.env, horizon), None
             self._gather_graph, self._gathers = None, 0
         steps = self._buffers["actions"].shape[0]
-        if self.fused_policy and self.fused_rollout:  # forward + draw + env.step of all steps in ONE launch
+        if (self.fused_policy or self.fused_conv) and self.fused_rollout:  # forward + draw + env.step of all steps in ONE launch
             first_draw = self.draws
-            policy.fused_rollout = lambda: (self._fw, first_draw)
+            weights = self._fw if self.fused_policy else self._cw_old
+            policy.fused_rollout = lambda: (weights, first_draw)
             self.draws += steps
         elif not self.fused_policy and self.graph_gather and self._gathers >= 1 and getattr(self.env, "_bound", False):
             # the first rollout ran eagerly (lazy initialisation done); from the second on the whole step loop is one graph

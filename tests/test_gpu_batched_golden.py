@@ -283,13 +283,14 @@ def test_batched_ppo_reproduces_the_reference_ppo_run(name, how):
         env.close()
 
 
-@pytest.mark.parametrize("how", ["fused", "graph", "torch"])
+@pytest.mark.parametrize("how", ["rollout", "fused", "graph", "torch"])
 @pytest.mark.parametrize("name", BG.PPO_CNN_FIXTURES)
 def test_batched_ppo_cnn_reproduces_the_reference_ppo_cnn_run(name, how):
     """The reference's PPOCNNAgent (policy_cnn.py) run by its own train(): BatchedPPOAgent(body="cnn") from the reference's initial
     weights gathers the reference's rollouts -- boards, actions, rewards, episode lengths exactly, returns bit for bit -- with the
-    trunk + actor forward + Categorical draw of every lockstep step in ONE hand-written launch (sgk_convq_sample: `fused` eager,
-    `graph` the second gather replayed from a hipGraph) or through the torch module + sgk_categorical_sample (`torch`); learn() (torch
+    whole gather ONE launch (sgk_convq_rollout: `rollout`, the default), or the trunk + actor forward + Categorical draw of every lockstep
+    step one launch (sgk_convq_sample: `fused` eager, `graph` the second gather replayed from a hipGraph), or through the torch module +
+    sgk_categorical_sample (`torch`); learn() (torch
     autograd on the conv body, the reference's minibatch rows) lands on the reference's losses and weights to rtol 2e-3 / atol 2e-5,
     the second gather runs under those weights, and batched_default_eval (greedy: the same kernel with epsilon 0) books the reference's
     evaluation episodes. 5, 8 and 4 channels; the fixtures' draws keep clear of the interval boundaries by more than fp32 drift."""
@@ -303,7 +304,8 @@ def test_batched_ppo_cnn_reproduces_the_reference_ppo_cnn_run(name, how):
     env.bind_torch_stream()
     agent = S.BatchedPPOAgent(env, fx.args(0), body="cnn", fused_conv=how != "torch")
     try:
-        assert agent.fused_conv == (how != "torch") and not agent.fused_policy
+        assert agent.fused_conv == (how != "torch") and not agent.fused_policy and agent.fused_rollout
+        agent.fused_rollout = how == "rollout"
         agent.graph_gather = how == "graph"
         agent.net.load_state_dict({k: torch.as_tensor(v).to(agent.device) for k, v in fx.weights(0).items()}, strict=False)
         agent.sync()

@@ -101,6 +101,66 @@ def test_convq_sample_is_the_ppo_cnn_actor_forward_and_the_categorical_draw(name
     env.close()
 
 
+@pytest.mark.parametrize("mode,auto_reset,mask", [("sample", False, True), ("sample", True, False), ("greedy", True, False), ("greedy", False, False)])
+@pytest.mark.parametrize("name,n,channels", [("BoatRace-v0", 1000, 5), ("SideEffectsSokoban-v0", 4133, 5), ("IslandNavigation-v0", 333, 4),
+                                             ("DistributionalShift-v0", 130, 8), ("WhiskyGold-v0", 257, 5), ("AbsentSupervisor-v0", 64, 4),
+                                             ("SafeInterruptibility-v0", 100, 5), ("ConveyorBelt-v0", 77, 8), ("TomatoWatering-v0", 90, 5),
+                                             ("FriendFoe-v0", 500, 5), ("BoatRace-v0", 1, 5)])
+def test_convq_rollout_is_the_per_step_launches_in_one(name, n, channels, mode, auto_reset, mask):
+    """sgk_convq_rollout (forward + draw + env.step of T lockstep steps in ONE launch, state in registers, boards in LDS) against the
+    launches it fuses -- sgk_convq_sample / sgk_convq_act, the board copy, sgk_step (+ sgk_reset_done), the record copy -- on a twin
+    batch: every step's board, action and record, the final boards / records / episode arrays and the metrics are identical (the same
+    arithmetic in the same order: bit for bit), with and without auto-reset and SGK_F_MASK_FINISHED, on all ten levels."""
+    import torch
+
+    T = 37
+    torch.manual_seed(2)
+    env_a = S.BatchedGridworldEnv(name, n, seed=11)
+    env_b = S.BatchedGridworldEnv(name, n, seed=11)
+    for e in (env_a, env_b):
+        e.step_random(9, auto_reset=True)
+        e.metrics_reset()
+    agent = S.BatchedDeepQAgent(env_a, _args(n_channels=channels), q_body="cnn")
+    with torch.no_grad():
+        for p in agent.Q.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.3, 0.3)
+    w = agent._cw
+    dev = agent.device
+    states = torch.full((T, n, env_a.n_cells), 77, dtype=torch.int8, device=dev)
+    actions = torch.full((T, n), 9, dtype=torch.uint8, device=dev)
+    recs = torch.full((T, n, 4), 5, dtype=torch.int8, device=dev)
+    env_a.convq_rollout(w, T, channels, mode=mode, epsilon=0.2, draw_index0=1000, auto_reset=auto_reset, states=states, actions=actions,
+                        recs=recs, mask_finished=mask)
+    rec_b = env_b._device_views()["rec"]
+    over = torch.zeros(n, dtype=torch.bool, device=dev)
+    for k in range(T):
+        boards = env_b.boards().reshape(n, -1)
+        want_s = boards.clone()
+        if mode == "sample":
+            a = env_b.convq_sample(w, 1000 + k, channels).clone()
+        else:
+            a = env_b.convq_act(w, 0.2, 1000 + k, channels).clone()
+        if mask:  # the entries of envs whose episode is over read zero
+            want_s[over] = 0
+            want_a = torch.where(over, torch.zeros_like(a), a)
+        else:
+            want_a = a
+        assert (states[k] == want_s).all(), k
+        assert (actions[k] == want_a).all(), k
+        env_b.step(a, auto_reset=auto_reset)
+        assert (recs[k] == rec_b).all(), k
+        over = (rec_b[:, 2] != 0) if not auto_reset else over
+    assert (env_a.boards() == env_b.boards()).all()
+    assert (env_a._device_views()["rec"] == rec_b).all()
+    assert (np.asarray(env_a.metrics()) == np.asarray(env_b.metrics())).all()
+    va, vb = env_a._device_views(), env_b._device_views()
+    for key in ("last_return", "last_performance", "n_episodes"):
+        assert (va[key] == vb[key]).all(), key
+    env_a.close()
+    env_b.close()
+
+
 def test_convq_step_and_graph_take_the_actions_of_the_torch_composition():
     """agent.step() / step_graphed() with the fused conv kernel against the same agent driven through torch's conv + sgk_epsilon_greedy:
     the same boards after 40 lockstep steps wherever the two score sets order the actions identically (greedy ties within fp32 rounding

@@ -52,7 +52,7 @@ def run_reference_batch(name, n, hidden=100, epochs=16):
           f"sgk_ppo_epochs {ms['kernel']:.3f} ms ({1e3 * ms['kernel'] / epochs:.1f} us/epoch)", flush=True)
     env.close()
 
-def run_unfused_gather(name, n, body, hidden=100, fused_conv=False):
+def run_unfused_gather(name, n, body, hidden=100, fused_conv=False, rollout=False):
     """Bodies without a fused ROLLOUT kernel: the T-step gather loop eager vs replayed from one hipGraph. fused_conv: ppo-cnn's trunk +
     actor forward + draw as one launch per step (sgk_convq_sample) instead of the torch module + sgk_categorical_sample."""
     ms = {}
@@ -63,6 +63,7 @@ def run_unfused_gather(name, n, body, hidden=100, fused_conv=False):
         a = types.SimpleNamespace(discount=0.99, lr=1e-3, batch_size=64, rollouts=1, epochs=4, clipping=0.2, entropy_bonus=0.01,
                                   critic_coeff=1.0, n_layers=2, n_hidden=hidden, n_channels=5, device=0, log_gradients=False, cheat=False)
         agent = S.BatchedPPOAgent(env, a, body=body, fused_conv=fused_conv)
+        agent.fused_rollout = rollout  # (True: the whole gather is one sgk_convq_rollout launch; `graphed` then changes nothing)
         agent.graph_gather = graphed
         for it in range(4):
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -70,11 +71,12 @@ def run_unfused_gather(name, n, body, hidden=100, fused_conv=False):
             torch.cuda.synchronize(); t1 = time.perf_counter()
         ms[graphed] = 1e3 * (t1 - t0)
         env.close()
-    print(f"{name} n={n} body={body} H={hidden} {'sgk_convq_sample' if fused_conv else 'unfused'} gather: eager {ms[False]:.1f} ms "
+    print(f"{name} n={n} body={body} H={hidden} {('sgk_convq_rollout' if rollout else 'sgk_convq_sample') if fused_conv else 'unfused'} gather: eager {ms[False]:.1f} ms "
           f"({1e3 * ms[False] / ro.actions.shape[0]:.1f} us/lockstep), one hipGraph {ms[True]:.1f} ms "
           f"({1e3 * ms[True] / ro.actions.shape[0]:.1f} us/lockstep)", flush=True)
 
-for name in ("BoatRace-v0", "SideEffectsSokoban-v0"):  # ppo-cnn's gather: the fused conv kernel against the torch module
+for name in ("BoatRace-v0", "SideEffectsSokoban-v0", "DistributionalShift-v0"):  # ppo-cnn's gather: the fused conv kernels against the torch module
+    run_unfused_gather(name, 32768, "cnn", fused_conv=True, rollout=True)
     run_unfused_gather(name, 32768, "cnn", fused_conv=True)
     run_unfused_gather(name, 32768, "cnn", fused_conv=False)
 if len(sys.argv) > 1 and sys.argv[1] == "cnn":

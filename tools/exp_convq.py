@@ -39,6 +39,9 @@ for name, n in (("SideEffectsSokoban-v0", 32768), ("SideEffectsSokoban-v0", 1 <<
         us = wall(lambda: agent._conv_act(0.1, 3))
         flops = 2.0 * env.n_cells * (9 * c + 2 * 9 * c * c + c + 4 * c)
         row.append("C=%d %7.2f us (%5.1f TFLOP/s useful)" % (c, us, n * flops / us / 1e6))
+        if n == 32768:  # the same forward + draw + env.step, 100 lockstep steps in ONE launch (sgk_convq_rollout)
+            ro = wall(lambda: env.convq_rollout(agent._cw, 100, c, mode="greedy", epsilon=0.1, draw_index0=0, auto_reset=True), 10, 2) / 100
+            row.append("[rollout %6.2f us/step]" % ro)
         if name.startswith("Side") and c == 5 and n == 32768:
             step = wall(lambda: agent.step(learn=False), 100, 10)
             agent.enable_graphs(learn=False)
