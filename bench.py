@@ -595,13 +595,17 @@ def run_config(args):
             dt_cnn_act = wall(lambda: cq.step(learn=False), 100, warm=10)
             dt_cnn_learn = wall(lambda: cq.step(learn=True), 100, warm=10)
             dt_cnn_kernel = wall(lambda: cq.act_explore(), 100, warm=10)
+            dt_cnn_rollout = wall(lambda: cq.act_rollout(100, epsilon=0.05), 5, warm=1) / 100  # frozen weights, fixed epsilon, one launch
             C, cells = cq.n_channels, env.n_cells
             conv_flops = 2.0 * cells * (9 * C + 2 * 9 * C * C + C + 4 * C)  # multiply-adds x 2 per board: L1, L2 + head, 1x1, linear
             cnn = {"q_body": "cnn", "parity": "none (not the reference's DeepQAgent)", "n_channels": C, "fused_kernel": bool(cq.fused_conv),
                    "acting": {"us_per_lockstep_step": dt_cnn_act * 1e6, "value": n / dt_cnn_act,
                               "how": "eager, three launches: sgk_convq_act (conv forward + act_explore), sgk_step, sgk_reset_done",
                               "forward_and_act_explore_us": dt_cnn_kernel * 1e6, "useful_flops_per_board": conv_flops,
-                              "forward_tflops": n * conv_flops / dt_cnn_kernel / 1e12},
+                              "forward_tflops": n * conv_flops / dt_cnn_kernel / 1e12,
+                              "rollout_us_per_lockstep_step": dt_cnn_rollout * 1e6, "rollout_value": n / dt_cnn_rollout,
+                              "rollout_how": "100 lockstep steps of {conv forward, eps-greedy draw, env.step + auto-reset} per launch "
+                                             "(sgk_convq_rollout: state in registers, boards in LDS)"},
                    "acting_plus_sgd": {"us_per_lockstep_step": dt_cnn_learn * 1e6, "value": n / dt_cnn_learn,
                                        "how": "the same with the replay add fused into step / reset + one torch autograd SGD step (batch 64, Adam "
                                               "amsgrad fused)"}}
