@@ -294,8 +294,8 @@ def test_fused_ppo_epochs_kernel_draws_valid_rows_uniformly():
 
 @pytest.mark.parametrize("body,hidden", [("cnn", 0), ("mlp", 48)])
 def test_graph_replayed_gather_equals_the_eager_step_loop(body, hidden):
-    """Bodies without a fused kernel (ppo-cnn, other MLP widths): from the second rollout on the T lockstep steps are one
-    hipGraph replay. Same draws (the index advances in device memory), same kernels: rollouts, env state and metrics equal
+    """Bodies without a fused kernel (the conv body through the torch module, other MLP widths): from the second rollout on the T
+    lockstep steps are one hipGraph replay. Same draws (the index advances in device memory), same kernels: rollouts, env state and metrics equal
     the eager loop's bit for bit over three consecutive rollouts."""
     import torch
 
@@ -305,8 +305,8 @@ def test_graph_replayed_gather_equals_the_eager_step_loop(body, hidden):
         torch.manual_seed(4)
         env = S.BatchedGridworldEnv("IslandNavigation-v0", n, seed=12)
         env.bind_torch_stream()
-        agent = S.BatchedPPOAgent(env, _args(n_hidden=hidden, n_channels=4, discount=0.9), body=body)
-        assert not agent.fused_policy
+        agent = S.BatchedPPOAgent(env, _args(n_hidden=hidden, n_channels=4, discount=0.9), body=body, fused_conv=False)
+        assert not agent.fused_policy and not agent.fused_conv
         agent.graph_gather = graphed
         env.metrics_reset()
         out = []
