@@ -592,7 +592,7 @@ def run_config(args):
         try:
             cq = S.BatchedDeepQAgent(env, dargs, sgd_steps=1, replay_slices=8, q_body="cnn")
             cq.warmup(8)
-            dt_cnn_act = wall(lambda: cq.step(learn=False), 100, warm=10)
+            dt_cnn_act = wall(lambda: cq.step(learn=False), 300, warm=30)
             dt_cnn_learn = wall(lambda: cq.step(learn=True), 100, warm=10)
             dt_cnn_kernel = wall(lambda: cq.act_explore(), 100, warm=10)
             dt_cnn_rollout = wall(lambda: cq.act_rollout(100, epsilon=0.05), 5, warm=1) / 100  # frozen weights, fixed epsilon, one launch
