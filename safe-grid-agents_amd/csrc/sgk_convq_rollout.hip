@@ -188,6 +188,7 @@ hipError_t launch_convq_rollout(const Shard &sh, const ConvQWeights &w, int n_ch
   do {                                                                                                                     \
     typedef ConvRolloutLds<E, CV> LD;                                                                                      \
     static_assert(LD::bytes <= 160u * 1024u, "convq rollout LDS plan");                                                   \
+    if (ConvDims<E>::H != sh.rules_host.height || ConvDims<E>::W != sh.rules_host.width) return hipErrorInvalidValue;      \
     constexpr size_t lds = LD::bytes;                                                                                      \
     const int64_t n_pass = (sh.n + LD::G::ENVS - 1) / LD::G::ENVS;                                                         \
     static std::atomic<unsigned long long> opted_in{0};                                                                    \
