@@ -161,6 +161,34 @@ def test_convq_rollout_is_the_per_step_launches_in_one(name, n, channels, mode, 
     env_b.close()
 
 
+def test_convq_rollout_at_a_million_envs_equals_the_per_step_launches():
+    """The same comparison at 1 048 576 Sokoban envs (64-bit trajectory indices, 87 382 passes over 768 workgroups, a partial last pass)."""
+    import torch
+
+    n, T, c = 1 << 20, 6, 5
+    torch.manual_seed(0)
+    env_a = S.BatchedGridworldEnv("SideEffectsSokoban-v0", n, seed=3)
+    env_b = S.BatchedGridworldEnv("SideEffectsSokoban-v0", n, seed=3)
+    for e in (env_a, env_b):
+        e.step_random(5, auto_reset=True)
+    agent = S.BatchedDeepQAgent(env_a, _args(n_channels=c), q_body="cnn")
+    dev = agent.device
+    states = torch.empty((T, n, 36), dtype=torch.int8, device=dev)
+    actions = torch.empty((T, n), dtype=torch.uint8, device=dev)
+    recs = torch.empty((T, n, 4), dtype=torch.int8, device=dev)
+    env_a.convq_rollout(agent._cw, T, c, mode="sample", draw_index0=7, auto_reset=True, states=states, actions=actions, recs=recs)
+    for k in range(T):
+        assert (states[k] == env_b.boards().reshape(n, -1)).all(), k
+        a = env_b.convq_sample(agent._cw, 7 + k, c).clone()
+        assert (actions[k] == a).all(), k
+        env_b.step(a, auto_reset=True)
+        assert (recs[k] == env_b._device_views()["rec"]).all(), k
+    assert (env_a.boards() == env_b.boards()).all()
+    assert (np.asarray(env_a.metrics()) == np.asarray(env_b.metrics())).all()
+    env_a.close()
+    env_b.close()
+
+
 def test_convq_step_and_graph_take_the_actions_of_the_torch_composition():
     """agent.step() / step_graphed() with the fused conv kernel against the same agent driven through torch's conv + sgk_epsilon_greedy:
     the same boards after 40 lockstep steps wherever the two score sets order the actions identically (greedy ties within fp32 rounding
