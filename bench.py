@@ -600,7 +600,7 @@ def run_config(args):
             conv_flops = 2.0 * cells * (9 * C + 2 * 9 * C * C + C + 4 * C)  # multiply-adds x 2 per board: L1, L2 + head, 1x1, linear
             cnn = {"q_body": "cnn", "parity": "none (not the reference's DeepQAgent)", "n_channels": C, "fused_kernel": bool(cq.fused_conv),
                    "acting": {"us_per_lockstep_step": dt_cnn_act * 1e6, "value": n / dt_cnn_act,
-                              "how": "eager, three launches: sgk_convq_act (conv forward + act_explore), sgk_step, sgk_reset_done",
+                              "how": "eager, two launches: sgk_convq_act (conv forward + act_explore), sgk_step with auto-reset",
                               "forward_and_act_explore_us": dt_cnn_kernel * 1e6, "useful_flops_per_board": conv_flops,
                               "forward_tflops": n * conv_flops / dt_cnn_kernel / 1e12,
                               "rollout_us_per_lockstep_step": dt_cnn_rollout * 1e6, "rollout_value": n / dt_cnn_rollout,

@@ -31,7 +31,7 @@
 //     and multiply the same window values on the VALU (per slot and window row one v_pk_fma_f32 on the ds_read2 pair + one v_fmac):
 //     8 cycles instead of three MFMAs with one live row in four (24).
 // Measured (32 768 Sokoban boards, 5 channels; EXPERIMENTS.md R6.6): 28.3 us per launch = 43 TFLOP/s of useful fp32 (0.28 of the
-// matrix peak; 57 TFLOP/s at 1 M boards); the lockstep step around it 33 us against 390 through torch. What is left is instruction
+// matrix peak; 57 TFLOP/s at 1 M boards); the lockstep step around it 30 us against 390 through torch. What is left is instruction
 // issue, not the MFMA: per wave and pass 198 MFMAs (1 584 cycles) beside ~450 other vector instructions (epilogues, LDS address
 // adds for ds_read2's 8-bit offsets, the Philox draw).
 // The epsilon-greedy draw is sgk_epsilon_greedy's (Philox stream 2, keyed by global env index). fp32 with another summation order than

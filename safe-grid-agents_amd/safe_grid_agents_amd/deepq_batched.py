@@ -391,15 +391,13 @@ class BatchedDeepQAgent:
             for _ in range(self.sgd_steps):
                 self.learn_batch()
         else:
-            env.step(actions, auto_reset=False)
+            env.step(actions, auto_reset=True)  # (step + reset of the finished envs in one launch: nobody needs the terminal boards)
         t = self.t
         self.update_epsilon()
         if learn and t % self.sync_every == self.sync_every - 1:
             self.sync_target_Q()
         if learn:
             rp.reset_store(env)  # reset_done + the NEXT transition's states in one launch
-        else:
-            env.reset_done()
         return actions
 
     # ---- the same lockstep iteration replayed from ONE hipGraph (torch.cuda.CUDAGraph) -------------------------------
@@ -439,8 +437,7 @@ class BatchedDeepQAgent:
                 self.learn_batch()
             self.replay.reset_store(env, captured=True)  # (head_dev already names the next slice)
         else:
-            env.step(actions, auto_reset=False)
-            env.reset_done()
+            env.step(actions, auto_reset=True)
 
     def enable_graphs(self, learn=True, cheat=False):
         """Capture one lockstep iteration. Needs a full replay ring (run warmup(replay_slices) first) so that the sampling

@@ -223,7 +223,7 @@ def test_bench_config_objects_carry_their_own_roofline_and_cpu_baseline(k):
         assert abs(w["breakdown_device_sum_us"] - sum(b.values())) < 1e-6 and abs(w["acting_and_replay_store_us"] + w["sgd_us"] - sum(b.values())) < 1e-6
         c = d["conv_q_body_non_parity"]
         assert c["parity"].startswith("none") and c["acting"]["value"] > 0 and c["acting_plus_sgd"]["value"] > 0
-        assert c["fused_kernel"] is True and c["acting"]["rollout_value"] > c["acting"]["value"]  # one launch beats three per step
+        assert c["fused_kernel"] is True and c["acting"]["rollout_value"] > c["acting"]["value"]  # one launch beats two per step
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
 
