@@ -560,7 +560,7 @@ def run_config(args):
         dt_best = min(dt_learn, dt_learn_graph)
         with_learning = {
             "us_per_lockstep_step": dt_best * 1e6, "value": n / dt_best,
-            "how": "four library calls (five launches) per lockstep step from Python" if dt_learn <= dt_learn_graph else "one hipGraph replay per lockstep step",
+            "how": "three library calls (four launches: policy_act, step_store, the SGD kernel, Adam + reset_done_store) per lockstep step from Python" if dt_learn <= dt_learn_graph else "one hipGraph replay per lockstep step",
             "eager_us_per_lockstep_step": dt_learn * 1e6, "eager_value": n / dt_learn,
             "graph_us_per_lockstep_step": dt_learn_graph * 1e6, "graph_value": n / dt_learn_graph,
             "breakdown_us": {k: v * 1e6 for k, v in pieces.items()},

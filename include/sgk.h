@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SGK_ABI_VERSION 4 /* 3: the tabular-Q tables in HBM are state-major (sgk_tabq_table_dev); 4: sgk_tabq_step, sgk_step_store, sgk_reset_done_store, sgk_convq_act, sgk_convq_sample, sgk_convq_rollout, sgk_dqn_learner's
+#define SGK_ABI_VERSION 4 /* 3: the tabular-Q tables in HBM are state-major (sgk_tabq_table_dev); 4: sgk_tabq_step, sgk_step_store, sgk_reset_done_store, sgk_convq_act, sgk_convq_sample, sgk_convq_rollout, sgk_dqn_sgd_step_reset_store, sgk_dqn_learner's
                              loss_mode / rows / rows_out, SGK_F_SEPARATE_LAUNCHES, the sgk_debug_* hooks are off unless asked for */
 
 #if defined(__GNUC__)
@@ -422,7 +422,8 @@ SGK_API int sgk_convq_rollout(sgk_env *h, const sgk_convq_weights *w, int32_t mo
                               uint32_t flags, int8_t *states_out_dev, uint8_t *actions_out_dev, sgk_step_rec *recs_out_dev);
 
 /* The two halves of the replay add FUSED into the launches around them (round 6; a lockstep step of dqn_learn -- learn.py:29-58 -- is
- * then sgk_policy_act, sgk_step_store, sgk_dqn_sgd_step, sgk_reset_done_store: four calls instead of six):
+ * then sgk_policy_act, sgk_step_store, sgk_dqn_sgd_step, sgk_reset_done_store: four calls instead of six -- or three, with the last two
+ * as sgk_dqn_sgd_step_reset_store):
  *   sgk_step_store        env.step(actions) for every env (learn.py:38; no auto-reset) AND ReplayBuffer.add's second half (contain.py:15-17
  *                         via value.py:114): the successor boards, the action, the reward (cheat != 0: the hidden reward and the executed
  *                         action, learn.py:41-47) and the terminal flag go into slice `slice` of the rings, next to the step's usual
@@ -487,6 +488,13 @@ typedef struct sgk_dqn_learner {
   int64_t *rows_out;   /* or NULL */
 } sgk_dqn_learner;
 SGK_API int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *learner);
+/* The same SGD step AND the lockstep step's last launch -- sgk_reset_done_store(flags, slice, slice_dev, ring_slices, states_ring): the
+ * reset of the finished envs (train.py:70) + the next transitions' states into the replay ring -- behind it in TWO launches instead of
+ * three: the Adam launch (one lane per parameter, a fraction of the chip) carries the reset as extra workgroups of its grid. The reset
+ * neither reads the weights nor the minibatch, and the SGD kernel before it has finished sampling the ring: results identical to
+ * sgk_dqn_sgd_step followed by sgk_reset_done_store. */
+SGK_API int sgk_dqn_sgd_step_reset_store(sgk_env *h, const sgk_dqn_learner *learner, uint32_t flags, int64_t slice, const int64_t *slice_dev,
+                                         int32_t ring_slices, int8_t *states_ring);
 
 /* ---- PPOBaseAgent.learn (reference policy_base.py:64-131) for PPOMLPAgent's default topology as ONE kernel ---------- */
 /* All `n_epochs` minibatch updates of one learn() call: per epoch `batch` rows drawn uniformly with replacement from the

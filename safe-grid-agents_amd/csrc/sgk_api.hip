@@ -922,7 +922,15 @@ int sgk_reset_done_store(sgk_env *h, uint32_t flags, int64_t slice, const int64_
   return SGK_OK;
 } SGK_CATCH_STATUS
 
-int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) try {
+struct DqnResetStore {  // sgk_dqn_sgd_step_reset_store's second half
+  uint32_t flags;
+  int64_t slice;
+  const int64_t *slice_dev;
+  int32_t ring_slices;
+  int8_t *states_ring;
+};
+
+static int dqn_sgd_step_impl(sgk_env *h, const sgk_dqn_learner *L, const DqnResetStore *rs) {
   SGK_CHECK_HANDLE(h);
   if (!L) return fail(SGK_ERR_INVALID, "learner is NULL");
   const void *need[] = {L->states, L->successors, L->actions, L->rewards, L->terminals, L->w1, L->b1, L->w2, L->b2, L->w3, L->b3,
@@ -961,7 +969,12 @@ int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) try {
   static const bool four_workgroups = [] { const char *v = getenv("SGK_DQN_WORKGROUPS"); return v && v[0] == '4' && v[1] == 0; }();
   d.multi_wg = four_workgroups ? 1 : 0;
 #endif
-  if (!one_launch || d.multi_wg) {
+  if (rs) {
+    d.reset_store = 1;
+    d.rs_flags = rs->flags; d.rs_slice = rs->slice; d.rs_slice_dev = reinterpret_cast<const long long *>(rs->slice_dev);
+    d.rs_ring = rs->ring_slices; d.rs_states_ring = rs->states_ring;
+  }
+  if (!one_launch || d.multi_wg || rs) {
     const size_t need = sgk::dqn_sgd_scratch_bytes(h->sh.n_cells, L->n_hidden);
     if (h->learn_scratch_bytes < need) {
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -979,8 +992,23 @@ int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) try {
     d.scratch = h->learn_scratch;
   }
   d.lr = L->lr; d.beta1 = L->beta1; d.beta2 = L->beta2; d.eps = L->eps; d.discount = L->discount; d.max_grad_norm = L->max_grad_norm;
+  if (rs && d.multi_wg) return fail(SGK_ERR_INVALID, "the four-workgroup experiment has no fused reset");
   SGK_HIP(sgk::launch_dqn_sgd(h->sh, d, h->stream));
   return SGK_OK;
+}
+
+int sgk_dqn_sgd_step(sgk_env *h, const sgk_dqn_learner *L) try {
+  return dqn_sgd_step_impl(h, L, nullptr);
+} SGK_CATCH_STATUS
+
+int sgk_dqn_sgd_step_reset_store(sgk_env *h, const sgk_dqn_learner *L, uint32_t flags, int64_t slice, const int64_t *slice_dev,
+                                 int32_t ring_slices, int8_t *states_ring) try {
+  SGK_CHECK_HANDLE(h);
+  if (flags & ~(uint32_t)SGK_F_NO_BOARDS) return fail(SGK_ERR_INVALID, "only SGK_F_NO_BOARDS is meaningful here");
+  if (!states_ring) return fail(SGK_ERR_INVALID, "NULL ring pointer");
+  if (slice < 0 || ring_slices < 0 || (slice_dev && ring_slices < 1)) return fail(SGK_ERR_INVALID, "bad slice / ring_slices");
+  const DqnResetStore rs{flags, slice, slice_dev, ring_slices, states_ring};
+  return dqn_sgd_step_impl(h, L, &rs);
 } SGK_CATCH_STATUS
 
 int sgk_ppo_epochs(sgk_env *h, const sgk_ppo_learner *L) try {

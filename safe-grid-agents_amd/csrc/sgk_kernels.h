@@ -123,6 +123,14 @@ struct DqnLearner {
   void *scratch;          // dqn_sgd_scratch_bytes() of device memory (zeroed once): Adam runs as a second, chip-wide launch; null: inside the one kernel
   int multi_wg;           // (-DSGK_DQN_MULTI_WG experiment build only) run the four-workgroup kernel on `scratch`
   double lr, beta1, beta2, eps, discount, max_grad_norm;
+  // sgk_dqn_sgd_step_reset_store: the Adam launch also resets the finished envs and stores the next transitions' states (what
+  // launch_reset_done_store does), as extra workgroups of the same grid
+  int reset_store = 0;
+  uint32_t rs_flags = 0;
+  int64_t rs_slice = 0;
+  const long long *rs_slice_dev = nullptr;
+  int32_t rs_ring = 0;
+  int8_t *rs_states_ring = nullptr;
 };  // (the replay's int8 rewards are in units of the level's reward_scale: launch_dqn_sgd takes it from the shard's rules)
 // env.step + the second half of ReplayBuffer.add / reset_done + the first half for the next step, one launch each (sgk_step.hip)
 hipError_t launch_step_store(const Shard &sh, const uint8_t *actions, uint32_t flags, int cheat, int64_t slice, const long long *slice_dev,

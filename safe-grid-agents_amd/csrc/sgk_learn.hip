@@ -16,6 +16,7 @@
 #include <atomic>
 
 #include "sgk_device.h"
+#include "sgk_step_store.h"
 
 extern "C" __device__ float __ockl_wfred_add_f32(float);
 
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(LWG) void dqn_sgd_kernel(LearnArgs a) {
 
 // Adam(amsgrad) + the transposed copies, one lane per parameter (the second launch of sgk_dqn_sgd_step: see AdamHeader above)
 template <int K0, int H>
-__global__ __launch_bounds__(256) void dqn_adam_kernel(LearnArgs a) {
+__device__ __forceinline__ void adam_body(const LearnArgs &a, int vblock) {
   using PM = ParamMap<K0, H>;
   const AdamHeader hd = *reinterpret_cast<const AdamHeader *>(a.adam_scratch);
   const float *g = a.adam_scratch + sizeof(AdamHeader) / sizeof(float);
@@ -753,7 +754,7 @@ __global__ __launch_bounds__(256) void dqn_adam_kernel(LearnArgs a) {
   ac.lr_bc1 = hd.lr_bc1;
   ac.inv_bc2_sqrt = hd.inv_bc2_sqrt;
   ac.beta1 = a.beta1; ac.beta2 = a.beta2; ac.eps = a.eps;
-  const int e = (int)(blockIdx.x * 256 + threadIdx.x);
+  const int e = (int)(vblock * 256 + threadIdx.x);
   if (e >= PM::P) return;
   const int ten = e < PM::o_b1 ? 0 : e < PM::o_w2 ? 1 : e < PM::o_b2 ? 2 : e < PM::o_w3 ? 3 : e < PM::o_b3 ? 4 : 5;
   const int off = ten == 0 ? PM::o_w1 : ten == 1 ? PM::o_b1 : ten == 2 ? PM::o_w2 : ten == 3 ? PM::o_b2 : ten == 4 ? PM::o_w3 : PM::o_b3;
@@ -767,6 +768,37 @@ __global__ __launch_bounds__(256) void dqn_adam_kernel(LearnArgs a) {
   if (ten == 0) { const int j = le / K0, k = le - j * K0; a.w1t[(size_t)k * H + j] = nw; }
   else if (ten == 2) { const int j = le / H, k = le - j * H; a.w2t[(size_t)k * H + j] = nw; }
   else if (ten == 4) { const int ai = le / H, k = le - ai * H; a.w3t[4 * k + ai] = nw; }
+}
+
+template <int K0, int H>
+__global__ __launch_bounds__(256) void dqn_adam_kernel(LearnArgs a) {
+  adam_body<K0, H>(a, (int)blockIdx.x);
+}
+
+// Adam AND the lockstep step's last launch -- reset_done + the next transitions' states into the replay ring (sgk_reset_done_store) --
+// in one grid (sgk_dqn_sgd_step_reset_store): the two are independent (the reset neither reads the weights nor the minibatch, and the
+// SGD kernel before this launch has finished sampling the ring), each alone is a 5 us launch that leaves most of the chip idle. The
+// first adam_blocks workgroups run Adam, the others the reset kernel's body over their own virtual grid.
+struct ResetStoreArgs {
+  const SgkRules *rules;
+  uint64_t *state;
+  int8_t *boards;
+  int32_t *n_resets;
+  const double *aux;
+  int64_t n;
+  uint64_t seed, env_base;
+  int32_t mode_flags;
+  StepStore st;
+};
+template <int H, int ENV, int LAYOUT>
+__global__ __launch_bounds__(256) void dqn_adam_reset_kernel(LearnArgs a, int adam_blocks, ResetStoreArgs r) {
+  static_assert(WG == 256, "the reset body's workgroup");
+  if ((int)blockIdx.x < adam_blocks) {  // (workgroup-uniform)
+    adam_body<Geom<ENV>::NC, H>(a, (int)blockIdx.x);
+  } else {
+    reset_body<ENV, LAYOUT, true>(r.rules, r.state, r.boards, nullptr, r.mode_flags, r.n, r.seed, r.env_base, r.n_resets, r.aux, r.st,
+                                  (int)blockIdx.x - adam_blocks, (int)gridDim.x - adam_blocks);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1709,7 +1741,7 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
       opted_in.fetch_or(1ull << (sh.device & 63));                                                                         \
     }                                                                                                                      \
     dqn_sgd_kernel<K0V, HV><<<dim3(1), dim3(LWG), lds, st>>>(a);                                                           \
-    if (a.adam_scratch) {                                                                                                  \
+    if (a.adam_scratch && !L.reset_store) {                                                                                \
       hipError_t le = hipGetLastError();                                                                                   \
       if (le != hipSuccess) return le;                                                                                     \
       dqn_adam_kernel<K0V, HV><<<dim3((ParamMap<K0V, HV>::P + 255) / 256), dim3(256), 0, st>>>(a);                         \
@@ -1734,6 +1766,29 @@ hipError_t launch_dqn_sgd(const Shard &sh, const DqnLearner &L, hipStream_t st) 
 #undef SGK_SGD_LAUNCH_K
 #undef SGK_SGD_LAUNCH
 #undef SGK_SGD_TRY_MULTI
+  if (L.reset_store) {  // Adam + reset_done + the next transitions' states in ONE launch behind the SGD kernel
+    if (!a.adam_scratch) return hipErrorInvalidValue;  // (the two-launch form only: the gradient must leave the SGD kernel)
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return le;
+    ResetStoreArgs r;
+    r.rules = sh.rules_dev; r.state = sh.state; r.boards = sh.boards; r.n_resets = sh.n_resets; r.aux = sh.aux;
+    r.n = sh.n; r.seed = sh.seed; r.env_base = sh.env_base;
+    r.mode_flags = 1 | ((L.rs_flags & SGK_F_NO_BOARDS) ? 4 : 0);
+    r.st = make_store(sh, L.rs_states_ring, nullptr, nullptr, nullptr, L.rs_slice, L.rs_slice_dev, L.rs_ring, 0);
+    const int reset_blocks = grid_for((sh.n + WG - 1) / WG, sh.max_grid);
+#define SGK_ADAM_RESET(HV)                                                                                                 \
+  do {                                                                                                                     \
+    const int adam_blocks = (ParamMap<Geom<E>::NC, HV>::P + 255) / 256;                                                    \
+    dqn_adam_reset_kernel<HV, E, L><<<dim3(adam_blocks + reset_blocks), dim3(256), 0, st>>>(a, adam_blocks, r);            \
+  } while (0)
+    const int nh = a.n_hidden;
+    SGK_DISPATCH_ENV_LAYOUT(sh.env_id, sh.layout, {
+      if (Geom<E>::NC != sh.n_cells) return hipErrorInvalidValue;
+      if (nh == 100) SGK_ADAM_RESET(100);
+      else SGK_ADAM_RESET(64);
+    });
+#undef SGK_ADAM_RESET
+  }
   return hipGetLastError();
 }
 

@@ -138,6 +138,7 @@ _SIGNATURES = {
     "sgk_epsilon_greedy_ex": (ctypes.c_int, [_V, _V, ctypes.c_double, ctypes.c_uint64, _V, _V, _V]),
     "sgk_policy_act": (ctypes.c_int, [_V, ctypes.POINTER(SgkMlpWeights), ctypes.c_double, ctypes.c_uint64, _V, _V, _V, _V]),
     "sgk_dqn_sgd_step": (ctypes.c_int, [_V, ctypes.POINTER(SgkDqnLearner)]),
+    "sgk_dqn_sgd_step_reset_store": (ctypes.c_int, [_V, ctypes.POINTER(SgkDqnLearner), ctypes.c_uint32, ctypes.c_int64, _V, ctypes.c_int32, _V]),
     "sgk_convq_act": (ctypes.c_int, [_V, ctypes.POINTER(SgkConvQWeights), ctypes.c_double, ctypes.c_uint64, _V, _V, _V, _V]),
     "sgk_convq_sample": (ctypes.c_int, [_V, ctypes.POINTER(SgkConvQWeights), ctypes.c_uint64, _V, _V, _V]),
     "sgk_convq_rollout": (ctypes.c_int, [_V, ctypes.POINTER(SgkConvQWeights), ctypes.c_int32, ctypes.c_double, ctypes.c_uint64, ctypes.c_int32,

@@ -109,6 +109,14 @@ class DeviceReplay:
             env.reset_done_store(self.states, self.head)
         self.ready_version = env._version
 
+    def reset_store_args(self, captured=False):
+        """(states ring, slice, slice_dev) of the reset_store that follows a learning step: for sgk_dqn_sgd_step_reset_store, which does
+        it inside the SGD step's second launch; the caller then calls note_reset_store."""
+        return (self.states, 0, self.head_dev) if captured else (self.states, self.head, None)
+
+    def note_reset_store(self, env):
+        self.ready_version = env._version
+
     def sample(self, batch):
         """Uniform with replacement over everything stored (contain.py:19-22), indices drawn on the device."""
         import torch
@@ -169,6 +177,7 @@ class BatchedDeepQAgent:
         self.t = 0  # lockstep steps taken == update_epsilon() calls
         n_layers, n_hidden = int(args.n_layers), int(args.n_hidden)
         self.fused_learn = False  # set below; sync_target_Q looks at it
+        self.fuse_reset = True  # with the fused learner: reset_done + next-states store inside the SGD step's Adam launch
         self.Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
         self.target_Q = self.build_Q(self.n_input, n_layers, n_hidden).to(self.device).eval()
         self.reference_loss_broadcast = bool(reference_loss_broadcast)
@@ -247,10 +256,11 @@ class BatchedDeepQAgent:
         self._fl["tw1t"].copy_(self.target_Q[0][0].weight.data.t())
         self._fl["tw2t"].copy_(self.target_Q[1][0][0].weight.data.t())
 
-    def _learn_batch_fused(self, rows=None, rows_out=None):
+    def _learn_batch_fused(self, rows=None, rows_out=None, reset_store=None):
         """One call of sgk_dqn_sgd_step; the kernel also keeps W1^T / W2^T / W3^T current, so the fused policy kernel needs no
         refresh afterwards. rows: int64 device tensor [batch] of transition indices (slice * n_envs + env) to train on instead of
-        the kernel's own draw; rows_out: int64 device tensor [batch] that receives the indices used."""
+        the kernel's own draw; rows_out: int64 device tensor [batch] that receives the indices used. reset_store = (states ring, slice,
+        slice_dev): sgk_dqn_sgd_step_reset_store -- the lockstep step's reset_done + next-states store ride in the Adam launch."""
         import ctypes
 
         from . import _lib
@@ -273,8 +283,17 @@ class BatchedDeepQAgent:
             discount=self.discount, max_grad_norm=10.0, rows=None if rows is None else ptr(rows),
             rows_out=None if rows_out is None else ptr(rows_out))
         env = self.env
-        env._sync_torch_to_lib()
-        _lib.check(env.lib.sgk_dqn_sgd_step(env._h.ptr, ctypes.byref(L)))
+        if reset_store is not None:
+            ring, sl, sl_dev = reset_store
+            S_ = int(ring.shape[0])
+            env._check(ring, "states ring", shape=(S_, env.n_envs, env.n_cells), dtypes=("int8",))
+            sd = None if sl_dev is None else ctypes.c_void_p(env._check(sl_dev, "slice_dev", numel=1, dtypes=("int64",)).data_ptr())
+            env._version += 1
+            env._sync_torch_to_lib()
+            _lib.check(env.lib.sgk_dqn_sgd_step_reset_store(env._h.ptr, ctypes.byref(L), 0, int(sl), sd, S_, ctypes.c_void_p(ring.data_ptr())))
+        else:
+            env._sync_torch_to_lib()
+            _lib.check(env.lib.sgk_dqn_sgd_step(env._h.ptr, ctypes.byref(L)))
         env._sync_lib_to_torch()
         self._fw_stale = False
         self.last_loss = fl["loss"]
@@ -385,18 +404,23 @@ class BatchedDeepQAgent:
         else:
             env.obs_f32(self._obs)
             actions = self.act_explore(self._obs) if explore else self.act(self._obs)
+        fused_reset = learn and self.fused_learn and self.fuse_reset  # the reset rides in the last SGD step's Adam launch
         if learn:
             # env.step + the rest of the add in ONE launch: successor boards, action, reward (hidden when cheating), terminal
             rp.step_store(env, actions, cheat)
-            for _ in range(self.sgd_steps):
-                self.learn_batch()
+            for i in range(self.sgd_steps):
+                if fused_reset and i == self.sgd_steps - 1:
+                    self._learn_batch_fused(reset_store=rp.reset_store_args())
+                    rp.note_reset_store(env)
+                else:
+                    self.learn_batch()
         else:
             env.step(actions, auto_reset=True)  # (step + reset of the finished envs in one launch: nobody needs the terminal boards)
         t = self.t
         self.update_epsilon()
         if learn and t % self.sync_every == self.sync_every - 1:
             self.sync_target_Q()
-        if learn:
+        if learn and not fused_reset:
             rp.reset_store(env)  # reset_done + the NEXT transition's states in one launch
         return actions
 
@@ -433,9 +457,15 @@ class BatchedDeepQAgent:
         if learn:
             self.replay.step_store(env, actions, cheat, captured=True)  # --cheat: hidden reward + executed action (learn.py:41-47)
             self.replay.head_dev.add_(1).remainder_(self.replay.slices)
-            for _ in range(self.sgd_steps):
-                self.learn_batch()
-            self.replay.reset_store(env, captured=True)  # (head_dev already names the next slice)
+            fused_reset = self.fused_learn and self.fuse_reset
+            for i in range(self.sgd_steps):
+                if fused_reset and i == self.sgd_steps - 1:
+                    self._learn_batch_fused(reset_store=self.replay.reset_store_args(captured=True))
+                    self.replay.note_reset_store(env)
+                else:
+                    self.learn_batch()
+            if not fused_reset:
+                self.replay.reset_store(env, captured=True)  # (head_dev already names the next slice)
         else:
             env.step(actions, auto_reset=True)
 

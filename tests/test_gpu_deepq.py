@@ -451,6 +451,51 @@ def test_train_batched_cli_deepq():
     env.close()
 
 
+@pytest.mark.parametrize("how", ["step", "graph"])
+@pytest.mark.parametrize("name,n,hidden", [("SideEffectsSokoban-v0", 4133, 100), ("BoatRace-v0", 600, 64), ("TomatoWatering-v0", 500, 100),
+                                           ("FriendFoe-v0", 70000, 100), ("IslandNavigation-v0", 1, 100)])
+def test_sgd_step_with_the_reset_in_its_adam_launch_equals_the_two_calls(name, n, hidden, how):
+    """sgk_dqn_sgd_step_reset_store (the SGD kernel, then ONE launch for Adam + reset_done + the next transitions' states) against
+    sgk_dqn_sgd_step followed by sgk_reset_done_store, on twin agents over 40 learning steps (eager calls and the captured iteration):
+    weights, Adam state, the whole replay ring, boards, records, episode arrays and metrics are identical bit for bit."""
+    import torch
+
+    agents = []
+    for fuse in (True, False):
+        torch.manual_seed(13)
+        env = S.BatchedGridworldEnv(name, n, seed=21)
+        env.bind_torch_stream()
+        agent = S.BatchedDeepQAgent(env, _args(n_hidden=hidden, epsilon_anneal=30, sync_every=7), replay_slices=6)
+        assert agent.fused_learn
+        agent.fuse_reset = fuse
+        agent.warmup(6)
+        if how == "graph":
+            agent.enable_graphs(learn=True)
+        for k in range(40):
+            if how == "graph":
+                agent.step_graphed(learn=True)
+            else:
+                agent.step(learn=True)
+        torch.cuda.synchronize()
+        agents.append((env, agent))
+    (ea, a), (eb, b) = agents
+    for pa, pb in zip(a.Q.parameters(), b.Q.parameters()):
+        assert torch.equal(pa, pb)
+    for key in ("m", "v", "vmax"):
+        for x, y in zip(a._fl[key], b._fl[key]):
+            assert torch.equal(x, y), key
+    for key in ("states", "successors", "actions", "rewards", "terminals"):
+        assert torch.equal(getattr(a.replay, key), getattr(b.replay, key)), key
+    assert a.replay.head == b.replay.head and a.t == b.t == 40
+    assert torch.equal(ea.boards(), eb.boards())
+    va, vb = ea._device_views(), eb._device_views()
+    for key in ("rec", "last_return", "last_performance", "n_episodes"):
+        assert torch.equal(va[key], vb[key]), key
+    assert (np.asarray(ea.metrics()) == np.asarray(eb.metrics())).all()
+    ea.close()
+    eb.close()
+
+
 def test_conv_q_body_option_shapes_env_parity_and_learning_on_boat_race():
     """`q_body="cnn"`: the NON-PARITY conv Q-body (the reference's DeepQAgent is an MLP, value.py:148-158; BASELINE config 4 says
     "conv policy") -- policy_cnn.py's trunk with a Q head, through PyTorch-ROCm. Shapes, the env under it stays bit-exact against the
