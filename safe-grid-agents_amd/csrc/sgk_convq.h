@@ -49,9 +49,12 @@ struct ConvQGeom {
   static constexpr int K1 = 9, K2 = 9 * C, KC2 = (K2 + 15) / 16;
   static constexpr int NF = C * NC;                      // linear inputs
   static constexpr int WLR = 4 * C;                      // the linear weights of one slot: [action][channel]
-  static constexpr int O_WL = 0, O_ACT = (SE * WLR + 3) & ~3;
+  // (the activations first: their LDS address is then the lane's own base register alone, and a row's constant offset fits the 8-bit
+  // dword offsets of ds_read2_b32 -- behind 3 KB of linear weights every row read needed a v_add_u32 first)
+  static constexpr int O_ACT = 0, O_WL = (ENVS * ENV_F + 3) & ~3;
+  static constexpr int PG = (255 - 2 * PW - 2) / PL + 1, NPG = (PLANES + PG - 1) / PG;  // planes per base register (ds_read2's offsets reach 255 dwords), base registers
   static constexpr int CENTRE = PW + 1;                  // slot r's own cell relative to its window's top-left corner
-  static constexpr size_t lds_bytes = sizeof(float) * (size_t)(O_ACT + ENVS * ENV_F);
+  static constexpr size_t lds_bytes = sizeof(float) * (size_t)(O_WL + SE * WLR);
   static constexpr int NB = (ENVS * NC + CQ_WG - 1) / CQ_WG;  // board bytes per lane and pass
   static_assert(ENVS >= 1 && 4 * PL <= C * PL && SE <= PL, "convq geometry");
 };
@@ -64,7 +67,7 @@ typedef float cq_f2 __attribute__((ext_vector_type(2)));
 // With five channels the fifth's weights (wrem[k], uniform: scalar registers) multiply the same window values on the VALU: per slot
 // and window row one v_pk_fma_f32 + one v_fmac (8 cycles) instead of three MFMAs with one live row in four (24 cycles).
 template <class G, int K, int KC, int IN_PLANE>
-__device__ __forceinline__ void cq_taps(const float *act, const int (&base)[G::GPW], const float (&a)[G::MT][KC], const float *__restrict__ wrem,
+__device__ __forceinline__ void cq_taps(const float *act, const int (&base)[G::GPW][G::NPG], const float (&a)[G::MT][KC], const float *__restrict__ wrem,
                                         cq_f4 (&acc)[G::GPW][G::MT], float (&racc)[G::GPW]) {
   cq_f2 racc2[G::GPW] = {};
   float racc1[G::GPW] = {};
@@ -78,11 +81,14 @@ __device__ __forceinline__ void cq_taps(const float *act, const int (&base)[G::G
     constexpr int ci = decltype(cic)::value;
     cq_static_for<3>([&](auto dc) {
       constexpr int dy = decltype(dc)::value;
-      constexpr int off = (IN_PLANE + ci) * G::PL + dy * G::PW;
+      // (addressed from the base register of the plane's group of four: the offset then fits ds_read2_b32's 8 bits of dwords and no
+      // address is computed inside the loop -- 34 + 29 v_add_u32 per pass otherwise)
+      constexpr int pg = (IN_PLANE + ci) / G::PG, off = ((IN_PLANE + ci) % G::PG) * G::PL + dy * G::PW;
+      static_assert(off + 2 < 256, "ds_read2 offset");
 #pragma unroll
       for (int j = 0; j < G::GPW; ++j) {
-        pr[ci & 1][j][dy] = cq_f2{act[base[j] + off], act[base[j] + off + 1]};
-        sg[ci & 1][j][dy] = act[base[j] + off + 2];
+        pr[ci & 1][j][dy] = cq_f2{act[base[j][pg] + off], act[base[j][pg] + off + 1]};
+        sg[ci & 1][j][dy] = act[base[j][pg] + off + 2];
       }
     });
   };
@@ -135,6 +141,7 @@ template <class G>
 struct CqLane {
   float a1[G::MT][1], a2[G::MT][G::KC2], ah[G::MT][G::KC2];
   int base[G::GPW], wlrow[G::GPW];
+  int pbase[G::GPW][G::NPG];  // base + the first plane of every group of four
   bool interior[G::GPW];
 };
 
@@ -173,6 +180,11 @@ __device__ __forceinline__ void cq_setup(CqLane<G> &L, float *WL, float *act, co
     const bool valid = s < G::ENVS * G::SE;
     const int e = valid ? s / G::SE : 0, r = valid ? s - e * G::SE : 0;
     L.base[j] = e * G::ENV_F + r;  // the window's top-left corner in plane 0
+#pragma unroll
+    for (int g = 0; g < G::NPG; ++g) {
+      L.pbase[j][g] = L.base[j] + g * G::PG * G::PL;
+      asm volatile("" : "+v"(L.pbase[j][g]));  // (opaque: otherwise the compiler folds it back into base + constant and re-adds it per row)
+    }
     L.wlrow[j] = r * G::WLR;
     L.interior[j] = valid && (r % G::PW) < WW;
   }
@@ -191,7 +203,7 @@ __device__ __forceinline__ void cq_network(const CqLane<G> &L, float *act, const
   {
     cq_f4 acc[G::GPW][G::MT] = {};
     float racc[G::GPW] = {};
-    cq_taps<G, G::K1, 1, 0>(act, L.base, L.a1, w1r + G::CM * G::K1 + hz, acc, racc);
+    cq_taps<G, G::K1, 1, 0>(act, L.pbase, L.a1, w1r + G::CM * G::K1 + hz, acc, racc);
 #pragma unroll
     for (int j = 0; j < G::GPW; ++j)
       if (L.interior[j]) {
@@ -204,7 +216,7 @@ __device__ __forceinline__ void cq_network(const CqLane<G> &L, float *act, const
   {
     cq_f4 acc[G::GPW][G::MT] = {};
     float racc[G::GPW] = {};
-    cq_taps<G, G::K2, G::KC2, 1>(act, L.base, L.a2, w2r + G::CM * G::K2 + hz, acc, racc);
+    cq_taps<G, G::K2, G::KC2, 1>(act, L.pbase, L.a2, w2r + G::CM * G::K2 + hz, acc, racc);
 #pragma unroll
     for (int j = 0; j < G::GPW; ++j)
       if (L.interior[j]) {
@@ -220,7 +232,7 @@ __device__ __forceinline__ void cq_network(const CqLane<G> &L, float *act, const
   {
     cq_f4 acc[G::GPW][G::MT] = {};
     float racc[G::GPW] = {};
-    cq_taps<G, G::K2, G::KC2, 1 + C>(act, L.base, L.ah, whr + G::CM * G::K2 + hz, acc, racc);
+    cq_taps<G, G::K2, G::KC2, 1 + C>(act, L.pbase, L.ah, whr + G::CM * G::K2 + hz, acc, racc);
 #pragma unroll
     for (int j = 0; j < G::GPW; ++j)
       if (L.interior[j]) {

@@ -32,8 +32,9 @@
 //     8 cycles instead of three MFMAs with one live row in four (24).
 // Measured (32 768 Sokoban boards, 5 channels; EXPERIMENTS.md R6.6): 28.3 us per launch = 43 TFLOP/s of useful fp32 (0.28 of the
 // matrix peak; 57 TFLOP/s at 1 M boards); the lockstep step around it 30 us against 390 through torch. What is left is instruction
-// issue, not the MFMA: per wave and pass 198 MFMAs (1 584 cycles) beside ~450 other vector instructions (epilogues, LDS address
-// adds for ds_read2's 8-bit offsets, the Philox draw).
+// issue and latency, not the MFMA: per wave and pass 198 MFMAs (1 584 cycles) beside ~390 other vector instructions (epilogues, the
+// fifth channel, the Philox draw; the ~60 address adds ds_read2's 8-bit offsets first needed are gone -- the planes sit at LDS address
+// 0 and every group of planes has its own base register -- which bought 1-3 %: the waves wait more than they issue).
 // The epsilon-greedy draw is sgk_epsilon_greedy's (Philox stream 2, keyed by global env index). fp32 with another summation order than
 // MIOpen / rocBLAS: scores agree with the torch module to fp32 tolerance (tests/test_gpu_convq.py: rtol 1e-4).
 #include "sgk_convq.h"
